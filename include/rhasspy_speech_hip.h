@@ -1,0 +1,130 @@
+/* rhasspy_speech_hip.h -- C ABI of librhasspy_speech_hip.so
+ *
+ * Drop-in boundary for the transcribe hot path of rhasspy/rhasspy-speech.  The reference crosses a
+ * *process* boundary here: rhasspy_speech/transcribe_wav.py:45-75 pipes
+ *     online2-wav-nnet3-latgen-faster | lattice-to-nbest | nbest-to-linear
+ * and rhasspy_speech/transcribe_stream.py:53-99 feeds s16le PCM to online2-cli-nnet3-decode-faster and
+ * then runs the same two lattice tools.  Each entry point below names the piece of that contract it
+ * replaces.  Plain C types only; every call returns 0 on success and a negative status on failure, with
+ * the message available from rs_last_error() (the reference's convention: non-zero exit status + stderr
+ * text, rhasspy_speech/tools.py:138-145).  Handles are opaque.  The caller owns every input buffer; the
+ * library owns results until rs_result_free().
+ *
+ * There is NO CPU fallback: model parsing runs on the host, every compute entry point needs an MI355X
+ * (gfx950) device and fails with RS_ERR_DEVICE otherwise.
+ */
+#ifndef RHASSPY_SPEECH_HIP_H_
+#define RHASSPY_SPEECH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_OK 0
+#define RS_ERR_ARG -1     /* bad argument */
+#define RS_ERR_MODEL -2   /* model/graph/config file could not be read (Kaldi's KALDI_ERR paths) */
+#define RS_ERR_DEVICE -3  /* no usable HIP device / HIP runtime error */
+#define RS_ERR_DECODE -4  /* decoding failed (e.g. no frames) */
+
+typedef struct rs_model rs_model;
+typedef struct rs_result rs_result;
+typedef struct rs_stream rs_stream;
+
+/* Options = the command-line flags the reference passes (transcribe_wav.py:46-55,
+ * transcribe_stream.py:55-60) plus the Kaldi defaults it relies on
+ * (decoder/lattice-faster-decoder.h:38-92, nnet3/decodable-simple-looped.h:50-60). */
+typedef struct rs_decode_opts {
+  float beam;                  /* --beam            (24.0 as rhasspy runs it) */
+  int32_t max_active;          /* --max-active      (7000) */
+  int32_t min_active;          /* --min-active      (200, Kaldi default) */
+  float lattice_beam;          /* --lattice-beam    (8.0) */
+  float beam_delta;            /* --beam-delta      (0.5) */
+  float acoustic_scale;        /* --acoustic-scale of the decodable (1.0 as rhasspy runs it) */
+  int32_t frames_per_chunk;    /* --frames-per-chunk (24; only changes streaming iVector timing) */
+  int32_t frame_subsampling_factor; /* must be 1: the reference never passes it */
+  int32_t device_id;           /* HIP device ordinal */
+  int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
+  int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */
+  int32_t reserved[7];
+} rs_decode_opts;
+
+/* Fills `opts` with the values the reference's Python passes / Kaldi defaults. */
+int rs_default_opts(rs_decode_opts *opts);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *rs_last_error(void);
+
+/* Replaces the per-process model loading of both binaries
+ * (online2-wav-nnet3-latgen-faster.cc:150-190: OnlineNnet2FeaturePipelineInfo from --config=online.conf,
+ * TransitionModel + AmNnetSimple from final.mdl, ReadFstKaldiGeneric(HCLG.fst)).  Parses on the host only;
+ * the device copy is made on first use or by rs_model_to_device().  Immutable afterwards, shareable
+ * between threads. */
+int rs_model_load_files(const char *final_mdl, const char *hclg_fst, const char *online_conf,
+                        const rs_decode_opts *opts, rs_model **out);
+/* Same, using the directory layout the reference hard-codes (transcribe_wav.py:43-44,56-57):
+ * <model_dir>/model/model/final.mdl, <model_dir>/model/online/conf/online.conf, <graph_dir>/HCLG.fst. */
+int rs_model_load(const char *model_dir, const char *graph_dir, const rs_decode_opts *opts, rs_model **out);
+int rs_model_to_device(rs_model *model);
+void rs_model_free(rs_model *model);
+/* Writes a one-line-per-item description of the parsed model (dims, layer plan, graph size) into buf;
+ * returns the number of bytes needed (like snprintf). */
+int rs_model_describe(const rs_model *model, char *buf, size_t len);
+
+/* Offline batch decode = N invocations of the reference's 3-process pipeline with --online=false
+ * (online2-wav-nnet3-latgen-faster.cc:196-300 + lattice-to-nbest.cc:80-110 + nbest-to-linear.cc:67-87).
+ * pcm[i] points to n_samples[i] mono 16 kHz int16 samples (WaveData::Read hands Kaldi the same values as
+ * floats, unscaled).  nbest = lattice-to-nbest --n; lattice_acoustic_scale = its --acoustic-scale. */
+int rs_decode_batch(rs_model *model, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_utts,
+                    int32_t nbest, float lattice_acoustic_scale, rs_result **out);
+/* Same with the samples already resident in device memory (HBM): d_pcm is one device buffer holding all
+ * utterances back to back, sample_offsets[i] (host array, n_utts+1 entries) delimits utterance i.
+ * stream = hipStream_t to run on (NULL = the model's own stream).  This is what bench.py times. */
+int rs_decode_batch_device(rs_model *model, const int16_t *d_pcm, const int64_t *sample_offsets,
+                           int32_t n_utts, int32_t nbest, float lattice_acoustic_scale, void *stream,
+                           rs_result **out);
+
+/* Streaming decode = online2-cli-nnet3-decode-faster (stdin s16le until EOF, :143-161) followed by
+ * lattice-to-nbest | nbest-to-linear (transcribe_stream.py:85-99).  Audio may arrive in arbitrary chunk
+ * sizes; the library re-chunks to the binary's fixed 1024-sample ticks (:37) so results do not depend on
+ * the caller's chunking, exactly like the reference. */
+int rs_stream_open(rs_model *model, rs_stream **out);
+int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples);
+int rs_stream_finish(rs_stream *stream, int32_t nbest, float lattice_acoustic_scale, rs_result **out);
+void rs_stream_free(rs_stream *stream);
+/* Decodes many streams concurrently (BASELINE.json config 5): each rs_stream_accept only buffers; this call
+ * advances every listed stream by whatever whole ticks it has buffered, batching the device work. */
+int rs_streams_advance(rs_stream *const *streams, int32_t n_streams);
+
+/* Result access.  Hypotheses of utterance `utt` are ordered best first, like the keys utt-1..utt-n that
+ * lattice-to-nbest writes (lattice-to-nbest.cc:100-106). */
+int32_t rs_result_num_utts(const rs_result *r);
+int32_t rs_result_num_hyps(const rs_result *r, int32_t utt);
+int32_t rs_result_num_frames(const rs_result *r, int32_t utt);
+/* Word ids (HCLG olabels, epsilons removed) of hypothesis k; *ids stays valid until rs_result_free. */
+int rs_result_words(const rs_result *r, int32_t utt, int32_t k, const int32_t **ids, int32_t *n);
+/* (graph cost, acoustic cost) of hypothesis k = the 4th/5th outputs of nbest-to-linear. */
+int rs_result_costs(const rs_result *r, int32_t utt, int32_t k, float *graph_cost, float *acoustic_cost);
+/* Renders exactly the bytes `nbest-to-linear ark:- ark:/dev/null ark,t:-` prints for this utterance:
+ * "utt-<k> <id> <id> ... \n" per hypothesis (key prefix `key`, "utt" in the reference).  Returns the number
+ * of bytes needed, like snprintf. */
+int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, size_t len);
+/* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
+ * (n x D_iv, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */
+int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols);
+/* Decoder work counters of one utterance, for the algorithmic-bytes figure of SURVEY.md section 8(d):
+ * out[0] = tokens expanded, [1] = arcs examined, [2] = token insertions (FindOrAddToken calls),
+ * [3] = tokens alive summed over frames, [4] = lattice arcs after pruning, [5] = frames where
+ * max_active bound, [6] = frames where min_active bound, [7] = token-capacity overflows. */
+int rs_result_counters(const rs_result *r, int32_t utt, int64_t out[8]);
+/* Wall-clock milliseconds of the stages of the call that produced r: out[0] = H2D, [1] = MFCC,
+ * [2] = iVector, [3] = nnet, [4] = decode, [5] = lattice+n-best (host), [6] = total. */
+int rs_result_timings(const rs_result *r, float out[8]);
+void rs_result_free(rs_result *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RHASSPY_SPEECH_HIP_H_ */

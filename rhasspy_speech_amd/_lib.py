@@ -1,0 +1,217 @@
+"""ctypes binding of librhasspy_speech_hip.so (include/rhasspy_speech_hip.h).
+
+This is the stub a maintainer of the reference would add in place of the subprocess pipeline of
+rhasspy_speech/transcribe_wav.py:45-75.  The library is the only compute path: if it is
+missing, import fails loudly; if no MI355X is present, every decode call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "librhasspy_speech_hip.so"
+
+RS_OK, RS_ERR_ARG, RS_ERR_MODEL, RS_ERR_DEVICE, RS_ERR_DECODE = 0, -1, -2, -3, -4
+
+
+class DecodeOpts(C.Structure):
+    _fields_ = [
+        ("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("lattice_beam", C.c_float),
+        ("beam_delta", C.c_float), ("acoustic_scale", C.c_float), ("frames_per_chunk", C.c_int32),
+        ("frame_subsampling_factor", C.c_int32), ("device_id", C.c_int32), ("keep_intermediates", C.c_int32),
+        ("max_tokens_per_frame", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+EXPORTS = [
+    "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
+    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_stream_open", "rs_stream_accept",
+    "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_result_num_utts", "rs_result_num_hyps",
+    "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_matrix",
+    "rs_result_counters", "rs_result_timings", "rs_result_free",
+]
+
+
+def load_library() -> C.CDLL:
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C rhasspy_speech_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    lib.rs_default_opts.argtypes = [C.POINTER(DecodeOpts)]
+    lib.rs_last_error.restype = C.c_char_p
+    lib.rs_model_load_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(DecodeOpts), C.POINTER(vp)]
+    lib.rs_model_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(DecodeOpts), C.POINTER(vp)]
+    lib.rs_model_to_device.argtypes = [vp]
+    lib.rs_model_free.argtypes = [vp]
+    lib.rs_model_free.restype = None
+    lib.rs_model_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.rs_decode_batch.argtypes = [vp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, f32, C.POINTER(vp)]
+    lib.rs_decode_batch_device.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, i32, f32, vp, C.POINTER(vp)]
+    lib.rs_stream_open.argtypes = [vp, C.POINTER(vp)]
+    lib.rs_stream_accept.argtypes = [vp, C.POINTER(C.c_int16), i32]
+    lib.rs_stream_finish.argtypes = [vp, i32, f32, C.POINTER(vp)]
+    lib.rs_stream_free.argtypes = [vp]
+    lib.rs_stream_free.restype = None
+    lib.rs_streams_advance.argtypes = [C.POINTER(vp), i32]
+    lib.rs_result_num_utts.argtypes = [vp]
+    lib.rs_result_num_hyps.argtypes = [vp, i32]
+    lib.rs_result_num_frames.argtypes = [vp, i32]
+    lib.rs_result_words.argtypes = [vp, i32, i32, C.POINTER(C.POINTER(i32)), C.POINTER(i32)]
+    lib.rs_result_costs.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32)]
+    lib.rs_result_text.argtypes = [vp, i32, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.rs_result_matrix.argtypes = [vp, i32, i32, C.POINTER(C.POINTER(f32)), C.POINTER(i32), C.POINTER(i32)]
+    lib.rs_result_counters.argtypes = [vp, i32, C.POINTER(C.c_int64)]
+    lib.rs_result_timings.argtypes = [vp, C.POINTER(f32)]
+    lib.rs_result_free.argtypes = [vp]
+    lib.rs_result_free.restype = None
+    return lib
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+class RsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+def _check(status: int) -> None:
+    if status != RS_OK:
+        raise RsError(status, lib().rs_last_error().decode("utf-8", "replace"))
+
+
+def default_opts(**overrides) -> DecodeOpts:
+    o = DecodeOpts()
+    _check(lib().rs_default_opts(C.byref(o)))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown decode option {k}")
+        setattr(o, k, v)
+    return o
+
+
+class Result:
+    """Owns an rs_result."""
+
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+
+    def close(self) -> None:
+        if self._h:
+            lib().rs_result_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def num_utts(self) -> int:
+        return lib().rs_result_num_utts(self._h)
+
+    def num_hyps(self, utt: int) -> int:
+        return lib().rs_result_num_hyps(self._h, utt)
+
+    def num_frames(self, utt: int) -> int:
+        return lib().rs_result_num_frames(self._h, utt)
+
+    def words(self, utt: int, k: int = 0) -> List[int]:
+        ids = C.POINTER(C.c_int32)()
+        n = C.c_int32()
+        _check(lib().rs_result_words(self._h, utt, k, C.byref(ids), C.byref(n)))
+        return [ids[i] for i in range(n.value)]
+
+    def costs(self, utt: int, k: int = 0) -> Tuple[float, float]:
+        g, a = C.c_float(), C.c_float()
+        _check(lib().rs_result_costs(self._h, utt, k, C.byref(g), C.byref(a)))
+        return g.value, a.value
+
+    def text(self, utt: int, key: str = "utt") -> bytes:
+        """The bytes `nbest-to-linear ... ark,t:-` would print for this utterance."""
+        n = lib().rs_result_text(self._h, utt, key.encode(), None, 0)
+        if n < 0:
+            _check(n)
+        buf = C.create_string_buffer(n + 1)
+        lib().rs_result_text(self._h, utt, key.encode(), buf, n + 1)
+        return buf.value
+
+    def matrix(self, utt: int, kind: int) -> np.ndarray:
+        data = C.POINTER(C.c_float)()
+        r, c = C.c_int32(), C.c_int32()
+        _check(lib().rs_result_matrix(self._h, utt, kind, C.byref(data), C.byref(r), C.byref(c)))
+        if r.value * c.value == 0:
+            return np.zeros((r.value, c.value), np.float32)
+        return np.ctypeslib.as_array(data, shape=(r.value, c.value)).copy()
+
+    def counters(self, utt: int) -> List[int]:
+        out = (C.c_int64 * 8)()
+        _check(lib().rs_result_counters(self._h, utt, out))
+        return list(out)
+
+    def timings(self) -> List[float]:
+        out = (C.c_float * 8)()
+        _check(lib().rs_result_timings(self._h, out))
+        return list(out)
+
+
+class Model:
+    """Owns an rs_model (parsed Kaldi model + HCLG; device copy made on first decode)."""
+
+    def __init__(self, model_dir: Optional[os.PathLike] = None, graph_dir: Optional[os.PathLike] = None,
+                 opts: Optional[DecodeOpts] = None, *, final_mdl=None, hclg=None, online_conf=None):
+        self._h = C.c_void_p()
+        self.opts = opts or default_opts()
+        if final_mdl is not None:
+            _check(lib().rs_model_load_files(str(final_mdl).encode(), str(hclg).encode(), str(online_conf).encode(),
+                                             C.byref(self.opts), C.byref(self._h)))
+        else:
+            _check(lib().rs_model_load(str(model_dir).encode(), str(graph_dir).encode(), C.byref(self.opts), C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().rs_model_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def to_device(self) -> None:
+        _check(lib().rs_model_to_device(self._h))
+
+    def describe(self) -> str:
+        n = lib().rs_model_describe(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().rs_model_describe(self._h, buf, n + 1)
+        return buf.value.decode()
+
+    def decode_batch(self, pcm: Sequence[np.ndarray], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
+        arrs = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm]
+        n = len(arrs)
+        ptrs = (C.POINTER(C.c_int16) * max(n, 1))()
+        lens = (C.c_int32 * max(n, 1))()
+        for i, a in enumerate(arrs):
+            ptrs[i] = a.ctypes.data_as(C.POINTER(C.c_int16))
+            lens[i] = a.shape[0]
+        out = C.c_void_p()
+        _check(lib().rs_decode_batch(self._h, ptrs, lens, n, nbest, lattice_acoustic_scale, C.byref(out)))
+        return Result(out)
+
+    def decode_batch_device(self, d_pcm_ptr: int, sample_offsets: np.ndarray, nbest: int = 1,
+                            lattice_acoustic_scale: float = 1.0, stream: int = 0) -> Result:
+        """d_pcm_ptr: device address (e.g. torch_tensor.data_ptr()) of all utterances back to back (int16)."""
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        out = C.c_void_p()
+        _check(lib().rs_decode_batch_device(self._h, C.c_void_p(d_pcm_ptr), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            off.shape[0] - 1, nbest, lattice_acoustic_scale, C.c_void_p(stream), C.byref(out)))
+        return Result(out)

@@ -1,0 +1,214 @@
+// extern "C" surface of librhasspy_speech_hip.so (see include/rhasspy_speech_hip.h).  No exception crosses
+// the boundary: every failure becomes a status code + thread-local message, mirroring how the reference's
+// binaries report KALDI_ERR text on stderr with a non-zero exit status (tools.py:138-145).
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int Guard(F &&f) {
+  try {
+    g_last_error.clear();
+    return f();
+  } catch (const rs::DeviceError &e) {
+    g_last_error = e.what();
+    return RS_ERR_DEVICE;
+  } catch (const rs::Error &e) {
+    g_last_error = e.what();
+    return RS_ERR_MODEL;
+  } catch (const std::exception &e) {
+    g_last_error = std::string("unexpected error: ") + e.what();
+    return RS_ERR_ARG;
+  }
+}
+int ArgError(const char *msg) {
+  g_last_error = msg;
+  return RS_ERR_ARG;
+}
+}  // namespace
+
+extern "C" {
+
+int rs_default_opts(rs_decode_opts *o) {
+  if (!o) return ArgError("rs_default_opts: null pointer");
+  std::memset(o, 0, sizeof(*o));
+  o->beam = 24.0f;           // transcribe_wav.py:24
+  o->max_active = 7000;      // transcribe_wav.py:21
+  o->min_active = 200;       // lattice-faster-decoder.h:61
+  o->lattice_beam = 8.0f;    // transcribe_wav.py:22
+  o->beam_delta = 0.5f;      // lattice-faster-decoder.h:66
+  o->acoustic_scale = 1.0f;  // transcribe_wav.py:53 ("--acoustic-scale=1.0")
+  o->frames_per_chunk = 24;  // decodable-simple-looped.h:57 rounded by GetChunkSize
+  o->frame_subsampling_factor = 1;
+  o->device_id = 0;
+  return RS_OK;
+}
+
+const char *rs_last_error(void) { return g_last_error.c_str(); }
+
+int rs_model_load_files(const char *final_mdl, const char *hclg_fst, const char *online_conf, const rs_decode_opts *opts,
+                        rs_model **out) {
+  if (!final_mdl || !hclg_fst || !online_conf || !out) return ArgError("rs_model_load_files: null argument");
+  return Guard([&]() {
+    rs_decode_opts o;
+    if (opts) o = *opts; else rs_default_opts(&o);
+    rs_model *m = new rs_model();
+    try {
+      m->m.reset(new rs::Model(final_mdl, hclg_fst, online_conf, o));
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    *out = m;
+    return RS_OK;
+  });
+}
+
+int rs_model_load(const char *model_dir, const char *graph_dir, const rs_decode_opts *opts, rs_model **out) {
+  if (!model_dir || !graph_dir || !out) return ArgError("rs_model_load: null argument");
+  std::string md(model_dir), gd(graph_dir);
+  return rs_model_load_files((md + "/model/model/final.mdl").c_str(), (gd + "/HCLG.fst").c_str(),
+                             (md + "/model/online/conf/online.conf").c_str(), opts, out);
+}
+
+int rs_model_to_device(rs_model *model) {
+  if (!model) return ArgError("rs_model_to_device: null model");
+  return Guard([&]() { model->m->ToDevice(); return RS_OK; });
+}
+
+void rs_model_free(rs_model *model) { delete model; }
+
+int rs_model_describe(const rs_model *model, char *buf, size_t len) {
+  if (!model) return ArgError("rs_model_describe: null model");
+  std::string d = model->m->Describe();
+  if (buf && len) {
+    size_t n = d.size() < len - 1 ? d.size() : len - 1;
+    std::memcpy(buf, d.data(), n);
+    buf[n] = 0;
+  }
+  return (int)d.size();
+}
+
+int rs_decode_batch(rs_model *model, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_utts, int32_t nbest,
+                    float lattice_acoustic_scale, rs_result **out) {
+  if (!model || !out || n_utts < 0 || (n_utts > 0 && (!pcm || !n_samples))) return ArgError("rs_decode_batch: bad argument");
+  return Guard([&]() {
+    auto r = model->m->DecodeBatchHost(pcm, n_samples, n_utts, nbest, lattice_acoustic_scale);
+    rs_result *res = new rs_result();
+    res->r = std::move(r);
+    *out = res;
+    return RS_OK;
+  });
+}
+
+int rs_decode_batch_device(rs_model *model, const int16_t *d_pcm, const int64_t *sample_offsets, int32_t n_utts, int32_t nbest,
+                           float lattice_acoustic_scale, void *stream, rs_result **out) {
+  if (!model || !out || n_utts < 0 || (n_utts > 0 && (!d_pcm || !sample_offsets))) return ArgError("rs_decode_batch_device: bad argument");
+  return Guard([&]() {
+    auto r = model->m->DecodeBatchDevice(d_pcm, sample_offsets, n_utts, nbest, lattice_acoustic_scale, (hipStream_t)stream);
+    rs_result *res = new rs_result();
+    res->r = std::move(r);
+    *out = res;
+    return RS_OK;
+  });
+}
+
+int rs_stream_open(rs_model *, rs_stream **) { return ArgError("rs_stream_open: streaming decode is not implemented yet"); }
+int rs_stream_accept(rs_stream *, const int16_t *, int32_t) { return ArgError("rs_stream_accept: streaming decode is not implemented yet"); }
+int rs_stream_finish(rs_stream *, int32_t, float, rs_result **) { return ArgError("rs_stream_finish: streaming decode is not implemented yet"); }
+void rs_stream_free(rs_stream *) {}
+int rs_streams_advance(rs_stream *const *, int32_t) { return ArgError("rs_streams_advance: streaming decode is not implemented yet"); }
+
+int32_t rs_result_num_utts(const rs_result *r) { return r ? (int32_t)r->r->utts.size() : 0; }
+
+static const rs::UttResult *Utt(const rs_result *r, int32_t utt) {
+  if (!r || utt < 0 || utt >= (int32_t)r->r->utts.size()) return nullptr;
+  return &r->r->utts[utt];
+}
+
+int32_t rs_result_num_hyps(const rs_result *r, int32_t utt) {
+  const rs::UttResult *u = Utt(r, utt);
+  return u ? (int32_t)u->hyps.size() : 0;
+}
+int32_t rs_result_num_frames(const rs_result *r, int32_t utt) {
+  const rs::UttResult *u = Utt(r, utt);
+  return u ? u->num_frames : 0;
+}
+
+int rs_result_words(const rs_result *r, int32_t utt, int32_t k, const int32_t **ids, int32_t *n) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u || !ids || !n) return ArgError("rs_result_words: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  if (k < 0 || k >= (int32_t)u->hyps.size()) return ArgError("rs_result_words: hypothesis index out of range");
+  *ids = u->hyps[k].words.data();
+  *n = (int32_t)u->hyps[k].words.size();
+  return RS_OK;
+}
+
+int rs_result_costs(const rs_result *r, int32_t utt, int32_t k, float *graph_cost, float *acoustic_cost) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u) return ArgError("rs_result_costs: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  if (k < 0 || k >= (int32_t)u->hyps.size()) return ArgError("rs_result_costs: hypothesis index out of range");
+  if (graph_cost) *graph_cost = u->hyps[k].graph_cost;
+  if (acoustic_cost) *acoustic_cost = u->hyps[k].acoustic_cost;
+  return RS_OK;
+}
+
+int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, size_t len) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u) return ArgError("rs_result_text: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  // BasicVectorHolder text form as nbest-to-linear writes it: "<key>-<k> id id ... \n" (trailing space before newline)
+  std::string s;
+  const std::string ky = key ? key : "utt";
+  for (size_t k = 0; k < u->hyps.size(); k++) {
+    s += ky + "-" + std::to_string(k + 1) + " ";
+    for (int32_t w : u->hyps[k].words) s += std::to_string(w) + " ";
+    s += "\n";
+  }
+  if (buf && len) {
+    size_t n = s.size() < len - 1 ? s.size() : len - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return (int)s.size();
+}
+
+int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u || !data || !rows || !cols) return ArgError("rs_result_matrix: bad argument");
+  const std::vector<float> *v = nullptr;
+  int c = 0, rws = 0;
+  if (kind == 0) { v = &u->feats; c = u->feat_dim; rws = c ? (int)(v->size() / c) : 0; }
+  else if (kind == 1) { v = &u->ivector; c = u->ivec_dim; rws = c ? (int)(v->size() / c) : 0; }
+  else if (kind == 2) { v = &u->loglikes; c = u->num_pdfs; rws = c ? (int)(v->size() / c) : 0; }
+  else return ArgError("rs_result_matrix: unknown kind");
+  if (v->empty() && c == 0) return ArgError("rs_result_matrix: intermediates were not kept (set rs_decode_opts.keep_intermediates)");
+  *data = v->data();
+  *rows = rws;
+  *cols = c;
+  return RS_OK;
+}
+
+int rs_result_counters(const rs_result *r, int32_t utt, int64_t out[8]) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u || !out) return ArgError("rs_result_counters: bad argument");
+  for (int i = 0; i < 8; i++) out[i] = u->counters[i];
+  return RS_OK;
+}
+
+int rs_result_timings(const rs_result *r, float out[8]) {
+  if (!r || !out) return ArgError("rs_result_timings: bad argument");
+  for (int i = 0; i < 8; i++) out[i] = r->r->timings[i];
+  return RS_OK;
+}
+
+void rs_result_free(rs_result *r) { delete r; }
+
+}  // extern "C"

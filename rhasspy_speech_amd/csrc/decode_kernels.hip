@@ -1,0 +1,430 @@
+// Token-passing beam search over the HCLG on gfx950: one workgroup per utterance, persistent over all
+// frames (no per-frame launches), every wavefront expanding tokens in parallel.
+//
+// Reference semantics reproduced (kaldi/src/decoder/lattice-faster-decoder.cc):
+//   InitDecoding :56-73, GetCutoff :644-711, ProcessEmitting :714-804, ProcessNonemitting :820-887,
+//   FindOrAddToken :253-293, ComputeFinalCosts :536-577, best-path traceback
+//   (lattice-faster-online-decoder.cc:56-173 / GetBestPath :95-102).
+// Design (not the reference's): the reference keeps a hash of heap-allocated tokens and walks it
+// sequentially; here the "hash" is a dense per-utterance table best[state] holding a packed 64-bit key
+// (order-preserving cost bits << 32 | arc index) that every lane updates with atomicMin, so recombination
+// is order-independent: a token's cost is the minimum over all incoming arcs of the reference's float
+// expression (cur_cost + (cost_offset - loglike)) + graph_cost, and exact ties go to the lowest arc index.
+// Pruning uses the *final* value of the reference's running next_cutoff: every
+// token the reference is guaranteed to create is created, order-dependent extras (>= best + beam) are not.
+// This file is compiled with -ffp-contract=off (cost expressions must not be fused).
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+
+#include "kernels.h"
+
+namespace rs {
+
+#define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define RS_NOARC 0xFFFFFFFFu
+
+__device__ __forceinline__ unsigned OrderedBits(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float FromOrdered(unsigned u) {
+  unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ unsigned long long PackKey(float cost, unsigned arc) {
+  return ((unsigned long long)OrderedBits(cost) << 32) | arc;
+}
+__device__ __forceinline__ float KeyCost(unsigned long long k) { return FromOrdered((unsigned)(k >> 32)); }
+// best[] is only ever touched with device-scope atomics / L1-bypassing loads (atomics execute in L2)
+__device__ __forceinline__ unsigned long long LoadKey(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void StoreKey(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NT>
+struct BlockCtx {
+  float red_f[NT / 64];
+  int red_i[NT / 64];
+  unsigned hist[256];
+  int n_next, q_n[2], overflow, error;
+  float bcast_f[2];
+  int bcast_i[4];
+  unsigned long long counters[8];
+};
+
+// min over the block of (v, idx), lowest idx on ties.  Contains barriers: call from uniform control flow.
+template <int NT>
+__device__ __forceinline__ void BlockMinArg(BlockCtx<NT> &c, float v, int idx, float *out_v, int *out_i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { c.red_f[wave] = v; c.red_i[wave] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bv = c.red_f[0];
+    int bi = c.red_i[0];
+    for (int w = 1; w < NT / 64; w++)
+      if (c.red_f[w] < bv || (c.red_f[w] == bv && c.red_i[w] < bi)) { bv = c.red_f[w]; bi = c.red_i[w]; }
+    c.bcast_f[0] = bv;
+    c.bcast_i[0] = bi;
+  }
+  __syncthreads();
+  *out_v = c.bcast_f[0];
+  *out_i = c.bcast_i[0];
+  __syncthreads();
+}
+
+// k-th smallest (0-based) cost of toks[0..n): exact radix select on the order-preserving bit pattern
+// (the value std::nth_element leaves at position k, lattice-faster-decoder.cc:679-695).
+template <int NT>
+__device__ float BlockKthSmallest(BlockCtx<NT> &c, const int4 *toks, int n, int k) {
+  unsigned prefix = 0, mask = 0;
+  int kk = k;
+  for (int pass = 0; pass < 4; pass++) {
+    const int shift = 24 - 8 * pass;
+    for (int i = threadIdx.x; i < 256; i += NT) c.hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += NT) {
+      unsigned uu = OrderedBits(__int_as_float(toks[i].y));
+      if ((uu & mask) == prefix) atomicAdd(&c.hist[(uu >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0, b = 0;
+      for (; b < 255; b++) {
+        int hh = (int)c.hist[b];
+        if (acc + hh > kk) break;
+        acc += hh;
+      }
+      c.bcast_i[1] = b;
+      c.bcast_i[2] = kk - acc;
+    }
+    __syncthreads();
+    prefix |= ((unsigned)c.bcast_i[1]) << shift;
+    mask |= 255u << shift;
+    kk = c.bcast_i[2];
+    __syncthreads();
+  }
+  return FromOrdered(prefix);
+}
+
+// Relax one arc into the frame under construction (FindOrAddToken).  Returns true if the table entry improved.
+template <int NT>
+__device__ __forceinline__ bool Relax(BlockCtx<NT> &c, unsigned long long *best, int *map_next, int4 *next_toks,
+                                      int next_cap, int ns, float tot, unsigned arc) {
+  const unsigned long long key = PackKey(tot, arc);
+  const unsigned long long old = atomicMin(&best[ns], key);
+  if (old == RS_EMPTY) {
+    int idx = atomicAdd(&c.n_next, 1);
+    if (idx < next_cap) {
+      next_toks[idx].x = ns;
+      map_next[ns] = idx;
+    } else {
+      c.overflow = 1;
+    }
+    return true;
+  }
+  return key < old;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
+                                                   const float *__restrict__ loglikes, int ld, DecodeWork w) {
+  __shared__ BlockCtx<NT> c;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int T = g.d_num_frames[u];
+  const int S = h.num_states;
+  unsigned long long *best = w.best + (size_t)u * S;
+  int *map_cur = w.map_a + (size_t)u * S, *map_next = w.map_b + (size_t)u * S;
+  int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
+  int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
+  int *queue[2] = {w.queue_a + (size_t)u * S, w.queue_b + (size_t)u * S};
+  int *in_queue = w.in_queue + (size_t)u * S;
+  const float INF = INFINITY;
+  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
+
+  for (int i = tid; i < S; i += NT) { StoreKey(&best[i], RS_EMPTY); map_cur[i] = -1; map_next[i] = -1; in_queue[i] = 0; }
+  if (tid == 0) {
+    c.n_next = 0; c.overflow = 0; c.error = 0; c.q_n[0] = c.q_n[1] = 0;
+    for (int i = 0; i < 8; i++) c.counters[i] = 0;
+    w.out_nwords[u] = 0;
+  }
+  unsigned long long cnt_expanded = 0, cnt_arcs = 0, cnt_insert = 0;
+  __syncthreads();
+
+  int off_cur = 0, n_cur = 0;       // frame f's token list
+  int off_next = 0;                 // frame under construction
+  if (tid == 0) {
+    Relax(c, best, map_next, tokens, w.tok_cap, h.start, 0.0f, RS_NOARC);
+    frame_off[0] = 0;
+  }
+  __syncthreads();
+  float closure_cutoff = o.beam;    // InitDecoding: ProcessNonemitting(config_.beam)
+
+  for (int f = -1; f < T; f++) {
+    int4 *next_toks = tokens + off_next;
+    const int next_cap = w.tok_cap - off_next;
+    if (f >= 0) {
+      // ================================================================ ProcessEmitting(frame f)
+      const int4 *cur = tokens + off_cur;
+      float lv = INF;
+      int li = 0x7fffffff;
+      for (int i = tid; i < n_cur; i += NT) {
+        float cst = __int_as_float(cur[i].y);
+        if (cst < lv || (cst == lv && i < li)) { lv = cst; li = i; }
+      }
+      float best_cost;
+      int best_idx;
+      BlockMinArg<NT>(c, lv, li, &best_cost, &best_idx);
+      // ---- GetCutoff
+      const float beam_cutoff = best_cost + o.beam;
+      float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
+      bool decided = false;
+      if (n_cur > o.max_active) max_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.max_active);
+      if (max_active_cutoff < beam_cutoff) {
+        adaptive_beam = max_active_cutoff - best_cost + o.beam_delta;
+        cur_cutoff = max_active_cutoff;
+        decided = true;
+        if (tid == 0) c.counters[5]++;
+      }
+      if (!decided) {
+        if (n_cur > o.min_active) {
+          if (o.min_active == 0) min_active_cutoff = best_cost;
+          else min_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.min_active);
+        }
+        if (min_active_cutoff > beam_cutoff) {
+          adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;
+          cur_cutoff = min_active_cutoff;
+          if (tid == 0 && n_cur > o.min_active) c.counters[6]++;
+        } else {
+          adaptive_beam = o.beam;
+          cur_cutoff = beam_cutoff;
+        }
+      }
+      const float cost_offset = (n_cur > 0) ? -best_cost : 0.f;
+      const float *ll_row = loglikes + (ll_base + f) * ld;
+      float local_min = INF;
+      for (int i = tid; i < n_cur; i += NT) {
+        const int4 tk = cur[i];
+        const float cur_cost = __int_as_float(tk.y);
+        if (!(cur_cost <= cur_cutoff)) continue;
+        cnt_expanded++;
+        const unsigned a0 = h.arc_begin[tk.x] + h.num_ieps[tk.x], a1 = h.arc_begin[tk.x + 1];
+        for (unsigned a = a0; a < a1; a++) {
+          const int4 arc = h.arcs[a];
+          const float lk = ll_row[arc.x - 1];
+          const float graph_cost = __int_as_float(arc.z);
+          const float ac_cost = cost_offset - lk;
+          const float tot = (cur_cost + ac_cost) + graph_cost;
+          if (i == best_idx) {
+            // :752-757  arc.weight + cost_offset - loglike + tok->tot_cost  (the reference's first bound)
+            const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;
+            local_min = fminf(local_min, nw);
+          }
+          local_min = fminf(local_min, tot);
+          Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a);
+          cnt_arcs++;
+          cnt_insert++;
+        }
+      }
+      float mn;
+      int dummy;
+      BlockMinArg<NT>(c, local_min, tid, &mn, &dummy);
+      const float next_cutoff = mn + adaptive_beam;   // = min over candidates of (tot_cost + adaptive_beam)
+      if (tid == 0) {
+        finfo[f * 4 + 0] = cost_offset;
+        finfo[f * 4 + 1] = cur_cutoff;
+        finfo[f * 4 + 2] = next_cutoff;
+        finfo[f * 4 + 3] = adaptive_beam;
+      }
+      // ---- drop candidates at or above the final cutoff (the reference never keeps a token it creates with
+      //      tot_cost >= next_cutoff alive past the next frame's beam; see header)
+      if (next_cutoff < INF) {
+        int nn = c.n_next < next_cap ? c.n_next : next_cap;
+        __syncthreads();
+        if (tid == 0) c.q_n[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < nn; i += NT) {
+          const int s = next_toks[i].x;
+          if (KeyCost(LoadKey(&best[s])) < next_cutoff) {
+            queue[0][atomicAdd(&c.q_n[0], 1)] = s;
+          } else {
+            StoreKey(&best[s], RS_EMPTY);
+            map_next[s] = -1;
+          }
+        }
+        __syncthreads();
+        nn = c.q_n[0];
+        for (int i = tid; i < nn; i += NT) {
+          const int s = queue[0][i];
+          next_toks[i].x = s;
+          map_next[s] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { c.n_next = nn; c.q_n[0] = 0; }
+      }
+      closure_cutoff = next_cutoff;
+      __syncthreads();
+    }
+    // ================================================================ ProcessNonemitting(closure_cutoff)
+    {
+      int qi = 0;
+      const int n0 = c.n_next < next_cap ? c.n_next : next_cap;
+      __syncthreads();
+      if (tid == 0) { c.q_n[0] = 0; c.q_n[1] = 0; }
+      __syncthreads();
+      for (int i = tid; i < n0; i += NT) {
+        const int s = next_toks[i].x;
+        if (h.num_ieps[s] != 0) {
+          queue[0][atomicAdd(&c.q_n[0], 1)] = s;
+          atomicExch(&in_queue[s], 1);
+        }
+      }
+      __syncthreads();
+      int guard_rounds = 0;
+      while (c.q_n[qi] > 0) {
+        const int qn = c.q_n[qi];
+        __syncthreads();
+        for (int i = tid; i < qn; i += NT) atomicExch(&in_queue[queue[qi][i]], 0);
+        if (tid == 0) c.q_n[qi ^ 1] = 0;
+        __syncthreads();
+        for (int i = tid; i < qn; i += NT) {
+          const int s = queue[qi][i];
+          const float cur_cost = KeyCost(LoadKey(&best[s]));
+          if (cur_cost >= closure_cutoff) continue;
+          cnt_expanded++;
+          const unsigned a0 = h.arc_begin[s], a1 = a0 + h.num_ieps[s];
+          for (unsigned a = a0; a < a1; a++) {
+            const int4 arc = h.arcs[a];
+            const float tot = cur_cost + __int_as_float(arc.z);
+            cnt_arcs++;
+            if (tot < closure_cutoff) {
+              cnt_insert++;
+              if (Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a) && h.num_ieps[arc.w] != 0) {
+                if (atomicExch(&in_queue[arc.w], 1) == 0) queue[qi ^ 1][atomicAdd(&c.q_n[qi ^ 1], 1)] = arc.w;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        qi ^= 1;
+        if (++guard_rounds > 100000) { if (tid == 0) c.error = 2; break; }   // epsilon cycle in the graph
+      }
+      __syncthreads();
+    }
+    // ================================================================ materialise frame f+1
+    {
+      const int nn = c.n_next < next_cap ? c.n_next : next_cap;
+      for (int i = tid; i < nn; i += NT) {
+        const int s = next_toks[i].x;
+        const unsigned long long key = LoadKey(&best[s]);
+        const unsigned arc = (unsigned)(key & 0xFFFFFFFFull);
+        int bp = -1;
+        if (arc != RS_NOARC) {
+          const int src = h.arc_src[arc];
+          bp = (h.arcs[arc].x == 0) ? map_next[src] : map_cur[src];
+        }
+        next_toks[i] = make_int4(s, __float_as_int(KeyCost(key)), bp, (int)arc);
+      }
+      __syncthreads();
+      // retire frame f: clear its map; clear best[] of the new frame; swap maps
+      const int4 *cur = tokens + off_cur;
+      for (int i = tid; i < n_cur; i += NT) map_cur[cur[i].x] = -1;
+      for (int i = tid; i < nn; i += NT) StoreKey(&best[next_toks[i].x], RS_EMPTY);
+      __syncthreads();
+      int *tmp = map_cur; map_cur = map_next; map_next = tmp;
+      off_cur = off_next;
+      n_cur = nn;
+      off_next = off_cur + n_cur;
+      if (tid == 0) {
+        frame_off[f + 2] = off_next;
+        c.counters[3] += (unsigned long long)nn;
+        c.n_next = 0;
+        if (nn == 0 && c.error == 0) c.error = 1;     // "no surviving tokens"
+      }
+      __syncthreads();
+      if (c.error) break;
+    }
+  }
+  // ================================================================ final costs + best-path traceback
+  // (frame T's tokens are tokens[off_cur .. off_cur + n_cur))
+  {
+    const int4 *cur = tokens + off_cur;
+    float lv1 = INF, lv2 = INF;
+    int li1 = 0x7fffffff, li2 = 0x7fffffff;
+    for (int i = tid; i < n_cur; i += NT) {
+      const float cst = __int_as_float(cur[i].y);
+      const float wf = cst + h.final_cost[cur[i].x];
+      if (wf < lv1 || (wf == lv1 && i < li1)) { lv1 = wf; li1 = i; }
+      if (cst < lv2 || (cst == lv2 && i < li2)) { lv2 = cst; li2 = i; }
+    }
+    float b1, b2;
+    int i1, i2;
+    BlockMinArg<NT>(c, lv1, li1, &b1, &i1);
+    BlockMinArg<NT>(c, lv2, li2, &b2, &i2);
+    atomicAdd(&c.counters[0], cnt_expanded);
+    atomicAdd(&c.counters[1], cnt_arcs);
+    atomicAdd(&c.counters[2], cnt_insert);
+    __syncthreads();
+    if (tid == 0) {
+      const bool reached = b1 < INF;
+      int idx = reached ? i1 : i2;
+      int F = c.error ? -1 : T;     // frame index of the token list (0..T)
+      double graph = 0.0, ac = 0.0;
+      int nw = 0;
+      int *words = w.out_words + (size_t)u * w.max_words;
+      bool truncated = false;
+      if (F >= 0 && n_cur > 0) {
+        if (reached) graph += (double)h.final_cost[cur[idx].x];
+        while (true) {
+          const int4 tk = tokens[frame_off[F] + idx];
+          if (tk.w < 0) break;
+          const int4 arc = h.arcs[tk.w];
+          graph += (double)__int_as_float(arc.z);
+          if (arc.x != 0) {
+            F -= 1;
+            const float off = finfo[F * 4 + 0];
+            const float lk = loglikes[(ll_base + F) * ld + (arc.x - 1)];
+            const float link_ac = off - lk;                   // ForwardLink::acoustic_cost
+            ac += (double)(link_ac - off);                    // GetRawLattice :166-172
+          }
+          if (arc.y != 0) {
+            if (nw < w.max_words) words[nw++] = arc.y;
+            else truncated = true;
+          }
+          idx = tk.z;
+        }
+        for (int a = 0, b = nw - 1; a < b; a++, b--) { int t2 = words[a]; words[a] = words[b]; words[b] = t2; }
+      }
+      w.out_nwords[u] = (c.error || truncated) ? -1 : nw;
+      float *oc = w.out_costs + (size_t)u * 4;
+      oc[0] = (float)graph;
+      oc[1] = (float)ac;
+      oc[2] = reached ? b1 : b2;
+      oc[3] = reached ? 1.f : 0.f;
+      c.counters[7] = (unsigned long long)c.overflow + 2ull * (unsigned long long)c.error;
+      long long *ctr = w.counters + (size_t)u * 8;
+      for (int i = 0; i < 8; i++) ctr[i] = (long long)c.counters[i];
+      frame_off[T + 1] = off_next;
+    }
+  }
+}
+
+void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                  const DecodeWork &w, hipStream_t s) {
+  if (g.n_utts == 0) return;
+  if (h.num_states > 20000)
+    hipLaunchKernelGGL(DecodeKernel<1024>, dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
+  else
+    hipLaunchKernelGGL(DecodeKernel<256>, dim3(g.n_utts), dim3(256), 0, s, h, o, g, loglikes, ld, w);
+}
+
+}  // namespace rs

@@ -1,0 +1,605 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace rs {
+
+void HipCheck(hipError_t e, const char *what, const char *file, int line) {
+  if (e != hipSuccess) {
+    std::ostringstream os;
+    os << "HIP error " << (int)e << " (" << hipGetErrorString(e) << ") at " << file << ":" << line << ": " << what;
+    throw DeviceError(os.str());
+  }
+}
+
+DeviceArena::~DeviceArena() { if (base_) (void)hipFree(base_); }
+
+void DeviceArena::Reserve(size_t bytes, hipStream_t s) {
+  if (bytes <= cap_) return;
+  if (base_) {
+    RS_HIP(hipStreamSynchronize(s));
+    RS_HIP(hipFree(base_));
+    base_ = nullptr;
+    cap_ = 0;
+  }
+  size_t want = bytes + bytes / 8 + (1u << 20);
+  RS_HIP(hipMalloc((void **)&base_, want));
+  RS_HIP(hipMemsetAsync(base_, 0, want, s));
+  cap_ = want;
+  used_ = 0;
+}
+
+void *DeviceArena::Alloc(size_t bytes) {
+  size_t a = (used_ + 255) & ~(size_t)255;
+  if (a + bytes > cap_) Fail("internal error: device arena too small");
+  used_ = a + bytes;
+  return base_ + a;
+}
+
+static int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------ model
+
+Model::Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf,
+             const rs_decode_opts &opts)
+    : opts_(opts) {
+  if (opts_.frame_subsampling_factor != 1)
+    Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
+  if (opts_.frames_per_chunk <= 0) Fail("frames-per-chunk must be positive");
+  ReadFeatureConfig(online_conf, &fc_);
+  am_.Read(final_mdl);
+  hclg_.Read(hclg);
+  if (fc_.mfcc.opts.dither != 0.0f)
+    Fail("mfcc.conf has --dither=" + std::to_string(fc_.mfcc.opts.dither) +
+         ": the reference's dither draws from glibc rand() (feature-window.cc:90-98) and is not reproduced on the "
+         "device; set --dither=0 in the mfcc config");
+  const Nnet &n = am_.nnet;
+  if (n.input_dim != fc_.mfcc.nceps)
+    Fail("Input feature dimension mismatch: got " + std::to_string(fc_.mfcc.nceps) + " but network expects " + std::to_string(n.input_dim));
+  int ivd = fc_.ie.present ? fc_.ie.ivector_dim() : 0;
+  if (n.ivector_dim != ivd) {
+    if (n.ivector_dim > 0 && ivd == 0) Fail("Ivector feature dimension mismatch: got -1 but network expects " + std::to_string(n.ivector_dim));
+    Fail("Ivector feature dimension mismatch: got " + std::to_string(ivd) + " but network expects " + std::to_string(n.ivector_dim));
+  }
+  // every emitting arc must name a valid transition-id
+  int ntid = (int)am_.trans.id2pdf.size();
+  for (auto &a : hclg_.arcs)
+    if (a.ilabel >= ntid) Fail("HCLG refers to transition-id " + std::to_string(a.ilabel) + " but the model has only " + std::to_string(ntid - 1));
+  // arcs must be ilabel-sorted within a state so that the epsilon arcs come first (mkgraph.sh output is)
+  arc_ilabel_.resize(hclg_.arcs.size());
+  for (int s = 0; s < hclg_.num_states(); s++) {
+    auto b = hclg_.arcs.begin() + hclg_.arc_begin[s], e = hclg_.arcs.begin() + hclg_.arc_begin[s + 1];
+    if (!std::is_sorted(b, e, [](const FstArc &x, const FstArc &y) { return x.ilabel < y.ilabel; }))
+      std::stable_sort(b, e, [](const FstArc &x, const FstArc &y) { return x.ilabel < y.ilabel; });
+    uint32_t ne = 0;
+    for (auto it = b; it != e; ++it) if (it->ilabel == 0) ne++;
+    hclg_.num_ieps[s] = ne;
+  }
+  for (size_t i = 0; i < hclg_.arcs.size(); i++) arc_ilabel_[i] = hclg_.arcs[i].ilabel;
+  L_ = n.left_context;
+  R_ = n.right_context;
+  if (fc_.ie.present) {
+    L_ = std::max(L_, fc_.ie.splice_left);
+    R_ = std::max(R_, fc_.ie.splice_right);
+    // splice + LDA as a segmented GEMM over the (padded) feature buffer: buffers 0 = raw, 1 = cmvn (filled in per batch)
+    const IvectorExtractor &ie = fc_.ie;
+    int C = fc_.mfcc.nceps, nsp = ie.splice_left + 1 + ie.splice_right;
+    lda_op_.kind = LayerOp::kGemm;
+    lda_op_.name = "ivector.splice+lda";
+    lda_op_.out_dim = ie.lda.rows;
+    lda_op_.W.Resize(ie.lda.rows, C * nsp);
+    bool affine = ie.lda.cols == C * nsp + 1;
+    if (affine) lda_op_.bias.resize(ie.lda.rows);
+    for (int r = 0; r < ie.lda.rows; r++) {
+      for (int c = 0; c < C * nsp; c++) lda_op_.W(r, c) = ie.lda(r, c);
+      if (affine) lda_op_.bias[r] = ie.lda(r, C * nsp);
+    }
+    for (int i = 0; i < nsp; i++) {
+      GemmSegment sg;
+      sg.src_buf = 0; sg.src_col = 0; sg.ncols = C; sg.offset = i - ie.splice_left; sg.w_col = i * C;
+      lda_op_.segs.push_back(sg);
+    }
+  }
+  for (auto &op : am_.nnet.ops) {
+    if (op.kind == LayerOp::kGemm && (int)op.segs.size() > kMaxSegs) Fail("nnet3: layer " + op.name + " has too many input segments");
+    if ((int)op.stages.size() > kMaxStages) Fail("nnet3: layer " + op.name + " has too many fused stages");
+    if (op.kind == LayerOp::kEltwise && op.terms.size() > 8) Fail("nnet3: layer " + op.name + " sums too many terms");
+  }
+}
+
+Model::~Model() {
+  for (void *p : owned_) (void)hipFree(p);
+  if (h_pcm_pinned_) (void)hipHostFree(h_pcm_pinned_);
+  if (d_pcm_) (void)hipFree(d_pcm_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void *Model::UploadBytes(const void *p, size_t bytes) {
+  void *d = nullptr;
+  RS_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+  owned_.push_back(d);
+  if (bytes) RS_HIP(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice));
+  return d;
+}
+template <typename T> T *Model::Upload(const std::vector<T> &v) { return static_cast<T *>(UploadBytes(v.data(), v.size() * sizeof(T))); }
+
+void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
+  plan->op = &op;
+  int k = 0;
+  plan->seg_k0.clear();
+  for (auto &sg : op.segs) { plan->seg_k0.push_back(k); k += RoundUp(sg.ncols, kGemmBK); }
+  plan->k_pad = k;
+  plan->n_pad = RoundUp(op.out_dim, kGemmBN);
+  std::vector<float> W((size_t)plan->n_pad * plan->k_pad, 0.0f);
+  for (size_t si = 0; si < op.segs.size(); si++) {
+    const GemmSegment &sg = op.segs[si];
+    for (int r = 0; r < op.out_dim; r++)
+      std::memcpy(&W[(size_t)r * plan->k_pad + plan->seg_k0[si]], &op.W.d[(size_t)r * op.W.cols + sg.w_col], sizeof(float) * sg.ncols);
+  }
+  plan->d_W = Upload(W);
+  plan->d_bias = op.bias.empty() ? nullptr : Upload(op.bias);
+  plan->d_stage.clear();
+  for (auto &st : op.stages) {
+    float *s = nullptr, *o = nullptr;
+    if (st.kind == EltStage::kScaleOffset) { s = Upload(st.scale); o = Upload(st.offset); }
+    plan->d_stage.emplace_back(s, o);
+  }
+}
+
+void Model::ToDevice() {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (on_device_) return;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    throw DeviceError("no HIP device available: librhasspy_speech_hip has no CPU fallback (hipGetDeviceCount: " +
+                      std::string(hipGetErrorString(e)) + ")");
+  if (opts_.device_id < 0 || opts_.device_id >= ndev) throw DeviceError("device_id " + std::to_string(opts_.device_id) + " out of range");
+  RS_HIP(hipSetDevice(opts_.device_id));
+  hipDeviceProp_t prop;
+  RS_HIP(hipGetDeviceProperties(&prop, opts_.device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    throw DeviceError(std::string("this library is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
+  RS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  // ---- MFCC tables
+  const MfccTables &t = fc_.mfcc;
+  mfcc_dev_.win = t.win; mfcc_dev_.shift = t.shift; mfcc_dev_.padded = t.padded; mfcc_dev_.nbins = t.nbins; mfcc_dev_.nceps = t.nceps;
+  mfcc_dev_.preemph = t.opts.preemph; mfcc_dev_.remove_dc = t.opts.remove_dc; mfcc_dev_.use_energy = t.opts.use_energy;
+  mfcc_dev_.raw_energy = t.opts.raw_energy; mfcc_dev_.log_energy_floor = t.log_energy_floor;
+  mfcc_dev_.window = Upload(t.window);
+  mfcc_dev_.mel_offset = Upload(t.mel_offset); mfcc_dev_.mel_len = Upload(t.mel_len); mfcc_dev_.mel_start = Upload(t.mel_start);
+  mfcc_dev_.mel_weights = Upload(t.mel_weights);
+  mfcc_dev_.dct = Upload(t.dct);
+  mfcc_dev_.lifter = Upload(t.lifter);
+  {
+    int NC = t.padded / 2;
+    std::vector<float> tw((size_t)2 * (NC + NC + 1));
+    for (int k = 0; k < NC; k++) { double a = 2.0 * M_PI * k / NC; tw[2 * k] = (float)cos(a); tw[2 * k + 1] = (float)-sin(a); }
+    for (int k = 0; k <= NC; k++) { double a = 2.0 * M_PI * k / t.padded; tw[2 * (NC + k)] = (float)cos(a); tw[2 * (NC + k) + 1] = (float)-sin(a); }
+    mfcc_dev_.twiddle = Upload(tw);
+  }
+  // ---- CMVN on the nnet input branch
+  if (fc_.use_cmvn) {
+    cmvn_nnet_dev_.dim = t.nceps; cmvn_nnet_dev_.cmn_window = fc_.cmvn.cmn_window;
+    cmvn_nnet_dev_.speaker_frames = fc_.cmvn.speaker_frames; cmvn_nnet_dev_.global_frames = fc_.cmvn.global_frames;
+    cmvn_nnet_dev_.global_stats = Upload(fc_.global_cmvn.d);
+  }
+  // ---- iVector extractor
+  if (fc_.ie.present) {
+    const IvectorExtractor &ie = fc_.ie;
+    cmvn_iv_dev_.dim = t.nceps; cmvn_iv_dev_.cmn_window = ie.cmvn.cmn_window; cmvn_iv_dev_.speaker_frames = ie.cmvn.speaker_frames;
+    cmvn_iv_dev_.global_frames = ie.cmvn.global_frames;
+    cmvn_iv_dev_.global_stats = Upload(ie.global_cmvn.d);
+    int G = ie.num_gauss(), D = ie.feat_dim();
+    if (G > 2048) Fail("iVector extractor: more than 2048 Gaussians are not supported");
+    if (D > 128) Fail("iVector extractor: feature dim > 128 is not supported");
+    if (ie.num_gselect > 8) Fail("iVector extractor: num-gselect > 8 is not supported");
+    std::vector<float> mt((size_t)D * G), vt((size_t)D * G);
+    for (int g = 0; g < G; g++)
+      for (int d = 0; d < D; d++) { mt[(size_t)d * G + g] = ie.means_invvars(g, d); vt[(size_t)d * G + g] = ie.inv_vars(g, d); }
+    ivec_dev_.feat_dim = D; ivec_dev_.ivec_dim = ie.ivector_dim(); ivec_dev_.num_gauss = G; ivec_dev_.num_gselect = ie.num_gselect;
+    ivec_dev_.num_cg_iters = ie.num_cg_iters; ivec_dev_.min_post = ie.min_post; ivec_dev_.posterior_scale = ie.posterior_scale;
+    ivec_dev_.max_count = ie.max_count; ivec_dev_.prior_offset = ie.prior_offset;
+    ivec_dev_.gconsts = Upload(ie.gconsts);
+    ivec_dev_.means_invvars_t = Upload(mt);
+    ivec_dev_.inv_vars_t = Upload(vt);
+    ivec_dev_.sigma_inv_M = Upload(ie.sigma_inv_M);
+    ivec_dev_.U = Upload(ie.U);
+    BuildGemmPlan(lda_op_, &lda_plan_);
+  }
+  // ---- nnet
+  gemm_plans_.assign(am_.nnet.ops.size(), GemmPlan());
+  for (size_t i = 0; i < am_.nnet.ops.size(); i++) BuildGemmPlan(am_.nnet.ops[i], &gemm_plans_[i]);
+  if (!am_.nnet.priors.empty()) {
+    std::vector<float> lp(am_.nnet.priors.size());
+    for (size_t i = 0; i < lp.size(); i++) lp[i] = logf(am_.nnet.priors[i]);
+    d_log_priors_ = Upload(lp);
+  }
+  // ---- HCLG
+  {
+    size_t A = hclg_.arcs.size();
+    std::vector<int4> arcs(A);
+    std::vector<int> src(A);
+    for (int s = 0; s < hclg_.num_states(); s++)
+      for (uint32_t a = hclg_.arc_begin[s]; a < hclg_.arc_begin[s + 1]; a++) {
+        const FstArc &fa = hclg_.arcs[a];
+        int pdf1 = fa.ilabel == 0 ? 0 : am_.trans.id2pdf[fa.ilabel] + 1;
+        int wbits;
+        std::memcpy(&wbits, &fa.weight, 4);
+        arcs[a] = make_int4(pdf1, fa.olabel, wbits, fa.nextstate);
+        src[a] = s;
+      }
+    hclg_dev_.num_states = hclg_.num_states();
+    hclg_dev_.num_arcs = (int)A;
+    hclg_dev_.start = hclg_.start;
+    hclg_dev_.arc_begin = Upload(hclg_.arc_begin);
+    hclg_dev_.num_ieps = Upload(hclg_.num_ieps);
+    hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
+    hclg_dev_.arc_src = Upload(src);
+    hclg_dev_.final_cost = Upload(hclg_.final_cost);
+  }
+  RS_HIP(hipDeviceSynchronize());
+  on_device_ = true;
+}
+
+std::string Model::Describe() const {
+  std::ostringstream os;
+  const MfccTables &t = fc_.mfcc;
+  os << "mfcc: win=" << t.win << " shift=" << t.shift << " padded=" << t.padded << " mel_bins=" << t.nbins << " ceps=" << t.nceps
+     << " dither=" << t.opts.dither << "\n";
+  os << "nnet_input_cmvn: " << (fc_.use_cmvn ? 1 : 0) << "\n";
+  if (fc_.ie.present)
+    os << "ivector: dim=" << fc_.ie.ivector_dim() << " gauss=" << fc_.ie.num_gauss() << " lda_dim=" << fc_.ie.feat_dim()
+       << " splice=" << fc_.ie.splice_left << "," << fc_.ie.splice_right << " gselect=" << fc_.ie.num_gselect
+       << " max_count=" << fc_.ie.max_count << " prior_offset=" << fc_.ie.prior_offset << "\n";
+  else os << "ivector: none\n";
+  const Nnet &n = am_.nnet;
+  os << "nnet: input_dim=" << n.input_dim << " ivector_dim=" << n.ivector_dim << " output_dim=" << n.output_dim
+     << " left_context=" << n.left_context << " right_context=" << n.right_context << " priors=" << n.priors.size()
+     << " components=" << n.components.size() << " ops=" << n.ops.size() << "\n";
+  for (auto &op : n.ops) {
+    os << "op: " << (op.kind == LayerOp::kGemm ? "gemm" : "eltwise") << " " << op.name << " out_dim=" << op.out_dim;
+    if (op.kind == LayerOp::kGemm) {
+      os << " k=" << op.W.cols << " segs=";
+      for (auto &s : op.segs) os << "[" << s.src_buf << ":" << s.offset << ":" << s.ncols << "]";
+    } else {
+      os << " terms=" << op.terms.size();
+    }
+    os << " stages=" << op.stages.size() << "\n";
+  }
+  os << "transition_model: tids=" << am_.trans.id2pdf.size() - 1 << " pdfs=" << am_.trans.num_pdfs << "\n";
+  os << "hclg: states=" << hclg_.num_states() << " arcs=" << hclg_.arcs.size() << " start=" << hclg_.start << "\n";
+  os << "halo: L=" << L_ << " R=" << R_ << "\n";
+  return os.str();
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+
+namespace {
+struct Timer {
+  hipEvent_t ev[8];
+  int n = 0;
+  hipStream_t s;
+  explicit Timer(hipStream_t st) : s(st) { for (auto &e : ev) (void)hipEventCreate(&e); }
+  ~Timer() { for (auto &e : ev) (void)hipEventDestroy(e); }
+  void Mark() { if (n < 8) (void)hipEventRecord(ev[n++], s); }
+  float Ms(int a, int b) { float ms = 0; if (a < n && b < n) (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; }
+};
+}  // namespace
+
+std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
+                                               float lat_scale) {
+  ToDevice();
+  std::vector<int64_t> off(n_utts + 1, 0);
+  for (int i = 0; i < n_utts; i++) {
+    if (n_samples[i] < 0 || (n_samples[i] > 0 && pcm[i] == nullptr)) Fail("rs_decode_batch: bad sample buffer for utterance " + std::to_string(i));
+    off[i + 1] = off[i] + n_samples[i];
+  }
+  std::unique_ptr<Result> res;
+  float h2d_ms = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    RS_HIP(hipSetDevice(opts_.device_id));
+    size_t total = (size_t)off[n_utts] + 512;
+    if (total > h_pcm_cap_) {
+      if (h_pcm_pinned_) RS_HIP(hipHostFree(h_pcm_pinned_));
+      if (d_pcm_) RS_HIP(hipFree(d_pcm_));
+      h_pcm_cap_ = total + total / 4;
+      RS_HIP(hipHostMalloc((void **)&h_pcm_pinned_, h_pcm_cap_ * sizeof(int16_t), hipHostMallocDefault));
+      RS_HIP(hipMalloc((void **)&d_pcm_, h_pcm_cap_ * sizeof(int16_t)));
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n_utts; i++)
+      if (n_samples[i]) std::memcpy(h_pcm_pinned_ + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
+    RS_HIP(hipMemcpyAsync(d_pcm_, h_pcm_pinned_, sizeof(int16_t) * (size_t)off[n_utts], hipMemcpyHostToDevice, stream_));
+    RS_HIP(hipStreamSynchronize(stream_));
+    h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  res = DecodeBatchDevice(d_pcm_, off.data(), n_utts, nbest, lat_scale, nullptr);
+  res->timings[0] = h2d_ms;
+  res->timings[6] += h2d_ms;
+  return res;
+}
+
+std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
+                                                 float lat_scale, hipStream_t user_stream) {
+  (void)lat_scale;
+  ToDevice();
+  std::lock_guard<std::mutex> lk(mu_);
+  RS_HIP(hipSetDevice(opts_.device_id));
+  hipStream_t s = user_stream ? user_stream : stream_;
+  auto wall0 = std::chrono::steady_clock::now();
+  std::unique_ptr<Result> res(new Result());
+  res->utts.resize(n_utts);
+  if (n_utts == 0) return res;
+  if (nbest < 1) Fail("nbest must be >= 1");
+  const Nnet &nn = am_.nnet;
+  const int C = fc_.mfcc.nceps, P = nn.output_dim;
+  // ---- geometry
+  std::vector<int> T(n_utts), row_base(n_utts + 1, 0), frame_base(n_utts + 1, 0);
+  int maxT = 0;
+  for (int u = 0; u < n_utts; u++) {
+    long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
+    if (ns < 0) Fail("sample offsets must be non-decreasing");
+    T[u] = NumFrames(ns, fc_.mfcc.opts);
+    maxT = std::max(maxT, T[u]);
+    row_base[u + 1] = row_base[u] + T[u] + L_ + R_;
+    frame_base[u + 1] = frame_base[u] + T[u];
+    res->utts[u].num_frames = T[u];
+  }
+  const int rows = row_base[n_utts];
+  const int guard = L_ + R_ + 8;
+  std::vector<int> row_utt(rows), row_t(rows);
+  for (int u = 0; u < n_utts; u++)
+    for (int r = row_base[u]; r < row_base[u + 1]; r++) { row_utt[r] = u; row_t[r] = r - row_base[u] - L_; }
+  // ---- arena sizing
+  auto fbytes = [&](int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
+  size_t need = 0;
+  need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 2 * sizeof(int) * (size_t)rows + 4096;
+  std::vector<int> buf_ld(nn.bufs.size());
+  for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
+  const bool has_iv = fc_.ie.present;
+  const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
+  const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
+  const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
+  if (fc_.use_cmvn) need += fbytes(ld_c);
+  if (has_iv) {
+    need += fbytes(ld_c) + 2 * fbytes(ld_l);
+    need += (size_t)rows * nsel * 8 + 1024;
+    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8 + (size_t)ld_i * 4) + 8192;
+  }
+  const int S = hclg_.num_states();
+  int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
+  cap_pf = std::min(cap_pf, S);
+  const long tok_cap_l = (long)(maxT + 2) * cap_pf;
+  if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
+  const int tok_cap = (int)tok_cap_l;
+  const int max_words = 1024;
+  need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)tok_cap * 16 + (size_t)(maxT + 2) * 4 + (size_t)(maxT + 1) * 16 +
+                            (size_t)max_words * 4 + 4 + 16 + 64) + 65536;
+  need += 64 * 256;   // alignment slack
+  arena_.Reserve(need + (1u << 20), s);
+  arena_.Reset();
+  // ---- upload geometry
+  BatchGeom g;
+  g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
+  {
+    int64_t *d_so = arena_.AllocT<int64_t>(n_utts + 1);
+    int *d_T = arena_.AllocT<int>(n_utts), *d_rb = arena_.AllocT<int>(n_utts + 1), *d_fb = arena_.AllocT<int>(n_utts + 1);
+    int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
+    RS_HIP(hipMemcpyAsync(d_so, sample_offsets, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice, s));
+    RS_HIP(hipMemcpyAsync(d_T, T.data(), sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+    RS_HIP(hipMemcpyAsync(d_rb, row_base.data(), sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
+    RS_HIP(hipMemcpyAsync(d_fb, frame_base.data(), sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
+    RS_HIP(hipMemcpyAsync(d_ru, row_utt.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    RS_HIP(hipMemcpyAsync(d_rt, row_t.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    RS_HIP(hipStreamSynchronize(s));   // the host vectors above go out of scope only at function end, but keep it simple
+    g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
+  }
+  auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
+  Timer tm(s);
+  tm.Mark();
+  // ---- features
+  std::vector<float *> bufp(nn.bufs.size(), nullptr);
+  for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(buf_ld[b]);
+  float *raw = bufp[nn.input_buf];
+  if (fc_.use_cmvn) {
+    raw = falloc(ld_c);
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s);
+    LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
+  } else {
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s);
+  }
+  const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
+  tm.Mark();
+  // ---- iVector
+  float *d_ivec = nullptr;
+  auto fill_gemm = [&](const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld,
+                       float *out, int ldo) {
+    GemmDev d;
+    std::memset(&d, 0, sizeof(d));
+    const LayerOp &op = *pl.op;
+    d.nsegs = (int)op.segs.size();
+    for (int i = 0; i < d.nsegs; i++) {
+      const GemmSegment &sg = op.segs[i];
+      GemmSegDev &o = d.segs[i];
+      if (sg.src_buf < 0) { o.src = ivec; o.ld = ivec_ld; o.per_utt = 1; o.row_off = 0; }
+      else { o.src = src[sg.src_buf]; o.ld = src_ld[sg.src_buf]; o.per_utt = 0; o.row_off = sg.offset; }
+      o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
+    }
+    d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
+    d.nstages = (int)op.stages.size();
+    for (int i = 0; i < d.nstages; i++) {
+      const EltStage &st = op.stages[i];
+      d.stages[i].kind = st.kind == EltStage::kRelu ? 0 : (st.kind == EltStage::kScaleOffset ? 1 : 4);
+      d.stages[i].scale = pl.d_stage[i].first; d.stages[i].offset = pl.d_stage[i].second; d.stages[i].alpha = st.alpha;
+    }
+    d.out = out; d.ldo = ldo;
+    return d;
+  };
+  if (has_iv) {
+    float *cm = falloc(ld_c), *lda_raw = falloc(ld_l), *lda_norm = falloc(ld_l);
+    LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
+    LaunchGemm(fill_gemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l), rows, g.d_row_utt, s);
+    LaunchGemm(fill_gemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l), rows, g.d_row_utt, s);
+    int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
+    float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
+    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, s);
+    double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
+    double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
+    double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
+    d_ivec = arena_.AllocT<float>((size_t)n_utts * ld_i);
+    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
+    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
+    RS_HIP(hipMemsetAsync(numf, 0, sizeof(double) * n_utts, s));
+    RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_utts * ld_i, s));
+    // OnlineIvectorEstimationStats ctor (ivector-extractor.cc:786-795): quadratic = I, linear = [prior_offset, 0, ...];
+    // current_ivector_ starts at [prior_offset, 0, ...] (online-ivector-feature.cc:440-442)
+    {
+      std::vector<double> hl((size_t)n_utts * Di, 0.0), hq((size_t)n_utts * usz, 0.0), hx((size_t)n_utts * Di, 0.0);
+      for (int u = 0; u < n_utts; u++) {
+        hl[(size_t)u * Di] = fc_.ie.prior_offset;
+        hx[(size_t)u * Di] = fc_.ie.prior_offset;
+        for (int r = 0; r < Di; r++) hq[(size_t)u * usz + (size_t)r * (r + 1) / 2 + r] = 1.0;
+      }
+      RS_HIP(hipMemcpyAsync(linear, hl.data(), sizeof(double) * hl.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(quad, hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipStreamSynchronize(s));
+    }
+    const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
+    LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
+    LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
+    LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, s);
+  }
+  tm.Mark();
+  // ---- acoustic model
+  for (size_t i = 0; i < nn.ops.size(); i++) {
+    const LayerOp &op = nn.ops[i];
+    if (op.kind == LayerOp::kGemm) {
+      LaunchGemm(fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]), rows, g.d_row_utt, s);
+    } else {
+      EltwiseDev d;
+      std::memset(&d, 0, sizeof(d));
+      d.nterms = (int)op.terms.size();
+      for (int k = 0; k < d.nterms; k++) {
+        d.terms[k].src = bufp[op.terms[k].src_buf]; d.terms[k].ld = buf_ld[op.terms[k].src_buf];
+        d.terms[k].col0 = op.terms[k].src_col; d.terms[k].row_off = op.terms[k].offset; d.terms[k].scale = op.terms[k].scale;
+      }
+      d.dim = op.out_dim; d.out = bufp[op.out_buf]; d.ldo = buf_ld[op.out_buf];
+      int ns = 0;
+      for (auto &st : op.stages) {
+        if (st.kind == EltStage::kLogSoftmax || st.kind == EltStage::kNormalize) {
+          if (op.stages.size() != 1 || op.terms.size() != 1 || op.terms[0].scale != 1.0f)
+            Fail("nnet3: row-wise component in a fused position is not supported: " + op.name);
+          d.row_reduce = st.kind == EltStage::kLogSoftmax ? 2 : 3;
+          d.alpha = st.alpha;
+        } else {
+          d.stages[ns].kind = st.kind == EltStage::kRelu ? 0 : (st.kind == EltStage::kScaleOffset ? 1 : 4);
+          d.stages[ns].scale = gemm_plans_[i].d_stage[&st - &op.stages[0]].first;
+          d.stages[ns].offset = gemm_plans_[i].d_stage[&st - &op.stages[0]].second;
+          d.stages[ns].alpha = st.alpha;
+          ns++;
+        }
+      }
+      d.nstages = ns;
+      LaunchEltwise(d, rows, s);
+    }
+  }
+  float *ll = bufp[nn.output_buf];
+  const int ll_ld = buf_ld[nn.output_buf];
+  if (d_log_priors_ || opts_.acoustic_scale != 1.0f) LaunchPriorScale(ll, ll_ld, rows, P, d_log_priors_, opts_.acoustic_scale, s);
+  tm.Mark();
+  // ---- decode
+  DecodeWork w;
+  std::memset(&w, 0, sizeof(w));
+  w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
+  w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
+  w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
+  w.queue_a = arena_.AllocT<int>((size_t)n_utts * S);
+  w.queue_b = arena_.AllocT<int>((size_t)n_utts * S);
+  w.in_queue = arena_.AllocT<int>((size_t)n_utts * S);
+  w.tok_cap = tok_cap;
+  w.tokens = arena_.AllocT<int4>((size_t)n_utts * tok_cap);
+  w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
+  w.max_words = max_words;
+  w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
+  w.out_nwords = arena_.AllocT<int>(n_utts);
+  w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
+  w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
+  DecodeOptsDev dopts;
+  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
+  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
+  LaunchDecode(hclg_dev_, dopts, g, ll, ll_ld, w, s);
+  tm.Mark();
+  // ---- results to host
+  std::vector<int> h_nw(n_utts), h_words((size_t)n_utts * max_words);
+  std::vector<float> h_costs((size_t)n_utts * 4);
+  std::vector<long long> h_ctr((size_t)n_utts * 8);
+  RS_HIP(hipMemcpyAsync(h_nw.data(), w.out_nwords, sizeof(int) * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(h_costs.data(), w.out_costs, sizeof(float) * 4 * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(h_ctr.data(), w.counters, sizeof(long long) * 8 * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(h_words.data(), w.out_words, sizeof(int) * (size_t)n_utts * max_words, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipStreamSynchronize(s));
+  RS_HIP(hipGetLastError());
+  tm.Mark();
+  for (int u = 0; u < n_utts; u++) {
+    UttResult &ur = res->utts[u];
+    for (int k = 0; k < 8; k++) ur.counters[k] = h_ctr[(size_t)u * 8 + k];
+    if (T[u] == 0) {
+      ur.status = RS_ERR_DECODE;
+      ur.error = "You cannot get a lattice if you decoded no frames.";   // online-nnet3-decoding.cc:68-69
+      continue;
+    }
+    if (h_nw[u] < 0) {
+      ur.status = RS_ERR_DECODE;
+      long long flags = ur.counters[7];
+      if (flags & 1) ur.error = "decoder token capacity exceeded (raise rs_decode_opts.max_tokens_per_frame)";
+      else if (flags & 4) ur.error = "epsilon cycle in the decoding graph";
+      else if (flags & 2) ur.error = "no surviving tokens (search error)";
+      else ur.error = "best path has more than " + std::to_string(max_words) + " words";
+      continue;
+    }
+    if (ur.counters[7] & 1) {
+      ur.status = RS_ERR_DECODE;
+      ur.error = "decoder token capacity exceeded (raise rs_decode_opts.max_tokens_per_frame)";
+      continue;
+    }
+    Hypothesis hy;
+    hy.words.assign(h_words.begin() + (size_t)u * max_words, h_words.begin() + (size_t)u * max_words + h_nw[u]);
+    hy.graph_cost = h_costs[(size_t)u * 4 + 0];
+    hy.acoustic_cost = h_costs[(size_t)u * 4 + 1];
+    ur.hyps.push_back(std::move(hy));
+  }
+  if (opts_.keep_intermediates) {
+    for (int u = 0; u < n_utts; u++) {
+      UttResult &ur = res->utts[u];
+      ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? 1 : 0;
+      if (T[u] == 0) continue;
+      ur.feats.resize((size_t)T[u] * C);
+      ur.loglikes.resize((size_t)T[u] * P);
+      const float *fin = bufp[nn.input_buf] + ((size_t)row_base[u] + L_) * buf_ld[nn.input_buf];
+      RS_HIP(hipMemcpy2D(ur.feats.data(), sizeof(float) * C, fin, sizeof(float) * buf_ld[nn.input_buf], sizeof(float) * C, T[u], hipMemcpyDeviceToHost));
+      const float *lin = ll + ((size_t)row_base[u] + L_) * ll_ld;
+      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, lin, sizeof(float) * ll_ld, sizeof(float) * P, T[u], hipMemcpyDeviceToHost));
+      if (has_iv) {
+        ur.ivector.resize(Di);
+        RS_HIP(hipMemcpy(ur.ivector.data(), d_ivec + (size_t)u * ld_i, sizeof(float) * Di, hipMemcpyDeviceToHost));
+      }
+    }
+  }
+  res->timings[1] = tm.Ms(0, 1);
+  res->timings[2] = tm.Ms(1, 2);
+  res->timings[3] = tm.Ms(2, 3);
+  res->timings[4] = tm.Ms(3, 4);
+  res->timings[5] = tm.Ms(4, 5);
+  res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  return res;
+}
+
+}  // namespace rs

@@ -1,0 +1,114 @@
+// Host orchestration of the batched transcribe pipeline on one MI355X (one process per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rhasspy_speech_hip.h"
+#include "kernels.h"
+#include "model.h"
+
+namespace rs {
+
+struct DeviceError : Error {
+  explicit DeviceError(const std::string &m) : Error(m) {}
+};
+void HipCheck(hipError_t e, const char *what, const char *file, int line);
+#define RS_HIP(x) ::rs::HipCheck((x), #x, __FILE__, __LINE__)
+
+// Grow-only device arena; reset at the start of every batch (no hipMalloc inside the timed region once warm).
+class DeviceArena {
+ public:
+  ~DeviceArena();
+  void Reset() { used_ = 0; }
+  void Reserve(size_t bytes, hipStream_t s);   // make sure capacity >= bytes (frees + reallocates if needed)
+  void *Alloc(size_t bytes);                   // 256-byte aligned; throws if Reserve() was too small
+  size_t capacity() const { return cap_; }
+  template <typename T> T *AllocT(size_t n) { return static_cast<T *>(Alloc(n * sizeof(T))); }
+ private:
+  char *base_ = nullptr;
+  size_t cap_ = 0, used_ = 0;
+};
+
+struct Hypothesis {
+  std::vector<int32_t> words;
+  float graph_cost = 0, acoustic_cost = 0;
+};
+struct UttResult {
+  int status = RS_OK;
+  std::string error;
+  int num_frames = 0;
+  std::vector<Hypothesis> hyps;
+  int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<float> feats, ivector, loglikes;   // keep_intermediates only
+  int feat_dim = 0, ivec_rows = 0, ivec_dim = 0, num_pdfs = 0;
+};
+struct Result {
+  std::vector<UttResult> utts;
+  float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// Device-resident, immutable part of a model.
+struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
+  const LayerOp *op = nullptr;
+  float *d_W = nullptr, *d_bias = nullptr;
+  int k_pad = 0, n_pad = 0;
+  std::vector<int> seg_k0;
+  std::vector<std::pair<float *, float *>> d_stage;   // scale/offset vectors per stage
+};
+
+class Model {
+ public:
+  Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf, const rs_decode_opts &opts);
+  ~Model();
+  void ToDevice();
+  std::string Describe() const;
+  std::unique_ptr<Result> DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
+                                            float lat_scale, hipStream_t stream);
+  std::unique_ptr<Result> DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
+                                          float lat_scale);
+  const rs_decode_opts &opts() const { return opts_; }
+  const FeatureConfig &features() const { return fc_; }
+  const AcousticModel &am() const { return am_; }
+  const Hclg &hclg() const { return hclg_; }
+
+ private:
+  template <typename T> T *Upload(const std::vector<T> &v);
+  void *UploadBytes(const void *p, size_t bytes);
+  void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
+
+  rs_decode_opts opts_;
+  FeatureConfig fc_;
+  AcousticModel am_;
+  Hclg hclg_;
+  std::vector<int32_t> arc_ilabel_;   // original transition-ids (device arcs carry pdf+1)
+
+  bool on_device_ = false;
+  std::mutex mu_;
+  hipStream_t stream_ = nullptr;
+  std::vector<void *> owned_;         // persistent device allocations
+  DeviceArena arena_;
+  // pinned staging for host-buffer batches
+  int16_t *h_pcm_pinned_ = nullptr;
+  size_t h_pcm_cap_ = 0;
+  int16_t *d_pcm_ = nullptr;
+  size_t d_pcm_cap_ = 0;
+
+  MfccDev mfcc_dev_{};
+  CmvnDev cmvn_iv_dev_{}, cmvn_nnet_dev_{};
+  IvecDev ivec_dev_{};
+  LayerOp lda_op_;                    // splice + LDA of the iVector branch, as a segmented GEMM
+  GemmPlan lda_plan_;
+  std::vector<GemmPlan> gemm_plans_;  // indexed like am_.nnet.ops (unused entries for eltwise ops)
+  float *d_log_priors_ = nullptr;
+  HclgDev hclg_dev_{};
+  int L_ = 0, R_ = 0;
+};
+
+}  // namespace rs
+
+struct rs_model { std::unique_ptr<rs::Model> m; };
+struct rs_result { std::unique_ptr<rs::Result> r; };

@@ -1,0 +1,172 @@
+// Launchers of the hand-written gfx950 kernels (one process per GPU; all launches go to the caller's
+// hipStream_t).  Device pointers unless noted.  Row layout shared by every per-frame buffer of a batch
+// ("ragged time-major with halo"): utterance u owns rows [row_base[u], row_base[u] + T_u + L + R);
+// frame t of u is row row_base[u] + L + t; L/R halo rows replicate the edge frames of the *input*
+// features so that every nnet layer can be evaluated on all rows with constant row offsets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rs {
+
+// ---------------------------------------------------------------- batch geometry (device copies)
+struct BatchGeom {
+  int n_utts = 0;
+  int L = 0, R = 0;            // halo
+  int total_rows = 0;          // sum of (T_u + L + R)
+  int total_frames = 0;        // sum of T_u
+  int max_frames = 0;
+  int guard = 0;               // zeroed guard rows before/after every frame buffer
+  const int64_t *d_sample_off = nullptr;  // n_utts + 1
+  const int *d_num_frames = nullptr;      // n_utts
+  const int *d_row_base = nullptr;        // n_utts + 1
+  const int *d_frame_base = nullptr;      // n_utts + 1 (prefix sum of T_u; compact per-frame arrays)
+  const int *d_row_utt = nullptr;         // total_rows: utterance of each row
+  const int *d_row_t = nullptr;           // total_rows: clamped frame index t in [0, T_u) of each row
+};
+
+// ---------------------------------------------------------------- MFCC
+struct MfccDev {
+  int win, shift, padded, nbins, nceps;
+  float preemph;
+  int remove_dc, use_energy, raw_energy;
+  float log_energy_floor;
+  const float *window;       // win
+  const int *mel_offset, *mel_len, *mel_start;
+  const float *mel_weights;
+  const float *dct;          // nceps x nbins
+  const float *lifter;       // nceps
+  const float *twiddle;      // padded/2 complex (cos, -sin) pairs for the complex FFT + untangle
+};
+// feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
+void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s);
+
+// ---------------------------------------------------------------- online CMVN (sliding window, causal)
+struct CmvnDev {
+  int dim, cmn_window, speaker_frames, global_frames;
+  const double *global_stats;   // 2 x (dim+1), row 0 used
+};
+// in/out: total_rows x ld, same layout.  Halo rows of `out` replicate its edge frames.
+void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s);
+
+// ---------------------------------------------------------------- generic segmented GEMM (FP32 MFMA)
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16;
+struct GemmSegDev {
+  const float *src;   // source buffer base (row 0 of the frame buffer), or iVector matrix if per_utt
+  int ld;             // leading dimension of the source
+  int col0;           // first source column
+  int ncols;          // valid K extent
+  int row_off;        // constant row offset (time offset)
+  int k0;             // first (padded) K index of this segment inside W
+  int per_utt;        // 1: row index = row_utt[row] (iVector input)
+};
+constexpr int kMaxSegs = 16;
+struct EltStageDev {
+  int kind;                 // 0 relu, 1 scale+offset, 4 scalar scale
+  const float *scale, *offset;
+  float alpha;
+};
+constexpr int kMaxStages = 6;
+struct GemmDev {
+  int nsegs;
+  GemmSegDev segs[kMaxSegs];
+  const float *W;     // n_pad x k_pad, row-major, zero padded (k_pad = sum of segment widths rounded to kGemmBK)
+  int k_pad, n, n_pad;
+  const float *bias;  // n (may be null)
+  int nstages;
+  EltStageDev stages[kMaxStages];
+  float *out;
+  int ldo;
+};
+void LaunchGemm(const GemmDev &d, int rows, const int *row_utt, hipStream_t s);
+
+struct SumTermDev { const float *src; int ld, col0, row_off; float scale; };
+struct EltwiseDev {
+  int nterms;
+  SumTermDev terms[8];
+  int nstages;
+  EltStageDev stages[kMaxStages];
+  int dim;
+  float *out;
+  int ldo;
+  int row_reduce;     // 0 none, 2 log-softmax, 3 normalize (alpha = target rms)
+  float alpha;
+};
+void LaunchEltwise(const EltwiseDev &d, int rows, hipStream_t s);
+// out[row][:] = (in[row][:] + neg_log_prior[:]) * scale  (decodable-online-looped.cc:218-223), in place
+void LaunchPriorScale(float *x, int ld, int rows, int dim, const float *log_priors, float scale, hipStream_t s);
+
+// ---------------------------------------------------------------- iVector
+struct IvecDev {
+  int feat_dim, ivec_dim, num_gauss, num_gselect, num_cg_iters;
+  float min_post, posterior_scale, max_count;
+  double prior_offset;
+  const float *gconsts;        // G
+  const float *means_invvars_t; // D x G (transposed for coalesced lane-per-Gaussian reads)
+  const float *inv_vars_t;      // D x G
+  const double *sigma_inv_M;    // G x D x I
+  const double *U;              // G x I(I+1)/2
+};
+// UBM posteriors per frame: post_idx/post_w: total_frames x num_gselect (idx -1 = unused)
+void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda_norm, int ld,
+                         int *post_idx, float *post_w, hipStream_t s);
+// Accumulates, per (utterance, Gaussian): gamma (n_utts x G) and weighted feature sums (n_utts x G x D),
+// in frame order (double), for frames [frame_begin[u], frame_end[u]) of each utterance (null = all).
+void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
+                          const float *post_w, const int *frame_begin, const int *frame_end,
+                          double *gamma, double *wfeats, hipStream_t s);
+// linear (n_utts x I) += sum_g Sigma_inv_M_g^T wfeats_g ; quadratic (n_utts x I(I+1)/2) += sum_g gamma_g U_g,
+// plus the max_count prior rescaling of OnlineIvectorEstimationStats::AccStats; num_frames (n_utts, double).
+void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const double *wfeats,
+                     double *linear, double *quadratic, double *num_frames, hipStream_t s);
+// Conjugate-gradient solve per utterance (LinearCgd, <= num_cg_iters), x in/out (double, n_utts x I);
+// ivec_out (float, n_utts x ldo) = x with prior_offset subtracted from element 0.
+void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,
+                     const double *num_frames, double *x, float *ivec_out, int ldo, hipStream_t s);
+
+// ---------------------------------------------------------------- decoder
+struct HclgDev {
+  int num_states, num_arcs, start;
+  const uint32_t *arc_begin;   // S + 1
+  const uint32_t *num_ieps;    // S
+  const int4 *arcs;            // {pdf+1 (0 = epsilon), olabel, weight bits, nextstate}
+  const int *arc_src;          // source state of each arc
+  const float *final_cost;     // S
+};
+struct DecodeOptsDev {
+  float beam, lattice_beam, beam_delta;
+  int max_active, min_active;
+};
+struct DecodeWork {
+  // per utterance
+  unsigned long long *best;   // n_utts x S : packed (ordered cost bits << 32 | arc), ~0 = empty
+  int *map_a, *map_b;         // n_utts x S : state -> token index (frame-local), -1 = none
+  int tok_cap;                // token capacity per utterance (all frames)
+  int4 *tokens;               // n_utts x tok_cap : {state, cost bits, backpointer (frame-local idx), arc (-1 start)}
+  int *frame_tok_off;         // n_utts x (max_frames + 2): start offset of each frame's tokens
+  float *frame_info;          // n_utts x (max_frames + 1) x 4 : {cost_offset, cur_cutoff, next_cutoff, adaptive_beam}
+  int *queue_a, *queue_b;     // n_utts x S work lists for the epsilon closure
+  int *in_queue;              // n_utts x S
+  // results
+  int *out_words;             // n_utts x max_words
+  int *out_nwords;            // n_utts
+  float *out_costs;           // n_utts x 4 : graph, acoustic, total, final-reached flag
+  long long *counters;        // n_utts x 8
+  int max_words;
+};
+void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                  const DecodeWork &w, hipStream_t s);
+
+// lattice extraction (backward pruning with lattice_beam), see decode.hip
+struct LatticeWork {
+  float *extra_cost;          // n_utts x tok_cap
+  int lat_cap;                // arc capacity per utterance
+  int4 *lat_arcs;             // n_utts x lat_cap : {src token (global idx), dst token (global idx), arc, frame}
+  float *lat_costs;           // n_utts x lat_cap x 2 : graph, acoustic (offset removed)
+  int *lat_narcs;             // n_utts
+  float *final_costs;         // n_utts x tok_cap? (only last frame used) -- stored in extra pass
+};
+void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                        const DecodeWork &w, const LatticeWork &lw, hipStream_t s);
+
+}  // namespace rs

@@ -1,0 +1,73 @@
+"""Parity-test case table shared by the GPU parity tests, the CPU oracle tests and oracle/gen_golden.py.
+
+A case = (synthetic model spec, graph kind, audio source, decoder options).  Model / graph files are
+regenerated from seeds with rhasspy_speech_amd.synth wherever the case is used; expected outputs of the
+reference for each case live in tests/golden/<case>.npz (written by oracle/gen_golden.py in the build container).
+"""
+from __future__ import annotations
+
+import wave
+from pathlib import Path
+
+import numpy as np
+
+from rhasspy_speech_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+CASES = {
+    # name: dict(spec=kwargs for tiny_spec/ModelSpec, big=bool, graph=..., audio=..., decoder opts, nbest)
+    "tiny_u0": dict(spec=dict(), graph="grammar", audio="synth:0:48000"),
+    "tiny_u3_short": dict(spec=dict(), graph="grammar", audio="synth:3:9000"),
+    "tiny_real_hot": dict(spec=dict(), graph="grammar", audio="wav:how_hot_is_it.wav"),
+    "tiny_real_time": dict(spec=dict(seed=5), graph="grammar", audio="wav:what_time_is_it.wav"),
+    "tiny_text_u1": dict(spec=dict(binary=False), graph="grammar", audio="synth:1:40000"),
+    "tiny_noiv_u2": dict(spec=dict(ivector_dim=0), graph="grammar", audio="synth:2:48000"),
+    "tiny_cmvn_u4": dict(spec=dict(nnet_cmvn=True), graph="grammar", audio="synth:4:48000"),
+    "tinyf_u5": dict(spec=dict(tdnnf=True, with_priors=True, with_log_softmax=True,
+                               layer_offsets=((0,), (-1, 0, 1), (-1, 0, 1), (-3, 0, 3))), graph="grammar", audio="synth:5:48000"),
+    "tiny_hmm_u6": dict(spec=dict(chain_topology=False, seed=3), graph="grammar", audio="synth:6:32000"),
+    "tiny_arpa_u7": dict(spec=dict(num_phones=40), graph="arpa:60:200", audio="synth:7:48000"),
+    "tiny_arpa_prune_u8": dict(spec=dict(num_phones=40), graph="arpa:300:1500", audio="synth:8:48000",
+                               opts=dict(max_active=60, min_active=20, beam=12.0)),
+    "tiny_vecfst_u9": dict(spec=dict(), graph="grammar:vector", audio="synth:9:30000"),
+    "zam_u0": dict(big=True, spec=dict(), graph="grammar", audio="synth:0:48000"),
+    "zam_u1": dict(big=True, spec=dict(), graph="grammar", audio="synth:1:48000"),
+    "zam_real_cold": dict(big=True, spec=dict(), graph="grammar", audio="wav:how_cold_is_it.wav"),
+}
+NBEST = 5
+
+
+def case_spec(case: dict) -> synth.ModelSpec:
+    return synth.ModelSpec(**case["spec"]) if case.get("big") else synth.tiny_spec(**case["spec"])
+
+
+def case_audio(case: dict, golden_dir: Path = GOLDEN) -> np.ndarray:
+    kind, *rest = case["audio"].split(":")
+    if kind == "synth":
+        return synth.synth_utterance(int(rest[0]), int(rest[1]))
+    with wave.open(str(golden_dir / "wav" / rest[0]), "rb") as w:
+        assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()
+
+
+def build_case_files(case: dict, root: Path, golden_dir: Path = GOLDEN):
+    """Writes model + graph + wav for a case under `root`; returns (model_dir, graph_dir, wav_path, pcm)."""
+    spec = case_spec(case)
+    model_dir, graph_dir = root / "model", root / "graph"
+    synth.write_model_dir(model_dir, spec)
+    g = case["graph"].split(":")
+    if g[0] == "grammar":
+        rng = np.random.default_rng(11)
+        sents = [s.split() for s in synth.DEFAULT_SENTENCES]
+        lex = synth.make_lexicon(sents, spec, rng)
+        fst = synth.make_grammar_hclg(sents, lex, spec, rng)
+        synth.write_graph_dir(graph_dir, fst, lex, const=(len(g) < 2 or g[1] != "vector"))
+    else:
+        synth.make_arpa_graph(graph_dir, spec, extra_words=int(g[1]), num_random_sentences=int(g[2]))
+    pcm = case_audio(case, golden_dir)
+    wav = root / "utt.wav"
+    synth.write_wav(wav, pcm)
+    return model_dir, graph_dir, wav, pcm
+
+

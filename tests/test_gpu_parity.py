@@ -1,0 +1,84 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors.
+
+Tolerances: transcripts (word-id sequences) exact; acoustic log-likelihoods 1e-4 absolute (north-star); MFCC
+features 2e-3 absolute on values up to ~1e2 (different FFT factorisation, float32); iVectors 1e-4.
+"""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+LOGLIKE_TOL = 1e-4
+FEAT_TOL = 2e-3
+IVEC_TOL = 1e-4
+
+
+def load_golden(name):
+    return np.load(cases.GOLDEN / f"{name}.npz")
+
+
+def parse_nbest(text: bytes):
+    out = []
+    for line in text.decode().splitlines():
+        p = line.split()
+        if p:
+            out.append([int(x) for x in p[1:]])
+    return out
+
+
+def make_model(case_cache, name, **extra):
+    from rhasspy_speech_amd import _lib
+    model_dir, graph_dir, wav, pcm = case_cache(name)
+    o = dict(keep_intermediates=1)
+    o.update(cases.CASES[name].get("opts", {}))
+    o.update(extra)
+    return _lib.Model(model_dir, graph_dir, _lib.default_opts(**o)), pcm
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_offline_case(case_cache, name):
+    g = load_golden(name)
+    model, pcm = make_model(case_cache, name)
+    res = model.decode_batch([pcm], nbest=1)
+    assert res.num_frames(0) == int(g["offline_num_frames"])
+    feats = res.matrix(0, 0)
+    assert feats.shape == g["input"].shape
+    assert np.abs(feats - g["input"]).max() < FEAT_TOL
+    if "offline_ivector" in g:
+        iv = res.matrix(0, 1)
+        assert np.abs(iv - g["offline_ivector"]).max() < IVEC_TOL
+    ll = res.matrix(0, 2)
+    sr, sc = g["loglikes_stride"]
+    diff = np.abs(ll[::sr, ::sc] - g["offline_loglikes"]).max()
+    assert diff < LOGLIKE_TOL, f"log-likelihood max abs diff {diff}"
+    ref = parse_nbest(bytes(g["offline_nbest_text"]))
+    assert res.words(0, 0) == ref[0]
+    gc, ac = res.costs(0, 0)
+    assert abs(gc - g["offline_graph_cost"][0]) < 2e-3 * max(1.0, abs(gc))
+    assert abs(ac - g["offline_acoustic_cost"][0]) < 2e-3 * max(1.0, abs(ac))
+    assert res.text(0).split(b"\n")[0].split() == bytes(g["offline_nbest_text"]).split(b"\n")[0].split()
+
+
+def test_batch_matches_single(case_cache):
+    """Ragged batch: every utterance decodes exactly as it does alone (no cross-utterance leakage)."""
+    from rhasspy_speech_amd import synth
+    model, _ = make_model(case_cache, "tiny_u0")
+    pcms = [synth.synth_utterance(20 + i, n) for i, n in enumerate([48000, 16000, 30000, 8000, 48000, 400, 24001])]
+    batch = model.decode_batch(pcms)
+    for i, p in enumerate(pcms):
+        single = model.decode_batch([p])
+        assert batch.words(i) == single.words(0)
+        assert np.array_equal(batch.matrix(i, 2), single.matrix(0, 2))
+        assert batch.costs(i) == single.costs(0)
+
+
+def test_too_short_utterance_fails_like_reference(case_cache):
+    from rhasspy_speech_amd import _lib
+    model, _ = make_model(case_cache, "tiny_u0")
+    res = model.decode_batch([np.zeros(300, np.int16), np.zeros(0, np.int16)])
+    for u in range(2):
+        with pytest.raises(_lib.RsError) as ei:
+            res.words(u)
+        assert "decoded no frames" in str(ei.value)
