@@ -37,6 +37,7 @@ class KaldiReader {
   bool binary() const { return binary_; }
   const std::string &name() const { return name_; }
   bool AtEnd();
+  bool RawEof() const { return pos_ >= buf_.size(); }   // no whitespace skipping
 
   // Tokens are ASCII runs terminated by whitespace (base/io-funcs.cc:134-168).
   std::string ReadToken();

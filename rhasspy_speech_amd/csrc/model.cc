@@ -675,7 +675,7 @@ void Nnet::Read(KaldiReader &r) {
   if (!line.empty() && line.find_first_not_of(" \t") != std::string::npos) Fail("Expected newline in config file, got " + line);
   std::vector<std::string> cfg;
   while (true) {
-    if (r.AtEnd()) Fail(r.name() + ": EOF inside <Nnet3> config section");
+    if (r.RawEof()) Fail(r.name() + ": EOF inside <Nnet3> config section");
     line = r.ReadLine();
     if (line.empty()) break;
     cfg.push_back(line);
