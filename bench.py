@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds decoded per wall-second (RTF^-1) of the transcribe hot path.
+
+Workload at N=1 = BASELINE.json configs[1]: "en_US-zamia grammar HCLG, batch of 256 synthetic 3 s utterances on 1
+MI355X".  No real zamia model exists offline, so the model is the synthetic "zamia-like-S" of SURVEY.md section
+8(d) written in genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iVector with a
+512-Gaussian UBM, 7x250 TDNN + prefinal, 2000 pdfs) and a grammar HCLG; audio is synthetic (seeded).  A "step" is
+one pass of the whole path (MFCC -> iVector -> TDNN -> beam search -> word ids) over the 256-utterance batch,
+with the int16 samples already resident in HBM when the timed region starts.
+
+Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`):
+utterances shard embarrassingly, one process per GPU, each rank decodes its own 256-utterance batch (weak
+scaling, no data-path collective); fixed-size result records are gathered over RCCL (all_gather) after the
+timed region's compute, inside the timed region.
+
+Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_UTTS = 256
+N_SAMPLES = 48000          # 3 s @ 16 kHz
+MAX_WORDS = 62             # result record: 64 x int32 = [n_words, words..., pad] + 2 floats
+
+
+def build_workload(root: Path, n_utts: int, rank: int):
+    from rhasspy_speech_amd import synth
+    spec = synth.ModelSpec()
+    model_dir, graph_dir = root / "model", root / "graph"
+    if not (graph_dir / "HCLG.fst").exists():
+        synth.write_model_dir(model_dir, spec)
+        synth.make_grammar_graph(graph_dir, spec)
+    pcm = np.stack([synth.synth_utterance(rank * 100000 + u, N_SAMPLES) for u in range(n_utts)])
+    return spec, model_dir, graph_dir, pcm
+
+
+def nnet_flops_per_row(desc: str) -> float:
+    """2 * K * N summed over the GEMM ops listed by rs_model_describe (algorithmic FLOPs per frame row)."""
+    fl = 0.0
+    for line in desc.splitlines():
+        if line.startswith("op: gemm"):
+            parts = dict(p.split("=") for p in line.split() if "=" in p)
+            fl += 2.0 * float(parts["k"]) * float(parts["out_dim"])
+    return fl
+
+
+def cpu_baseline(model_dir: Path, graph_dir: Path, pcm: np.ndarray, seconds_budget: float = 20.0):
+    """Times the REFERENCE itself (oracle/_ref Kaldi binaries built from /root/reference by oracle/build_ref.sh)
+    on this box's host cores on a bounded sample of the same workload: the 3-process pipeline of
+    transcribe_wav.py:45-75, one utterance per pipeline invocation, one pipeline at a time (1 core)."""
+    from rhasspy_speech_amd import synth
+    bin_dir = ROOT / "oracle" / "_ref" / "bin"
+    exe = bin_dir / "online2-wav-nnet3-latgen-faster"
+    if not exe.exists():
+        return None
+    env = dict(os.environ, PATH=f"{bin_dir}:{os.environ['PATH']}")
+    conf = model_dir / "model" / "online" / "conf" / "online.conf"
+    n_done, audio, t0 = 0, 0.0, time.perf_counter()
+    with tempfile.TemporaryDirectory() as td:
+        while n_done < pcm.shape[0] and (time.perf_counter() - t0) < seconds_budget and n_done < 64:
+            wav = Path(td) / "u.wav"
+            synth.write_wav(wav, pcm[n_done])
+            cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false "
+                   f"--word-symbol-table={graph_dir}/words.txt --config={conf} --max-active=7000 --lattice-beam=8.0 "
+                   f"--acoustic-scale=1.0 --beam=24.0 {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst "
+                   f"'ark:echo utt utt|' 'scp:echo utt {wav}|' ark:- | lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | "
+                   f"nbest-to-linear ark:- ark:/dev/null ark,t:-")
+            r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                return None
+            n_done += 1
+            audio += pcm.shape[1] / 16000.0
+    wall = time.perf_counter() - t0
+    return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference",
+            "sample": f"{n_done} of the {pcm.shape[0]} utterances, one transcribe_wav.py-style 3-process pipeline per "
+                      f"utterance (model + HCLG re-loaded every call, as the reference does)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=N_UTTS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+
+    from rhasspy_speech_amd import _lib
+    cache = Path(tempfile.gettempdir()) / f"rs_bench_zamia_like_S_rank{rank}"
+    spec, model_dir, graph_dir, pcm = build_workload(cache, args.utts, rank)
+    model = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank))
+    model.to_device()
+    desc = model.describe()
+    d_pcm = torch.from_numpy(pcm.reshape(-1)).to(f"cuda:{local_rank}")
+    offsets = np.arange(args.utts + 1, dtype=np.int64) * N_SAMPLES
+    audio_seconds = args.utts * N_SAMPLES / 16000.0
+
+    def step():
+        res = model.decode_batch_device(d_pcm.data_ptr(), offsets)
+        rec = np.zeros((args.utts, 66), np.int32)
+        for u in range(args.utts):
+            w = res.words(u)[:MAX_WORDS]
+            rec[u, 0] = len(w)
+            rec[u, 1:1 + len(w)] = w
+            g, a = res.costs(u)
+            rec[u, 64:66] = np.array([g, a], np.float32).view(np.int32)
+        if world > 1:
+            t = torch.from_numpy(rec).to(f"cuda:{local_rank}")
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)       # the path's one exchange step: fixed-size result records over RCCL/xGMI
+            rec = torch.cat(out).cpu().numpy()
+        return res, rec
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage = np.zeros(8)
+    counters = np.zeros(8)
+    for _ in range(args.steps):
+        res, rec = step()
+        stage += np.array(res.timings())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage /= args.steps
+    for u in range(args.utts):
+        counters += np.array(res.counters(u), dtype=np.float64)
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        value = world * audio_seconds * args.steps / elapsed
+        rows = args.utts * (298 + 30)
+        flops = nnet_flops_per_row(desc) * rows
+        n_gemm = sum(1 for l in desc.splitlines() if l.startswith("op: gemm"))
+        # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token
+        # insertions x 16 B (8 B table key read-modify-write twice), tokens alive x 16 B token record
+        dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
+        roof_mfma = {"bound": "mfma", "achieved": flops / (stage[3] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": flops / (stage[3] * 1e-3) / 1e12 / 157.3, "traffic": None,
+                     "kernel": f"GemmKernel x{n_gemm} launches (whole nnet stage)", "stage_ms": float(stage[3])}
+        roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                    "kernel": "DecodeKernel (1 launch)", "stage_ms": float(stage[4])}
+        roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
+        out = {
+            "metric": "audio-seconds decoded/sec (RTF^-1) en_US-zamia grammar HCLG", "value": value, "unit": "audio-seconds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"zamia-like-S synthetic Kaldi model (40-dim MFCC, 100-dim iVector, 7x250 TDNN, 2000 pdfs), "
+                                   f"grammar HCLG, {args.utts} x 3 s utterances per GPU, beam 24 / max-active 7000 / lattice-beam 8",
+                       "utts_per_gpu": args.utts, "seconds_per_utt": 3.0, "parallelism": f"utterance-sharded x{world}"},
+            "roofline": roofline,
+            "stages_ms": {"mfcc": float(stage[1]), "ivector": float(stage[2]), "nnet": float(stage[3]), "decode": float(stage[4]),
+                          "d2h+host": float(stage[5]), "total_call": float(stage[6])},
+            "other_roofline": roof_dec if roofline is roof_mfma else roof_mfma,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model_dir, graph_dir, pcm)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

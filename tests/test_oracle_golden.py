@@ -1,0 +1,62 @@
+"""CPU tests that PIN the oracle: every stage of oracle/pipeline.py against vectors produced by the reference's
+own binaries (tests/golden/*.npz, see oracle/gen_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+FAST = ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tiny_real_time", "tiny_text_u1", "tiny_noiv_u2", "tiny_cmvn_u4", "tinyf_u5",
+        "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold"]
+
+
+def parse_nbest(text: bytes):
+    return [[int(x) for x in ln.split()[1:]] for ln in text.decode().splitlines() if ln.split()]
+
+
+@pytest.fixture(scope="module")
+def oracles(case_cache):
+    from oracle import pipeline
+    built = {}
+
+    def get(name):
+        if name not in built:
+            model_dir, graph_dir, wav, pcm = case_cache(name)
+            o = cases.CASES[name].get("opts", {})
+            built[name] = (pipeline.Oracle(model_dir, graph_dir, **o), pcm)
+        return built[name]
+
+    return get
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_oracle_matches_reference(oracles, name):
+    g = np.load(cases.GOLDEN / f"{name}.npz")
+    orc, pcm = oracles(name)
+    tr = orc.transcribe(pcm, nbest=cases.NBEST)
+    assert tr.num_frames == int(g["offline_num_frames"])
+    fd = np.abs(tr.feats - g["input"])
+    assert fd.max() < 5e-3 and np.quantile(fd, 0.99) < 1e-3
+    if "offline_ivector" in g:
+        assert np.abs(tr.ivector - g["offline_ivector"][0]).max() < 1e-4
+    sr, sc = g["loglikes_stride"]
+    assert np.abs(tr.loglikes[::sr, ::sc] - g["offline_loglikes"]).max() < 1e-4
+    ref = parse_nbest(bytes(g["offline_nbest_text"]))
+    got = [p.words for p in tr.nbest]
+    assert got == ref, (got, ref)
+    np.testing.assert_allclose([p.graph_cost for p in tr.nbest], g["offline_graph_cost"], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose([p.acoustic_cost for p in tr.nbest], g["offline_acoustic_cost"], rtol=2e-4, atol=2e-3)
+    assert tr.text().split() == bytes(g["offline_nbest_text"]).split()
+
+
+def test_oracle_intermediate_ivector_features(oracles):
+    """CMVN / splice+LDA streams of the iVector branch against the reference classes' own output."""
+    from oracle import pipeline
+    g = np.load(cases.GOLDEN / "tiny_u0.npz")
+    orc, pcm = oracles("tiny_u0")
+    feats = orc.features(pcm)
+    cm = pipeline.online_cmvn(feats, orc.ie["gstats"])
+    assert np.abs(cm - g["cmvn"]).max() < 5e-3
+    raw = pipeline.lda_transform(pipeline.splice(feats, orc.ie["left"], orc.ie["right"]), orc.ie["lda"])
+    nrm = pipeline.lda_transform(pipeline.splice(cm, orc.ie["left"], orc.ie["right"]), orc.ie["lda"])
+    assert np.abs(raw - g["lda"]).max() < 1e-3
+    assert np.abs(nrm - g["lda_norm"]).max() < 1e-3
