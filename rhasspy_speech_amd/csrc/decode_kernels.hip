@@ -415,7 +415,186 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       for (int i = 0; i < 8; i++) ctr[i] = (long long)c.counters[i];
       frame_off[T + 1] = off_next;
     }
+    // leave both state->token maps empty (the lattice pass rebuilds them frame by frame)
+    for (int i = tid; i < n_cur; i += NT) map_cur[cur[i].x] = -1;
   }
+}
+
+// ===================================================================================== lattice extraction
+// Backward pass = FinalizeDecoding: PruneForwardLinksFinal on the last frame, PruneForwardLinks(delta = 0) on
+// every earlier frame (lattice-faster-decoder.cc:376-458,299-370,625-640).  Forward links are not stored by
+// the search kernel; they are re-derived here from the token lists with the same float expressions and the
+// same existence rules (emitting link: source cost <= cur_cutoff and tot < next_cutoff; epsilon link: source
+// cost < closure cutoff and tot < closure cutoff), so link costs are bit-identical to the search's.
+// extra_cost is the exact fixpoint the reference's "while (changed)" loops converge to.
+template <int NT>
+__global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
+                                                    const float *__restrict__ loglikes, int ld, DecodeWork w, LatticeWork lw) {
+  __shared__ BlockCtx<NT> c;
+  __shared__ int s_changed;
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int T = g.d_num_frames[u];
+  if (T <= 0 || w.out_nwords[u] < 0) return;
+  const int S = h.num_states;
+  int *map_cur = w.map_a + (size_t)u * S, *map_nxt = w.map_b + (size_t)u * S;
+  const int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
+  const int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  const float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
+  float *extra = lw.extra_cost + (size_t)u * w.tok_cap;
+  const float INF = INFINITY, beam = o.lattice_beam;
+  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
+
+  // ---- final costs on the last frame (ComputeFinalCosts)
+  float final_best;
+  bool have_final;
+  {
+    const int4 *cur = tokens + frame_off[T];
+    const int n = frame_off[T + 1] - frame_off[T];
+    float lv1 = INF, lv2 = INF;
+    for (int i = tid; i < n; i += NT) {
+      const float cst = __int_as_float(cur[i].y);
+      lv1 = fminf(lv1, cst + h.final_cost[cur[i].x]);
+      lv2 = fminf(lv2, cst);
+    }
+    float b1, b2;
+    int d1, d2;
+    BlockMinArg<NT>(c, lv1, tid, &b1, &d1);
+    BlockMinArg<NT>(c, lv2, tid, &b2, &d2);
+    have_final = b1 < INF;
+    final_best = have_final ? b1 : b2;
+  }
+  for (int f = T; f >= 0; f--) {
+    const int off = frame_off[f], n = frame_off[f + 1] - off;
+    const int off_n = frame_off[f + 1];
+    const int4 *cur = tokens + off;
+    const int4 *nxt = tokens + off_n;
+    for (int i = tid; i < n; i += NT) map_cur[cur[i].x] = i;
+    __syncthreads();
+    const float cost_offset = f < T ? finfo[f * 4 + 0] : 0.f, cur_cutoff = f < T ? finfo[f * 4 + 1] : 0.f,
+                next_cutoff = f < T ? finfo[f * 4 + 2] : 0.f;
+    const float closure_cutoff = f > 0 ? finfo[(f - 1) * 4 + 2] : o.beam;
+    const float *ll_row = loglikes + (ll_base + (f < T ? f : 0)) * ld;
+    // ---- pass 1: the part of extra_cost that does not depend on this frame's other tokens
+    for (int i = tid; i < n; i += NT) {
+      const int4 tk = cur[i];
+      const float cost = __int_as_float(tk.y);
+      float e = INF;
+      if (f == T) e = cost + (have_final ? h.final_cost[tk.x] : 0.f) - final_best;
+      else if (cost <= cur_cutoff) {
+        const unsigned a0 = h.arc_begin[tk.x] + h.num_ieps[tk.x], a1 = h.arc_begin[tk.x + 1];
+        for (unsigned a = a0; a < a1; a++) {
+          const int4 arc = h.arcs[a];
+          const float ac = cost_offset - ll_row[arc.x - 1];
+          const float tot = (cost + ac) + __int_as_float(arc.z);
+          if (!(tot < next_cutoff)) continue;
+          const int j = map_nxt[arc.w];
+          if (j < 0) continue;
+          float le = extra[off_n + j] + (tot - __int_as_float(nxt[j].y));
+          if (le > beam) continue;
+          if (le < 0.f) le = 0.f;
+          e = fminf(e, le);
+        }
+      }
+      extra[off + i] = e;
+    }
+    __syncthreads();
+    // ---- pass 2: epsilon links inside the frame, to the fixpoint
+    for (int round = 0; round < 1000; round++) {
+      if (tid == 0) s_changed = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += NT) {
+        const int4 tk = cur[i];
+        if (h.num_ieps[tk.x] == 0) continue;
+        const float cost = __int_as_float(tk.y);
+        if (cost >= closure_cutoff) continue;
+        float e = extra[off + i];
+        const float e0 = e;
+        const unsigned a0 = h.arc_begin[tk.x], a1 = a0 + h.num_ieps[tk.x];
+        for (unsigned a = a0; a < a1; a++) {
+          const int4 arc = h.arcs[a];
+          const float tot = cost + __int_as_float(arc.z);
+          if (!(tot < closure_cutoff)) continue;
+          const int j = map_cur[arc.w];
+          if (j < 0) continue;
+          float le = __hip_atomic_load(&extra[off + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (tot - __int_as_float(cur[j].y));
+          if (le > beam) continue;
+          if (le < 0.f) le = 0.f;
+          e = fminf(e, le);
+        }
+        if (e < e0) { __hip_atomic_store(&extra[off + i], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); s_changed = 1; }
+      }
+      __syncthreads();
+      const int ch = s_changed;
+      __syncthreads();
+      if (!ch) break;
+    }
+    if (f == T) {
+      for (int i = tid; i < n; i += NT) if (extra[off + i] > beam) extra[off + i] = INF;
+      __syncthreads();
+    }
+    // ---- pass 3: emit surviving links (and the final-cost records of the last frame)
+    for (int i = tid; i < n; i += NT) {
+      const int4 tk = cur[i];
+      const float cost = __int_as_float(tk.y);
+      if (!(extra[off + i] < INF)) continue;
+      if (f == T) {
+        const float fc = have_final ? h.final_cost[tk.x] : 0.f;
+        if (fc < INF) {
+          const int k = atomicAdd(lw.arcs_count, 1);
+          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, -1, -1, fc, 0.f};
+        }
+      } else if (cost <= cur_cutoff) {
+        const unsigned a0 = h.arc_begin[tk.x] + h.num_ieps[tk.x], a1 = h.arc_begin[tk.x + 1];
+        for (unsigned a = a0; a < a1; a++) {
+          const int4 arc = h.arcs[a];
+          const float ac = cost_offset - ll_row[arc.x - 1];
+          const float gc = __int_as_float(arc.z);
+          const float tot = (cost + ac) + gc;
+          if (!(tot < next_cutoff)) continue;
+          const int j = map_nxt[arc.w];
+          if (j < 0) continue;
+          const float le = extra[off_n + j] + (tot - __int_as_float(nxt[j].y));
+          if (le > beam) continue;
+          const int k = atomicAdd(lw.arcs_count, 1);
+          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, off_n + j, (int)a, gc, ac - cost_offset};
+        }
+      }
+      if (h.num_ieps[tk.x] != 0 && cost < closure_cutoff) {
+        const unsigned a0 = h.arc_begin[tk.x], a1 = a0 + h.num_ieps[tk.x];
+        for (unsigned a = a0; a < a1; a++) {
+          const int4 arc = h.arcs[a];
+          const float gc = __int_as_float(arc.z);
+          const float tot = cost + gc;
+          if (!(tot < closure_cutoff)) continue;
+          const int j = map_cur[arc.w];
+          if (j < 0) continue;
+          const float le = extra[off + j] + (tot - __int_as_float(cur[j].y));
+          if (le > beam) continue;
+          const int k = atomicAdd(lw.arcs_count, 1);
+          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, off + j, (int)a, gc, 0.f};
+        }
+      }
+    }
+    __syncthreads();
+    // retire frame f+1's map, keep frame f's as "next"
+    if (f < T) {
+      const int n_nxt = frame_off[f + 2] - off_n;
+      for (int i = tid; i < n_nxt; i += NT) map_nxt[nxt[i].x] = -1;
+    }
+    __syncthreads();
+    int *tmp = map_cur; map_cur = map_nxt; map_nxt = tmp;
+  }
+  // clear the last map (frame 0)
+  {
+    const int n = frame_off[1] - frame_off[0];
+    for (int i = tid; i < n; i += NT) map_nxt[tokens[frame_off[0] + i].x] = -1;
+  }
+}
+
+void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                        const DecodeWork &w, const LatticeWork &lw, hipStream_t s) {
+  if (g.n_utts == 0) return;
+  hipLaunchKernelGGL(LatticeKernel<256>, dim3(g.n_utts), dim3(256), 0, s, h, o, g, loglikes, ld, w, lw);
 }
 
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,

@@ -1,10 +1,13 @@
 #include "engine.h"
+#include "lattice.h"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <sstream>
+#include <unordered_map>
 
 namespace rs {
 
@@ -327,7 +330,6 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
 
 std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
                                                  float lat_scale, hipStream_t user_stream) {
-  (void)lat_scale;
   ToDevice();
   std::lock_guard<std::mutex> lk(mu_);
   RS_HIP(hipSetDevice(opts_.device_id));
@@ -575,6 +577,74 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     hy.graph_cost = h_costs[(size_t)u * 4 + 0];
     hy.acoustic_cost = h_costs[(size_t)u * 4 + 1];
     ur.hyps.push_back(std::move(hy));
+  }
+  // ---- n-best through the lattice (the reference's determinise | lattice-to-nbest | nbest-to-linear tail)
+  if (nbest > 1 || lat_scale != 1.0f) {
+    auto t_l0 = std::chrono::steady_clock::now();
+    LatticeWork lw;
+    std::memset(&lw, 0, sizeof(lw));
+    const size_t extra_bytes = sizeof(float) * (size_t)n_utts * tok_cap + 256;
+    size_t cap = 1u << 20;
+    std::vector<LatArc> h_arcs;
+    for (int attempt = 0; attempt < 8; attempt++) {
+      float *d_extra = nullptr;
+      LatArc *d_arcs = nullptr;
+      int *d_count = nullptr;
+      RS_HIP(hipMalloc((void **)&d_extra, extra_bytes));
+      RS_HIP(hipMalloc((void **)&d_arcs, sizeof(LatArc) * cap));
+      RS_HIP(hipMalloc((void **)&d_count, sizeof(int)));
+      RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
+      lw.extra_cost = d_extra; lw.arcs = d_arcs; lw.arcs_cap = (int)cap; lw.arcs_count = d_count;
+      LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
+      int count = 0;
+      RS_HIP(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      RS_HIP(hipStreamSynchronize(s));
+      bool ok = count <= (int)cap;
+      if (ok) {
+        h_arcs.resize(count);
+        if (count) RS_HIP(hipMemcpy(h_arcs.data(), d_arcs, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost));
+      }
+      (void)hipFree(d_extra); (void)hipFree(d_arcs); (void)hipFree(d_count);
+      if (ok) break;
+      cap = (size_t)count + (size_t)count / 4 + 1024;
+      if (attempt == 7) Fail("lattice extraction: arc buffer overflow");
+    }
+    // group by utterance
+    std::vector<std::vector<const LatArc *>> per(n_utts);
+    for (auto &a : h_arcs) if (a.utt >= 0 && a.utt < n_utts) per[a.utt].push_back(&a);
+    for (int u = 0; u < n_utts; u++) {
+      UttResult &ur = res->utts[u];
+      if (ur.status != RS_OK) continue;
+      RawLattice lat;
+      std::unordered_map<int, int> id;
+      auto sid = [&](int tok) {
+        auto it = id.find(tok);
+        if (it != id.end()) return it->second;
+        int k = (int)id.size();
+        id[tok] = k;
+        return k;
+      };
+      lat.start = sid(0);   // the start token is the first token of frame 0
+      for (const LatArc *a : per[u]) { sid(a->src); if (a->arc >= 0) sid(a->dst); }
+      lat.num_states = (int)id.size();
+      lat.final_cost.assign(lat.num_states, std::numeric_limits<double>::infinity());
+      for (const LatArc *a : per[u]) {
+        if (a->arc < 0) { lat.final_cost[id[a->src]] = a->graph; continue; }
+        lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic});
+      }
+      std::vector<NbestPath> paths = LatticeNbest(lat, nbest, opts_.lattice_beam, lat_scale);
+      ur.counters[4] = (int64_t)lat.arcs.size();
+      if (paths.empty()) continue;   // keep the traceback result (cannot happen for a consistent lattice)
+      ur.hyps.clear();
+      for (auto &p : paths) {
+        Hypothesis hy;
+        hy.words = p.words;
+        hy.graph_cost = (float)p.graph_cost;
+        hy.acoustic_cost = (float)p.acoustic_cost;
+        ur.hyps.push_back(std::move(hy));
+      }
+    }
+    res->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
   }
   if (opts_.keep_intermediates) {
     for (int u = 0; u < n_utts; u++) {

@@ -157,14 +157,15 @@ struct DecodeWork {
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                   const DecodeWork &w, hipStream_t s);
 
-// lattice extraction (backward pruning with lattice_beam), see decode.hip
+// Lattice extraction = FinalizeDecoding (lattice-faster-decoder.cc:625-640): backward pass over the stored
+// token lists that recomputes every forward link, derives the exact extra_cost of every token
+// (PruneForwardLinksFinal / PruneForwardLinks with delta = 0) and emits the links within lattice_beam.
+struct LatArc { int utt, src, dst, arc; float graph, acoustic; };   // arc = -1: final-cost record of token `src`
 struct LatticeWork {
   float *extra_cost;          // n_utts x tok_cap
-  int lat_cap;                // arc capacity per utterance
-  int4 *lat_arcs;             // n_utts x lat_cap : {src token (global idx), dst token (global idx), arc, frame}
-  float *lat_costs;           // n_utts x lat_cap x 2 : graph, acoustic (offset removed)
-  int *lat_narcs;             // n_utts
-  float *final_costs;         // n_utts x tok_cap? (only last frame used) -- stored in extra pass
+  LatArc *arcs;               // shared output buffer
+  int arcs_cap;
+  int *arcs_count;            // one global counter (may exceed arcs_cap: then the caller retries with a larger buffer)
 };
 void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                         const DecodeWork &w, const LatticeWork &lw, hipStream_t s);

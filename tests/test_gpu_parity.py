@@ -85,3 +85,39 @@ def test_too_short_utterance_fails_like_reference(case_cache):
         with pytest.raises(_lib.RsError) as ei:
             res.words(u)
         assert "decoded no frames" in str(ei.value)
+
+
+@pytest.mark.parametrize("name", [n for n in cases.CASES])
+def test_offline_nbest(case_cache, name):
+    """n-best lists (lattice-to-nbest --n=5 | nbest-to-linear) with their graph / acoustic costs."""
+    g = load_golden(name)
+    model, pcm = make_model(case_cache, name, keep_intermediates=0)
+    res = model.decode_batch([pcm], nbest=cases.NBEST)
+    ref = parse_nbest(bytes(g["offline_nbest_text"]))
+    got = [res.words(0, k) for k in range(res.num_hyps(0))]
+    assert got == ref, (got, ref)
+    gc = np.array([res.costs(0, k)[0] for k in range(len(got))])
+    ac = np.array([res.costs(0, k)[1] for k in range(len(got))])
+    np.testing.assert_allclose(gc, g["offline_graph_cost"], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(ac, g["offline_acoustic_cost"], rtol=2e-4, atol=2e-3)
+    assert res.text(0).split() == bytes(g["offline_nbest_text"]).split()
+    # the 1-best through the lattice equals the device traceback
+    one = model.decode_batch([pcm], nbest=1)
+    assert one.words(0) == got[0]
+
+
+def test_gpu_matches_oracle_on_fresh_inputs(case_cache):
+    """Seeded inputs that have no golden: HIP path vs the CPU oracle (oracle pinned by tests/test_oracle_golden.py)."""
+    from oracle import pipeline
+    from rhasspy_speech_amd import synth
+    model_dir, graph_dir, _, _ = case_cache("tiny_u0")
+    model, _ = make_model(case_cache, "tiny_u0")
+    orc = pipeline.Oracle(model_dir, graph_dir)
+    pcms = [synth.synth_utterance(100 + i, n) for i, n in enumerate([48000, 21000, 35000, 12345])]
+    res = model.decode_batch(pcms, nbest=3)
+    for i, p in enumerate(pcms):
+        tr = orc.transcribe(p, nbest=3)
+        assert np.abs(res.matrix(i, 2) - tr.loglikes).max() < LOGLIKE_TOL
+        assert [res.words(i, k) for k in range(res.num_hyps(i))] == [q.words for q in tr.nbest]
+        # decoder work counters: same number of frames' worth of live tokens as the sequential reference algorithm
+        assert res.counters(i)[3] > 0
