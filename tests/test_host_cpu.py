@@ -1,0 +1,141 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/rhasspy_speech_hip.h declares, host-side model
+parsing (no compute without a GPU), the Python layer against goldens captured from the reference's own Python,
+and the multi-rank sharding/gather logic over gloo."""
+import json
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from rhasspy_speech_amd import _lib
+    header = (ROOT / "include" / "rhasspy_speech_hip.h").read_text()
+    declared = set(re.findall(r"\b(rs_[a-z_]+)\s*\(", header))
+    lib = _lib.load_library()
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_default_opts_are_the_reference_flags():
+    from rhasspy_speech_amd import _lib
+    o = _lib.default_opts()
+    assert (o.beam, o.max_active, o.min_active, o.lattice_beam, o.beam_delta, o.acoustic_scale) == (24.0, 7000, 200, 8.0, 0.5, 1.0)
+    assert (o.frames_per_chunk, o.frame_subsampling_factor) == (24, 1)
+
+
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_text_u1", "tinyf_u5", "tiny_noiv_u2", "tiny_hmm_u6", "tiny_vecfst_u9", "tiny_arpa_u7"])
+def test_model_parsing_host_side(case_cache, name):
+    from rhasspy_speech_amd import _lib
+    model_dir, graph_dir, _, _ = case_cache(name)
+    m = _lib.Model(model_dir, graph_dir)
+    d = m.describe()
+    spec = cases.case_spec(cases.CASES[name])
+    assert f"output_dim={spec.num_pdfs}" in d and f"pdfs={spec.num_pdfs}" in d
+    assert f"ceps={spec.num_ceps}" in d
+    if spec.ivector_dim:
+        assert f"ivector: dim={spec.ivector_dim} gauss={spec.num_gauss}" in d
+    else:
+        assert "ivector: none" in d
+    # relu + batchnorm are fused into their affine layer's GEMM epilogue
+    assert "tdnn1.affine+tdnn1.relu+tdnn1.batchnorm" in d
+    # the xent branch of chain models is not on the path
+    assert "xent" not in d
+
+
+def test_text_and_binary_models_parse_identically(case_cache):
+    from rhasspy_speech_amd import _lib
+    a = _lib.Model(*case_cache("tiny_u0")[:2]).describe()
+    b = _lib.Model(*case_cache("tiny_text_u1")[:2]).describe()
+    assert a == b
+
+
+def test_no_gpu_means_loud_failure_not_fallback(case_cache):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rhasspy_speech_amd import _lib
+    m = _lib.Model(*case_cache("tiny_u0")[:2])
+    with pytest.raises(_lib.RsError) as ei:
+        m.decode_batch([np.zeros(16000, np.int16)])
+    assert ei.value.status == _lib.RS_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+
+
+def test_bad_model_files_fail_like_kaldi(tmp_path, case_cache):
+    from rhasspy_speech_amd import _lib
+    model_dir, graph_dir, _, _ = case_cache("tiny_u0")
+    with pytest.raises(_lib.RsError) as ei:
+        _lib.Model(tmp_path / "nope", graph_dir)
+    assert ei.value.status == _lib.RS_ERR_MODEL
+    bad = tmp_path / "HCLG.fst"
+    bad.write_bytes(b"not an fst at all")
+    with pytest.raises(_lib.RsError) as ei:
+        _lib.Model(final_mdl=model_dir / "model/model/final.mdl", hclg=bad, online_conf=model_dir / "model/online/conf/online.conf")
+    assert "Bad FST header" in str(ei.value)
+    conf = tmp_path / "online.conf"
+    conf.write_text("--feature-type=mfcc\n--no-such-option=1\n")
+    with pytest.raises(_lib.RsError) as ei:
+        _lib.Model(final_mdl=model_dir / "model/model/final.mdl", hclg=graph_dir / "HCLG.fst", online_conf=conf)
+    assert "Invalid option" in str(ei.value)
+
+
+def test_python_layer_matches_reference_python():
+    from rhasspy_speech_amd import meta
+    g = json.loads((cases.GOLDEN / "python_api.json").read_text())
+    words = {i: w for i, w in enumerate(g["words"])}
+    for c in g["cases"]:
+        got = meta.texts_from_int2sym(meta.int2sym(c["nbest_stdout"].encode(), words))
+        assert got == c["texts"], c
+    assert meta.encode_meta(g["encode_meta"]["input"]) == g["encode_meta"]["output"]
+    assert meta.decode_meta_single(g["encode_meta"]["output"].split(":", 1)[1]) == g["encode_meta"]["input"]
+
+
+def test_transcriber_signature_matches_reference():
+    import inspect
+    from rhasspy_speech_amd import KaldiNnet3WavTranscriber
+    sig = inspect.signature(KaldiNnet3WavTranscriber.__init__)
+    p = sig.parameters
+    assert [p[k].default for k in ("max_active", "lattice_beam", "acoustic_scale", "beam")] == [7000, 8.0, 1.0, 24.0]
+    sig = inspect.signature(KaldiNnet3WavTranscriber.async_transcribe)
+    assert list(sig.parameters)[1:] == ["wav_path", "lang_dir", "nbest", "max_fuzzy_cost", "require_fuzzy"]
+    assert inspect.iscoroutinefunction(KaldiNnet3WavTranscriber.async_transcribe)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from rhasspy_speech_amd import shard
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world, n = dist.get_rank(), dist.get_world_size(), 11
+idx = shard.shard_indices(n, rank, world)
+words = [[i, i + 1, 7 * i % 13] [: 1 + i % 3] for i in idx]          # stand-in for the decoder's output
+costs = [(float(i) + 0.5, -float(i) * 2.0) for i in idx]
+got = shard.gather_records(shard.pack_records(idx, words, costs), n)
+assert sorted(got) == list(range(n)), got
+for i in range(n):
+    assert got[i] == ([i, i + 1, 7 * i % 13][: 1 + i % 3], float(i) + 0.5, -float(i) * 2.0), (i, got[i])
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_sharded_gather_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(ROOT)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()[-2000:]
+        assert b"ok" in out
