@@ -82,7 +82,8 @@ __device__ __forceinline__ void BlockMinArg(BlockCtx<NT> &c, float v, int idx, f
 }
 
 // k-th smallest (0-based) cost of toks[0..n): exact radix select on the order-preserving bit pattern
-// (the value std::nth_element leaves at position k, lattice-faster-decoder.cc:679-695).
+// (the value std::nth_element leaves at position k, lattice-faster-decoder.cc:679-695).  The 256-bin prefix
+// scan of each pass is done by one wavefront with shuffles (4 bins per lane).
 template <int NT>
 __device__ float BlockKthSmallest(BlockCtx<NT> &c, const int4 *toks, int n, int k) {
   unsigned prefix = 0, mask = 0;
@@ -96,22 +97,27 @@ __device__ float BlockKthSmallest(BlockCtx<NT> &c, const int4 *toks, int n, int 
       if ((uu & mask) == prefix) atomicAdd(&c.hist[(uu >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0, b = 0;
-      for (; b < 255; b++) {
-        int hh = (int)c.hist[b];
-        if (acc + hh > kk) break;
-        acc += hh;
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const int h0 = (int)c.hist[4 * l], h1 = (int)c.hist[4 * l + 1], h2 = (int)c.hist[4 * l + 2], h3 = (int)c.hist[4 * l + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+      const int exc = inc - tot;
+      if (exc <= kk && kk < inc) {
+        int acc = exc, b = 4 * l;
+        if (acc + h0 <= kk) { acc += h0; b++; if (acc + h1 <= kk) { acc += h1; b++; if (acc + h2 <= kk) { acc += h2; b++; } } }
+        c.bcast_i[1] = b;
+        c.bcast_i[2] = kk - acc;
       }
-      c.bcast_i[1] = b;
-      c.bcast_i[2] = kk - acc;
     }
     __syncthreads();
     prefix |= ((unsigned)c.bcast_i[1]) << shift;
     mask |= 255u << shift;
     kk = c.bcast_i[2];
-    __syncthreads();
   }
+  __syncthreads();
   return FromOrdered(prefix);
 }
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <sstream>
@@ -50,6 +51,7 @@ static int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
 Model::Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf,
              const rs_decode_opts &opts)
     : opts_(opts) {
+  if (const char *e = std::getenv("RS_FORCE_SPARSE_DECODER")) force_sparse_ = e[0] == '1';
   if (opts_.frame_subsampling_factor != 1)
     Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
   if (opts_.frames_per_chunk <= 0) Fail("frames-per-chunk must be positive");
@@ -244,6 +246,31 @@ void Model::ToDevice() {
     hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
     hclg_dev_.arc_src = Upload(src);
     hclg_dev_.final_cost = Upload(hclg_.final_cost);
+    // reverse graph for the dense (pull) decoder: in-arcs per destination state, in forward-arc order
+    dense_ok_ = DenseDecodeFits(hclg_.num_states(), am_.nnet.output_dim);
+    if (dense_ok_) {
+      const int S = hclg_.num_states();
+      std::vector<uint32_t> be(S + 1, 0), bx(S + 1, 0);
+      for (size_t a = 0; a < A; a++) (hclg_.arcs[a].ilabel == 0 ? bx : be)[hclg_.arcs[a].nextstate + 1]++;
+      for (int st = 0; st < S; st++) { be[st + 1] += be[st]; bx[st + 1] += bx[st]; }
+      std::vector<int4> ie(be[S]), ix(bx[S]);
+      std::vector<uint32_t> fe(be.begin(), be.end() - 1), fx(bx.begin(), bx.end() - 1);
+      for (size_t a = 0; a < A; a++) {
+        const int4 &fa = arcs[a];
+        int4 rec = make_int4(src[a], fa.x, fa.z, (int)a);
+        if (fa.x == 0) ix[fx[fa.w]++] = rec; else ie[fe[fa.w]++] = rec;
+      }
+      std::vector<int> eps_dst;
+      for (int st = 0; st < S; st++) if (bx[st + 1] > bx[st]) eps_dst.push_back(st);
+      rev_dev_.in_begin_e = Upload(be);
+      rev_dev_.in_begin_x = Upload(bx);
+      rev_dev_.in_e = static_cast<int4 *>(UploadBytes(ie.data(), ie.size() * sizeof(int4)));
+      rev_dev_.in_x = static_cast<int4 *>(UploadBytes(ix.data(), ix.size() * sizeof(int4)));
+      rev_dev_.eps_dst = Upload(eps_dst);
+      rev_dev_.num_eps_dst = (int)eps_dst.size();
+      rev_dev_.in_begin_e_host_total = (int)ie.size();
+      rev_dev_.in_begin_x_host_total = (int)ix.size();
+    }
   }
   RS_HIP(hipDeviceSynchronize());
   on_device_ = true;
@@ -383,6 +410,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   const int max_words = 1024;
   need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)tok_cap * 16 + (size_t)(maxT + 2) * 4 + (size_t)(maxT + 1) * 16 +
                             (size_t)max_words * 4 + 4 + 16 + 64) + 65536;
+  need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32) + 4096;   // dense decoder back-pointer rows
   need += 64 * 256;   // alignment slack
   arena_.Reserve(need + (1u << 20), s);
   arena_.Reset();
@@ -517,27 +545,40 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (d_log_priors_ || opts_.acoustic_scale != 1.0f) LaunchPriorScale(ll, ll_ld, rows, P, d_log_priors_, opts_.acoustic_scale, s);
   tm.Mark();
   // ---- decode
+  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f);
+  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_;
+  DecodeOptsDev dopts;
+  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
+  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
   DecodeWork w;
   std::memset(&w, 0, sizeof(w));
-  w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
-  w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
-  w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
-  w.queue_a = arena_.AllocT<int>((size_t)n_utts * S);
-  w.queue_b = arena_.AllocT<int>((size_t)n_utts * S);
-  w.in_queue = arena_.AllocT<int>((size_t)n_utts * S);
-  w.tok_cap = tok_cap;
-  w.tokens = arena_.AllocT<int4>((size_t)n_utts * tok_cap);
-  w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
-  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
   w.max_words = max_words;
   w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
   w.out_nwords = arena_.AllocT<int>(n_utts);
   w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
   w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
-  DecodeOptsDev dopts;
-  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
-  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
-  LaunchDecode(hclg_dev_, dopts, g, ll, ll_ld, w, s);
+  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
+  if (use_dense) {
+    DenseWork dw;
+    std::memset(&dw, 0, sizeof(dw));
+    dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
+    dw.out_words = w.out_words; dw.out_nwords = w.out_nwords; dw.out_costs = w.out_costs; dw.counters = w.counters;
+    dw.frame_info = w.frame_info; dw.max_words = max_words;
+    dw.path_cap = 4 * (maxT + 2);
+    dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
+    LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
+  } else {
+    w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
+    w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
+    w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
+    w.queue_a = arena_.AllocT<int>((size_t)n_utts * S);
+    w.queue_b = arena_.AllocT<int>((size_t)n_utts * S);
+    w.in_queue = arena_.AllocT<int>((size_t)n_utts * S);
+    w.tok_cap = tok_cap;
+    w.tokens = arena_.AllocT<int4>((size_t)n_utts * tok_cap);
+    w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+    LaunchDecode(hclg_dev_, dopts, g, ll, ll_ld, w, s);
+  }
   tm.Mark();
   // ---- results to host
   std::vector<int> h_nw(n_utts), h_words((size_t)n_utts * max_words);
@@ -579,7 +620,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     ur.hyps.push_back(std::move(hy));
   }
   // ---- n-best through the lattice (the reference's determinise | lattice-to-nbest | nbest-to-linear tail)
-  if (nbest > 1 || lat_scale != 1.0f) {
+  if (want_lattice) {
     auto t_l0 = std::chrono::steady_clock::now();
     LatticeWork lw;
     std::memset(&lw, 0, sizeof(lw));

@@ -105,6 +105,9 @@ class Model {
   std::vector<GemmPlan> gemm_plans_;  // indexed like am_.nnet.ops (unused entries for eltwise ops)
   float *d_log_priors_ = nullptr;
   HclgDev hclg_dev_{};
+  RevGraphDev rev_dev_{};
+  bool dense_ok_ = false;
+  bool force_sparse_ = false;   // RS_FORCE_SPARSE_DECODER=1: always use the general (token-list) kernel
   int L_ = 0, R_ = 0;
 };
 

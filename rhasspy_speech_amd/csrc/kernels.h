@@ -157,6 +157,35 @@ struct DecodeWork {
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                   const DecodeWork &w, hipStream_t s);
 
+// Dense ("pull") variant for graphs whose per-state tables fit in LDS: one thread per destination state walks
+// its incoming arcs (reverse graph), so there are no atomics and no token lists; the frame's token costs live
+// in LDS.  Produces exactly the sparse kernel's costs and back-pointers (same float expressions, same
+// lowest-arc-index tie rule).  Back-pointer rows go to HBM for the traceback.
+struct RevGraphDev {
+  const uint32_t *in_begin_e;   // S + 1 : emitting in-arcs of each state
+  const uint32_t *in_begin_x;   // S + 1 : epsilon in-arcs
+  const int4 *in_e;             // {src state, pdf + 1, weight bits, forward arc index}, sorted by forward arc index
+  const int4 *in_x;
+  const int *eps_dst;           // states with at least one epsilon in-arc
+  int num_eps_dst;
+  int in_begin_e_host_total;    // number of emitting / epsilon in-arcs (= in_begin_*[S])
+  int in_begin_x_host_total;
+};
+struct DenseWork {
+  int *bp;                    // n_utts x (max_frames + 1) x S : back-pointer arc of each (frame, state), -2 = no token, -1 = start
+  int *out_words, *out_nwords;
+  float *out_costs;           // n_utts x 4
+  long long *counters;        // n_utts x 8
+  float *frame_info;          // n_utts x (max_frames + 1) x 4
+  int max_words;
+  int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
+  int path_cap;
+};
+size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
+bool DenseDecodeFits(int num_states, int num_pdfs);
+void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
+                       const float *loglikes, int ld, int num_pdfs, const DenseWork &w, hipStream_t s);
+
 // Lattice extraction = FinalizeDecoding (lattice-faster-decoder.cc:625-640): backward pass over the stored
 // token lists that recomputes every forward link, derives the exact extra_cost of every token
 // (PruneForwardLinksFinal / PruneForwardLinks with delta = 0) and emits the links within lattice_beam.
