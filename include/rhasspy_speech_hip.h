@@ -94,9 +94,15 @@ int rs_stream_open(rs_model *model, rs_stream **out);
 int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples);
 int rs_stream_finish(rs_stream *stream, int32_t nbest, float lattice_acoustic_scale, rs_result **out);
 void rs_stream_free(rs_stream *stream);
-/* Decodes many streams concurrently (BASELINE.json config 5): each rs_stream_accept only buffers; this call
- * advances every listed stream by whatever whole ticks it has buffered, batching the device work. */
+/* Many concurrent streams (BASELINE.json config 5).  The reference's streaming result is a deterministic function
+ * of the sample sequence: which frames each nnet chunk's iVector has seen follows from the 1024-sample tick
+ * schedule alone (decodable-online-looped.cc:56-84,186-194), not from wall-clock time.  The library therefore
+ * reproduces it exactly from the buffered samples; rs_streams_advance is a scheduling hint (currently a no-op that
+ * validates its arguments) and rs_streams_finish ends all listed streams (stdin EOF) and decodes them as ONE
+ * device batch; result utterance i belongs to streams[i]. */
 int rs_streams_advance(rs_stream *const *streams, int32_t n_streams);
+int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale,
+                      rs_result **out);
 
 /* Result access.  Hypotheses of utterance `utt` are ordered best first, like the keys utt-1..utt-n that
  * lattice-to-nbest writes (lattice-to-nbest.cc:100-106). */
@@ -112,7 +118,7 @@ int rs_result_costs(const rs_result *r, int32_t utt, int32_t k, float *graph_cos
  * of bytes needed, like snprintf. */
 int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, size_t len);
 /* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
- * (n x D_iv, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */
+ * (n x D_iv: one row offline, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */
 int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols);
 /* Decoder work counters of one utterance, for the algorithmic-bytes figure of SURVEY.md section 8(d):
  * out[0] = tokens expanded, [1] = arcs examined, [2] = token insertions (FindOrAddToken calls),

@@ -304,6 +304,51 @@ class Nnet3:
             offs += node_max
         self.halo = offs + 2
 
+    # ---- exact model context (ComputeSimpleNnetContext, nnet-utils.cc:146): how far the output at t looks
+    def context(self) -> Tuple[int, int]:
+        memo: Dict[str, Tuple[int, int]] = {}
+
+        def desc_ctx(sd: str) -> Tuple[int, int]:
+            sd = sd.strip()
+            m = re.match(r"^(\w+)\((.*)\)$", sd, re.S)
+            if m and m.group(1) in ("Append", "Sum", "Offset", "Scale", "ReplaceIndex", "IfDefined"):
+                fn, args = m.group(1), self._split_args(m.group(2))
+                if fn in ("Append", "Sum"):
+                    cs = [desc_ctx(a) for a in args]
+                    return max(c[0] for c in cs), max(c[1] for c in cs)
+                if fn == "Offset":
+                    l, r = desc_ctx(args[0])
+                    o = int(args[1])
+                    return l - o, r + o
+                if fn == "Scale":
+                    return desc_ctx(args[1])
+                if fn == "ReplaceIndex":
+                    return (-10 ** 6, -10 ** 6)      # constant over t
+                return desc_ctx(args[0])
+            return node_ctx(sd)
+
+        def node_ctx(name: str) -> Tuple[int, int]:
+            if name in memo:
+                return memo[name]
+            kv = self.nodes[name]
+            if kv["_type"] == "input-node":
+                out = (0, 0) if name == "input" else (-10 ** 6, -10 ** 6)
+            elif kv["_type"] == "dim-range-node":
+                out = node_ctx(kv["input-node"])
+            else:
+                l, r = desc_ctx(kv["input"])
+                if kv["_type"] == "component-node":
+                    c = self.nf.components[kv["component"]]
+                    if c.type == "TdnnComponent":
+                        offs = [int(x) for x in c.fields["<TimeOffsets>"]]
+                        l, r = l - min(offs), r + max(offs)
+                out = (l, r)
+            memo[name] = out
+            return out
+
+        l, r = node_ctx("output")
+        return max(l, 0), max(r, 0)
+
     # ---- descriptor evaluation on the padded time axis (rows = t in [-halo, T + halo))
     def _shift(self, a: np.ndarray, o: int) -> np.ndarray:
         if o == 0:
@@ -561,6 +606,78 @@ class Oracle:
             iv = self.offline_ivector(feats)
             rows = np.tile(iv[None, :], (feats.shape[0] + 2 * self.nnet.halo, 1))
         return nn_in, iv, self.nnet.forward(nn_in, rows, self.acoustic_scale)
+
+    # ---- streaming semantics of online2-cli-nnet3-decode-faster (1024-sample ticks, one iVector per nnet chunk)
+    def stream_schedule(self, n_samples: int, tick: int = 1024):
+        """For every nnet chunk: (tick index at which it is computed, last frame whose stats the iVector has seen).
+        decodable-online-looped.cc:56-84 (NumFramesReady), :186-194 (iVector frame), online2-cli...cc:143-161."""
+        L, R = self.nnet.context()
+        T = self.mfcc.num_frames(n_samples)
+        nchunks = (T + self.chunk - 1) // self.chunk
+        sched = []
+        k = 0
+        nt = (n_samples + tick - 1) // tick
+        sr = self.ie["right"] if self.ie is not None else 0
+        for j in range(nt):
+            fr = self.mfcc.num_frames(min(tick * (j + 1), n_samples))
+            ready = max(0, fr - R) // self.chunk
+            while k < ready and k < nchunks:
+                sched.append((j, min(fr - 1, fr - sr - 1)))
+                k += 1
+        while k < nchunks:
+            sched.append((nt, T - 1))      # after InputFinished(): everything is available
+            k += 1
+        return sched, L, R
+
+    def loglikes_stream(self, feats: np.ndarray, n_samples: int):
+        nn_in = feats if self.nnet_cmvn is None else online_cmvn(feats, self.nnet_cmvn)
+        sched, L, R = self.stream_schedule(n_samples)
+        T = feats.shape[0]
+        if self.ie is None:
+            return nn_in, None, self.nnet.forward(nn_in, None, self.acoustic_scale)
+        ie = self.ie
+        cm = online_cmvn(feats, ie["gstats"])
+        st = IvectorStats(ie["ext"], ie["max_count"])
+        x = np.zeros(ie["ext"].M.shape[2])
+        x[0] = ie["ext"].prior_offset
+        done = 0            # frames already in the stats
+        ivs = []
+        for (_, last) in sched:
+            if last + 1 > done:
+                # frames done..last; their splice context is complete (or clamped at the true end after the flush)
+                T_ready = T if last == T - 1 else last + 1 + ie["right"]
+                self._ivector_acc(st, feats, cm, done, last + 1, min(T_ready, T))
+                done = last + 1
+                x = st.get_ivector(x)
+            out = x.astype(F32)
+            out[0] = F32(np.float64(out[0]) - ie["ext"].prior_offset)
+            ivs.append(out)
+        ivs = np.stack(ivs)
+        # which chunk supplied the iVector "slot" of every padded row (nnet-compile-looped.cc:164-231)
+        H = self.nnet.halo
+        ts = np.arange(-H, T + H)
+        slot = (ts // self.chunk) * self.chunk
+        provider = {}
+        ends = [self.chunk * (k + 1) + R for k in range(len(sched))]
+        begin0 = -L
+        for k in range(len(sched)):
+            lo = begin0 if k == 0 else ends[k - 1]
+            for t in range(lo, ends[k]):
+                provider.setdefault((t // self.chunk) * self.chunk, k)
+        maxk = len(sched) - 1
+        idx = np.array([min(provider.get(int(sl), maxk if sl > 0 else 0), maxk) for sl in slot])
+        return nn_in, ivs, self.nnet.forward(nn_in, ivs[idx], self.acoustic_scale)
+
+    def transcribe_stream(self, pcm: np.ndarray, nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Transcript:
+        pcm = np.asarray(pcm)
+        feats = self.features(pcm)
+        T = feats.shape[0]
+        if T == 0:
+            raise RuntimeError("You cannot get a lattice if you decoded no frames.")
+        nn_in, ivs, ll = self.loglikes_stream(feats, len(pcm))
+        lattice, ctr = decode(self.fst, self.id2pdf, ll, **self.opts)
+        paths = lat.nbest(lattice, nbest, self.opts["lattice_beam"], lattice_acoustic_scale)
+        return Transcript(T, nn_in, ivs, ll, paths, lattice, ctr)
 
     def transcribe(self, pcm: np.ndarray, nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Transcript:
         feats = self.features(np.asarray(pcm))

@@ -30,7 +30,7 @@ class DecodeOpts(C.Structure):
 EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
     "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_stream_open", "rs_stream_accept",
-    "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_result_num_utts", "rs_result_num_hyps",
+    "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_free",
 ]
@@ -59,6 +59,7 @@ def load_library() -> C.CDLL:
     lib.rs_stream_free.argtypes = [vp]
     lib.rs_stream_free.restype = None
     lib.rs_streams_advance.argtypes = [C.POINTER(vp), i32]
+    lib.rs_streams_finish.argtypes = [C.POINTER(vp), i32, i32, f32, C.POINTER(vp)]
     lib.rs_result_num_utts.argtypes = [vp]
     lib.rs_result_num_hyps.argtypes = [vp, i32]
     lib.rs_result_num_frames.argtypes = [vp, i32]
@@ -215,3 +216,36 @@ class Model:
         _check(lib().rs_decode_batch_device(self._h, C.c_void_p(d_pcm_ptr), off.ctypes.data_as(C.POINTER(C.c_int64)),
                                             off.shape[0] - 1, nbest, lattice_acoustic_scale, C.c_void_p(stream), C.byref(out)))
         return Result(out)
+
+
+class Stream:
+    """Owns an rs_stream: the stdin of one online2-cli-nnet3-decode-faster process."""
+
+    def __init__(self, model: Model):
+        self.model = model
+        self._h = C.c_void_p()
+        _check(lib().rs_stream_open(model._h, C.byref(self._h)))
+
+    def accept(self, pcm) -> None:
+        a = np.ascontiguousarray(np.frombuffer(pcm, dtype="<i2") if isinstance(pcm, (bytes, bytearray, memoryview)) else pcm, dtype=np.int16)
+        _check(lib().rs_stream_accept(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[0]))
+
+    def finish(self, nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
+        out = C.c_void_p()
+        _check(lib().rs_stream_finish(self._h, nbest, lattice_acoustic_scale, C.byref(out)))
+        return Result(out)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rs_stream_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def finish_streams(streams: Sequence[Stream], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
+    """Ends all streams (EOF) and decodes them as one device batch; utterance i of the result = streams[i]."""
+    arr = (C.c_void_p * len(streams))(*[s._h for s in streams])
+    out = C.c_void_p()
+    _check(lib().rs_streams_finish(arr, len(streams), nbest, lattice_acoustic_scale, C.byref(out)))
+    return Result(out)

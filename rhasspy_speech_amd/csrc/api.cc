@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "engine.h"
 
@@ -118,11 +119,59 @@ int rs_decode_batch_device(rs_model *model, const int16_t *d_pcm, const int64_t 
   });
 }
 
-int rs_stream_open(rs_model *, rs_stream **) { return ArgError("rs_stream_open: streaming decode is not implemented yet"); }
-int rs_stream_accept(rs_stream *, const int16_t *, int32_t) { return ArgError("rs_stream_accept: streaming decode is not implemented yet"); }
-int rs_stream_finish(rs_stream *, int32_t, float, rs_result **) { return ArgError("rs_stream_finish: streaming decode is not implemented yet"); }
-void rs_stream_free(rs_stream *) {}
-int rs_streams_advance(rs_stream *const *, int32_t) { return ArgError("rs_streams_advance: streaming decode is not implemented yet"); }
+int rs_stream_open(rs_model *model, rs_stream **out) {
+  if (!model || !out) return ArgError("rs_stream_open: null argument");
+  return Guard([&]() {
+    rs_stream *st = new rs_stream();
+    st->model = model;
+    *out = st;
+    return RS_OK;
+  });
+}
+
+int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples) {
+  if (!stream || n_samples < 0 || (n_samples > 0 && !pcm)) return ArgError("rs_stream_accept: bad argument");
+  if (stream->finished) return ArgError("rs_stream_accept: stream already finished");
+  return Guard([&]() {
+    stream->pcm.insert(stream->pcm.end(), pcm, pcm + n_samples);
+    return RS_OK;
+  });
+}
+
+int rs_streams_advance(rs_stream *const *streams, int32_t n_streams) {
+  if (n_streams < 0 || (n_streams > 0 && !streams)) return ArgError("rs_streams_advance: bad argument");
+  for (int i = 0; i < n_streams; i++) if (!streams[i]) return ArgError("rs_streams_advance: null stream");
+  g_last_error.clear();
+  return RS_OK;
+}
+
+int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale, rs_result **out) {
+  if (!out || n_streams < 0 || (n_streams > 0 && !streams)) return ArgError("rs_streams_finish: bad argument");
+  for (int i = 0; i < n_streams; i++) {
+    if (!streams[i] || !streams[i]->model) return ArgError("rs_streams_finish: null stream");
+    if (streams[i]->model != streams[0]->model) return ArgError("rs_streams_finish: all streams must belong to one model");
+    if (streams[i]->finished) return ArgError("rs_streams_finish: stream already finished");
+  }
+  if (n_streams == 0) return ArgError("rs_streams_finish: no streams");
+  return Guard([&]() {
+    std::vector<const int16_t *> ptr(n_streams);
+    std::vector<int32_t> len(n_streams);
+    for (int i = 0; i < n_streams; i++) { ptr[i] = streams[i]->pcm.data(); len[i] = (int32_t)streams[i]->pcm.size(); }
+    auto r = streams[0]->model->m->DecodeBatchHost(ptr.data(), len.data(), n_streams, nbest, lattice_acoustic_scale, /*streaming=*/true);
+    for (int i = 0; i < n_streams; i++) { streams[i]->finished = true; std::vector<int16_t>().swap(streams[i]->pcm); }
+    rs_result *res = new rs_result();
+    res->r = std::move(r);
+    *out = res;
+    return RS_OK;
+  });
+}
+
+int rs_stream_finish(rs_stream *stream, int32_t nbest, float lattice_acoustic_scale, rs_result **out) {
+  rs_stream *one[1] = {stream};
+  return rs_streams_finish(one, 1, nbest, lattice_acoustic_scale, out);
+}
+
+void rs_stream_free(rs_stream *stream) { delete stream; }
 
 int32_t rs_result_num_utts(const rs_result *r) { return r ? (int32_t)r->r->utts.size() : 0; }
 

@@ -322,7 +322,7 @@ struct Timer {
 }  // namespace
 
 std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
-                                               float lat_scale) {
+                                               float lat_scale, bool streaming) {
   ToDevice();
   std::vector<int64_t> off(n_utts + 1, 0);
   for (int i = 0; i < n_utts; i++) {
@@ -349,14 +349,14 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
     RS_HIP(hipStreamSynchronize(stream_));
     h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  res = DecodeBatchDevice(d_pcm_, off.data(), n_utts, nbest, lat_scale, nullptr);
+  res = DecodeBatchDevice(d_pcm_, off.data(), n_utts, nbest, lat_scale, nullptr, streaming);
   res->timings[0] = h2d_ms;
   res->timings[6] += h2d_ms;
   return res;
 }
 
 std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
-                                                 float lat_scale, hipStream_t user_stream) {
+                                                 float lat_scale, hipStream_t user_stream, bool streaming) {
   ToDevice();
   std::lock_guard<std::mutex> lk(mu_);
   RS_HIP(hipSetDevice(opts_.device_id));
@@ -385,13 +385,60 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   std::vector<int> row_utt(rows), row_t(rows);
   for (int u = 0; u < n_utts; u++)
     for (int r = row_base[u]; r < row_base[u + 1]; r++) { row_utt[r] = u; row_t[r] = r - row_base[u] - L_; }
+  // ---- iVector schedule.  Offline (--online=false): one estimate per utterance from all frames.  Streaming:
+  // one estimate per nnet chunk, from the frames available at the 1024-sample tick on which
+  // DecodableNnetLoopedOnlineBase::AdvanceChunk runs for that chunk (decodable-online-looped.cc:56-84,186-194;
+  // online2-cli-nnet3-decode-faster.cc:143-161).  The schedule only depends on sample counts, so the streaming
+  // result is reproduced exactly without replaying wall-clock time.
+  const bool has_iv = fc_.ie.present;
+  const int chunk = opts_.frames_per_chunk;
+  std::vector<int> ivrow_base(n_utts + 1, 0);               // first iVector row of each utterance
+  std::vector<std::vector<int>> chunk_last(n_utts);          // streaming: last stats frame of every chunk
+  int max_chunks = 1;
+  for (int u = 0; u < n_utts; u++) {
+    int nrows_u = 1;
+    if (streaming && has_iv) {
+      const long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
+      const int nch = (T[u] + chunk - 1) / chunk;
+      const int Rm = nn.right_context, sr = fc_.ie.splice_right;
+      const long nt = (ns + 1023) / 1024;
+      int k = 0;
+      for (long j = 0; j < nt && k < nch; j++) {
+        const int fr = NumFrames(std::min<long>(1024 * (j + 1), ns), fc_.mfcc.opts);
+        const int ready = std::max(0, fr - Rm) / chunk;
+        while (k < ready && k < nch) { chunk_last[u].push_back(std::min(fr - 1, fr - sr - 1)); k++; }
+      }
+      while (k < nch) { chunk_last[u].push_back(T[u] - 1); k++; }
+      nrows_u = std::max(nch, 1);
+      max_chunks = std::max(max_chunks, nch);
+    }
+    ivrow_base[u + 1] = ivrow_base[u] + nrows_u;
+  }
+  const int n_ivrows = ivrow_base[n_utts];
+  // which iVector row every frame row reads: the chunk that supplied its Round(ivector, chunk) slot
+  // (nnet-compile-looped.cc:164-231: chunk 0 supplies the slots of t in [-L, chunk + R), chunk k the new ones of
+  //  [k*chunk + R, (k+1)*chunk + R))
+  std::vector<int> row_ivec(rows);
+  for (int u = 0; u < n_utts; u++) {
+    const int nch = (int)chunk_last[u].size();
+    for (int r = row_base[u]; r < row_base[u + 1]; r++) {
+      int k = 0;
+      if (streaming && has_iv && nch > 0) {
+        const int t = r - row_base[u] - L_;
+        const int slot = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
+        // smallest k whose input range [.., (k+1)*chunk + R) contains a time with this slot: slot < (k+1)*chunk + R
+        k = 0;
+        while (k < nch - 1 && slot >= (k + 1) * chunk + nn.right_context) k++;
+      }
+      row_ivec[r] = ivrow_base[u] + k;
+    }
+  }
   // ---- arena sizing
   auto fbytes = [&](int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
   size_t need = 0;
-  need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 2 * sizeof(int) * (size_t)rows + 4096;
+  need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 3 * sizeof(int) * (size_t)rows + 4096;
   std::vector<int> buf_ld(nn.bufs.size());
   for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
-  const bool has_iv = fc_.ie.present;
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
   const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
   const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
@@ -399,7 +446,8 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (has_iv) {
     need += fbytes(ld_c) + 2 * fbytes(ld_l);
     need += (size_t)rows * nsel * 8 + 1024;
-    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8 + (size_t)ld_i * 4) + 8192;
+    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192;
+    need += (size_t)max_chunks * n_utts * 16 + 4096;
   }
   const int S = hclg_.num_states();
   int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
@@ -415,12 +463,15 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   arena_.Reserve(need + (1u << 20), s);
   arena_.Reset();
   // ---- upload geometry
+  int *d_row_ivec = nullptr;
   BatchGeom g;
   g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
   {
     int64_t *d_so = arena_.AllocT<int64_t>(n_utts + 1);
     int *d_T = arena_.AllocT<int>(n_utts), *d_rb = arena_.AllocT<int>(n_utts + 1), *d_fb = arena_.AllocT<int>(n_utts + 1);
     int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
+    d_row_ivec = arena_.AllocT<int>(rows);
+    RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
     RS_HIP(hipMemcpyAsync(d_so, sample_offsets, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice, s));
     RS_HIP(hipMemcpyAsync(d_T, T.data(), sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
     RS_HIP(hipMemcpyAsync(d_rb, row_base.data(), sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
@@ -474,19 +525,19 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (has_iv) {
     float *cm = falloc(ld_c), *lda_raw = falloc(ld_l), *lda_norm = falloc(ld_l);
     LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
-    LaunchGemm(fill_gemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l), rows, g.d_row_utt, s);
-    LaunchGemm(fill_gemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l), rows, g.d_row_utt, s);
+    LaunchGemm(fill_gemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l), rows, d_row_ivec, s);
+    LaunchGemm(fill_gemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l), rows, d_row_ivec, s);
     int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
     float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
     LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, s);
     double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
     double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
     double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
-    d_ivec = arena_.AllocT<float>((size_t)n_utts * ld_i);
+    d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i);
     RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
     RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
     RS_HIP(hipMemsetAsync(numf, 0, sizeof(double) * n_utts, s));
-    RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_utts * ld_i, s));
+    RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_ivrows * ld_i, s));
     // OnlineIvectorEstimationStats ctor (ivector-extractor.cc:786-795): quadratic = I, linear = [prior_offset, 0, ...];
     // current_ivector_ starts at [prior_offset, 0, ...] (online-ivector-feature.cc:440-442)
     {
@@ -502,16 +553,45 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
       RS_HIP(hipStreamSynchronize(s));
     }
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
-    LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
-    LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
-    LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, s);
+    if (!streaming) {
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
+      LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
+      LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
+    } else {
+      // per-chunk schedule tables: [step][utt] frame_begin, frame_end, out_row, active
+      std::vector<int> fb((size_t)max_chunks * n_utts, 0), fe((size_t)max_chunks * n_utts, 0), orow((size_t)max_chunks * n_utts, -1),
+          act((size_t)max_chunks * n_utts, 0);
+      for (int u = 0; u < n_utts; u++) {
+        int done = 0;
+        for (size_t k = 0; k < chunk_last[u].size(); k++) {
+          const size_t i = k * n_utts + u;
+          const int last = chunk_last[u][k];
+          orow[i] = ivrow_base[u] + (int)k;
+          if (last + 1 > done) { fb[i] = done; fe[i] = last + 1; act[i] = 1; done = last + 1; }
+        }
+      }
+      int *d_fb = arena_.AllocT<int>(fb.size()), *d_fe = arena_.AllocT<int>(fb.size()), *d_or = arena_.AllocT<int>(fb.size()),
+          *d_ac = arena_.AllocT<int>(fb.size());
+      RS_HIP(hipMemcpyAsync(d_fb, fb.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_fe, fe.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_or, orow.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_ac, act.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipStreamSynchronize(s));
+      for (int k = 0; k < max_chunks; k++) {
+        const size_t o = (size_t)k * n_utts;
+        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, s);
+        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
+        LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
+        LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
+      }
+    }
   }
   tm.Mark();
   // ---- acoustic model
   for (size_t i = 0; i < nn.ops.size(); i++) {
     const LayerOp &op = nn.ops[i];
     if (op.kind == LayerOp::kGemm) {
-      LaunchGemm(fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]), rows, g.d_row_utt, s);
+      LaunchGemm(fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]), rows, d_row_ivec, s);
     } else {
       EltwiseDev d;
       std::memset(&d, 0, sizeof(d));
@@ -690,7 +770,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (opts_.keep_intermediates) {
     for (int u = 0; u < n_utts; u++) {
       UttResult &ur = res->utts[u];
-      ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? 1 : 0;
+      ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? ivrow_base[u + 1] - ivrow_base[u] : 0;
       if (T[u] == 0) continue;
       ur.feats.resize((size_t)T[u] * C);
       ur.loglikes.resize((size_t)T[u] * P);
@@ -699,8 +779,9 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
       const float *lin = ll + ((size_t)row_base[u] + L_) * ll_ld;
       RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, lin, sizeof(float) * ll_ld, sizeof(float) * P, T[u], hipMemcpyDeviceToHost));
       if (has_iv) {
-        ur.ivector.resize(Di);
-        RS_HIP(hipMemcpy(ur.ivector.data(), d_ivec + (size_t)u * ld_i, sizeof(float) * Di, hipMemcpyDeviceToHost));
+        ur.ivector.resize((size_t)ur.ivec_rows * Di);
+        RS_HIP(hipMemcpy2D(ur.ivector.data(), sizeof(float) * Di, d_ivec + (size_t)ivrow_base[u] * ld_i, sizeof(float) * ld_i,
+                           sizeof(float) * Di, ur.ivec_rows, hipMemcpyDeviceToHost));
       }
     }
   }

@@ -66,10 +66,12 @@ class Model {
   ~Model();
   void ToDevice();
   std::string Describe() const;
+  // streaming = true reproduces online2-cli-nnet3-decode-faster: 1024-sample ticks, one iVector per nnet chunk
+  // estimated from the frames available at the tick the chunk is computed on (warm-started CG).
   std::unique_ptr<Result> DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
-                                            float lat_scale, hipStream_t stream);
+                                            float lat_scale, hipStream_t stream, bool streaming = false);
   std::unique_ptr<Result> DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
-                                          float lat_scale);
+                                          float lat_scale, bool streaming = false);
   const rs_decode_opts &opts() const { return opts_; }
   const FeatureConfig &features() const { return fc_; }
   const AcousticModel &am() const { return am_; }
@@ -115,3 +117,4 @@ class Model {
 
 struct rs_model { std::unique_ptr<rs::Model> m; };
 struct rs_result { std::unique_ptr<rs::Result> r; };
+struct rs_stream { rs_model *model = nullptr; std::vector<int16_t> pcm; bool finished = false; };

@@ -432,6 +432,22 @@ __global__ void IvecNumFramesKernel(IvecDev iv, int n_utts, const float *__restr
   num_frames[u] += tot;
 }
 
+// zero the per-step accumulators of the Gaussians that were touched (cheaper than a 40 MB memset per chunk)
+__global__ void IvecClearKernel(IvecDev iv, float *__restrict__ gamma, double *__restrict__ wfeats) {
+  const int u = blockIdx.y, gi = blockIdx.x * blockDim.y + threadIdx.y;
+  if (gi >= iv.num_gauss) return;
+  if (gamma[(size_t)u * iv.num_gauss + gi] == 0.f) return;
+  double *wf = wfeats + ((size_t)u * iv.num_gauss + gi) * iv.feat_dim;
+  for (int d = threadIdx.x; d < iv.feat_dim; d += blockDim.x) wf[d] = 0.0;
+  // (one wave per Gaussian: every lane has read gamma before lane 0 clears it)
+  if (threadIdx.x == 0) gamma[(size_t)u * iv.num_gauss + gi] = 0.f;
+}
+void LaunchIvecClear(const IvecDev &iv, int n_utts, double *gamma, double *wfeats, hipStream_t s) {
+  if (n_utts == 0) return;
+  dim3 block(64, 4), grid((iv.num_gauss + 3) / 4, n_utts);
+  hipLaunchKernelGGL(IvecClearKernel, grid, block, 0, s, iv, reinterpret_cast<float *>(gamma), wfeats);
+}
+
 void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const double *wfeats, double *linear,
                      double *quadratic, double *num_frames, hipStream_t s) {
   if (n_utts == 0) return;
@@ -469,9 +485,13 @@ __device__ __forceinline__ double SpMatVecRow(const double *A, const double *x, 
 
 __global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, const double *__restrict__ quadratic,
                                 const double *__restrict__ num_frames, double *__restrict__ xio,
-                                float *__restrict__ ivec_out, int ldo) {
+                                float *__restrict__ ivec_out, int ldo, const int *__restrict__ out_row,
+                                const int *__restrict__ active) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int u = blockIdx.x, tid = threadIdx.x, n = iv.ivec_dim;
+  const int orow = out_row ? out_row[u] : u;
+  if (orow < 0) return;                                    // this utterance has no chunk at this step
+  const bool solve = active ? active[u] != 0 : true;       // 0: re-emit the current estimate (no new frames)
   const int usz = n * (n + 1) / 2;
   double *A = reinterpret_cast<double *>(smem_raw);
   double *x = A + usz, *r = x + n, *p = r + n, *Ap = p + n, *b = Ap + n, *scratch = b + n;
@@ -479,7 +499,9 @@ __global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, c
   for (int i = tid; i < n; i += blockDim.x) { b[i] = linear[(size_t)u * n + i]; x[i] = xio[(size_t)u * n + i]; }
   __syncthreads();
   const bool have = num_frames[u] > 0.0;
-  if (have) {
+  if (!solve) {
+    // nothing
+  } else if (have) {
     if (tid == 0 && x[0] == 0.0) x[0] = iv.prior_offset;     // GetIvector: better initial guess
     __syncthreads();
     const bool mine = tid < n;
@@ -523,21 +545,22 @@ __global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, c
     __syncthreads();
   }
   if (tid < n) {
-    xio[(size_t)u * n + tid] = x[tid];
+    if (solve) xio[(size_t)u * n + tid] = x[tid];
     float v = (float)x[tid];
     if (tid == 0) v = (float)((double)v - iv.prior_offset);   // (*feat)(0) -= PriorOffset() on the float copy
-    ivec_out[(size_t)u * ldo + tid] = v;
+    ivec_out[(size_t)orow * ldo + tid] = v;
   }
 }
 
 void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,
-                     const double *num_frames, double *x, float *ivec_out, int ldo, hipStream_t s) {
+                     const double *num_frames, double *x, float *ivec_out, int ldo, const int *out_row, const int *active,
+                     hipStream_t s) {
   if (n_utts == 0) return;
   int n = iv.ivec_dim;
   int threads = 64;
   while (threads < n) threads <<= 1;
   size_t smem = sizeof(double) * ((size_t)n * (n + 1) / 2 + 5 * (size_t)n + threads);
-  hipLaunchKernelGGL(IvecSolveKernel, dim3(n_utts), dim3(threads), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo);
+  hipLaunchKernelGGL(IvecSolveKernel, dim3(n_utts), dim3(threads), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
 }
 
 }  // namespace rs

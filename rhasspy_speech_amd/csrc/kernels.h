@@ -58,7 +58,7 @@ struct GemmSegDev {
   int ncols;          // valid K extent
   int row_off;        // constant row offset (time offset)
   int k0;             // first (padded) K index of this segment inside W
-  int per_utt;        // 1: row index = row_utt[row] (iVector input)
+  int per_utt;        // 1: row index = row_ivec[row] (iVector input: one row per utterance, or per nnet chunk when streaming)
 };
 constexpr int kMaxSegs = 16;
 struct EltStageDev {
@@ -78,7 +78,7 @@ struct GemmDev {
   float *out;
   int ldo;
 };
-void LaunchGemm(const GemmDev &d, int rows, const int *row_utt, hipStream_t s);
+void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
 
 struct SumTermDev { const float *src; int ld, col0, row_off; float scale; };
 struct EltwiseDev {
@@ -121,8 +121,12 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
                      double *linear, double *quadratic, double *num_frames, hipStream_t s);
 // Conjugate-gradient solve per utterance (LinearCgd, <= num_cg_iters), x in/out (double, n_utts x I);
 // ivec_out (float, n_utts x ldo) = x with prior_offset subtracted from element 0.
+// out_row (null = u): row of ivec_out receiving utterance u's estimate, -1 = skip; active (null = all): 0 = no new
+// frames since the last estimate, just re-emit it (the reference does not re-run CG then).
 void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,
-                     const double *num_frames, double *x, float *ivec_out, int ldo, hipStream_t s);
+                     const double *num_frames, double *x, float *ivec_out, int ldo, const int *out_row, const int *active,
+                     hipStream_t s);
+void LaunchIvecClear(const IvecDev &iv, int n_utts, double *gamma, double *wfeats, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder
 struct HclgDev {

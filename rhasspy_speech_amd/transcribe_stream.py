@@ -1,0 +1,85 @@
+"""Transcribe an audio stream on an MI355X.
+
+Same public surface as rhasspy_speech/transcribe_stream.py:18-129: `KaldiNnet3StreamTranscriber.async_transcribe`
+consumes an async iterable of raw s16le 16 kHz mono chunks (the bytes the reference writes to the stdin of
+`online2-cli-nnet3-decode-faster`, :76-82) and returns the decoded texts.  The library re-chunks to the binary's
+fixed 1024-sample ticks, so -- like the reference -- the result does not depend on how the caller slices the audio.
+"""
+from __future__ import annotations
+
+import asyncio
+import logging
+from collections.abc import AsyncIterable
+from pathlib import Path
+from typing import List, Optional, Union
+
+from . import _lib
+from .meta import int2sym, read_words_txt, texts_from_int2sym
+from .tools import KaldiTools
+
+_LOGGER = logging.getLogger(__name__)
+
+
+class KaldiNnet3StreamTranscriber:
+    def __init__(
+        self,
+        model_dir: Union[str, Path],
+        graph_dir: Union[str, Path],
+        tools: Optional[KaldiTools] = None,
+        max_active: int = 7000,
+        lattice_beam: float = 8.0,
+        acoustic_scale: float = 1.0,
+        beam: float = 24.0,
+        device_id: int = 0,
+    ):
+        self.model_dir = Path(model_dir)
+        self.graph_dir = Path(graph_dir)
+        self.tools = tools
+        self.max_active = max_active
+        self.lattice_beam = lattice_beam
+        self.acoustic_scale = acoustic_scale
+        self.beam = beam
+        self.device_id = device_id
+        self._model: Optional[_lib.Model] = None
+        self._words = None
+
+    def _ensure_loaded(self) -> _lib.Model:
+        if self._model is None:
+            opts = _lib.default_opts(max_active=self.max_active, lattice_beam=self.lattice_beam, beam=self.beam,
+                                     acoustic_scale=1.0, device_id=self.device_id)
+            self._model = _lib.Model(self.model_dir, self.graph_dir, opts)
+            self._words = read_words_txt(self.graph_dir / "words.txt")
+        return self._model
+
+    async def async_transcribe(
+        self,
+        audio_stream: AsyncIterable[Optional[bytes]],
+        lang_dir: Union[str, Path],
+        nbest: int = 1,
+        max_fuzzy_cost: Optional[float] = None,
+        require_fuzzy: bool = False,
+    ) -> List[str]:
+        lang_dir = Path(lang_dir)
+        stream = _lib.Stream(self._ensure_loaded())
+        try:
+            async for chunk in audio_stream:
+                if chunk:
+                    stream.accept(chunk)
+            _LOGGER.debug("Stream ended")
+            loop = asyncio.get_running_loop()
+            try:
+                res = await loop.run_in_executor(None, stream.finish, nbest, self.acoustic_scale)
+                nbest_stdout = res.text(0, "utt")
+            except _lib.RsError as e:
+                # The reference never checks the decoder's exit status (transcribe_stream.py:82) and then fails in
+                # lattice-to-nbest on the missing lattice; surface the decoder's message instead.
+                raise RuntimeError(f"Unexpected error running command online2-cli-nnet3-decode-faster (HIP): {e}") from e
+        finally:
+            stream.close()
+        int2sym_stdout = int2sym(nbest_stdout, self._words)
+        _LOGGER.debug("nbest: %s", int2sym_stdout)
+        if (lang_dir / "G.fuzzy.fst").exists():
+            raise NotImplementedError("G.fuzzy.fst post-processing is not part of the MI355X hot path")
+        if require_fuzzy:
+            return []
+        return texts_from_int2sym(int2sym_stdout)

@@ -138,3 +138,47 @@ def test_dense_and_sparse_decoders_agree(case_cache, name, monkeypatch):
         np.testing.assert_allclose(a.costs(u), b.costs(u), rtol=1e-6)
         # same number of live tokens summed over frames => same token sets
         assert a.counters(u)[3] == b.counters(u)[3]
+
+
+STREAM_CASES = [n for n in cases.CASES if n not in ("zam_u1",)]
+
+
+@pytest.mark.parametrize("name", STREAM_CASES)
+def test_streaming_case(case_cache, name):
+    """online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one warm-started iVector per nnet chunk."""
+    from rhasspy_speech_amd import _lib
+    g = load_golden(name)
+    model, pcm = make_model(case_cache, name)
+    st = _lib.Stream(model)
+    # deliberately odd chunking: the result must not depend on it
+    for i in range(0, len(pcm), 777):
+        st.accept(pcm[i:i + 777])
+    res = st.finish(nbest=cases.NBEST)
+    assert res.num_frames(0) == int(g["stream_num_frames"])
+    if "stream_ivector" in g:
+        iv = res.matrix(0, 1)
+        assert iv.shape == g["stream_ivector"].shape
+        assert np.abs(iv - g["stream_ivector"]).max() < IVEC_TOL
+    ll = res.matrix(0, 2)
+    sr, sc = g["loglikes_stride"]
+    assert np.abs(ll[::sr, ::sc] - g["stream_loglikes"]).max() < LOGLIKE_TOL
+    ref = parse_nbest(bytes(g["stream_nbest_text"]))
+    assert [res.words(0, k) for k in range(res.num_hyps(0))] == ref
+    assert res.text(0).split() == bytes(g["stream_nbest_text"]).split()
+
+
+def test_many_streams_one_batch(case_cache):
+    from rhasspy_speech_amd import _lib, synth
+    model, _ = make_model(case_cache, "tiny_u0")
+    pcms = [synth.synth_utterance(500 + i, n) for i, n in enumerate([48000, 20000, 70000, 5000])]
+    streams = [_lib.Stream(model) for _ in pcms]
+    for s, p in zip(streams, pcms):
+        s.accept(p.tobytes())
+    batch = _lib.finish_streams(streams, nbest=2)
+    for i, p in enumerate(pcms):
+        s = _lib.Stream(model)
+        s.accept(p)
+        one = s.finish(nbest=2)
+        assert [batch.words(i, k) for k in range(batch.num_hyps(i))] == [one.words(0, k) for k in range(one.num_hyps(0))]
+        assert np.array_equal(batch.matrix(i, 1), one.matrix(0, 1))
+        assert np.array_equal(batch.matrix(i, 2), one.matrix(0, 2))

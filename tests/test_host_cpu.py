@@ -110,6 +110,15 @@ def test_transcriber_signature_matches_reference():
     assert inspect.iscoroutinefunction(KaldiNnet3WavTranscriber.async_transcribe)
 
 
+def test_stream_transcriber_signature_matches_reference():
+    import inspect
+    from rhasspy_speech_amd.transcribe_stream import KaldiNnet3StreamTranscriber
+    p = inspect.signature(KaldiNnet3StreamTranscriber.__init__).parameters
+    assert [p[k].default for k in ("max_active", "lattice_beam", "acoustic_scale", "beam")] == [7000, 8.0, 1.0, 24.0]
+    sig = inspect.signature(KaldiNnet3StreamTranscriber.async_transcribe)
+    assert list(sig.parameters)[1:] == ["audio_stream", "lang_dir", "nbest", "max_fuzzy_cost", "require_fuzzy"]
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist

@@ -60,3 +60,18 @@ def test_oracle_intermediate_ivector_features(oracles):
     nrm = pipeline.lda_transform(pipeline.splice(cm, orc.ie["left"], orc.ie["right"]), orc.ie["lda"])
     assert np.abs(raw - g["lda"]).max() < 1e-3
     assert np.abs(nrm - g["lda_norm"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7"])
+def test_oracle_streaming_matches_reference(oracles, name):
+    """online2-cli-nnet3-decode-faster goldens: per-chunk iVectors, log-likelihoods, n-best text."""
+    g = np.load(cases.GOLDEN / f"{name}.npz")
+    orc, pcm = oracles(name)
+    sched, L, R = orc.stream_schedule(len(pcm))
+    if "stream_chunk_tick" in g:
+        assert [j for j, _ in sched] == [int(x) for x in g["stream_chunk_tick"]]
+    tr = orc.transcribe_stream(pcm, nbest=cases.NBEST)
+    if "stream_ivector" in g:
+        assert np.abs(tr.ivector - g["stream_ivector"]).max() < 1e-4
+    assert np.abs(tr.loglikes - g["stream_loglikes"]).max() < 1e-4
+    assert tr.text() == bytes(g["stream_nbest_text"])
