@@ -446,7 +446,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (has_iv) {
     need += fbytes(ld_c) + 2 * fbytes(ld_l);
     need += (size_t)rows * nsel * 8 + 1024;
-    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192;
+    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192 + 1024;
     need += (size_t)max_chunks * n_utts * 16 + 4096;
   }
   const int S = hclg_.num_states();
@@ -533,7 +533,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
     double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
     double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
-    d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i);
+    d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i + 256);   // + slack: staging loads may read past a row's end
     RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
     RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
     RS_HIP(hipMemsetAsync(numf, 0, sizeof(double) * n_utts, s));

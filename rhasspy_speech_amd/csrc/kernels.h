@@ -50,7 +50,7 @@ struct CmvnDev {
 void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s);
 
 // ---------------------------------------------------------------- generic segmented GEMM (FP32 MFMA)
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 16;
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
 struct GemmSegDev {
   const float *src;   // source buffer base (row 0 of the frame buffer), or iVector matrix if per_utt
   int ld;             // leading dimension of the source

@@ -30,13 +30,23 @@ __device__ __forceinline__ float ApplyStage(const EltStageDev &st, float v, int 
 }
 
 // 128 x 128 block tile, 4 waves in a 2 x 2 grid, each wave a 64 x 64 tile = 2 x 2 MFMA 32x32 accumulators.
-__global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int *__restrict__ row_utt) {
+// The K loop runs over (segment, k-tile) pairs; the global loads of tile i+1 are issued into registers before
+// the MFMA work of tile i (software pipelining), so HBM/L2 latency hides behind 32 x BK/16 MFMAs per wave.
+__global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int *__restrict__ row_ivec) {
   constexpr int BM = kGemmBM, BN = kGemmBN, BK = kGemmBK, LDS_LD = BK + 1;
+  constexpr int NV = BK / 16;                  // float4 loads per thread per operand half
   __shared__ float As[BM * LDS_LD];
   __shared__ float Bs[BN * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int row0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware tile order: the hardware deals workgroup b to XCD b % 8; all column tiles of one row tile are given
+  // to the same XCD back to back, so the row tile's activations are fetched into that XCD's L2 once and the
+  // weights (<= 2 MB) stay L2-resident.  Placement only affects speed, never results.
+  const int ncol = (d.n + BN - 1) / BN, nrow = (rows + BM - 1) / BM;
+  const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
+  if (rt >= nrow) return;
+  const int row0 = rt * BM, n0 = ct * BN;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -45,63 +55,75 @@ __global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // each thread stages 2 float4 of A and 2 of B per K step
-  const int lr0 = tid >> 2, lk = (tid & 3) * 4;       // rows lr0 and lr0 + 64
-  for (int s = 0; s < d.nsegs; s++) {
-    const GemmSegDev sg = d.segs[s];
-    long arow[2];
-    bool avalid[2];
+  // staging: thread (lr0, lk) owns rows lr0 and lr0 + 64, columns lk + 16 * v (v < NV) of each tile
+  const int lr0 = tid >> 2, lk = (tid & 3) * 4;
+  int grow[2];
+  bool avalid[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) { grow[h] = row0 + lr0 + h * 64; avalid[h] = grow[h] < rows; if (!avalid[h]) grow[h] = 0; }
+  const float *wrow[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) wrow[h] = d.W + (size_t)(n0 + lr0 + h * 64) * d.k_pad;
+
+  float4 av[2][NV], bv[2][NV];
+  // Branch-free staging loads: every lane always loads (rows past the end were clamped to row 0 and are dropped in
+  // the epilogue; columns past the segment's width are zeroed with selects).  Conditional loads make hipcc
+  // branch around each load and serialise them behind s_waitcnt.  Reads past a row's end stay inside the buffer
+  // (rows are padded / followed by guard rows; W is zero-padded to k_pad).
+  auto issue = [&](int seg, int k0) {
+    const GemmSegDev &sg = d.segs[seg];
+    const bool vec_ok = ((sg.ld & 3) == 0) && ((sg.col0 & 3) == 0);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      int grow = row0 + lr0 + h * 64;
-      avalid[h] = grow < rows;
-      int gr = avalid[h] ? grow : 0;
-      arow[h] = sg.per_utt ? (long)row_utt[gr] : (long)gr + sg.row_off;
-    }
-    const bool vec_ok = ((sg.ld & 3) == 0) && ((sg.col0 & 3) == 0);
-    const int kpad = (sg.ncols + BK - 1) / BK * BK;
-    for (int k0 = 0; k0 < kpad; k0 += BK) {
-      float4 av[2], bv[2];
+      const long arow = sg.per_utt ? (long)row_ivec[grow[h]] : (long)grow[h] + sg.row_off;
+      const float *ap = sg.src + arow * sg.ld + sg.col0;
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        av[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int kk = k0 + lk;
-        if (avalid[h] && kk < sg.ncols) {
-          const float *p = sg.src + arow[h] * sg.ld + sg.col0 + kk;
-          if (vec_ok && kk + 4 <= sg.ncols) {
-            av[h] = *reinterpret_cast<const float4 *>(p);
-          } else {
-            av[h].x = p[0];
-            if (kk + 1 < sg.ncols) av[h].y = p[1];
-            if (kk + 2 < sg.ncols) av[h].z = p[2];
-            if (kk + 3 < sg.ncols) av[h].w = p[3];
-          }
+      for (int v = 0; v < NV; v++) {
+        const int kk = k0 + lk + 16 * v;
+        float4 x;
+        if (vec_ok) {
+          x = *reinterpret_cast<const float4 *>(ap + kk);
+        } else {
+          x.x = ap[kk]; x.y = ap[kk + 1]; x.z = ap[kk + 2]; x.w = ap[kk + 3];
         }
-        const int gn = n0 + lr0 + h * 64;
-        bv[h] = (gn < d.n_pad) ? *reinterpret_cast<const float4 *>(d.W + (size_t)gn * d.k_pad + sg.k0 + kk)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        av[h][v] = x;            // masked later, when it is written to LDS (keeps the loads in flight across the MFMAs)
+        bv[h][v] = *reinterpret_cast<const float4 *>(wrow[h] + sg.k0 + kk);
       }
-      __syncthreads();   // previous step's LDS reads are done
+    }
+  };
+  int seg = 0, k0 = 0;
+  int kpad = (d.segs[0].ncols + BK - 1) / BK * BK;
+  if (d.nsegs > 0) issue(0, 0);
+  while (seg < d.nsegs) {
+    const int lim = d.segs[seg].ncols - k0 - lk;      // valid columns of the staged tile, relative to this lane's first
+    __syncthreads();                     // previous tile's LDS reads are done
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        float *pa = &As[(lr0 + h * 64) * LDS_LD + lk];
-        pa[0] = av[h].x; pa[1] = av[h].y; pa[2] = av[h].z; pa[3] = av[h].w;
-        float *pb = &Bs[(lr0 + h * 64) * LDS_LD + lk];
-        pb[0] = bv[h].x; pb[1] = bv[h].y; pb[2] = bv[h].z; pb[3] = bv[h].w;
-      }
-      __syncthreads();
+    for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        const int kc = kk + (lane >> 5);
-        float a0 = As[(wm * 64 + (lane & 31)) * LDS_LD + kc];
-        float a1 = As[(wm * 64 + 32 + (lane & 31)) * LDS_LD + kc];
-        float b0 = Bs[(wn * 64 + (lane & 31)) * LDS_LD + kc];
-        float b1 = Bs[(wn * 64 + 32 + (lane & 31)) * LDS_LD + kc];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int v = 0; v < NV; v++) {
+        float *pa = &As[(lr0 + h * 64) * LDS_LD + lk + 16 * v];
+        const int l2 = lim - 16 * v;
+        pa[0] = l2 > 0 ? av[h][v].x : 0.f; pa[1] = l2 > 1 ? av[h][v].y : 0.f;
+        pa[2] = l2 > 2 ? av[h][v].z : 0.f; pa[3] = l2 > 3 ? av[h][v].w : 0.f;
+        float *pb = &Bs[(lr0 + h * 64) * LDS_LD + lk + 16 * v];
+        pb[0] = bv[h][v].x; pb[1] = bv[h][v].y; pb[2] = bv[h][v].z; pb[3] = bv[h][v].w;
       }
+    // advance to the next tile and start its loads before computing this one
+    k0 += BK;
+    if (k0 >= kpad) { seg++; k0 = 0; if (seg < d.nsegs) kpad = (d.segs[seg].ncols + BK - 1) / BK * BK; }
+    if (seg < d.nsegs) issue(seg, k0);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const int kc = kk + (lane >> 5);
+      const float a0 = As[(wm * 64 + (lane & 31)) * LDS_LD + kc];
+      const float a1 = As[(wm * 64 + 32 + (lane & 31)) * LDS_LD + kc];
+      const float b0 = Bs[(wn * 64 + (lane & 31)) * LDS_LD + kc];
+      const float b1 = Bs[(wn * 64 + 32 + (lane & 31)) * LDS_LD + kc];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -124,10 +146,11 @@ __global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int
   }
 }
 
-void LaunchGemm(const GemmDev &d, int rows, const int *row_utt, hipStream_t s) {
+void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   if (rows <= 0) return;
-  dim3 grid((rows + kGemmBM - 1) / kGemmBM, (d.n + kGemmBN - 1) / kGemmBN);
-  hipLaunchKernelGGL(GemmKernel, grid, dim3(256), 0, s, d, rows, row_utt);
+  const int nrow = (rows + kGemmBM - 1) / kGemmBM, ncol = (d.n + kGemmBN - 1) / kGemmBN;
+  const int nrow8 = (nrow + 7) / 8 * 8;      // row tiles are dealt to the 8 XCDs round-robin
+  hipLaunchKernelGGL(GemmKernel, dim3(nrow8 * ncol), dim3(256), 0, s, d, rows, row_ivec);
 }
 
 // ------------------------------------------------------------------------------------------ elementwise
