@@ -122,13 +122,7 @@ def main() -> None:
 
     def step():
         res = model.decode_batch_device(d_pcm.data_ptr(), offsets)
-        rec = np.zeros((args.utts, 66), np.int32)
-        for u in range(args.utts):
-            w = res.words(u)[:MAX_WORDS]
-            rec[u, 0] = len(w)
-            rec[u, 1:1 + len(w)] = w
-            g, a = res.costs(u)
-            rec[u, 64:66] = np.array([g, a], np.float32).view(np.int32)
+        rec = res.pack(MAX_WORDS)          # fixed 264-byte records: status, n_words, word ids, graph/acoustic cost
         if world > 1:
             t = torch.from_numpy(rec).to(f"cuda:{local_rank}")
             out = [torch.empty_like(t) for _ in range(world)]

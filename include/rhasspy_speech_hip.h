@@ -117,6 +117,10 @@ int rs_result_costs(const rs_result *r, int32_t utt, int32_t k, float *graph_cos
  * "utt-<k> <id> <id> ... \n" per hypothesis (key prefix `key`, "utt" in the reference).  Returns the number
  * of bytes needed, like snprintf. */
 int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, size_t len);
+/* Fixed-size result records of the best hypothesis of every utterance, for the multi-GPU gather (one RCCL
+ * all_gather of these records is the path's only exchange step): out[u * (max_words + 4)] =
+ * {status (0 ok), n_words, word ids (max_words slots, truncated), graph cost bits, acoustic cost bits}. */
+int rs_result_pack(const rs_result *r, int32_t max_words, int32_t *out);
 /* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
  * (n x D_iv: one row offline, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */
 int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols);

@@ -32,7 +32,7 @@ EXPORTS = [
     "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_stream_open", "rs_stream_accept",
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_matrix",
-    "rs_result_counters", "rs_result_timings", "rs_result_free",
+    "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
 ]
 
 
@@ -69,6 +69,7 @@ def load_library() -> C.CDLL:
     lib.rs_result_matrix.argtypes = [vp, i32, i32, C.POINTER(C.POINTER(f32)), C.POINTER(i32), C.POINTER(i32)]
     lib.rs_result_counters.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     lib.rs_result_timings.argtypes = [vp, C.POINTER(f32)]
+    lib.rs_result_pack.argtypes = [vp, i32, C.POINTER(i32)]
     lib.rs_result_free.argtypes = [vp]
     lib.rs_result_free.restype = None
     return lib
@@ -160,6 +161,12 @@ class Result:
         out = (C.c_int64 * 8)()
         _check(lib().rs_result_counters(self._h, utt, out))
         return list(out)
+
+    def pack(self, max_words: int = 62) -> np.ndarray:
+        """(num_utts, max_words + 4) int32 records: status, n_words, words, graph/acoustic cost bits (for the gather)."""
+        out = np.zeros((self.num_utts, max_words + 4), np.int32)
+        _check(lib().rs_result_pack(self._h, max_words, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     def timings(self) -> List[float]:
         out = (C.c_float * 8)()

@@ -1,6 +1,7 @@
 // extern "C" surface of librhasspy_speech_hip.so (see include/rhasspy_speech_hip.h).  No exception crosses
 // the boundary: every failure becomes a status code + thread-local message, mirroring how the reference's
 // binaries report KALDI_ERR text on stderr with a non-zero exit status (tools.py:138-145).
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -227,6 +228,26 @@ int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, 
     buf[n] = 0;
   }
   return (int)s.size();
+}
+
+int rs_result_pack(const rs_result *r, int32_t max_words, int32_t *out) {
+  if (!r || !out || max_words < 0) return ArgError("rs_result_pack: bad argument");
+  const int stride = max_words + 4;
+  for (size_t u = 0; u < r->r->utts.size(); u++) {
+    const rs::UttResult &ur = r->r->utts[u];
+    int32_t *rec = out + u * stride;
+    std::memset(rec, 0, sizeof(int32_t) * stride);
+    rec[0] = ur.status;
+    if (ur.status != RS_OK || ur.hyps.empty()) { rec[1] = -1; continue; }
+    const rs::Hypothesis &h = ur.hyps[0];
+    const int n = (int)std::min<size_t>(h.words.size(), (size_t)max_words);
+    rec[1] = n;
+    std::memcpy(rec + 2, h.words.data(), sizeof(int32_t) * n);
+    std::memcpy(rec + 2 + max_words, &h.graph_cost, 4);
+    std::memcpy(rec + 3 + max_words, &h.acoustic_cost, 4);
+  }
+  g_last_error.clear();
+  return RS_OK;
 }
 
 int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols) {

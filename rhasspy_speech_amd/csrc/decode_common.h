@@ -1,0 +1,274 @@
+// Device helpers shared by the LDS-resident decoders (decode_dense.hip, decode_reg.hip): order-preserving cost
+// keys, block reductions, exact radix select, and the final-cost / traceback / result stage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+
+#include "kernels.h"
+
+namespace rs {
+namespace dd {
+
+#define RS_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define RS_NOARC 0xFFFFFFFFu
+
+__device__ __forceinline__ unsigned OrderedBits(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float FromOrdered(unsigned u) {
+  unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ unsigned long long PackKey(float cost, unsigned arc) {
+  return ((unsigned long long)OrderedBits(cost) << 32) | arc;
+}
+__device__ __forceinline__ float KeyCost(unsigned long long k) {
+  return k == RS_EMPTY ? INFINITY : FromOrdered((unsigned)(k >> 32));
+}
+
+template <int NW>
+struct Red {
+  float f[NW];
+  int i[NW];
+  int c0[NW], c1[NW], c2[NW];
+  float bf[2];
+  int bi[4];
+  int changed;
+  unsigned hist[256];
+  unsigned long long ctr[8];
+  double dsum[2 * NW];
+};
+
+template <int NT>
+__device__ __forceinline__ void BlockMinArg(Red<NT / 64> &r, float v, int idx, float *ov, int *oi) {
+  constexpr int NW = NT / 64;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float xv = __shfl_xor(v, o, 64);
+    int xi = __shfl_xor(idx, o, 64);
+    if (xv < v || (xv == v && xi < idx)) { v = xv; idx = xi; }
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { r.f[w] = v; r.i[w] = idx; }
+  __syncthreads();
+  float bv = r.f[0];
+  int bi = r.i[0];
+#pragma unroll
+  for (int k = 1; k < NW; k++) if (r.f[k] < bv || (r.f[k] == bv && r.i[k] < bi)) { bv = r.f[k]; bi = r.i[k]; }
+  *ov = bv;
+  *oi = bi;
+  __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void BlockSum3(Red<NT / 64> &r, int a, int b, int c, int *oa, int *ob, int *oc) {
+  constexpr int NW = NT / 64;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { r.c0[w] = a; r.c1[w] = b; r.c2[w] = c; }
+  __syncthreads();
+  int sa = 0, sb = 0, sc = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { sa += r.c0[k]; sb += r.c1[k]; sc += r.c2[k]; }
+  *oa = sa; *ob = sb; *oc = sc;
+  __syncthreads();
+}
+
+// exact k-th smallest (0-based) of the finite entries of cost[0..S): radix select on the order-preserving bit
+// pattern.  The bits shared by the smallest and the largest finite cost are skipped (a frame's costs share sign,
+// exponent and usually several mantissa bits, which would otherwise pile every element onto one histogram bin
+// and serialise the LDS atomics); the 256-bin prefix scan of each pass is one wavefront of shuffles.
+template <int NT>
+__device__ float KthSmallest(Red<NT / 64> &r, const float *cost, int S, int k, float min_cost) {
+  constexpr int NW = NT / 64;
+  // block max of the finite costs
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < S; i += NT) { const float c = cost[i]; if (c < INFINITY) mx = fmaxf(mx, c); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) r.f[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = r.f[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) mx = fmaxf(mx, r.f[w]);
+  __syncthreads();
+  const unsigned umin = OrderedBits(min_cost), umax = OrderedBits(mx);
+  const unsigned diff = umin ^ umax;
+  if (diff == 0) return min_cost;
+  const int nbits = (32 - __clz((int)diff) + 7) & ~7;          // differing low bits, rounded up to whole digits
+  unsigned mask = nbits >= 32 ? 0u : ~((1u << nbits) - 1u);
+  unsigned prefix = umin & mask;
+  int kk = k;
+  for (int shift = nbits - 8; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += NT) r.hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += NT) {
+      const float c = cost[i];
+      if (c < INFINITY) {
+        unsigned u = OrderedBits(c);
+        if ((u & mask) == prefix) atomicAdd(&r.hist[(u >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const int h0 = (int)r.hist[4 * l], h1 = (int)r.hist[4 * l + 1], h2 = (int)r.hist[4 * l + 2], h3 = (int)r.hist[4 * l + 3];
+      const int tot = h0 + h1 + h2 + h3;
+      int inc = tot;                       // inclusive scan over lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if (l >= o) inc += v; }
+      const int exc = inc - tot;
+      if (exc <= kk && kk < inc) {
+        int acc = exc, bb = 4 * l;
+        if (acc + h0 <= kk) { acc += h0; bb++; if (acc + h1 <= kk) { acc += h1; bb++; if (acc + h2 <= kk) { acc += h2; bb++; } } }
+        r.bi[1] = bb;
+        r.bi[2] = kk - acc;
+      }
+    }
+    __syncthreads();
+    prefix |= ((unsigned)r.bi[1]) << shift;
+    mask |= 255u << shift;
+    kk = r.bi[2];
+  }
+  __syncthreads();
+  return FromOrdered(prefix);
+}
+
+// Final costs (ComputeFinalCosts), best-path traceback (GetBestPath) and result records.  cost_cur = the last frame's
+// dense costs in LDS; bp = back-pointer rows [T+1][S] in HBM; smem = the dynamic LDS region (reused for staging).
+template <int NT>
+__device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const BatchGeom &g, const float *__restrict__ loglikes, int ld,
+                                const DenseWork &w, const float *cost_cur, const int *bp, const float *finfo, unsigned char *smem,
+                                int smem_bytes, int u, int T, int S, size_t ll_base, int error, unsigned long long n_expanded,
+                                unsigned long long n_arcs, unsigned long long n_insert, unsigned long long n_alive,
+                                int max_active_frames, int min_active_frames) {
+  constexpr int NW = NT / 64;
+  const int tid = threadIdx.x;
+  const float INF = INFINITY;
+  float lv1 = INF, lv2 = INF;
+  int li1 = 0x7fffffff, li2 = 0x7fffffff;
+  if (!error)
+    for (int s = tid; s < S; s += NT) {
+      const float c = cost_cur[s];
+      if (!(c < INF)) continue;
+      const float wf = c + h.final_cost[s];
+      if (wf < lv1 || (wf == lv1 && s < li1)) { lv1 = wf; li1 = s; }
+      if (c < lv2 || (c == lv2 && s < li2)) { lv2 = c; li2 = s; }
+    }
+  float b1, b2;
+  int i1, i2;
+  BlockMinArg<NT>(red, lv1, li1, &b1, &i1);
+  BlockMinArg<NT>(red, lv2, li2, &b2, &i2);
+  // counters: block sums via LDS atomics on the histogram scratch (reused)
+  for (int i = tid; i < 8; i += NT) red.ctr[i] = 0;
+  __syncthreads();
+  unsigned long long *ctr = red.ctr;
+  atomicAdd(&ctr[0], n_expanded);
+  atomicAdd(&ctr[1], n_arcs);
+  atomicAdd(&ctr[2], n_insert);
+  atomicAdd(&ctr[3], n_alive);
+  __syncthreads();
+  const bool reached = b1 < INF;
+  const bool ok = !error && T > 0 && b2 < INF;
+  // ---- traceback (GetBestPath).  The back-pointer rows are staged through LDS a block of frames at a time so
+  // that the inherently sequential walk runs at LDS latency; arc sources come from LDS too when they fit.
+  int *stage = reinterpret_cast<int *>(smem);
+  const int stage_ints = smem_bytes / 4;
+  const bool src_in_lds = (h.num_arcs + S) <= stage_ints / 2 && h.num_arcs > 0;
+  int *lds_src = stage;                                   // [num_arcs]
+  int *rows = src_in_lds ? stage + h.num_arcs : stage;    // staged back-pointer rows
+  const int rows_cap = (stage_ints - (src_in_lds ? h.num_arcs : 0)) / S;
+  int *path = w.path + (size_t)u * w.path_cap * 2;        // (arc, source frame) pairs, last arc first
+  int path_len = 0;
+  __syncthreads();
+  if (ok) {
+    if (src_in_lds) for (int i = tid; i < h.num_arcs; i += NT) lds_src[i] = h.arc_srcx[i];
+    int F = T, st = reached ? i1 : i2;
+    bool done = false;
+    while (!done) {
+      const int lo = F - rows_cap + 1 > 0 ? F - rows_cap + 1 : 0;     // stage rows lo..F
+      const int nrow = F - lo + 1;
+      __syncthreads();
+      for (int i = tid; i < nrow * S; i += NT) rows[i] = bp[(size_t)lo * S + i];
+      __syncthreads();
+      if (tid == 0) {
+        while (true) {
+          const int arc = rows[(F - lo) * S + st];
+          if (arc < 0) { done = true; break; }
+          const int sx = src_in_lds ? lds_src[arc] : h.arc_srcx[arc];      // source state | (epsilon arc ? 1 << 31 : 0)
+          const int src = sx & 0x7fffffff;
+          const bool emitting = sx >= 0;
+          const int Fs = emitting ? F - 1 : F;
+          if (path_len < w.path_cap) { path[2 * path_len] = arc; path[2 * path_len + 1] = Fs; }
+          path_len++;
+          st = src;
+          F = Fs;
+          if (F < lo) break;       // need older rows
+        }
+        red.bi[0] = done ? 1 : 0; red.bi[1] = F; red.bi[2] = st; red.bi[3] = path_len;
+      }
+      __syncthreads();
+      done = red.bi[0] != 0; F = red.bi[1]; st = red.bi[2]; path_len = red.bi[3];
+    }
+  }
+  __syncthreads();
+  // ---- path costs and words, in parallel over the path
+  const bool path_ok = ok && path_len <= w.path_cap;
+  double pg = 0.0, pa = 0.0;
+  if (path_ok) {
+    for (int i = tid; i < path_len; i += NT) {
+      const int arc = path[2 * i], Fs = path[2 * i + 1];
+      const int4 a = h.arcs[arc];
+      pg += (double)__int_as_float(a.z);
+      if (a.x != 0) {
+        const float off = finfo[Fs * 4 + 0];
+        const float lk = loglikes[(ll_base + Fs) * ld + (a.x - 1)];
+        const float link_ac = off - lk;             // ForwardLink::acoustic_cost
+        pa += (double)(link_ac - off);              // GetRawLattice :166-172
+      }
+      path[2 * i + 1] = a.y;                        // olabel replaces the frame
+    }
+  }
+  // deterministic block sums in double
+  double *dsum = red.dsum;
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) { pg += __shfl_xor(pg, o2, 64); pa += __shfl_xor(pa, o2, 64); }
+  if ((tid & 63) == 0) { dsum[(tid >> 6) * 2] = pg; dsum[(tid >> 6) * 2 + 1] = pa; }
+  __syncthreads();
+  if (tid < 64) {
+    // wave 0: ordered compaction of the word labels (path is stored last-arc-first)
+    int *words = w.out_words + (size_t)u * w.max_words;
+    int nw = 0;
+    bool truncated = false;
+    if (path_ok) {
+      for (int base = path_len - 1; base >= 0; base -= 64) {
+        const int i = base - tid;
+        const int wl = (i >= 0) ? path[2 * i + 1] : 0;
+        const unsigned long long m = __ballot(wl != 0);
+        if (wl != 0) {
+          const int pos = nw + __popcll(m & ((1ull << tid) - 1ull));
+          if (pos < w.max_words) words[pos] = wl; else truncated = true;
+        }
+        nw += __popcll(m);
+      }
+    }
+    truncated = __any(truncated) || nw > w.max_words;
+    if (tid == 0) {
+      double graph = 0.0, ac = 0.0;
+      for (int k = 0; k < NW; k++) { graph += dsum[k * 2]; ac += dsum[k * 2 + 1]; }
+      if (ok && reached) graph += (double)h.final_cost[i1];
+      w.out_nwords[u] = (!path_ok || truncated) ? -1 : nw;
+      float *oc = w.out_costs + (size_t)u * 4;
+      oc[0] = (float)graph; oc[1] = (float)ac; oc[2] = reached ? b1 : b2; oc[3] = reached ? 1.f : 0.f;
+      long long *c8 = w.counters + (size_t)u * 8;
+      for (int i = 0; i < 4; i++) c8[i] = (long long)ctr[i];
+      c8[4] = 0; c8[5] = max_active_frames; c8[6] = min_active_frames; c8[7] = error ? 2 : 0;
+    }
+  }
+}
+
+}  // namespace dd
+}  // namespace rs

@@ -82,14 +82,28 @@ __device__ __forceinline__ void BlockMinArg(BlockCtx<NT> &c, float v, int idx, f
 }
 
 // k-th smallest (0-based) cost of toks[0..n): exact radix select on the order-preserving bit pattern
-// (the value std::nth_element leaves at position k, lattice-faster-decoder.cc:679-695).  The 256-bin prefix
-// scan of each pass is done by one wavefront with shuffles (4 bins per lane).
+// (the value std::nth_element leaves at position k, lattice-faster-decoder.cc:679-695).  Bits shared by the
+// smallest and largest cost are skipped (they would pile every token onto one histogram bin); the 256-bin prefix
+// scan of each pass is one wavefront of shuffles.
 template <int NT>
-__device__ float BlockKthSmallest(BlockCtx<NT> &c, const int4 *toks, int n, int k) {
-  unsigned prefix = 0, mask = 0;
+__device__ float BlockKthSmallest(BlockCtx<NT> &c, const int4 *toks, int n, int k, float min_cost) {
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += NT) mx = fmaxf(mx, __int_as_float(toks[i].y));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) c.red_f[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = c.red_f[0];
+  for (int w = 1; w < NT / 64; w++) mx = fmaxf(mx, c.red_f[w]);
+  __syncthreads();
+  const unsigned umin = OrderedBits(min_cost), umax = OrderedBits(mx);
+  const unsigned diff = umin ^ umax;
+  if (diff == 0) return min_cost;
+  const int nbits = (32 - __clz((int)diff) + 7) & ~7;
+  unsigned mask = nbits >= 32 ? 0u : ~((1u << nbits) - 1u);
+  unsigned prefix = umin & mask;
   int kk = k;
-  for (int pass = 0; pass < 4; pass++) {
-    const int shift = 24 - 8 * pass;
+  for (int shift = nbits - 8; shift >= 0; shift -= 8) {
     for (int i = threadIdx.x; i < 256; i += NT) c.hist[i] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += NT) {
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       const float beam_cutoff = best_cost + o.beam;
       float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
       bool decided = false;
-      if (n_cur > o.max_active) max_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.max_active);
+      if (n_cur > o.max_active) max_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.max_active, best_cost);
       if (max_active_cutoff < beam_cutoff) {
         adaptive_beam = max_active_cutoff - best_cost + o.beam_delta;
         cur_cutoff = max_active_cutoff;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       if (!decided) {
         if (n_cur > o.min_active) {
           if (o.min_active == 0) min_active_cutoff = best_cost;
-          else min_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.min_active);
+          else min_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.min_active, best_cost);
         }
         if (min_active_cutoff > beam_cutoff) {
           adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;

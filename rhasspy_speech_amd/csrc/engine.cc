@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace rs {
@@ -52,6 +53,12 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
              const rs_decode_opts &opts)
     : opts_(opts) {
   if (const char *e = std::getenv("RS_FORCE_SPARSE_DECODER")) force_sparse_ = e[0] == '1';
+  if (const char *e = std::getenv("RS_SUBBATCHES")) max_groups_ = std::atoi(e);
+  if (const char *e = std::getenv("RS_DECODER")) {
+    const std::string v(e);
+    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : 0;
+    if (decoder_choice_ == 3) force_sparse_ = true;
+  }
   if (opts_.frame_subsampling_factor != 1)
     Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
   if (opts_.frames_per_chunk <= 0) Fail("frames-per-chunk must be positive");
@@ -121,6 +128,7 @@ Model::~Model() {
   if (h_pcm_pinned_) (void)hipHostFree(h_pcm_pinned_);
   if (d_pcm_) (void)hipFree(d_pcm_);
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
 }
 
 void *Model::UploadBytes(const void *p, size_t bytes) {
@@ -170,6 +178,7 @@ void Model::ToDevice() {
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw DeviceError(std::string("this library is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
   RS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  RS_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   // ---- MFCC tables
   const MfccTables &t = fc_.mfcc;
   mfcc_dev_.win = t.win; mfcc_dev_.shift = t.shift; mfcc_dev_.padded = t.padded; mfcc_dev_.nbins = t.nbins; mfcc_dev_.nceps = t.nceps;
@@ -245,6 +254,11 @@ void Model::ToDevice() {
     hclg_dev_.num_ieps = Upload(hclg_.num_ieps);
     hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
     hclg_dev_.arc_src = Upload(src);
+    {
+      std::vector<int> srcx(A);
+      for (size_t a = 0; a < A; a++) srcx[a] = src[a] | (arcs[a].x == 0 ? (int)0x80000000 : 0);
+      hclg_dev_.arc_srcx = Upload(srcx);
+    }
     hclg_dev_.final_cost = Upload(hclg_.final_cost);
     // reverse graph for the dense (pull) decoder: in-arcs per destination state, in forward-arc order
     dense_ok_ = DenseDecodeFits(hclg_.num_states(), am_.nnet.output_dim);
@@ -270,6 +284,31 @@ void Model::ToDevice() {
       rev_dev_.num_eps_dst = (int)eps_dst.size();
       rev_dev_.in_begin_e_host_total = (int)ie.size();
       rev_dev_.in_begin_x_host_total = (int)ix.size();
+      // register-resident variant: state s -> thread s % NT, slot s / NT; needs <= 4 slots and a bounded number of
+      // in-arcs per thread (KE/KX of the kernel instantiations in decode_reg.hip)
+      const int P = am_.nnet.output_dim;
+      for (int variant = 0; variant < 2 && reg_dev_.nt == 0 && P < (1 << 28); variant++) {
+        const int NT = variant == 0 ? 256 : 1024, KE = variant == 0 ? 16 : 8, KX = variant == 0 ? 16 : 8;
+        if (S > 4 * NT) continue;
+        std::vector<int4> et((size_t)KE * NT, make_int4(-1, 0, 0, 0)), xt((size_t)KX * NT, make_int4(-1, 0, 0, 0));
+        std::vector<int> ne(NT, 0), nx(NT, 0);
+        bool ok = true;
+        for (size_t a = 0; a < A && ok; a++) {      // forward-arc order => per-thread lists are sorted by arc index
+          const int4 &fa = arcs[a];
+          const int t = fa.w % NT, slot = fa.w / NT;
+          if (fa.x == 0) {
+            if (nx[t] >= KX) { ok = false; break; }
+            xt[(size_t)nx[t]++ * NT + t] = make_int4(src[a], slot, fa.z, (int)a);
+          } else {
+            if (ne[t] >= KE) { ok = false; break; }
+            et[(size_t)ne[t]++ * NT + t] = make_int4(src[a], fa.x | (slot << 28), fa.z, (int)a);
+          }
+        }
+        if (!ok) continue;
+        reg_dev_.nt = NT;
+        reg_dev_.e_tab = static_cast<int4 *>(UploadBytes(et.data(), et.size() * sizeof(int4)));
+        reg_dev_.x_tab = static_cast<int4 *>(UploadBytes(xt.data(), xt.size() * sizeof(int4)));
+      }
     }
   }
   RS_HIP(hipDeviceSynchronize());
@@ -360,12 +399,47 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   ToDevice();
   std::lock_guard<std::mutex> lk(mu_);
   RS_HIP(hipSetDevice(opts_.device_id));
-  hipStream_t s = user_stream ? user_stream : stream_;
+  if (nbest < 1) Fail("nbest must be >= 1");
   auto wall0 = std::chrono::steady_clock::now();
   std::unique_ptr<Result> res(new Result());
   res->utts.resize(n_utts);
   if (n_utts == 0) return res;
-  if (nbest < 1) Fail("nbest must be >= 1");
+  // two concurrent groups unless the caller pinned a stream, the batch is small, or RS_SUBBATCHES=1
+  const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
+  if (ngroups == 1) {
+    DecodeGroup(d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : stream_, streaming, arena_[0],
+                res->utts.data(), res->timings);
+  } else {
+    const int half = (n_utts + 1) / 2;
+    float t2[2][8] = {{0}, {0}};
+    std::exception_ptr err[2];
+    auto run = [&](int gi) {
+      try {
+        const int u0 = gi == 0 ? 0 : half, n = gi == 0 ? half : n_utts - half;
+        DecodeGroup(d_pcm, sample_offsets + u0, n, nbest, lat_scale, gi == 0 ? stream_ : stream2_, streaming, arena_[gi],
+                    res->utts.data() + u0, t2[gi]);
+      } catch (...) {
+        err[gi] = std::current_exception();
+      }
+    };
+    std::thread th(run, 1);
+    run(0);
+    th.join();
+    for (int gi = 0; gi < 2; gi++) if (err[gi]) std::rethrow_exception(err[gi]);
+    for (int k = 0; k < 8; k++) res->timings[k] = t2[0][k] + t2[1][k];   // stage times add up; they overlap in wall time
+  }
+  res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  return res;
+}
+
+// One group of utterances, start to finish, on one stream with one arena.  DecodeBatchDevice runs two groups
+// concurrently (two host threads, two streams) so that the latency-bound stages of one group (search, iVector)
+// overlap the MFMA-bound stage (TDNN) of the other.
+void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
+                        hipStream_t s, bool streaming, DeviceArena &arena_, UttResult *out_utts, float *timings) {
+  RS_HIP(hipSetDevice(opts_.device_id));
+  auto wall0 = std::chrono::steady_clock::now();
+  if (n_utts == 0) return;
   const Nnet &nn = am_.nnet;
   const int C = fc_.mfcc.nceps, P = nn.output_dim;
   // ---- geometry
@@ -378,7 +452,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     maxT = std::max(maxT, T[u]);
     row_base[u + 1] = row_base[u] + T[u] + L_ + R_;
     frame_base[u + 1] = frame_base[u] + T[u];
-    res->utts[u].num_frames = T[u];
+    out_utts[u].num_frames = T[u];
   }
   const int rows = row_base[n_utts];
   const int guard = L_ + R_ + 8;
@@ -626,7 +700,8 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   tm.Mark();
   // ---- decode
   const bool want_lattice = (nbest > 1 || lat_scale != 1.0f);
-  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_;
+  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
+  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
   DecodeOptsDev dopts;
   dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
   dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
@@ -646,7 +721,8 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     dw.frame_info = w.frame_info; dw.max_words = max_words;
     dw.path_cap = 4 * (maxT + 2);
     dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
-    LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
+    if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, s);
+    else LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
   } else {
     w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
     w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
@@ -672,7 +748,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   RS_HIP(hipGetLastError());
   tm.Mark();
   for (int u = 0; u < n_utts; u++) {
-    UttResult &ur = res->utts[u];
+    UttResult &ur = out_utts[u];
     for (int k = 0; k < 8; k++) ur.counters[k] = h_ctr[(size_t)u * 8 + k];
     if (T[u] == 0) {
       ur.status = RS_ERR_DECODE;
@@ -734,7 +810,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     std::vector<std::vector<const LatArc *>> per(n_utts);
     for (auto &a : h_arcs) if (a.utt >= 0 && a.utt < n_utts) per[a.utt].push_back(&a);
     for (int u = 0; u < n_utts; u++) {
-      UttResult &ur = res->utts[u];
+      UttResult &ur = out_utts[u];
       if (ur.status != RS_OK) continue;
       RawLattice lat;
       std::unordered_map<int, int> id;
@@ -765,11 +841,11 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
         ur.hyps.push_back(std::move(hy));
       }
     }
-    res->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
+    timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
   }
   if (opts_.keep_intermediates) {
     for (int u = 0; u < n_utts; u++) {
-      UttResult &ur = res->utts[u];
+      UttResult &ur = out_utts[u];
       ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? ivrow_base[u + 1] - ivrow_base[u] : 0;
       if (T[u] == 0) continue;
       ur.feats.resize((size_t)T[u] * C);
@@ -785,13 +861,12 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
       }
     }
   }
-  res->timings[1] = tm.Ms(0, 1);
-  res->timings[2] = tm.Ms(1, 2);
-  res->timings[3] = tm.Ms(2, 3);
-  res->timings[4] = tm.Ms(3, 4);
-  res->timings[5] = tm.Ms(4, 5);
-  res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  return res;
+  timings[1] = tm.Ms(0, 1);
+  timings[2] = tm.Ms(1, 2);
+  timings[3] = tm.Ms(2, 3);
+  timings[4] = tm.Ms(3, 4);
+  timings[5] = tm.Ms(4, 5);
+  timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 }
 
 }  // namespace rs

@@ -78,6 +78,8 @@ class Model {
   const Hclg &hclg() const { return hclg_; }
 
  private:
+  void DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
+                   hipStream_t s, bool streaming, DeviceArena &arena, UttResult *out_utts, float *timings);
   template <typename T> T *Upload(const std::vector<T> &v);
   void *UploadBytes(const void *p, size_t bytes);
   void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
@@ -92,7 +94,10 @@ class Model {
   std::mutex mu_;
   hipStream_t stream_ = nullptr;
   std::vector<void *> owned_;         // persistent device allocations
-  DeviceArena arena_;
+  DeviceArena arena_[2];               // one per concurrent utterance group
+  hipStream_t stream2_ = nullptr;
+  int max_groups_ = 1;                 // RS_SUBBATCHES=2: two concurrent utterance groups (measured: no gain on MI355X, the
+                                       // latency-bound kernels take CU resources from the GEMMs)
   // pinned staging for host-buffer batches
   int16_t *h_pcm_pinned_ = nullptr;
   size_t h_pcm_cap_ = 0;
@@ -108,6 +113,8 @@ class Model {
   float *d_log_priors_ = nullptr;
   HclgDev hclg_dev_{};
   RevGraphDev rev_dev_{};
+  RegGraphDev reg_dev_{};
+  int decoder_choice_ = 0;      // RS_DECODER=reg|dense|sparse forces a kernel variant (tests); 0 = automatic
   bool dense_ok_ = false;
   bool force_sparse_ = false;   // RS_FORCE_SPARSE_DECODER=1: always use the general (token-list) kernel
   int L_ = 0, R_ = 0;

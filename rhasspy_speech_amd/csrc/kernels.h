@@ -135,6 +135,7 @@ struct HclgDev {
   const uint32_t *num_ieps;    // S
   const int4 *arcs;            // {pdf+1 (0 = epsilon), olabel, weight bits, nextstate}
   const int *arc_src;          // source state of each arc
+  const int *arc_srcx;         // source state | (1 << 31 if the arc is an epsilon arc): one load per traceback hop
   const float *final_cost;     // S
 };
 struct DecodeOptsDev {
@@ -185,6 +186,15 @@ struct DenseWork {
   int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
   int path_cap;
 };
+// Register-resident variant (decode_reg.hip): thread t of an NT-thread workgroup owns states {t, t + NT, ...} (<= 4) and
+// keeps their incoming arcs in VGPRs.  Tables are [arc slot][thread] so that loading them is coalesced.
+struct RegGraphDev {
+  int nt = 0;                 // 0 = graph does not fit this variant
+  const int4 *e_tab;          // [KE][nt] {src state (-1 unused), (pdf + 1) | slot << 28, weight bits, forward arc index}
+  const int4 *x_tab;          // [KX][nt] {src state (-1 unused), slot, weight bits, forward arc index}
+};
+bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
+                     const float *loglikes, int ld, const DenseWork &w, hipStream_t s);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,

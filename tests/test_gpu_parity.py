@@ -124,20 +124,23 @@ def test_gpu_matches_oracle_on_fresh_inputs(case_cache):
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_noiv_u2", "zam_u0"])
-def test_dense_and_sparse_decoders_agree(case_cache, name, monkeypatch):
-    """The LDS-resident pull decoder (small graphs) and the general token-list decoder are the same search."""
+def test_decoder_variants_agree(case_cache, name, monkeypatch):
+    """The register-resident, the LDS-resident (pull) and the general token-list decoder are the same search."""
     from rhasspy_speech_amd import synth
-    dense, pcm = make_model(case_cache, name)
-    monkeypatch.setenv("RS_FORCE_SPARSE_DECODER", "1")
-    sparse, _ = make_model(case_cache, name)
-    monkeypatch.delenv("RS_FORCE_SPARSE_DECODER")
+    models = {}
+    for variant in ("sparse", "dense", "reg"):
+        monkeypatch.setenv("RS_DECODER", variant)
+        models[variant], pcm = make_model(case_cache, name)
+    monkeypatch.delenv("RS_DECODER")
     pcms = [pcm] + [synth.synth_utterance(300 + i, n) for i, n in enumerate([48000, 17000, 33000])]
-    a, b = dense.decode_batch(pcms), sparse.decode_batch(pcms)
-    for u in range(len(pcms)):
-        assert a.words(u) == b.words(u)
-        np.testing.assert_allclose(a.costs(u), b.costs(u), rtol=1e-6)
-        # same number of live tokens summed over frames => same token sets
-        assert a.counters(u)[3] == b.counters(u)[3]
+    ref = models["sparse"].decode_batch(pcms)
+    for variant in ("dense", "reg"):
+        got = models[variant].decode_batch(pcms)
+        for u in range(len(pcms)):
+            assert got.words(u) == ref.words(u), variant
+            np.testing.assert_allclose(got.costs(u), ref.costs(u), rtol=1e-6)
+            # same number of live tokens summed over frames => same token sets
+            assert got.counters(u)[3] == ref.counters(u)[3], variant
 
 
 STREAM_CASES = [n for n in cases.CASES if n not in ("zam_u1",)]
