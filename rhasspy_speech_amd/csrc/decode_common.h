@@ -37,6 +37,8 @@ struct Red {
   int bi[4];
   int changed;
   unsigned hist[256];
+  float cand[64];
+  int ncand;
   unsigned long long ctr[8];
   double dsum[2 * NW];
 };
@@ -135,6 +137,77 @@ __device__ float KthSmallest(Red<NT / 64> &r, const float *cost, int S, int k, f
   }
   __syncthreads();
   return FromOrdered(prefix);
+}
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int DppZ(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND); }
+// inclusive prefix sum over the 64 lanes of a wavefront (DPP row shifts + row broadcasts, no LDS traffic)
+__device__ __forceinline__ int WaveScanIncl(int v) {
+  v += DppZ<0x111, 0xF, true>(v);      // row_shr:1
+  v += DppZ<0x112, 0xF, true>(v);      // row_shr:2
+  v += DppZ<0x114, 0xF, true>(v);      // row_shr:4
+  v += DppZ<0x118, 0xF, true>(v);      // row_shr:8
+  v += DppZ<0x142, 0xA, false>(v);     // row_bcast:15 into rows 1 and 3
+  v += DppZ<0x143, 0xC, false>(v);     // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// Exact k-th smallest (0-based) of the finite entries of cost[0..S), all of which lie in [lo, hi]: ONE histogram pass
+// over 256 linear bins (float subtract / multiply / truncate are monotone, so bin order agrees with value order), every
+// wave scans the histogram itself, then the handful of values in the bin that holds rank k are ranked directly.
+// Falls back to the radix select when that bin is crowded.  Requires r.hist[] == 0 and r.ncand == 0 on entry and
+// leaves them so.
+template <int NT>
+__device__ float KthSmallestBinned(Red<NT / 64> &r, const float *cost, int S, int k, float lo, float hi) {
+  if (!(hi > lo)) return lo;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float scale = 255.0f / (hi - lo);
+  for (int i = tid; i < S; i += NT) {
+    const float c = cost[i];
+    if (c < INFINITY) { int b = (int)((c - lo) * scale); b = b > 255 ? 255 : b; atomicAdd(&r.hist[b], 1u); }
+  }
+  __syncthreads();
+  const uint4 hv = *reinterpret_cast<const uint4 *>(&r.hist[4 * lane]);
+  const int h0 = (int)hv.x, h1 = (int)hv.y, h2 = (int)hv.z, h3 = (int)hv.w;
+  const int tot = h0 + h1 + h2 + h3;
+  const int inc = WaveScanIncl(tot), exc = inc - tot;
+  const bool hit = (exc <= k) & (k < inc);
+  int bb = 4 * lane, acc = exc, m = h0;
+  if (acc + h0 <= k) { acc += h0; bb++; m = h1; if (acc + h1 <= k) { acc += h1; bb++; m = h2; if (acc + h2 <= k) { acc += h2; bb++; m = h3; } } }
+  const unsigned long long hm = __ballot(hit);
+  if (hm == 0ull) {             // k >= number of finite entries: caller error; behave like the radix select on its maximum
+    __syncthreads();
+    for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
+    __syncthreads();
+    return hi;
+  }
+  const int hl = __ffsll((long long)hm) - 1;
+  const int bin = __builtin_amdgcn_readlane(bb, hl), kk = k - __builtin_amdgcn_readlane(acc, hl), cnt = __builtin_amdgcn_readlane(m, hl);
+  if (cnt > 64) {
+    __syncthreads();
+    const float v = KthSmallest<NT>(r, cost, S, k, lo);
+    for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
+    __syncthreads();
+    return v;
+  }
+  for (int i = tid; i < S; i += NT) {
+    const float c = cost[i];
+    if (c < INFINITY) {
+      int b = (int)((c - lo) * scale); b = b > 255 ? 255 : b;
+      if (b == bin) r.cand[atomicAdd(&r.ncand, 1)] = c;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
+  if (tid < cnt) {
+    const float v = r.cand[tid];
+    int lt = 0, le = 0;
+    for (int j = 0; j < cnt; j++) { const float x = r.cand[j]; lt += (int)(x < v); le += (int)(x <= v); }
+    if (lt <= kk && kk < le) r.bf[0] = v;
+  }
+  if (tid == 0) r.ncand = 0;
+  __syncthreads();
+  return r.bf[0];
 }
 
 // Final costs (ComputeFinalCosts), best-path traceback (GetBestPath) and result records.  cost_cur = the last frame's

@@ -1,14 +1,21 @@
 // Register-resident token passing for small grammar graphs (the rhasspy use case: a few hundred to a few
-// thousand HCLG states).
+// thousand HCLG states, a few thousand arcs).
 //
 // Same search and same results as decode_dense.hip / decode_kernels.hip (reference:
 // lattice-faster-decoder.cc:56-73,644-887).  Observation that drives the design: with a dense state table the set
-// of arcs a thread has to evaluate is the same on every frame.  So thread t OWNS the states {t, t+NT, ...} and
-// their incoming arcs for the whole utterance: arc records (source state, pdf, weight, arc id) are loaded into
-// VGPRs once, and the log-likelihoods of exactly those arcs are fetched from HBM/L2 one frame ahead.  A frame is
-// then a handful of independent LDS gathers (source-token costs) plus two block reductions instead of chains of
-// dependent LDS reads: ~10x fewer cycles per frame than the LDS-graph variant on the bench graph.
-// LDS holds only the dense cost array of the current frame and the packed keys of the frame under construction.
+// of arcs a workgroup has to evaluate is the same on every frame.  So the ARCS are dealt out to the threads once
+// (arc i -> thread i % NT) and stay in VGPRs for the whole utterance: {LDS address of the source cost, LDS address
+// of the destination key, pdf, weight, arc id}; the log-likelihoods of exactly those arcs are fetched from HBM/L2
+// one frame ahead.  A frame is then
+//   * one pass over the registers: independent LDS gathers of the source costs, a few VALU ops per arc and one
+//     non-returning 64-bit LDS atomic min per surviving arc (key = ordered cost bits << 32 | arc id, so the
+//     result does not depend on the order in which arcs arrive),
+//   * the same for the epsilon arcs, repeated to the fixpoint (the number of rounds is the epsilon depth of the
+//     graph, known on the host, so no convergence vote is needed for acyclic epsilon subgraphs),
+//   * a pass over the states that commits keys -> costs / back-pointers and collects the next frame's statistics,
+//   * three block reductions done with DPP row rotations + readlane (no ds_bpermute chains) and ONE barrier each.
+// Everything in the frame loop is written branch-free on purpose: hipcc turns conditional loads and short-circuit
+// conditions into exec-mask branches with a wait in front of each, which is what made the first version slow.
 // Compiled with -ffp-contract=off.
 #include "decode_common.h"
 
@@ -21,16 +28,63 @@ using namespace dd;
 #define RS_T(i) do { } while (0)
 #endif
 
-template <int NT, int MAXS, int KE, int KX>
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ unsigned Dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// wave-wide reductions: butterfly of row rotations inside each row of 16 lanes, then the four row results through
+// SGPRs.  The result is wave-uniform.
+__device__ __forceinline__ unsigned WaveMinU(unsigned v) {
+  v = min(v, Dpp<0x121>(v));      // row_ror:1
+  v = min(v, Dpp<0x122>(v));      // row_ror:2
+  v = min(v, Dpp<0x124>(v));      // row_ror:4
+  v = min(v, Dpp<0x128>(v));      // row_ror:8
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ unsigned WaveMaxU(unsigned v) {
+  v = max(v, Dpp<0x121>(v));
+  v = max(v, Dpp<0x122>(v));
+  v = max(v, Dpp<0x124>(v));
+  v = max(v, Dpp<0x128>(v));
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ int WaveSum(int x) {
+  unsigned v = (unsigned)x;
+  v += Dpp<0x121>(v);
+  v += Dpp<0x122>(v);
+  v += Dpp<0x124>(v);
+  v += Dpp<0x128>(v);
+  return __builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) +
+         __builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ float OrderedToFloat(unsigned u) {      // branch-free FromOrdered
+  return __uint_as_float(u ^ ((unsigned)((int)~u >> 31) | 0x80000000u));
+}
+__device__ __forceinline__ unsigned FloatToOrdered(float f) {      // branch-free OrderedBits
+  const unsigned b = __float_as_uint(f);
+  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
+}  // namespace
+
+template <int NT, int KE, int KX>
 __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg, DecodeOptsDev o, BatchGeom g,
                                                       const float *__restrict__ loglikes, int ld, DenseWork w, int smem_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / 64;
   __shared__ Red<NW> red;
-  const int u = blockIdx.x, tid = threadIdx.x;
+  __shared__ int4 xr[2][NW];       // cross-wave exchange, ping-pong so that a reduction needs one barrier
+  int rb = 0;
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = g.d_num_frames[u], S = h.num_states;
-  unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem);
-  float *cost_cur = reinterpret_cast<float *>(smem + (((size_t)S * 8 + 15) & ~(size_t)15));
+  float *cost_cur = reinterpret_cast<float *>(smem);                                       // [S + 1], [S] = +inf forever
+  unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem + rg.key_base);   // [S + 1], [S] = empty forever
   int *bp = w.bp + (size_t)u * (g.max_frames + 1) * S;
   float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
   const float INF = INFINITY;
@@ -38,40 +92,36 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   unsigned long long n_expanded = 0, n_arcs = 0, n_insert = 0, n_alive = 0;
   int max_active_frames = 0, min_active_frames = 0;
 
-  // ---- my states and my arcs, in registers for the whole utterance
-  int4 ea[KE];         // {src state (-1 = unused), pdf + 1 | slot << 28, weight bits, forward arc index}
-  int4 xa[KX];         // {src state (-1 = unused), slot, weight bits, forward arc index}
+  // ---- my arcs, in registers for the whole utterance
+  int4 ea[KE];         // {src cost addr | dst key addr << 16, pdf, weight bits, forward arc index}
+  int4 xa[KX];         // {src key-high-word addr | dst key addr << 16, -, weight bits, forward arc index}
 #pragma unroll
   for (int a = 0; a < KE; a++) ea[a] = rg.e_tab[(size_t)a * NT + tid];
 #pragma unroll
   for (int a = 0; a < KX; a++) xa[a] = rg.x_tab[(size_t)a * NT + tid];
-  float mycost[MAXS];
-  unsigned long long key[MAXS];
-#pragma unroll
-  for (int j = 0; j < MAXS; j++) {
-    mycost[j] = INF;
-    key[j] = RS_EMPTY;
-    const int s = j * NT + tid;
-    if (s < S) { cost_cur[s] = INF; key_next[s] = RS_EMPTY; }
-  }
-  if (h.start % NT == tid) {
-#pragma unroll
-    for (int j = 0; j < MAXS; j++) if (h.start / NT == j) key[j] = PackKey(0.0f, RS_NOARC);
-  }
-  // log-likelihoods of my emitting arcs, fetched one frame ahead
+  for (int s = tid; s <= S; s += NT) { cost_cur[s] = INF; key_next[s] = RS_EMPTY; }
+  for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // KthSmallestBinned's invariant
+  if (tid == 0) red.ncand = 0;
+  // log-likelihoods of my emitting arcs, fetched one frame ahead (padding arcs read pdf 0 and never pass the cutoff)
   float ll_nxt[KE];
+#pragma unroll
+  for (int a = 0; a < KE; a++) ll_nxt[a] = 0.f;
   if (T > 0) {
     const float *row = loglikes + ll_base * ld;
 #pragma unroll
-    for (int a = 0; a < KE; a++) ll_nxt[a] = ea[a].x >= 0 ? row[(ea[a].y & 0x0FFFFFFF) - 1] : 0.f;
+    for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
   }
+  __syncthreads();
+  if (tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
+  __syncthreads();
   float closure_cutoff = o.beam;
   int error = 0;
-  __syncthreads();
+  // statistics of the committed frame, collected by the commit pass
+  float st_min = INF, st_max = -INF;
+  int st_arg = 0x7fffffff, st_cnt = 0;
 #ifdef RS_DECODE_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_last = clock64();
-  long long n_rounds = 0;
 #endif
 
   for (int f = -1; f < T; f++) {
@@ -82,36 +132,58 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       if (f + 1 < T) {
         const float *row = loglikes + (ll_base + f + 1) * ld;
 #pragma unroll
-        for (int a = 0; a < KE; a++) ll_nxt[a] = ea[a].x >= 0 ? row[(ea[a].y & 0x0FFFFFFF) - 1] : 0.f;
+        for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
       }
-      // ---- best token, token count (my states' costs are in registers)
-      float lv = INF;
-      int li = 0x7fffffff, cnt = 0;
+      // ---- best token (ties: smallest state), token count
+      float best_cost, max_cost;
+      int best_state, N;
+      {
+        const unsigned ub = FloatToOrdered(st_min);
+        const unsigned wm = WaveMinU(ub);
+        const unsigned wa = WaveMinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
+        const int wn = WaveSum(st_cnt);
+        const unsigned wx = WaveMaxU(FloatToOrdered(st_max));
+        if (lane == 0) xr[rb][wave] = make_int4((int)wm, (int)wa, wn, (int)wx);
+        __syncthreads();
+        unsigned long long bk = ~0ull;
+        unsigned bx = 0u;
+        N = 0;
 #pragma unroll
-      for (int j = 0; j < MAXS; j++) {
-        const float c = mycost[j];
-        if (c < INF) { cnt++; if (c < lv) { lv = c; li = j * NT + tid; } }
+        for (int k = 0; k < NW; k++) {
+          const int4 e = xr[rb][k];
+          const unsigned long long kk = ((unsigned long long)(unsigned)e.x << 32) | (unsigned)e.y;
+          bk = kk < bk ? kk : bk;
+          N += e.z;
+          bx = max(bx, (unsigned)e.w);
+        }
+        rb ^= 1;
+        max_cost = OrderedToFloat(bx);
+        best_cost = OrderedToFloat((unsigned)(bk >> 32));
+        best_state = (int)(unsigned)(bk & 0xFFFFFFFFull);
       }
-      float best_cost;
-      int best_state;
-      BlockMinArg<NT>(red, lv, li, &best_cost, &best_state);
-      const float beam_cutoff = best_cost + o.beam;
-      int c_le = 0, c_lt = 0;
-#pragma unroll
-      for (int j = 0; j < MAXS; j++) {
-        const float c = mycost[j];
-        c_le += (c <= beam_cutoff && c < INF);
-        c_lt += (c < beam_cutoff);
-      }
-      int N;
-      BlockSum3<NT>(red, cnt, c_le, c_lt, &N, &c_le, &c_lt);
       if (N == 0) { error = 1; break; }
       RS_T(0);
       // ---- GetCutoff (lattice-faster-decoder.cc:644-711)
+      const float beam_cutoff = best_cost + o.beam;
+      int c_le = 0, c_lt = 0;
+      if (N > o.max_active || N > o.min_active) {       // the counts only matter then (uniform branch)
+        for (int s = tid; s < S; s += NT) {
+          const float c = cost_cur[s];
+          c_le += (int)(c <= beam_cutoff) & (int)(c < INF);
+          c_lt += (int)(c < beam_cutoff);
+        }
+        const int wa = WaveSum(c_le), wb = WaveSum(c_lt);
+        if (lane == 0) xr[rb][wave] = make_int4(wa, wb, 0, 0);
+        __syncthreads();
+        c_le = 0; c_lt = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) { const int4 e = xr[rb][k]; c_le += e.x; c_lt += e.y; }
+        rb ^= 1;
+      }
       float cur_cutoff, adaptive_beam;
       bool decided = false;
       if (N > o.max_active && c_lt > o.max_active) {
-        const float mac = KthSmallest<NT>(red, cost_cur, S, o.max_active, best_cost);
+        const float mac = KthSmallestBinned<NT>(red, cost_cur, S, o.max_active, best_cost, max_cost);
         adaptive_beam = mac - best_cost + o.beam_delta;
         cur_cutoff = mac;
         decided = true;
@@ -122,7 +194,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         bool loosened;
         if (N > o.min_active) {
           if (o.min_active == 0 || c_le > o.min_active) min_active_cutoff = best_cost;   // tmp[min_active] <= beam_cutoff
-          else min_active_cutoff = KthSmallest<NT>(red, cost_cur, S, o.min_active, best_cost);
+          else min_active_cutoff = KthSmallestBinned<NT>(red, cost_cur, S, o.min_active, best_cost, max_cost);
           loosened = min_active_cutoff > beam_cutoff;
         } else {
           loosened = true;      // fewer than min_active tokens: the cutoff stays +inf (:691-705)
@@ -137,120 +209,153 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         }
       }
       const float cost_offset = -best_cost;
+      if (cur_cutoff < INF) {
+        for (int s = tid; s < S; s += NT) n_expanded += (unsigned)(cost_cur[s] <= cur_cutoff);
+      } else if (tid == 0) {
+        n_expanded += (unsigned)N;
+      }
       RS_T(1);
-      // ---- ProcessEmitting: all source costs are gathered with independent LDS reads
+      // ---- ProcessEmitting: independent LDS gathers, then one LDS atomic min per surviving arc
       float csrc[KE];
 #pragma unroll
-      for (int a = 0; a < KE; a++) csrc[a] = ea[a].x >= 0 ? cost_cur[ea[a].x] : INF;
+      for (int a = 0; a < KE; a++) csrc[a] = *reinterpret_cast<const float *>(smem + (ea[a].x & 0xFFFF));
       float local_min = INF;
-#pragma unroll
-      for (int j = 0; j < MAXS; j++) {
-        key[j] = RS_EMPTY;
-        n_expanded += (mycost[j] < INF && mycost[j] <= cur_cutoff);
-      }
+      const int best_addr = best_state * 4;
 #pragma unroll
       for (int a = 0; a < KE; a++) {
         const float c = csrc[a];
-        if (c < INF && c <= cur_cutoff) {
-          const float lk = llv[a];
-          const float gc = __int_as_float(ea[a].z);
-          const float tot = (c + (cost_offset - lk)) + gc;
-          n_arcs++;
-          if (ea[a].x == best_state) local_min = fminf(local_min, ((gc + cost_offset) - lk) + c);   // :752-757
-          local_min = fminf(local_min, tot);
-          const unsigned long long kk = PackKey(tot, (unsigned)ea[a].w);
-          const int slot = (unsigned)ea[a].y >> 28;
-#pragma unroll
-          for (int j = 0; j < MAXS; j++) if (slot == j && kk < key[j]) key[j] = kk;
-        }
+        const bool pass = (c < INF) & (c <= cur_cutoff);
+        const float lk = llv[a];
+        const float gc = __int_as_float(ea[a].z);
+        const float tot = (c + (cost_offset - lk)) + gc;
+        const float alt = ((gc + cost_offset) - lk) + c;                           // :752-757, arcs of the best token
+        const float m = ((ea[a].x & 0xFFFF) == best_addr) ? fminf(tot, alt) : tot;
+        local_min = fminf(local_min, pass ? m : INF);
+        n_arcs += (unsigned)pass;
+        if (pass)
+          atomicMin(reinterpret_cast<unsigned long long *>(smem + ((unsigned)ea[a].x >> 16)),
+                    ((unsigned long long)FloatToOrdered(tot) << 32) | (unsigned)ea[a].w);
       }
-      float mn;
-      int dummy;
-      BlockMinArg<NT>(red, local_min, tid, &mn, &dummy);
-      const float next_cutoff = mn + adaptive_beam;
-      if (tid == 0) { finfo[f * 4 + 0] = cost_offset; finfo[f * 4 + 1] = cur_cutoff; finfo[f * 4 + 2] = next_cutoff; finfo[f * 4 + 3] = adaptive_beam; }
-      if (next_cutoff < INF) {
+      float next_cutoff;
+      {
+        const unsigned wm = WaveMinU(FloatToOrdered(local_min));
+        if (lane == 0) xr[rb][wave] = make_int4((int)wm, 0, 0, 0);
+        __syncthreads();          // also: every emitting insertion has landed
+        unsigned bm = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < MAXS; j++) if (!(KeyCost(key[j]) < next_cutoff)) key[j] = RS_EMPTY;
+        for (int k = 0; k < NW; k++) bm = min(bm, (unsigned)xr[rb][k].x);
+        rb ^= 1;
+        next_cutoff = OrderedToFloat(bm) + adaptive_beam;
       }
-      closure_cutoff = next_cutoff;
+      if (tid == 0) *reinterpret_cast<float4 *>(finfo + (size_t)f * 4) = make_float4(cost_offset, cur_cutoff, next_cutoff, adaptive_beam);
+      closure_cutoff = next_cutoff;      // tokens at or above it are neither expanded below nor committed
       RS_T(2);
     }
-    // ---- publish my keys, then ProcessNonemitting to the fixpoint (Jacobi rounds over my epsilon in-arcs)
+    // ---- ProcessNonemitting to the fixpoint
+    if (KX > 0 && rg.eps_depth != 0) {
+      const int rounds = rg.eps_depth > 0 ? rg.eps_depth : 1 << 30;
+      for (int round = 0; round < rounds; round++) {
+        unsigned hsrc[KX];
 #pragma unroll
-    for (int j = 0; j < MAXS; j++) { const int s = j * NT + tid; if (s < S) key_next[s] = key[j]; }
-    __syncthreads();
-    for (int round = 0; round < 100000; round++) {
-      unsigned long long ksrc[KX];
+        for (int a = 0; a < KX; a++) hsrc[a] = *reinterpret_cast<const unsigned *>(smem + (xa[a].x & 0xFFFF));
+        int changed = 0;
 #pragma unroll
-      for (int a = 0; a < KX; a++) ksrc[a] = xa[a].x >= 0 ? key_next[xa[a].x] : RS_EMPTY;
-      int changed = 0;
-#pragma unroll
-      for (int a = 0; a < KX; a++) {
-        const float c = KeyCost(ksrc[a]);
-        if (c < closure_cutoff) {
+        for (int a = 0; a < KX; a++) {
+          const float c = OrderedToFloat(hsrc[a]);               // empty key -> NaN -> fails both tests
           const float tot = c + __int_as_float(xa[a].z);
-          if (round == 0) n_arcs++;
-          if (tot < closure_cutoff) {
-            const unsigned long long kk = PackKey(tot, (unsigned)xa[a].w);
-#pragma unroll
-            for (int j = 0; j < MAXS; j++) if (xa[a].y == j && kk < key[j]) { key[j] = kk; changed = 1; n_insert++; }
+          const bool live = c < closure_cutoff;
+          const bool pass = live & (tot < closure_cutoff);
+          if (round == 0) n_arcs += (unsigned)live;
+          if (pass) {
+            const unsigned long long kk = ((unsigned long long)FloatToOrdered(tot) << 32) | (unsigned)xa[a].w;
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(smem + ((unsigned)xa[a].x >> 16));
+            if (rg.eps_depth > 0) {
+              atomicMin(dst, kk);
+            } else {
+              const unsigned long long old = atomicMin(dst, kk);
+              if (kk < old) { changed = 1; n_insert++; }
+            }
           }
         }
-      }
-      __syncthreads();          // everybody has read the old keys
-      if (changed) {
+        if (rg.eps_depth > 0) {
+          __syncthreads();
+        } else {
+          // cyclic or deep epsilon subgraph: vote
+          const int any = __ballot(changed) != 0ull;
+          if (lane == 0) xr[rb][wave] = make_int4(any, 0, 0, 0);
+          __syncthreads();
+          int tot_any = 0;
 #pragma unroll
-        for (int j = 0; j < MAXS; j++) { const int s = j * NT + tid; if (s < S) key_next[s] = key[j]; }
+          for (int k = 0; k < NW; k++) tot_any |= xr[rb][k].x;
+          rb ^= 1;
+          if (!tot_any) break;
+        }
       }
-#ifdef RS_DECODE_PROFILE
-      n_rounds++;
-#endif
-      if (!__syncthreads_or(changed)) break;
     }
     RS_T(3);
-    // ---- commit frame f+1
+    // ---- commit frame f+1: keys -> costs and back-pointers; statistics for the next frame
     int *bp_row = bp + (size_t)(f + 1) * S;
-#pragma unroll
-    for (int j = 0; j < MAXS; j++) {
-      const int s = j * NT + tid;
-      if (s < S) {
-        if (key[j] == RS_EMPTY) { bp_row[s] = -2; mycost[j] = INF; }
-        else { bp_row[s] = (int)(unsigned)(key[j] & 0xFFFFFFFFull); mycost[j] = FromOrdered((unsigned)(key[j] >> 32)); n_alive++; }
-        cost_cur[s] = mycost[j];
-      }
+    st_min = INF; st_max = -INF; st_arg = 0x7fffffff; st_cnt = 0;
+    for (int s = tid; s < S; s += NT) {
+      const unsigned long long k = key_next[s];
+      const float c = OrderedToFloat((unsigned)(k >> 32));
+      const bool alive = c < closure_cutoff;                     // empty -> NaN -> false
+      bp_row[s] = alive ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
+      cost_cur[s] = alive ? c : INF;
+      key_next[s] = RS_EMPTY;
+      st_cnt += (int)alive;
+      const bool better = alive & (c < st_min);
+      st_min = better ? c : st_min;
+      st_arg = better ? s : st_arg;
+      st_max = (alive & (c > st_max)) ? c : st_max;
     }
-    __syncthreads();
+    n_alive += (unsigned)st_cnt;
     RS_T(4);
+    // no barrier here: the first reduction of the next frame has one before anybody reads cost_cur / adds to key_next
   }
+  __syncthreads();
   RS_T(5);
   FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
                       n_insert, n_alive, max_active_frames, min_active_frames);
 #ifdef RS_DECODE_PROFILE
   RS_T(6);
   if (u == 0 && tid == 0)
-    printf("reg decode cycles/frame: stats %lld cutoff %lld emit %lld closure %lld (%.2f rounds) commit %lld | finish total %lld (T=%d)\n",
-           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, (double)n_rounds / (T + 1), prof[4] / T, prof[6], T);
+    printf("reg decode cycles/frame: stats %lld cutoff %lld emit %lld closure %lld commit %lld | finish total %lld (T=%d)\n",
+           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[6], T);
 #endif
+}
+
+template <int NT, int KE, int KX>
+static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                      const DenseWork &w, size_t smem, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeKernel<NT, KE, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem);
+}
+
+// the instantiations; RegDecodeConfig picks the smallest one the graph fits
+static const int kRegConfigs[][3] = {{256, 8, 4}, {256, 16, 8}, {256, 32, 16}, {512, 32, 16}};
+
+bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx) {
+  if (num_states > kRegMaxStates) return false;
+  for (const auto &c : kRegConfigs)
+    if ((long long)c[0] * c[1] >= num_emitting && (long long)c[0] * c[2] >= num_eps) { *nt = c[0]; *ke = c[1]; *kx = c[2]; return true; }
+  return false;
 }
 
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
                      const float *loglikes, int ld, const DenseWork &w, hipStream_t s) {
   if (g.n_utts == 0) return true;
-  size_t smem = (((size_t)h.num_states * 8 + 15) & ~(size_t)15) + (((size_t)h.num_states * 4 + 15) & ~(size_t)15);
+  size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
   if (smem < 48 * 1024) smem = 48 * 1024;      // room to stage back-pointer rows for the traceback
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeKernel<256, 4, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeKernel<1024, 4, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
-  if (r.nt == 256)
-    hipLaunchKernelGGL((RegDecodeKernel<256, 4, 16, 16>), dim3(g.n_utts), dim3(256), smem, s, h, r, o, g, loglikes, ld, w, (int)smem);
-  else if (r.nt == 1024)
-    hipLaunchKernelGGL((RegDecodeKernel<1024, 4, 8, 8>), dim3(g.n_utts), dim3(1024), smem, s, h, r, o, g, loglikes, ld, w, (int)smem);
-  else
-    return false;
+  if (r.nt == 256 && r.ke == 8 && r.kx == 4) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
+  else if (r.nt == 256 && r.ke == 16 && r.kx == 8) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, s);
+  else if (r.nt == 256 && r.ke == 32 && r.kx == 16) LaunchOne<256, 32, 16>(h, r, o, g, loglikes, ld, w, smem, s);
+  else if (r.nt == 512 && r.ke == 32 && r.kx == 16) LaunchOne<512, 32, 16>(h, r, o, g, loglikes, ld, w, smem, s);
+  else return false;
   return true;
 }
 

@@ -284,28 +284,35 @@ void Model::ToDevice() {
       rev_dev_.num_eps_dst = (int)eps_dst.size();
       rev_dev_.in_begin_e_host_total = (int)ie.size();
       rev_dev_.in_begin_x_host_total = (int)ix.size();
-      // register-resident variant: state s -> thread s % NT, slot s / NT; needs <= 4 slots and a bounded number of
-      // in-arcs per thread (KE/KX of the kernel instantiations in decode_reg.hip)
+      // register-resident variant (decode_reg.hip): arcs dealt out to threads in forward order
       const int P = am_.nnet.output_dim;
-      for (int variant = 0; variant < 2 && reg_dev_.nt == 0 && P < (1 << 28); variant++) {
-        const int NT = variant == 0 ? 256 : 1024, KE = variant == 0 ? 16 : 8, KX = variant == 0 ? 16 : 8;
-        if (S > 4 * NT) continue;
-        std::vector<int4> et((size_t)KE * NT, make_int4(-1, 0, 0, 0)), xt((size_t)KX * NT, make_int4(-1, 0, 0, 0));
-        std::vector<int> ne(NT, 0), nx(NT, 0);
-        bool ok = true;
-        for (size_t a = 0; a < A && ok; a++) {      // forward-arc order => per-thread lists are sorted by arc index
+      int nt = 0, ke = 0, kx = 0;
+      if (P > 0 && RegDecodeConfig(S, (int)ie.size(), (int)ix.size(), &nt, &ke, &kx)) {
+        const int key_base = (int)(((size_t)(S + 1) * 4 + 15) & ~(size_t)15);
+        const int pad_e = (4 * S) | ((key_base + 8 * S) << 16), pad_x = (key_base + 8 * S + 4) | ((key_base + 8 * S) << 16);
+        std::vector<int4> et((size_t)ke * nt, make_int4(pad_e, 0, 0, 0)), xt((size_t)kx * nt, make_int4(pad_x, 0, 0, 0));
+        size_t ne = 0, nx = 0;
+        for (size_t a = 0; a < A; a++) {
           const int4 &fa = arcs[a];
-          const int t = fa.w % NT, slot = fa.w / NT;
-          if (fa.x == 0) {
-            if (nx[t] >= KX) { ok = false; break; }
-            xt[(size_t)nx[t]++ * NT + t] = make_int4(src[a], slot, fa.z, (int)a);
-          } else {
-            if (ne[t] >= KE) { ok = false; break; }
-            et[(size_t)ne[t]++ * NT + t] = make_int4(src[a], fa.x | (slot << 28), fa.z, (int)a);
-          }
+          const int dst_addr = (key_base + 8 * fa.w) << 16;
+          if (fa.x == 0) xt[nx++] = make_int4((key_base + 8 * src[a] + 4) | dst_addr, 0, fa.z, (int)a);
+          else et[ne++] = make_int4((4 * src[a]) | dst_addr, fa.x - 1, fa.z, (int)a);
         }
-        if (!ok) continue;
-        reg_dev_.nt = NT;
+        // longest path of the epsilon subgraph = number of closure rounds; cyclic or deep -> the kernel votes instead
+        int depth = 0;
+        {
+          std::vector<int> indeg(S, 0), len(S, 0), order;
+          std::vector<std::vector<int>> out(S);
+          for (size_t a = 0; a < A; a++) if (arcs[a].x == 0) { out[src[a]].push_back(arcs[a].w); indeg[arcs[a].w]++; }
+          for (int st = 0; st < S; st++) if (indeg[st] == 0) order.push_back(st);
+          for (size_t i = 0; i < order.size(); i++)
+            for (int d : out[order[i]]) { len[d] = std::max(len[d], len[order[i]] + 1); if (--indeg[d] == 0) order.push_back(d); }
+          if ((int)order.size() < S) depth = -1;
+          else { for (int st = 0; st < S; st++) depth = std::max(depth, len[st]); if (depth > 6) depth = -1; }
+        }
+        reg_dev_.nt = nt; reg_dev_.ke = ke; reg_dev_.kx = kx;
+        reg_dev_.eps_depth = depth;
+        reg_dev_.key_base = key_base;
         reg_dev_.e_tab = static_cast<int4 *>(UploadBytes(et.data(), et.size() * sizeof(int4)));
         reg_dev_.x_tab = static_cast<int4 *>(UploadBytes(xt.data(), xt.size() * sizeof(int4)));
       }

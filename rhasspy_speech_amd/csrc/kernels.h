@@ -186,13 +186,19 @@ struct DenseWork {
   int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
   int path_cap;
 };
-// Register-resident variant (decode_reg.hip): thread t of an NT-thread workgroup owns states {t, t + NT, ...} (<= 4) and
-// keeps their incoming arcs in VGPRs.  Tables are [arc slot][thread] so that loading them is coalesced.
+// Register-resident variant (decode_reg.hip): the arcs are dealt out to the threads of an NT-thread workgroup (arc i ->
+// thread i % NT, register slot i / NT) and live in VGPRs for the whole utterance.  Tables are [slot][thread] so that
+// loading them is coalesced; LDS addresses are baked in on the host (cost_cur at byte 0, keys at key_base).
+constexpr int kRegMaxStates = 5000;      // 16-bit LDS byte addresses: key_base + 8 * (S + 1) < 65536
 struct RegGraphDev {
   int nt = 0;                 // 0 = graph does not fit this variant
-  const int4 *e_tab;          // [KE][nt] {src state (-1 unused), (pdf + 1) | slot << 28, weight bits, forward arc index}
-  const int4 *x_tab;          // [KX][nt] {src state (-1 unused), slot, weight bits, forward arc index}
+  int ke = 0, kx = 0;         // register slots per thread for emitting / epsilon arcs (a kernel instantiation)
+  int eps_depth = 0;          // longest epsilon path (rounds to the fixpoint); 0 = no epsilon arcs; -1 = cyclic or deep -> vote
+  int key_base = 0;           // byte offset of key_next[] in the dynamic LDS region
+  const int4 *e_tab;          // [ke][nt] {4*src | (key_base + 8*dst) << 16, pdf, weight bits, forward arc index}
+  const int4 *x_tab;          // [kx][nt] {(key_base + 8*src + 4) | (key_base + 8*dst) << 16, 0, weight bits, forward arc index}
 };
+bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx);
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
                      const float *loglikes, int ld, const DenseWork &w, hipStream_t s);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);

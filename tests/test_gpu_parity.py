@@ -123,14 +123,21 @@ def test_gpu_matches_oracle_on_fresh_inputs(case_cache):
         assert res.counters(i)[3] > 0
 
 
-@pytest.mark.parametrize("name", ["tiny_u0", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_noiv_u2", "zam_u0"])
-def test_decoder_variants_agree(case_cache, name, monkeypatch):
+VARIANT_CASES = [("tiny_u0", {}), ("tiny_arpa_u7", {}), ("tiny_arpa_prune_u8", {}), ("tiny_noiv_u2", {}), ("zam_u0", {}),
+                 # pruning paths of GetCutoff: max-active and min-active selection on most frames
+                 ("zam_u0", dict(max_active=150, min_active=100, beam=10.0)),
+                 ("zam_u0", dict(max_active=400, min_active=300, beam=6.0)),
+                 ("zam_u1", dict(max_active=40, min_active=0, beam=16.0))]
+
+
+@pytest.mark.parametrize("name,extra", VARIANT_CASES)
+def test_decoder_variants_agree(case_cache, name, extra, monkeypatch):
     """The register-resident, the LDS-resident (pull) and the general token-list decoder are the same search."""
     from rhasspy_speech_amd import synth
     models = {}
     for variant in ("sparse", "dense", "reg"):
         monkeypatch.setenv("RS_DECODER", variant)
-        models[variant], pcm = make_model(case_cache, name)
+        models[variant], pcm = make_model(case_cache, name, **extra)
     monkeypatch.delenv("RS_DECODER")
     pcms = [pcm] + [synth.synth_utterance(300 + i, n) for i, n in enumerate([48000, 17000, 33000])]
     ref = models["sparse"].decode_batch(pcms)
@@ -141,6 +148,8 @@ def test_decoder_variants_agree(case_cache, name, monkeypatch):
             np.testing.assert_allclose(got.costs(u), ref.costs(u), rtol=1e-6)
             # same number of live tokens summed over frames => same token sets
             assert got.counters(u)[3] == ref.counters(u)[3], variant
+            # the pruning branches were actually taken the same number of times
+            assert got.counters(u)[5] == ref.counters(u)[5] and got.counters(u)[6] == ref.counters(u)[6], variant
 
 
 STREAM_CASES = [n for n in cases.CASES if n not in ("zam_u1",)]
