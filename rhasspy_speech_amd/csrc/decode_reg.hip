@@ -18,6 +18,7 @@
 // conditions into exec-mask branches with a wait in front of each, which is what made the first version slow.
 // Compiled with -ffp-contract=off.
 #include "decode_common.h"
+#include "wave_ops.h"
 
 namespace rs {
 using namespace dd;
@@ -28,50 +29,6 @@ using namespace dd;
 #define RS_T(i) do { } while (0)
 #endif
 
-namespace {
-
-template <int CTRL>
-__device__ __forceinline__ unsigned Dpp(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-// wave-wide reductions: butterfly of row rotations inside each row of 16 lanes, then the four row results through
-// SGPRs.  The result is wave-uniform.
-__device__ __forceinline__ unsigned WaveMinU(unsigned v) {
-  v = min(v, Dpp<0x121>(v));      // row_ror:1
-  v = min(v, Dpp<0x122>(v));      // row_ror:2
-  v = min(v, Dpp<0x124>(v));      // row_ror:4
-  v = min(v, Dpp<0x128>(v));      // row_ror:8
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  return min(min(a, b), min(c, d));
-}
-__device__ __forceinline__ unsigned WaveMaxU(unsigned v) {
-  v = max(v, Dpp<0x121>(v));
-  v = max(v, Dpp<0x122>(v));
-  v = max(v, Dpp<0x124>(v));
-  v = max(v, Dpp<0x128>(v));
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ int WaveSum(int x) {
-  unsigned v = (unsigned)x;
-  v += Dpp<0x121>(v);
-  v += Dpp<0x122>(v);
-  v += Dpp<0x124>(v);
-  v += Dpp<0x128>(v);
-  return __builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) +
-         __builtin_amdgcn_readlane((int)v, 48);
-}
-__device__ __forceinline__ float OrderedToFloat(unsigned u) {      // branch-free FromOrdered
-  return __uint_as_float(u ^ ((unsigned)((int)~u >> 31) | 0x80000000u));
-}
-__device__ __forceinline__ unsigned FloatToOrdered(float f) {      // branch-free OrderedBits
-  const unsigned b = __float_as_uint(f);
-  return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
-}
-
-}  // namespace
 
 template <int NT, int KE, int KX>
 __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg, DecodeOptsDev o, BatchGeom g,
@@ -138,11 +95,11 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       float best_cost, max_cost;
       int best_state, N;
       {
-        const unsigned ub = FloatToOrdered(st_min);
-        const unsigned wm = WaveMinU(ub);
-        const unsigned wa = WaveMinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
-        const int wn = WaveSum(st_cnt);
-        const unsigned wx = WaveMaxU(FloatToOrdered(st_max));
+        const unsigned ub = wv::FloatToOrdered(st_min);
+        const unsigned wm = wv::MinU(ub);
+        const unsigned wa = wv::MinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
+        const int wn = wv::Sum(st_cnt);
+        const unsigned wx = wv::MaxU(wv::FloatToOrdered(st_max));
         if (lane == 0) xr[rb][wave] = make_int4((int)wm, (int)wa, wn, (int)wx);
         __syncthreads();
         unsigned long long bk = ~0ull;
@@ -157,8 +114,8 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           bx = max(bx, (unsigned)e.w);
         }
         rb ^= 1;
-        max_cost = OrderedToFloat(bx);
-        best_cost = OrderedToFloat((unsigned)(bk >> 32));
+        max_cost = wv::OrderedToFloat(bx);
+        best_cost = wv::OrderedToFloat((unsigned)(bk >> 32));
         best_state = (int)(unsigned)(bk & 0xFFFFFFFFull);
       }
       if (N == 0) { error = 1; break; }
@@ -172,7 +129,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           c_le += (int)(c <= beam_cutoff) & (int)(c < INF);
           c_lt += (int)(c < beam_cutoff);
         }
-        const int wa = WaveSum(c_le), wb = WaveSum(c_lt);
+        const int wa = wv::Sum(c_le), wb = wv::Sum(c_lt);
         if (lane == 0) xr[rb][wave] = make_int4(wa, wb, 0, 0);
         __syncthreads();
         c_le = 0; c_lt = 0;
@@ -234,18 +191,18 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         n_arcs += (unsigned)pass;
         if (pass)
           atomicMin(reinterpret_cast<unsigned long long *>(smem + ((unsigned)ea[a].x >> 16)),
-                    ((unsigned long long)FloatToOrdered(tot) << 32) | (unsigned)ea[a].w);
+                    ((unsigned long long)wv::FloatToOrdered(tot) << 32) | (unsigned)ea[a].w);
       }
       float next_cutoff;
       {
-        const unsigned wm = WaveMinU(FloatToOrdered(local_min));
+        const unsigned wm = wv::MinU(wv::FloatToOrdered(local_min));
         if (lane == 0) xr[rb][wave] = make_int4((int)wm, 0, 0, 0);
         __syncthreads();          // also: every emitting insertion has landed
         unsigned bm = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < NW; k++) bm = min(bm, (unsigned)xr[rb][k].x);
         rb ^= 1;
-        next_cutoff = OrderedToFloat(bm) + adaptive_beam;
+        next_cutoff = wv::OrderedToFloat(bm) + adaptive_beam;
       }
       if (tid == 0) *reinterpret_cast<float4 *>(finfo + (size_t)f * 4) = make_float4(cost_offset, cur_cutoff, next_cutoff, adaptive_beam);
       closure_cutoff = next_cutoff;      // tokens at or above it are neither expanded below nor committed
@@ -261,13 +218,13 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         int changed = 0;
 #pragma unroll
         for (int a = 0; a < KX; a++) {
-          const float c = OrderedToFloat(hsrc[a]);               // empty key -> NaN -> fails both tests
+          const float c = wv::OrderedToFloat(hsrc[a]);               // empty key -> NaN -> fails both tests
           const float tot = c + __int_as_float(xa[a].z);
           const bool live = c < closure_cutoff;
           const bool pass = live & (tot < closure_cutoff);
           if (round == 0) n_arcs += (unsigned)live;
           if (pass) {
-            const unsigned long long kk = ((unsigned long long)FloatToOrdered(tot) << 32) | (unsigned)xa[a].w;
+            const unsigned long long kk = ((unsigned long long)wv::FloatToOrdered(tot) << 32) | (unsigned)xa[a].w;
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(smem + ((unsigned)xa[a].x >> 16));
             if (rg.eps_depth > 0) {
               atomicMin(dst, kk);
@@ -298,7 +255,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     st_min = INF; st_max = -INF; st_arg = 0x7fffffff; st_cnt = 0;
     for (int s = tid; s < S; s += NT) {
       const unsigned long long k = key_next[s];
-      const float c = OrderedToFloat((unsigned)(k >> 32));
+      const float c = wv::OrderedToFloat((unsigned)(k >> 32));
       const bool alive = c < closure_cutoff;                     // empty -> NaN -> false
       bp_row[s] = alive ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
       cost_cur[s] = alive ? c : INF;

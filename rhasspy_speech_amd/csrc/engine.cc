@@ -529,6 +529,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
     need += (size_t)rows * nsel * 8 + 1024;
     need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192 + 1024;
     need += (size_t)max_chunks * n_utts * 16 + 4096;
+    need += IvecStatsScratchDoubles(ivec_dev_, n_utts) * 8 + 1024;
   }
   const int S = hclg_.num_states();
   int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
@@ -617,26 +618,29 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
     d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i + 256);   // + slack: staging loads may read past a row's end
     RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
     RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
-    RS_HIP(hipMemsetAsync(numf, 0, sizeof(double) * n_utts, s));
     RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_ivrows * ld_i, s));
-    // OnlineIvectorEstimationStats ctor (ivector-extractor.cc:786-795): quadratic = I, linear = [prior_offset, 0, ...];
-    // current_ivector_ starts at [prior_offset, 0, ...] (online-ivector-feature.cc:440-442)
-    {
-      std::vector<double> hl((size_t)n_utts * Di, 0.0), hq((size_t)n_utts * usz, 0.0), hx((size_t)n_utts * Di, 0.0);
-      for (int u = 0; u < n_utts; u++) {
-        hl[(size_t)u * Di] = fc_.ie.prior_offset;
-        hx[(size_t)u * Di] = fc_.ie.prior_offset;
-        for (int r = 0; r < Di; r++) hq[(size_t)u * usz + (size_t)r * (r + 1) / 2 + r] = 1.0;
-      }
-      RS_HIP(hipMemcpyAsync(linear, hl.data(), sizeof(double) * hl.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipMemcpyAsync(quad, hq.data(), sizeof(double) * hq.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipMemcpyAsync(x, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipStreamSynchronize(s));
-    }
+    LaunchIvecInit(ivec_dev_, n_utts, linear, quad, x, numf, s);
+    double *iv_scratch = arena_.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, n_utts));
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     if (!streaming) {
       LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
-      LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
+      LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
+      if (std::getenv("RS_DEBUG_IVEC")) {
+        RS_HIP(hipStreamSynchronize(s));
+        std::vector<int> pi((size_t)rows * nsel); std::vector<float> pw((size_t)rows * nsel), gm((size_t)G);
+        std::vector<double> hl(Di), hq(usz), hw((size_t)G * Dl); double nf = 0;
+        RS_HIP(hipMemcpy(pi.data(), post_idx, pi.size() * 4, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(pw.data(), post_w, pw.size() * 4, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(gm.data(), gamma, gm.size() * 4, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(hl.data(), linear, hl.size() * 8, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(hq.data(), quad, hq.size() * 8, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(hw.data(), wfeats, hw.size() * 8, hipMemcpyDeviceToHost));
+        RS_HIP(hipMemcpy(&nf, numf, 8, hipMemcpyDeviceToHost));
+        for (int t = 0; t < 3; t++) { size_t r = (size_t)g.L + t; printf("post[%d]:", t); for (int j = 0; j < nsel; j++) printf(" (%d %.6f)", pi[r * nsel + j], pw[r * nsel + j]); printf("\n"); }
+        double gs = 0, ws = 0; for (float v : gm) gs += v; for (double v : hw) ws += v;
+        printf("gamma_sum %.6f wfeats_sum %.6f numf %.6f\nlinear:", gs, ws, nf); for (int i = 0; i < std::min(Di, 6); i++) printf(" %.6f", hl[i]);
+        printf("\nquad:"); for (int i = 0; i < std::min(usz, 6); i++) printf(" %.6f", hq[i]); printf("\n");
+      }
       LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
     } else {
       // per-chunk schedule tables: [step][utt] frame_begin, frame_end, out_row, active
@@ -661,7 +665,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       for (int k = 0; k < max_chunks; k++) {
         const size_t o = (size_t)k * n_utts;
         LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, s);
-        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, s);
+        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
         LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
         LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
       }

@@ -1,0 +1,520 @@
+// Online iVector estimator kernels for gfx950: UBM posteriors, statistics, conjugate-gradient solve.
+//
+// Reference behaviour being reproduced (kaldi/src):
+//   gmm/diag-gmm.cc:546-562 + hmm/posterior.cc:440-509 (UBM log-likes, posterior pruning)
+//   ivector/ivector-extractor.cc:611-668,732-795 + matrix/optimization.cc:453-566 (stats, prior, CG solve)
+//   online2/online-ivector-feature.cc:225-330,440-442 (what is accumulated when)
+//
+// Shape of the work (zamia-like: D = 40, G = 512, I = 100, 5 Gaussians kept per frame):
+//   * UBM scoring is a [rows x 2D] x [2D x G] product followed by a per-row top-k: a wave scores R rows at once so
+//     every Gaussian parameter fetched is used R times (packed fp32 FMAs), then selects with DPP reductions;
+//   * the statistics are two batch products over the utterances, in double as the reference keeps them:
+//     linear[u] = sum_{g,d} Sigma^-1 M_g[d,:] * wfeats[u,g,d]   ([U x G D] x [G D x I])
+//     quadratic[u] = sum_g gamma[u,g] * U_g                    ([U x G] x [G x I(I+1)/2])
+//     both are tiled over 8 utterances per workgroup so the model matrices stream through L2 n_utts/8 times
+//     instead of n_utts times;
+//   * the solve is one workgroup per utterance with the packed quadratic term in LDS.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+
+#include "kernels.h"
+#include "wave_ops.h"
+
+namespace rs {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------ UBM posteriors
+// NPL = Gaussians per lane (G <= 64 * NPL), R = rows per wave.  Gaussian parameters are stored transposed (D x G)
+// so that a wave reads 64 consecutive floats per dimension.  Selection (VectorToPosteriorEntry): candidates are
+// the Gaussians whose log-likelihood exceeds max + log(min_post); the num_gselect best are kept (exp() is
+// monotone, so ranking by log-likelihood is ranking by posterior; ties -> lowest Gaussian index), then pruned and
+// renormalised exactly as posterior.cc:494-507 does.  exp() is evaluated in double for the kept ones only.
+template <int NPL, int R>
+__global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
+                                                     int *__restrict__ post_idx, float *__restrict__ post_w) {
+  constexpr int NP2 = (NPL + 1) / 2;
+  __shared__ float xs[4][R][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + wave) * R;
+  const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
+  unsigned active = 0;          // bit r: row r is a real frame (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int row = row0 + r;
+    bool ok = row < g.total_rows;
+    if (ok) {
+      const int u = g.d_row_utt[row], t = g.d_row_t[row];
+      ok = t >= 0 && t < g.d_num_frames[u];
+    }
+    active |= ok ? (1u << r) : 0u;
+    for (int d = lane; d < D; d += 64) xs[wave][r][d] = ok ? feats[(size_t)row * ld + d] : 0.f;
+  }
+  __syncthreads();
+  if (active != 0u) {
+    f32x2 a1[R][NP2], a2[R][NP2];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int j = 0; j < NP2; j++) { a1[r][j] = f32x2{0.f, 0.f}; a2[r][j] = f32x2{0.f, 0.f}; }
+    // clamped Gaussian indices: lanes past G score the last Gaussian again and are ignored at selection
+    int gidx[2 * NP2];
+#pragma unroll
+    for (int j = 0; j < 2 * NP2; j++) { const int gi = lane + j * 64; gidx[j] = gi < G ? gi : G - 1; }
+    for (int d = 0; d < D; d++) {
+      const float *mi = iv.means_invvars_t + (size_t)d * G, *vi = iv.inv_vars_t + (size_t)d * G;
+      f32x2 m[NP2], v[NP2];
+#pragma unroll
+      for (int j = 0; j < NP2; j++) {
+        m[j] = f32x2{mi[gidx[2 * j]], mi[gidx[2 * j + 1]]};
+        v[j] = f32x2{vi[gidx[2 * j]], vi[gidx[2 * j + 1]]};
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const float xv = xs[wave][r][d], xq = xv * xv;
+        const f32x2 x1 = f32x2{xv, xv}, x2 = f32x2{xq, xq};
+#pragma unroll
+        for (int j = 0; j < NP2; j++) {
+          a1[r][j] = __builtin_elementwise_fma(x1, m[j], a1[r][j]);
+          a2[r][j] = __builtin_elementwise_fma(x2, v[j], a2[r][j]);
+        }
+      }
+    }
+    float gc[2 * NP2];
+#pragma unroll
+    for (int j = 0; j < 2 * NP2; j++) gc[j] = iv.gconsts[gidx[j]];
+    const float log_min_post = logf(iv.min_post);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (!((active >> r) & 1u)) continue;         // wave-uniform
+      // log-likelihoods as order-preserving keys; lanes past G get key 0 (below every real value)
+      unsigned key[2 * NP2];
+      unsigned lmax = 0u;
+#pragma unroll
+      for (int j = 0; j < 2 * NP2; j++) {
+        const float s1 = (j & 1) ? a1[r][j >> 1].y : a1[r][j >> 1].x, s2 = (j & 1) ? a2[r][j >> 1].y : a2[r][j >> 1].x;
+        float v = gc[j] + s1;
+        v = v + (-0.5f) * s2;
+        key[j] = (lane + j * 64 < G && j < NPL) ? wv::FloatToOrdered(v) : 0u;
+        lmax = max(lmax, key[j]);
+      }
+      const unsigned kmax = wv::MaxU(lmax);
+      const float max_like = wv::OrderedToFloat(kmax);
+      const unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);     // candidates: like > cutoff
+      float sel_ll[8];
+      int sel_i[8];
+      int nfound = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        sel_ll[k] = 0.f;
+        sel_i[k] = -1;
+        if (k < nsel && nfound == k) {
+          unsigned bv = 0u;
+          int bj = 0;
+#pragma unroll
+          for (int j = 0; j < 2 * NP2; j++) if (key[j] > bv) { bv = key[j]; bj = j; }
+          const unsigned wm = wv::MaxU(bv);
+          if (wm > kcut) {
+            const unsigned long long tie = __ballot(bv == wm);
+            int gi;
+            if (__popcll(tie) == 1) {
+              const int src = __ffsll((long long)tie) - 1;
+              gi = src + 64 * __builtin_amdgcn_readlane(bj, src);
+            } else {
+              gi = (int)wv::MinU(bv == wm ? (unsigned)(lane + 64 * bj) : 0x7fffffffu);
+            }
+            sel_ll[k] = wv::OrderedToFloat(wm);
+            sel_i[k] = gi;
+            nfound = k + 1;
+#pragma unroll
+            for (int j = 0; j < 2 * NP2; j++) if (lane + j * 64 == gi) key[j] = 0u;
+          }
+        }
+      }
+      // posteriors of the kept Gaussians: lane k evaluates exp(like_k - max_like) in double, as the reference does
+      float my_ll = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (lane == k) my_ll = sel_ll[k];
+      const float my_post = lane < nfound ? (float)exp((double)(my_ll - max_like)) : 0.f;
+      float sel_w[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) sel_w[k] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(my_post), k));
+      // prune + renormalise (posterior.cc:494-507), identical on every lane
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k < nfound) tot += sel_w[k];
+      const float cutoff = iv.min_post * tot;
+#pragma unroll
+      for (int k = 7; k >= 1; k--)
+        if (nfound == k + 1 && sel_w[k] < cutoff) { tot -= sel_w[k]; nfound = k; }
+      const float inv_tot = (float)(1.0 / (double)tot);
+      const float scale = iv.posterior_scale * 1.0f;
+      float w = 0.f;
+      int gi = -1;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (k == lane && k < nfound) { w = sel_w[k] * inv_tot; w *= scale; gi = sel_i[k]; }
+      if (lane < nsel) {
+        post_idx[(size_t)(row0 + r) * nsel + lane] = gi;
+        post_w[(size_t)(row0 + r) * nsel + lane] = w;
+      }
+    }
+  }
+  // rows that are not frames (halo)
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (!((active >> r) & 1u) && row0 + r < g.total_rows && lane < nsel) post_idx[(size_t)(row0 + r) * nsel + lane] = -1;
+}
+
+void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda_norm, int ld, int *post_idx,
+                         float *post_w, hipStream_t s) {
+  if (g.total_rows <= 0) return;
+  const int npl = (iv.num_gauss + 63) / 64;
+#define RS_UBM(N, RR)                                                                                                  \
+  hipLaunchKernelGGL((UbmPostKernel<N, RR>), dim3((g.total_rows + 4 * RR - 1) / (4 * RR)), dim3(256), 0, s, iv, g, lda_norm, ld, \
+                     post_idx, post_w)
+  if (npl <= 2) RS_UBM(2, 8);
+  else if (npl <= 4) RS_UBM(4, 8);
+  else if (npl <= 8) RS_UBM(8, 8);
+  else if (npl <= 16) RS_UBM(16, 4);
+  else RS_UBM(32, 2);
+#undef RS_UBM
+}
+
+// ------------------------------------------------------------------------------------------ iVector stats
+// OnlineIvectorEstimationStats ctor (ivector-extractor.cc:786-795): quadratic = I, linear = [prior_offset, 0, ...];
+// current_ivector_ starts at [prior_offset, 0, ...] (online-ivector-feature.cc:440-442); num_frames = 0.
+__global__ void IvecInitKernel(IvecDev iv, double *__restrict__ linear, double *__restrict__ quadratic, double *__restrict__ x,
+                               double *__restrict__ num_frames) {
+  const int u = blockIdx.x, I = iv.ivec_dim, usz = I * (I + 1) / 2;
+  for (int k = threadIdx.x; k < usz; k += blockDim.x) quadratic[(size_t)u * usz + k] = 0.0;
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    linear[(size_t)u * I + i] = i == 0 ? iv.prior_offset : 0.0;
+    x[(size_t)u * I + i] = i == 0 ? iv.prior_offset : 0.0;
+  }
+  if (threadIdx.x == 0) num_frames[u] = 0.0;
+  __syncthreads();
+  for (int r = threadIdx.x; r < I; r += blockDim.x) quadratic[(size_t)u * usz + (size_t)r * (r + 1) / 2 + r] = 1.0;
+}
+void LaunchIvecInit(const IvecDev &iv, int n_utts, double *linear, double *quadratic, double *x, double *num_frames, hipStream_t s) {
+  if (n_utts == 0) return;
+  hipLaunchKernelGGL(IvecInitKernel, dim3(n_utts), dim3(256), 0, s, iv, linear, quadratic, x, num_frames);
+}
+
+// Block per utterance; frames in order so that every per-Gaussian sum is accumulated in the reference's
+// frame order (AccStats: weighted_feats.AddVec per frame, float tot_weight).
+__global__ __launch_bounds__(256) void IvecAccumKernel(IvecDev iv, BatchGeom g, const float *__restrict__ lda, int ld,
+                                                        const int *__restrict__ post_idx, const float *__restrict__ post_w,
+                                                        const int *frame_begin, const int *frame_end,
+                                                        float *__restrict__ gamma, double *__restrict__ wfeats) {
+  int u = blockIdx.x;
+  int T = g.d_num_frames[u];
+  int t0 = frame_begin ? frame_begin[u] : 0, t1 = frame_end ? frame_end[u] : T;
+  if (t1 > T) t1 = T;
+  int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
+  size_t base = (size_t)g.d_row_base[u] + g.L;
+  float *gm = gamma + (size_t)u * G;
+  double *wf = wfeats + (size_t)u * G * D;
+  for (int t = t0; t < t1; t++) {
+    size_t row = base + t;
+    for (int i = threadIdx.x; i < nsel * D; i += blockDim.x) {
+      int j = i / D, d = i % D;
+      int gi = post_idx[row * nsel + j];
+      if (gi >= 0) {
+        float w = post_w[row * nsel + j];
+        wf[(size_t)gi * D + d] += (double)w * (double)lda[row * ld + d];
+        if (d == 0) gm[gi] += w;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
+                          const float *post_w, const int *frame_begin, const int *frame_end, double *gamma,
+                          double *wfeats, hipStream_t s) {
+  if (g.n_utts == 0) return;
+  // gamma is kept in float (GaussInfo::tot_weight is a BaseFloat); the buffer is sized for doubles, we use
+  // its first half as floats.
+  hipLaunchKernelGGL(IvecAccumKernel, dim3(g.n_utts), dim3(256), 0, s, iv, g, lda, ld, post_idx, post_w, frame_begin,
+                     frame_end, reinterpret_cast<float *>(gamma), wfeats);
+}
+
+constexpr int kIvecUB = 8;        // utterances per workgroup in the two batch products
+constexpr int kIvecKS = 32;       // Gaussian ranges the linear-term product is split into
+
+// Per utterance: tot = sum_g gamma_g (double sum of the float per-Gaussian totals, g ascending), the max_count prior
+// rescaling step of AccStats (ivector-extractor.cc:634-649) as `change`, and num_frames += tot.
+__global__ __launch_bounds__(64) void IvecTotKernel(IvecDev iv, const float *__restrict__ gamma, double *__restrict__ num_frames,
+                                                    double *__restrict__ change) {
+  __shared__ float gs[4096];
+  const int u = blockIdx.x, G = iv.num_gauss;
+  double tot = 0.0;
+  for (int g0 = 0; g0 < G; g0 += 4096) {
+    const int n = G - g0 < 4096 ? G - g0 : 4096;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) gs[i] = gamma[(size_t)u * G + g0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < n; i++) tot += (double)gs[i];
+  }
+  if (threadIdx.x == 0) {
+    double ch = 0.0;
+    const double oldn = num_frames[u], newn = oldn + tot;
+    if (iv.max_count > 0.0f) {
+      const double mc = (double)iv.max_count;
+      const double old_scale = (oldn > mc ? oldn : mc) / mc, new_scale = (newn > mc ? newn : mc) / mc;
+      ch = new_scale - old_scale;
+    }
+    change[u] = ch;
+    num_frames[u] = newn;
+  }
+}
+
+// partial[ks][u][i] = sum over the Gaussians of range ks and all d of Sigma_inv_M[g][d][i] * wfeats[u][g][d]
+__global__ __launch_bounds__(128) void IvecLinearPartialKernel(IvecDev iv, int n_utts, const double *__restrict__ wfeats,
+                                                               double *__restrict__ partial) {
+  constexpr int UB = kIvecUB, GB = 4;
+  __shared__ double wfl[GB][UB][128];
+  const int D = iv.feat_dim, G = iv.num_gauss, I = iv.ivec_dim;
+  const int u0 = blockIdx.x * UB, ks = blockIdx.y;
+  const int per = (G + kIvecKS - 1) / kIvecKS, g_begin = ks * per, g_end = g_begin + per < G ? g_begin + per : G;
+  for (int i0 = 0; i0 < I; i0 += 128) {
+    const int i = i0 + threadIdx.x, ic = i < I ? i : I - 1;
+    double acc[UB];
+#pragma unroll
+    for (int uu = 0; uu < UB; uu++) acc[uu] = 0.0;
+    for (int gb = g_begin; gb < g_end; gb += GB) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < GB * UB * D; e += 128) {
+        const int d = e % D, uu = (e / D) % UB, gg = e / (D * UB);
+        const int gi = gb + gg, u = u0 + uu;
+        wfl[gg][uu][d] = (gi < g_end && u < n_utts) ? wfeats[((size_t)u * G + gi) * D + d] : 0.0;
+      }
+      __syncthreads();
+      for (int gg = 0; gg < GB; gg++) {
+        const int gi = gb + gg < g_end ? gb + gg : g_end - 1;      // past the range: wfl is zero there
+        const double *sim = iv.sigma_inv_M + (size_t)gi * D * I + ic;
+        // DC independent loads in flight per lane, then DC x UB FMAs against LDS broadcasts
+        constexpr int DC = 8;
+        int d0 = 0;
+        for (; d0 + DC <= D; d0 += DC) {
+          double sv[DC];
+#pragma unroll
+          for (int dd = 0; dd < DC; dd++) sv[dd] = sim[(size_t)(d0 + dd) * I];
+#pragma unroll
+          for (int dd = 0; dd < DC; dd++)
+#pragma unroll
+            for (int uu = 0; uu < UB; uu++) acc[uu] += sv[dd] * wfl[gg][uu][d0 + dd];
+        }
+        for (; d0 < D; d0++) {
+          const double sv = sim[(size_t)d0 * I];
+#pragma unroll
+          for (int uu = 0; uu < UB; uu++) acc[uu] += sv * wfl[gg][uu][d0];
+        }
+      }
+    }
+    if (i < I)
+#pragma unroll
+      for (int uu = 0; uu < UB; uu++)
+        if (u0 + uu < n_utts) partial[((size_t)ks * n_utts + u0 + uu) * I + i] = acc[uu];
+  }
+}
+// linear[u][i] += sum_ks partial[ks][u][i] (fixed order)
+__global__ void IvecLinearReduceKernel(IvecDev iv, int n_utts, const double *__restrict__ partial, double *__restrict__ linear) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, I = iv.ivec_dim;
+  if (idx >= n_utts * I) return;
+  double acc = 0.0;
+  for (int ks = 0; ks < kIvecKS; ks++) acc += partial[(size_t)ks * n_utts * I + idx];
+  linear[idx] += acc;
+}
+
+// quadratic[u][k] += sum_g gamma[u][g] U_g[k] (+ the prior rescaling on the diagonal and on linear[0])
+__global__ __launch_bounds__(128) void IvecQuadKernel(IvecDev iv, int n_utts, const float *__restrict__ gamma,
+                                                      const double *__restrict__ change, double *__restrict__ quadratic,
+                                                      double *__restrict__ linear) {
+  constexpr int UB = kIvecUB, GC = 512;
+  __shared__ float gml[UB][GC];
+  const int G = iv.num_gauss, I = iv.ivec_dim, usz = I * (I + 1) / 2;
+  const int u0 = blockIdx.y * UB;
+  const int k = blockIdx.x * 128 + threadIdx.x, kc = k < usz ? k : usz - 1;
+  double acc[UB];
+#pragma unroll
+  for (int uu = 0; uu < UB; uu++) acc[uu] = 0.0;
+  for (int g0 = 0; g0 < G; g0 += GC) {
+    const int n = G - g0 < GC ? G - g0 : GC;
+    __syncthreads();
+    for (int e = threadIdx.x; e < UB * n; e += 128) {
+      const int uu = e / n, gi = e % n;
+      gml[uu][gi] = u0 + uu < n_utts ? gamma[(size_t)(u0 + uu) * G + g0 + gi] : 0.f;
+    }
+    __syncthreads();
+    const double *Uc = iv.U + (size_t)g0 * usz + kc;
+    constexpr int GU = 8;         // independent loads in flight per lane
+    int gi = 0;
+    for (; gi + GU <= n; gi += GU) {
+      double uv[GU];
+#pragma unroll
+      for (int q = 0; q < GU; q++) uv[q] = Uc[(size_t)(gi + q) * usz];
+#pragma unroll
+      for (int q = 0; q < GU; q++)
+#pragma unroll
+        for (int uu = 0; uu < UB; uu++) acc[uu] += (double)gml[uu][gi + q] * uv[q];
+    }
+    for (; gi < n; gi++) {
+      const double uv = Uc[(size_t)gi * usz];
+#pragma unroll
+      for (int uu = 0; uu < UB; uu++) acc[uu] += (double)gml[uu][gi] * uv;
+    }
+  }
+  if (k >= usz) return;
+  // is k a diagonal element?  k = r(r+1)/2 + r
+  int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= k) r++;
+  while (r * (r + 1) / 2 > k) r--;
+  const bool diag = (k == r * (r + 1) / 2 + r);
+#pragma unroll
+  for (int uu = 0; uu < UB; uu++) {
+    const int u = u0 + uu;
+    if (u >= n_utts) break;
+    const double ch = change[u];
+    quadratic[(size_t)u * usz + k] += acc[uu] + ((diag && ch != 0.0) ? ch : 0.0);
+    if (k == 0 && ch != 0.0) linear[(size_t)u * I] += iv.prior_offset * ch;
+  }
+}
+
+// zero the per-step accumulators of the Gaussians that were touched (cheaper than a 40 MB memset per chunk)
+__global__ void IvecClearKernel(IvecDev iv, float *__restrict__ gamma, double *__restrict__ wfeats) {
+  const int u = blockIdx.y, gi = blockIdx.x * blockDim.y + threadIdx.y;
+  if (gi >= iv.num_gauss) return;
+  if (gamma[(size_t)u * iv.num_gauss + gi] == 0.f) return;
+  double *wf = wfeats + ((size_t)u * iv.num_gauss + gi) * iv.feat_dim;
+  for (int d = threadIdx.x; d < iv.feat_dim; d += blockDim.x) wf[d] = 0.0;
+  // (one wave per Gaussian: every lane has read gamma before lane 0 clears it)
+  if (threadIdx.x == 0) gamma[(size_t)u * iv.num_gauss + gi] = 0.f;
+}
+void LaunchIvecClear(const IvecDev &iv, int n_utts, double *gamma, double *wfeats, hipStream_t s) {
+  if (n_utts == 0) return;
+  dim3 block(64, 4), grid((iv.num_gauss + 3) / 4, n_utts);
+  hipLaunchKernelGGL(IvecClearKernel, grid, block, 0, s, iv, reinterpret_cast<float *>(gamma), wfeats);
+}
+
+size_t IvecStatsScratchDoubles(const IvecDev &iv, int n_utts) { return (size_t)kIvecKS * n_utts * iv.ivec_dim + n_utts; }
+
+void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const double *wfeats, double *linear,
+                     double *quadratic, double *num_frames, double *scratch, hipStream_t s) {
+  if (n_utts == 0) return;
+  const float *gm = reinterpret_cast<const float *>(gamma);
+  double *partial = scratch, *change = scratch + (size_t)kIvecKS * n_utts * iv.ivec_dim;
+  const int ub = (n_utts + kIvecUB - 1) / kIvecUB, usz = iv.ivec_dim * (iv.ivec_dim + 1) / 2;
+  hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
+  hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
+  hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
+  hipLaunchKernelGGL(IvecQuadKernel, dim3((usz + 127) / 128, ub), dim3(128), 0, s, iv, n_utts, gm, change, quadratic, linear);
+}
+
+// ------------------------------------------------------------------------------------------ CG solve
+__device__ __forceinline__ double BlockSum(double v, double *scratch) {
+  // deterministic tree reduction over the block
+  int tid = threadIdx.x;
+  scratch[tid] = v;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if (tid < o) scratch[tid] += scratch[tid + o];
+    __syncthreads();
+  }
+  double r = scratch[0];
+  __syncthreads();
+  return r;
+}
+
+// y = A x for packed-lower symmetric A (row r: elements r(r+1)/2 .. +r)
+__device__ __forceinline__ double SpMatVecRow(const double *A, const double *x, int r, int n) {
+  double acc = 0.0;
+  const double *row = A + (size_t)r * (r + 1) / 2;
+  for (int c = 0; c <= r; c++) acc += row[c] * x[c];
+  for (int c = r + 1; c < n; c++) acc += A[(size_t)c * (c + 1) / 2 + r] * x[c];
+  return acc;
+}
+
+__global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, const double *__restrict__ quadratic,
+                                const double *__restrict__ num_frames, double *__restrict__ xio,
+                                float *__restrict__ ivec_out, int ldo, const int *__restrict__ out_row,
+                                const int *__restrict__ active) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int u = blockIdx.x, tid = threadIdx.x, n = iv.ivec_dim;
+  const int orow = out_row ? out_row[u] : u;
+  if (orow < 0) return;                                    // this utterance has no chunk at this step
+  const bool solve = active ? active[u] != 0 : true;       // 0: re-emit the current estimate (no new frames)
+  const int usz = n * (n + 1) / 2;
+  double *A = reinterpret_cast<double *>(smem_raw);
+  double *x = A + usz, *r = x + n, *p = r + n, *Ap = p + n, *b = Ap + n, *scratch = b + n;
+  for (int i = tid; i < usz; i += blockDim.x) A[i] = quadratic[(size_t)u * usz + i];
+  for (int i = tid; i < n; i += blockDim.x) { b[i] = linear[(size_t)u * n + i]; x[i] = xio[(size_t)u * n + i]; }
+  __syncthreads();
+  const bool have = num_frames[u] > 0.0;
+  if (!solve) {
+    // nothing
+  } else if (have) {
+    if (tid == 0 && x[0] == 0.0) x[0] = iv.prior_offset;     // GetIvector: better initial guess
+    __syncthreads();
+    const bool mine = tid < n;
+    // p0 = b - A x0 ; r0 = -p0
+    double ax = mine ? SpMatVecRow(A, x, tid, n) : 0.0;
+    if (mine) { p[tid] = b[tid] - ax; r[tid] = -p[tid]; }
+    __syncthreads();
+    double r_cur = BlockSum(mine ? r[tid] * r[tid] : 0.0, scratch);
+    const double r_initial = r_cur;
+    double r_recompute = r_cur;
+    const double max_error_sq = DBL_MIN, residual_factor = (double)(0.01f * 0.01f), inv_residual_factor = 1.0 / residual_factor;
+    int k = 0;
+    for (; k < n + 5 && k != iv.num_cg_iters; k++) {
+      double apv = mine ? SpMatVecRow(A, p, tid, n) : 0.0;
+      if (mine) Ap[tid] = apv;
+      __syncthreads();
+      double pr = BlockSum(mine ? p[tid] * r[tid] : 0.0, scratch);
+      double pap = BlockSum(mine ? p[tid] * Ap[tid] : 0.0, scratch);
+      double alpha = -pr / pap;
+      if (mine) { x[tid] += alpha * p[tid]; r[tid] += alpha * Ap[tid]; }
+      __syncthreads();
+      double r_next = BlockSum(mine ? r[tid] * r[tid] : 0.0, scratch);
+      if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
+        double ax2 = mine ? SpMatVecRow(A, x, tid, n) : 0.0;
+        if (mine) r[tid] = ax2 - b[tid];
+        __syncthreads();
+        r_next = BlockSum(mine ? r[tid] * r[tid] : 0.0, scratch);
+        r_recompute = r_next;
+      }
+      if (r_next <= max_error_sq) break;
+      double beta = r_next / r_cur;
+      if (mine) p[tid] = p[tid] * beta - r[tid];
+      __syncthreads();
+      r_cur = r_next;
+    }
+    // (the reference falls back to an exact solve if the residual got worse; with an SPD system and <= 15
+    //  iterations CG is monotone in the A-norm, the squared residual only grows in pathological cases)
+    (void)r_initial;
+  } else {
+    if (tid < n) x[tid] = (tid == 0) ? iv.prior_offset : 0.0;
+    __syncthreads();
+  }
+  if (tid < n) {
+    if (solve) xio[(size_t)u * n + tid] = x[tid];
+    float v = (float)x[tid];
+    if (tid == 0) v = (float)((double)v - iv.prior_offset);   // (*feat)(0) -= PriorOffset() on the float copy
+    ivec_out[(size_t)orow * ldo + tid] = v;
+  }
+}
+
+void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,
+                     const double *num_frames, double *x, float *ivec_out, int ldo, const int *out_row, const int *active,
+                     hipStream_t s) {
+  if (n_utts == 0) return;
+  int n = iv.ivec_dim;
+  int threads = 64;
+  while (threads < n) threads <<= 1;
+  size_t smem = sizeof(double) * ((size_t)n * (n + 1) / 2 + 5 * (size_t)n + threads);
+  hipLaunchKernelGGL(IvecSolveKernel, dim3(n_utts), dim3(threads), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
+}
+
+}  // namespace rs

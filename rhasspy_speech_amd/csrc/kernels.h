@@ -117,8 +117,12 @@ void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *ld
                           double *gamma, double *wfeats, hipStream_t s);
 // linear (n_utts x I) += sum_g Sigma_inv_M_g^T wfeats_g ; quadratic (n_utts x I(I+1)/2) += sum_g gamma_g U_g,
 // plus the max_count prior rescaling of OnlineIvectorEstimationStats::AccStats; num_frames (n_utts, double).
+// scratch: IvecStatsScratchDoubles() doubles of workspace.
 void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const double *wfeats,
-                     double *linear, double *quadratic, double *num_frames, hipStream_t s);
+                     double *linear, double *quadratic, double *num_frames, double *scratch, hipStream_t s);
+size_t IvecStatsScratchDoubles(const IvecDev &iv, int n_utts);
+// Fresh estimator state per utterance: quadratic = I, linear = x = [prior_offset, 0, ...], num_frames = 0.
+void LaunchIvecInit(const IvecDev &iv, int n_utts, double *linear, double *quadratic, double *x, double *num_frames, hipStream_t s);
 // Conjugate-gradient solve per utterance (LinearCgd, <= num_cg_iters), x in/out (double, n_utts x I);
 // ivec_out (float, n_utts x ldo) = x with prior_offset subtracted from element 0.
 // out_row (null = u): row of ivec_out receiving utterance u's estimate, -1 = skip; active (null = all): 0 = no new
