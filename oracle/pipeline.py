@@ -76,6 +76,169 @@ class MfccOpts:
         return o
 
 
+def _libm_f32(name: str):
+    """cosf / sinf of the C library: the reference's tables are std::cos(float) / std::sin(float) values, and numpy's
+    vectorised float32 trig functions differ from libm in the last bit for some arguments."""
+    import ctypes
+    import ctypes.util
+    fn = getattr(ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6"), name)
+    fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+    return lambda x: F32(fn(float(x)))
+
+
+class SplitRadixRealFft:
+    """matrix/srfft.cc restated for a batch of frames: the in-place float32 split-radix complex FFT of N/2 points
+    (ComputeRecursive :212-355, tables :78-115, BitReversePermute :185-209) and the real-FFT post-processing whose
+    twiddle is advanced by a float32 recurrence (:360-417).  The recursion is unrolled into levels of independent
+    butterflies (blocks of one recursion depth touch disjoint points); every butterfly performs the reference's float32
+    operations on the same operands, numpy just applies it to all frames at once.  Output: the power spectrum of
+    feature-functions.cc:29-51 (bins 0 .. N/2)."""
+
+    def __init__(self, n_real: int):
+        self.NR = n_real
+        self.N = N = n_real // 2
+        logn = N.bit_length() - 1
+        two_pi = 6.283185307179586476925286766559005
+        cosf, sinf = _libm_f32("cosf"), _libm_f32("sinf")
+        levels = []
+        cur = [(0, logn)]
+        while cur:
+            nxt, k0, k1, k2 = [], [], [], []
+            for off, lg in cur:
+                if lg >= 3:
+                    m = 1 << lg
+                    m2, m4, m8 = m // 2, m // 4, m // 8
+                    for n in range(m4):
+                        if n == 0:
+                            tw, mode = [0.0] * 6, 0
+                        elif n == m8:
+                            tw, mode = [0.0] * 6, 1
+                        else:
+                            a = F32(n * two_pi / m)
+                            c, sn = cosf(a), sinf(a)
+                            a3 = F32(3 * n * two_pi / m)
+                            c3, s3 = cosf(a3), sinf(a3)
+                            tw, mode = [c, -(sn + c), sn - c, c3, -(s3 + c3), s3 - c3], 2
+                        k0.append((off + n, off + n + m4, off + n + m2, off + n + m2 + m4, mode, tw))
+                    nxt += [(off, lg - 1), (off + m2, lg - 2), (off + 3 * (m // 4), lg - 2)]
+                elif lg == 2:
+                    k1.append(off)
+                elif lg == 1:
+                    k2.append(off)
+            if k0 or k1 or k2:
+                e = np.array([t[:4] for t in k0], np.int64).reshape(-1, 4)
+                mode = np.array([t[4] for t in k0], np.int64)
+                tw = np.array([t[5] for t in k0], F32).reshape(-1, 6)
+                levels.append((e, mode, tw, np.array(k1, np.int64), np.array(k2, np.int64)))
+            cur = nxt
+        self.levels = levels
+        # bit-reversal pass as a gather
+        lg2 = logn >> 1
+        nn = 1 << lg2
+        if logn & 1:
+            lg2 += 1
+        seed = [0] * (1 << lg2)
+        if lg2 >= 1:
+            seed[1] = 1
+        for j in range(2, lg2 + 1):
+            imax = 1 << (j - 1)
+            for i in range(imax):
+                seed[i] <<= 1
+                seed[i + imax] = seed[i] + 1
+        perm = list(range(N))
+        if logn > 1:
+            for off in range(1, nn):
+                fj = nn * seed[off]
+                perm[off], perm[fj] = perm[fj], perm[off]
+                pp = off
+                for gno in range(1, seed[off]):
+                    pp += nn
+                    j = fj + seed[gno]
+                    perm[pp], perm[j] = perm[j], perm[pp]
+        self.perm = np.array(perm, np.int64)
+        # exp(-2 pi i k / NR), advanced by float32 complex multiplications
+        x = F32(two_pi / n_real * -1)
+        root_re, root_im = cosf(x), sinf(x)
+        k_re, k_im = F32(1.0), F32(0.0)
+        kn = [(k_re, k_im)]
+        for _ in range(1, N // 2 + 1):
+            t_re = F32(F32(k_re * root_re) - F32(k_im * root_im))
+            k_im = F32(F32(k_re * root_im) + F32(k_im * root_re))
+            k_re = t_re
+            kn.append((k_re, k_im))
+        self.kn = np.array(kn, F32)
+
+    def power_spectrum(self, frames: np.ndarray) -> np.ndarray:
+        """frames: T x NR float32 (windowed, zero padded).  Returns T x (NR/2 + 1) float32."""
+        assert frames.dtype == F32
+        xr = np.ascontiguousarray(frames[:, 0::2])
+        xi = np.ascontiguousarray(frames[:, 1::2])
+        sq = F32(0.70710678118654752440)
+        for e, mode, tw, k1, k2 in self.levels:
+            if len(e):
+                e0, e1, e2, e3 = e[:, 0], e[:, 1], e[:, 2], e[:, 3]
+                ar, ai, br, bi = xr[:, e0], xi[:, e0], xr[:, e1], xi[:, e1]
+                cr, ci, dr, di = xr[:, e2], xi[:, e2], xr[:, e3], xi[:, e3]
+                xr[:, e0], xi[:, e0] = ar + cr, ai + ci
+                xr[:, e1], xi[:, e1] = br + dr, bi + di
+                p_r, p_i, q_r, q_i = ar - cr, ai - ci, br - dr, bi - di
+                r1, i2, i1, r2 = p_r + q_i, p_i + q_r, p_i - q_r, p_r - q_i
+                # n == m/8
+                s_r1, s_i1 = sq * (r1 + i1), sq * (i1 - r1)
+                s_r2, s_i2 = sq * (i2 - r2), -sq * (r2 + i2)
+                # general twiddle
+                cn, spcn, smcn, c3n, spc3n, smc3n = (tw[None, :, j] for j in range(6))
+                t2 = cn * (r1 + i1)
+                g_i1 = spcn * r1 + t2
+                g_r1 = smcn * i1 + t2
+                t2 = c3n * (r2 + i2)
+                g_i2 = spc3n * r2 + t2
+                g_r2 = smc3n * i2 + t2
+                m1, m2 = (mode == 1)[None, :], (mode == 2)[None, :]
+                xr[:, e2] = np.where(m2, g_r1, np.where(m1, s_r1, r1))
+                xi[:, e2] = np.where(m2, g_i1, np.where(m1, s_i1, i1))
+                xr[:, e3] = np.where(m2, g_r2, np.where(m1, s_r2, r2))
+                xi[:, e3] = np.where(m2, g_i2, np.where(m1, s_i2, i2))
+            if len(k1):
+                r0, r1, r2, r3 = (xr[:, k1 + j] for j in range(4))
+                i0, i1, i2, i3 = (xi[:, k1 + j] for j in range(4))
+                r0, r2 = r0 + r2, r0 - r2
+                i0, i2 = i0 + i2, i0 - i2
+                r1, r3 = r1 + r3, r1 - r3
+                i1, i3 = i1 + i3, i1 - i3
+                r0, r1 = r0 + r1, r0 - r1
+                i0, i1 = i0 + i1, i0 - i1
+                t1, t2 = r2 + i3, i2 + r3
+                i2 = i2 - r3
+                r3 = r2 - i3
+                r2, i3 = t1, t2
+                for j, (rv, iv) in enumerate(((r0, i0), (r1, i1), (r2, i2), (r3, i3))):
+                    xr[:, k1 + j], xi[:, k1 + j] = rv, iv
+            if len(k2):
+                r0, r1, i0, i1 = xr[:, k2], xr[:, k2 + 1], xi[:, k2], xi[:, k2 + 1]
+                xr[:, k2], xr[:, k2 + 1] = r0 + r1, r0 - r1
+                xi[:, k2], xi[:, k2 + 1] = i0 + i1, i0 - i1
+        xr, xi = xr[:, self.perm], xi[:, self.perm]
+        N = self.N
+        power = np.zeros((frames.shape[0], N + 1), F32)
+        k = np.arange(1, N // 2 + 1)
+        kd = N - k
+        kn_re, kn_im = self.kn[k, 0][None, :], self.kn[k, 1][None, :]
+        half = F32(0.5)
+        ck_re, ck_im = half * (xr[:, k] + xr[:, kd]), half * (xi[:, k] - xi[:, kd])
+        dk_re, dk_im = half * (xi[:, k] + xi[:, kd]), -half * (xr[:, k] - xr[:, kd])
+        a_re = ck_re + (kn_re * dk_re - kn_im * dk_im)
+        a_im = ck_im + (kn_re * dk_im + kn_im * dk_re)
+        b_re = ck_re + ((-kn_re) * dk_re - kn_im * (-dk_im))
+        b_im = -ck_im + ((-kn_re) * (-dk_im) + kn_im * dk_re)
+        power[:, kd] = b_re * b_re + b_im * b_im          # k' = N/2 - k first: for k == k' the A_k value below wins
+        power[:, k] = a_re * a_re + a_im * a_im
+        zeroth, n2th = xr[:, 0] + xi[:, 0], xr[:, 0] - xi[:, 0]
+        power[:, 0] = zeroth * zeroth
+        power[:, N] = n2th * n2th
+        return power
+
+
 class Mfcc:
     def __init__(self, o: MfccOpts):
         assert o.dither == 0.0 and not o.use_energy and o.window_type == "povey"
@@ -111,6 +274,7 @@ class Mfcc:
         self.dct = dct[:o.num_ceps].astype(F32)
         q = o.cepstral_lifter
         self.lifter = (1.0 + 0.5 * q * np.sin(math.pi * np.arange(o.num_ceps) / q)).astype(F32) if q != 0 else np.ones(o.num_ceps, F32)
+        self.fft = SplitRadixRealFft(self.padded)
 
     def num_frames(self, n: int) -> int:
         return 0 if n < self.win else 1 + (n - self.win) // self.shift
@@ -130,8 +294,7 @@ class Mfcc:
         pre *= self.window[None, :]
         pad = np.zeros((T, self.padded), F32)
         pad[:, :self.win] = pre
-        spec = np.fft.rfft(pad.astype(np.float64), axis=1)
-        power = (spec.real ** 2 + spec.imag ** 2).astype(F32)
+        power = self.fft.power_spectrum(pad)
         mel = power @ self.melW.T
         mel = np.log(np.maximum(mel, np.finfo(F32).eps)).astype(F32)
         return ((mel @ self.dct.T) * self.lifter[None, :]).astype(F32)

@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "srfft_plan.h"
 #include "lattice.h"
 
 #include <algorithm>
@@ -190,11 +191,15 @@ void Model::ToDevice() {
   mfcc_dev_.dct = Upload(t.dct);
   mfcc_dev_.lifter = Upload(t.lifter);
   {
-    int NC = t.padded / 2;
-    std::vector<float> tw((size_t)2 * (NC + NC + 1));
-    for (int k = 0; k < NC; k++) { double a = 2.0 * M_PI * k / NC; tw[2 * k] = (float)cos(a); tw[2 * k + 1] = (float)-sin(a); }
-    for (int k = 0; k <= NC; k++) { double a = 2.0 * M_PI * k / t.padded; tw[2 * (NC + k)] = (float)cos(a); tw[2 * (NC + k) + 1] = (float)-sin(a); }
-    mfcc_dev_.twiddle = Upload(tw);
+    const SrfftPlan pl = BuildSrfftPlan(t.padded);
+    if ((int)pl.level_begin.size() - 1 > 15) Fail("FFT plan has too many levels");
+    static_assert(sizeof(SrfftTask) == 16, "SrfftTask is read as an int4");
+    mfcc_dev_.fft_tasks = static_cast<const int *>(UploadBytes(pl.tasks.data(), pl.tasks.size() * sizeof(SrfftTask)));
+    mfcc_dev_.fft_num_levels = (int)pl.level_begin.size() - 1;
+    for (size_t i = 0; i < pl.level_begin.size(); i++) mfcc_dev_.fft_level_begin[i] = pl.level_begin[i];
+    mfcc_dev_.fft_tw = Upload(pl.tw.empty() ? std::vector<float>(6, 0.f) : pl.tw);
+    mfcc_dev_.fft_perm = Upload(pl.perm);
+    mfcc_dev_.fft_kn = Upload(pl.kn);
   }
   // ---- CMVN on the nnet input branch
   if (fc_.use_cmvn) {

@@ -29,15 +29,83 @@ __device__ __forceinline__ float WaveMax(float v) {
 
 // ------------------------------------------------------------------------------------------ MFCC
 // One wave per output row (halo rows recompute their clamped edge frame: <10 % extra work for 3 s
-// utterances, no special cases downstream).  512-point real FFT = 256-point complex Stockham radix-4 FFT
-// (4 passes, one butterfly per lane per pass, ping-pong in LDS) + untangle.
+// utterances, no special cases downstream).
+//
+// The real FFT is the reference's own algorithm (matrix/srfft.cc: in-place single-precision split radix + a
+// post-processing pass whose twiddle comes from a float recurrence), restated as levels of independent butterfly
+// tasks (srfft_plan.h) executed lane-parallel with the same float operations on the same operands, so the power
+// spectrum matches the reference to the bit instead of to its own ~1e-3 rounding noise.  This file is compiled with
+// -ffp-contract=off for that reason.
+__device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restrict__ tw, float *xr, float *xi) {
+  const int kind = tk.x & 0xff, lg = tk.x >> 8, off = tk.y;
+  if (kind == 0) {
+    // srfft.cc:278-333 for one n: the four points it touches are private to this task
+    const int m = 1 << lg, m2 = m >> 1, m4 = m >> 2, n = tk.z;
+    const int e0 = off + n, e1 = e0 + m4, e2 = e0 + m2, e3 = e2 + m4;
+    const float ar = xr[e0], ai = xi[e0], br = xr[e1], bi = xi[e1], cr = xr[e2], ci = xi[e2], dr = xr[e3], di = xi[e3];
+    // step 1 on (e0, e2) and (e1, e3)
+    xr[e0] = ar + cr; xi[e0] = ai + ci;
+    xr[e1] = br + dr; xi[e1] = bi + di;
+    const float p_r = ar - cr, p_i = ai - ci, q_r = br - dr, q_i = bi - di;
+    // step 2 on the pair (e2, e3)
+    float r1 = p_r + q_i, i2 = p_i + q_r, i1 = p_i - q_r, r2 = p_r - q_i;
+    // steps 3 & 4
+    if (tk.w == -2) {
+      const float sqhalf = 0.70710678118654752440f;
+      const float t1 = sqhalf * (r1 + i1);
+      i1 = sqhalf * (i1 - r1);
+      r1 = t1;
+      const float t2 = sqhalf * (i2 - r2);
+      i2 = -sqhalf * (r2 + i2);
+      r2 = t2;
+    } else if (tk.w >= 0) {
+      const float *w = tw + (size_t)tk.w * 6;
+      const float cn = w[0], spcn = w[1], smcn = w[2], c3n = w[3], spc3n = w[4], smc3n = w[5];
+      float t2 = cn * (r1 + i1);
+      float t1 = spcn * r1 + t2;
+      r1 = smcn * i1 + t2;
+      i1 = t1;
+      t2 = c3n * (r2 + i2);
+      t1 = spc3n * r2 + t2;
+      r2 = smc3n * i2 + t2;
+      i2 = t1;
+    }
+    xr[e2] = r1; xi[e2] = i1;
+    xr[e3] = r2; xi[e3] = i2;
+  } else if (kind == 1) {
+    // srfft.cc:227-264: the whole length-4 transform
+    float r0 = xr[off], r1 = xr[off + 1], r2 = xr[off + 2], r3 = xr[off + 3];
+    float i0 = xi[off], i1 = xi[off + 1], i2 = xi[off + 2], i3 = xi[off + 3];
+    float t;
+    t = r0 + r2; r2 = r0 - r2; r0 = t;
+    t = i0 + i2; i2 = i0 - i2; i0 = t;
+    t = r1 + r3; r3 = r1 - r3; r1 = t;
+    t = i1 + i3; i3 = i1 - i3; i1 = t;
+    t = r0 + r1; r1 = r0 - r1; r0 = t;
+    t = i0 + i1; i1 = i0 - i1; i0 = t;
+    const float t1 = r2 + i3, t2 = i2 + r3;
+    i2 = i2 - r3;
+    r3 = r2 - i3;
+    r2 = t1;
+    i3 = t2;
+    xr[off] = r0; xr[off + 1] = r1; xr[off + 2] = r2; xr[off + 3] = r3;
+    xi[off] = i0; xi[off + 1] = i1; xi[off + 2] = i2; xi[off + 3] = i3;
+  } else {
+    // srfft.cc:265-274: length 2
+    const float r0 = xr[off], r1 = xr[off + 1], i0 = xi[off], i1 = xi[off + 1];
+    xr[off] = r0 + r1; xr[off + 1] = r0 - r1;
+    xi[off] = i0 + i1; xi[off + 1] = i0 - i1;
+  }
+}
+
 template <int NFFT>   // padded window (real points)
 __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
                                                   float *__restrict__ feats, int ld) {
   constexpr int NC = NFFT / 2;        // complex points
   constexpr int WPB = 4;              // waves (frames) per block
-  __shared__ float2 bufA[WPB][NC];
-  __shared__ float2 bufB[WPB][NC];
+  __shared__ float xbuf[WPB][NFFT];
+  __shared__ float xrb[WPB][NC];
+  __shared__ float xib[WPB][NC];
   __shared__ float pw[WPB][NC + 1];
   __shared__ float lm[WPB][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,7 +118,7 @@ __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const 
     int T = g.d_num_frames[u];
     t = t < 0 ? 0 : (t >= T ? T - 1 : t);
   }
-  float *x = reinterpret_cast<float *>(bufA[wave]);   // NFFT floats view
+  float *x = xbuf[wave];
   float raw_energy = 0.f;
   if (active) {
     const int16_t *src = pcm + g.d_sample_off[u] + (int64_t)t * m.shift;
@@ -72,67 +140,58 @@ __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const 
     }
   }
   __syncthreads();
-  float y[(NFFT / 2 + 63) / 64 * 2];   // pre-emphasised + windowed samples owned by this lane
+  float *xr = xrb[wave], *xi = xib[wave];
   if (active) {
-    // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does)
-    int n = 0;
-    for (int i = lane; i < m.win; i += RS_WAVE, n++) {
-      float prev = x[i > 0 ? i - 1 : 0];
-      float v = x[i] - m.preemph * prev;
-      y[n] = v * m.window[i];
+    // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does) and
+    // window; the even / odd samples are the real / imaginary parts of the half-length complex transform
+    float e = 0.f;
+    for (int i = lane; i < NFFT; i += RS_WAVE) {
+      float y = 0.f;
+      if (i < m.win) {
+        const float prev = x[i > 0 ? i - 1 : 0];
+        const float v = x[i] - m.preemph * prev;
+        y = v * m.window[i];
+        e += y * y;
+      }
+      if (i & 1) xi[i >> 1] = y; else xr[i >> 1] = y;
     }
+    if (m.use_energy && !m.raw_energy) raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
   }
   __syncthreads();
-  if (active) {
-    int n = 0;
-    for (int i = lane; i < m.win; i += RS_WAVE, n++) x[i] = y[n];
-    if (m.use_energy && !m.raw_energy) {
-      float e = 0.f;
-      n = 0;
-      for (int i = lane; i < m.win; i += RS_WAVE, n++) e += y[n] * y[n];
-      raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
-    }
+  // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
+  const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
+  for (int L = 0; L < m.fft_num_levels; L++) {
+    if (active)
+      for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], m.fft_tw, xr, xi);
+    __syncthreads();
   }
-  __syncthreads();
-  // 3. complex FFT of z[n] = x[2n] + i x[2n+1]  (bufA already holds it: float2 view of x)
-  float2 *in = bufA[wave], *out = bufB[wave];
-  const float2 *tw = reinterpret_cast<const float2 *>(m.twiddle);   // W_NC^k = (cos, -sin)(2 pi k / NC), k < NC
-  for (int Ns = 1; Ns < NC; Ns *= 4) {
-    if (active) {
-      for (int j = lane; j < NC / 4; j += RS_WAVE) {
-        int k = j % Ns;
-        float2 v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float2 a = in[j + r * (NC / 4)];
-          int ti = (k * r * (NC / (Ns * 4))) % NC;
-          float2 w = tw[ti];
-          v[r] = make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
-        }
-        // radix-4 butterfly (forward transform, W_4 = -i)
-        float2 s0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y), d0 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
-        float2 s1 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y), d1 = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
-        int j0 = (j / Ns) * Ns * 4 + k;
-        out[j0] = make_float2(s0.x + s1.x, s0.y + s1.y);
-        out[j0 + Ns] = make_float2(d0.x + d1.y, d0.y - d1.x);
-        out[j0 + 2 * Ns] = make_float2(s0.x - s1.x, s0.y - s1.y);
-        out[j0 + 3 * Ns] = make_float2(d0.x - d1.y, d0.y + d1.x);
+  // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
+  // spectrum element k of the bit-reversal pass is element perm[k] of the in-place result
+  if (active) {
+    for (int k = lane + 1; 2 * k <= NC; k += RS_WAVE) {
+      const int kd = NC - k;
+      const int pk = m.fft_perm[k], pd = m.fft_perm[kd];
+      const float bk_re = xr[pk], bk_im = xi[pk], bd_re = xr[pd], bd_im = xi[pd];
+      const float kn_re = m.fft_kn[2 * k], kn_im = m.fft_kn[2 * k + 1];
+      const float ck_re = 0.5f * (bk_re + bd_re), ck_im = 0.5f * (bk_im - bd_im);
+      const float dk_re = 0.5f * (bk_im + bd_im), dk_im = -0.5f * (bk_re - bd_re);
+      // A_k = C_k + kN D_k
+      const float a_re = ck_re + (kn_re * dk_re - kn_im * dk_im);
+      const float a_im = ck_im + (kn_re * dk_im + kn_im * dk_re);
+      pw[wave][k] = a_re * a_re + a_im * a_im;
+      if (kd != k) {
+        // A_k' = conj(C_k) + (-conj(kN)) conj(D_k)
+        const float nd_im = -dk_im, nk_re = -kn_re;
+        const float b_re = ck_re + (nk_re * dk_re - kn_im * nd_im);
+        const float b_im = -ck_im + (nk_re * nd_im + kn_im * dk_re);
+        pw[wave][kd] = b_re * b_re + b_im * b_im;
       }
     }
-    __syncthreads();
-    float2 *tmp = in; in = out; out = tmp;
-  }
-  // NC = 256 -> 4 passes (even) so the result is back in bufA; NC = 128 (3.5 passes) is not a power of 4
-  // 4. untangle -> power spectrum of the real transform, bins 0..NC
-  if (active) {
-    const float2 *tw2 = tw + NC;    // W_NFFT^k, k <= NC
-    for (int k = lane; k <= NC; k += RS_WAVE) {
-      float2 zk = in[k & (NC - 1)], zn = in[(NC - k) & (NC - 1)];
-      float er = 0.5f * (zk.x + zn.x), ei = 0.5f * (zk.y - zn.y);     // even part
-      float orr = 0.5f * (zk.y + zn.y), oi = -0.5f * (zk.x - zn.x);   // odd part (already times -i)
-      float2 w = tw2[k];
-      float xr = er + (orr * w.x - oi * w.y), xi = ei + (orr * w.y + oi * w.x);
-      pw[wave][k] = xr * xr + xi * xi;
+    if (lane == 0) {
+      const float d0 = xr[m.fft_perm[0]], d1 = xi[m.fft_perm[0]];
+      const float zeroth = d0 + d1, n2th = d0 - d1;
+      pw[wave][0] = zeroth * zeroth;
+      pw[wave][NC] = n2th * n2th;
     }
   }
   __syncthreads();

@@ -36,7 +36,13 @@ struct MfccDev {
   const float *mel_weights;
   const float *dct;          // nceps x nbins
   const float *lifter;       // nceps
-  const float *twiddle;      // padded/2 complex (cos, -sin) pairs for the complex FFT + untangle
+  // split-radix FFT plan (srfft_plan.h)
+  const int *fft_tasks;      // SrfftTask records (int4 each), level-major
+  int fft_num_levels;
+  int fft_level_begin[16];   // task range of each level
+  const float *fft_tw;       // 6 floats per twiddled butterfly
+  const int *fft_perm;       // padded/2: bit-reversal pass as a gather
+  const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
 };
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s);

@@ -9,16 +9,17 @@
 // "segments" (source buffer, time offset, column range) and reads the rows it needs straight from the
 // producer's output; halo rows make the row offset a constant (kernels.h).
 //
-// FP32 in / FP32 accumulate on v_mfma_f32_32x32x2_f32 (exact f32, 157 TF peak): the 1e-4 log-likelihood
+// FP32 in / FP32 accumulate on v_mfma_f32_16x16x4_f32 (exact f32, 157 TF peak): the 1e-4 log-likelihood
 // bound of the north-star rules out bf16/fp8 operands.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 
 #include "kernels.h"
 
 namespace rs {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float ApplyStage(const EltStageDev &st, float v, int col) {
   switch (st.kind) {
@@ -29,16 +30,29 @@ __device__ __forceinline__ float ApplyStage(const EltStageDev &st, float v, int 
   }
 }
 
-// 128 x 128 block tile, 4 waves in a 2 x 2 grid, each wave a 64 x 64 tile = 2 x 2 MFMA 32x32 accumulators.
-// The K loop runs over (segment, k-tile) pairs; the global loads of tile i+1 are issued into registers before
-// the MFMA work of tile i (software pipelining), so HBM/L2 latency hides behind 32 x BK/16 MFMAs per wave.
-__global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int *__restrict__ row_ivec) {
-  constexpr int BM = kGemmBM, BN = kGemmBN, BK = kGemmBK, LDS_LD = BK + 1;
-  constexpr int NV = BK / 16;                  // float4 loads per thread per operand half
-  __shared__ float As[BM * LDS_LD];
-  __shared__ float Bs[BN * LDS_LD];
+// Block tile BM x BN = (16 MT WM) x (64 WN), 4 waves in a WM x WN grid, each wave a (16 MT) x 64 tile of
+// v_mfma_f32_16x16x4_f32 accumulators (16-row granularity lets the launcher pick BM so that the number of tiles
+// divides evenly over the 256 CUs: a 128-row tile would leave the last round 1/8 full on the hidden layers).
+//
+// K loop over (segment, 32-wide k-tile) pairs, two-stage LDS ring, ONE barrier per k-tile:
+//   iteration t: fragments of tile t: LDS -> registers (16-byte reads); tile t+1: registers -> the other LDS stage;
+//   global loads of tile t+2 -> registers; then MT x 4 x 8 MFMAs.  Loads therefore have two full iterations to land.
+// LDS rows are 36 floats: 16-byte aligned for b128 accesses and conflict-free for the fragment reads
+// (lane (i, q) reads 8 consecutive floats at 36 i + 8 q: the 16 lanes of a phase cover all 64 banks).
+// K index mapping inside a k-tile: MFMA step s multiplies A[i][8 q + s] with B[8 q + s][j] (q = lane / 16 is the
+// instruction's own k index), so each lane's 8 operands of a row are contiguous in LDS.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256, 2) void GemmKernel(GemmDev d, int rows, const int *__restrict__ row_ivec, int epi_mode) {
+  constexpr int BM = 16 * MT * WM, BN = 64 * WN, BK = kGemmBK, LDS_LD = 36;
+  constexpr int NA = BM / 32, NB = BN / 32;          // 16-byte staging loads per thread and operand
+  constexpr int STAGE = (BM + BN) * LDS_LD;          // floats per LDS stage
+  constexpr int C_LD = BN + 4;                       // epilogue staging pitch: conflict-free for the C/D layout
+  static_assert(BM * C_LD <= 2 * STAGE, "the output tile is staged in the k-loop's LDS");
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: the hardware deals workgroup b to XCD b % 8; all column tiles of one row tile are given
   // to the same XCD back to back, so the row tile's activations are fetched into that XCD's L2 once and the
   // weights (<= 2 MB) stay L2-resident.  Placement only affects speed, never results.
@@ -47,110 +61,196 @@ __global__ __launch_bounds__(256) void GemmKernel(GemmDev d, int rows, const int
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
   if (rt >= nrow) return;
   const int row0 = rt * BM, n0 = ct * BN;
-  f32x16 acc[2][2];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: thread (lr0, lk) owns rows lr0 and lr0 + 64, columns lk + 16 * v (v < NV) of each tile
-  const int lr0 = tid >> 2, lk = (tid & 3) * 4;
-  int grow[2];
-  bool avalid[2];
+  // staging: thread (lr, kq) owns rows lr + 32 h of each tile, floats 4 kq .. 4 kq + 3 of the k-tile
+  const int lr = tid >> 3, kq = (tid & 7) * 4;
+  int grow[NA];
 #pragma unroll
-  for (int h = 0; h < 2; h++) { grow[h] = row0 + lr0 + h * 64; avalid[h] = grow[h] < rows; if (!avalid[h]) grow[h] = 0; }
-  const float *wrow[2];
+  for (int h = 0; h < NA; h++) { grow[h] = row0 + lr + h * 32; if (grow[h] >= rows) grow[h] = 0; }   // clamped rows are dropped in the epilogue
+  // W's K axis is the concatenation of the (padded) segments, so the weight pointers simply advance by BK per tile
+  const float *wptr[NB];
 #pragma unroll
-  for (int h = 0; h < 2; h++) wrow[h] = d.W + (size_t)(n0 + lr0 + h * 64) * d.k_pad;
+  for (int h = 0; h < NB; h++) wptr[h] = d.W + (size_t)(n0 + lr + h * 32) * d.k_pad + kq;
+  const float *aptr[NA];       // activation pointers: recomputed when the cursor enters a segment, then += BK
 
-  float4 av[2][NV], bv[2][NV];
-  // Branch-free staging loads: every lane always loads (rows past the end were clamped to row 0 and are dropped in
-  // the epilogue; columns past the segment's width are zeroed with selects).  Conditional loads make hipcc
-  // branch around each load and serialise them behind s_waitcnt.  Reads past a row's end stay inside the buffer
-  // (rows are padded / followed by guard rows; W is zero-padded to k_pad).
-  auto issue = [&](int seg, int k0) {
+  f32x4 av[NA], bv[NB];
+  int staged_lim = 0;
+  int seg = 0, k0 = 0, nt = 0;              // (segment, k0) cursor of the next tile to issue
+  for (int sgi = 0; sgi < d.nsegs; sgi++) nt += (d.segs[sgi].ncols + BK - 1) / BK;
+  auto enter_segment = [&]() __attribute__((always_inline)) {
     const GemmSegDev &sg = d.segs[seg];
-    const bool vec_ok = ((sg.ld & 3) == 0) && ((sg.col0 & 3) == 0);
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NA; h++) {
       const long arow = sg.per_utt ? (long)row_ivec[grow[h]] : (long)grow[h] + sg.row_off;
-      const float *ap = sg.src + arow * sg.ld + sg.col0;
-#pragma unroll
-      for (int v = 0; v < NV; v++) {
-        const int kk = k0 + lk + 16 * v;
-        float4 x;
-        if (vec_ok) {
-          x = *reinterpret_cast<const float4 *>(ap + kk);
-        } else {
-          x.x = ap[kk]; x.y = ap[kk + 1]; x.z = ap[kk + 2]; x.w = ap[kk + 3];
-        }
-        av[h][v] = x;            // masked later, when it is written to LDS (keeps the loads in flight across the MFMAs)
-        bv[h][v] = *reinterpret_cast<const float4 *>(wrow[h] + sg.k0 + kk);
-      }
+      aptr[h] = sg.src + arow * sg.ld + sg.col0 + kq;
     }
   };
-  int seg = 0, k0 = 0;
-  int kpad = (d.segs[0].ncols + BK - 1) / BK * BK;
-  if (d.nsegs > 0) issue(0, 0);
-  while (seg < d.nsegs) {
-    const int lim = d.segs[seg].ncols - k0 - lk;      // valid columns of the staged tile, relative to this lane's first
-    __syncthreads();                     // previous tile's LDS reads are done
+  // Branch-free staging loads: every lane always loads (columns past the segment's width are zeroed with selects
+  // when the tile is written to LDS).  Reads past a row's end stay inside the buffer (rows are padded / followed by
+  // guard rows; W is zero-padded to k_pad).
+  auto issue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int h = 0; h < NA; h++) {
+      if (VEC) av[h] = *reinterpret_cast<const f32x4 *>(aptr[h]);     // every segment's rows are 16-byte aligned (checked by the launcher)
+      else av[h] = f32x4{aptr[h][0], aptr[h][1], aptr[h][2], aptr[h][3]};
+      aptr[h] += BK;
+    }
 #pragma unroll
-      for (int v = 0; v < NV; v++) {
-        float *pa = &As[(lr0 + h * 64) * LDS_LD + lk + 16 * v];
-        const int l2 = lim - 16 * v;
-        pa[0] = l2 > 0 ? av[h][v].x : 0.f; pa[1] = l2 > 1 ? av[h][v].y : 0.f;
-        pa[2] = l2 > 2 ? av[h][v].z : 0.f; pa[3] = l2 > 3 ? av[h][v].w : 0.f;
-        float *pb = &Bs[(lr0 + h * 64) * LDS_LD + lk + 16 * v];
-        pb[0] = bv[h][v].x; pb[1] = bv[h][v].y; pb[2] = bv[h][v].z; pb[3] = bv[h][v].w;
-      }
-    // advance to the next tile and start its loads before computing this one
+    for (int h = 0; h < NB; h++) { bv[h] = *reinterpret_cast<const f32x4 *>(wptr[h]); wptr[h] += BK; }
+    staged_lim = d.segs[seg].ncols - k0 - kq;      // valid columns of the staged tile, relative to this lane's first
     k0 += BK;
-    if (k0 >= kpad) { seg++; k0 = 0; if (seg < d.nsegs) kpad = (d.segs[seg].ncols + BK - 1) / BK * BK; }
-    if (seg < d.nsegs) issue(seg, k0);
-    __syncthreads();
+    if (k0 >= d.segs[seg].ncols) { seg++; k0 = 0; if (seg < d.nsegs) enter_segment(); }
+  };
+  auto stage_store = [&](int stage) __attribute__((always_inline)) {
+    float *As = gsm + stage * STAGE, *Bs = As + BM * LDS_LD;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int kc = kk + (lane >> 5);
-      const float a0 = As[(wm * 64 + (lane & 31)) * LDS_LD + kc];
-      const float a1 = As[(wm * 64 + 32 + (lane & 31)) * LDS_LD + kc];
-      const float b0 = Bs[(wn * 64 + (lane & 31)) * LDS_LD + kc];
-      const float b1 = Bs[(wn * 64 + 32 + (lane & 31)) * LDS_LD + kc];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int h = 0; h < NA; h++) {
+      const f32x4 x = av[h];
+      *reinterpret_cast<f32x4 *>(&As[(lr + h * 32) * LDS_LD + kq]) =
+          f32x4{staged_lim > 0 ? x[0] : 0.f, staged_lim > 1 ? x[1] : 0.f, staged_lim > 2 ? x[2] : 0.f, staged_lim > 3 ? x[3] : 0.f};
+    }
+#pragma unroll
+    for (int h = 0; h < NB; h++) *reinterpret_cast<f32x4 *>(&Bs[(lr + h * 32) * LDS_LD + kq]) = bv[h];
+  };
+  if (nt > 0) { enter_segment(); issue(); stage_store(0); }
+  if (nt > 1) issue();
+  __syncthreads();
+  const int fi = lane & 15, fq = (lane >> 4) * 8;
+  for (int t = 0; t < nt; t++) {
+    const float *As = gsm + (t & 1) * STAGE, *Bs = As + BM * LDS_LD;
+    f32x4 af[MT][2], bf[4][2];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const float *pa = &As[(wm * 16 * MT + i * 16 + fi) * LDS_LD + fq];
+      af[i][0] = *reinterpret_cast<const f32x4 *>(pa);
+      af[i][1] = *reinterpret_cast<const f32x4 *>(pa + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float *pb = &Bs[(wn * 64 + j * 16 + fi) * LDS_LD + fq];
+      bf[j][0] = *reinterpret_cast<const f32x4 *>(pb);
+      bf[j][1] = *reinterpret_cast<const f32x4 *>(pb + 4);
+    }
+    if (t + 1 < nt) {
+      stage_store((t + 1) & 1);
+      if (t + 2 < nt) issue();
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+#pragma unroll
+      for (int i = 0; i < MT; i++) {
+        const float a = s < 4 ? af[i][0][s & 3] : af[i][1][s & 3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float b = s < 4 ? bf[j][0][s & 3] : bf[j][1][s & 3];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Bias and the fused
+  // stages are applied in registers (a lane's column is fixed per j, so the per-column parameters are loaded once),
+  // the tile is transposed through LDS and leaves as 16-byte row-contiguous stores.
+  float *Cs = gsm;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int cl = wn * 64 + j * 16 + (lane & 15), col = n0 + cl;
+    const bool cok = col < d.n;
+    const int cc = cok ? col : 0;
+    const float bias = (d.bias && cok) ? d.bias[cc] : 0.f;
+    float sc = 1.f, of = 0.f;
+    if (epi_mode == 2) { sc = d.stages[1].scale[cc]; of = d.stages[1].offset[cc]; }
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float v = __fadd_rn(bias, acc[i][j][r]);
+        if (epi_mode == 1) {
+          v = v > 0.f ? v : 0.f;
+        } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
+          v = v > 0.f ? v : 0.f;
+          v = __fadd_rn(__fmul_rn(v, sc), of);
+        } else if (epi_mode == 3) {
+          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, cc);
+        }
+        Cs[(wm * 16 * MT + i * 16 + 4 * (lane >> 4) + r) * C_LD + cl] = v;
+      }
     }
   }
-  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (col >= d.n) continue;
-    const float bias = d.bias ? d.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= rows) continue;
-        float v = __fadd_rn(bias, acc[i][j][r]);
-        for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, col);
-        d.out[(size_t)row * d.ldo + col] = v;
-      }
+  __syncthreads();
+  const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
+  if (vec_out) {
+    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+      const int rl = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const int row = row0 + rl, col = n0 + c4;
+      if (row < rows && col < d.n)
+        *reinterpret_cast<f32x4 *>(d.out + (size_t)row * d.ldo + col) = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+    }
+  } else {
+    for (int idx = tid; idx < BM * BN; idx += 256) {
+      const int rl = idx / BN, cl = idx % BN;
+      const int row = row0 + rl, col = n0 + cl;
+      if (row < rows && col < d.n) d.out[(size_t)row * d.ldo + col] = Cs[rl * C_LD + cl];
     }
   }
 }
 
+template <int MT, int WM, int WN, bool VEC>
+static void LaunchGemmV(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+  constexpr int BM = 16 * MT * WM, BN = 64 * WN;
+  constexpr size_t smem = 2 * (size_t)(BM + BN) * 36 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernel<MT, WM, WN, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int nrow = (rows + BM - 1) / BM, ncol = (d.n + BN - 1) / BN;
+  const int nrow8 = (nrow + 7) / 8 * 8;      // row tiles are dealt to the 8 XCDs round-robin
+  // fused-stage pattern of the epilogue: 0 none, 1 ReLU, 2 ReLU + per-column scale/offset (BatchNorm), 3 generic
+  int epi = 3;
+  if (d.nstages == 0) epi = 0;
+  else if (d.nstages == 1 && d.stages[0].kind == 0) epi = 1;
+  else if (d.nstages == 2 && d.stages[0].kind == 0 && d.stages[1].kind == 1) epi = 2;
+  hipLaunchKernelGGL((GemmKernel<MT, WM, WN, VEC>), dim3(nrow8 * ncol), dim3(256), smem, s, d, rows, row_ivec, epi);
+}
+template <int MT, int WM, int WN>
+static void LaunchGemmT(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+  bool vec = true;
+  for (int i = 0; i < d.nsegs; i++)
+    vec = vec && (d.segs[i].ld & 3) == 0 && (d.segs[i].col0 & 3) == 0 && (reinterpret_cast<uintptr_t>(d.segs[i].src) & 15) == 0;
+  if (vec) LaunchGemmV<MT, WM, WN, true>(d, rows, row_ivec, s);
+  else LaunchGemmV<MT, WM, WN, false>(d, rows, row_ivec, s);
+}
+
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   if (rows <= 0) return;
-  const int nrow = (rows + kGemmBM - 1) / kGemmBM, ncol = (d.n + kGemmBN - 1) / kGemmBN;
-  const int nrow8 = (nrow + 7) / 8 * 8;      // row tiles are dealt to the 8 XCDs round-robin
-  hipLaunchKernelGGL(GemmKernel, dim3(nrow8 * ncol), dim3(256), 0, s, d, rows, row_ivec);
+  static int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // tile height: the one whose busiest CU does the least work (ties -> the taller tile)
+  auto cost = [&](int bm, int bn) {
+    const long tiles = (long)((rows + bm - 1) / bm) * ((d.n + bn - 1) / bn);
+    return ((tiles + num_cu - 1) / num_cu) * bm * bn;
+  };
+  if (d.n <= 64) {
+    if (cost(64, 64) < cost(128, 64)) LaunchGemmT<1, 4, 1>(d, rows, row_ivec, s);
+    else LaunchGemmT<2, 4, 1>(d, rows, row_ivec, s);
+    return;
+  }
+  long c128 = cost(128, 128), c96 = cost(96, 128), c64 = cost(64, 128);
+  static int force_bm = [] { const char *e = std::getenv("RS_GEMM_BM"); return e ? std::atoi(e) : 0; }();
+  if (force_bm == 128) c128 = 0; else if (force_bm == 96) c96 = 0; else if (force_bm == 64) c64 = 0;
+  if (c128 <= c96 && c128 <= c64) LaunchGemmT<4, 2, 2>(d, rows, row_ivec, s);
+  else if (c96 <= c64) LaunchGemmT<3, 2, 2>(d, rows, row_ivec, s);
+  else LaunchGemmT<2, 2, 2>(d, rows, row_ivec, s);
 }
 
 // ------------------------------------------------------------------------------------------ elementwise

@@ -12,8 +12,11 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 LOGLIKE_TOL = 1e-4
-FEAT_TOL = 5e-3
-FEAT_TOL_P99 = 1e-3
+# MFCC: the split-radix FFT restates the reference's float operations one for one; what is left is the summation order
+# of the DC mean / mel / DCT dot products and libm-vs-device logf (typically 8e-5 on c0 ~ 100; near-empty mel bins of the
+# synthetic audio amplify the DC-mean rounding to ~2e-4)
+FEAT_TOL = 5e-4
+FEAT_TOL_P99 = 3e-4
 IVEC_TOL = 1e-4
 
 

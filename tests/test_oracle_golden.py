@@ -35,7 +35,9 @@ def test_oracle_matches_reference(oracles, name):
     tr = orc.transcribe(pcm, nbest=cases.NBEST)
     assert tr.num_frames == int(g["offline_num_frames"])
     fd = np.abs(tr.feats - g["input"])
-    assert fd.max() < 5e-3 and np.quantile(fd, 0.99) < 1e-3
+    # the FFT is the reference's own, operation for operation; what is left is the order of the BLAS sums (DC mean, mel,
+    # DCT), which perturbs near-empty mel bins of the synthetic audio
+    assert fd.max() < 5e-4 and np.quantile(fd, 0.99) < 3e-4
     if "offline_ivector" in g:
         assert np.abs(tr.ivector - g["offline_ivector"][0]).max() < 1e-4
     sr, sc = g["loglikes_stride"]
@@ -55,11 +57,11 @@ def test_oracle_intermediate_ivector_features(oracles):
     orc, pcm = oracles("tiny_u0")
     feats = orc.features(pcm)
     cm = pipeline.online_cmvn(feats, orc.ie["gstats"])
-    assert np.abs(cm - g["cmvn"]).max() < 5e-3
+    assert np.abs(cm - g["cmvn"]).max() < 5e-4
     raw = pipeline.lda_transform(pipeline.splice(feats, orc.ie["left"], orc.ie["right"]), orc.ie["lda"])
     nrm = pipeline.lda_transform(pipeline.splice(cm, orc.ie["left"], orc.ie["right"]), orc.ie["lda"])
-    assert np.abs(raw - g["lda"]).max() < 1e-3
-    assert np.abs(nrm - g["lda_norm"]).max() < 1e-3
+    assert np.abs(raw - g["lda"]).max() < 2e-4
+    assert np.abs(nrm - g["lda_norm"]).max() < 2e-4
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7"])
