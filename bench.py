@@ -57,6 +57,23 @@ def nnet_flops_per_row(desc: str) -> float:
     return fl
 
 
+def gemm_traffic_bytes(n_gemm: int):
+    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v2_pmc.json):
+    FETCH_SIZE (KB, doubled: this rocprofv3 tallies the 128-B requests of a 16 B/lane streaming read at 64 B) + WRITE_SIZE
+    (KB), averaged over the launches of the nnet stage.  None when the summary is absent."""
+    path = ROOT / "profiles" / "r01" / "bench_v2_pmc.json"
+    if not path.exists():
+        return None
+    ks = json.loads(path.read_text())["kernels"]
+    tot, n = 0.0, 0
+    for name, c in ks.items():
+        if "GemmKernel" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or "<2, 4, 1" in name or "<1, 4, 1" in name:
+            continue        # the narrow (BN = 64) instantiations are the two iVector LDA launches, not the nnet stage
+        tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * c["FETCH_SIZE"]["launches"]
+        n += c["FETCH_SIZE"]["launches"]
+    return tot / n if n else None
+
+
 def cpu_baseline(model_dir: Path, graph_dir: Path, pcm: np.ndarray, seconds_budget: float = 20.0):
     """Times the REFERENCE itself (oracle/_ref Kaldi binaries built from /root/reference by oracle/build_ref.sh)
     on this box's host cores on a bounded sample of the same workload: the 3-process pipeline of
@@ -162,12 +179,15 @@ def main() -> None:
         # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token
         # insertions x 16 B (8 B table key read-modify-write twice), tokens alive x 16 B token record
         dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
+        # dominant kernel: the segmented FP32-MFMA GEMM (one launch per affine layer).  achieved = algorithmic FLOPs of the
+        # stage's launches / their duration, timed with HIP events on the library's stream (rs_result_timings)
         roof_mfma = {"bound": "mfma", "achieved": flops / (stage[3] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": flops / (stage[3] * 1e-3) / 1e12 / 157.3, "traffic": None,
-                     "kernel": f"GemmKernel x{n_gemm} launches (whole nnet stage)", "stage_ms": float(stage[3])}
+                     "frac": flops / (stage[3] * 1e-3) / 1e12 / 157.3, "traffic": gemm_traffic_bytes(n_gemm),
+                     "kernel": f"GemmKernel, {n_gemm} launches per step (the nnet stage)", "launches": n_gemm,
+                     "avg_launch_ms": float(stage[3]) / n_gemm, "flops_per_launch": flops / n_gemm, "stage_ms": float(stage[3])}
         roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                    "kernel": "DecodeKernel (1 launch)", "stage_ms": float(stage[4])}
+                    "kernel": "RegDecodeKernel (1 launch, one workgroup per utterance, latency-bound)", "stage_ms": float(stage[4])}
         roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
         out = {
             "metric": "audio-seconds decoded/sec (RTF^-1) en_US-zamia grammar HCLG", "value": value, "unit": "audio-seconds/s",
