@@ -196,11 +196,14 @@ void Model::ToDevice() {
     static_assert(sizeof(SrfftTask) == 16, "SrfftTask is read as an int4");
     mfcc_dev_.fft_tasks = static_cast<const int *>(UploadBytes(pl.tasks.data(), pl.tasks.size() * sizeof(SrfftTask)));
     mfcc_dev_.fft_num_levels = (int)pl.level_begin.size() - 1;
+    mfcc_dev_.fft_num_tasks = (int)pl.tasks.size();
+    mfcc_dev_.fft_num_tw = (int)(pl.tw.size() / 6);
     for (size_t i = 0; i < pl.level_begin.size(); i++) mfcc_dev_.fft_level_begin[i] = pl.level_begin[i];
     mfcc_dev_.fft_tw = Upload(pl.tw.empty() ? std::vector<float>(6, 0.f) : pl.tw);
     mfcc_dev_.fft_perm = Upload(pl.perm);
     mfcc_dev_.fft_kn = Upload(pl.kn);
   }
+  if (t.nceps > 128) Fail("more than 128 cepstral coefficients are not supported");
   // ---- CMVN on the nnet input branch
   if (fc_.use_cmvn) {
     cmvn_nnet_dev_.dim = t.nceps; cmvn_nnet_dev_.cmn_window = fc_.cmvn.cmn_window;

@@ -102,6 +102,8 @@ template <int NFFT>   // padded window (real points)
 __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
                                                   float *__restrict__ feats, int ld) {
   constexpr int NC = NFFT / 2;        // complex points
+  const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
+  const float *fft_tw = m.fft_tw;
   constexpr int WPB = 4;              // waves (frames) per block
   __shared__ float xbuf[WPB][NFFT];
   __shared__ float xrb[WPB][NC];
@@ -159,10 +161,9 @@ __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const 
   }
   __syncthreads();
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
-  const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
   for (int L = 0; L < m.fft_num_levels; L++) {
     if (active)
-      for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], m.fft_tw, xr, xi);
+      for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], fft_tw, xr, xi);
     __syncthreads();
   }
   // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
@@ -217,57 +218,81 @@ __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const 
 
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s) {
   int blocks = (g.total_rows + 3) / 4;
-  if (blocks == 0) return;
+  if (!blocks) return;
   if (m.padded == 512) hipLaunchKernelGGL(MfccKernel<512>, dim3(blocks), dim3(256), 0, s, m, g, pcm, feats, ld);
   else hipLaunchKernelGGL(MfccKernel<2048>, dim3(blocks), dim3(256), 0, s, m, g, pcm, feats, ld);
 }
 
 // ------------------------------------------------------------------------------------------ online CMVN
-// One thread per (utterance, dim); frames are walked sequentially with the same add-new / subtract-old
-// double-precision update ComputeStatsForFrame performs, then SmoothOnlineCmvnStats with the global stats
-// (no speaker stats: the reference starts every utterance from a fresh process) and mean-only ApplyCmvn.
-__global__ void OnlineCmvnKernel(CmvnDev c, BatchGeom g, const float *__restrict__ in, float *__restrict__ out, int ld) {
-  int u = blockIdx.x, d = threadIdx.x;
-  if (d >= c.dim) return;
-  int T = g.d_num_frames[u];
-  size_t base = (size_t)g.d_row_base[u] + g.L;
-  double sum = 0.0, count = 0.0;
-  const double gsum = c.global_stats[d], gcount = c.global_stats[c.dim];
-  float first = 0.f, last = 0.f;
-  for (int t = 0; t < T; t++) {
-    float xv = in[(base + t) * ld + d];
-    sum += (double)xv;
-    count += 1.0;
-    int prev = t - c.cmn_window;
-    if (prev >= 0) {
-      sum -= (double)in[(base + prev) * ld + d];
-      count -= 1.0;
+// Workgroup per utterance, frames in chunks staged through LDS.  Per chunk: (1) thread d walks the frames with the same
+// add-new / subtract-old double-precision update ComputeStatsForFrame performs (the only sequential part: two adds
+// per frame), (2) one thread per frame does SmoothOnlineCmvnStats' per-frame scalars (the two fp64 divisions), (3) all
+// threads apply the mean-only ApplyCmvn to the chunk in parallel with coalesced stores.  No speaker stats: the
+// reference starts every utterance from a fresh process.
+constexpr int kCmvnTC = 32, kCmvnMaxDim = 128;
+__global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, const float *__restrict__ in, float *__restrict__ out, int ld) {
+  __shared__ float xs[kCmvnTC][kCmvnMaxDim];      // the chunk
+  __shared__ float xp[kCmvnTC][kCmvnMaxDim];      // the frames leaving the window while the chunk enters
+  __shared__ double ss[kCmvnTC][kCmvnMaxDim];     // running sums after each frame
+  __shared__ double nn[kCmvnTC], aa[kCmvnTC];     // frame count in the window; weight of the global stats
+  __shared__ float al[kCmvnTC];                   // -1 / (smoothed count)
+  __shared__ float edge[2][kCmvnMaxDim];          // normalised first / last frame (halo rows replicate them)
+  const int u = blockIdx.x, tid = threadIdx.x, D = c.dim, W = c.cmn_window;
+  const int T = g.d_num_frames[u];
+  const size_t base = (size_t)g.d_row_base[u] + g.L;
+  double sum = 0.0, count = 0.0;                  // threads < D
+  const double gcount = c.global_stats[D];
+  for (int t0 = 0; t0 < T; t0 += kCmvnTC) {
+    const int n = T - t0 < kCmvnTC ? T - t0 : kCmvnTC;
+    for (int idx = tid; idx < n * D; idx += 256) {
+      const int i = idx / D, d = idx % D, tp = t0 + i - W;
+      xs[i][d] = in[(base + t0 + i) * ld + d];
+      xp[i][d] = tp >= 0 ? in[(base + tp) * ld + d] : 0.f;
     }
-    double s = sum, n = count;
-    if (n < (double)c.cmn_window) {
-      double from_global = (double)c.cmn_window - n;
-      if (from_global > (double)c.global_frames) from_global = (double)c.global_frames;
-      if (from_global > 0.0) {
-        double a = from_global / gcount;
-        s += a * gsum;
-        n += a * gcount;
+    __syncthreads();
+    if (tid < D) {
+      for (int i = 0; i < n; i++) {
+        sum += (double)xs[i][tid];
+        count += 1.0;
+        if (t0 + i - W >= 0) { sum -= (double)xp[i][tid]; count -= 1.0; }
+        ss[i][tid] = sum;
+        if (tid == 0) nn[i] = count;
       }
     }
-    float alpha = (float)(-1.0 / n);
-    float offset = (float)((double)alpha * s);
-    float yv = xv + offset;
-    out[(base + t) * ld + d] = yv;
-    if (t == 0) first = yv;
-    last = yv;
+    __syncthreads();
+    if (tid < n) {
+      double nf = nn[tid], a = 0.0;
+      if (nf < (double)W) {
+        double from_global = (double)W - nf;
+        if (from_global > (double)c.global_frames) from_global = (double)c.global_frames;
+        if (from_global > 0.0) { a = from_global / gcount; nf += a * gcount; }
+      }
+      aa[tid] = a;
+      al[tid] = (float)(-1.0 / nf);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * D; idx += 256) {
+      const int i = idx / D, d = idx % D;
+      double sv = ss[i][d];
+      const double a = aa[i];
+      if (a > 0.0) sv += a * c.global_stats[d];
+      const float offset = (float)((double)al[i] * sv);
+      const float yv = xs[i][d] + offset;
+      out[(base + t0 + i) * ld + d] = yv;
+      if (t0 + i == 0) edge[0][d] = yv;
+      if (t0 + i == T - 1) edge[1][d] = yv;
+    }
+    __syncthreads();
   }
-  for (int t = -g.L; t < 0; t++) out[(base + t) * ld + d] = first;
-  for (int t = T; t < T + g.R; t++) out[(base + t) * ld + d] = last;
+  if (T > 0) {
+    for (int idx = tid; idx < g.L * D; idx += 256) out[(base - g.L + idx / D) * ld + idx % D] = edge[0][idx % D];
+    for (int idx = tid; idx < g.R * D; idx += 256) out[(base + T + idx / D) * ld + idx % D] = edge[1][idx % D];
+  }
 }
 
 void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s) {
   if (g.n_utts == 0) return;
-  int threads = ((c.dim + 63) / 64) * 64;
-  hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(threads), 0, s, c, g, in, out, ld);
+  hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(256), 0, s, c, g, in, out, ld);
 }
 
 }  // namespace rs

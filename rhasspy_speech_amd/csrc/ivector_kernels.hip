@@ -35,7 +35,12 @@ template <int NPL, int R>
 __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
                                                      int *__restrict__ post_idx, float *__restrict__ post_w) {
   constexpr int NP2 = (NPL + 1) / 2;
+  static_assert(R <= 8, "phase B maps (row, slot) to lane = 8 row + slot");
   __shared__ float xs[4][R][128];
+  __shared__ unsigned ckey[4][64 * 2 * NP2];      // per-wave candidate list
+  __shared__ int cgi[4][64 * 2 * NP2];
+  __shared__ float sel_ll[4][R][8], sel_max[4][R];
+  __shared__ int sel_gi[4][R][8], sel_n[4][R];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + wave) * R;
   const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
@@ -85,10 +90,11 @@ __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, co
 #pragma unroll
     for (int j = 0; j < 2 * NP2; j++) gc[j] = iv.gconsts[gidx[j]];
     const float log_min_post = logf(iv.min_post);
+    // ---- phase A, per row: candidates (like > max + log min_post) are compacted into a per-wave LDS list, the
+    // num_gselect best are taken from the list (normally a handful of entries, one per lane)
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (!((active >> r) & 1u)) continue;         // wave-uniform
-      // log-likelihoods as order-preserving keys; lanes past G get key 0 (below every real value)
       unsigned key[2 * NP2];
       unsigned lmax = 0u;
 #pragma unroll
@@ -96,68 +102,106 @@ __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, co
         const float s1 = (j & 1) ? a1[r][j >> 1].y : a1[r][j >> 1].x, s2 = (j & 1) ? a2[r][j >> 1].y : a2[r][j >> 1].x;
         float v = gc[j] + s1;
         v = v + (-0.5f) * s2;
-        key[j] = (lane + j * 64 < G && j < NPL) ? wv::FloatToOrdered(v) : 0u;
+        key[j] = (lane + j * 64 < G && j < NPL) ? wv::FloatToOrdered(v) : 0u;   // lanes past G: below every real value
         lmax = max(lmax, key[j]);
       }
       const unsigned kmax = wv::MaxU(lmax);
       const float max_like = wv::OrderedToFloat(kmax);
-      const unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);     // candidates: like > cutoff
-      float sel_ll[8];
-      int sel_i[8];
-      int nfound = 0;
+      const unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);
+      int C = 0;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        sel_ll[k] = 0.f;
-        sel_i[k] = -1;
-        if (k < nsel && nfound == k) {
-          unsigned bv = 0u;
-          int bj = 0;
-#pragma unroll
-          for (int j = 0; j < 2 * NP2; j++) if (key[j] > bv) { bv = key[j]; bj = j; }
-          const unsigned wm = wv::MaxU(bv);
-          if (wm > kcut) {
-            const unsigned long long tie = __ballot(bv == wm);
-            int gi;
-            if (__popcll(tie) == 1) {
-              const int src = __ffsll((long long)tie) - 1;
-              gi = src + 64 * __builtin_amdgcn_readlane(bj, src);
-            } else {
-              gi = (int)wv::MinU(bv == wm ? (unsigned)(lane + 64 * bj) : 0x7fffffffu);
-            }
-            sel_ll[k] = wv::OrderedToFloat(wm);
-            sel_i[k] = gi;
-            nfound = k + 1;
-#pragma unroll
-            for (int j = 0; j < 2 * NP2; j++) if (lane + j * 64 == gi) key[j] = 0u;
+      for (int j = 0; j < 2 * NP2; j++) {
+        const bool cand = key[j] > kcut;
+        const unsigned long long mask = __ballot(cand);
+        if (mask != 0ull) {                        // wave-uniform, rare per j
+          if (cand) {
+            const int pos = C + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            ckey[wave][pos] = key[j];
+            cgi[wave][pos] = lane + j * 64;
           }
+          C += __popcll(mask);
         }
       }
-      // posteriors of the kept Gaussians: lane k evaluates exp(like_k - max_like) in double, as the reference does
-      float my_ll = 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int nfound = 0;
+      if (C <= 64) {
+        unsigned kv = lane < C ? ckey[wave][lane] : 0u;
+        const int gv = lane < C ? cgi[wave][lane] : 0x7fffffff;
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (lane == k) my_ll = sel_ll[k];
-      const float my_post = lane < nfound ? (float)exp((double)(my_ll - max_like)) : 0.f;
-      float sel_w[8];
+        for (int k = 0; k < 8; k++) {
+          if (k < nsel && nfound == k) {
+            const unsigned wm = wv::MaxU(kv);
+            if (wm != 0u) {
+              const unsigned long long tie = __ballot(kv == wm);
+              int gi;
+              if (__popcll(tie) == 1) gi = __builtin_amdgcn_readlane(gv, __ffsll((long long)tie) - 1);
+              else gi = (int)wv::MinU(kv == wm ? (unsigned)gv : 0x7fffffffu);     // ties -> lowest Gaussian index
+              if (lane == 0) { sel_ll[wave][r][k] = wv::OrderedToFloat(wm); sel_gi[wave][r][k] = gi; }
+              nfound = k + 1;
+              if (gv == gi) kv = 0u;
+            }
+          }
+        }
+      } else {
+        for (int k = 0; k < nsel && nfound == k; k++) {
+          unsigned bv = 0u;
+          int bg = 0x7fffffff, bi = -1;
+          for (int i = lane; i < C; i += 64) {
+            const unsigned kk = ckey[wave][i];
+            const int gg = cgi[wave][i];
+            if (kk > bv || (kk == bv && kk != 0u && gg < bg)) { bv = kk; bg = gg; bi = i; }
+          }
+          const unsigned wm = wv::MaxU(bv);
+          if (wm == 0u) break;
+          const int gi = (int)wv::MinU(bv == wm ? (unsigned)bg : 0x7fffffffu);
+          if (bv == wm && bg == gi) ckey[wave][bi] = 0u;
+          if (lane == 0) { sel_ll[wave][r][k] = wv::OrderedToFloat(wm); sel_gi[wave][r][k] = gi; }
+          nfound = k + 1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (lane == 0) { sel_n[wave][r] = nfound; sel_max[wave][r] = max_like; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- phase B, all rows of the wave at once: lane (r, k) evaluates exp(like - max) in double as the reference
+    // does; lane r then prunes and renormalises row r (posterior.cc:494-507) and writes it
+    {
+      const int r = lane >> 3, k = lane & 7;
+      const bool row_ok = r < R && ((active >> r) & 1u);
+      const int nf = row_ok ? sel_n[wave][r] : 0;
+      float post = 0.f;
+      if (k < nf) post = (float)exp((double)(sel_ll[wave][r][k] - sel_max[wave][r]));
+      if (r < R) sel_ll[wave][r][k] = post;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < R && ((active >> lane) & 1u)) {
+        const int rr = lane;
+        int nfound = sel_n[wave][rr];
+        float sel_w[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) sel_w[k] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(my_post), k));
-      // prune + renormalise (posterior.cc:494-507), identical on every lane
-      float tot = 0.f;
+        for (int q = 0; q < 8; q++) sel_w[q] = sel_ll[wave][rr][q];
+        float tot = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (k < nfound) tot += sel_w[k];
-      const float cutoff = iv.min_post * tot;
+        for (int q = 0; q < 8; q++) if (q < nfound) tot += sel_w[q];
+        const float cutoff = iv.min_post * tot;
 #pragma unroll
-      for (int k = 7; k >= 1; k--)
-        if (nfound == k + 1 && sel_w[k] < cutoff) { tot -= sel_w[k]; nfound = k; }
-      const float inv_tot = (float)(1.0 / (double)tot);
-      const float scale = iv.posterior_scale * 1.0f;
-      float w = 0.f;
-      int gi = -1;
+        for (int q = 7; q >= 1; q--)
+          if (nfound == q + 1 && sel_w[q] < cutoff) { tot -= sel_w[q]; nfound = q; }
+        const float inv_tot = (float)(1.0 / (double)tot);
+        const float scale = iv.posterior_scale * 1.0f;
 #pragma unroll
-      for (int k = 0; k < 8; k++)
-        if (k == lane && k < nfound) { w = sel_w[k] * inv_tot; w *= scale; gi = sel_i[k]; }
-      if (lane < nsel) {
-        post_idx[(size_t)(row0 + r) * nsel + lane] = gi;
-        post_w[(size_t)(row0 + r) * nsel + lane] = w;
+        for (int q = 0; q < 8; q++) {
+          if (q < nsel) {
+            float w = 0.f;
+            int gi = -1;
+            if (q < nfound) { w = sel_w[q] * inv_tot; w *= scale; gi = sel_gi[wave][rr][q]; }
+            post_idx[(size_t)(row0 + rr) * nsel + q] = gi;
+            post_w[(size_t)(row0 + rr) * nsel + q] = w;
+          }
+        }
       }
     }
   }
@@ -202,33 +246,115 @@ void LaunchIvecInit(const IvecDev &iv, int n_utts, double *linear, double *quadr
   hipLaunchKernelGGL(IvecInitKernel, dim3(n_utts), dim3(256), 0, s, iv, linear, quadratic, x, num_frames);
 }
 
-// Block per utterance; frames in order so that every per-Gaussian sum is accumulated in the reference's
-// frame order (AccStats: weighted_feats.AddVec per frame, float tot_weight).
-__global__ __launch_bounds__(256) void IvecAccumKernel(IvecDev iv, BatchGeom g, const float *__restrict__ lda, int ld,
-                                                        const int *__restrict__ post_idx, const float *__restrict__ post_w,
-                                                        const int *frame_begin, const int *frame_end,
-                                                        float *__restrict__ gamma, double *__restrict__ wfeats) {
-  int u = blockIdx.x;
-  int T = g.d_num_frames[u];
-  int t0 = frame_begin ? frame_begin[u] : 0, t1 = frame_end ? frame_end[u] : T;
-  if (t1 > T) t1 = T;
-  int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
-  size_t base = (size_t)g.d_row_base[u] + g.L;
+// Per-Gaussian first-order statistics (AccStats: weighted_feats.AddVec per frame in double, float tot_weight), every sum
+// accumulated in the reference's frame order.  Workgroup per utterance, frames in chunks:
+//   1. the chunk's posteriors (<= num_gselect per frame) and feature rows are staged in LDS;
+//   2. the entries are counting-sorted by Gaussian, stably in frame order: 16 waves histogram 16 frame segments, a
+//      per-Gaussian prefix over the segments gives every segment its write cursor, each wave then walks its segment
+//      frame by frame (the Gaussians of one frame are distinct, so a frame's entries can be placed in parallel);
+//   3. the (Gaussian, dim) sums are independent: each thread takes pairs, walks that Gaussian's entry list in order
+//      and does its read-modify-write of wfeats / gamma exactly once -- instead of one global round trip per frame.
+constexpr int kAccTC = 256;          // frames per chunk
+constexpr int kAccNSeg = 16;         // frame segments sorted in parallel (<= waves per workgroup); fewer when G is large
+__global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g, const float *__restrict__ lda, int ld,
+                                                         const int *__restrict__ post_idx, const float *__restrict__ post_w,
+                                                         const int *frame_begin, const int *frame_end,
+                                                         float *__restrict__ gamma, double *__restrict__ wfeats, int nseg) {
+  extern __shared__ __attribute__((aligned(16))) char acc_smem[];
+  const int u = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int T = g.d_num_frames[u];
+  int t_begin = frame_begin ? frame_begin[u] : 0, t_end = frame_end ? frame_end[u] : T;
+  if (t_end > T) t_end = T;
+  const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
+  const size_t base = (size_t)g.d_row_base[u] + g.L;
   float *gm = gamma + (size_t)u * G;
   double *wf = wfeats + (size_t)u * G * D;
-  for (int t = t0; t < t1; t++) {
-    size_t row = base + t;
-    for (int i = threadIdx.x; i < nsel * D; i += blockDim.x) {
-      int j = i / D, d = i % D;
-      int gi = post_idx[row * nsel + j];
-      if (gi >= 0) {
-        float w = post_w[row * nsel + j];
-        wf[(size_t)gi * D + d] += (double)w * (double)lda[row * ld + d];
-        if (d == 0) gm[gi] += w;
+  // LDS carve-up
+  float *xs = reinterpret_cast<float *>(acc_smem);                    // [kAccTC][D]
+  int *eidx = reinterpret_cast<int *>(xs + (size_t)kAccTC * D);       // [kAccTC * nsel] Gaussian of each entry (-1 = none)
+  float *ew = reinterpret_cast<float *>(eidx + kAccTC * nsel);        // [kAccTC * nsel] posterior
+  int *hist = reinterpret_cast<int *>(ew + kAccTC * nsel);            // [kAccNSeg][G]  counts, then write cursors
+  int *cnt = hist + nseg * G;                                         // [G]
+  int *off = cnt + G;                                                 // [G + 1]
+  unsigned short *order = reinterpret_cast<unsigned short *>(off + G + 1);   // [kAccTC * nsel] entry ids sorted by Gaussian
+  for (int t0 = t_begin; t0 < t_end; t0 += kAccTC) {
+    const int n = t_end - t0 < kAccTC ? t_end - t0 : kAccTC, ne = n * nsel;
+    const int seglen = (n + nseg - 1) / nseg;
+    __syncthreads();
+    for (int i = tid; i < n * D; i += 1024) xs[i] = lda[(base + t0 + i / D) * ld + i % D];
+    for (int e = tid; e < ne; e += 1024) { eidx[e] = post_idx[(base + t0) * nsel + e]; ew[e] = post_w[(base + t0) * nsel + e]; }
+    for (int i = tid; i < nseg * G; i += 1024) hist[i] = 0;
+    __syncthreads();
+    // 2a. per-segment histograms
+    if (wave < nseg) {
+      const int f0 = wave * seglen, f1 = f0 + seglen < n ? f0 + seglen : n;
+      for (int e = f0 * nsel + lane; e < f1 * nsel; e += 64) { const int gi = eidx[e]; if (gi >= 0) atomicAdd(&hist[wave * G + gi], 1); }
+    }
+    __syncthreads();
+    // 2b. per Gaussian: exclusive prefix over the segments; then an exclusive scan over the Gaussians
+    for (int gi = tid; gi < G; gi += 1024) {
+      int run = 0;
+      for (int sgm = 0; sgm < nseg; sgm++) { const int c = hist[sgm * G + gi]; hist[sgm * G + gi] = run; run += c; }
+      cnt[gi] = run;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int carry = 0;
+      for (int g0 = 0; g0 < G; g0 += 64) {
+        const int gi = g0 + lane, c = gi < G ? cnt[gi] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (gi < G) off[gi] = carry + inc - c;
+        carry += __shfl(inc, 63, 64);
+      }
+      if (lane == 0) off[G] = carry;
+    }
+    __syncthreads();
+    // 2c. stable placement: a wave walks its segment frame by frame
+    if (wave < nseg) {
+      const int f0 = wave * seglen, f1 = f0 + seglen < n ? f0 + seglen : n;
+      for (int f = f0; f < f1; f++) {
+        if (lane < nsel) {
+          const int e = f * nsel + lane, gi = eidx[e];
+          if (gi >= 0) { const int pos = off[gi] + hist[wave * G + gi]; hist[wave * G + gi]++; order[pos] = (unsigned short)e; }
+        }
       }
     }
     __syncthreads();
+    // 3. independent (Gaussian, dim) sums, each in frame order; the read-modify-write of wfeats is batched so that
+    // PG global loads are in flight at once
+    constexpr int PG = 8;
+    for (int p0 = tid; p0 < G * D; p0 += 1024 * PG) {
+      double acc[PG];
+#pragma unroll
+      for (int q = 0; q < PG; q++) { const int p = p0 + q * 1024; acc[q] = p < G * D ? wf[p] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < PG; q++) {
+        const int p = p0 + q * 1024;
+        if (p >= G * D) continue;
+        const int gi = p / D, d = p % D, c = cnt[gi];
+        if (c == 0) continue;
+        const int o0 = off[gi];
+        double a = acc[q];
+        for (int k = 0; k < c; k++) {
+          const int e = order[o0 + k];
+          a += (double)ew[e] * (double)xs[(e / nsel) * D + d];
+        }
+        wf[p] = a;
+        if (d == 0) {
+          float ga = gm[gi];
+          for (int k = 0; k < c; k++) ga += ew[order[o0 + k]];
+          gm[gi] = ga;
+        }
+      }
+    }
   }
+}
+
+static size_t IvecAccumSmemBytes(const IvecDev &iv, int nseg) {
+  const size_t ne = (size_t)kAccTC * iv.num_gselect;
+  return (size_t)kAccTC * iv.feat_dim * 4 + ne * 8 + ((size_t)nseg * iv.num_gauss + 2 * (size_t)iv.num_gauss + 1) * 4 + ne * 2 + 64;
 }
 
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
@@ -237,8 +363,16 @@ void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *ld
   if (g.n_utts == 0) return;
   // gamma is kept in float (GaussInfo::tot_weight is a BaseFloat); the buffer is sized for doubles, we use
   // its first half as floats.
-  hipLaunchKernelGGL(IvecAccumKernel, dim3(g.n_utts), dim3(256), 0, s, iv, g, lda, ld, post_idx, post_w, frame_begin,
-                     frame_end, reinterpret_cast<float *>(gamma), wfeats);
+  int nseg = kAccNSeg;
+  while (nseg > 1 && IvecAccumSmemBytes(iv, nseg) > 150 * 1024) nseg >>= 1;
+  const size_t smem = IvecAccumSmemBytes(iv, nseg);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecAccumKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(IvecAccumKernel, dim3(g.n_utts), dim3(1024), smem, s, iv, g, lda, ld, post_idx, post_w, frame_begin,
+                     frame_end, reinterpret_cast<float *>(gamma), wfeats, nseg);
 }
 
 constexpr int kIvecUB = 8;        // utterances per workgroup in the two batch products
@@ -506,11 +640,145 @@ __global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, c
   }
 }
 
+// ---- fast path for ivector_dim <= 128: the quadratic term is expanded to a full n x n matrix in LDS so that a row's
+// dot product reads consecutive addresses across lanes (conflict-free), the dot products of a CG step are reduced with
+// DPP row rotations inside a wave and one LDS exchange across waves (one barrier per reduction instead of a tree).
+// Same iteration (LinearCgd, matrix/optimization.cc:453-566) and the same decisions as IvecSolveKernel.
+template <int CTRL>
+__device__ __forceinline__ double DppD(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ReadLaneD(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double WaveSumD(double v) {
+  v += DppD<0x121>(v);
+  v += DppD<0x122>(v);
+  v += DppD<0x124>(v);
+  v += DppD<0x128>(v);
+  return (ReadLaneD(v, 0) + ReadLaneD(v, 16)) + (ReadLaneD(v, 32) + ReadLaneD(v, 48));
+}
+template <int K, int NW>
+__device__ __forceinline__ void BlockSumK(const double (&v)[K], double (&out)[K], double (*xch)[NW][4], int &rb) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const double w = WaveSumD(v[k]);
+    if (lane == 0) xch[rb][wave][k] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double t = xch[rb][0][k];
+#pragma unroll
+    for (int w = 1; w < NW; w++) t += xch[rb][w][k];
+    out[k] = t;
+  }
+  rb ^= 1;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const double *__restrict__ linear,
+                                                               const double *__restrict__ quadratic, const double *__restrict__ num_frames,
+                                                               double *__restrict__ xio, float *__restrict__ ivec_out, int ldo,
+                                                               const int *__restrict__ out_row, const int *__restrict__ active) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double xch[2][NW][4];
+  int rb = 0;
+  const int u = blockIdx.x, tid = threadIdx.x, n = iv.ivec_dim;
+  const int orow = out_row ? out_row[u] : u;
+  if (orow < 0) return;                                    // this utterance has no chunk at this step
+  const bool solve = active ? active[u] != 0 : true;       // 0: re-emit the current estimate (no new frames)
+  const int usz = n * (n + 1) / 2;
+  double *A = reinterpret_cast<double *>(smem_raw);        // n x n, symmetric
+  double *xs = A + (size_t)n * n, *ps = xs + n;            // the vectors a row product reads
+  const bool mine = tid < n;
+  const bool have = num_frames[u] > 0.0;
+  double x = mine ? xio[(size_t)u * n + tid] : 0.0;
+  if (solve && have) {
+    // expand the packed lower triangle: element k = r(r+1)/2 + c  (c <= r)
+    for (int k = tid; k < usz; k += 64 * NW) {
+      int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= k) r++;
+      while (r * (r + 1) / 2 > k) r--;
+      const int cc = k - r * (r + 1) / 2;
+      const double v = quadratic[(size_t)u * usz + k];
+      A[(size_t)r * n + cc] = v;
+      A[(size_t)cc * n + r] = v;
+    }
+    const double b = mine ? linear[(size_t)u * n + tid] : 0.0;
+    if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
+    if (mine) xs[tid] = x;
+    __syncthreads();
+    auto matvec = [&](const double *vec) __attribute__((always_inline)) {
+      double acc = 0.0;
+      if (mine)
+        for (int c = 0; c < n; c++) acc += A[(size_t)c * n + tid] * vec[c];
+      return acc;
+    };
+    // p0 = b - A x0 ; r0 = -p0
+    double p = b - matvec(xs), r = -p;
+    if (!mine) { p = 0.0; r = 0.0; }
+    double in1[1] = {r * r}, out1[1];
+    BlockSumK<1, NW>(in1, out1, xch, rb);
+    double r_cur = out1[0], r_recompute = r_cur;
+    const double max_error_sq = DBL_MIN, residual_factor = (double)(0.01f * 0.01f), inv_residual_factor = 1.0 / residual_factor;
+    for (int k = 0; k < n + 5 && k != iv.num_cg_iters; k++) {
+      if (mine) ps[tid] = p;
+      __syncthreads();
+      const double ap = matvec(ps);
+      double in2[2] = {p * r, p * ap}, out2[2];
+      BlockSumK<2, NW>(in2, out2, xch, rb);
+      const double alpha = -out2[0] / out2[1];
+      x += alpha * p;
+      r += alpha * ap;
+      in1[0] = r * r;
+      BlockSumK<1, NW>(in1, out1, xch, rb);
+      double r_next = out1[0];
+      if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
+        if (mine) xs[tid] = x;
+        __syncthreads();
+        r = mine ? matvec(xs) - b : 0.0;
+        in1[0] = r * r;
+        BlockSumK<1, NW>(in1, out1, xch, rb);
+        r_next = out1[0];
+        r_recompute = r_next;
+      }
+      if (r_next <= max_error_sq) break;
+      const double beta = r_next / r_cur;
+      p = p * beta - r;
+      r_cur = r_next;
+    }
+  } else if (solve) {
+    x = (tid == 0) ? iv.prior_offset : 0.0;
+  }
+  if (mine) {
+    if (solve) xio[(size_t)u * n + tid] = x;
+    float v = (float)x;
+    if (tid == 0) v = (float)((double)v - iv.prior_offset);   // (*feat)(0) -= PriorOffset() on the float copy
+    ivec_out[(size_t)orow * ldo + tid] = v;
+  }
+}
+
 void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,
                      const double *num_frames, double *x, float *ivec_out, int ldo, const int *out_row, const int *active,
                      hipStream_t s) {
   if (n_utts == 0) return;
   int n = iv.ivec_dim;
+  if (n <= 128) {
+    const size_t smem = sizeof(double) * ((size_t)n * n + 2 * (size_t)n);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr_set = true;
+    }
+    if (n <= 64) hipLaunchKernelGGL(IvecSolveFullKernel<1>, dim3(n_utts), dim3(64), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
+    else hipLaunchKernelGGL(IvecSolveFullKernel<2>, dim3(n_utts), dim3(128), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
+    return;
+  }
   int threads = 64;
   while (threads < n) threads <<= 1;
   size_t smem = sizeof(double) * ((size_t)n * (n + 1) / 2 + 5 * (size_t)n + threads);

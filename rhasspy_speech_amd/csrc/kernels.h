@@ -38,7 +38,7 @@ struct MfccDev {
   const float *lifter;       // nceps
   // split-radix FFT plan (srfft_plan.h)
   const int *fft_tasks;      // SrfftTask records (int4 each), level-major
-  int fft_num_levels;
+  int fft_num_levels, fft_num_tasks, fft_num_tw;
   int fft_level_begin[16];   // task range of each level
   const float *fft_tw;       // 6 floats per twiddled butterfly
   const int *fft_perm;       // padded/2: bit-reversal pass as a gather
