@@ -28,6 +28,11 @@ __device__ __forceinline__ float KeyCost(unsigned long long k) {
   return k == RS_EMPTY ? INFINITY : FromOrdered((unsigned)(k >> 32));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. every
+// barrier of the frame loop would wait for the back-pointer stores just issued and for the log-likelihood prefetch of the
+// next frame (~1 us each); nothing in the loop communicates through global memory.
+__device__ __forceinline__ void LdsBarrier() { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NW>
 struct Red {
   float f[NW];
@@ -155,18 +160,17 @@ __device__ __forceinline__ int WaveScanIncl(int v) {
 // Exact k-th smallest (0-based) of the finite entries of cost[0..S), all of which lie in [lo, hi]: ONE histogram pass
 // over 256 linear bins (float subtract / multiply / truncate are monotone, so bin order agrees with value order), every
 // wave scans the histogram itself, then the handful of values in the bin that holds rank k are ranked directly.
-// Falls back to the radix select when that bin is crowded.  Requires r.hist[] == 0 and r.ncand == 0 on entry and
-// leaves them so.
+// Falls back to the radix select when that bin is crowded.  The histogram pass is the caller's (KthBin per finite
+// entry into r.hist, then a barrier) so that it can share a loop; KthFromHist needs r.ncand == 0 on entry and leaves
+// r.hist zeroed and r.ncand == 0.  *n_le = number of entries <= the result.
+__device__ __forceinline__ int KthBin(float c, float lo, float scale) {
+  const int b = (int)((c - lo) * scale);
+  return b > 255 ? 255 : b;
+}
 template <int NT>
-__device__ float KthSmallestBinned(Red<NT / 64> &r, const float *cost, int S, int k, float lo, float hi) {
-  if (!(hi > lo)) return lo;
+__device__ float KthFromHist(Red<NT / 64> &r, const float *cost, int S, int k, float lo, float hi, int *n_le) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const float scale = 255.0f / (hi - lo);
-  for (int i = tid; i < S; i += NT) {
-    const float c = cost[i];
-    if (c < INFINITY) { int b = (int)((c - lo) * scale); b = b > 255 ? 255 : b; atomicAdd(&r.hist[b], 1u); }
-  }
-  __syncthreads();
+  const float scale = hi > lo ? 255.0f / (hi - lo) : 0.f;
   const uint4 hv = *reinterpret_cast<const uint4 *>(&r.hist[4 * lane]);
   const int h0 = (int)hv.x, h1 = (int)hv.y, h2 = (int)hv.z, h3 = (int)hv.w;
   const int tot = h0 + h1 + h2 + h3;
@@ -175,38 +179,38 @@ __device__ float KthSmallestBinned(Red<NT / 64> &r, const float *cost, int S, in
   int bb = 4 * lane, acc = exc, m = h0;
   if (acc + h0 <= k) { acc += h0; bb++; m = h1; if (acc + h1 <= k) { acc += h1; bb++; m = h2; if (acc + h2 <= k) { acc += h2; bb++; m = h3; } } }
   const unsigned long long hm = __ballot(hit);
-  if (hm == 0ull) {             // k >= number of finite entries: caller error; behave like the radix select on its maximum
-    __syncthreads();
-    for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
-    __syncthreads();
-    return hi;
-  }
-  const int hl = __ffsll((long long)hm) - 1;
-  const int bin = __builtin_amdgcn_readlane(bb, hl), kk = k - __builtin_amdgcn_readlane(acc, hl), cnt = __builtin_amdgcn_readlane(m, hl);
-  if (cnt > 64) {
+  const int hl = hm ? __ffsll((long long)hm) - 1 : 0;
+  const int bin = __builtin_amdgcn_readlane(bb, hl), before = __builtin_amdgcn_readlane(acc, hl), cnt = __builtin_amdgcn_readlane(m, hl);
+  const int kk = k - before;
+  if (hm == 0ull || cnt > 64) {
+    // k beyond the number of entries (caller error), or a crowded bin (many equal costs): radix select
     __syncthreads();
     const float v = KthSmallest<NT>(r, cost, S, k, lo);
+    int le = 0;
+    for (int i = tid; i < S; i += NT) le += (int)(cost[i] <= v);
     for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
+    if (tid == 0) r.bi[3] = 0;
     __syncthreads();
+    atomicAdd(&r.bi[3], le);
+    __syncthreads();
+    *n_le = r.bi[3];
     return v;
   }
   for (int i = tid; i < S; i += NT) {
     const float c = cost[i];
-    if (c < INFINITY) {
-      int b = (int)((c - lo) * scale); b = b > 255 ? 255 : b;
-      if (b == bin) r.cand[atomicAdd(&r.ncand, 1)] = c;
-    }
+    if (c < INFINITY && KthBin(c, lo, scale) == bin) r.cand[atomicAdd(&r.ncand, 1)] = c;
   }
-  __syncthreads();
+  LdsBarrier();
   for (int i = tid; i < 256; i += NT) r.hist[i] = 0;
   if (tid < cnt) {
     const float v = r.cand[tid];
     int lt = 0, le = 0;
     for (int j = 0; j < cnt; j++) { const float x = r.cand[j]; lt += (int)(x < v); le += (int)(x <= v); }
-    if (lt <= kk && kk < le) r.bf[0] = v;
+    if (lt <= kk && kk < le) { r.bf[0] = v; r.bi[3] = before + le; }
   }
   if (tid == 0) r.ncand = 0;
-  __syncthreads();
+  LdsBarrier();
+  *n_le = r.bi[3];
   return r.bf[0];
 }
 

@@ -20,6 +20,8 @@
 #include "decode_common.h"
 #include "wave_ops.h"
 
+#include <cstdlib>
+
 namespace rs {
 using namespace dd;
 
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 #pragma unroll
   for (int a = 0; a < KX; a++) xa[a] = rg.x_tab[(size_t)a * NT + tid];
   for (int s = tid; s <= S; s += NT) { cost_cur[s] = INF; key_next[s] = RS_EMPTY; }
-  for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // KthSmallestBinned's invariant
+  for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // KthFromHist's invariant
   if (tid == 0) red.ncand = 0;
   // log-likelihoods of my emitting arcs, fetched one frame ahead (padding arcs read pdf 0 and never pass the cutoff)
   float ll_nxt[KE];
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   float closure_cutoff = o.beam;
   int error = 0;
   // statistics of the committed frame, collected by the commit pass
-  float st_min = INF, st_max = -INF;
+  float st_min = INF;
   int st_arg = 0x7fffffff, st_cnt = 0;
 #ifdef RS_DECODE_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -92,18 +94,19 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
       }
       // ---- best token (ties: smallest state), token count
-      float best_cost, max_cost;
+      float best_cost;
       int best_state, N;
       {
         const unsigned ub = wv::FloatToOrdered(st_min);
         const unsigned wm = wv::MinU(ub);
-        const unsigned wa = wv::MinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
+        const unsigned long long tie = __ballot(ub == wm);
+        unsigned wa;
+        if (__popcll(tie) == 1) wa = (unsigned)__builtin_amdgcn_readlane(st_arg, __ffsll((long long)tie) - 1);
+        else wa = wv::MinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
         const int wn = wv::Sum(st_cnt);
-        const unsigned wx = wv::MaxU(wv::FloatToOrdered(st_max));
-        if (lane == 0) xr[rb][wave] = make_int4((int)wm, (int)wa, wn, (int)wx);
-        __syncthreads();
+        if (lane == 0) xr[rb][wave] = make_int4((int)wm, (int)wa, wn, 0);
+        LdsBarrier();
         unsigned long long bk = ~0ull;
-        unsigned bx = 0u;
         N = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) {
@@ -111,47 +114,70 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           const unsigned long long kk = ((unsigned long long)(unsigned)e.x << 32) | (unsigned)e.y;
           bk = kk < bk ? kk : bk;
           N += e.z;
-          bx = max(bx, (unsigned)e.w);
         }
         rb ^= 1;
-        max_cost = wv::OrderedToFloat(bx);
         best_cost = wv::OrderedToFloat((unsigned)(bk >> 32));
         best_state = (int)(unsigned)(bk & 0xFFFFFFFFull);
       }
       if (N == 0) { error = 1; break; }
       RS_T(0);
-      // ---- GetCutoff (lattice-faster-decoder.cc:644-711)
+      // ---- GetCutoff (lattice-faster-decoder.cc:644-711).  One pass over the tokens counts those inside the beam and
+      // fills the 256-bin histogram the exact k-th-smallest selection starts from (decode_common.h); both are only needed
+      // when a max-active / min-active limit can bind.  Every live cost is < the previous frame's cutoff, which bounds
+      // the bins (when that cutoff is infinite the true maximum is reduced first).
       const float beam_cutoff = best_cost + o.beam;
       int c_le = 0, c_lt = 0;
-      if (N > o.max_active || N > o.min_active) {       // the counts only matter then (uniform branch)
+      const bool need_counts = N > o.max_active || N > o.min_active;      // wave-uniform
+      float hist_hi = closure_cutoff;
+      if (need_counts) {
+        if (!(hist_hi < INF)) {
+          float mx = -INF;
+          for (int s = tid; s < S; s += NT) { const float c = cost_cur[s]; mx = c < INF ? fmaxf(mx, c) : mx; }
+          const unsigned wx = wv::MaxU(wv::FloatToOrdered(mx));
+          if (lane == 0) xr[rb][wave] = make_int4((int)wx, 0, 0, 0);
+          LdsBarrier();
+          unsigned bx = 0u;
+#pragma unroll
+          for (int k = 0; k < NW; k++) bx = max(bx, (unsigned)xr[rb][k].x);
+          rb ^= 1;
+          hist_hi = wv::OrderedToFloat(bx);
+        }
+        const float hscale = hist_hi > best_cost ? 255.0f / (hist_hi - best_cost) : 0.f;
         for (int s = tid; s < S; s += NT) {
           const float c = cost_cur[s];
           c_le += (int)(c <= beam_cutoff) & (int)(c < INF);
           c_lt += (int)(c < beam_cutoff);
+          if (c < INF) atomicAdd(&red.hist[KthBin(c, best_cost, hscale)], 1u);
         }
         const int wa = wv::Sum(c_le), wb = wv::Sum(c_lt);
         if (lane == 0) xr[rb][wave] = make_int4(wa, wb, 0, 0);
-        __syncthreads();
+        LdsBarrier();           // counts exchanged, histogram complete
         c_le = 0; c_lt = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) { const int4 e = xr[rb][k]; c_le += e.x; c_lt += e.y; }
         rb ^= 1;
       }
-      float cur_cutoff, adaptive_beam;
-      bool decided = false;
-      if (N > o.max_active && c_lt > o.max_active) {
-        const float mac = KthSmallestBinned<NT>(red, cost_cur, S, o.max_active, best_cost, max_cost);
-        adaptive_beam = mac - best_cost + o.beam_delta;
-        cur_cutoff = mac;
-        decided = true;
-        max_active_frames++;
+      int kth = -1;                // which order statistic GetCutoff needs, if any
+      if (N > o.max_active && c_lt > o.max_active) kth = o.max_active;
+      else if (N > o.min_active && !(o.min_active == 0 || c_le > o.min_active)) kth = o.min_active;
+      float kth_cost = 0.f;
+      int kth_le = 0;              // tokens at or below it
+      if (need_counts) {
+        if (kth >= 0) kth_cost = KthFromHist<NT>(red, cost_cur, S, kth, best_cost, hist_hi, &kth_le);
+        else for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // next use is at least one barrier away
       }
-      if (!decided) {
+      float cur_cutoff, adaptive_beam;
+      int n_exp;
+      if (N > o.max_active && c_lt > o.max_active) {
+        adaptive_beam = kth_cost - best_cost + o.beam_delta;
+        cur_cutoff = kth_cost;
+        n_exp = kth_le;
+        max_active_frames++;
+      } else {
         float min_active_cutoff = INF;
         bool loosened;
         if (N > o.min_active) {
-          if (o.min_active == 0 || c_le > o.min_active) min_active_cutoff = best_cost;   // tmp[min_active] <= beam_cutoff
-          else min_active_cutoff = KthSmallestBinned<NT>(red, cost_cur, S, o.min_active, best_cost, max_cost);
+          min_active_cutoff = kth >= 0 ? kth_cost : best_cost;           // best_cost stands for "tmp[min_active] <= beam_cutoff"
           loosened = min_active_cutoff > beam_cutoff;
         } else {
           loosened = true;      // fewer than min_active tokens: the cutoff stays +inf (:691-705)
@@ -159,18 +185,16 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         if (loosened) {
           adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;
           cur_cutoff = min_active_cutoff;
+          n_exp = N > o.min_active ? kth_le : N;
           if (N > o.min_active) min_active_frames++;
         } else {
           adaptive_beam = o.beam;
           cur_cutoff = beam_cutoff;
+          n_exp = need_counts ? c_le : N;      // without a binding limit every token is inside the beam... counted lazily
         }
       }
       const float cost_offset = -best_cost;
-      if (cur_cutoff < INF) {
-        for (int s = tid; s < S; s += NT) n_expanded += (unsigned)(cost_cur[s] <= cur_cutoff);
-      } else if (tid == 0) {
-        n_expanded += (unsigned)N;
-      }
+      if (tid == 0) n_expanded += (unsigned)n_exp;
       RS_T(1);
       // ---- ProcessEmitting: independent LDS gathers, then one LDS atomic min per surviving arc
       float csrc[KE];
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       {
         const unsigned wm = wv::MinU(wv::FloatToOrdered(local_min));
         if (lane == 0) xr[rb][wave] = make_int4((int)wm, 0, 0, 0);
-        __syncthreads();          // also: every emitting insertion has landed
+        LdsBarrier();          // also: every emitting insertion has landed
         unsigned bm = 0xFFFFFFFFu;
 #pragma unroll
         for (int k = 0; k < NW; k++) bm = min(bm, (unsigned)xr[rb][k].x);
@@ -235,12 +259,12 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           }
         }
         if (rg.eps_depth > 0) {
-          __syncthreads();
+          LdsBarrier();
         } else {
           // cyclic or deep epsilon subgraph: vote
           const int any = __ballot(changed) != 0ull;
           if (lane == 0) xr[rb][wave] = make_int4(any, 0, 0, 0);
-          __syncthreads();
+          LdsBarrier();
           int tot_any = 0;
 #pragma unroll
           for (int k = 0; k < NW; k++) tot_any |= xr[rb][k].x;
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     RS_T(3);
     // ---- commit frame f+1: keys -> costs and back-pointers; statistics for the next frame
     int *bp_row = bp + (size_t)(f + 1) * S;
-    st_min = INF; st_max = -INF; st_arg = 0x7fffffff; st_cnt = 0;
+    st_min = INF; st_arg = 0x7fffffff; st_cnt = 0;
     for (int s = tid; s < S; s += NT) {
       const unsigned long long k = key_next[s];
       const float c = wv::OrderedToFloat((unsigned)(k >> 32));
@@ -264,7 +288,6 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       const bool better = alive & (c < st_min);
       st_min = better ? c : st_min;
       st_arg = better ? s : st_arg;
-      st_max = (alive & (c > st_max)) ? c : st_max;
     }
     n_alive += (unsigned)st_cnt;
     RS_T(4);
@@ -293,13 +316,18 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
   hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem);
 }
 
-// the instantiations; RegDecodeConfig picks the smallest one the graph fits
-static const int kRegConfigs[][3] = {{256, 8, 4}, {256, 16, 8}, {256, 32, 16}, {512, 32, 16}};
+// the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state
+// grammar graph, 298 frames): 64 threads 7.5 us/frame, 256 -> 4.2, 512 -> 3.7, 1024 -> 5.1: the per-lane instruction count
+// dominates until the barriers of 16 waves take over.
+static const int kRegConfigs[][3] = {{512, 4, 2}, {512, 8, 4}, {256, 16, 8}, {256, 32, 16}, {256, 8, 4}};
 
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx) {
   if (num_states > kRegMaxStates) return false;
-  for (const auto &c : kRegConfigs)
+  static int force_nt = [] { const char *e = std::getenv("RS_REG_NT"); return e ? std::atoi(e) : 0; }();
+  for (const auto &c : kRegConfigs) {
+    if (force_nt && c[0] != force_nt) continue;
     if ((long long)c[0] * c[1] >= num_emitting && (long long)c[0] * c[2] >= num_eps) { *nt = c[0]; *ke = c[1]; *kx = c[2]; return true; }
+  }
   return false;
 }
 
@@ -307,11 +335,14 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
                      const float *loglikes, int ld, const DenseWork &w, hipStream_t s) {
   if (g.n_utts == 0) return true;
   size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
-  if (smem < 48 * 1024) smem = 48 * 1024;      // room to stage back-pointer rows for the traceback
-  if (r.nt == 256 && r.ke == 8 && r.kx == 4) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
+  // room to stage back-pointer rows for the traceback: when every utterance has a CU to itself anyway, take most of the LDS
+  const size_t stage = g.n_utts <= 256 ? 128 * 1024 : 48 * 1024;
+  if (smem < stage) smem = stage;
+  if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, s);
+  else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
   else if (r.nt == 256 && r.ke == 16 && r.kx == 8) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, s);
   else if (r.nt == 256 && r.ke == 32 && r.kx == 16) LaunchOne<256, 32, 16>(h, r, o, g, loglikes, ld, w, smem, s);
-  else if (r.nt == 512 && r.ke == 32 && r.kx == 16) LaunchOne<512, 32, 16>(h, r, o, g, loglikes, ld, w, smem, s);
+  else if (r.nt == 256 && r.ke == 8 && r.kx == 4) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
   else return false;
   return true;
 }
