@@ -252,7 +252,12 @@ class Mfcc:
         nfft = self.padded // 2
         nyq = F32(0.5) * F32(o.samp_freq)
         high = F32(o.high_freq) if o.high_freq > 0 else nyq + F32(o.high_freq)
-        mel = lambda f: F32(1127.0) * np.log(F32(1.0) + np.asarray(f, F32) / F32(700.0), dtype=F32)
+        # MelScale (mel-computations.h:82-84) with the C library's logf: numpy's vectorised float32 log differs from it in
+        # the last bit for some arguments, which moves a filter edge by one ulp -- visible (1e-3 on the cepstra) whenever a
+        # strong spectral line sits on that edge
+        logf = _libm_f32("logf")
+        mel = lambda f: (F32(1127.0) * np.array([logf(v) for v in np.atleast_1d(F32(1.0) + np.asarray(f, F32) / F32(700.0))], F32)).reshape(np.shape(f)) \
+            if np.ndim(f) else F32(F32(1127.0) * logf(F32(1.0) + F32(f) / F32(700.0)))
         bw = F32(o.samp_freq) / F32(self.padded)
         ml, mh = mel(F32(o.low_freq)), mel(high)
         delta = F32((mh - ml) / F32(o.num_bins + 1))

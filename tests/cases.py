@@ -34,6 +34,9 @@ CASES = {
     "zam_u0": dict(big=True, spec=dict(), graph="grammar", audio="synth:0:48000"),
     "zam_u1": dict(big=True, spec=dict(), graph="grammar", audio="synth:1:48000"),
     "zam_real_cold": dict(big=True, spec=dict(), graph="grammar", audio="wav:how_cold_is_it.wav"),
+    # 30 s: the CMVN window (600 frames) slides, max-count prior rescaling of the iVector stats saturates, 123 nnet chunks
+    "zam_long30": dict(big=True, spec=dict(), graph="grammar", audio="synth:20:480000"),
+    "zam_s12005": dict(big=True, spec=dict(), graph="grammar", audio="synth:12005:472320"),
 }
 NBEST = 5
 

@@ -12,11 +12,11 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 LOGLIKE_TOL = 1e-4
-# MFCC: the split-radix FFT restates the reference's float operations one for one; what is left is the summation order
-# of the DC mean / mel / DCT dot products and libm-vs-device logf (typically 8e-5 on c0 ~ 100; near-empty mel bins of the
-# synthetic audio amplify the DC-mean rounding to ~2e-4)
-FEAT_TOL = 5e-4
-FEAT_TOL_P99 = 3e-4
+# MFCC: the split-radix FFT restates the reference's float operations one for one and the mel filter edges come from the
+# same libm logf; what is left is the summation order of the mel / DCT dot products times the cepstral lifter (<= 12) and
+# libm-vs-device logf: observed max 8e-5 on c0 ~ 100
+FEAT_TOL = 2e-4
+FEAT_TOL_P99 = 1e-4
 IVEC_TOL = 1e-4
 
 

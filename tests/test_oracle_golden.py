@@ -6,7 +6,7 @@ import pytest
 from tests import cases
 
 FAST = ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tiny_real_time", "tiny_text_u1", "tiny_noiv_u2", "tiny_cmvn_u4", "tinyf_u5",
-        "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold"]
+        "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold", "zam_long30", "zam_s12005"]
 
 
 def parse_nbest(text: bytes):
@@ -35,9 +35,9 @@ def test_oracle_matches_reference(oracles, name):
     tr = orc.transcribe(pcm, nbest=cases.NBEST)
     assert tr.num_frames == int(g["offline_num_frames"])
     fd = np.abs(tr.feats - g["input"])
-    # the FFT is the reference's own, operation for operation; what is left is the order of the BLAS sums (DC mean, mel,
-    # DCT), which perturbs near-empty mel bins of the synthetic audio
-    assert fd.max() < 5e-4 and np.quantile(fd, 0.99) < 3e-4
+    # the FFT is the reference's own, operation for operation, and the mel filter edges come from the same libm logf; what is
+    # left is the order of the BLAS sums (mel, DCT) times the cepstral lifter (up to 12)
+    assert fd.max() < 2e-4 and np.quantile(fd, 0.99) < 1e-4
     if "offline_ivector" in g:
         assert np.abs(tr.ivector - g["offline_ivector"][0]).max() < 1e-4
     sr, sc = g["loglikes_stride"]
@@ -64,7 +64,7 @@ def test_oracle_intermediate_ivector_features(oracles):
     assert np.abs(nrm - g["lda_norm"]).max() < 2e-4
 
 
-@pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7"])
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7", "zam_long30", "zam_s12005"])
 def test_oracle_streaming_matches_reference(oracles, name):
     """online2-cli-nnet3-decode-faster goldens: per-chunk iVectors, log-likelihoods, n-best text."""
     g = np.load(cases.GOLDEN / f"{name}.npz")
@@ -75,5 +75,6 @@ def test_oracle_streaming_matches_reference(oracles, name):
     tr = orc.transcribe_stream(pcm, nbest=cases.NBEST)
     if "stream_ivector" in g:
         assert np.abs(tr.ivector - g["stream_ivector"]).max() < 1e-4
-    assert np.abs(tr.loglikes - g["stream_loglikes"]).max() < 1e-4
+    sr, sc = g["loglikes_stride"]          # big cases keep a strided sample of the log-likelihood matrix
+    assert np.abs(tr.loglikes[::sr, ::sc] - g["stream_loglikes"]).max() < 1e-4
     assert tr.text() == bytes(g["stream_nbest_text"])
