@@ -44,12 +44,15 @@ __device__ __forceinline__ void StoreKey(unsigned long long *p, unsigned long lo
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int kPrefixCap = 8192;
+
 template <int NT>
 struct BlockCtx {
   float red_f[NT / 64];
   int red_i[NT / 64];
   unsigned hist[256];
   int n_next, q_n[2], overflow, error;
+  int pre[kPrefixCap + 1];           // exclusive prefix of the tokens' emitting out-degrees
   float bcast_f[2];
   int bcast_i[4];
   unsigned long long counters[8];
@@ -232,29 +235,63 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       const float cost_offset = (n_cur > 0) ? -best_cost : 0.f;
       const float *ll_row = loglikes + (ll_base + f) * ld;
       float local_min = INF;
-      for (int i = tid; i < n_cur; i += NT) {
-        const int4 tk = cur[i];
-        const float cur_cost = __int_as_float(tk.y);
-        if (!(cur_cost <= cur_cutoff)) continue;
-        cnt_expanded++;
-        const unsigned a0 = h.arc_begin[tk.x] + h.num_ieps[tk.x], a1 = h.arc_begin[tk.x + 1];
-        for (unsigned a = a0; a < a1; a++) {
-          const int4 arc = h.arcs[a];
-          const float lk = ll_row[arc.x - 1];
-          const float graph_cost = __int_as_float(arc.z);
-          const float ac_cost = cost_offset - lk;
-          const float tot = (cur_cost + ac_cost) + graph_cost;
-          if (i == best_idx) {
-            // :752-757  arc.weight + cost_offset - loglike + tok->tot_cost  (the reference's first bound)
-            const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;
-            local_min = fminf(local_min, nw);
-          }
-          local_min = fminf(local_min, tot);
-          Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a);
-          cnt_arcs++;
-          cnt_insert++;
+      // Arc-parallel expansion: the out-degrees of the frame's tokens are prefix-summed in LDS and every thread takes
+      // arcs j = tid, tid + NT, ... of the concatenated arc list (binary search for the owning token).  A token-per-thread
+      // loop would serialise thousands of L2 atomics on the back-off / unigram states of an n-gram graph.
+      auto relax_arc = [&](unsigned a, float cur_cost, bool is_best) __attribute__((always_inline)) {
+        const int4 arc = h.arcs[a];
+        const float lk = ll_row[arc.x - 1];
+        const float graph_cost = __int_as_float(arc.z);
+        const float ac_cost = cost_offset - lk;
+        const float tot = (cur_cost + ac_cost) + graph_cost;
+        if (is_best) {
+          // :752-757  arc.weight + cost_offset - loglike + tok->tot_cost  (the reference's first bound)
+          const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;
+          local_min = fminf(local_min, nw);
+        }
+        local_min = fminf(local_min, tot);
+        Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a);
+        cnt_arcs++;
+        cnt_insert++;
+      };
+      for (int c0 = 0; c0 < n_cur; c0 += kPrefixCap) {         // token chunks whose degree prefix fits LDS
+        const int nc = n_cur - c0 < kPrefixCap ? n_cur - c0 : kPrefixCap;
+        const int4 *ctok = cur + c0;
+        // degrees (0 for tokens beyond the cutoff), contiguous segment per thread
+        const int seg = (nc + NT - 1) / NT;
+        const int i0 = tid * seg < nc ? tid * seg : nc, i1 = i0 + seg < nc ? i0 + seg : nc;
+        int lsum = 0;
+        for (int i = i0; i < i1; i++) {
+          const int4 tk = ctok[i];
+          int deg = 0;
+          if (__int_as_float(tk.y) <= cur_cutoff) { deg = (int)(h.arc_begin[tk.x + 1] - h.arc_begin[tk.x] - h.num_ieps[tk.x]); cnt_expanded++; }
+          c.pre[i] = deg;
+          lsum += deg;
+        }
+        // exclusive scan of the per-thread sums over the block
+        int inc = lsum;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if ((tid & 63) >= o2) inc += v; }
+        __syncthreads();          // previous chunk's readers of c.red_i / c.pre are done
+        if ((tid & 63) == 63) c.red_i[tid >> 6] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int wv = 0; wv < (tid >> 6); wv++) wbase += c.red_i[wv];
+        int total = 0;
+        for (int wv = 0; wv < NT / 64; wv++) total += c.red_i[wv];
+        int run = wbase + inc - lsum;
+        for (int i = i0; i < i1; i++) { const int dgr = c.pre[i]; c.pre[i] = run; run += dgr; }
+        if (tid == 0) c.pre[nc] = total;
+        __syncthreads();
+        for (int j = tid; j < total; j += NT) {
+          int lo = 0, hi = nc;            // last token with pre[t] <= j
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.pre[mid] <= j) lo = mid; else hi = mid; }
+          const int4 tk = ctok[lo];
+          const unsigned a = h.arc_begin[tk.x] + h.num_ieps[tk.x] + (unsigned)(j - c.pre[lo]);
+          relax_arc(a, __int_as_float(tk.y), c0 + lo == best_idx);
         }
       }
+      __syncthreads();
       float mn;
       int dummy;
       BlockMinArg<NT>(c, local_min, tid, &mn, &dummy);
