@@ -39,6 +39,26 @@ void DeviceArena::Reserve(size_t bytes, hipStream_t s) {
   used_ = 0;
 }
 
+HostArena::~HostArena() { for (auto &b : blocks_) (void)hipHostFree(b.first); }
+
+void *HostArena::Alloc(size_t bytes) {
+  // blocks are never freed before destruction, so pointers handed out earlier in the same call stay valid when a new
+  // block is appended; Reset() restarts from the first block
+  for (;;) {
+    if (cur_ < blocks_.size()) {
+      const size_t a = (used_ + 63) & ~(size_t)63;
+      if (a + bytes <= blocks_[cur_].second) { used_ = a + bytes; return blocks_[cur_].first + a; }
+      cur_++;
+      used_ = 0;
+      continue;
+    }
+    const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 20);
+    char *p = nullptr;
+    RS_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+    blocks_.push_back({p, want});
+  }
+}
+
 void *DeviceArena::Alloc(size_t bytes) {
   size_t a = (used_ + 255) & ~(size_t)255;
   if (a + bytes > cap_) Fail("internal error: device arena too small");
@@ -423,7 +443,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
   if (ngroups == 1) {
     DecodeGroup(d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : stream_, streaming, arena_[0],
-                res->utts.data(), res->timings);
+                host_arena_[0], res->utts.data(), res->timings);
   } else {
     const int half = (n_utts + 1) / 2;
     float t2[2][8] = {{0}, {0}};
@@ -432,7 +452,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
       try {
         const int u0 = gi == 0 ? 0 : half, n = gi == 0 ? half : n_utts - half;
         DecodeGroup(d_pcm, sample_offsets + u0, n, nbest, lat_scale, gi == 0 ? stream_ : stream2_, streaming, arena_[gi],
-                    res->utts.data() + u0, t2[gi]);
+                    host_arena_[gi], res->utts.data() + u0, t2[gi]);
       } catch (...) {
         err[gi] = std::current_exception();
       }
@@ -451,7 +471,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
 // concurrently (two host threads, two streams) so that the latency-bound stages of one group (search, iVector)
 // overlap the MFMA-bound stage (TDNN) of the other.
 void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
-                        hipStream_t s, bool streaming, DeviceArena &arena_, UttResult *out_utts, float *timings) {
+                        hipStream_t s, bool streaming, DeviceArena &arena_, HostArena &harena, UttResult *out_utts, float *timings) {
   RS_HIP(hipSetDevice(opts_.device_id));
   auto wall0 = std::chrono::steady_clock::now();
   if (n_utts == 0) return;
@@ -471,9 +491,6 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   }
   const int rows = row_base[n_utts];
   const int guard = L_ + R_ + 8;
-  std::vector<int> row_utt(rows), row_t(rows);
-  for (int u = 0; u < n_utts; u++)
-    for (int r = row_base[u]; r < row_base[u + 1]; r++) { row_utt[r] = u; row_t[r] = r - row_base[u] - L_; }
   // ---- iVector schedule.  Offline (--online=false): one estimate per utterance from all frames.  Streaming:
   // one estimate per nnet chunk, from the frames available at the 1024-sample tick on which
   // DecodableNnetLoopedOnlineBase::AdvanceChunk runs for that chunk (decodable-online-looped.cc:56-84,186-194;
@@ -507,8 +524,11 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   // which iVector row every frame row reads: the chunk that supplied its Round(ivector, chunk) slot
   // (nnet-compile-looped.cc:164-231: chunk 0 supplies the slots of t in [-L, chunk + R), chunk k the new ones of
   //  [k*chunk + R, (k+1)*chunk + R))
-  std::vector<int> row_ivec(rows);
-  for (int u = 0; u < n_utts; u++) {
+  // (offline: every row of an utterance reads its single iVector row -- filled in on the device with the row geometry)
+  harena.Reset();
+  const bool host_row_ivec = streaming && has_iv;
+  int *row_ivec = host_row_ivec ? harena.AllocT<int>(rows) : nullptr;
+  for (int u = 0; host_row_ivec && u < n_utts; u++) {
     const int nch = (int)chunk_last[u].size();
     for (int r = row_base[u]; r < row_base[u + 1]; r++) {
       int k = 0;
@@ -557,18 +577,26 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   BatchGeom g;
   g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
   {
-    int64_t *d_so = arena_.AllocT<int64_t>(n_utts + 1);
-    int *d_T = arena_.AllocT<int>(n_utts), *d_rb = arena_.AllocT<int>(n_utts + 1), *d_fb = arena_.AllocT<int>(n_utts + 1);
+    // one page-locked staging block -> one async copy; the per-row arrays are derived on the device
+    const size_t n1 = (size_t)n_utts + 1;
+    const size_t bytes = n1 * sizeof(int64_t) + 4 * n1 * sizeof(int);
+    char *hp = static_cast<char *>(harena.Alloc(bytes));
+    char *dp = static_cast<char *>(arena_.Alloc(bytes));
+    int64_t *h_so = reinterpret_cast<int64_t *>(hp);
+    int *h_T = reinterpret_cast<int *>(hp + n1 * sizeof(int64_t)), *h_rb = h_T + n1, *h_fb = h_rb + n1, *h_ib = h_fb + n1;
+    std::memcpy(h_so, sample_offsets, n1 * sizeof(int64_t));
+    std::memcpy(h_T, T.data(), sizeof(int) * n_utts);
+    h_T[n_utts] = 0;
+    std::memcpy(h_rb, row_base.data(), sizeof(int) * n1);
+    std::memcpy(h_fb, frame_base.data(), sizeof(int) * n1);
+    std::memcpy(h_ib, ivrow_base.data(), sizeof(int) * n1);
+    RS_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s));
+    int64_t *d_so = reinterpret_cast<int64_t *>(dp);
+    int *d_T = reinterpret_cast<int *>(dp + n1 * sizeof(int64_t)), *d_rb = d_T + n1, *d_fb = d_rb + n1, *d_ib = d_fb + n1;
     int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
     d_row_ivec = arena_.AllocT<int>(rows);
-    RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_so, sample_offsets, sizeof(int64_t) * (n_utts + 1), hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_T, T.data(), sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_rb, row_base.data(), sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_fb, frame_base.data(), sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_ru, row_utt.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    RS_HIP(hipMemcpyAsync(d_rt, row_t.data(), sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    RS_HIP(hipStreamSynchronize(s));   // the host vectors above go out of scope only at function end, but keep it simple
+    if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    LaunchRowGeometry(n_utts, rows, L_, d_rb, d_ib, d_ru, d_rt, host_row_ivec ? nullptr : d_row_ivec, s);
     g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
@@ -756,13 +784,17 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   }
   tm.Mark();
   // ---- results to host
-  std::vector<int> h_nw(n_utts), h_words((size_t)n_utts * max_words);
-  std::vector<float> h_costs((size_t)n_utts * 4);
-  std::vector<long long> h_ctr((size_t)n_utts * 8);
-  RS_HIP(hipMemcpyAsync(h_nw.data(), w.out_nwords, sizeof(int) * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpyAsync(h_costs.data(), w.out_costs, sizeof(float) * 4 * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpyAsync(h_ctr.data(), w.counters, sizeof(long long) * 8 * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpyAsync(h_words.data(), w.out_words, sizeof(int) * (size_t)n_utts * max_words, hipMemcpyDeviceToHost, s));
+  // page-locked destination; only the first kWordsInline word ids of every utterance travel with the first copy (longer
+  // transcripts fetch their row afterwards)
+  constexpr int kWordsInline = 48;
+  int *h_nw = harena.AllocT<int>(n_utts), *h_words = harena.AllocT<int>((size_t)n_utts * kWordsInline);
+  float *h_costs = harena.AllocT<float>((size_t)n_utts * 4);
+  long long *h_ctr = harena.AllocT<long long>((size_t)n_utts * 8);
+  RS_HIP(hipMemcpyAsync(h_nw, w.out_nwords, sizeof(int) * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(h_costs, w.out_costs, sizeof(float) * 4 * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpyAsync(h_ctr, w.counters, sizeof(long long) * 8 * n_utts, hipMemcpyDeviceToHost, s));
+  RS_HIP(hipMemcpy2DAsync(h_words, sizeof(int) * kWordsInline, w.out_words, sizeof(int) * max_words, sizeof(int) * kWordsInline, n_utts,
+                          hipMemcpyDeviceToHost, s));
   RS_HIP(hipStreamSynchronize(s));
   RS_HIP(hipGetLastError());
   tm.Mark();
@@ -789,7 +821,12 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       continue;
     }
     Hypothesis hy;
-    hy.words.assign(h_words.begin() + (size_t)u * max_words, h_words.begin() + (size_t)u * max_words + h_nw[u]);
+    if (h_nw[u] <= kWordsInline) {
+      hy.words.assign(h_words + (size_t)u * kWordsInline, h_words + (size_t)u * kWordsInline + h_nw[u]);
+    } else {
+      hy.words.resize(h_nw[u]);
+      RS_HIP(hipMemcpy(hy.words.data(), w.out_words + (size_t)u * max_words, sizeof(int) * h_nw[u], hipMemcpyDeviceToHost));
+    }
     hy.graph_cost = h_costs[(size_t)u * 4 + 0];
     hy.acoustic_cost = h_costs[(size_t)u * 4 + 1];
     ur.hyps.push_back(std::move(hy));

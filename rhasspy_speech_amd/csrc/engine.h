@@ -33,6 +33,19 @@ class DeviceArena {
   size_t cap_ = 0, used_ = 0;
 };
 
+// Grow-only page-locked host staging: small H2D / D2H transfers of a decode call are truly asynchronous from it and never
+// wait on a pageable-memory bounce buffer.  Contents stay valid until the next Reset().
+class HostArena {
+ public:
+  ~HostArena();
+  void Reset() { used_ = 0; cur_ = 0; }
+  void *Alloc(size_t bytes);                   // 64-byte aligned; grows (a new block) when needed
+  template <typename T> T *AllocT(size_t n) { return static_cast<T *>(Alloc(n * sizeof(T))); }
+ private:
+  std::vector<std::pair<char *, size_t>> blocks_;
+  size_t cur_ = 0, used_ = 0;
+};
+
 struct Hypothesis {
   std::vector<int32_t> words;
   float graph_cost = 0, acoustic_cost = 0;
@@ -79,7 +92,7 @@ class Model {
 
  private:
   void DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
-                   hipStream_t s, bool streaming, DeviceArena &arena, UttResult *out_utts, float *timings);
+                   hipStream_t s, bool streaming, DeviceArena &arena, HostArena &harena, UttResult *out_utts, float *timings);
   template <typename T> T *Upload(const std::vector<T> &v);
   void *UploadBytes(const void *p, size_t bytes);
   void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
@@ -95,6 +108,7 @@ class Model {
   hipStream_t stream_ = nullptr;
   std::vector<void *> owned_;         // persistent device allocations
   DeviceArena arena_[2];               // one per concurrent utterance group
+  HostArena host_arena_[2];
   hipStream_t stream2_ = nullptr;
   int max_groups_ = 1;                 // RS_SUBBATCHES=2: two concurrent utterance groups (measured: no gain on MI355X, the
                                        // latency-bound kernels take CU resources from the GEMMs)

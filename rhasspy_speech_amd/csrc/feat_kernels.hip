@@ -295,4 +295,24 @@ void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, flo
   hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(256), 0, s, c, g, in, out, ld);
 }
 
+// ------------------------------------------------------------------------------------------ row geometry
+// Per-row lookup tables of the ragged time-major layout (kernels.h), derived on the device from the per-utterance row
+// bases: utterance of a row, its frame index relative to the utterance (negative / >= T in the halo), and -- offline --
+// the iVector row it reads.
+__global__ void RowGeometryKernel(int n_utts, int rows, int L, const int *__restrict__ row_base, const int *__restrict__ ivrow_base,
+                                  int *__restrict__ row_utt, int *__restrict__ row_t, int *__restrict__ row_ivec) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int lo = 0, hi = n_utts;          // largest u with row_base[u] <= r
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (row_base[mid] <= r) lo = mid; else hi = mid; }
+  row_utt[r] = lo;
+  row_t[r] = r - row_base[lo] - L;
+  if (row_ivec) row_ivec[r] = ivrow_base[lo];
+}
+void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const int *ivrow_base, int *row_utt, int *row_t, int *row_ivec,
+                       hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(RowGeometryKernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_utts, rows, L, row_base, ivrow_base, row_utt, row_t, row_ivec);
+}
+
 }  // namespace rs

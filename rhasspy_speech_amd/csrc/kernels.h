@@ -47,6 +47,9 @@ struct MfccDev {
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s);
 
+void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const int *ivrow_base, int *row_utt, int *row_t, int *row_ivec,
+                       hipStream_t s);
+
 // ---------------------------------------------------------------- online CMVN (sliding window, causal)
 struct CmvnDev {
   int dim, cmn_window, speaker_frames, global_frames;
