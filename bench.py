@@ -173,7 +173,7 @@ def main() -> None:
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         value = world * audio_seconds * args.steps / elapsed
-        rows = args.utts * (298 + 30)
+        rows = args.utts * 298          # algorithmic: the real frames only (halo rows of the hidden layers are overhead)
         flops = nnet_flops_per_row(desc) * rows
         n_gemm = sum(1 for l in desc.splitlines() if l.startswith("op: gemm"))
         # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token

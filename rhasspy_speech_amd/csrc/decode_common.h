@@ -341,8 +341,9 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       float *oc = w.out_costs + (size_t)u * 4;
       oc[0] = (float)graph; oc[1] = (float)ac; oc[2] = reached ? b1 : b2; oc[3] = reached ? 1.f : 0.f;
       long long *c8 = w.counters + (size_t)u * 8;
-      for (int i = 0; i < 4; i++) c8[i] = (long long)ctr[i];
-      c8[4] = 0; c8[5] = max_active_frames; c8[6] = min_active_frames; c8[7] = error ? 2 : 0;
+      // += : a resumable decoder has already flushed the counts of earlier time slabs (the buffer starts zeroed)
+      for (int i = 0; i < 4; i++) c8[i] += (long long)ctr[i];
+      c8[4] = 0; c8[5] += max_active_frames; c8[6] += min_active_frames; c8[7] = error ? 2 : 0;
     }
   }
 }

@@ -34,14 +34,24 @@ using namespace dd;
 
 template <int NT, int KE, int KX>
 __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg, DecodeOptsDev o, BatchGeom g,
-                                                      const float *__restrict__ loglikes, int ld, DenseWork w, int smem_bytes) {
+                                                      const float *__restrict__ loglikes, int ld, DenseWork w, int smem_bytes,
+                                                      int f_begin, int f_end) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the search is a chain of short dependent steps: when it shares a CU with GEMM waves (pipelined output layer), its
+  // instructions should win the issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   constexpr int NW = NT / 64;
   __shared__ Red<NW> red;
   __shared__ int4 xr[2][NW];       // cross-wave exchange, ping-pong so that a reduction needs one barrier
   int rb = 0;
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = g.d_num_frames[u], S = h.num_states;
+  // time slab [f_begin, f_end): an utterance is started by the slab with f_begin == -1, resumed from w.state_cost by later
+  // ones, and finished (traceback, results) by the slab that holds its last frame
+  if (f_begin >= 0 && f_begin >= T) return;
+  const int f_stop = f_end < T ? f_end : T;
+  const bool finishing = f_end >= T;
+  float *state = w.state_cost + (size_t)u * (S + 4);
   float *cost_cur = reinterpret_cast<float *>(smem);                                       // [S + 1], [S] = +inf forever
   unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem + rg.key_base);   // [S + 1], [S] = empty forever
   int *bp = w.bp + (size_t)u * (g.max_frames + 1) * S;
@@ -58,32 +68,43 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   for (int a = 0; a < KE; a++) ea[a] = rg.e_tab[(size_t)a * NT + tid];
 #pragma unroll
   for (int a = 0; a < KX; a++) xa[a] = rg.x_tab[(size_t)a * NT + tid];
-  for (int s = tid; s <= S; s += NT) { cost_cur[s] = INF; key_next[s] = RS_EMPTY; }
+  for (int s = tid; s <= S; s += NT) { cost_cur[s] = (f_begin >= 0 && s < S) ? state[s] : INF; key_next[s] = RS_EMPTY; }
   for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // KthFromHist's invariant
   if (tid == 0) red.ncand = 0;
   // log-likelihoods of my emitting arcs, fetched one frame ahead (padding arcs read pdf 0 and never pass the cutoff)
+  const int f_first = f_begin < 0 ? 0 : f_begin;
   float ll_nxt[KE];
 #pragma unroll
   for (int a = 0; a < KE; a++) ll_nxt[a] = 0.f;
-  if (T > 0) {
-    const float *row = loglikes + ll_base * ld;
+  if (f_first < T) {
+    const float *row = loglikes + (ll_base + f_first) * ld;
 #pragma unroll
     for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
   }
   __syncthreads();
-  if (tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
-  __syncthreads();
-  float closure_cutoff = o.beam;
-  int error = 0;
-  // statistics of the committed frame, collected by the commit pass
+  if (f_begin < 0 && tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
+  float closure_cutoff = f_begin < 0 ? o.beam : state[S];
+  int error = f_begin < 0 ? 0 : (int)state[S + 1];
+  // statistics of the committed frame, collected by the commit pass (recomputed when resuming)
   float st_min = INF;
   int st_arg = 0x7fffffff, st_cnt = 0;
+  if (f_begin >= 0) {
+    for (int s = tid; s < S; s += NT) {
+      const float c = cost_cur[s];
+      const bool alive = c < INF;
+      st_cnt += (int)alive;
+      const bool better = alive & (c < st_min);
+      st_min = better ? c : st_min;
+      st_arg = better ? s : st_arg;
+    }
+  }
+  __syncthreads();
 #ifdef RS_DECODE_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_last = clock64();
 #endif
 
-  for (int f = -1; f < T; f++) {
+  for (int f = f_begin; f < f_stop && !error; f++) {
     if (f >= 0) {
       float llv[KE];
 #pragma unroll
@@ -295,6 +316,25 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   }
   __syncthreads();
   RS_T(5);
+  if (!finishing) {
+    // park the utterance: token costs and the scalars the next slab needs; counters are flushed (they add up)
+    for (int s = tid; s < S; s += NT) state[s] = cost_cur[s];
+    if (tid == 0) { state[S] = closure_cutoff; state[S + 1] = (float)error; }
+    for (int i = tid; i < 8; i += NT) red.ctr[i] = 0;
+    __syncthreads();
+    atomicAdd(&red.ctr[0], n_expanded);
+    atomicAdd(&red.ctr[1], n_arcs);
+    atomicAdd(&red.ctr[2], n_insert);
+    atomicAdd(&red.ctr[3], n_alive);
+    __syncthreads();
+    if (tid == 0) {
+      long long *c8 = w.counters + (size_t)u * 8;
+      for (int i = 0; i < 4; i++) c8[i] += (long long)red.ctr[i];
+      c8[5] += max_active_frames;
+      c8[6] += min_active_frames;
+    }
+    return;
+  }
   FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
                       n_insert, n_alive, max_active_frames, min_active_frames);
 #ifdef RS_DECODE_PROFILE
@@ -307,13 +347,13 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 
 template <int NT, int KE, int KX>
 static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
-                      const DenseWork &w, size_t smem, hipStream_t s) {
+                      const DenseWork &w, size_t smem, int f_begin, int f_end, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeKernel<NT, KE, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem);
+  hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem, f_begin, f_end);
 }
 
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state
@@ -332,17 +372,19 @@ bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int
 }
 
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
-                     const float *loglikes, int ld, const DenseWork &w, hipStream_t s) {
+                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s) {
   if (g.n_utts == 0) return true;
   size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
   // room to stage back-pointer rows for the traceback: when every utterance has a CU to itself anyway, take most of the LDS
-  const size_t stage = g.n_utts <= 256 ? 128 * 1024 : 48 * 1024;
+  // (a slab that finishes no utterance does not trace back: it keeps its LDS footprint minimal so that the GEMM workgroups
+  // of the next slab's output layer stay co-resident)
+  const size_t stage = f_end <= g.max_frames ? 0 : (g.n_utts <= 256 ? 128 * 1024 : 48 * 1024);
   if (smem < stage) smem = stage;
-  if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, s);
-  else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
-  else if (r.nt == 256 && r.ke == 16 && r.kx == 8) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, s);
-  else if (r.nt == 256 && r.ke == 32 && r.kx == 16) LaunchOne<256, 32, 16>(h, r, o, g, loglikes, ld, w, smem, s);
-  else if (r.nt == 256 && r.ke == 8 && r.kx == 4) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, s);
+  if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (r.nt == 256 && r.ke == 16 && r.kx == 8) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (r.nt == 256 && r.ke == 32 && r.kx == 16) LaunchOne<256, 32, 16>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (r.nt == 256 && r.ke == 8 && r.kx == 4) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else return false;
   return true;
 }

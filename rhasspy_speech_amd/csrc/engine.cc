@@ -150,6 +150,8 @@ Model::~Model() {
   if (d_pcm_) (void)hipFree(d_pcm_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
+  if (stream_dec_) (void)hipStreamDestroy(stream_dec_);
+  for (auto &e : slab_ev_) if (e) (void)hipEventDestroy(e);
 }
 
 void *Model::UploadBytes(const void *p, size_t bytes) {
@@ -200,6 +202,13 @@ void Model::ToDevice() {
     throw DeviceError(std::string("this library is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
   RS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   RS_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  {
+    // the search of a slab is latency-bound and must not queue behind the thousands of GEMM workgroups of the next slab
+    int prio_low = 0, prio_high = 0;
+    RS_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    RS_HIP(hipStreamCreateWithPriority(&stream_dec_, hipStreamNonBlocking, prio_high));
+  }
+  for (auto &e : slab_ev_) RS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // ---- MFCC tables
   const MfccTables &t = fc_.mfcc;
   mfcc_dev_.win = t.win; mfcc_dev_.shift = t.shift; mfcc_dev_.padded = t.padded; mfcc_dev_.nbins = t.nbins; mfcc_dev_.nceps = t.nceps;
@@ -546,6 +555,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   auto fbytes = [&](int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
   size_t need = 0;
   need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 3 * sizeof(int) * (size_t)rows + 4096;
+  need += sizeof(int) * ((size_t)frame_base[n_utts] + 8 * (size_t)n_utts + 64) + 1024;     // frame-row map
   std::vector<int> buf_ld(nn.bufs.size());
   for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
@@ -598,6 +608,40 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
     if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
     LaunchRowGeometry(n_utts, rows, L_, d_rb, d_ib, d_ru, d_rt, host_row_ivec ? nullptr : d_row_ivec, s);
     g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
+  }
+  // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
+  // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
+  const int total_frames = frame_base[n_utts];
+  // decoder selection
+  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f);
+  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
+  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
+  // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
+  // output GEMM of slab k+1 (MFMA-bound) runs while slab k is searched (latency-bound) on a second, high-priority stream.
+  // Measured on the bench batch: 5.07 -> 4.97 ms with 3 slabs -- the search runs at half speed while it shares the CUs
+  // with GEMM waves, so most of the overlap is given back; off by default (RS_OVERLAP_SLABS=n turns it on).
+  const int overlap_env = [] { const char *e = std::getenv("RS_OVERLAP_SLABS"); return e ? std::atoi(e) : 1; }();
+  const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
+                            nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
+  const bool pipelined = use_reg && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
+                         s == stream_;
+  const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
+  std::vector<int> slab_off(n_slabs + 1, 0);
+  int *d_frame_rows = nullptr;
+  if (total_frames > 0) {
+    const int n_segs = n_slabs * n_utts;
+    int *h_seg = harena.AllocT<int>(n_segs + 1);
+    int acc_rows = 0;
+    for (int k = 0; k < n_slabs; k++) {
+      slab_off[k] = acc_rows;
+      for (int u = 0; u < n_utts; u++) { h_seg[k * n_utts + u] = acc_rows; acc_rows += std::min(std::max(T[u] - k * slab_len, 0), slab_len); }
+    }
+    h_seg[n_segs] = acc_rows;
+    slab_off[n_slabs] = acc_rows;
+    int *d_seg = arena_.AllocT<int>(n_segs + 1);
+    d_frame_rows = arena_.AllocT<int>(total_frames);
+    RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
+    LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   Timer tm(s);
@@ -707,12 +751,53 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       }
     }
   }
+  // ---- decoder selection and work buffers (before the acoustic model: the last layer is pipelined with the search)
+  DecodeOptsDev dopts;
+  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
+  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
+  DecodeWork w;
+  std::memset(&w, 0, sizeof(w));
+  w.max_words = max_words;
+  w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
+  w.out_nwords = arena_.AllocT<int>(n_utts);
+  w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
+  w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
+  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
+  DenseWork dw;
+  std::memset(&dw, 0, sizeof(dw));
+  if (use_dense) {
+    dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
+    dw.out_words = w.out_words; dw.out_nwords = w.out_nwords; dw.out_costs = w.out_costs; dw.counters = w.counters;
+    dw.frame_info = w.frame_info; dw.max_words = max_words;
+    dw.path_cap = 4 * (maxT + 2);
+    dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
+    dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (S + 4));
+    RS_HIP(hipMemsetAsync(w.counters, 0, sizeof(long long) * 8 * (size_t)n_utts, s));
+  }
   tm.Mark();
   // ---- acoustic model
   for (size_t i = 0; i < nn.ops.size(); i++) {
     const LayerOp &op = nn.ops[i];
     if (op.kind == LayerOp::kGemm) {
-      LaunchGemm(fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]), rows, d_row_ivec, s);
+      GemmDev gd = fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]);
+      const BufferInfo &ob = nn.bufs[op.out_buf];
+      if (pipelined && i + 1 == nn.ops.size()) {
+        // slab k: output layer on the main stream, then the search of that slab on the decode stream
+        for (int k = 0; k < n_slabs; k++) {
+          gd.row_map = d_frame_rows + slab_off[k];
+          LaunchGemm(gd, slab_off[k + 1] - slab_off[k], d_row_ivec, s);
+          RS_HIP(hipEventRecord(slab_ev_[k], s));
+          RS_HIP(hipStreamWaitEvent(stream_dec_, slab_ev_[k], 0));
+          LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, bufp[nn.output_buf], buf_ld[nn.output_buf], dw, k == 0 ? -1 : k * slab_len,
+                          k + 1 == n_slabs ? maxT + 1 : (k + 1) * slab_len, stream_dec_);
+        }
+        RS_HIP(hipEventRecord(slab_ev_[8], stream_dec_));
+      } else if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
+        gd.row_map = d_frame_rows;
+        LaunchGemm(gd, total_frames, d_row_ivec, s);
+      } else {
+        LaunchGemm(gd, rows, d_row_ivec, s);
+      }
     } else {
       EltwiseDev d;
       std::memset(&d, 0, sizeof(d));
@@ -746,29 +831,10 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   if (d_log_priors_ || opts_.acoustic_scale != 1.0f) LaunchPriorScale(ll, ll_ld, rows, P, d_log_priors_, opts_.acoustic_scale, s);
   tm.Mark();
   // ---- decode
-  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f);
-  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
-  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
-  DecodeOptsDev dopts;
-  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
-  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
-  DecodeWork w;
-  std::memset(&w, 0, sizeof(w));
-  w.max_words = max_words;
-  w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
-  w.out_nwords = arena_.AllocT<int>(n_utts);
-  w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
-  w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
-  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
-  if (use_dense) {
-    DenseWork dw;
-    std::memset(&dw, 0, sizeof(dw));
-    dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
-    dw.out_words = w.out_words; dw.out_nwords = w.out_nwords; dw.out_costs = w.out_costs; dw.counters = w.counters;
-    dw.frame_info = w.frame_info; dw.max_words = max_words;
-    dw.path_cap = 4 * (maxT + 2);
-    dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
-    if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, s);
+  if (pipelined) {
+    RS_HIP(hipStreamWaitEvent(s, slab_ev_[8], 0));       // the search of the last slab
+  } else if (use_dense) {
+    if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, -1, maxT + 1, s);
     else LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
   } else {
     w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);

@@ -106,6 +106,8 @@ class Model {
   bool on_device_ = false;
   std::mutex mu_;
   hipStream_t stream_ = nullptr;
+  hipStream_t stream_dec_ = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on stream_
+  hipEvent_t slab_ev_[9] = {};
   std::vector<void *> owned_;         // persistent device allocations
   DeviceArena arena_[2];               // one per concurrent utterance group
   HostArena host_arena_[2];

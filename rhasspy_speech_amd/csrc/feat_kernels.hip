@@ -309,6 +309,20 @@ __global__ void RowGeometryKernel(int n_utts, int rows, int L, const int *__rest
   row_t[r] = r - row_base[lo] - L;
   if (row_ivec) row_ivec[r] = ivrow_base[lo];
 }
+__global__ void FrameRowsKernel(int n_utts, int n_segs, int total, int L, int slab_len, const int *__restrict__ seg_off,
+                                const int *__restrict__ row_base, int *__restrict__ frame_rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n_segs;          // largest segment with seg_off[seg] <= i
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= i) lo = mid; else hi = mid; }
+  const int k = lo / n_utts, u = lo % n_utts;
+  frame_rows[i] = row_base[u] + L + k * slab_len + (i - seg_off[lo]);
+}
+void LaunchFrameRows(int n_utts, int n_segs, int total, int L, int slab_len, const int *seg_off, const int *row_base, int *frame_rows,
+                     hipStream_t s) {
+  if (total <= 0) return;
+  hipLaunchKernelGGL(FrameRowsKernel, dim3((total + 255) / 256), dim3(256), 0, s, n_utts, n_segs, total, L, slab_len, seg_off, row_base, frame_rows);
+}
 void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const int *ivrow_base, int *row_utt, int *row_t, int *row_ivec,
                        hipStream_t s) {
   if (rows <= 0) return;

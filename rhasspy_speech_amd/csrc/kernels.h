@@ -47,6 +47,10 @@ struct MfccDev {
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s);
 
+// frame_rows[i] = physical row of the i-th frame in slab-major order: entry (k, u) of seg_off (n_segs + 1 offsets, n_segs =
+// n_slabs * n_utts) starts the frames [k * slab_len, ...) of utterance u.
+void LaunchFrameRows(int n_utts, int n_segs, int total, int L, int slab_len, const int *seg_off, const int *row_base, int *frame_rows,
+                     hipStream_t s);
 void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const int *ivrow_base, int *row_utt, int *row_t, int *row_ivec,
                        hipStream_t s);
 
@@ -86,6 +90,7 @@ struct GemmDev {
   EltStageDev stages[kMaxStages];
   float *out;
   int ldo;
+  const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
 };
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
 
@@ -198,6 +203,8 @@ struct DenseWork {
   int max_words;
   int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
   int path_cap;
+  // resumable decoding (decode_reg.hip): token costs and scalars carried between the time slabs of one utterance
+  float *state_cost;          // n_utts x (S + 4): S costs, then {closure cutoff, error flag}
 };
 // Register-resident variant (decode_reg.hip): the arcs are dealt out to the threads of an NT-thread workgroup (arc i ->
 // thread i % NT, register slot i / NT) and live in VGPRs for the whole utterance.  Tables are [slot][thread] so that
@@ -212,8 +219,10 @@ struct RegGraphDev {
   const int4 *x_tab;          // [kx][nt] {(key_base + 8*src + 4) | (key_base + 8*dst) << 16, 0, weight bits, forward arc index}
 };
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx);
+// Decodes frames [f_begin, f_end) of every utterance (f_begin = -1 starts an utterance; the slab that contains an
+// utterance's last frame also does its traceback).  w.counters must be zeroed before the first slab.
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
-                     const float *loglikes, int ld, const DenseWork &w, hipStream_t s);
+                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,

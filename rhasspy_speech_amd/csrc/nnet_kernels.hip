@@ -84,14 +84,16 @@ __device__ __forceinline__ void GemmEpilogue(const f32x4 (&acc)[MT][4], const Ge
     for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
       const int rl = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
       const int row = row0 + rl, col = n0 + c4;
-      if (row < rows && col < d.n)
-        *reinterpret_cast<f32x4 *>(d.out + (size_t)row * d.ldo + col) = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+      if (row < rows && col < d.n) {
+        const int prow = d.row_map ? d.row_map[row] : row;
+        *reinterpret_cast<f32x4 *>(d.out + (size_t)prow * d.ldo + col) = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+      }
     }
   } else {
     for (int idx = tid; idx < BM * BN; idx += 256) {
       const int rl = idx / BN, cl = idx % BN;
       const int row = row0 + rl, col = n0 + cl;
-      if (row < rows && col < d.n) d.out[(size_t)row * d.ldo + col] = Cs[rl * C_LD + cl];
+      if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl];
     }
   }
 }
@@ -123,7 +125,11 @@ __global__ __launch_bounds__(256, 2) void GemmKernel(GemmDev d, int rows, const 
   const int lr = tid >> 3, kq = (tid & 7) * 4;
   int grow[NA];
 #pragma unroll
-  for (int h = 0; h < NA; h++) { grow[h] = row0 + lr + h * 32; if (grow[h] >= rows) grow[h] = 0; }   // clamped rows are dropped in the epilogue
+  for (int h = 0; h < NA; h++) {
+    grow[h] = row0 + lr + h * 32;
+    if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
+    if (d.row_map) grow[h] = d.row_map[grow[h]];
+  }
   // W's K axis is the concatenation of the (padded) segments, so the weight pointers simply advance by BK per tile
   const float *wptr[NB];
 #pragma unroll
@@ -242,7 +248,11 @@ __global__ __launch_bounds__(256, 2) void GemmKernelDma(GemmDev d, int rows, con
   const int wbase = __builtin_amdgcn_readfirstlane(wave) * 8 * BK;      // this wave's 8 rows inside a 32-row group (floats)
   int grow[NA];
 #pragma unroll
-  for (int h = 0; h < NA; h++) { grow[h] = row0 + lr + h * 32; if (grow[h] >= rows) grow[h] = 0; }   // clamped rows are dropped in the epilogue
+  for (int h = 0; h < NA; h++) {
+    grow[h] = row0 + lr + h * 32;
+    if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
+    if (d.row_map) grow[h] = d.row_map[grow[h]];
+  }
   const float *wptr[NB];
 #pragma unroll
   for (int h = 0; h < NB; h++) wptr[h] = d.W + (size_t)(n0 + lr + h * 32) * d.k_pad + kq;

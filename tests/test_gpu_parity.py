@@ -155,6 +155,22 @@ def test_decoder_variants_agree(case_cache, name, extra, monkeypatch):
             assert got.counters(u)[5] == ref.counters(u)[5] and got.counters(u)[6] == ref.counters(u)[6], variant
 
 
+def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
+    """RS_OVERLAP_SLABS=n: the output layer and the (resumable) register-resident search are pipelined over n time slabs."""
+    from rhasspy_speech_amd import synth
+    ref_model, pcm = make_model(case_cache, "zam_u0")
+    pcms = [pcm] + [synth.synth_utterance(700 + i, n) for i, n in enumerate([48000, 5000, 33000, 90000, 1700])]
+    ref = ref_model.decode_batch(pcms)
+    for slabs in ("2", "5"):
+        monkeypatch.setenv("RS_OVERLAP_SLABS", slabs)
+        got = make_model(case_cache, "zam_u0")[0].decode_batch(pcms)
+        for u in range(len(pcms)):
+            assert got.words(u) == ref.words(u)
+            np.testing.assert_array_equal(got.costs(u), ref.costs(u))
+            assert got.counters(u)[:4] == ref.counters(u)[:4] and got.counters(u)[5:7] == ref.counters(u)[5:7]
+            np.testing.assert_array_equal(got.matrix(u, 2), ref.matrix(u, 2))
+
+
 STREAM_CASES = [n for n in cases.CASES if n not in ("zam_u1",)]
 
 
