@@ -58,10 +58,10 @@ def nnet_flops_per_row(desc: str) -> float:
 
 
 def gemm_traffic_bytes(n_gemm: int):
-    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v2_pmc.json):
+    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v3_pmc.json):
     FETCH_SIZE (KB, doubled: this rocprofv3 tallies the 128-B requests of a 16 B/lane streaming read at 64 B) + WRITE_SIZE
     (KB), averaged over the launches of the nnet stage.  None when the summary is absent."""
-    path = ROOT / "profiles" / "r01" / "bench_v2_pmc.json"
+    path = ROOT / "profiles" / "r01" / "bench_v3_pmc.json"
     if not path.exists():
         return None
     ks = json.loads(path.read_text())["kernels"]
