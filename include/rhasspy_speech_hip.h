@@ -134,6 +134,18 @@ int rs_result_counters(const rs_result *r, int32_t utt, int64_t out[8]);
 int rs_result_timings(const rs_result *r, float out[8]);
 void rs_result_free(rs_result *r);
 
+/* ---- fuzzy matching of an n-best list against <lang_dir>/G.fuzzy.fst (host side, no GPU involved).
+ * Replaces rhasspy_speech/transcribe_util.py:11-88 (`get_fuzzy_text`: the n-best text piped through fstcompile |
+ * fstcompose - G.fuzzy.fst | fstshortestpath | fstrmepsilon | fsttopsort | fstproject | fstprint, then the printed arcs
+ * summed in Python).  rs_fuzzy_open parses the FST once (the reference re-reads it per utterance). */
+typedef struct rs_fuzzy rs_fuzzy;
+int rs_fuzzy_open(const char *fuzzy_fst_path, rs_fuzzy **out);
+/* nbest_text = the bytes rs_result_text() renders (`utt-k id id ...` lines).  On a match *n_out = number of output labels
+ * (<= cap written to olabels, word ids of <lang_dir>/words.txt incl. `__output:` meta words, epsilons removed) and *cost =
+ * the value the reference compares with max_fuzzy_cost; *n_out = -1 when the reference would return None. */
+int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
+void rs_fuzzy_free(rs_fuzzy *f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,4 +69,23 @@ for d in "$HERE"/drivers/*.cc; do
   [ -f "$d" ] || continue
   link_tool "$d" "$(basename "${d%.cc}")"
 done
+# 4. the OpenFst command-line tools the reference's fuzzy matcher pipes an n-best list through (transcribe_util.py:47-60,
+#    kaldi.py:391-408): libfstscript + eight mains, from the vendored OpenFst sources
+if [ "${RS_BUILD_FST_TOOLS:-1}" = "1" ] && [ -d "$F/script" ]; then
+  FSTFLAGS=(-std=c++14 -O2 -fPIC -w -I"$F/include")
+  export FSTFLAGS_STR="$(printf '%q ' "${FSTFLAGS[@]}")"
+  mkdir -p "$OUT/obj_fst"
+  ls "$F"/script/*.cc | xargs -P "$JOBS" -I{} bash -c '
+    src="{}"; obj="$OUT/obj_fst/$(basename "${src%.cc}").o"
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ]; then eval g++ $FSTFLAGS_STR -c "$src" -o "$obj"; fi'
+  g++ -shared -o "$OUT/libfstscript_ref.so" "$OUT"/obj_fst/*.o
+  for t in fstcompile fstarcsort fstcompose fstshortestpath fstrmepsilon fsttopsort fstproject fstprint; do
+    if [ ! -f "$OUT/bin/$t" ] || [ "$F/bin/$t.cc" -nt "$OUT/bin/$t" ]; then
+      g++ "${FSTFLAGS[@]}" "$F/bin/$t.cc" "$F/bin/$t-main.cc" -o "$OUT/bin/$t" -L"$OUT" -lfstscript_ref -lkaldi_ref -Wl,-rpath,'$ORIGIN/..' \
+          -L"$LIBDIR" -l:"$(basename "$BLAS")" -Wl,-rpath,"$LIBDIR" -lpthread -ldl &
+      while [ "$(jobs -r | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done
+    fi
+  done
+  wait
+fi
 echo "oracle/_ref built: $(ls "$OUT/bin" | wc -l) tools"

@@ -33,6 +33,7 @@ EXPORTS = [
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
+    "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free",
 ]
 
 
@@ -72,6 +73,10 @@ def load_library() -> C.CDLL:
     lib.rs_result_pack.argtypes = [vp, i32, C.POINTER(i32)]
     lib.rs_result_free.argtypes = [vp]
     lib.rs_result_free.restype = None
+    lib.rs_fuzzy_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.rs_fuzzy_match.argtypes = [vp, C.c_char_p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
+    lib.rs_fuzzy_free.argtypes = [vp]
+    lib.rs_fuzzy_free.restype = None
     return lib
 
 
@@ -256,3 +261,31 @@ def finish_streams(streams: Sequence[Stream], nbest: int = 1, lattice_acoustic_s
     out = C.c_void_p()
     _check(lib().rs_streams_finish(arr, len(streams), nbest, lattice_acoustic_scale, C.byref(out)))
     return Result(out)
+
+
+class FuzzyMatcher:
+    """Owns an rs_fuzzy: <lang_dir>/G.fuzzy.fst parsed once (host side, no GPU)."""
+
+    def __init__(self, fuzzy_fst_path):
+        self._h = C.c_void_p()
+        _check(lib().rs_fuzzy_open(str(fuzzy_fst_path).encode(), C.byref(self._h)))
+
+    def match(self, nbest_text: bytes):
+        """(output word ids, cost) of the cheapest fuzzy path, or None where the reference's get_fuzzy_text returns None."""
+        cap = 256
+        while True:
+            buf = (C.c_int32 * cap)()
+            n, cost = C.c_int32(), C.c_double()
+            _check(lib().rs_fuzzy_match(self._h, bytes(nbest_text), buf, cap, C.byref(n), C.byref(cost)))
+            if n.value < 0:
+                return None
+            if n.value <= cap:
+                return list(buf[:n.value]), cost.value
+            cap = n.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().rs_fuzzy_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close

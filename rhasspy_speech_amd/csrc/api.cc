@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "fuzzy.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -280,5 +281,29 @@ int rs_result_timings(const rs_result *r, float out[8]) {
 }
 
 void rs_result_free(rs_result *r) { delete r; }
+
+struct rs_fuzzy {
+  rs::FuzzyMatcher m;
+  explicit rs_fuzzy(const std::string &path) : m(path) {}
+};
+
+int rs_fuzzy_open(const char *fuzzy_fst_path, rs_fuzzy **out) {
+  if (!fuzzy_fst_path || !out) return ArgError("rs_fuzzy_open: null argument");
+  return Guard([&]() { *out = new rs_fuzzy(fuzzy_fst_path); return RS_OK; });
+}
+
+int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost) {
+  if (!f || !nbest_text || !n_out || !cost || (cap > 0 && !olabels)) return ArgError("rs_fuzzy_match: null argument");
+  return Guard([&]() {
+    const rs::FuzzyResult r = f->m.Match(nbest_text);
+    *cost = r.cost;
+    if (!r.matched) { *n_out = -1; return RS_OK; }
+    *n_out = (int32_t)r.olabels.size();
+    for (int32_t i = 0; i < *n_out && i < cap; i++) olabels[i] = r.olabels[i];
+    return RS_OK;
+  });
+}
+
+void rs_fuzzy_free(rs_fuzzy *f) { delete f; }
 
 }  // extern "C"

@@ -14,7 +14,8 @@ from pathlib import Path
 from typing import List, Optional, Union
 
 from . import _lib
-from .meta import int2sym, read_words_txt, texts_from_int2sym
+from .meta import decode_meta, int2sym, read_words_txt, texts_from_int2sym
+from .transcribe_util import get_fuzzy_text
 from .tools import KaldiTools
 
 _LOGGER = logging.getLogger(__name__)
@@ -78,8 +79,12 @@ class KaldiNnet3StreamTranscriber:
             stream.close()
         int2sym_stdout = int2sym(nbest_stdout, self._words)
         _LOGGER.debug("nbest: %s", int2sym_stdout)
-        if (lang_dir / "G.fuzzy.fst").exists():
-            raise NotImplementedError("G.fuzzy.fst post-processing is not part of the MI355X hot path")
+        fuzzy_result = get_fuzzy_text(nbest_stdout, lang_dir)      # transcribe_stream.py:111-116
+        if fuzzy_result is not None:
+            text, cost = fuzzy_result
+            _LOGGER.debug("Fuzzy cost: %s", cost)
+            if cost <= max_fuzzy_cost:       # (like the reference, a TypeError when max_fuzzy_cost is None)
+                return [decode_meta(text)]
         if require_fuzzy:
             return []
         return texts_from_int2sym(int2sym_stdout)

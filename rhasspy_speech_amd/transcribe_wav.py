@@ -17,7 +17,8 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 
 from . import _lib
-from .meta import int2sym, read_words_txt, texts_from_int2sym
+from .meta import decode_meta, int2sym, read_words_txt, texts_from_int2sym
+from .transcribe_util import get_fuzzy_text
 from .tools import KaldiTools
 
 _LOGGER = logging.getLogger(__name__)
@@ -90,19 +91,21 @@ class KaldiNnet3WavTranscriber:
     def transcribe(self, wav_path, lang_dir, nbest: int = 1, max_fuzzy_cost=None, require_fuzzy: bool = False) -> List[str]:
         return self._finish(self._nbest_stdout([read_wav_pcm16(wav_path)], nbest)[0], Path(lang_dir), max_fuzzy_cost, require_fuzzy)
 
-    def transcribe_many(self, wav_paths: Sequence[Union[str, Path]], lang_dir, nbest: int = 1) -> List[List[str]]:
+    def transcribe_many(self, wav_paths: Sequence[Union[str, Path]], lang_dir, nbest: int = 1, max_fuzzy_cost=None,
+                        require_fuzzy: bool = False) -> List[List[str]]:
         """Batched: all files decoded in one device pass."""
         outs = self._nbest_stdout([read_wav_pcm16(p) for p in wav_paths], nbest)
-        return [self._finish(o, Path(lang_dir), None, False) for o in outs]
+        return [self._finish(o, Path(lang_dir), max_fuzzy_cost, require_fuzzy) for o in outs]
 
     def _finish(self, nbest_stdout: bytes, lang_dir: Path, max_fuzzy_cost, require_fuzzy: bool) -> List[str]:
         int2sym_stdout = int2sym(nbest_stdout, self._words)
         _LOGGER.debug("nbest: %s", int2sym_stdout)
-        if (lang_dir / "G.fuzzy.fst").exists():
-            # The reference pipes the n-best through 7 OpenFst CLI tools here (transcribe_util.py:11-88): out of
-            # scope for the hot path (SURVEY.md section 8(f) item 3).  Fail loudly rather than silently skipping it.
-            raise NotImplementedError("G.fuzzy.fst post-processing is not part of the MI355X hot path; remove the file or "
-                                      "run rhasspy_speech.transcribe_util.get_fuzzy_text on the n-best yourself")
+        fuzzy_result = get_fuzzy_text(nbest_stdout, lang_dir)      # transcribe_wav.py:87-92
+        if fuzzy_result is not None:
+            text, cost = fuzzy_result
+            _LOGGER.debug("Fuzzy cost: %s", cost)
+            if cost <= max_fuzzy_cost:       # (like the reference, a TypeError when max_fuzzy_cost is None)
+                return [decode_meta(text)]
         if require_fuzzy:
             return []
         return texts_from_int2sym(int2sym_stdout)

@@ -148,3 +148,44 @@ def test_sharded_gather_two_ranks_gloo(tmp_path):
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0, err.decode()[-2000:]
         assert b"ok" in out
+
+
+# ------------------------------------------------------------------------------------------ fuzzy matcher (host side)
+def _fuzzy_cases():
+    import json
+    return json.loads((cases.GOLDEN / "fuzzy" / "cases.json").read_text())
+
+
+def test_fuzzy_matcher_matches_reference():
+    """rs_fuzzy_match vs the reference's get_fuzzy_text run on its own OpenFst tools (oracle/gen_fuzzy_golden.py): the text
+    and the cost (an exact double: it is what gets compared with max_fuzzy_cost) of every case, including the ties between
+    equally cheap paths, which fall the way fstcompose | fstshortestpath make them fall."""
+    from rhasspy_speech_amd import transcribe_util
+    n_match = 0
+    for c in _fuzzy_cases():
+        got = transcribe_util.get_fuzzy_text(c["nbest"].encode(), cases.GOLDEN / "fuzzy" / c["lang"])
+        if c["result"] is None:
+            assert got is None, c
+        else:
+            assert got is not None and got[0] == c["result"][0] and got[1] == c["result"][1], (c, got)
+            n_match += 1
+    assert n_match > 100
+
+
+def test_fuzzy_control_flow_of_the_transcriber(tmp_path):
+    """transcribe_wav.py:87-105: a fuzzy hit within max_fuzzy_cost replaces the n-best list by one decoded text; otherwise
+    require_fuzzy empties the result; without G.fuzzy.fst nothing changes."""
+    from rhasspy_speech_amd.transcribe_wav import KaldiNnet3WavTranscriber
+    from rhasspy_speech_amd.meta import read_words_txt, decode_meta
+    lang = cases.GOLDEN / "fuzzy" / "eps"
+    hit = next(c for c in _fuzzy_cases() if c["lang"] == "eps" and c["result"] is not None and c["result"][1] > 0.5)
+    t = KaldiNnet3WavTranscriber("unused", "unused")
+    t._words = read_words_txt(lang / "words.txt")
+    nb = hit["nbest"].encode()
+    assert t._finish(nb, lang, hit["result"][1], False) == [decode_meta(hit["result"][0])]
+    plain = t._finish(nb, tmp_path, None, False)                       # no G.fuzzy.fst there
+    assert len(plain) == len([l for l in hit["nbest"].splitlines() if len(l.split()) > 1])
+    assert t._finish(nb, lang, hit["result"][1] - 0.25, False) == plain   # too expensive: fall back to the n-best list
+    assert t._finish(nb, lang, hit["result"][1] - 0.25, True) == []
+    with pytest.raises(TypeError):
+        t._finish(nb, lang, None, False)                               # the reference compares `cost <= None` too
