@@ -48,7 +48,8 @@ typedef struct rs_decode_opts {
   int32_t device_id;           /* HIP device ordinal */
   int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
   int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */
-  int32_t reserved[7];
+  int32_t emit_lattice;        /* 1: results keep the determinised lattice (rs_result_lattice); forces the lattice path */
+  int32_t reserved[6];
 } rs_decode_opts;
 
 /* Fills `opts` with the values the reference's Python passes / Kaldi defaults. */
@@ -111,6 +112,14 @@ int32_t rs_result_num_hyps(const rs_result *r, int32_t utt);
 int32_t rs_result_num_frames(const rs_result *r, int32_t utt);
 /* Word ids (HCLG olabels, epsilons removed) of hypothesis k; *ids stays valid until rs_result_free. */
 int rs_result_words(const rs_result *r, int32_t utt, int32_t k, const int32_t **ids, int32_t *n);
+/* The utterance's lattice as one binary CompactLattice table entry ("<key> " + VectorFst<CompactLatticeArc> with no "\0B" marker,
+ * lat/kaldi-lattice.cc:62-70,:478-500, fstext/lattice-weight.h:141-145,:471-475,:532-540): what online2-wav-nnet3-latgen-faster
+ * writes to its `ark:` wspecifier (online2-wav-nnet3-latgen-faster.cc:286-300), i.e. the bytes the reference pipes into
+ * lattice-to-nbest.  Needs rs_decode_opts.emit_lattice = 1.  The lattice is determinised on words within lattice_beam and
+ * is equivalent to the reference's (same word sequences, costs and best alignments), not byte-identical: state numbering
+ * is this library's.  Returns the entry's size in bytes (copies min(size, cap) bytes to buf), or a negative error. */
+int64_t rs_result_lattice(const rs_result *res, int32_t utt, const char *key, char *buf, int64_t cap);
+
 /* (graph cost, acoustic cost) of hypothesis k = the 4th/5th outputs of nbest-to-linear. */
 int rs_result_costs(const rs_result *r, int32_t utt, int32_t k, float *graph_cost, float *acoustic_cost);
 /* Renders exactly the bytes `nbest-to-linear ark:- ark:/dev/null ark,t:-` prints for this utterance:

@@ -23,7 +23,7 @@ class DecodeOpts(C.Structure):
         ("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("lattice_beam", C.c_float),
         ("beam_delta", C.c_float), ("acoustic_scale", C.c_float), ("frames_per_chunk", C.c_int32),
         ("frame_subsampling_factor", C.c_int32), ("device_id", C.c_int32), ("keep_intermediates", C.c_int32),
-        ("max_tokens_per_frame", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("max_tokens_per_frame", C.c_int32), ("emit_lattice", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -31,7 +31,7 @@ EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
     "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_stream_open", "rs_stream_accept",
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
-    "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_matrix",
+    "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free",
 ]
@@ -67,6 +67,8 @@ def load_library() -> C.CDLL:
     lib.rs_result_words.argtypes = [vp, i32, i32, C.POINTER(C.POINTER(i32)), C.POINTER(i32)]
     lib.rs_result_costs.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32)]
     lib.rs_result_text.argtypes = [vp, i32, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.rs_result_lattice.argtypes = [vp, i32, C.c_char_p, C.c_char_p, C.c_int64]
+    lib.rs_result_lattice.restype = C.c_int64
     lib.rs_result_matrix.argtypes = [vp, i32, i32, C.POINTER(C.POINTER(f32)), C.POINTER(i32), C.POINTER(i32)]
     lib.rs_result_counters.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     lib.rs_result_timings.argtypes = [vp, C.POINTER(f32)]
@@ -153,6 +155,15 @@ class Result:
         buf = C.create_string_buffer(n + 1)
         lib().rs_result_text(self._h, utt, key.encode(), buf, n + 1)
         return buf.value
+
+    def lattice(self, utt: int, key: str = "utt") -> bytes:
+        """One binary CompactLattice table entry (what online2-wav-nnet3-latgen-faster writes); needs emit_lattice=1."""
+        n = lib().rs_result_lattice(self._h, utt, key.encode(), None, 0)
+        if n < 0:
+            _check(int(n))
+        buf = C.create_string_buffer(int(n))
+        lib().rs_result_lattice(self._h, utt, key.encode(), buf, n)
+        return buf.raw
 
     def matrix(self, utt: int, kind: int) -> np.ndarray:
         data = C.POINTER(C.c_float)()

@@ -231,6 +231,21 @@ int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, 
   return (int)s.size();
 }
 
+int64_t rs_result_lattice(const rs_result *r, int32_t utt, const char *key, char *buf, int64_t cap) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u || cap < 0 || (cap > 0 && !buf)) return ArgError("rs_result_lattice: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  if (!u->clat) return ArgError("rs_result_lattice: the model was not opened with rs_decode_opts.emit_lattice = 1");
+  try {
+    const std::string s = rs::CompactLatticeArkEntry(key ? key : "utt", *u->clat);
+    if (buf && cap) std::memcpy(buf, s.data(), std::min<size_t>(s.size(), (size_t)cap));
+    return (int64_t)s.size();
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return RS_ERR_DECODE;
+  }
+}
+
 int rs_result_pack(const rs_result *r, int32_t max_words, int32_t *out) {
   if (!r || !out || max_words < 0) return ArgError("rs_result_pack: bad argument");
   const int stride = max_words + 4;

@@ -613,7 +613,10 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
   const int total_frames = frame_base[n_utts];
   // decoder selection
-  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f);
+  // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
+  // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
+  const bool unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
+  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || unscale);
   const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
   const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
   // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
@@ -949,17 +952,25 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       lat.final_cost.assign(lat.num_states, std::numeric_limits<double>::infinity());
       for (const LatArc *a : per[u]) {
         if (a->arc < 0) { lat.final_cost[id[a->src]] = a->graph; continue; }
-        lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic});
+        lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic, hclg_.arcs[a->arc].ilabel});
       }
-      std::vector<NbestPath> paths = LatticeNbest(lat, nbest, opts_.lattice_beam, lat_scale);
+      std::vector<NbestPath> paths = LatticeNbest(lat, nbest, opts_.lattice_beam, unscale ? lat_scale / opts_.acoustic_scale : lat_scale);
       ur.counters[4] = (int64_t)lat.arcs.size();
+      if (opts_.emit_lattice) {
+        ur.clat = std::make_shared<CompactLat>(DeterminizeLattice(lat, opts_.lattice_beam));
+        if (unscale) {
+          const double inv = 1.0 / opts_.acoustic_scale;
+          for (auto &v : ur.clat->arcs) for (auto &a : v) a.w.acoustic *= inv;
+          for (auto &fw : ur.clat->final_w) fw.acoustic *= inv;
+        }
+      }
       if (paths.empty()) continue;   // keep the traceback result (cannot happen for a consistent lattice)
       ur.hyps.clear();
       for (auto &p : paths) {
         Hypothesis hy;
         hy.words = p.words;
         hy.graph_cost = (float)p.graph_cost;
-        hy.acoustic_cost = (float)p.acoustic_cost;
+        hy.acoustic_cost = (float)(unscale ? p.acoustic_cost / opts_.acoustic_scale : p.acoustic_cost);
         ur.hyps.push_back(std::move(hy));
       }
     }

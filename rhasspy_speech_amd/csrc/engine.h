@@ -9,6 +9,7 @@
 
 #include "../../include/rhasspy_speech_hip.h"
 #include "kernels.h"
+#include "lattice.h"
 #include "model.h"
 
 namespace rs {
@@ -58,6 +59,7 @@ struct UttResult {
   int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<float> feats, ivector, loglikes;   // keep_intermediates only
   int feat_dim = 0, ivec_rows = 0, ivec_dim = 0, num_pdfs = 0;
+  std::shared_ptr<CompactLat> clat;              // emit_lattice only
 };
 struct Result {
   std::vector<UttResult> utts;

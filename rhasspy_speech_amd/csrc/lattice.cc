@@ -180,4 +180,239 @@ std::vector<NbestPath> LatticeNbest(const RawLattice &lat, int n, double lattice
   return found;
 }
 
+// ------------------------------------------------------------------------------------------ determinisation
+namespace {
+
+struct Elem {           // subset element: lattice state + residual weight / alignment relative to the subset's incoming arc
+  int state;
+  Pair w;
+  std::vector<int32_t> tids;
+};
+
+struct SubsetKey {
+  std::vector<Elem> elems;       // sorted by state
+  bool operator<(const SubsetKey &o) const {
+    if (elems.size() != o.elems.size()) return elems.size() < o.elems.size();
+    for (size_t i = 0; i < elems.size(); i++) {
+      const Elem &a = elems[i], &b = o.elems[i];
+      if (a.state != b.state) return a.state < b.state;
+      if (a.w.g != b.w.g) return a.w.g < b.w.g;
+      if (a.w.a != b.w.a) return a.w.a < b.w.a;
+      if (a.tids != b.tids) return a.tids < b.tids;
+    }
+    return false;
+  }
+};
+
+}  // namespace
+
+CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
+  CompactLat out;
+  const int N = lat.num_states;
+  if (N == 0 || lat.start < 0) return out;
+  const double INF = std::numeric_limits<double>::infinity();
+  std::vector<int> begin(N + 1, 0);
+  for (auto &a : lat.arcs) begin[a.src + 1]++;
+  for (int s = 0; s < N; s++) begin[s + 1] += begin[s];
+  std::vector<int> order(lat.arcs.size()), fill(begin.begin(), begin.end() - 1);
+  for (size_t i = 0; i < lat.arcs.size(); i++) order[fill[lat.arcs[i].src]++] = (int)i;
+  std::vector<int> indeg(N, 0), topo(N, -1), by_rank;
+  for (auto &a : lat.arcs) indeg[a.dst]++;
+  std::vector<int> stack;
+  for (int s = 0; s < N; s++) if (indeg[s] == 0) stack.push_back(s);
+  while (!stack.empty()) {
+    int s = stack.back();
+    stack.pop_back();
+    topo[s] = (int)by_rank.size();
+    by_rank.push_back(s);
+    for (int k = begin[s]; k < begin[s + 1]; k++) { int d = lat.arcs[order[k]].dst; if (--indeg[d] == 0) stack.push_back(d); }
+  }
+  if ((int)by_rank.size() != N) Fail("lattice has a cycle");
+  std::vector<double> beta(N, INF);
+  for (int r = N - 1; r >= 0; r--) {
+    int s = by_rank[r];
+    double b = lat.final_cost[s];
+    for (int k = begin[s]; k < begin[s + 1]; k++) {
+      const RawLattice::Arc &a = lat.arcs[order[k]];
+      b = std::min(b, a.graph + a.acoustic + beta[a.dst]);
+    }
+    beta[s] = b;
+  }
+  const double best_total = beta[lat.start];
+  if (!(best_total < INF)) return out;
+  const double cutoff = best_total + beam;
+
+  // epsilon closure (word label 0) of a seed set, pruned with the forward cost `alpha` of the subset; returns the elements
+  // sorted by state, best (weight, alignment) per state
+  auto closure = [&](std::vector<Elem> seed, double alpha) {
+    std::map<int, Elem> cur;       // state -> best element
+    std::priority_queue<std::pair<int, int>, std::vector<std::pair<int, int>>, std::greater<std::pair<int, int>>> q;
+    for (auto &e : seed) {
+      auto f = cur.find(e.state);
+      if (f == cur.end() || Better(e.w, f->second.w)) { cur[e.state] = e; q.push({topo[e.state], e.state}); }
+    }
+    std::map<int, char> done;
+    while (!q.empty()) {
+      const int s = q.top().second;
+      q.pop();
+      if (done.count(s)) continue;
+      done[s] = 1;
+      const Elem es = cur[s];
+      for (int k = begin[s]; k < begin[s + 1]; k++) {
+        const RawLattice::Arc &a = lat.arcs[order[k]];
+        if (a.olabel != 0) continue;
+        Elem c{a.dst, Pair{es.w.g + a.graph, es.w.a + a.acoustic}, es.tids};
+        if (a.ilabel != 0) c.tids.push_back(a.ilabel);
+        if (alpha + c.w.g + c.w.a + beta[a.dst] > cutoff) continue;
+        auto f = cur.find(a.dst);
+        if (f == cur.end() || Better(c.w, f->second.w)) { cur[a.dst] = c; q.push({topo[a.dst], a.dst}); }
+      }
+    }
+    std::vector<Elem> v;
+    for (auto &kv : cur) v.push_back(kv.second);
+    return v;
+  };
+  // common weight (the best element's, LatticeWeight order) and common alignment prefix are moved out of the subset
+  auto normalise = [&](std::vector<Elem> *v, CompactLat::Weight *common) {
+    Pair best = (*v)[0].w;
+    for (auto &e : *v) if (Better(e.w, best)) best = e.w;
+    size_t pre = (*v)[0].tids.size();
+    for (auto &e : *v) {
+      size_t k = 0;
+      while (k < pre && k < e.tids.size() && e.tids[k] == (*v)[0].tids[k]) k++;
+      pre = k;
+    }
+    common->graph = best.g;
+    common->acoustic = best.a;
+    common->tids.assign((*v)[0].tids.begin(), (*v)[0].tids.begin() + pre);
+    for (auto &e : *v) { e.w.g -= best.g; e.w.a -= best.a; e.tids.erase(e.tids.begin(), e.tids.begin() + pre); }
+  };
+  std::map<SubsetKey, int> ids;
+  std::vector<SubsetKey> subsets;
+  std::vector<double> alpha;          // best forward total of every output state
+  auto state_of = [&](std::vector<Elem> v, double a) {
+    SubsetKey key{std::move(v)};
+    auto it = ids.find(key);
+    if (it != ids.end()) { if (a < alpha[it->second]) alpha[it->second] = a; return it->second; }
+    const int id = (int)subsets.size();
+    ids.emplace(key, id);
+    subsets.push_back(std::move(key));
+    alpha.push_back(a);
+    out.arcs.emplace_back();
+    out.final_w.emplace_back();
+    out.is_final.push_back(0);
+    return id;
+  };
+  // start: a state whose single epsilon-word arc carries the common part of the initial subset
+  {
+    std::vector<Elem> init = closure({Elem{lat.start, Pair{0, 0}, {}}}, 0.0);
+    CompactLat::Weight common;
+    normalise(&init, &common);
+    const bool trivial = common.graph == 0 && common.acoustic == 0 && common.tids.empty();
+    if (trivial) {
+      out.start = state_of(init, 0.0);
+    } else {
+      out.arcs.emplace_back();
+      out.final_w.emplace_back();
+      out.is_final.push_back(0);
+      subsets.push_back(SubsetKey{});          // placeholder for the extra start state (never expanded)
+      alpha.push_back(0.0);
+      out.start = 0;
+      const int s1 = state_of(init, common.graph + common.acoustic);
+      out.arcs[0].push_back({s1, 0, common});
+    }
+  }
+  for (size_t si = 0; si < subsets.size(); si++) {
+    if (subsets[si].elems.empty()) continue;
+    if (subsets.size() > 2000000) Fail("lattice determinisation: too many states");
+    const std::vector<Elem> elems = subsets[si].elems;      // copy: `subsets` grows below
+    const double a0 = alpha[si];
+    // final weight
+    {
+      bool have = false;
+      Elem bestf{};
+      for (auto &e : elems) {
+        if (!(lat.final_cost[e.state] < INF)) continue;
+        Elem c = e;
+        c.w.g += lat.final_cost[e.state];
+        if (a0 + c.w.g + c.w.a > cutoff) continue;
+        if (!have || Better(c.w, bestf.w)) { bestf = c; have = true; }
+      }
+      if (have) {
+        out.is_final[si] = 1;
+        out.final_w[si].graph = bestf.w.g;
+        out.final_w[si].acoustic = bestf.w.a;
+        out.final_w[si].tids = bestf.tids;
+      }
+    }
+    // word arcs
+    std::map<int, std::vector<Elem>> nxt;
+    for (auto &e : elems) {
+      for (int k = begin[e.state]; k < begin[e.state + 1]; k++) {
+        const RawLattice::Arc &a = lat.arcs[order[k]];
+        if (a.olabel == 0) continue;
+        Elem c{a.dst, Pair{e.w.g + a.graph, e.w.a + a.acoustic}, e.tids};
+        if (a.ilabel != 0) c.tids.push_back(a.ilabel);
+        if (a0 + c.w.g + c.w.a + beta[a.dst] > cutoff) continue;
+        nxt[a.olabel].push_back(std::move(c));
+      }
+    }
+    for (auto &kv : nxt) {
+      std::vector<Elem> v = closure(std::move(kv.second), a0);
+      if (v.empty()) continue;
+      CompactLat::Weight common;
+      normalise(&v, &common);
+      const int d = state_of(std::move(v), a0 + common.graph + common.acoustic);
+      out.arcs[si].push_back({d, kv.first, common});
+    }
+  }
+  return out;
+}
+
+std::string CompactLatticeArkEntry(const std::string &key, const CompactLat &clat) {
+  std::string o = key + " ";       // no "\0B": this holder's binary form starts with the FST magic (kaldi-lattice.cc:478-500)
+  auto put = [&](const void *p, size_t n) { o.append(reinterpret_cast<const char *>(p), n); };
+  auto put_i32 = [&](int32_t v) { put(&v, 4); };
+  auto put_i64 = [&](int64_t v) { put(&v, 8); };
+  auto put_str = [&](const std::string &s) { put_i32((int32_t)s.size()); o.append(s); };
+  auto put_w = [&](const CompactLat::Weight &w) {
+    const float g = (float)w.graph, a = (float)w.acoustic;
+    put(&g, 4);
+    put(&a, 4);
+    put_i32((int32_t)w.tids.size());
+    for (int32_t t : w.tids) put_i32(t);
+  };
+  int64_t narcs = 0;
+  for (auto &v : clat.arcs) narcs += (int64_t)v.size();
+  // FstHeader (fst.cc:58-82): magic, fst type, arc type, version, flags, properties, start, #states, #arcs
+  put_i32(2125659606);
+  put_str("vector");
+  put_str("compactlattice44");
+  put_i32(2);
+  put_i32(0);
+  const uint64_t props = 0x1ull | 0x2ull;            // kExpanded | kMutable: nothing else is claimed
+  put(&props, 8);
+  put_i64(clat.arcs.empty() ? -1 : clat.start);
+  put_i64((int64_t)clat.arcs.size());
+  put_i64(narcs);
+  const float inf = std::numeric_limits<float>::infinity();
+  for (size_t s = 0; s < clat.arcs.size(); s++) {
+    if (clat.is_final[s]) {
+      put_w(clat.final_w[s]);
+    } else {                                          // CompactLatticeWeight::Zero() = (inf, inf, empty string)
+      put(&inf, 4);
+      put(&inf, 4);
+      put_i32(0);
+    }
+    put_i64((int64_t)clat.arcs[s].size());
+    for (auto &a : clat.arcs[s]) {
+      put_i32(a.label);
+      put_i32(a.label);
+      put_w(a.w);
+      put_i32(a.dst);
+    }
+  }
+  return o;
+}
+
 }  // namespace rs
