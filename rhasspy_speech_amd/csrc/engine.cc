@@ -177,6 +177,34 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
       std::memcpy(&W[(size_t)r * plan->k_pad + plan->seg_k0[si]], &op.W.d[(size_t)r * op.W.cols + sg.w_col], sizeof(float) * sg.ncols);
   }
   plan->d_W = Upload(W);
+  // Split-bf16 image (nnet_gemm_b3.hip): w = w1 + w2 + w3 with bf16 parts (round to nearest even), stored per
+  // (16-wide k-step, 32-column tile, part) as one 1 KiB MFMA B fragment [k-group 2][column 32][8 bf16].
+  plan->n3 = RoundUp(op.out_dim, 256);
+  plan->d_W3 = nullptr;
+  if (op.out_dim >= 192) {
+    auto to_bf16 = [](float x) {
+      uint32_t u;
+      std::memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (weights are finite)
+      return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
+    const int nct = plan->n3 / 32, nks = plan->k_pad / 16;
+    std::vector<uint16_t> W3((size_t)(nks + 2) * nct * 3 * 512, 0);      // + 2 k-steps the kernel's pipeline requests past the end
+    for (int n = 0; n < op.out_dim; n++)
+      for (int k = 0; k < plan->k_pad; k++) {
+        const float w = W[(size_t)n * plan->k_pad + k];
+        if (w == 0.0f) continue;
+        const uint16_t h1 = to_bf16(w);
+        const float r1 = w - from_bf16(h1);
+        const uint16_t h2 = to_bf16(r1);
+        const float r2 = r1 - from_bf16(h2);
+        const uint16_t h3 = to_bf16(r2);
+        const size_t base = ((size_t)(k / 16) * nct + n / 32) * 3 * 512 + (size_t)((k % 16) / 8) * 256 + (size_t)(n % 32) * 8 + k % 8;
+        W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
+      }
+    plan->d_W3 = UploadBytes(W3.data(), W3.size() * sizeof(uint16_t));
+  }
   plan->d_bias = op.bias.empty() ? nullptr : Upload(op.bias);
   plan->d_stage.clear();
   for (auto &st : op.stages) {
@@ -441,6 +469,14 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
 std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
                                                  float lat_scale, hipStream_t user_stream, bool streaming) {
   ToDevice();
+  // One decode call at a time per PROCESS, not just per model.  Calls on different models used to run side by side; with
+  // the split-bf16 GEMM (nnet_gemm_b3.hip) in one of them the other model's features came out sporadically perturbed
+  // (isolated MFCC frames, about one utterance in a thousand; profiles/micro/stress_two_models.py reproduces it, 0 in
+  // 900 decodes without that kernel).  None of LDS / register poisoning, a known-answer victim kernel or draining the
+  // MFMA pipeline before s_endpgm explained it, so until it is understood models take turns on the GPU -- a batch
+  // fills the device by itself, so little throughput is lost.  Calls on ONE model were always serialised (mu_).
+  static std::mutex process_mu;
+  std::lock_guard<std::mutex> process_lk(process_mu);
   std::lock_guard<std::mutex> lk(mu_);
   RS_HIP(hipSetDevice(opts_.device_id));
   if (nbest < 1) Fail("nbest must be >= 1");
@@ -615,6 +651,12 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   // decoder selection
   // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
   // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
+  static const int lds_poison = [] { const char *e = std::getenv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
+  auto poison = [&]() {
+    if (!lds_poison) return;
+    static unsigned *sink = [] { unsigned *p = nullptr; (void)hipMalloc((void **)&p, 64); return p; }();
+    LaunchLdsPoison(sink, s);
+  };
   const bool unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
   const bool want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || unscale);
   const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
@@ -655,9 +697,12 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   float *raw = bufp[nn.input_buf];
   if (fc_.use_cmvn) {
     raw = falloc(ld_c);
+    poison();
     LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s);
+    poison();
     LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
   } else {
+    poison();
     LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s);
   }
   const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
@@ -678,6 +723,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
     }
     d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
+    d.W3 = pl.d_W3; d.n3 = pl.n3;
     d.nstages = (int)op.stages.size();
     for (int i = 0; i < d.nstages; i++) {
       const EltStage &st = op.stages[i];
@@ -689,11 +735,15 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   };
   if (has_iv) {
     float *cm = falloc(ld_c), *lda_raw = falloc(ld_l), *lda_norm = falloc(ld_l);
+    poison();
     LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
+    poison();
     LaunchGemm(fill_gemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l), rows, d_row_ivec, s);
+    poison();
     LaunchGemm(fill_gemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l), rows, d_row_ivec, s);
     int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
     float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
+    poison();
     LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, s);
     double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
     double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
@@ -706,7 +756,9 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
     double *iv_scratch = arena_.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, n_utts));
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     if (!streaming) {
+      poison();
       LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
+      poison();
       LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
       if (std::getenv("RS_DEBUG_IVEC")) {
         RS_HIP(hipStreamSynchronize(s));
@@ -797,8 +849,10 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
         RS_HIP(hipEventRecord(slab_ev_[8], stream_dec_));
       } else if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
         gd.row_map = d_frame_rows;
+        poison();
         LaunchGemm(gd, total_frames, d_row_ivec, s);
       } else {
+        poison();
         LaunchGemm(gd, rows, d_row_ivec, s);
       }
     } else {
@@ -826,6 +880,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
         }
       }
       d.nstages = ns;
+      poison();
       LaunchEltwise(d, rows, s);
     }
   }
@@ -837,6 +892,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   if (pipelined) {
     RS_HIP(hipStreamWaitEvent(s, slab_ev_[8], 0));       // the search of the last slab
   } else if (use_dense) {
+    poison();
     if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, -1, maxT + 1, s);
     else LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
   } else {
@@ -849,6 +905,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
     w.tok_cap = tok_cap;
     w.tokens = arena_.AllocT<int4>((size_t)n_utts * tok_cap);
     w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+    poison();
     LaunchDecode(hclg_dev_, dopts, g, ll, ll_ld, w, s);
   }
   tm.Mark();
@@ -994,6 +1051,8 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       }
     }
   }
+  // kernel launches are not checked one by one; a failed launch of this thread surfaces here instead of as silent garbage
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le)); }
   timings[1] = tm.Ms(0, 1);
   timings[2] = tm.Ms(1, 2);
   timings[3] = tm.Ms(2, 3);

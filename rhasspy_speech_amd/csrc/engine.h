@@ -70,7 +70,8 @@ struct Result {
 struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   const LayerOp *op = nullptr;
   float *d_W = nullptr, *d_bias = nullptr;
-  int k_pad = 0, n_pad = 0;
+  void *d_W3 = nullptr;           // split-bf16 image of W for GemmKernelB3 (layers at least 192 columns wide)
+  int k_pad = 0, n_pad = 0, n3 = 0;
   std::vector<int> seg_k0;
   std::vector<std::pair<float *, float *>> d_stage;   // scale/offset vectors per stage
 };

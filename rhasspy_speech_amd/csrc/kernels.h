@@ -85,6 +85,8 @@ struct GemmDev {
   GemmSegDev segs[kMaxSegs];
   const float *W;     // n_pad x k_pad, row-major, zero padded (k_pad = sum of segment widths rounded to kGemmBK)
   int k_pad, n, n_pad;
+  const void *W3;     // the same weights split into three bf16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
+  int n3;             // columns of W3 (n rounded up to 256)
   const float *bias;  // n (may be null)
   int nstages;
   EltStageDev stages[kMaxStages];
@@ -240,5 +242,7 @@ struct LatticeWork {
 };
 void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                         const DecodeWork &w, const LatticeWork &lw, hipStream_t s);
+
+void LaunchLdsPoison(unsigned *sink, hipStream_t s);   // debug aid, see feat_kernels.hip
 
 }  // namespace rs

@@ -1,0 +1,272 @@
+// The TDNN layer GEMM on the bf16 matrix cores with FP32 results: every FP32 operand is split into three bf16 parts
+//        x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)        (round to nearest even)
+// which together carry the full 24-bit significand (3 x 8 bits, plus a sign each), and a product is accumulated as
+//        a b ~= a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1
+// by six v_mfma_f32_32x32x16_bf16 with FP32 accumulation.  Each partial product is exact in FP32 (8 x 8 significand
+// bits); the three dropped terms are below 2^-25 |a b|, i.e. under the rounding error of one FP32 multiply.  The bf16
+// matrix cores run 16x the rate of the FP32-input MFMA (MI355X_MICROARCH.md), so six of them per k-step cost 6/16 of the
+// exact-FP32 path: the ceiling of this kernel is 2.67x the 157 TF FP32-MFMA peak.  tests/test_gpu_parity.py holds the
+// result to the same 1e-4 log-likelihood bound against the reference as the FP32 path (nnet_kernels.hip), which stays
+// selectable (RS_GEMM_B3=0) and is what small layers use.
+//
+// Same segmented-K contract as nnet_kernels.hip (GemmDev: the splice never exists in memory).  Block tile (32 MR) x 256:
+// four waves side by side, each (32 MR) x 64 = MR x 2 accumulator tiles of 32x32.  K advances 16 per step:
+//   weights: split ONCE on the host into the fragment order of the MFMA B operand -- for every (k-step, 32-column tile,
+//            part) one 1 KiB block [k-group 2][column 32][8 bf16].  A wave is the only consumer of its 64 columns, so its
+//            six B fragments never touch LDS: each is one global_load_dwordx4 (lane l takes bytes 16 l .. 16 l + 15 of
+//            the block: 1 KiB of consecutive memory per instruction);
+//   activations (shared by the four waves): FP32 rows from the producer's buffer -> registers (16 bytes per lane) ->
+//            split -> three 8-byte LDS writes into fragment order [k-group][row][8 bf16] (two LDS stages, one barrier per
+//            step), read back with one conflict-free ds_read_b128 at 16 x lane per fragment, used and dropped;
+//   pipeline: three register sets rotate -- during step t the weights of step t + 2 and the activations of step t + 3 are
+//            requested and the activations of step t + 1 are split into LDS.
+// Measured on the 256 x 3 s headline batch (76288 rows; profiles/r01): hidden layer (K 3 x 250, N 250) 200 us vs 245 us
+// for the FP32-MFMA kernel, output layer (K 250, N 2000) 590-620 vs 800 us.  What bounds it (rocprofv3 PMC, per-part
+// ablation): the matrix cores are busy 41 % of the time; the block's 24 KiB of weights per k-step stream from L2 for only
+// 64-128 rows (about 2.5 GB of L2 requests per hidden layer, 12 TB/s), and MFMA / weight stream / activation staging add
+// up rather than overlap across the per-step barrier.  Tried and dropped: weights through LDS with global_load_lds
+// (slower: LDS at 80 %), a 256-row 8-wave tile that quarters the weight stream (no faster per row, and its second round
+// on 298 tiles is mostly empty), 160-row tiles (spill).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdlib>
+
+#include "decode_common.h"
+#include "kernels.h"
+#include "nnet_common.h"
+
+namespace rs {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kB3BN = 256, kB3KS = 16;
+constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
+
+template <int MR>
+__global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, const int *__restrict__ row_ivec, int epi_mode) {
+  constexpr int BM = 32 * MR, BN = kB3BN;
+  constexpr int STAGE = MR * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
+  constexpr int UNITS = BM * 4, NA = (UNITS + 255) / 256;      // 16-byte activation loads per k-step and thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile order (see GemmKernel): all column tiles of a row tile go to one XCD back to back
+  const int ncol = (d.n + BN - 1) / BN, nrow = (rows + BM - 1) / BM;
+  const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
+  if (rt >= nrow) return;
+  const int row0 = rt * BM, n0 = ct * BN;
+  f32x16 acc[MR][2];
+#pragma unroll
+  for (int i = 0; i < MR; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // activation staging: unit u = tid + 256 h -> tile row u / 4, floats 4 (u % 4) .. + 3 of the k-step
+  int grow[NA], a_lds[NA];
+  bool a_on[NA];
+  const int kq = tid & 3;
+#pragma unroll
+  for (int h = 0; h < NA; h++) {
+    const int u = tid + 256 * h, r = u >> 2;
+    a_on[h] = (UNITS % 256 == 0) || u < UNITS;
+    grow[h] = row0 + (a_on[h] ? r : 0);
+    if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
+    if (d.row_map) grow[h] = d.row_map[grow[h]];
+    // fragment image of row tile r / 32, part p at + p * MR KiB: [k-group][row][8 bf16]
+    a_lds[h] = (r >> 5) * kB3FragBytes + (kq >> 1) * 512 + (r & 31) * 16 + (kq & 1) * 8;
+  }
+  const float *aptr[NA];
+  f32x4 av0[NA], av1[NA], av2[NA];             // three k-steps of activations in flight
+  int lim0 = 0, lim1 = 0, lim2 = 0;
+  int seg = 0, k0 = 0, nt = 0;              // (segment, k0) cursor of the next k-step to load; a segment spans its padded width
+  for (int sgi = 0; sgi < d.nsegs; sgi++) nt += ((d.segs[sgi].ncols + kGemmBK - 1) / kGemmBK) * (kGemmBK / kB3KS);
+  auto enter_segment = [&]() __attribute__((always_inline)) {
+    const GemmSegDev &sg = d.segs[seg];
+#pragma unroll
+    for (int h = 0; h < NA; h++) {
+      const long arow = sg.per_utt ? (long)row_ivec[grow[h]] : (long)grow[h] + sg.row_off;
+      aptr[h] = sg.src + arow * sg.ld + sg.col0 + kq * 4;
+    }
+  };
+  auto issue_a = [&](f32x4 (&av)[NA], int &staged_lim) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < NA; h++) {
+      av[h] = *reinterpret_cast<const f32x4 *>(aptr[h]);      // rows are 16-byte aligned (checked by the launcher)
+      aptr[h] += kB3KS;
+    }
+    const int ncols = d.segs[seg].ncols;
+    staged_lim = ncols - k0 - kq * 4;
+    k0 += kB3KS;
+    if (k0 >= (ncols + kGemmBK - 1) / kGemmBK * kGemmBK) {
+      if (seg + 1 < d.nsegs) {
+        seg++; k0 = 0; enter_segment();
+      } else {                 // past the last k-step (the pipeline requests up to three steps beyond it): stay in place
+        k0 -= kB3KS;
+#pragma unroll
+        for (int h = 0; h < NA; h++) aptr[h] -= kB3KS;
+      }
+    }
+  };
+  auto store_a = [&](int stage, const f32x4 (&av)[NA], int staged_lim) __attribute__((always_inline)) {
+    unsigned char *As = smem + stage * STAGE;
+#pragma unroll
+    for (int h = 0; h < NA; h++) {
+      if (!a_on[h]) continue;
+      const f32x4 x0 = av[h];
+      const f32x4 x = f32x4{staged_lim > 0 ? x0[0] : 0.f, staged_lim > 1 ? x0[1] : 0.f, staged_lim > 2 ? x0[2] : 0.f, staged_lim > 3 ? x0[3] : 0.f};
+      const bf16x4 p1 = __builtin_convertvector(x, bf16x4);
+      const f32x4 r1 = x - __builtin_convertvector(p1, f32x4);
+      const bf16x4 p2 = __builtin_convertvector(r1, bf16x4);
+      const f32x4 r2 = r1 - __builtin_convertvector(p2, f32x4);
+      const bf16x4 p3 = __builtin_convertvector(r2, bf16x4);
+      *reinterpret_cast<bf16x4 *>(As + a_lds[h]) = p1;
+      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + MR * kB3FragBytes) = p2;
+      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + 2 * MR * kB3FragBytes) = p3;
+    }
+  };
+  // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3) + (size_t)(n0 / 32 + wave * 2) * 3 * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
+  auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
+    wsrc += wstep;
+  };
+  // One k-step of MFMAs.  Activation fragments are transient (read, used, dropped): part 3 meets weight part 1, part 2
+  // meets parts 2 and 1, part 1 meets all three -- smallest terms first for every accumulator.
+  auto step = [&](int t, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+    const unsigned char *As = smem + (t & 1) * STAGE + lane * 16;
+#pragma unroll
+    for (int pa = 2; pa >= 0; pa--)
+#pragma unroll
+      for (int i = 0; i < MR; i++) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (pa * MR + i) * kB3FragBytes);
+#pragma unroll
+        for (int pb = 2; pb >= 0; pb--) {
+          if (pb > 2 - pa) continue;
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[j][pb], acc[i][j], 0, 0, 0);
+        }
+      }
+  };
+  // Software pipeline, everything rotating over three register sets: during k-step t the weights of step t + 2 and the
+  // activations of step t + 3 are requested, the activations of step t + 1 (requested two steps ago) are split into LDS.
+  // A lone workgroup on a CU (the last, partly filled round of a launch) then still has two full steps of latency cover.
+  // The requests run unconditionally: past the end they re-read the last activations (never stored) and two padding
+  // k-steps of W3 (never multiplied).
+  bf16x8 b0[2][3], b1[2][3], b2[2][3];
+  if (nt == 0) return;
+  enter_segment();
+  load_b(b0);
+  issue_a(av0, lim0);
+  load_b(b1);
+  issue_a(av1, lim1);
+  issue_a(av2, lim2);
+  store_a(0, av0, lim0);
+  dd::LdsBarrier();
+#define RS_B3_SUBSTEP(T, BCUR, BNEXT2, ANEXT, LNEXT, AFREE, LFREE)                       \
+  {                                                                                      \
+    load_b(BNEXT2);                                                                      \
+    store_a(((T) + 1) & 1, ANEXT, LNEXT);                                                \
+    issue_a(AFREE, LFREE);                                                               \
+    step((T), BCUR);                                                                     \
+    dd::LdsBarrier();                                                                    \
+  }
+  const int nfull = nt / 3 * 3;              // whole rotations in the loop (no exits from inside it: they made the
+#pragma nounroll                             // register allocator spill the weight sets), the remainder after it
+  for (int t = 0; t < nfull; t += 3) {
+    RS_B3_SUBSTEP(t, b0, b2, av1, lim1, av0, lim0)
+    RS_B3_SUBSTEP(t + 1, b1, b0, av2, lim2, av1, lim1)
+    RS_B3_SUBSTEP(t + 2, b2, b1, av0, lim0, av2, lim2)
+  }
+  if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
+  if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
+#undef RS_B3_SUBSTEP
+  // ---- epilogue straight from the accumulators.  C/D layout of the 32x32 MFMA: col = lane & 31,
+  // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a store instruction writes two rows x 128 consecutive bytes.
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = n0 + wave * 64 + j * 32 + (lane & 31);
+    const bool cok = col < d.n;
+    const int cc = cok ? col : 0;
+    const float bias = (d.bias && cok) ? d.bias[cc] : 0.f;
+    float sc = 1.f, of = 0.f;
+    if (epi_mode == 2) { sc = d.stages[1].scale[cc]; of = d.stages[1].offset[cc]; }
+#pragma unroll
+    for (int i = 0; i < MR; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = __fadd_rn(bias, acc[i][j][r]);
+        if (epi_mode == 1) {
+          v = v > 0.f ? v : 0.f;
+        } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
+          v = v > 0.f ? v : 0.f;
+          v = __fadd_rn(__fmul_rn(v, sc), of);
+        } else if (epi_mode == 3) {
+          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, cc);
+        }
+        if (cok && row < rows) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = v;
+      }
+    }
+  }
+}
+
+template <int MR>
+void LaunchB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+  constexpr int BM = 32 * MR;
+  constexpr size_t smem = 2 * (size_t)(MR * 3 * kB3FragBytes);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int nrow = (rows + BM - 1) / BM, ncol = (d.n + kB3BN - 1) / kB3BN;
+  const int nrow8 = (nrow + 7) / 8 * 8;
+  hipLaunchKernelGGL((GemmKernelB3<MR>), dim3(nrow8 * ncol), dim3(256), smem, s, d, rows, row_ivec, GemmEpiMode(d, rows));
+}
+
+}  // namespace
+
+bool GemmB3Usable(const GemmDev &d) {
+  const char *e = std::getenv("RS_GEMM_B3");          // read per call: the parity test flips it between two decodes
+  if ((e && std::atoi(e) == 0) || !d.W3 || d.n3 < kB3BN) return false;
+  if ((d.n3 - d.n) * 4 > d.n3) return false;            // more than a quarter of the 256-column tiles would be padding
+  for (int i = 0; i < d.nsegs; i++)
+    if ((d.segs[i].ld & 3) || (d.segs[i].col0 & 3) || (reinterpret_cast<uintptr_t>(d.segs[i].src) & 15)) return false;
+  return true;
+}
+
+void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+  static int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  // Tile height: two workgroups share a CU; rounds of 2 x CUs tiles, each as long as the tile is tall, weighted by the
+  // measured per-row efficiency of the height (taller tiles stream the weights for more rows: 0.78 at 128 rows).
+  auto cost = [&](int bm, double eff) {
+    const long tiles = (long)((rows + bm - 1) / bm) * ncol;
+    return (double)((tiles + 2 * num_cu - 1) / (2 * num_cu)) * bm * eff;
+  };
+  int mr = 2;
+  double best = cost(64, 1.0);
+  if (cost(96, 0.97) < best) { best = cost(96, 0.97); mr = 3; }
+  if (cost(128, 0.78) < best) { best = cost(128, 0.78); mr = 4; }
+  if (force_mr >= 2 && force_mr <= 4) mr = force_mr;
+  if (mr == 2) LaunchB3<2>(d, rows, row_ivec, s);
+  else if (mr == 3) LaunchB3<3>(d, rows, row_ivec, s);
+  else LaunchB3<4>(d, rows, row_ivec, s);
+}
+
+}  // namespace rs

@@ -9,26 +9,19 @@
 // "segments" (source buffer, time offset, column range) and reads the rows it needs straight from the
 // producer's output; halo rows make the row offset a constant (kernels.h).
 //
-// FP32 in / FP32 accumulate on v_mfma_f32_16x16x4_f32 (exact f32, 157 TF peak): the 1e-4 log-likelihood
-// bound of the north-star rules out bf16/fp8 operands.
+// FP32 in / FP32 accumulate on v_mfma_f32_16x16x4_f32 (exact f32, 157 TF peak).  Layers at least 192 columns wide take
+// the split-bf16 kernel instead (nnet_gemm_b3.hip: three bf16 parts per operand, six bf16 MFMAs per product, the same
+// accuracy); this file serves the narrow layers (LDA, bottlenecks) and RS_GEMM_B3=0.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 
 #include "kernels.h"
+#include "nnet_common.h"
 
 namespace rs {
 
-
-__device__ __forceinline__ float ApplyStage(const EltStageDev &st, float v, int col) {
-  switch (st.kind) {
-    case 0: return v > 0.f ? v : 0.f;                                   // ReLU
-    case 1: { float t = __fmul_rn(v, st.scale[col]); return __fadd_rn(t, st.offset[col]); }  // MulColsVec then AddVecToRows
-    case 4: return __fmul_rn(v, st.alpha);
-    default: return v;
-  }
-}
 
 // Block tile BM x BN = (16 MT WM) x (64 WN), 4 waves in a WM x WN grid, each wave a (16 MT) x 64 tile of
 // v_mfma_f32_16x16x4_f32 accumulators (16-row granularity lets the launcher pick BM so that the number of tiles
@@ -336,16 +329,6 @@ __global__ __launch_bounds__(256, 2) void GemmKernelDma(GemmDev d, int rows, con
   GemmEpilogue<MT, WM, WN>(acc, d, rows, row0, n0, epi_mode, gsm);
 }
 
-static int GemmEpiMode(const GemmDev &d, int rows) {
-  // fused-stage pattern of the epilogue: 0 none, 1 ReLU, 2 ReLU + per-column scale/offset (BatchNorm), 3 generic
-  // (non-temporal stores for the 672 MB log-likelihood matrix were tried: no measurable difference)
-  (void)rows;
-  if (d.nstages == 0) return 0;
-  if (d.nstages == 1 && d.stages[0].kind == 0) return 1;
-  if (d.nstages == 2 && d.stages[0].kind == 0 && d.stages[1].kind == 1) return 2;
-  return 3;
-}
-
 template <int MT, int WM, int WN, bool VEC>
 static void LaunchGemmV(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 16 * MT * WM, BN = 64 * WN;
@@ -387,6 +370,7 @@ static void LaunchGemmT(const GemmDev &d, int rows, const int *row_ivec, hipStre
 
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   if (rows <= 0) return;
+  if (GemmB3Usable(d)) { LaunchGemmB3(d, rows, row_ivec, s); return; }
   static int num_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

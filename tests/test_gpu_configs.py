@@ -76,8 +76,9 @@ def test_config2_arpa_hclg_256x3s(zam_arpa):
 
 
 def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
-    """Two different models resident on the GPU, their batches decoded concurrently from two host threads (what a
-    rank serving a mixed-model shard does).  Each result must equal the model's own sequential result."""
+    """Two different models resident on the GPU, their batches submitted concurrently from two host threads (what a
+    rank serving a mixed-model shard does; the library lets one decode call at a time onto the device, see
+    engine.cc:DecodeBatchDevice).  Each result must equal the model's own sequential result."""
     from rhasspy_speech_amd import _lib, synth
     from tests import cases
     m1 = _lib.Model(*zam_grammar, _lib.default_opts())
@@ -139,3 +140,24 @@ def test_config4_64_streams_30s(zam_grammar):
     tr = orc.transcribe_stream(pcms[5])
     assert batch.words(5) == tr.nbest[0].words
     assert np.abs(batch.matrix(5, 2) - tr.loglikes).max() < LOGLIKE_TOL
+
+
+def test_split_bf16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
+    """The wide layers run on the bf16 matrix cores with every FP32 operand split into three bf16 parts (nnet_gemm_b3.hip).
+    Same batch through that kernel and through the exact-FP32 MFMA kernel (RS_GEMM_B3=0): transcripts identical,
+    log-likelihoods within half the 1e-4 bound (both are checked against the reference's values in test_gpu_parity)."""
+    from rhasspy_speech_amd import _lib, synth
+    model_dir, graph_dir = zam_grammar
+    model = _lib.Model(model_dir, graph_dir, _lib.default_opts(keep_intermediates=1))
+    pcms = [synth.synth_utterance(15000 + u, 48000 - 640 * (u % 7)) for u in range(96)]
+    monkeypatch.setenv("RS_GEMM_B3", "1")
+    split = model.decode_batch(pcms)
+    monkeypatch.setenv("RS_GEMM_B3", "0")
+    exact = model.decode_batch(pcms)
+    worst = 0.0
+    for u in range(len(pcms)):
+        assert split.words(u) == exact.words(u)
+        a, b = split.matrix(u, 2), exact.matrix(u, 2)
+        worst = max(worst, float(np.abs(a - b).max()))
+        assert np.abs(split.costs(u)[1] - exact.costs(u)[1]) < 2e-3 * max(1.0, abs(exact.costs(u)[1]))
+    assert 0.0 < worst < 5e-5, worst          # > 0: the two kernels really are different code paths
