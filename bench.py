@@ -58,16 +58,16 @@ def nnet_flops_per_row(desc: str) -> float:
 
 
 def gemm_traffic_bytes(n_gemm: int):
-    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v3_pmc.json):
+    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v4_pmc.json):
     FETCH_SIZE (KB, doubled: this rocprofv3 tallies the 128-B requests of a 16 B/lane streaming read at 64 B) + WRITE_SIZE
     (KB), averaged over the launches of the nnet stage.  None when the summary is absent."""
-    path = ROOT / "profiles" / "r01" / "bench_v3_pmc.json"
+    path = ROOT / "profiles" / "r01" / "bench_v4_pmc.json"
     if not path.exists():
         return None
     ks = json.loads(path.read_text())["kernels"]
     tot, n = 0.0, 0
     for name, c in ks.items():
-        if "GemmKernel" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or "<2, 4, 1" in name or "<1, 4, 1" in name:
+        if "GemmKernel" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or "<2, 4, 1" in name or "<1, 4, 1" in name or "GemmKernelDma" in name:
             continue        # the narrow (BN = 64) instantiations are the two iVector LDA launches, not the nnet stage
         tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * c["FETCH_SIZE"]["launches"]
         n += c["FETCH_SIZE"]["launches"]

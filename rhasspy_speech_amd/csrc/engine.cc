@@ -190,19 +190,30 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     };
     auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
     const int nct = plan->n3 / 32, nks = plan->k_pad / 16;
+    // k-step order: segment after segment, or -- when every segment is a row-shifted view of the same columns of one
+    // buffer -- alternating between the segments (step t = segment t % nsegs, columns 16 (t / nsegs))
+    const int nsegs = (int)op.segs.size();
+    plan->interleave = nsegs > 1;
+    for (auto &sg : op.segs)
+      plan->interleave = plan->interleave && sg.src_buf >= 0 && sg.src_buf == op.segs[0].src_buf && sg.src_col == op.segs[0].src_col &&
+                         sg.ncols == op.segs[0].ncols;
+    std::vector<int> step_k(nks);          // first W column of k-step t
+    for (int t = 0; t < nks; t++)
+      step_k[t] = plan->interleave ? plan->seg_k0[t % nsegs] + (t / nsegs) * 16 : t * 16;
     std::vector<uint16_t> W3((size_t)(nks + 2) * nct * 3 * 512, 0);      // + 2 k-steps the kernel's pipeline requests past the end
     for (int n = 0; n < op.out_dim; n++)
-      for (int k = 0; k < plan->k_pad; k++) {
-        const float w = W[(size_t)n * plan->k_pad + k];
-        if (w == 0.0f) continue;
-        const uint16_t h1 = to_bf16(w);
-        const float r1 = w - from_bf16(h1);
-        const uint16_t h2 = to_bf16(r1);
-        const float r2 = r1 - from_bf16(h2);
-        const uint16_t h3 = to_bf16(r2);
-        const size_t base = ((size_t)(k / 16) * nct + n / 32) * 3 * 512 + (size_t)((k % 16) / 8) * 256 + (size_t)(n % 32) * 8 + k % 8;
-        W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
-      }
+      for (int t = 0; t < nks; t++)
+        for (int kk = 0; kk < 16; kk++) {
+          const float w = W[(size_t)n * plan->k_pad + step_k[t] + kk];
+          if (w == 0.0f) continue;
+          const uint16_t h1 = to_bf16(w);
+          const float r1 = w - from_bf16(h1);
+          const uint16_t h2 = to_bf16(r1);
+          const float r2 = r1 - from_bf16(h2);
+          const uint16_t h3 = to_bf16(r2);
+          const size_t base = ((size_t)t * nct + n / 32) * 3 * 512 + (size_t)(kk / 8) * 256 + (size_t)(n % 32) * 8 + kk % 8;
+          W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
+        }
     plan->d_W3 = UploadBytes(W3.data(), W3.size() * sizeof(uint16_t));
   }
   plan->d_bias = op.bias.empty() ? nullptr : Upload(op.bias);
@@ -486,6 +497,7 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (n_utts == 0) return res;
   // two concurrent groups unless the caller pinned a stream, the batch is small, or RS_SUBBATCHES=1
   const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
+  active_groups_ = ngroups;
   if (ngroups == 1) {
     DecodeGroup(d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : stream_, streaming, arena_[0],
                 host_arena_[0], res->utts.data(), res->timings);
@@ -723,7 +735,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
     }
     d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-    d.W3 = pl.d_W3; d.n3 = pl.n3;
+    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = active_groups_;
     d.nstages = (int)op.stages.size();
     for (int i = 0; i < d.nstages; i++) {
       const EltStage &st = op.stages[i];

@@ -72,6 +72,7 @@ struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   float *d_W = nullptr, *d_bias = nullptr;
   void *d_W3 = nullptr;           // split-bf16 image of W for GemmKernelB3 (layers at least 192 columns wide)
   int k_pad = 0, n_pad = 0, n3 = 0;
+  bool interleave = false;        // W3 k-steps alternate between the segments (see GemmKernelB3)
   std::vector<int> seg_k0;
   std::vector<std::pair<float *, float *>> d_stage;   // scale/offset vectors per stage
 };
@@ -122,6 +123,7 @@ class Model {
   size_t h_pcm_cap_ = 0;
   int16_t *d_pcm_ = nullptr;
   size_t d_pcm_cap_ = 0;
+  int active_groups_ = 1;          // sub-batch groups of the decode call in flight (set under mu_)
 
   MfccDev mfcc_dev_{};
   CmvnDev cmvn_iv_dev_{}, cmvn_nnet_dev_{};

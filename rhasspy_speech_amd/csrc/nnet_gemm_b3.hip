@@ -28,6 +28,7 @@
 // (slower: LDS at 80 %), a 256-row 8-wave tile that quarters the weight stream (no faster per row, and its second round
 // on 298 tiles is mostly empty), 160-row tiles (spill).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -47,18 +48,24 @@ constexpr int kB3BN = 256, kB3KS = 16;
 constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
 
 template <int MR>
-__global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, const int *__restrict__ row_ivec, int epi_mode) {
+__global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
   constexpr int BM = 32 * MR, BN = kB3BN;
   constexpr int STAGE = MR * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
   constexpr int UNITS = BM * 4, NA = (UNITS + 255) / 256;      // 16-byte activation loads per k-step and thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware tile order (see GemmKernel): all column tiles of a row tile go to one XCD back to back
-  const int ncol = (d.n + BN - 1) / BN, nrow = (rows + BM - 1) / BM;
-  const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  // Two tile heights in one launch: the first nbig row tiles are BM rows tall, the rows after them are cut into tiles of
+  // half that height (MR even), launched last.  The launcher sizes nbig to whole rounds of the chip, so that the rest --
+  // which would otherwise be one mostly empty round of tall tiles -- spreads over all CUs as short ones.
+  const int ncol = (d.n + BN - 1) / BN;
+  const int big_blocks = (nbig + 7) / 8 * 8 * ncol;
+  const bool small = (int)blockIdx.x >= big_blocks;
+  const int mr_eff = small ? MR / 2 : MR;                         // row tiles (of 32) this workgroup computes
+  const int bid = small ? blockIdx.x - big_blocks : blockIdx.x, xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
-  if (rt >= nrow) return;
-  const int row0 = rt * BM, n0 = ct * BN;
+  const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
+  if (small ? row0 >= rows : rt >= nbig) return;
   f32x16 acc[MR][2];
 #pragma unroll
   for (int i = 0; i < MR; i++)
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, cons
 #pragma unroll
   for (int h = 0; h < NA; h++) {
     const int u = tid + 256 * h, r = u >> 2;
-    a_on[h] = (UNITS % 256 == 0) || u < UNITS;
+    a_on[h] = u < mr_eff * 128;
     grow[h] = row0 + (a_on[h] ? r : 0);
     if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
     if (d.row_map) grow[h] = d.row_map[grow[h]];
@@ -94,16 +101,32 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, cons
       aptr[h] = sg.src + arow * sg.ld + sg.col0 + kq * 4;
     }
   };
+  // K order.  Default: segment after segment.  d.interleave (all segments are row-shifted views of one buffer, the TDNN
+  // Append(Offset(x, -k), x, Offset(x, k))): k-step t belongs to segment t % nsegs at columns 16 (t / nsegs), so the
+  // shifted reads of the same columns follow each other and hit in L2 instead of streaming the activations from HBM once
+  // per segment (FETCH_SIZE was 5x the algorithmic bytes); W3 is laid out in the same order by the host.
+  const bool inter = d.interleave != 0;
   auto issue_a = [&](f32x4 (&av)[NA], int &staged_lim) __attribute__((always_inline)) {
+    const long delta = inter ? (long)(d.segs[seg].row_off - d.segs[0].row_off) * d.segs[0].ld : 0;
 #pragma unroll
-    for (int h = 0; h < NA; h++) {
-      av[h] = *reinterpret_cast<const f32x4 *>(aptr[h]);      // rows are 16-byte aligned (checked by the launcher)
-      aptr[h] += kB3KS;
-    }
-    const int ncols = d.segs[seg].ncols;
+    for (int h = 0; h < NA; h++) av[h] = *reinterpret_cast<const f32x4 *>(aptr[h] + delta);      // 16-byte aligned rows (launcher)
+    const int ncols = d.segs[seg].ncols, padded = (ncols + kGemmBK - 1) / kGemmBK * kGemmBK;
     staged_lim = ncols - k0 - kq * 4;
+    if (inter) {
+      if (++seg == d.nsegs) {
+        seg = 0;
+        if (k0 + kB3KS < padded) {
+          k0 += kB3KS;
+#pragma unroll
+          for (int h = 0; h < NA; h++) aptr[h] += kB3KS;
+        }                    // else: past the last k-step, stay in place (those requests are never used)
+      }
+      return;
+    }
+#pragma unroll
+    for (int h = 0; h < NA; h++) aptr[h] += kB3KS;
     k0 += kB3KS;
-    if (k0 >= (ncols + kGemmBK - 1) / kGemmBK * kGemmBK) {
+    if (k0 >= padded) {
       if (seg + 1 < d.nsegs) {
         seg++; k0 = 0; enter_segment();
       } else {                 // past the last k-step (the pipeline requests up to three steps beyond it): stay in place
@@ -148,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, cons
     for (int pa = 2; pa >= 0; pa--)
 #pragma unroll
       for (int i = 0; i < MR; i++) {
+        if (i >= mr_eff) continue;
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (pa * MR + i) * kB3FragBytes);
 #pragma unroll
         for (int pb = 2; pb >= 0; pb--) {
@@ -202,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, cons
     if (epi_mode == 2) { sc = d.stages[1].scale[cc]; of = d.stages[1].offset[cc]; }
 #pragma unroll
     for (int i = 0; i < MR; i++) {
+      if (i >= mr_eff) continue;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, cons
 }
 
 template <int MR>
-void LaunchB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 32 * MR;
   constexpr size_t smem = 2 * (size_t)(MR * 3 * kB3FragBytes);
   static bool attr_set = false;
@@ -229,9 +254,10 @@ void LaunchB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  const int nrow = (rows + BM - 1) / BM, ncol = (d.n + kB3BN - 1) / kB3BN;
-  const int nrow8 = (nrow + 7) / 8 * 8;
-  hipLaunchKernelGGL((GemmKernelB3<MR>), dim3(nrow8 * ncol), dim3(256), smem, s, d, rows, row_ivec, GemmEpiMode(d, rows));
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = (rest + BM / 2 - 1) / (BM / 2);
+  const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
+  hipLaunchKernelGGL((GemmKernelB3<MR>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, row_ivec, GemmEpiMode(d, rows));
 }
 
 }  // namespace
@@ -252,21 +278,28 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
     return n > 0 ? n : 256;
   }();
   static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
+  static int mixed = [] { const char *e = std::getenv("RS_GEMM_B3_MIXED"); return e ? std::atoi(e) : 1; }();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
-  // Tile height: two workgroups share a CU; rounds of 2 x CUs tiles, each as long as the tile is tall, weighted by the
-  // measured per-row efficiency of the height (taller tiles stream the weights for more rows: 0.78 at 128 rows).
-  auto cost = [&](int bm, double eff) {
-    const long tiles = (long)((rows + bm - 1) / bm) * ncol;
-    return (double)((tiles + 2 * num_cu - 1) / (2 * num_cu)) * bm * eff;
-  };
-  int mr = 2;
+  const long slots = std::max(2L * num_cu / std::max(d.share, 1), 8L);      // two workgroups per CU; the device may be shared
+  // Tile height: rounds of `slots` tiles, each as long as the tile is tall, weighted by the measured per-row efficiency
+  // of the height (taller tiles stream the weights for more rows: 0.78 at 128 rows).
+  auto rounds = [&](long row_tiles) { return (double)((row_tiles * ncol + slots - 1) / slots); };
+  auto cost = [&](int bm, double eff) { return rounds((rows + bm - 1) / bm) * bm * eff; };
+  int mr = 2, nbig = (rows + 63) / 64;
   double best = cost(64, 1.0);
-  if (cost(96, 0.97) < best) { best = cost(96, 0.97); mr = 3; }
-  if (cost(128, 0.78) < best) { best = cost(128, 0.78); mr = 4; }
-  if (force_mr >= 2 && force_mr <= 4) mr = force_mr;
-  if (mr == 2) LaunchB3<2>(d, rows, row_ivec, s);
-  else if (mr == 3) LaunchB3<3>(d, rows, row_ivec, s);
-  else LaunchB3<4>(d, rows, row_ivec, s);
+  if (cost(96, 0.97) < best) { best = cost(96, 0.97); mr = 3; nbig = (rows + 95) / 96; }
+  if (cost(128, 0.78) < best) { best = cost(128, 0.78); mr = 4; nbig = (rows + 127) / 128; }
+  if (mixed) {
+    // whole rounds of 128-row tiles, the remaining rows as 64-row tiles of the same launch
+    const long full = (long)(rows / 128) * ncol / slots * slots / ncol;        // 128-row tiles in whole rounds
+    const long rest = rows - full * 128;
+    const double c = rounds(full) * 128 * 0.78 + rounds((rest + 63) / 64) * 64 * 1.0;
+    if (full > 0 && c < best) { best = c; mr = 4; nbig = (int)full; }
+  }
+  if (force_mr >= 2 && force_mr <= 4) { mr = force_mr; nbig = (rows + 32 * mr - 1) / (32 * mr); }
+  if (mr == 2) LaunchB3<2>(d, rows, nbig, row_ivec, s);
+  else if (mr == 3) LaunchB3<3>(d, rows, nbig, row_ivec, s);
+  else LaunchB3<4>(d, rows, nbig, row_ivec, s);
 }
 
 }  // namespace rs
