@@ -26,7 +26,8 @@
 // 64-128 rows (about 2.5 GB of L2 requests per hidden layer, 12 TB/s), and MFMA / weight stream / activation staging add
 // up rather than overlap across the per-step barrier.  Tried and dropped: weights through LDS with global_load_lds
 // (slower: LDS at 80 %), a 256-row 8-wave tile that quarters the weight stream (no faster per row, and its second round
-// on 298 tiles is mostly empty), 160-row tiles (spill).
+// on 298 tiles is mostly empty), 160-row tiles (spill), no LDS at all (every wave loading and splitting the activation rows
+// of its own fragments, no barrier: 256 us, the four-fold repeated loads and splits cost more than the barrier).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
