@@ -49,7 +49,10 @@ typedef struct rs_decode_opts {
   int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
   int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */
   int32_t emit_lattice;        /* 1: results keep the determinised lattice (rs_result_lattice); forces the lattice path */
-  int32_t reserved[6];
+  int32_t prune_output_pdfs;   /* 1: evaluate the output layer only for the pdfs that occur on HCLG arcs (the search can read
+                                * no others; transcripts and costs unchanged).  0 (default) computes every pdf like the
+                                * reference does.  Ignored with keep_intermediates and when the net ends in a log-softmax. */
+  int32_t reserved[5];
 } rs_decode_opts;
 
 /* Fills `opts` with the values the reference's Python passes / Kaldi defaults. */

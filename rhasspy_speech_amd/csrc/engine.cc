@@ -137,11 +137,63 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
       lda_op_.segs.push_back(sg);
     }
   }
+  PruneOutputLayer();
   for (auto &op : am_.nnet.ops) {
     if (op.kind == LayerOp::kGemm && (int)op.segs.size() > kMaxSegs) Fail("nnet3: layer " + op.name + " has too many input segments");
     if ((int)op.stages.size() > kMaxStages) Fail("nnet3: layer " + op.name + " has too many fused stages");
     if (op.kind == LayerOp::kEltwise && op.terms.size() > 8) Fail("nnet3: layer " + op.name + " sums too many terms");
   }
+}
+
+// rs_decode_opts.prune_output_pdfs: the search looks log-likelihoods up by the pdf of the arc it crosses
+// (DecodableNnetLoopedOnline::LogLikelihood, decodable-online-looped.cc:213-224), so a pdf that is on no HCLG arc is never
+// read.  Grammar graphs use a fraction of the model's pdfs (362 of 2000 for the bench grammar): the output affine is cut
+// down to those rows and the arcs' pdf ids are renumbered.  Only when the output node IS that affine (a log-softmax or
+// any other row-wise stage after it needs every pdf) and only when at least 30 % of the pdfs go.
+void Model::PruneOutputLayer() {
+  if (!opts_.prune_output_pdfs || opts_.keep_intermediates) return;
+  Nnet &n = am_.nnet;
+  if (n.ops.empty()) return;
+  LayerOp &op = n.ops.back();
+  if (op.kind != LayerOp::kGemm || op.out_buf != n.output_buf || op.out_dim != n.output_dim) return;
+  for (auto &st : op.stages)
+    if (st.kind == EltStage::kLogSoftmax || st.kind == EltStage::kNormalize) return;
+  const int P = n.output_dim;
+  std::vector<int> remap(P, -1);
+  int count = 0;
+  for (auto &a : hclg_.arcs)
+    if (a.ilabel > 0) {
+      const int pdf = am_.trans.id2pdf[a.ilabel];
+      if (pdf < 0 || pdf >= P) Fail("HCLG refers to pdf " + std::to_string(pdf) + " but the model has " + std::to_string(P));
+      if (remap[pdf] < 0) remap[pdf] = 0, count++;
+    }
+  if (count == 0 || (long)count * 10 > (long)P * 7) return;
+  count = 0;
+  for (int p = 0; p < P; p++) if (remap[p] >= 0) remap[p] = count++;
+  MatF W;
+  W.Resize(count, op.W.cols);
+  std::vector<float> bias(op.bias.empty() ? 0 : count), priors(n.priors.empty() ? 0 : count);
+  for (int p = 0; p < P; p++) {
+    if (remap[p] < 0) continue;
+    std::memcpy(&W.d[(size_t)remap[p] * W.cols], &op.W.d[(size_t)p * op.W.cols], sizeof(float) * W.cols);
+    if (!bias.empty()) bias[remap[p]] = op.bias[p];
+    if (!priors.empty()) priors[remap[p]] = n.priors[p];
+  }
+  for (auto &st : op.stages)
+    if (st.kind == EltStage::kScaleOffset) {
+      std::vector<float> sc(count), of(count);
+      for (int p = 0; p < P; p++) if (remap[p] >= 0) { sc[remap[p]] = st.scale[p]; of[remap[p]] = st.offset[p]; }
+      st.scale.swap(sc);
+      st.offset.swap(of);
+    }
+  op.W = std::move(W);
+  op.bias.swap(bias);
+  if (!priors.empty()) n.priors.swap(priors);
+  op.out_dim = count;
+  n.bufs[n.output_buf].dim = count;
+  n.output_dim = count;
+  pdf_remap_.swap(remap);
+  pruned_from_ = P;
 }
 
 Model::~Model() {
@@ -318,6 +370,7 @@ void Model::ToDevice() {
       for (uint32_t a = hclg_.arc_begin[s]; a < hclg_.arc_begin[s + 1]; a++) {
         const FstArc &fa = hclg_.arcs[a];
         int pdf1 = fa.ilabel == 0 ? 0 : am_.trans.id2pdf[fa.ilabel] + 1;
+        if (pdf1 > 0 && !pdf_remap_.empty()) pdf1 = pdf_remap_[pdf1 - 1] + 1;
         int wbits;
         std::memcpy(&wbits, &fa.weight, 4);
         arcs[a] = make_int4(pdf1, fa.olabel, wbits, fa.nextstate);
@@ -424,6 +477,7 @@ std::string Model::Describe() const {
     os << " stages=" << op.stages.size() << "\n";
   }
   os << "transition_model: tids=" << am_.trans.id2pdf.size() - 1 << " pdfs=" << am_.trans.num_pdfs << "\n";
+  if (pruned_from_) os << "output layer: pruned to the " << am_.nnet.output_dim << " of " << pruned_from_ << " pdfs that occur on HCLG arcs\n";
   os << "hclg: states=" << hclg_.num_states() << " arcs=" << hclg_.arcs.size() << " start=" << hclg_.start << "\n";
   os << "halo: L=" << L_ << " R=" << R_ << "\n";
   return os.str();

@@ -123,6 +123,9 @@ class Model {
   size_t h_pcm_cap_ = 0;
   int16_t *d_pcm_ = nullptr;
   size_t d_pcm_cap_ = 0;
+  std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)
+  int pruned_from_ = 0;            // number of pdfs before pruning (0 = not pruned)
+  void PruneOutputLayer();
   int active_groups_ = 1;          // sub-batch groups of the decode call in flight (set under mu_)
 
   MfccDev mfcc_dev_{};

@@ -161,3 +161,18 @@ def test_split_bf16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
         worst = max(worst, float(np.abs(a - b).max()))
         assert np.abs(split.costs(u)[1] - exact.costs(u)[1]) < 2e-3 * max(1.0, abs(exact.costs(u)[1]))
     assert 0.0 < worst < 5e-5, worst          # > 0: the two kernels really are different code paths
+
+
+def test_pruned_output_layer_on_a_batch(zam_grammar):
+    """prune_output_pdfs on the headline model / graph (362 of the 2000 pdfs are on HCLG arcs): a ragged batch decodes to
+    the same words and costs as with the full output layer."""
+    from rhasspy_speech_amd import _lib, synth
+    model_dir, graph_dir = zam_grammar
+    full = _lib.Model(model_dir, graph_dir, _lib.default_opts())
+    pruned = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=1))
+    assert "pruned to the" in pruned.describe()
+    pcms = [synth.synth_utterance(17000 + u, 48000 - 480 * (u % 9)) for u in range(80)]
+    a, b = full.decode_batch(pcms), pruned.decode_batch(pcms)
+    for u in range(len(pcms)):
+        assert a.words(u) == b.words(u)
+        np.testing.assert_allclose(b.costs(u), a.costs(u), rtol=2e-4, atol=2e-3)

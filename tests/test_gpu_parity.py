@@ -213,3 +213,28 @@ def test_many_streams_one_batch(case_cache):
         assert [batch.words(i, k) for k in range(batch.num_hyps(i))] == [one.words(0, k) for k in range(one.num_hyps(0))]
         assert np.array_equal(batch.matrix(i, 1), one.matrix(0, 1))
         assert np.array_equal(batch.matrix(i, 2), one.matrix(0, 2))
+
+
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_arpa_u7", "tiny_hmm_u6", "zam_u1", "tinyf_u5"])
+def test_pruned_output_layer_gives_the_same_search(case_cache, name):
+    """rs_decode_opts.prune_output_pdfs evaluates the output layer only for the pdfs on HCLG arcs: same words, same costs
+    (to GEMM rounding: the narrower layer may take another tile shape), n-best included; nets ending in a log-softmax
+    (tinyf_u5) must not be pruned."""
+    from rhasspy_speech_amd import _lib
+    model_dir, graph_dir, _, pcm = case_cache(name)
+    o = dict(cases.CASES[name].get("opts", {}))
+    full = _lib.Model(model_dir, graph_dir, _lib.default_opts(**o))
+    pruned = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=1, **o))
+    assert "pruned to the" not in full.describe()
+    if name == "tinyf_u5":
+        assert "pruned to the" not in pruned.describe()
+    elif name == "zam_u1":                # (the tiny models' graphs use most of their 48 pdfs: pruning is skipped below 30 %)
+        assert "pruned to the" in pruned.describe(), pruned.describe()
+    for nbest in (1, cases.NBEST):
+        a, b = full.decode_batch([pcm], nbest=nbest), pruned.decode_batch([pcm], nbest=nbest)
+        assert a.num_hyps(0) == b.num_hyps(0)
+        for k in range(a.num_hyps(0)):
+            assert a.words(0, k) == b.words(0, k)
+            np.testing.assert_allclose(b.costs(0, k), a.costs(0, k), rtol=2e-4, atol=2e-3)
+    ref = parse_nbest(bytes(load_golden(name)["offline_nbest_text"]))
+    assert pruned.decode_batch([pcm]).words(0) == ref[0]
