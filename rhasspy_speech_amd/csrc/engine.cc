@@ -538,10 +538,14 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   // the split-bf16 GEMM (nnet_gemm_b3.hip) in one of them the other model's features came out sporadically perturbed
   // (isolated MFCC frames, about one utterance in a thousand; profiles/micro/stress_two_models.py reproduces it, 0 in
   // 900 decodes without that kernel).  None of LDS / register poisoning, a known-answer victim kernel or draining the
-  // MFMA pipeline before s_endpgm explained it, so until it is understood models take turns on the GPU -- a batch
-  // fills the device by itself, so little throughput is lost.  Calls on ONE model were always serialised (mu_).
+  // MFMA pipeline before s_endpgm explained it.  The kernel's later revision (two tile heights, interleaved k-steps) no
+  // longer reproduces it even without this lock (0 in 1 000 decodes, RS_NO_PROCESS_LOCK=1), but the cause was never
+  // found, so models keep taking turns on the GPU -- a batch fills the device by itself, so little throughput is lost.
+  // Calls on ONE model were always serialised (mu_).
   static std::mutex process_mu;
-  std::lock_guard<std::mutex> process_lk(process_mu);
+  static const bool no_lock = std::getenv("RS_NO_PROCESS_LOCK") != nullptr;      // debugging the issue above
+  std::unique_lock<std::mutex> process_lk(process_mu, std::defer_lock);
+  if (!no_lock) process_lk.lock();
   std::lock_guard<std::mutex> lk(mu_);
   RS_HIP(hipSetDevice(opts_.device_id));
   if (nbest < 1) Fail("nbest must be >= 1");
