@@ -215,41 +215,71 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
-  // ---- epilogue straight from the accumulators.  C/D layout of the 32x32 MFMA: col = lane & 31,
-  // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a store instruction writes two rows x 128 consecutive bytes.
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Bias
+  // and the fused stages are applied in registers; each 32-row slab of the tile is then transposed through LDS (free
+  // after the loop; pitch 264 floats keeps both halves of a wave on different banks) and leaves as 16-byte row-contiguous
+  // stores, 1 KiB per row and wave instruction -- storing straight from the accumulators (two rows x 128 bytes per
+  // instruction) cost 40 us of a 200 us hidden layer.
+  constexpr int C_LD = BN + 8;
+  float *Cs = reinterpret_cast<float *>(smem);
+  const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
+  float bias[2], sc[2], of[2];
+  int ccol[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int col = n0 + wave * 64 + j * 32 + (lane & 31);
     const bool cok = col < d.n;
-    const int cc = cok ? col : 0;
-    const float bias = (d.bias && cok) ? d.bias[cc] : 0.f;
-    float sc = 1.f, of = 0.f;
-    if (epi_mode == 2) { sc = d.stages[1].scale[cc]; of = d.stages[1].offset[cc]; }
+    ccol[j] = cok ? col : 0;
+    bias[j] = (d.bias && cok) ? d.bias[ccol[j]] : 0.f;
+    sc[j] = 1.f; of[j] = 0.f;
+    if (epi_mode == 2) { sc[j] = d.stages[1].scale[ccol[j]]; of[j] = d.stages[1].offset[ccol[j]]; }
+  }
 #pragma unroll
-    for (int i = 0; i < MR; i++) {
-      if (i >= mr_eff) continue;
+  for (int i = 0; i < MR; i++) {
+    if (i >= mr_eff) break;                       // workgroup-uniform
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int cl = wave * 64 + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = __fadd_rn(bias, acc[i][j][r]);
+        float v = __fadd_rn(bias[j], acc[i][j][r]);
         if (epi_mode == 1) {
           v = v > 0.f ? v : 0.f;
         } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
           v = v > 0.f ? v : 0.f;
-          v = __fadd_rn(__fmul_rn(v, sc), of);
+          v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);
         } else if (epi_mode == 3) {
-          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, cc);
+          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);
         }
-        if (cok && row < rows) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = v;
+        Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;
       }
     }
+    dd::LdsBarrier();
+    if (vec_out) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int unit = tid + 256 * q, rl = unit >> 6, c4 = (unit & 63) * 4;
+        const int row = row0 + i * 32 + rl, col = n0 + c4;
+        if (row < rows && col < d.n)
+          *reinterpret_cast<f32x4 *>(d.out + (size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col) =
+              *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+      }
+    } else {
+      for (int idx = tid; idx < 32 * BN; idx += 256) {
+        const int rl = idx / BN, cl = idx % BN;
+        const int row = row0 + i * 32 + rl, col = n0 + cl;
+        if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl];
+      }
+    }
+    dd::LdsBarrier();
   }
 }
 
 template <int MR>
 void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 32 * MR;
-  constexpr size_t smem = 2 * (size_t)(MR * 3 * kB3FragBytes);
+  constexpr size_t stage = 2 * (size_t)(MR * 3 * kB3FragBytes), ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t smem = stage > ctile ? stage : ctile;          // the epilogue stages 32-row slabs of the output tile
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
