@@ -48,7 +48,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kB3BN = 256, kB3KS = 16;
 constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
 
-template <int MR>
+template <int MR, bool MIXED>
 __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
   constexpr int BM = 32 * MR, BN = kB3BN;
   constexpr int STAGE = MR * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   // which would otherwise be one mostly empty round of tall tiles -- spreads over all CUs as short ones.
   const int ncol = (d.n + BN - 1) / BN;
   const int big_blocks = (nbig + 7) / 8 * 8 * ncol;
-  const bool small = (int)blockIdx.x >= big_blocks;
+  const bool small = MIXED && (int)blockIdx.x >= big_blocks;
   const int mr_eff = small ? MR / 2 : MR;                         // row tiles (of 32) this workgroup computes
   const int bid = small ? blockIdx.x - big_blocks : blockIdx.x, xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   int lim0 = 0, lim1 = 0, lim2 = 0;
   int seg = 0, k0 = 0, nt = 0;              // (segment, k0) cursor of the next k-step to load; a segment spans its padded width
   for (int sgi = 0; sgi < d.nsegs; sgi++) nt += ((d.segs[sgi].ncols + kGemmBK - 1) / kGemmBK) * (kGemmBK / kB3KS);
+  // per-segment scalars live in the lanes of two VGPRs (lane s = segment s) and are fetched with v_readlane: reading them
+  // from the kernel arguments inside the loop cost two or three s_load + s_waitcnt lgkmcnt(0) round trips per k-step, and
+  // that wait also drains the LDS queue
+  const int seg_ncols_v = lane < d.nsegs ? d.segs[lane < kMaxSegs ? lane : 0].ncols : 0;
+  const int seg_rowoff_v = lane < d.nsegs ? d.segs[lane < kMaxSegs ? lane : 0].row_off : 0;
+  const int nsegs = d.nsegs, ld0 = d.segs[0].ld, rowoff0 = d.segs[0].row_off;
   auto enter_segment = [&]() __attribute__((always_inline)) {
     const GemmSegDev &sg = d.segs[seg];
 #pragma unroll
@@ -108,13 +114,13 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   // per segment (FETCH_SIZE was 5x the algorithmic bytes); W3 is laid out in the same order by the host.
   const bool inter = d.interleave != 0;
   auto issue_a = [&](f32x4 (&av)[NA], int &staged_lim) __attribute__((always_inline)) {
-    const long delta = inter ? (long)(d.segs[seg].row_off - d.segs[0].row_off) * d.segs[0].ld : 0;
+    const long delta = inter ? (long)(__builtin_amdgcn_readlane(seg_rowoff_v, seg) - rowoff0) * ld0 : 0;
 #pragma unroll
     for (int h = 0; h < NA; h++) av[h] = *reinterpret_cast<const f32x4 *>(aptr[h] + delta);      // 16-byte aligned rows (launcher)
-    const int ncols = d.segs[seg].ncols, padded = (ncols + kGemmBK - 1) / kGemmBK * kGemmBK;
+    const int ncols = __builtin_amdgcn_readlane(seg_ncols_v, seg), padded = (ncols + kGemmBK - 1) / kGemmBK * kGemmBK;
     staged_lim = ncols - k0 - kq * 4;
     if (inter) {
-      if (++seg == d.nsegs) {
+      if (++seg == nsegs) {
         seg = 0;
         if (k0 + kB3KS < padded) {
           k0 += kB3KS;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
     for (int h = 0; h < NA; h++) aptr[h] += kB3KS;
     k0 += kB3KS;
     if (k0 >= padded) {
-      if (seg + 1 < d.nsegs) {
+      if (seg + 1 < nsegs) {
         seg++; k0 = 0; enter_segment();
       } else {                 // past the last k-step (the pipeline requests up to three steps beyond it): stay in place
         k0 -= kB3KS;
@@ -168,19 +174,25 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   // meets parts 2 and 1, part 1 meets all three -- smallest terms first for every accumulator.
   auto step = [&](int t, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
     const unsigned char *As = smem + (t & 1) * STAGE + lane * 16;
+    // fragment reads run one fragment ahead of the MFMAs that use them
+    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(As + (2 * MR) * kB3FragBytes), nxt = cur;
 #pragma unroll
-    for (int pa = 2; pa >= 0; pa--)
-#pragma unroll
-      for (int i = 0; i < MR; i++) {
-        if (i >= mr_eff) continue;
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (pa * MR + i) * kB3FragBytes);
+    for (int idx = 0; idx < 3 * MR; idx++) {
+      const int pa = 2 - idx / MR, i = idx % MR;
+      if (idx + 1 < 3 * MR) {
+        const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
+        nxt = *reinterpret_cast<const bf16x8 *>(As + (pa2 * MR + i2) * kB3FragBytes);
+      }
+      if (!MIXED || i < mr_eff) {
 #pragma unroll
         for (int pb = 2; pb >= 0; pb--) {
           if (pb > 2 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[j][pb], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, bf[j][pb], acc[i][j], 0, 0, 0);
         }
       }
+      cur = nxt;
+    }
   };
   // Software pipeline, everything rotating over three register sets: during k-step t the weights of step t + 2 and the
   // activations of step t + 3 are requested, the activations of step t + 1 (requested two steps ago) are split into LDS.
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   }
 #pragma unroll
   for (int i = 0; i < MR; i++) {
-    if (i >= mr_eff) break;                       // workgroup-uniform
+    if (MIXED && i >= mr_eff) break;              // workgroup-uniform
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int cl = wave * 64 + j * 32 + (lane & 31);
@@ -275,20 +287,20 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   }
 }
 
-template <int MR>
+template <int MR, bool MIXED>
 void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 32 * MR;
   constexpr size_t stage = 2 * (size_t)(MR * 3 * kB3FragBytes), ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
   constexpr size_t smem = stage > ctile ? stage : ctile;          // the epilogue stages 32-row slabs of the output tile
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const int rest = std::max(rows - nbig * BM, 0), nsmall = (rest + BM / 2 - 1) / (BM / 2);
   const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3<MR>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, row_ivec, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3<MR, MIXED>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, row_ivec, GemmEpiMode(d, rows));
 }
 
 }  // namespace
@@ -328,9 +340,10 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
     if (full > 0 && c < best) { best = c; mr = 4; nbig = (int)full; }
   }
   if (force_mr >= 2 && force_mr <= 4) { mr = force_mr; nbig = (rows + 32 * mr - 1) / (32 * mr); }
-  if (mr == 2) LaunchB3<2>(d, rows, nbig, row_ivec, s);
-  else if (mr == 3) LaunchB3<3>(d, rows, nbig, row_ivec, s);
-  else LaunchB3<4>(d, rows, nbig, row_ivec, s);
+  if (mr == 2) LaunchB3<2, false>(d, rows, nbig, row_ivec, s);
+  else if (mr == 3) LaunchB3<3, false>(d, rows, nbig, row_ivec, s);
+  else if ((long)nbig * 128 >= rows) LaunchB3<4, false>(d, rows, nbig, row_ivec, s);
+  else LaunchB3<4, true>(d, rows, nbig, row_ivec, s);
 }
 
 }  // namespace rs
