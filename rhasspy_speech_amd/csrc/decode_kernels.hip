@@ -257,6 +257,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       for (int c0 = 0; c0 < n_cur; c0 += kPrefixCap) {         // token chunks whose degree prefix fits LDS
         const int nc = n_cur - c0 < kPrefixCap ? n_cur - c0 : kPrefixCap;
         const int4 *ctok = cur + c0;
+        if (c0 > 0) __syncthreads();      // the previous chunk's arc loop still reads c.pre (binary search) in other threads
         // degrees (0 for tokens beyond the cutoff), contiguous segment per thread
         const int seg = (nc + NT - 1) / NT;
         const int i0 = tid * seg < nc ? tid * seg : nc, i1 = i0 + seg < nc ? i0 + seg : nc;

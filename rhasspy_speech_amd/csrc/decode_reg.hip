@@ -150,7 +150,12 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       int c_le = 0, c_lt = 0;
       const bool need_counts = N > o.max_active || N > o.min_active;      // wave-uniform
       float hist_hi = closure_cutoff;
-      if (need_counts) {
+      // Every live token passed `cost < closure_cutoff` when the previous frame was committed.  When that cutoff is not
+      // above this frame's beam cutoff (the usual case: best + beam on both sides), all N tokens are inside the beam and
+      // the counting pass, its barrier and the histogram are skipped; they are still needed when max-active can bind.
+      const bool need_pass = need_counts && (!(closure_cutoff <= beam_cutoff) || N > o.max_active);
+      if (need_counts && !need_pass) { c_le = N; c_lt = N; }
+      if (need_pass) {
         if (!(hist_hi < INF)) {
           float mx = -INF;
           for (int s = tid; s < S; s += NT) { const float c = cost_cur[s]; mx = c < INF ? fmaxf(mx, c) : mx; }
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       else if (N > o.min_active && !(o.min_active == 0 || c_le > o.min_active)) kth = o.min_active;
       float kth_cost = 0.f;
       int kth_le = 0;              // tokens at or below it
-      if (need_counts) {
+      if (need_pass) {
         if (kth >= 0) kth_cost = KthFromHist<NT>(red, cost_cur, S, kth, best_cost, hist_hi, &kth_le);
         else for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // next use is at least one barrier away
       }
