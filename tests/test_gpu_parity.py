@@ -238,3 +238,27 @@ def test_pruned_output_layer_gives_the_same_search(case_cache, name):
             np.testing.assert_allclose(b.costs(0, k), a.costs(0, k), rtol=2e-4, atol=2e-3)
     ref = parse_nbest(bytes(load_golden(name)["offline_nbest_text"]))
     assert pruned.decode_batch([pcm]).words(0) == ref[0]
+
+
+@pytest.mark.parametrize("dims", [dict(hidden_dim=200, prefinal_dim=216, num_phones=100),       # n = 200/216/200: 256-column tile, padded
+                                  dict(hidden_dim=328, prefinal_dim=250, num_phones=260),       # n = 328 (fp32 path), 520 pdfs (3 tiles)
+                                  dict(hidden_dim=250, prefinal_dim=250, num_phones=1000, ivector_dim=0)])
+def test_split_bf16_gemm_odd_shapes_match_oracle(tmp_path, dims):
+    """Layer shapes around the split-bf16 kernel's tile edges (output widths that leave padding in the 256-column tile,
+    segment widths that are not multiples of the 16-wide k-step, a net without iVector input): log-likelihoods against the
+    CPU oracle on a ragged batch, which also runs tiles with fewer than 64 live rows."""
+    from oracle import pipeline
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.ModelSpec(**dims)
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    assert "gemm" in model.describe()
+    orc = pipeline.Oracle(tmp_path / "model", tmp_path / "graph")
+    pcms = [synth.synth_utterance(300 + i, n) for i, n in enumerate([20000, 9000, 16000])]
+    res = model.decode_batch(pcms)
+    for i, p in enumerate(pcms):
+        tr = orc.transcribe(p)
+        diff = np.abs(res.matrix(i, 2) - tr.loglikes).max()
+        assert diff < LOGLIKE_TOL, (dims, i, diff)
+        assert res.words(i) == tr.nbest[0].words
