@@ -198,12 +198,14 @@ void Model::PruneOutputLayer() {
 
 Model::~Model() {
   for (void *p : owned_) (void)hipFree(p);
-  if (h_pcm_pinned_) (void)hipHostFree(h_pcm_pinned_);
-  if (d_pcm_) (void)hipFree(d_pcm_);
-  if (stream_) (void)hipStreamDestroy(stream_);
-  if (stream2_) (void)hipStreamDestroy(stream2_);
-  if (stream_dec_) (void)hipStreamDestroy(stream_dec_);
-  for (auto &e : slab_ev_) if (e) (void)hipEventDestroy(e);
+  for (auto &c : ctx_) {
+    if (c->h_pcm_pinned) (void)hipHostFree(c->h_pcm_pinned);
+    if (c->d_pcm) (void)hipFree(c->d_pcm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream_dec) (void)hipStreamDestroy(c->stream_dec);
+    for (auto &e : c->slab_ev) if (e) (void)hipEventDestroy(e);
+  }
 }
 
 void *Model::UploadBytes(const void *p, size_t bytes) {
@@ -291,15 +293,21 @@ void Model::ToDevice() {
   RS_HIP(hipGetDeviceProperties(&prop, opts_.device_id));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw DeviceError(std::string("this library is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
-  RS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  RS_HIP(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   {
+    const char *e = std::getenv("RS_CONTEXTS");
+    const int n = std::min(std::max(e ? std::atoi(e) : 1, 1), 8);      // see the note at ProcessTurn: one pipeline at a time by default
     // the search of a slab is latency-bound and must not queue behind the thousands of GEMM workgroups of the next slab
     int prio_low = 0, prio_high = 0;
     RS_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-    RS_HIP(hipStreamCreateWithPriority(&stream_dec_, hipStreamNonBlocking, prio_high));
+    for (int i = 0; i < n; i++) {
+      std::unique_ptr<DecodeContext> c(new DecodeContext());
+      RS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      RS_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      RS_HIP(hipStreamCreateWithPriority(&c->stream_dec, hipStreamNonBlocking, prio_high));
+      for (auto &ev : c->slab_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx_.push_back(std::move(c));
+    }
   }
-  for (auto &e : slab_ev_) RS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // ---- MFCC tables
   const MfccTables &t = fc_.mfcc;
   mfcc_dev_.win = t.win; mfcc_dev_.shift = t.shift; mfcc_dev_.padded = t.padded; mfcc_dev_.nbins = t.nbins; mfcc_dev_.nceps = t.nceps;
@@ -497,6 +505,50 @@ struct Timer {
 };
 }  // namespace
 
+// One decode pipeline at a time per process, by default (RS_CONTEXTS=1, and calls on different models take turns).
+//
+// Several pipelines on the device at once are faster -- with four decode contexts and four calls in flight the headline
+// batch takes 3.6 ms instead of 4.2, because the latency-bound search of one batch leaves the CUs to the GEMMs of the next
+// (RS_CONTEXTS=4, bench.py --inflight 4) -- but they are not yet safe: while another pipeline is in its result / start-of-
+// call phase, two back-to-back runs of the MFCC kernel on the same inputs can disagree in a few frames.  What is known
+// (profiles/micro/stress_same_model.py, stress_two_models.py reproduce it in seconds; 0 differences in 25 600 results
+// with one pipeline): identical inputs and identical FFT output, but the power spectrum read back from LDS differs from
+// its recomputation in groups of exactly 16 lanes; it needs three or more hardware queues busy (GPU_MAX_HW_QUEUES=1: never,
+// 2: rarely); it is independent of LDS / register poisoning, of kernel-argument placement, of the number of waves per
+// workgroup, of stream priorities, of the copy engine used for the result copies, and a known-answer kernel running beside
+// the pipelines is never disturbed.  Until the cause is found the library does not overlap pipelines unless asked to.
+namespace {
+class ProcessTurn {
+ public:
+  explicit ProcessTurn(const void *model) {
+    static const bool off = std::getenv("RS_NO_PROCESS_LOCK") != nullptr;
+    if (off) return;
+    std::unique_lock<std::mutex> lk(Mu());
+    bool counted = false;      // a model waiting for its turn stops the owner's further calls from overlapping (no starvation)
+    while (!(Owner() == nullptr || (Owner() == model && Waiters() == 0))) {
+      if (!counted && Owner() != model) { Waiters()++; counted = true; }
+      Cv().wait(lk);
+    }
+    if (counted) Waiters()--;
+    Owner() = model;
+    Depth()++;
+    held_ = true;
+  }
+  ~ProcessTurn() {
+    if (!held_) return;
+    { std::lock_guard<std::mutex> lk(Mu()); if (--Depth() == 0) Owner() = nullptr; }
+    Cv().notify_all();
+  }
+ private:
+  static std::mutex &Mu() { static std::mutex m; return m; }
+  static std::condition_variable &Cv() { static std::condition_variable c; return c; }
+  static const void *&Owner() { static const void *o = nullptr; return o; }
+  static int &Depth() { static int d = 0; return d; }
+  static int &Waiters() { static int w = 0; return w; }
+  bool held_ = false;
+};
+}  // namespace
+
 std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
                                                float lat_scale, bool streaming) {
   ToDevice();
@@ -505,48 +557,67 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
     if (n_samples[i] < 0 || (n_samples[i] > 0 && pcm[i] == nullptr)) Fail("rs_decode_batch: bad sample buffer for utterance " + std::to_string(i));
     off[i + 1] = off[i] + n_samples[i];
   }
+  ProcessTurn turn(this);
+  DecodeContext *cx = AcquireContext();
   std::unique_ptr<Result> res;
-  float h2d_ms = 0;
-  {
-    std::lock_guard<std::mutex> lk(mu_);
+  try {
     RS_HIP(hipSetDevice(opts_.device_id));
     size_t total = (size_t)off[n_utts] + 512;
-    if (total > h_pcm_cap_) {
-      if (h_pcm_pinned_) RS_HIP(hipHostFree(h_pcm_pinned_));
-      if (d_pcm_) RS_HIP(hipFree(d_pcm_));
-      h_pcm_cap_ = total + total / 4;
-      RS_HIP(hipHostMalloc((void **)&h_pcm_pinned_, h_pcm_cap_ * sizeof(int16_t), hipHostMallocDefault));
-      RS_HIP(hipMalloc((void **)&d_pcm_, h_pcm_cap_ * sizeof(int16_t)));
+    if (total > cx->h_pcm_cap) {
+      if (cx->h_pcm_pinned) RS_HIP(hipHostFree(cx->h_pcm_pinned));
+      if (cx->d_pcm) RS_HIP(hipFree(cx->d_pcm));
+      cx->h_pcm_pinned = nullptr; cx->d_pcm = nullptr;
+      cx->h_pcm_cap = total + total / 4;
+      RS_HIP(hipHostMalloc((void **)&cx->h_pcm_pinned, cx->h_pcm_cap * sizeof(int16_t), hipHostMallocDefault));
+      RS_HIP(hipMalloc((void **)&cx->d_pcm, cx->h_pcm_cap * sizeof(int16_t)));
     }
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < n_utts; i++)
-      if (n_samples[i]) std::memcpy(h_pcm_pinned_ + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
-    RS_HIP(hipMemcpyAsync(d_pcm_, h_pcm_pinned_, sizeof(int16_t) * (size_t)off[n_utts], hipMemcpyHostToDevice, stream_));
-    RS_HIP(hipStreamSynchronize(stream_));
-    h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (n_samples[i]) std::memcpy(cx->h_pcm_pinned + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
+    RS_HIP(hipMemcpyAsync(cx->d_pcm, cx->h_pcm_pinned, sizeof(int16_t) * (size_t)off[n_utts], hipMemcpyHostToDevice, cx->stream));
+    RS_HIP(hipStreamSynchronize(cx->stream));
+    const float h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    res = DecodeInContext(*cx, cx->d_pcm, off.data(), n_utts, nbest, lat_scale, nullptr, streaming);
+    res->timings[0] = h2d_ms;
+    res->timings[6] += h2d_ms;
+  } catch (...) {
+    ReleaseContext(cx);
+    throw;
   }
-  res = DecodeBatchDevice(d_pcm_, off.data(), n_utts, nbest, lat_scale, nullptr, streaming);
-  res->timings[0] = h2d_ms;
-  res->timings[6] += h2d_ms;
+  ReleaseContext(cx);
   return res;
 }
 
 std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
                                                  float lat_scale, hipStream_t user_stream, bool streaming) {
   ToDevice();
-  // One decode call at a time per PROCESS, not just per model.  Calls on different models used to run side by side; with
-  // the split-bf16 GEMM (nnet_gemm_b3.hip) in one of them the other model's features came out sporadically perturbed
-  // (isolated MFCC frames, about one utterance in a thousand; profiles/micro/stress_two_models.py reproduces it, 0 in
-  // 900 decodes without that kernel).  None of LDS / register poisoning, a known-answer victim kernel or draining the
-  // MFMA pipeline before s_endpgm explained it.  The kernel's later revision (two tile heights, interleaved k-steps) no
-  // longer reproduces it even without this lock (0 in 1 000 decodes, RS_NO_PROCESS_LOCK=1), but the cause was never
-  // found, so models keep taking turns on the GPU -- a batch fills the device by itself, so little throughput is lost.
-  // Calls on ONE model were always serialised (mu_).
-  static std::mutex process_mu;
-  static const bool no_lock = std::getenv("RS_NO_PROCESS_LOCK") != nullptr;      // debugging the issue above
-  std::unique_lock<std::mutex> process_lk(process_mu, std::defer_lock);
-  if (!no_lock) process_lk.lock();
-  std::lock_guard<std::mutex> lk(mu_);
+  ProcessTurn turn(this);
+  DecodeContext *cx = AcquireContext();
+  std::unique_ptr<Result> res;
+  try {
+    res = DecodeInContext(*cx, d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream, streaming);
+  } catch (...) {
+    ReleaseContext(cx);
+    throw;
+  }
+  ReleaseContext(cx);
+  return res;
+}
+
+Model::DecodeContext *Model::AcquireContext() {
+  std::unique_lock<std::mutex> lk(ctx_mu_);
+  for (;;) {
+    for (auto &c : ctx_) if (!c->busy) { c->busy = true; return c.get(); }
+    ctx_cv_.wait(lk);
+  }
+}
+void Model::ReleaseContext(DecodeContext *cx) {
+  { std::lock_guard<std::mutex> lk(ctx_mu_); cx->busy = false; }
+  ctx_cv_.notify_one();
+}
+
+std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
+                                               float lat_scale, hipStream_t user_stream, bool streaming) {
   RS_HIP(hipSetDevice(opts_.device_id));
   if (nbest < 1) Fail("nbest must be >= 1");
   auto wall0 = std::chrono::steady_clock::now();
@@ -555,10 +626,10 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   if (n_utts == 0) return res;
   // two concurrent groups unless the caller pinned a stream, the batch is small, or RS_SUBBATCHES=1
   const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
-  active_groups_ = ngroups;
+  cx.active_groups = ngroups;
   if (ngroups == 1) {
-    DecodeGroup(d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : stream_, streaming, arena_[0],
-                host_arena_[0], res->utts.data(), res->timings);
+    DecodeGroup(cx, 0, d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : cx.stream, streaming,
+                res->utts.data(), res->timings);
   } else {
     const int half = (n_utts + 1) / 2;
     float t2[2][8] = {{0}, {0}};
@@ -566,8 +637,8 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
     auto run = [&](int gi) {
       try {
         const int u0 = gi == 0 ? 0 : half, n = gi == 0 ? half : n_utts - half;
-        DecodeGroup(d_pcm, sample_offsets + u0, n, nbest, lat_scale, gi == 0 ? stream_ : stream2_, streaming, arena_[gi],
-                    host_arena_[gi], res->utts.data() + u0, t2[gi]);
+        DecodeGroup(cx, gi, d_pcm, sample_offsets + u0, n, nbest, lat_scale, gi == 0 ? cx.stream : cx.stream2, streaming,
+                    res->utts.data() + u0, t2[gi]);
       } catch (...) {
         err[gi] = std::current_exception();
       }
@@ -585,8 +656,10 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
 // One group of utterances, start to finish, on one stream with one arena.  DecodeBatchDevice runs two groups
 // concurrently (two host threads, two streams) so that the latency-bound stages of one group (search, iVector)
 // overlap the MFMA-bound stage (TDNN) of the other.
-void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
-                        hipStream_t s, bool streaming, DeviceArena &arena_, HostArena &harena, UttResult *out_utts, float *timings) {
+void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
+                        hipStream_t s, bool streaming, UttResult *out_utts, float *timings) {
+  DeviceArena &arena_ = cx.arena[gi];
+  HostArena &harena = cx.host_arena[gi];
   RS_HIP(hipSetDevice(opts_.device_id));
   auto wall0 = std::chrono::steady_clock::now();
   if (n_utts == 0) return;
@@ -739,7 +812,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
                             nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
   const bool pipelined = use_reg && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
-                         s == stream_;
+                         s == cx.stream;
   const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
   std::vector<int> slab_off(n_slabs + 1, 0);
   int *d_frame_rows = nullptr;
@@ -793,7 +866,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
       o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
     }
     d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = active_groups_;
+    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups;
     d.nstages = (int)op.stages.size();
     for (int i = 0; i < d.nstages; i++) {
       const EltStage &st = op.stages[i];
@@ -911,12 +984,12 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
         for (int k = 0; k < n_slabs; k++) {
           gd.row_map = d_frame_rows + slab_off[k];
           LaunchGemm(gd, slab_off[k + 1] - slab_off[k], d_row_ivec, s);
-          RS_HIP(hipEventRecord(slab_ev_[k], s));
-          RS_HIP(hipStreamWaitEvent(stream_dec_, slab_ev_[k], 0));
+          RS_HIP(hipEventRecord(cx.slab_ev[k], s));
+          RS_HIP(hipStreamWaitEvent(cx.stream_dec, cx.slab_ev[k], 0));
           LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, bufp[nn.output_buf], buf_ld[nn.output_buf], dw, k == 0 ? -1 : k * slab_len,
-                          k + 1 == n_slabs ? maxT + 1 : (k + 1) * slab_len, stream_dec_);
+                          k + 1 == n_slabs ? maxT + 1 : (k + 1) * slab_len, cx.stream_dec);
         }
-        RS_HIP(hipEventRecord(slab_ev_[8], stream_dec_));
+        RS_HIP(hipEventRecord(cx.slab_ev[8], cx.stream_dec));
       } else if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
         gd.row_map = d_frame_rows;
         poison();
@@ -960,7 +1033,7 @@ void Model::DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int
   tm.Mark();
   // ---- decode
   if (pipelined) {
-    RS_HIP(hipStreamWaitEvent(s, slab_ev_[8], 0));       // the search of the last slab
+    RS_HIP(hipStreamWaitEvent(s, cx.slab_ev[8], 0));       // the search of the last slab
   } else if (use_dense) {
     poison();
     if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, -1, maxT + 1, s);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -95,8 +96,9 @@ class Model {
   const Hclg &hclg() const { return hclg_; }
 
  private:
-  void DecodeGroup(const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
-                   hipStream_t s, bool streaming, DeviceArena &arena, HostArena &harena, UttResult *out_utts, float *timings);
+  struct DecodeContext;
+  void DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
+                   hipStream_t s, bool streaming, UttResult *out_utts, float *timings);
   template <typename T> T *Upload(const std::vector<T> &v);
   void *UploadBytes(const void *p, size_t bytes);
   void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
@@ -108,25 +110,33 @@ class Model {
   std::vector<int32_t> arc_ilabel_;   // original transition-ids (device arcs carry pdf+1)
 
   bool on_device_ = false;
-  std::mutex mu_;
-  hipStream_t stream_ = nullptr;
-  hipStream_t stream_dec_ = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on stream_
-  hipEvent_t slab_ev_[9] = {};
+  std::mutex mu_;                      // ToDevice
   std::vector<void *> owned_;         // persistent device allocations
-  DeviceArena arena_[2];               // one per concurrent utterance group
-  HostArena host_arena_[2];
-  hipStream_t stream2_ = nullptr;
-  int max_groups_ = 1;                 // RS_SUBBATCHES=2: two concurrent utterance groups (measured: no gain on MI355X, the
-                                       // latency-bound kernels take CU resources from the GEMMs)
-  // pinned staging for host-buffer batches
-  int16_t *h_pcm_pinned_ = nullptr;
-  size_t h_pcm_cap_ = 0;
-  int16_t *d_pcm_ = nullptr;
-  size_t d_pcm_cap_ = 0;
+  int max_groups_ = 1;                 // RS_SUBBATCHES=2: two concurrent utterance groups inside one call
+  // Everything one decode call needs for itself.  A model owns a few of them so that calls from different host threads can
+  // be in flight together: the search of one batch is latency-bound and leaves the device to the next batch's GEMMs.
+  struct DecodeContext {
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipStream_t stream_dec = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on `stream`
+    hipEvent_t slab_ev[9] = {};
+    DeviceArena arena[2];                  // one per concurrent utterance group
+    HostArena host_arena[2];
+    int16_t *h_pcm_pinned = nullptr;       // pinned staging for host-buffer batches
+    size_t h_pcm_cap = 0;
+    int16_t *d_pcm = nullptr;
+    int active_groups = 1;
+    bool busy = false;
+  };
+  std::vector<std::unique_ptr<DecodeContext>> ctx_;
+  std::mutex ctx_mu_;
+  std::condition_variable ctx_cv_;
+  DecodeContext *AcquireContext();
+  void ReleaseContext(DecodeContext *cx);
+  std::unique_ptr<Result> DecodeInContext(DecodeContext &cx, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
+                                          float lat_scale, hipStream_t user_stream, bool streaming);
   std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)
   int pruned_from_ = 0;            // number of pdfs before pruning (0 = not pruned)
   void PruneOutputLayer();
-  int active_groups_ = 1;          // sub-batch groups of the decode call in flight (set under mu_)
 
   MfccDev mfcc_dev_{};
   CmvnDev cmvn_iv_dev_{}, cmvn_nnet_dev_{};

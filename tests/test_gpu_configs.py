@@ -176,3 +176,28 @@ def test_pruned_output_layer_on_a_batch(zam_grammar):
     for u in range(len(pcms)):
         assert a.words(u) == b.words(u)
         np.testing.assert_allclose(b.costs(u), a.costs(u), rtol=2e-4, atol=2e-3)
+
+
+def test_concurrent_calls_on_one_model(zam_grammar):
+    """Several host threads decoding different batches on ONE model at the same time (each call gets its own decode
+    context: streams, arenas, staging): every result equals the sequential one."""
+    from rhasspy_speech_amd import _lib, synth
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    batches = [[synth.synth_utterance(21000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(40 + 24 * b)] for b in range(4)]
+    ref = [model.decode_batch(pcms) for pcms in batches]
+    out = [[] for _ in batches]
+
+    def run(b):
+        for _ in range(4):
+            out[b].append(model.decode_batch(batches[b]))
+
+    ts = [threading.Thread(target=run, args=(b,)) for b in range(len(batches))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for b, pcms in enumerate(batches):
+        assert len(out[b]) == 4
+        for res in out[b]:
+            for u in range(len(pcms)):
+                _same_result(res, u, ref[b], u)
