@@ -13,11 +13,16 @@ subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o
 burner = ctypes.CDLL(str(so))
 name = sys.argv[1] if len(sys.argv) > 1 else "tinyf_u5"
 with tempfile.TemporaryDirectory() as td:
-    md, gd, _, _ = cases.build_case_files(cases.CASES[name], Path(td))
+    if name == "zam":
+        spec = synth.ModelSpec(); md, gd = Path(td) / "m", Path(td) / "g"
+        synth.write_model_dir(md, spec); synth.make_grammar_graph(gd, spec)
+        pcms = [synth.synth_utterance(21300 + u, 48000 - 320 * ((u + 3) % 11)) for u in range(72)]
+    else:
+        md, gd, _, _ = cases.build_case_files(cases.CASES[name], Path(td))
+        pcms = [synth.synth_utterance(9500 + u, 30000 + 900 * (u % 7)) for u in range(160)]
     m = _lib.Model(md, gd, _lib.default_opts(keep_intermediates=1))
-    pcms = [synth.synth_utterance(9500 + u, 30000 + 900 * (u % 7)) for u in range(160)]
     ref = m.decode_batch(pcms)
-    for kind, label in ((0, "bf16 mfma 64 acc regs"), (3, "bf16 mfma 160 acc regs"), (4, "bf16 mfma 224 acc regs")):
+    for kind, label in ((2, "valu"), (1, "f32 mfma"), (0, "bf16 mfma 64 acc regs"), (3, "bf16 mfma 160 acc regs")):
         stop = False
         def bg():
             while not stop:
