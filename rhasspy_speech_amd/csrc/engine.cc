@@ -507,16 +507,12 @@ struct Timer {
 
 // One decode pipeline at a time per process, by default (RS_CONTEXTS=1, and calls on different models take turns).
 //
-// Several pipelines on the device at once are faster -- with four decode contexts and four calls in flight the headline
-// batch takes 3.6 ms instead of 4.2, because the latency-bound search of one batch leaves the CUs to the GEMMs of the next
-// (RS_CONTEXTS=4, bench.py --inflight 4) -- but they are not yet safe: while another pipeline is in its result / start-of-
-// call phase, two back-to-back runs of the MFCC kernel on the same inputs can disagree in a few frames.  What is known
-// (profiles/micro/stress_same_model.py, stress_two_models.py reproduce it in seconds; 0 differences in 25 600 results
-// with one pipeline): identical inputs and identical FFT output, but the power spectrum read back from LDS differs from
-// its recomputation in groups of exactly 16 lanes; it needs three or more hardware queues busy (GPU_MAX_HW_QUEUES=1: never,
-// 2: rarely); it is independent of LDS / register poisoning, of kernel-argument placement, of the number of waves per
-// workgroup, of stream priorities, of the copy engine used for the result copies, and a known-answer kernel running beside
-// the pipelines is never disturbed.  Until the cause is found the library does not overlap pipelines unless asked to.
+// Several pipelines on the device at once would be faster (the latency-bound search of one batch leaves the CUs to the
+// GEMMs of the next: 3.7 ms per headline batch instead of 4.2), but a GemmKernelB3 workgroup sharing a CU with another
+// pipeline's workgroups perturbs their results (isolated MFCC frames; DESIGN.md section 5 lists what is known, the
+// scripts under profiles/micro reproduce it in seconds).  With RS_CONTEXTS > 1 the GEMM therefore runs as CU-exclusive
+// 512-thread workgroups (GemmDev::exclusive), which is safe (0 differences in the stress runs) but a third slower, so
+// overlapping does not pay yet and stays off by default.
 namespace {
 class ProcessTurn {
  public:
@@ -866,7 +862,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
     }
     d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups;
+    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups; d.exclusive = ctx_.size() > 1 ? 1 : 0;
     d.nstages = (int)op.stages.size();
     for (int i = 0; i < d.nstages; i++) {
       const EltStage &st = op.stages[i];

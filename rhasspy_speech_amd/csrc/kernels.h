@@ -88,6 +88,7 @@ struct GemmDev {
   const void *W3;     // the same weights split into three bf16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
   int n3;             // columns of W3 (n rounded up to 256)
   int interleave;     // 1: W3's k-steps alternate between the segments (all segments shifted views of one buffer)
+  int exclusive;      // 1: GemmKernelB3 keeps every other workgroup off its CU (several decode pipelines in flight)
   int share;          // launches of this kind that run side by side on the device (sub-batch groups): tile planning hint
   const float *bias;  // n (may be null)
   int nstages;

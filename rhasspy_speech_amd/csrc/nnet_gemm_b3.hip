@@ -48,13 +48,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kB3BN = 256, kB3KS = 16;
 constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
 
-template <int MR, bool MIXED>
-__global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
-  constexpr int BM = 32 * MR, BN = kB3BN;
-  constexpr int STAGE = MR * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
-  constexpr int UNITS = BM * 4, NA = (UNITS + 255) / 256;      // 16-byte activation loads per k-step and thread
+// WM = 1: 256 threads, two workgroups per CU.  WM = 2: 512 threads = two such wave rows stacked (64 MR rows), launched with
+// (almost) all of the CU's LDS so that no other workgroup shares the CU -- used when several decode pipelines are in flight
+// (see engine.cc: ProcessTurn for why this kernel must then keep other kernels' workgroups off its CU).
+template <int MR, bool MIXED, int WM>
+__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
+  static_assert(!(MIXED && WM > 1), "two tile heights only with one wave row");
+  constexpr int RT = MR * WM, BM = 32 * RT, BN = kB3BN, NT = 256 * WM;
+  constexpr int STAGE = RT * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
+  constexpr int UNITS = BM * 4, NA = (UNITS + NT - 1) / NT;      // 16-byte activation loads per k-step and thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;          // wave row (0 .. WM-1), 64-column slice
   // XCD-aware tile order (see GemmKernel): all column tiles of a row tile go to one XCD back to back
   // Two tile heights in one launch: the first nbig row tiles are BM rows tall, the rows after them are cut into tiles of
   // half that height (MR even), launched last.  The launcher sizes nbig to whole rounds of the chip, so that the rest --
@@ -81,12 +86,12 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   const int kq = tid & 3;
 #pragma unroll
   for (int h = 0; h < NA; h++) {
-    const int u = tid + 256 * h, r = u >> 2;
-    a_on[h] = u < mr_eff * 128;
+    const int u = tid + NT * h, r = u >> 2;
+    a_on[h] = u < (MIXED ? mr_eff * 128 : UNITS);
     grow[h] = row0 + (a_on[h] ? r : 0);
     if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
     if (d.row_map) grow[h] = d.row_map[grow[h]];
-    // fragment image of row tile r / 32, part p at + p * MR KiB: [k-group][row][8 bf16]
+    // fragment image of row tile r / 32, part p at + p * RT KiB: [k-group][row][8 bf16]
     a_lds[h] = (r >> 5) * kB3FragBytes + (kq >> 1) * 512 + (r & 31) * 16 + (kq & 1) * 8;
   }
   const float *aptr[NA];
@@ -156,12 +161,12 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
       const f32x4 r2 = r1 - __builtin_convertvector(p2, f32x4);
       const bf16x4 p3 = __builtin_convertvector(r2, bf16x4);
       *reinterpret_cast<bf16x4 *>(As + a_lds[h]) = p1;
-      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + MR * kB3FragBytes) = p2;
-      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + 2 * MR * kB3FragBytes) = p3;
+      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
+      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + 2 * RT * kB3FragBytes) = p3;
     }
   };
   // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3
-  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3) + (size_t)(n0 / 32 + wave * 2) * 3 * kB3FragBytes + lane * 16;
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3) + (size_t)(n0 / 32 + wn * 2) * 3 * kB3FragBytes + lane * 16;
   const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
   auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
@@ -175,13 +180,13 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   auto step = [&](int t, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
     const unsigned char *As = smem + (t & 1) * STAGE + lane * 16;
     // fragment reads run one fragment ahead of the MFMAs that use them
-    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(As + (2 * MR) * kB3FragBytes), nxt = cur;
+    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(As + (2 * RT + wm * MR) * kB3FragBytes), nxt = cur;
 #pragma unroll
     for (int idx = 0; idx < 3 * MR; idx++) {
       const int pa = 2 - idx / MR, i = idx % MR;
       if (idx + 1 < 3 * MR) {
         const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
-        nxt = *reinterpret_cast<const bf16x8 *>(As + (pa2 * MR + i2) * kB3FragBytes);
+        nxt = *reinterpret_cast<const bf16x8 *>(As + (pa2 * RT + wm * MR + i2) * kB3FragBytes);
       }
       if (!MIXED || i < mr_eff) {
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   int ccol[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int col = n0 + wave * 64 + j * 32 + (lane & 31);
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
     const bool cok = col < d.n;
     ccol[j] = cok ? col : 0;
     bias[j] = (d.bias && cok) ? d.bias[ccol[j]] : 0.f;
@@ -247,39 +252,43 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
     if (epi_mode == 2) { sc[j] = d.stages[1].scale[ccol[j]]; of[j] = d.stages[1].offset[ccol[j]]; }
   }
 #pragma unroll
-  for (int i = 0; i < MR; i++) {
-    if (MIXED && i >= mr_eff) break;              // workgroup-uniform
+  for (int sl = 0; sl < RT; sl++) {                // 32-row slab sl of the tile belongs to wave row sl / MR
+    constexpr int kDummy = 0; (void)kDummy;
+    const int i = sl % MR;
+    if (MIXED && sl >= mr_eff) break;              // workgroup-uniform
+    if (wm == sl / MR) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int cl = wave * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < 2; j++) {
+        const int cl = wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float v = __fadd_rn(bias[j], acc[i][j][r]);
-        if (epi_mode == 1) {
-          v = v > 0.f ? v : 0.f;
-        } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
-          v = v > 0.f ? v : 0.f;
-          v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);
-        } else if (epi_mode == 3) {
-          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);
+        for (int r = 0; r < 16; r++) {
+          float v = __fadd_rn(bias[j], acc[i][j][r]);
+          if (epi_mode == 1) {
+            v = v > 0.f ? v : 0.f;
+          } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
+            v = v > 0.f ? v : 0.f;
+            v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);
+          } else if (epi_mode == 3) {
+            for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);
+          }
+          Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;
         }
-        Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;
       }
     }
     dd::LdsBarrier();
     if (vec_out) {
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int unit = tid + 256 * q, rl = unit >> 6, c4 = (unit & 63) * 4;
-        const int row = row0 + i * 32 + rl, col = n0 + c4;
+      for (int q = 0; q < 2048 / NT; q++) {
+        const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4;
+        const int row = row0 + sl * 32 + rl, col = n0 + c4;
         if (row < rows && col < d.n)
           *reinterpret_cast<f32x4 *>(d.out + (size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col) =
               *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
       }
     } else {
-      for (int idx = tid; idx < 32 * BN; idx += 256) {
+      for (int idx = tid; idx < 32 * BN; idx += NT) {
         const int rl = idx / BN, cl = idx % BN;
-        const int row = row0 + i * 32 + rl, col = n0 + cl;
+        const int row = row0 + sl * 32 + rl, col = n0 + cl;
         if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl];
       }
     }
@@ -287,20 +296,21 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3(GemmDev d, int rows, int 
   }
 }
 
-template <int MR, bool MIXED>
+template <int MR, bool MIXED, int WM>
 void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
-  constexpr int BM = 32 * MR;
-  constexpr size_t stage = 2 * (size_t)(MR * 3 * kB3FragBytes), ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
-  constexpr size_t smem = stage > ctile ? stage : ctile;          // the epilogue stages 32-row slabs of the output tile
+  constexpr int BM = 32 * MR * WM;
+  constexpr size_t stage = 2 * (size_t)(MR * WM * 3 * kB3FragBytes), ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  // WM = 2 asks for all but 1 KiB of the CU's LDS: no other workgroup fits beside it
+  constexpr size_t smem = WM == 1 ? (stage > ctile ? stage : ctile) : (size_t)159 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3<MR, MIXED, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
-  const int rest = std::max(rows - nbig * BM, 0), nsmall = (rest + BM / 2 - 1) / (BM / 2);
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
   const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3<MR, MIXED>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, row_ivec, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3<MR, MIXED, WM>), dim3(blocks), dim3(256 * WM), smem, s, d, rows, nbig, row_ivec, GemmEpiMode(d, rows));
 }
 
 }  // namespace
@@ -323,6 +333,13 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
   static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
   static int mixed = [] { const char *e = std::getenv("RS_GEMM_B3_MIXED"); return e ? std::atoi(e) : 1; }();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  if (d.exclusive) {
+    // one 512-thread workgroup per CU; tile height 128 or 192 rows, whichever leaves the fuller last round
+    auto rounds1 = [&](int bm) { return (double)(((long)((rows + bm - 1) / bm) * ncol + num_cu - 1) / num_cu) * bm; };
+    if (rounds1(192) * 0.97 < rounds1(128)) LaunchB3<3, false, 2>(d, rows, (rows + 191) / 192, row_ivec, s);
+    else LaunchB3<2, false, 2>(d, rows, (rows + 127) / 128, row_ivec, s);
+    return;
+  }
   const long slots = std::max(2L * num_cu / std::max(d.share, 1), 8L);      // two workgroups per CU; the device may be shared
   // Tile height: rounds of `slots` tiles, each as long as the tile is tall, weighted by the measured per-row efficiency
   // of the height (taller tiles stream the weights for more rows: 0.78 at 128 rows).
@@ -340,10 +357,10 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
     if (full > 0 && c < best) { best = c; mr = 4; nbig = (int)full; }
   }
   if (force_mr >= 2 && force_mr <= 4) { mr = force_mr; nbig = (rows + 32 * mr - 1) / (32 * mr); }
-  if (mr == 2) LaunchB3<2, false>(d, rows, nbig, row_ivec, s);
-  else if (mr == 3) LaunchB3<3, false>(d, rows, nbig, row_ivec, s);
-  else if ((long)nbig * 128 >= rows) LaunchB3<4, false>(d, rows, nbig, row_ivec, s);
-  else LaunchB3<4, true>(d, rows, nbig, row_ivec, s);
+  if (mr == 2) LaunchB3<2, false, 1>(d, rows, nbig, row_ivec, s);
+  else if (mr == 3) LaunchB3<3, false, 1>(d, rows, nbig, row_ivec, s);
+  else if ((long)nbig * 128 >= rows) LaunchB3<4, false, 1>(d, rows, nbig, row_ivec, s);
+  else LaunchB3<4, true, 1>(d, rows, nbig, row_ivec, s);
 }
 
 }  // namespace rs
