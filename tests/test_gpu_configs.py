@@ -201,3 +201,35 @@ def test_concurrent_calls_on_one_model(zam_grammar):
         for res in out[b]:
             for u in range(len(pcms)):
                 _same_result(res, u, ref[b], u)
+
+
+def test_overlapped_contexts_use_the_cu_exclusive_gemm(zam_grammar, monkeypatch):
+    """RS_CONTEXTS > 1 lets calls on one model overlap on the device; the wide layers then run as CU-exclusive workgroups
+    (nnet_gemm_b3.hip, WM = 2).  Same results as the default model, sequentially and from four threads at once."""
+    from rhasspy_speech_amd import _lib, synth
+    default = _lib.Model(*zam_grammar, _lib.default_opts())
+    monkeypatch.setenv("RS_CONTEXTS", "4")
+    overlapped = _lib.Model(*zam_grammar, _lib.default_opts())
+    overlapped.to_device()
+    monkeypatch.delenv("RS_CONTEXTS")
+    batches = [[synth.synth_utterance(23000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(24 + 16 * b)] for b in range(4)]
+    ref = [default.decode_batch(p) for p in batches]
+    for b, p in enumerate(batches):
+        one = overlapped.decode_batch(p)
+        for u in range(len(p)):
+            _same_result(one, u, ref[b], u)
+    out = [[] for _ in batches]
+
+    def run(b):
+        for _ in range(3):
+            out[b].append(overlapped.decode_batch(batches[b]))
+
+    ts = [threading.Thread(target=run, args=(b,)) for b in range(len(batches))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for b, p in enumerate(batches):
+        for res in out[b]:
+            for u in range(len(p)):
+                _same_result(res, u, ref[b], u)
