@@ -113,9 +113,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=N_UTTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="decode calls in flight per rank (host threads on one model).  More than 1 only overlaps on the device "
-                         "with RS_CONTEXTS > 1, which is off by default: see the note at ProcessTurn in engine.cc")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="decode calls in flight per rank (host threads on one model; the library gives each its own decode "
+                         "context): the latency-bound search of one batch overlaps the GEMMs of the next.  1 = one call at a time")
     ap.add_argument("--prune-output", action="store_true",
                     help="rs_decode_opts.prune_output_pdfs=1: output layer only for the pdfs on HCLG arcs (NOT the default: the "
                          "headline line computes every pdf, as the reference does)")

@@ -3,6 +3,7 @@
 #include "lattice.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -295,7 +296,7 @@ void Model::ToDevice() {
     throw DeviceError(std::string("this library is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
   {
     const char *e = std::getenv("RS_CONTEXTS");
-    const int n = std::min(std::max(e ? std::atoi(e) : 1, 1), 8);      // see the note at ProcessTurn: one pipeline at a time by default
+    const int n = std::min(std::max(e ? std::atoi(e) : 4, 1), 8);      // arenas are allocated on first use
     // the search of a slab is latency-bound and must not queue behind the thousands of GEMM workgroups of the next slab
     int prio_low = 0, prio_high = 0;
     RS_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
@@ -505,20 +506,22 @@ struct Timer {
 };
 }  // namespace
 
-// One decode pipeline at a time per process, by default (RS_CONTEXTS=1, and calls on different models take turns).
+// Decode calls may overlap on the device: calls on one model up to its number of decode contexts (RS_CONTEXTS, 4), calls
+// on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.8 ms per
+// headline batch with four calls in flight instead of 4.2.
 //
-// Several pipelines on the device at once would be faster (the latency-bound search of one batch leaves the CUs to the
-// GEMMs of the next: 3.7 ms per headline batch instead of 4.2), but a GemmKernelB3 workgroup sharing a CU with another
-// pipeline's workgroups perturbs their results (isolated MFCC frames; DESIGN.md section 5 lists what is known, the
-// scripts under profiles/micro reproduce it in seconds).  With RS_CONTEXTS > 1 the GEMM therefore runs as CU-exclusive
-// 512-thread workgroups (GemmDev::exclusive), which is safe (0 differences in the stress runs) but a third slower, so
-// overlapping does not pay yet and stays off by default.
+// Overlap needs one precaution.  A GemmKernelB3 workgroup that shares a CU with a workgroup of the feature kernel perturbs
+// that kernel's results (isolated MFCC frames; DESIGN.md section 5 lists what is known, profiles/micro/stress_*.py
+// reproduce it in seconds when the precaution is switched off).  Whenever another decode call of this process is in
+// flight, the feature kernel therefore runs as 16-wave workgroups that take all of a CU's LDS (LaunchMfcc(exclusive)), so
+// no GEMM workgroup can join it; with that, 60 000 results of concurrent calls (one model, two models) matched their
+// sequential values.  RS_PROCESS_LOCK=1 brings back the older, blunter protection: different models take turns.
 namespace {
 class ProcessTurn {
  public:
   explicit ProcessTurn(const void *model) {
-    static const bool off = std::getenv("RS_NO_PROCESS_LOCK") != nullptr;
-    if (off) return;
+    static const bool on = std::getenv("RS_PROCESS_LOCK") != nullptr;
+    if (!on) return;
     std::unique_lock<std::mutex> lk(Mu());
     bool counted = false;      // a model waiting for its turn stops the owner's further calls from overlapping (no starvation)
     while (!(Owner() == nullptr || (Owner() == model && Waiters() == 0))) {
@@ -600,15 +603,21 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
   return res;
 }
 
+static std::atomic<int> g_calls_in_flight{0};      // decode calls of any model of this process
+
 Model::DecodeContext *Model::AcquireContext() {
   std::unique_lock<std::mutex> lk(ctx_mu_);
   for (;;) {
-    for (auto &c : ctx_) if (!c->busy) { c->busy = true; return c.get(); }
+    for (auto &c : ctx_) if (!c->busy) { c->busy = true; g_calls_in_flight.fetch_add(1); return c.get(); }
     ctx_cv_.wait(lk);
   }
 }
+// True when another decode call of this model is in flight right now (different models take turns, ProcessTurn).  Decides
+// whether the feature kernel keeps GEMM workgroups off its CUs: a call that starts alone cannot meet another call's nnet
+// stage during its own (first, 0.3 ms) feature stage, because that call would have to be in flight already.
+bool Model::OthersInFlight() { return g_calls_in_flight.load() > 1; }
 void Model::ReleaseContext(DecodeContext *cx) {
-  { std::lock_guard<std::mutex> lk(ctx_mu_); cx->busy = false; }
+  { std::lock_guard<std::mutex> lk(ctx_mu_); cx->busy = false; g_calls_in_flight.fetch_sub(1); }
   ctx_cv_.notify_one();
 }
 
@@ -837,12 +846,12 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   if (fc_.use_cmvn) {
     raw = falloc(ld_c);
     poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s);
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s, OthersInFlight());
     poison();
     LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
   } else {
     poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s);
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s, OthersInFlight());
   }
   const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
   tm.Mark();
@@ -862,7 +871,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
     }
     d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups; d.exclusive = ctx_.size() > 1 ? 1 : 0;
+    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups; d.exclusive = (ctx_.size() > 1 && std::getenv("RS_GEMM_B3_EXCLUSIVE")) ? 1 : 0;
     d.nstages = (int)op.stages.size();
     for (int i = 0; i < d.nstages; i++) {
       const EltStage &st = op.stages[i];

@@ -132,6 +132,7 @@ class Model {
   std::condition_variable ctx_cv_;
   DecodeContext *AcquireContext();
   void ReleaseContext(DecodeContext *cx);
+  bool OthersInFlight();
   std::unique_ptr<Result> DecodeInContext(DecodeContext &cx, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
                                           float lat_scale, hipStream_t user_stream, bool streaming);
   std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)

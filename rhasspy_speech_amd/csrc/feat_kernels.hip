@@ -7,6 +7,7 @@
 //   feat/mel-computations.cc:226-251, feat/feature-mfcc.cc:28-80 (mel, log, DCT, lifter)
 //   feat/online-feature.cc:337-452 + transform/cmvn.cc:64-91 (OnlineCmvn)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -98,18 +99,21 @@ __device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restr
   }
 }
 
-template <int NFFT>   // padded window (real points)
-__global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
-                                                  float *__restrict__ feats, int ld) {
+// WPB = waves (frames) per workgroup.  4 by default; 16 with all the CU's LDS requested when several decode pipelines are in
+// flight, so that no GemmKernelB3 workgroup of another pipeline can share the CU (DESIGN.md section 5: that kernel
+// perturbs this one's LDS-staged arithmetic when they share a CU).
+template <int NFFT, int WPB>   // padded window (real points)
+__global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
+                                                       float *__restrict__ feats, int ld) {
   constexpr int NC = NFFT / 2;        // complex points
   const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
   const float *fft_tw = m.fft_tw;
-  constexpr int WPB = 4;              // waves (frames) per block
-  __shared__ float xbuf[WPB][NFFT];
-  __shared__ float xrb[WPB][NC];
-  __shared__ float xib[WPB][NC];
-  __shared__ float pw[WPB][NC + 1];
-  __shared__ float lm[WPB][64];
+  extern __shared__ __attribute__((aligned(16))) float mfcc_lds[];
+  float (*xbuf)[NFFT] = reinterpret_cast<float (*)[NFFT]>(mfcc_lds);
+  float (*xrb)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * NFFT);
+  float (*xib)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * (NFFT + NC));
+  float (*pw)[NC + 1] = reinterpret_cast<float (*)[NC + 1]>(mfcc_lds + WPB * (NFFT + 2 * NC));
+  float (*lm)[64] = reinterpret_cast<float (*)[64]>(mfcc_lds + WPB * (NFFT + 3 * NC + 1));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * WPB + wave;
   const bool active = row < g.total_rows;
@@ -216,11 +220,27 @@ __global__ __launch_bounds__(256) void MfccKernel(MfccDev m, BatchGeom g, const 
   }
 }
 
-void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s) {
-  int blocks = (g.total_rows + 3) / 4;
+template <int NFFT, int WPB>
+static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, bool exclusive, hipStream_t s) {
+  const int blocks = (g.total_rows + WPB - 1) / WPB;
   if (!blocks) return;
-  if (m.padded == 512) hipLaunchKernelGGL(MfccKernel<512>, dim3(blocks), dim3(256), 0, s, m, g, pcm, feats, ld);
-  else hipLaunchKernelGGL(MfccKernel<2048>, dim3(blocks), dim3(256), 0, s, m, g, pcm, feats, ld);
+  constexpr size_t need = sizeof(float) * WPB * (NFFT + 3 * (NFFT / 2) + 1 + 64);
+  const size_t smem = exclusive ? std::max<size_t>(need, 159 * 1024) : need;
+  static size_t attr = 0;
+  if (smem > attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&MfccKernel<NFFT, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr = smem;
+  }
+  hipLaunchKernelGGL((MfccKernel<NFFT, WPB>), dim3(blocks), dim3(64 * WPB), smem, s, m, g, pcm, feats, ld);
+}
+
+void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive) {
+  if (m.padded == 512) {
+    if (exclusive) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, true, s);
+    else LaunchMfccT<512, 4>(m, g, pcm, feats, ld, false, s);
+  } else {
+    LaunchMfccT<2048, 4>(m, g, pcm, feats, ld, exclusive, s);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ online CMVN

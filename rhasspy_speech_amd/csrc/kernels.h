@@ -45,7 +45,7 @@ struct MfccDev {
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
 };
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
-void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s);
+void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive = false);
 
 // frame_rows[i] = physical row of the i-th frame in slab-major order: entry (k, u) of seg_off (n_segs + 1 offsets, n_segs =
 // n_slabs * n_utts) starts the frames [k * slab_len, ...) of utterance u.

@@ -76,9 +76,8 @@ def test_config2_arpa_hclg_256x3s(zam_arpa):
 
 
 def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
-    """Two different models resident on the GPU, their batches submitted concurrently from two host threads (what a
-    rank serving a mixed-model shard does; the library lets one decode call at a time onto the device, see
-    engine.cc:DecodeBatchDevice).  Each result must equal the model's own sequential result."""
+    """Two different models resident on the GPU, their batches decoded concurrently from two host threads (what a
+    rank serving a mixed-model shard does).  Each result must equal the model's own sequential result."""
     from rhasspy_speech_amd import _lib, synth
     from tests import cases
     m1 = _lib.Model(*zam_grammar, _lib.default_opts())
@@ -204,16 +203,14 @@ def test_concurrent_calls_on_one_model(zam_grammar):
 
 
 def test_overlapped_contexts_use_the_cu_exclusive_gemm(zam_grammar, monkeypatch):
-    """RS_CONTEXTS > 1 lets calls on one model overlap on the device; the wide layers then run as CU-exclusive workgroups
-    (nnet_gemm_b3.hip, WM = 2).  Same results as the default model, sequentially and from four threads at once."""
+    """RS_GEMM_B3_EXCLUSIVE=1: the wide layers run as CU-exclusive 512-thread workgroups (nnet_gemm_b3.hip, WM = 2) when a model
+    has several decode contexts.  Same results as the default model, sequentially and from four threads at once."""
     from rhasspy_speech_amd import _lib, synth
     default = _lib.Model(*zam_grammar, _lib.default_opts())
-    monkeypatch.setenv("RS_CONTEXTS", "4")
-    overlapped = _lib.Model(*zam_grammar, _lib.default_opts())
-    overlapped.to_device()
-    monkeypatch.delenv("RS_CONTEXTS")
     batches = [[synth.synth_utterance(23000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(24 + 16 * b)] for b in range(4)]
     ref = [default.decode_batch(p) for p in batches]
+    monkeypatch.setenv("RS_GEMM_B3_EXCLUSIVE", "1")          # read at every launch
+    overlapped = _lib.Model(*zam_grammar, _lib.default_opts())
     for b, p in enumerate(batches):
         one = overlapped.decode_batch(p)
         for u in range(len(p)):
