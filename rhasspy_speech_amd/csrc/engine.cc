@@ -507,15 +507,18 @@ struct Timer {
 }  // namespace
 
 // Decode calls may overlap on the device: calls on one model up to its number of decode contexts (RS_CONTEXTS, 4), calls
-// on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.8 ms per
+// on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.7 ms per
 // headline batch with four calls in flight instead of 4.2.
 //
-// Overlap needs one precaution.  A GemmKernelB3 workgroup that shares a CU with a workgroup of the feature kernel perturbs
-// that kernel's results (isolated MFCC frames; DESIGN.md section 5 lists what is known, profiles/micro/stress_*.py
-// reproduce it in seconds when the precaution is switched off).  Whenever another decode call of this process is in
-// flight, the feature kernel therefore runs as 16-wave workgroups that take all of a CU's LDS (LaunchMfcc(exclusive)), so
-// no GEMM workgroup can join it; with that, 60 000 results of concurrent calls (one model, two models) matched their
-// sequential values.  RS_PROCESS_LOCK=1 brings back the older, blunter protection: different models take turns.
+// Overlap needed one fix that is NOT in this file.  Waves executing packed FP32 VALU instructions (v_pk_add_f32 /
+// v_pk_mul_f32, which the compiler forms by itself when it vectorises scalar float code) produced wrong results in
+// 16-lane groups whenever MFMA-issuing waves of another kernel (GemmKernelB3 of another call) shared their CU: isolated
+// MFCC frames came out perturbed, first noticed as two models disturbing each other (DESIGN.md section 5 has the
+// evidence; profiles/micro/stress_*.py reproduce it in seconds when feat_kernels.hip is built without NOPACK).  The
+// Makefile therefore builds the feature and the small nnet kernels with -fno-slp-vectorize -fno-vectorize; with that,
+// 60 000 results of concurrent calls (one model, two models) match their sequential values.  Two older, blunter
+// protections remain as switches: RS_MFCC_EXCLUSIVE=1 (the feature kernel takes whole CUs while other calls are in
+// flight) and RS_PROCESS_LOCK=1 (different models take turns).
 namespace {
 class ProcessTurn {
  public:
@@ -612,12 +615,12 @@ Model::DecodeContext *Model::AcquireContext() {
     ctx_cv_.wait(lk);
   }
 }
-// True when another decode call of this model is in flight right now (different models take turns, ProcessTurn).  Decides
-// whether the feature kernel keeps GEMM workgroups off its CUs: a call that starts alone cannot meet another call's nnet
-// stage during its own (first, 0.3 ms) feature stage, because that call would have to be in flight already.
+// RS_MFCC_EXCLUSIVE=1: true when another decode call of this process is in flight right now; the feature kernel then keeps
+// GEMM workgroups off its CUs (a call that starts alone cannot meet another call's nnet stage during its own, first,
+// 0.3 ms feature stage, because that call would have to be in flight already).
 bool Model::OthersInFlight() {
-  static const bool off = [] { const char *e = std::getenv("RS_MFCC_EXCLUSIVE"); return e && std::atoi(e) == 0; }();      // reproducing the interference
-  return !off && g_calls_in_flight.load() > 1;
+  static const bool on = [] { const char *e = std::getenv("RS_MFCC_EXCLUSIVE"); return e && std::atoi(e) != 0; }();
+  return on && g_calls_in_flight.load() > 1;
 }
 void Model::ReleaseContext(DecodeContext *cx) {
   { std::lock_guard<std::mutex> lk(ctx_mu_); cx->busy = false; g_calls_in_flight.fetch_sub(1); }
