@@ -380,10 +380,12 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
                      const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s) {
   if (g.n_utts == 0) return true;
   size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
-  // room to stage back-pointer rows for the traceback: when every utterance has a CU to itself anyway, take most of the LDS
-  // (a slab that finishes no utterance does not trace back: it keeps its LDS footprint minimal so that the GEMM workgroups
-  // of the next slab's output layer stay co-resident)
-  const size_t stage = f_end <= g.max_frames ? 0 : (g.n_utts <= 256 ? 128 * 1024 : 48 * 1024);
+  // room to stage back-pointer rows for the traceback.  48 KB, not more: with 128 KB a search workgroup left no room for
+  // the GEMM workgroups (33 KB each) of the next decode call on its CU, and the overlap of calls in flight was limited to
+  // the feature / iVector stages (3.7 ms per headline batch against 3.35 with 48 KB; the search itself takes the same
+  // time).  A slab that finishes no utterance does not trace back and keeps its LDS footprint minimal.
+  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 48; }();
+  const size_t stage = f_end <= g.max_frames ? 0 : stage_kb * 1024;
   if (smem < stage) smem = stage;
   if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
