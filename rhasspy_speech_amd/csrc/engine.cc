@@ -507,7 +507,7 @@ struct Timer {
 }  // namespace
 
 // Decode calls may overlap on the device: calls on one model up to its number of decode contexts (RS_CONTEXTS, 4), calls
-// on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.7 ms per
+// on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.3 ms per
 // headline batch with four calls in flight instead of 4.2.
 //
 // Overlap needed one fix that is NOT in this file.  Waves executing packed FP32 VALU instructions (v_pk_add_f32 /
