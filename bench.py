@@ -6,7 +6,12 @@ MI355X".  No real zamia model exists offline, so the model is the synthetic "zam
 8(d) written in genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iVector with a
 512-Gaussian UBM, 7x250 TDNN + prefinal, 2000 pdfs) and a grammar HCLG; audio is synthetic (seeded).  A "step" is
 one pass of the whole path (MFCC -> iVector -> TDNN -> beam search -> word ids) over the 256-utterance batch,
-with the int16 samples already resident in HBM when the timed region starts.
+with the int16 samples already resident in HBM when the timed region starts.  The K timed steps are submitted from a few
+host threads (`--inflight`, default 4) so that consecutive batches overlap on the device, as a serving process would run
+them: the latency-bound search of one batch shares the CUs with the GEMMs of the next.  Every step's result records are
+checked against the first step's (same input), and every step is complete before the closing synchronize + barrier.
+Stage times and the roofline are taken from un-overlapped calls made right after the timed region (`--inflight 1` gives
+the one-call-at-a-time figure for the whole step).
 
 Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`):
 utterances shard embarrassingly, one process per GPU, each rank decodes its own 256-utterance batch (weak
