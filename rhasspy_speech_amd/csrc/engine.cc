@@ -914,22 +914,6 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
       poison();
       LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
-      if (std::getenv("RS_DEBUG_IVEC")) {
-        RS_HIP(hipStreamSynchronize(s));
-        std::vector<int> pi((size_t)rows * nsel); std::vector<float> pw((size_t)rows * nsel), gm((size_t)G);
-        std::vector<double> hl(Di), hq(usz), hw((size_t)G * Dl); double nf = 0;
-        RS_HIP(hipMemcpy(pi.data(), post_idx, pi.size() * 4, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(pw.data(), post_w, pw.size() * 4, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(gm.data(), gamma, gm.size() * 4, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(hl.data(), linear, hl.size() * 8, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(hq.data(), quad, hq.size() * 8, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(hw.data(), wfeats, hw.size() * 8, hipMemcpyDeviceToHost));
-        RS_HIP(hipMemcpy(&nf, numf, 8, hipMemcpyDeviceToHost));
-        for (int t = 0; t < 3; t++) { size_t r = (size_t)g.L + t; printf("post[%d]:", t); for (int j = 0; j < nsel; j++) printf(" (%d %.6f)", pi[r * nsel + j], pw[r * nsel + j]); printf("\n"); }
-        double gs = 0, ws = 0; for (float v : gm) gs += v; for (double v : hw) ws += v;
-        printf("gamma_sum %.6f wfeats_sum %.6f numf %.6f\nlinear:", gs, ws, nf); for (int i = 0; i < std::min(Di, 6); i++) printf(" %.6f", hl[i]);
-        printf("\nquad:"); for (int i = 0; i < std::min(usz, 6); i++) printf(" %.6f", hq[i]); printf("\n");
-      }
       LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
     } else {
       // per-chunk schedule tables: [step][utt] frame_begin, frame_end, out_row, active
