@@ -114,8 +114,8 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcm: np.ndarray, seconds_budg
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--utts", type=int, default=N_UTTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=4,
