@@ -190,3 +190,28 @@ def test_fuzzy_control_flow_of_the_transcriber(tmp_path):
     assert t._finish(nb, lang, hit["result"][1] - 0.25, True) == []
     with pytest.raises(TypeError):
         t._finish(nb, lang, None, False)                               # the reference compares `cost <= None` too
+
+
+@pytest.mark.parametrize("source,extra", [("feat_kernels.hip", ["-ffp-contract=off"]), ("nnet_kernels.hip", []),
+                                           ("nnet_gemm_b3.hip", []), ("decode_reg.hip", ["-ffp-contract=off"])])
+def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
+    """Kernels that can share a CU with the MFMA GEMM of another decode call must not contain packed FP32 VALU math
+    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): those instructions gave wrong results in 16-lane groups next to
+    GemmKernelB3.  The compiler forms them on its own when it vectorises scalar float code, so the
+    Makefile builds these files with NOPACK; this test compiles them the same way and looks at the ISA.
+    (ivector_kernels.hip uses v_pk_fma_f32 on purpose in UbmPostKernel and is not covered.)"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc")
+    if hipcc is None:
+        pytest.skip("hipcc not on PATH")
+    csrc = Path(__file__).resolve().parent.parent / "rhasspy_speech_amd" / "csrc"
+    nopack = re.search(r"^NOPACK\s*=\s*(.*)$", (csrc / "Makefile").read_text(), re.M).group(1).split()
+    assert "-fno-slp-vectorize" in nopack and "-fno-vectorize" in nopack
+    flags = nopack if source in ("feat_kernels.hip", "nnet_kernels.hip") else []
+    out = tmp_path / "k.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, *flags, "-S", "--cuda-device-only", str(csrc / source),
+                    "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    packed = re.findall(r"v_pk_(?:add|mul|fma)_f32", out.read_text())
+    assert not packed, f"{source}: {len(packed)} packed FP32 instructions"
