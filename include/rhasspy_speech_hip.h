@@ -158,6 +158,14 @@ int rs_fuzzy_open(const char *fuzzy_fst_path, rs_fuzzy **out);
 int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
 void rs_fuzzy_free(rs_fuzzy *f);
 
+/* Host-side entry for tests and tools (no GPU needed): determinises a raw lattice -- the state-level lattice the search
+ * leaves behind, given as n_arcs arcs (src, dst, word label, transition-id; graph and acoustic cost), a start state and
+ * per-state final costs (+inf = not final) -- with the same code rs_result_lattice uses (lattice beam `beam`) and renders
+ * the binary CompactLattice table entry.  Returns the entry's size (copies min(size, cap) bytes), or a negative error. */
+int64_t rs_lattice_entry_from_raw(int32_t num_states, int32_t start, const float *final_cost, int32_t n_arcs, const int32_t *arc_src,
+                                  const int32_t *arc_dst, const int32_t *arc_word, const int32_t *arc_tid, const float *arc_graph,
+                                  const float *arc_acoustic, float beam, const char *key, char *buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ EXPORTS = [
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
-    "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free",
+    "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
 ]
 
 
@@ -79,6 +79,9 @@ def load_library() -> C.CDLL:
     lib.rs_fuzzy_match.argtypes = [vp, C.c_char_p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     lib.rs_fuzzy_free.argtypes = [vp]
     lib.rs_fuzzy_free.restype = None
+    pf, pi = C.POINTER(f32), C.POINTER(i32)
+    lib.rs_lattice_entry_from_raw.argtypes = [i32, i32, pf, i32, pi, pi, pi, pi, pf, pf, f32, C.c_char_p, C.c_char_p, C.c_int64]
+    lib.rs_lattice_entry_from_raw.restype = C.c_int64
     return lib
 
 
@@ -300,3 +303,23 @@ class FuzzyMatcher:
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+def lattice_entry_from_raw(num_states: int, start: int, final_cost, arcs, beam: float, key: str = "utt") -> bytes:
+    """Host-only (no GPU): determinise a raw lattice and render the CompactLattice table entry.  `arcs` = iterable of
+    (src, dst, word, transition_id, graph_cost, acoustic_cost); `final_cost[s]` = +inf for non-final states."""
+    arcs = list(arcs)
+    n = len(arcs)
+    fc = np.ascontiguousarray(final_cost, dtype=np.float32)
+    cols = [np.ascontiguousarray([a[k] for a in arcs], dtype=np.int32) for k in range(4)]
+    g = np.ascontiguousarray([a[4] for a in arcs], dtype=np.float32)
+    ac = np.ascontiguousarray([a[5] for a in arcs], dtype=np.float32)
+    pi, pf = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    args = [num_states, start, fc.ctypes.data_as(pf), n, *[c.ctypes.data_as(pi) for c in cols], g.ctypes.data_as(pf), ac.ctypes.data_as(pf),
+            float(beam), key.encode()]
+    size = lib().rs_lattice_entry_from_raw(*args, None, 0)
+    if size < 0:
+        _check(int(size))
+    buf = C.create_string_buffer(int(size))
+    lib().rs_lattice_entry_from_raw(*args, buf, size)
+    return buf.raw

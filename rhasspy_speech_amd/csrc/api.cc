@@ -321,4 +321,29 @@ int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, 
 
 void rs_fuzzy_free(rs_fuzzy *f) { delete f; }
 
+int64_t rs_lattice_entry_from_raw(int32_t num_states, int32_t start, const float *final_cost, int32_t n_arcs, const int32_t *arc_src,
+                                  const int32_t *arc_dst, const int32_t *arc_word, const int32_t *arc_tid, const float *arc_graph,
+                                  const float *arc_acoustic, float beam, const char *key, char *buf, int64_t cap) {
+  if (num_states <= 0 || start < 0 || start >= num_states || !final_cost || n_arcs < 0 || cap < 0 || (cap > 0 && !buf) ||
+      (n_arcs > 0 && (!arc_src || !arc_dst || !arc_word || !arc_tid || !arc_graph || !arc_acoustic)))
+    return ArgError("rs_lattice_entry_from_raw: bad argument");
+  try {
+    rs::RawLattice lat;
+    lat.start = start;
+    lat.num_states = num_states;
+    lat.final_cost.assign(final_cost, final_cost + num_states);
+    for (int i = 0; i < n_arcs; i++) {
+      if (arc_src[i] < 0 || arc_src[i] >= num_states || arc_dst[i] < 0 || arc_dst[i] >= num_states)
+        return ArgError("rs_lattice_entry_from_raw: arc state out of range");
+      lat.arcs.push_back({arc_src[i], arc_dst[i], arc_word[i], (double)arc_graph[i], (double)arc_acoustic[i], arc_tid[i]});
+    }
+    const std::string s = rs::CompactLatticeArkEntry(key ? key : "utt", rs::DeterminizeLattice(lat, beam));
+    if (buf && cap) std::memcpy(buf, s.data(), std::min<size_t>(s.size(), (size_t)cap));
+    return (int64_t)s.size();
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return RS_ERR_DECODE;
+  }
+}
+
 }  // extern "C"
