@@ -16,5 +16,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- p
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> $OUT/pmc_fetch.log
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> $OUT/pmc_write.log
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> $OUT/pmc_sq.log
-python bench.py --steps 20 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench.log
+python bench.py > $OUT/bench_line.json 2> $OUT/bench.log                       # the default invocation, as the driver runs it
+python bench.py --no-cpu-baseline --prune-output > $OUT/bench_line_pruned_output.json 2>> $OUT/bench.log
+python bench.py --no-cpu-baseline --inflight 1 > $OUT/bench_line_one_call_in_flight.json 2>> $OUT/bench.log
 find $OUT -name "*.csv" | head -20

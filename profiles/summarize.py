@@ -37,6 +37,12 @@ if stats:
 line = (src / "bench_line.json").read_text().strip().splitlines()[-1]
 json.loads(line)
 (dst / f"bench_{ver}_line.json").write_text(line + "\n")
+for extra in ("pruned_output", "one_call_in_flight"):          # the same bench with one switch changed (collect.sh)
+    f = src / f"bench_line_{extra}.json"
+    if f.exists() and f.read_text().strip():
+        extra_line = f.read_text().strip().splitlines()[-1]
+        json.loads(extra_line)
+        (dst / f"bench_{ver}_line_{extra}.json").write_text(extra_line + "\n")
 kernels = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
