@@ -134,9 +134,18 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP library has no CPU fallback")
+    # One rank per GPU.  (Test hook: RS_BENCH_BACKEND=gloo lets two ranks share the single GPU of a test box -- RCCL refuses
+    # two ranks on one device -- to exercise the N > 1 control flow; the records then travel through host memory.)
+    backend = os.environ.get("RS_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    comm_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from rhasspy_speech_amd import _lib
     cache = Path(tempfile.gettempdir()) / f"rs_bench_zamia_like_S_rank{rank}"
@@ -151,7 +160,7 @@ def main() -> None:
     def gather(res):
         rec = res.pack(MAX_WORDS)          # fixed 264-byte records: status, n_words, word ids, graph/acoustic cost
         if world > 1:
-            t = torch.from_numpy(rec).to(f"cuda:{local_rank}")
+            t = torch.from_numpy(rec).to(comm_device)
             out = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(out, t)       # the path's one exchange step: fixed-size result records over RCCL/xGMI
             rec = torch.cat(out).cpu().numpy()
@@ -187,7 +196,7 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # Stage times and the roofline come from un-overlapped calls made right after the timed region (with two calls in flight
