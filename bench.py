@@ -105,10 +105,30 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcm: np.ndarray, seconds_budg
                 return None
             n_done += 1
             audio += pcm.shape[1] / 16000.0
-    wall = time.perf_counter() - t0
+        wall = time.perf_counter() - t0
+        # Beside it: the same binaries fed a table of utterances, so the model and HCLG load once -- the reference's decode
+        # rate without its per-call start-up (not how rhasspy-speech calls them, but the fairer figure for the kernels).
+        n_tab = min(16, pcm.shape[0])
+        for i in range(n_tab):
+            synth.write_wav(Path(td) / f"t{i}.wav", pcm[i])
+        (Path(td) / "wav.scp").write_text("".join(f"utt{i} {td}/t{i}.wav\n" for i in range(n_tab)))
+        (Path(td) / "spk2utt").write_text("".join(f"utt{i} utt{i}\n" for i in range(n_tab)))
+        cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false "
+               f"--word-symbol-table={graph_dir}/words.txt --config={conf} --max-active=7000 --lattice-beam=8.0 "
+               f"--acoustic-scale=1.0 --beam=24.0 {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst "
+               f"ark:{td}/spk2utt scp:{td}/wav.scp ark:- | lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | "
+               f"nbest-to-linear ark:- ark:/dev/null ark,t:-")
+        t1 = time.perf_counter()
+        r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall_tab = time.perf_counter() - t1
+        steady = None
+        if r.returncode == 0 and len(r.stdout.decode().splitlines()) == n_tab:
+            steady = {"value": n_tab * pcm.shape[1] / 16000.0 / wall_tab, "unit": "audio-seconds/s", "cores": 1,
+                      "sample": f"{n_tab} utterances through ONE pipeline invocation (model + HCLG loaded once)"}
     return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference",
             "sample": f"{n_done} of the {pcm.shape[0]} utterances, one transcribe_wav.py-style 3-process pipeline per "
-                      f"utterance (model + HCLG re-loaded every call, as the reference does)"}
+                      f"utterance (model + HCLG re-loaded every call, as the reference does)",
+            "one_load": steady}
 
 
 def main() -> None:
