@@ -10,7 +10,6 @@ import collections
 import csv
 import glob
 import json
-import re
 import shutil
 import sys
 from pathlib import Path

@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import io
 import math
-import os
 import struct
 from dataclasses import dataclass, field
 from pathlib import Path

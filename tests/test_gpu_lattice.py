@@ -9,7 +9,6 @@ CompactLattice table entry the reference's online2-wav-nnet3-latgen-faster write
 import json
 from pathlib import Path
 
-import numpy as np
 import pytest
 
 from tests import cases
