@@ -99,6 +99,13 @@ __device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restr
   }
 }
 
+// The waves of a workgroup work on different frames, each in its own slices of the LDS arrays: a wave only has to order
+// its own LDS traffic (its earlier writes land before its later reads), no wave ever waits for another one.
+__device__ __forceinline__ void WaveLdsSync() {
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // WPB = waves (frames) per workgroup.  4 by default; 16 with all the CU's LDS requested when several decode pipelines are in
 // flight, so that no GemmKernelB3 workgroup of another pipeline can share the CU (DESIGN.md section 5: that kernel
 // perturbs this one's LDS-staged arithmetic when they share a CU).
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
       raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
     }
   }
-  __syncthreads();
+  WaveLdsSync();
   float *xr = xrb[wave], *xi = xib[wave];
   if (active) {
     // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does) and
@@ -163,12 +170,12 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     }
     if (m.use_energy && !m.raw_energy) raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
   }
-  __syncthreads();
+  WaveLdsSync();
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
   for (int L = 0; L < m.fft_num_levels; L++) {
     if (active)
       for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], fft_tw, xr, xi);
-    __syncthreads();
+    WaveLdsSync();
   }
   // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
   // spectrum element k of the bit-reversal pass is element perm[k] of the in-place result
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
       pw[wave][NC] = n2th * n2th;
     }
   }
-  __syncthreads();
+  WaveLdsSync();
   // 5. mel filterbank + log
   if (active && lane < m.nbins) {
     int off = m.mel_offset[lane], len = m.mel_len[lane];
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     for (int i = 0; i < len; i++) e += w[i] * pw[wave][off + i];
     lm[wave][lane] = logf(fmaxf(e, FLT_EPSILON));
   }
-  __syncthreads();
+  WaveLdsSync();
   // 6. DCT + lifter, write the row
   if (active && lane < m.nceps) {
     const float *d = m.dct + lane * m.nbins;
