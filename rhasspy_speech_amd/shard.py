@@ -59,3 +59,47 @@ def gather_records(local: np.ndarray, n_total: int, device=None):
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return unpack_records(torch.cat(outs).cpu().numpy())
+
+
+def decode_mixed_sharded(models, utt_model: Sequence[str], pcm: Sequence[np.ndarray], rank: int = 0, world: int = 1, device=None):
+    """A batch whose utterances name different models (BASELINE config 3: de_DE + fr_FR utterances in one batch), sharded
+    over the ranks of one node -- SURVEY.md section 8(b)'s `rs_decode_batch_sharded`, on the host side, in the reference's
+    own language; the communicator is torch.distributed's (RCCL with the "nccl" backend).
+
+    `models` maps a name to a loaded model (`_lib.Model`, or anything with `decode_batch(list of int16 arrays)` returning
+    an object with `words(u)` / `costs(u)`), resident on this rank's GPU; `utt_model[i]` names the model of utterance i.
+    Utterance i belongs to rank i % world; a rank decodes its utterances of each model as ONE batch per model, the
+    batches of different models concurrently from one host thread each (they overlap on the device), and one all_gather of
+    the fixed-size 1-best records returns {utterance index: (word ids, graph cost, acoustic cost)} on every rank."""
+    import threading
+    if len(utt_model) != len(pcm):
+        raise ValueError("utt_model and pcm differ in length")
+    groups = {}
+    for i in shard_indices(len(pcm), rank, world):
+        if utt_model[i] not in models:
+            raise KeyError(f"utterance {i} names model {utt_model[i]!r}, which is not loaded")
+        groups.setdefault(utt_model[i], []).append(i)
+    results, errors = {}, []
+
+    def run(name, idx):
+        try:
+            results[name] = models[name].decode_batch([pcm[i] for i in idx])
+        except Exception as e:          # re-raised on the calling thread, after every rank has reached the gather
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(name, idx)) for name, idx in groups.items()]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    indices, words, costs = [], [], []
+    if not errors:
+        for name, idx in groups.items():
+            for u, i in enumerate(idx):
+                indices.append(i)
+                words.append(results[name].words(u))
+                costs.append(results[name].costs(u))
+    gathered = gather_records(pack_records(indices, words, costs), len(pcm), device)
+    if errors:
+        raise errors[0]
+    return gathered

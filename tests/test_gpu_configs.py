@@ -107,6 +107,19 @@ def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
     ids = list(range(len(pcm1) + len(pcm2)))
     mine = [shard.shard_indices(len(ids), r, 8) for r in range(8)]
     assert sorted(i for part in mine for i in part) == ids
+    # the mixed batch through the host entry point (shard.decode_mixed_sharded; one rank here): utterances of the two
+    # models interleaved in one list, each decoded by its own model, results back in the caller's order
+    names, pcm, src = [], [], []
+    for u in range(max(len(pcm1), len(pcm2))):
+        if u < len(pcm1):
+            names.append("zam"); pcm.append(pcm1[u]); src.append((ref1, u))
+        if u < len(pcm2):
+            names.append("tinyf"); pcm.append(pcm2[u]); src.append((ref2, u))
+    got = shard.decode_mixed_sharded({"zam": m1, "tinyf": m2}, names, pcm)
+    assert sorted(got) == list(range(len(pcm)))
+    for i, (ref, u) in enumerate(src):
+        g, a = ref.costs(u)
+        assert got[i][0] == ref.words(u)[:shard.MAX_WORDS] and got[i][1:] == (np.float32(g), np.float32(a)), i
 
 
 def test_config4_64_streams_30s(zam_grammar):

@@ -134,6 +134,30 @@ got = shard.gather_records(shard.pack_records(idx, words, costs), n)
 assert sorted(got) == list(range(n)), got
 for i in range(n):
     assert got[i] == ([i, i + 1, 7 * i % 13][: 1 + i % 3], float(i) + 0.5, -float(i) * 2.0), (i, got[i])
+# a mixed-model batch: two stand-in "models" (the real ones need a GPU), utterance i belongs to model names[i % 3 == 0]
+class Fake:
+    def __init__(self, tag): self.tag, self.calls = tag, 0
+    def decode_batch(self, pcm):
+        self.calls += 1
+        fake = self
+        class R:
+            def words(self, u): return [fake.tag, int(pcm[u][0]), len(pcm[u])]
+            def costs(self, u): return (float(pcm[u][0]) / 4.0, -float(len(pcm[u])))
+        return R()
+models = {"de": Fake(1), "fr": Fake(2)}
+n = 13
+names = ["de" if i % 3 == 0 else "fr" for i in range(n)]
+pcm = [np.full(5 + i, 100 + i, np.int16) for i in range(n)]
+got = shard.decode_mixed_sharded(models, names, pcm, rank, world)
+assert sorted(got) == list(range(n))
+for i in range(n):
+    assert got[i] == ([1 if i % 3 == 0 else 2, 100 + i, 5 + i], (100 + i) / 4.0, -float(5 + i)), (i, got[i])
+assert models["de"].calls <= 1 and models["fr"].calls <= 1          # one batch per model and rank
+try:
+    shard.decode_mixed_sharded(models, ["es"] * n, pcm, rank, world)
+    raise SystemExit("an unknown model name must be an error")
+except KeyError:
+    pass
 dist.destroy_process_group()
 print("ok", rank)
 '''
