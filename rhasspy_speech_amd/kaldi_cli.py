@@ -1,0 +1,143 @@
+"""Executables with the names and command lines of the two Kaldi decoder binaries the reference spawns, backed by the HIP
+library ("optional stronger drop-in"): with `rhasspy_speech_amd/bin` first on PATH the UNMODIFIED
+reference Python (`rhasspy_speech/transcribe_wav.py:46-74`, `transcribe_stream.py:53-99`) runs on the GPU path --
+these programs write the binary CompactLattice table the Kaldi ones write (`rs_result_lattice`), and the reference's
+`lattice-to-nbest | nbest-to-linear` read it as before.
+
+  online2-wav-nnet3-latgen-faster [--opts] final.mdl HCLG.fst <spk2utt-rspecifier> <wav-rspecifier> <lattice-wspecifier>
+      (online2bin/online2-wav-nnet3-latgen-faster.cc:196-300; every utterance of the table is one device batch)
+  online2-cli-nnet3-decode-faster [--opts] final.mdl HCLG.fst words.txt <lattice-wspecifier>      (s16le PCM on stdin)
+      (online2bin/online2-cli-nnet3-decode-faster.cc:129-170; key "utt")
+
+Like the binaries, a process loads the model, decodes and exits; errors go to stderr with a non-zero status
+(tools.py:138-145 turns that into RuntimeError).  No CPU fallback: without a GPU the library's error is the program's.
+"""
+from __future__ import annotations
+
+import subprocess
+import sys
+import wave
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# option -> (rs_decode_opts field, type); the others the reference passes are accepted and have no effect here
+_DECODE_OPTS = {"max-active": ("max_active", int), "min-active": ("min_active", int), "beam": ("beam", float),
+                "lattice-beam": ("lattice_beam", float), "acoustic-scale": ("acoustic_scale", float)}
+_IGNORED = {"online", "do-endpointing", "word-symbol-table", "frames-per-chunk", "extra-left-context-initial", "frame-subsampling-factor",
+            "chunk-length", "num-threads-startup", "verbose"}
+
+
+def parse_command_line(argv: List[str]) -> Tuple[Dict[str, object], str, List[str]]:
+    """(decode options, --config path, positional arguments); unknown options are errors, as in Kaldi's ParseOptions."""
+    opts: Dict[str, object] = {}
+    config, pos = None, []
+    for a in argv:
+        if a.startswith("--"):
+            name, _, value = a[2:].partition("=")
+            if name == "config":
+                config = value
+            elif name in _DECODE_OPTS:
+                field, conv = _DECODE_OPTS[name]
+                opts[field] = conv(value)
+            elif name in _IGNORED:
+                if name == "online" and value.lower() not in ("false", "f", "0"):
+                    raise ValueError("--online=true is not supported (the reference passes --online=false)")
+            else:
+                raise ValueError(f"invalid option --{name}")
+        else:
+            pos.append(a)
+    if config is None:
+        raise ValueError("--config=<online.conf> is required")
+    return opts, config, pos
+
+
+def read_table(rspecifier: str) -> List[Tuple[str, str]]:
+    """Text `ark:` / `scp:` rspecifier -> [(key, rest of line)]; `cmd|` forms are run through the shell as Kaldi does."""
+    kind, _, rest = rspecifier.partition(":")
+    if kind.split(",")[0] not in ("ark", "scp"):
+        raise ValueError(f"unsupported rspecifier {rspecifier!r}")
+    rest = rest.strip()
+    if rest.endswith("|"):
+        text = subprocess.run(["bash", "-c", rest[:-1]], check=True, stdout=subprocess.PIPE).stdout.decode()
+    elif rest == "-":
+        text = sys.stdin.read()
+    else:
+        text = Path(rest).read_text()
+    rows = []
+    for line in text.splitlines():
+        key, _, value = line.strip().partition(" ")
+        if key:
+            rows.append((key, value.strip()))
+    return rows
+
+
+def read_wav(path: str) -> np.ndarray:
+    with wave.open(path, "rb") as w:
+        if w.getsampwidth() != 2 or w.getnchannels() != 1:
+            raise ValueError(f"{path}: expected 16-bit mono PCM (wave-reader.cc:199-200)")
+        return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+
+
+def open_wspecifier(wspecifier: str):
+    kind, _, rest = wspecifier.partition(":")
+    if kind.split(",")[0] != "ark" or "t" in kind.split(",")[1:]:
+        raise ValueError(f"unsupported lattice wspecifier {wspecifier!r} (binary ark only)")
+    return sys.stdout.buffer if rest == "-" else open(rest, "wb")
+
+
+def _load(opts, config, final_mdl, hclg):
+    from . import _lib
+    return _lib, _lib.Model(final_mdl=final_mdl, hclg=hclg, online_conf=config, opts=_lib.default_opts(emit_lattice=1, **opts))
+
+
+def wav_main(argv: List[str]) -> int:
+    opts, config, pos = parse_command_line(argv)
+    if len(pos) != 5:
+        raise ValueError("usage: online2-wav-nnet3-latgen-faster [options] <nnet3-in> <fst-in> <spk2utt-rspecifier> <wav-rspecifier> <lattice-wspecifier>")
+    final_mdl, hclg, spk2utt, wav_rspec, lat_wspec = pos
+    wavs = dict(read_table(wav_rspec))
+    utts = [u for _, us in read_table(spk2utt) for u in us.split()]
+    missing = [u for u in utts if u not in wavs]
+    if missing:
+        raise ValueError(f"no wav for utterance {missing[0]}")
+    _lib, model = _load(opts, config, final_mdl, hclg)
+    res = model.decode_batch([read_wav(wavs[u]) for u in utts])
+    out = open_wspecifier(lat_wspec)
+    for i, u in enumerate(utts):
+        out.write(res.lattice(i, u))
+    out.flush()
+    return 0
+
+
+def cli_main(argv: List[str]) -> int:
+    opts, config, pos = parse_command_line(argv)
+    if len(pos) != 4:
+        raise ValueError("usage: online2-cli-nnet3-decode-faster [options] <nnet3-in> <fst-in> <word-symbol-table> <lattice-wspecifier>")
+    final_mdl, hclg, _words, lat_wspec = pos
+    _lib, model = _load(opts, config, final_mdl, hclg)
+    stream = _lib.Stream(model)
+    carry = b""
+    while True:
+        chunk = sys.stdin.buffer.read(2048)            # the reference's read size (transcribe_stream.py:70-76 feeds what it gets)
+        if not chunk:
+            break
+        chunk = carry + chunk
+        n = len(chunk) // 2 * 2
+        carry = chunk[n:]
+        if n:
+            stream.accept(np.frombuffer(chunk[:n], dtype=np.int16))
+    res = stream.finish()
+    out = open_wspecifier(lat_wspec)
+    out.write(res.lattice(0, "utt"))
+    out.flush()
+    return 0
+
+
+def run(main, argv: List[str]) -> int:
+    try:
+        return main(argv)
+    except Exception as e:               # like KALDI_ERR: message on stderr, status 1
+        print(f"ERROR ({Path(sys.argv[0]).name}): {e}", file=sys.stderr)
+        return 1
