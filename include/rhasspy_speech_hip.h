@@ -133,6 +133,25 @@ int rs_result_text(const rs_result *r, int32_t utt, const char *key, char *buf, 
  * all_gather of these records is the path's only exchange step): out[u * (max_words + 4)] =
  * {status (0 ok), n_words, word ids (max_words slots, truncated), graph cost bits, acoustic cost bits}. */
 int rs_result_pack(const rs_result *r, int32_t max_words, int32_t *out);
+/* Multi-GPU entry point (BASELINE.json configs[3]: a batch whose utterances name different
+ * models, sharded over the GPUs of one node).  The reference runs one process per utterance with no shared state
+ * (rhasspy_speech/tools.py:117-147), so the partition is free: utterance i belongs to rank i % world.  Every rank calls this
+ * with the same utt_model[] / n_utts (one process per GPU; models[m] resident on this rank's device); pcm[i] / n_samples[i]
+ * need only be valid for the rank's own utterances.  The rank decodes its utterances -- one device batch per model, the
+ * models' batches concurrently -- and ONE ncclAllGather over `rccl_comm` (an ncclComm_t whose rank / size are `rank` /
+ * `world`; RCCL over xGMI) fills `records` (n_utts x RS_SHARD_RECORD_INTS int32) for EVERY utterance on every rank:
+ *   [0] utterance index, [1] status (RS_OK, a negative RS_ERR_*, or RS_SHARD_ABSENT), [2] number of words of the 1-best (if it
+ *   exceeds RS_SHARD_MAX_WORDS the ids were cut), [3 .. 3+RS_SHARD_MAX_WORDS) word ids, then graph / acoustic cost (float bits).
+ * Failures travel in the status field and the collective always runs, so a failing rank cannot leave the others waiting;
+ * the return value is this rank's first failure (after the gather).  With rccl_comm = NULL no collective is
+ * issued and only the rank's own records are filled (the others read RS_SHARD_ABSENT): for callers that gather themselves. */
+#define RS_SHARD_MAX_WORDS 63
+#define RS_SHARD_RECORD_INTS (3 + RS_SHARD_MAX_WORDS + 2)   /* 68 int32 = 272 bytes */
+#define RS_SHARD_ABSENT 1
+int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int32_t *utt_model, const int16_t *const *pcm,
+                            const int32_t *n_samples, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm,
+                            int32_t *records);
+
 /* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
  * (n x D_iv: one row offline, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */
 int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float **data, int32_t *rows, int32_t *cols);

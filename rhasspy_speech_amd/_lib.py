@@ -29,7 +29,7 @@ class DecodeOpts(C.Structure):
 
 EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
-    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_stream_open", "rs_stream_accept",
+    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_stream_open", "rs_stream_accept",
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
@@ -54,6 +54,8 @@ def load_library() -> C.CDLL:
     lib.rs_model_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.rs_decode_batch.argtypes = [vp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, f32, C.POINTER(vp)]
     lib.rs_decode_batch_device.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, i32, f32, vp, C.POINTER(vp)]
+    lib.rs_decode_batch_sharded.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, i32, vp,
+                                            C.POINTER(i32)]
     lib.rs_stream_open.argtypes = [vp, C.POINTER(vp)]
     lib.rs_stream_accept.argtypes = [vp, C.POINTER(C.c_int16), i32]
     lib.rs_stream_finish.argtypes = [vp, i32, f32, C.POINTER(vp)]
@@ -244,6 +246,34 @@ class Model:
         return Result(out)
 
 
+SHARD_MAX_WORDS = 63
+SHARD_RECORD_INTS = 3 + SHARD_MAX_WORDS + 2
+SHARD_ABSENT = 1
+
+
+def decode_batch_sharded(models: Sequence[Model], utt_model: Sequence[int], pcm: Sequence[Optional[np.ndarray]], rank: int = 0, world: int = 1,
+                         rccl_comm: int = 0) -> Tuple[np.ndarray, int, str]:
+    """rs_decode_batch_sharded: -> (records (n_utts, SHARD_RECORD_INTS) int32, status of this rank, its error text).
+    pcm[i] may be None for utterances of other ranks.  rccl_comm = ncclComm_t as an integer (0: no collective, own records
+    only).  Never raises for a decode failure: the status travels in the records so that every rank sees it."""
+    n = len(pcm)
+    arrs = [None if (p is None or i % world != rank) else np.ascontiguousarray(p, dtype=np.int16) for i, p in enumerate(pcm)]
+    ptrs = (C.POINTER(C.c_int16) * max(n, 1))()
+    lens = (C.c_int32 * max(n, 1))()
+    for i, a in enumerate(arrs):
+        if a is not None:
+            ptrs[i] = a.ctypes.data_as(C.POINTER(C.c_int16))
+            lens[i] = a.shape[0]
+    um = np.ascontiguousarray(utt_model, dtype=np.int32)
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    rec = np.zeros((n, SHARD_RECORD_INTS), np.int32)
+    st = lib().rs_decode_batch_sharded(handles, len(models), um.ctypes.data_as(C.POINTER(C.c_int32)), ptrs, lens, n, rank, world,
+                                       C.c_void_p(rccl_comm or None), rec.ctypes.data_as(C.POINTER(C.c_int32)))
+    if st == RS_ERR_ARG:
+        _check(st)
+    return rec, st, ("" if st == RS_OK else lib().rs_last_error().decode("utf-8", "replace"))
+
+
 class Stream:
     """Owns an rs_stream: the stdin of one online2-cli-nnet3-decode-faster process."""
 
@@ -267,6 +297,12 @@ class Stream:
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+def advance_streams(streams: Sequence[Stream]) -> None:
+    """rs_streams_advance: run the device work that the audio accepted so far makes possible, batched over the streams."""
+    arr = (C.c_void_p * len(streams))(*[s._h for s in streams])
+    _check(lib().rs_streams_advance(arr, len(streams)))
 
 
 def finish_streams(streams: Sequence[Stream], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:

@@ -10,6 +10,11 @@
 #include "engine.h"
 #include "fuzzy.h"
 
+namespace rs {
+int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
+                       int n_utts, int rank, int world, void *comm, int32_t *records, std::string *error);
+}
+
 namespace {
 thread_local std::string g_last_error;
 
@@ -118,6 +123,22 @@ int rs_decode_batch_device(rs_model *model, const int16_t *d_pcm, const int64_t 
     res->r = std::move(r);
     *out = res;
     return RS_OK;
+  });
+}
+
+int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int32_t *utt_model, const int16_t *const *pcm,
+                            const int32_t *n_samples, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm, int32_t *records) {
+  if (!models || n_models <= 0 || n_utts < 0 || world < 1 || rank < 0 || rank >= world || !records ||
+      (n_utts > 0 && (!utt_model || !pcm || !n_samples)))
+    return ArgError("rs_decode_batch_sharded: bad argument");
+  for (int m = 0; m < n_models; m++) if (!models[m]) return ArgError("rs_decode_batch_sharded: null model");
+  for (int i = 0; i < n_utts; i++)
+    if (utt_model[i] < 0 || utt_model[i] >= n_models) return ArgError("rs_decode_batch_sharded: utt_model entry names no model");
+  return Guard([&]() {
+    std::string err;
+    const int rc = rs::DecodeBatchSharded(models, n_models, utt_model, pcm, n_samples, n_utts, rank, world, rccl_comm, records, &err);
+    if (rc != RS_OK) g_last_error = err;
+    return rc;
   });
 }
 

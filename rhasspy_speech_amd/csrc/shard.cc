@@ -1,0 +1,169 @@
+// rs_decode_batch_sharded: the multi-GPU entry point of SURVEY.md section 8(b)/(e).
+//
+// The reference has no parallelism (one process per utterance, rhasspy_speech/tools.py:117-147), so utterances are
+// independent: utterance i belongs to rank i % world, every rank runs the whole path on its utterances with replicated
+// models (one device batch per model, the models' batches concurrently from one host thread each), and ONE collective --
+// ncclAllGather of fixed 272-byte records over the caller's RCCL communicator -- returns every utterance's 1-best to every
+// rank.  Failures travel inside the records (status field), never around the collective: a rank whose decode failed still
+// takes part in the gather, so no rank is left waiting.
+//
+// RCCL is bound at first use with dlopen("librccl.so.1"): a process that already carries RCCL (torch.distributed's "nccl"
+// backend IS RCCL on ROCm) gets that same copy, so a communicator created there (ProcessGroupNCCL._comm_ptr()) is valid
+// here; a process that never shards never loads it.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <exception>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.h"
+
+namespace rs {
+namespace {
+
+struct Rccl {
+  using AllGatherFn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+  using CountFn = int (*)(void *, int *);
+  using ErrFn = const char *(*)(int);
+  AllGatherFn all_gather = nullptr;
+  CountFn comm_count = nullptr, comm_rank = nullptr;
+  ErrFn error_string = nullptr;
+  std::string load_error;
+  static const Rccl &Get() {
+    static const Rccl r = [] {
+      Rccl x;
+      void *h = nullptr;
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+      }
+      if (!h) { x.load_error = std::string("cannot load RCCL: ") + dlerror(); return x; }
+      x.all_gather = reinterpret_cast<AllGatherFn>(dlsym(h, "ncclAllGather"));
+      x.comm_count = reinterpret_cast<CountFn>(dlsym(h, "ncclCommCount"));
+      x.comm_rank = reinterpret_cast<CountFn>(dlsym(h, "ncclCommUserRank"));
+      x.error_string = reinterpret_cast<ErrFn>(dlsym(h, "ncclGetErrorString"));
+      if (!x.all_gather || !x.comm_count || !x.comm_rank) x.load_error = "RCCL library lacks ncclAllGather / ncclCommCount / ncclCommUserRank";
+      return x;
+    }();
+    return r;
+  }
+};
+constexpr int kNcclInt32 = 2;      // ncclInt32 (rccl.h: ncclDataType_t)
+
+// grow-only device + pinned staging for the gather (a handful of KB; never freed: hipFree would stall every stream)
+struct GatherBuffers {
+  std::mutex mu;
+  int device = -1;
+  int32_t *d_send = nullptr, *d_recv = nullptr, *h_stage = nullptr;
+  size_t send_cap = 0, recv_cap = 0;
+  hipStream_t stream = nullptr;
+};
+GatherBuffers &Buffers() { static GatherBuffers b; return b; }
+
+void FillRecord(int32_t *rec, int utt, const UttResult &ur) {
+  std::memset(rec, 0, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+  rec[0] = utt;
+  rec[1] = ur.status;
+  if (ur.status != RS_OK || ur.hyps.empty()) { if (ur.status == RS_OK) rec[1] = RS_ERR_DECODE; return; }
+  const Hypothesis &h = ur.hyps[0];
+  rec[2] = (int32_t)h.words.size();                       // the full length: > RS_SHARD_MAX_WORDS tells the reader it was cut
+  const size_t n = std::min<size_t>(h.words.size(), RS_SHARD_MAX_WORDS);
+  std::memcpy(rec + 3, h.words.data(), sizeof(int32_t) * n);
+  std::memcpy(rec + 3 + RS_SHARD_MAX_WORDS, &h.graph_cost, 4);
+  std::memcpy(rec + 4 + RS_SHARD_MAX_WORDS, &h.acoustic_cost, 4);
+}
+
+}  // namespace
+
+// returns RS_OK, or the first per-model failure of this rank (after the collective has run)
+int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
+                       int n_utts, int rank, int world, void *comm, int32_t *records, std::string *error) {
+  if (comm) {     // a communicator that contradicts rank / world is refused before anything is launched (nobody would be left waiting)
+    const Rccl &nc = Rccl::Get();
+    if (!nc.load_error.empty()) throw DeviceError(nc.load_error);
+    int cn = 0, cr = -1;
+    if (nc.comm_count(comm, &cn) != 0 || nc.comm_rank(comm, &cr) != 0 || cn != world || cr != rank)
+      throw Error("rs_decode_batch_sharded: rank/world (" + std::to_string(rank) + "/" + std::to_string(world) +
+                  ") do not match the communicator's (" + std::to_string(cr) + "/" + std::to_string(cn) + ")");
+  }
+  const int per = (n_utts + world - 1) / world;           // records per rank in the gather (short shards are padded)
+  std::vector<std::vector<int>> mine(n_models);
+  for (int i = rank; i < n_utts; i += world) mine[utt_model[i]].push_back(i);
+  // ---- this rank's utterances: one device batch per model, the batches of different models concurrently
+  std::vector<std::unique_ptr<Result>> results(n_models);
+  std::vector<std::string> errs(n_models);
+  std::vector<int> codes(n_models, RS_OK);
+  auto run = [&](int m) {
+    if (mine[m].empty()) return;
+    try {
+      std::vector<const int16_t *> p;
+      std::vector<int32_t> n;
+      for (int i : mine[m]) { p.push_back(pcm[i]); n.push_back(n_samples[i]); }
+      results[m] = models[m]->m->DecodeBatchHost(p.data(), n.data(), (int)p.size(), 1, 1.0f);
+    } catch (const DeviceError &e) { errs[m] = e.what(); codes[m] = RS_ERR_DEVICE;
+    } catch (const Error &e) { errs[m] = e.what(); codes[m] = RS_ERR_MODEL;
+    } catch (const std::exception &e) { errs[m] = e.what(); codes[m] = RS_ERR_ARG; }
+  };
+  {
+    std::vector<std::thread> th;
+    int first = -1;
+    for (int m = 0; m < n_models; m++) if (!mine[m].empty()) { if (first < 0) first = m; else th.emplace_back(run, m); }
+    if (first >= 0) run(first);
+    for (auto &t : th) t.join();
+  }
+  std::vector<int32_t> local((size_t)per * RS_SHARD_RECORD_INTS, 0);
+  for (int k = 0; k < per; k++) { local[(size_t)k * RS_SHARD_RECORD_INTS] = -1; local[(size_t)k * RS_SHARD_RECORD_INTS + 1] = RS_SHARD_ABSENT; }
+  int rc = RS_OK;
+  for (int m = 0; m < n_models; m++) {
+    if (codes[m] != RS_OK && rc == RS_OK) { rc = codes[m]; if (error) *error = errs[m]; }
+    for (size_t k = 0; k < mine[m].size(); k++) {
+      const int i = mine[m][k];
+      int32_t *rec = &local[(size_t)((i - rank) / world) * RS_SHARD_RECORD_INTS];
+      if (codes[m] != RS_OK) { std::memset(rec, 0, sizeof(int32_t) * RS_SHARD_RECORD_INTS); rec[0] = i; rec[1] = codes[m]; }
+      else FillRecord(rec, i, results[m]->utts[k]);
+    }
+  }
+  // ---- the exchange step
+  for (int i = 0; i < n_utts; i++) {
+    int32_t *rec = records + (size_t)i * RS_SHARD_RECORD_INTS;
+    std::memset(rec, 0, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+    rec[0] = i; rec[1] = RS_SHARD_ABSENT;
+  }
+  auto scatter = [&](const int32_t *block, int nrec) {
+    for (int k = 0; k < nrec; k++) {
+      const int32_t *rec = block + (size_t)k * RS_SHARD_RECORD_INTS;
+      if (rec[0] >= 0 && rec[0] < n_utts) std::memcpy(records + (size_t)rec[0] * RS_SHARD_RECORD_INTS, rec, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+    }
+  };
+  if (comm == nullptr) {     // one rank without a communicator, or the caller gathers by other means: this rank's records only
+    scatter(local.data(), per);
+    return rc;
+  }
+  const Rccl &nc = Rccl::Get();
+  GatherBuffers &gb = Buffers();
+  std::lock_guard<std::mutex> lk(gb.mu);
+  const int dev = models[0]->m->opts().device_id;
+  RS_HIP(hipSetDevice(dev));
+  if (gb.device != dev) { gb.device = dev; gb.d_send = gb.d_recv = gb.h_stage = nullptr; gb.send_cap = gb.recv_cap = 0; gb.stream = nullptr; }
+  if (!gb.stream) RS_HIP(hipStreamCreateWithFlags(&gb.stream, hipStreamNonBlocking));
+  const size_t send_bytes = local.size() * sizeof(int32_t), recv_bytes = send_bytes * world;
+  if (send_bytes > gb.send_cap || recv_bytes > gb.recv_cap) {
+    gb.send_cap = send_bytes * 2; gb.recv_cap = recv_bytes * 2;
+    RS_HIP(hipMalloc((void **)&gb.d_send, gb.send_cap));
+    RS_HIP(hipMalloc((void **)&gb.d_recv, gb.recv_cap));
+    RS_HIP(hipHostMalloc((void **)&gb.h_stage, gb.recv_cap, hipHostMallocDefault));
+  }
+  std::memcpy(gb.h_stage, local.data(), send_bytes);
+  RS_HIP(hipMemcpyAsync(gb.d_send, gb.h_stage, send_bytes, hipMemcpyHostToDevice, gb.stream));
+  const int nr = nc.all_gather(gb.d_send, gb.d_recv, local.size(), kNcclInt32, comm, gb.stream);
+  if (nr != 0) throw DeviceError(std::string("ncclAllGather failed: ") + (nc.error_string ? nc.error_string(nr) : std::to_string(nr).c_str()));
+  RS_HIP(hipMemcpyAsync(gb.h_stage, gb.d_recv, recv_bytes, hipMemcpyDeviceToHost, gb.stream));
+  RS_HIP(hipStreamSynchronize(gb.stream));
+  scatter(gb.h_stage, per * world);
+  return rc;
+}
+
+}  // namespace rs

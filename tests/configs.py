@@ -1,0 +1,81 @@
+"""BASELINE.json configs[1..4] at their full sizes: one definition shared by bench.py, the GPU tests and
+oracle/gen_config_golden.py (which runs the REFERENCE binaries on exactly these inputs and stores per-utterance
+transcripts + costs under tests/golden/configs/).
+
+Models, graphs and audio are regenerated from seeds wherever a config is used (numpy Generator streams are stable), so
+the fixtures hold only the reference's outputs.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from rhasspy_speech_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "configs"
+
+N_SAMPLES_3S = 48000
+N_SAMPLES_30S = 30 * 16000
+
+
+def grammar_utterances(n_utts: int = 256, rank: int = 0) -> List[np.ndarray]:
+    """configs[1] (the bench line): 256 synthetic 3 s utterances per rank."""
+    return [synth.synth_utterance(rank * 100000 + u, N_SAMPLES_3S) for u in range(n_utts)]
+
+
+def arpa_utterances(n_utts: int = 256) -> List[np.ndarray]:
+    """configs[2]: 256 x 3 s on the ARPA-LM HCLG."""
+    return [synth.synth_utterance(7000 + u, N_SAMPLES_3S) for u in range(n_utts)]
+
+
+def stream_utterances(n_streams: int = 64) -> List[np.ndarray]:
+    """configs[4]: 64 concurrent 30 s streams (lengths ragged by up to 49 frame shifts)."""
+    rng = np.random.default_rng(4)
+    return [synth.synth_utterance(12000 + i, N_SAMPLES_30S - 160 * int(rng.integers(0, 50))) for i in range(n_streams)]
+
+
+# configs[3]: two independently seeded zamia-size model + graph sets standing in for de_DE-zamia / fr_FR-guyot
+# (SURVEY.md section 8(d)), 512 utterances each, interleaved in one 1024-utterance batch.
+MIXED_MODELS: Dict[str, dict] = {
+    "de_DE-like": dict(model_seed=21, graph_seed=31, audio_base=30000),
+    "fr_FR-like": dict(model_seed=22, graph_seed=32, audio_base=40000),
+}
+
+
+def mixed_utterances(n_per_model: int = 512) -> Tuple[List[str], List[np.ndarray]]:
+    names, pcm = [], []
+    for u in range(n_per_model):
+        for name, m in MIXED_MODELS.items():
+            names.append(name)
+            pcm.append(synth.synth_utterance(m["audio_base"] + u, N_SAMPLES_3S - 320 * (u % 4)))
+    return names, pcm
+
+
+def build_grammar_model(root: Path, model_seed: int = 1, graph_seed: int = 11) -> Tuple[Path, Path]:
+    root = Path(root)
+    model_dir, graph_dir = root / "model", root / "graph"
+    if not (graph_dir / "HCLG.fst").exists():
+        spec = synth.ModelSpec(seed=model_seed)
+        synth.write_model_dir(model_dir, spec)
+        synth.make_grammar_graph(graph_dir, spec, seed=graph_seed)
+    return model_dir, graph_dir
+
+
+def build_arpa_model(root: Path) -> Tuple[Path, Path]:
+    root = Path(root)
+    model_dir, graph_dir = root / "model", root / "graph"
+    if not (graph_dir / "HCLG.fst").exists():
+        spec = synth.ModelSpec()
+        synth.write_model_dir(model_dir, spec)
+        synth.make_arpa_graph(graph_dir, spec, extra_words=600, num_random_sentences=4000)
+    return model_dir, graph_dir
+
+
+def load_golden(name: str):
+    """-> (words: list of word-id lists, graph_cost, acoustic_cost) as the reference produced them."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    off = g["word_offsets"]
+    words = [g["words"][off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    return words, g["graph_cost"], g["acoustic_cost"]

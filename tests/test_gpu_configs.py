@@ -1,12 +1,14 @@
-"""BASELINE.json configs[2..4] at their full sizes on the HIP path (`-m gpu`).
+"""BASELINE.json configs[1..4] at their full sizes on the HIP path (`-m gpu`), every utterance checked against the REFERENCE.
 
-configs[1] is the bench line (bench.py); the other GPU configurations are parity cases:
-  [2] ARPA-LM HCLG (larger FST), 256 x 3 s batch;
-  [3] mixed-model batch (two different models decoded side by side, utterance-sharded);
-  [4] streaming decode, 64 concurrent 30 s streams.
-No golden from the reference exists at these sizes (the reference takes minutes per case), so they are checked through
-size-independent properties -- every utterance of a big batch decodes exactly as it does alone, every decoder variant
-agrees -- plus the CPU oracle (pinned to the reference by tests/test_oracle_golden.py) on a few sampled utterances.
+tests/golden/configs/*.npz hold what the reference binaries (oracle/_ref, built from /root/reference; generator
+oracle/gen_config_golden.py) produce for every utterance of
+  [1] the headline grammar batch (256 x 3 s; the bench line),
+  [2] the ARPA-LM HCLG batch (256 x 3 s),
+  [3] the mixed-model batch: 1024 utterances, two independently seeded zamia-size model + graph sets, 512 each,
+  [4] 64 concurrent 30 s streams (online2-cli-nnet3-decode-faster semantics),
+namely 1-best word ids + nbest-to-linear's graph / acoustic cost.  Transcripts must be equal, costs within 2e-4 relative
+(+2e-3 absolute: the reference's own BLAS-dependent rounding).  Property checks (a batch member
+decodes as it does alone, decoder variants agree) stay beside them.
 """
 from __future__ import annotations
 
@@ -15,30 +17,34 @@ import threading
 import numpy as np
 import pytest
 
+from tests import configs
+
 pytestmark = pytest.mark.gpu
 
 LOGLIKE_TOL = 1e-4
+COST_RTOL, COST_ATOL = 2e-4, 2e-3
 
 
 @pytest.fixture(scope="module")
 def zam_arpa(tmp_path_factory):
     """zamia-like-S acoustic model + a back-off ARPA HCLG (a few thousand states: beyond the register-resident decoder)."""
-    from rhasspy_speech_amd import synth
-    root = tmp_path_factory.mktemp("zam_arpa")
-    spec = synth.ModelSpec()
-    synth.write_model_dir(root / "model", spec)
-    synth.make_arpa_graph(root / "graph", spec, extra_words=600, num_random_sentences=4000)
-    return root / "model", root / "graph"
+    return configs.build_arpa_model(tmp_path_factory.mktemp("zam_arpa"))
 
 
 @pytest.fixture(scope="module")
 def zam_grammar(tmp_path_factory):
-    from rhasspy_speech_amd import synth
-    root = tmp_path_factory.mktemp("zam_grammar")
-    spec = synth.ModelSpec()
-    synth.write_model_dir(root / "model", spec)
-    synth.make_grammar_graph(root / "graph", spec)
-    return root / "model", root / "graph"
+    return configs.build_grammar_model(tmp_path_factory.mktemp("zam_grammar"))
+
+
+def _check_against_reference(name, words_of, costs_of, n):
+    """Every utterance: transcript equal to the reference's, costs within tolerance."""
+    ref_words, ref_g, ref_a = configs.load_golden(name)
+    assert len(ref_words) == n
+    bad = [u for u in range(n) if words_of(u) != ref_words[u]]
+    assert not bad, f"{name}: {len(bad)} of {n} transcripts differ from the reference, first {bad[:5]}: {words_of(bad[0])} vs {ref_words[bad[0]]}"
+    got = np.array([costs_of(u) for u in range(n)], np.float64)
+    np.testing.assert_allclose(got[:, 0], ref_g, rtol=COST_RTOL, atol=COST_ATOL, err_msg=f"{name}: graph costs")
+    np.testing.assert_allclose(got[:, 1], ref_a, rtol=COST_RTOL, atol=COST_ATOL, err_msg=f"{name}: acoustic costs")
 
 
 def _same_result(a, i, b, j):
@@ -48,31 +54,102 @@ def _same_result(a, i, b, j):
     np.testing.assert_array_equal(a.costs(i), b.costs(j))
 
 
+def test_config1_headline_batch_vs_reference(zam_grammar):
+    """The bench line's batch (rank 0): all 256 transcripts and costs equal the reference's, through both entry points."""
+    import torch
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    pcms = configs.grammar_utterances()
+    res = model.decode_batch(pcms)
+    _check_against_reference("c1_grammar", res.words, res.costs, len(pcms))
+    d_pcm = torch.from_numpy(np.concatenate(pcms)).to("cuda:0")
+    off = np.arange(len(pcms) + 1, dtype=np.int64) * configs.N_SAMPLES_3S
+    dev = model.decode_batch_device(d_pcm.data_ptr(), off)
+    _check_against_reference("c1_grammar", dev.words, dev.costs, len(pcms))
+    # the output layer cut down to the pdfs on HCLG arcs: same transcripts
+    pruned = _lib.Model(*zam_grammar, _lib.default_opts(prune_output_pdfs=1)).decode_batch(pcms)
+    _check_against_reference("c1_grammar", pruned.words, pruned.costs, len(pcms))
+
+
 def test_config2_arpa_hclg_256x3s(zam_arpa):
-    from rhasspy_speech_amd import _lib, synth
-    from oracle import pipeline
+    from rhasspy_speech_amd import _lib
     model_dir, graph_dir = zam_arpa
     model = _lib.Model(model_dir, graph_dir, _lib.default_opts())
     desc = model.describe()
     n_states = int(desc.split("hclg: states=")[1].split()[0])
     assert n_states > 2000, desc           # a larger FST than the grammar graph (625 states)
-    pcms = [synth.synth_utterance(7000 + u, 48000) for u in range(256)]
+    pcms = configs.arpa_utterances()
     batch = model.decode_batch(pcms)
     assert batch.num_utts == 256
+    _check_against_reference("c2_arpa", batch.words, batch.costs, len(pcms))
     # every utterance of the batch decodes exactly as it does alone (sampled)
     for u in (0, 1, 77, 128, 255):
         one = model.decode_batch([pcms[u]])
         _same_result(batch, u, one, 0)
-    # the CPU oracle on a few of them: transcripts exact
-    orc = pipeline.Oracle(model_dir, graph_dir)
-    for u in (3, 200):
-        tr = orc.transcribe(pcms[u])
-        assert batch.words(u) == tr.nbest[0].words
-        np.testing.assert_allclose(batch.costs(u)[:2], [tr.nbest[0].graph_cost, tr.nbest[0].acoustic_cost], rtol=2e-4, atol=2e-3)
     # n-best through the lattice path on a slice of the batch
     nb = model.decode_batch(pcms[:16], nbest=3)
     for u in range(16):
         assert nb.words(u, 0) == batch.words(u)
+
+
+def test_config3_mixed_batch_1024_two_zamia_size_models(tmp_path_factory):
+    """BASELINE configs[3] as specified: 1024 utterances, two independently seeded zamia-size model + graph sets (512 each,
+    interleaved), through the sharded entry point (one rank here; ranks are covered by the gloo test on CPU).  Every
+    transcript and cost against the reference's."""
+    from rhasspy_speech_amd import _lib, shard
+    models = {}
+    for name, m in configs.MIXED_MODELS.items():
+        md, gd = configs.build_grammar_model(tmp_path_factory.mktemp(name.replace("-", "_")), m["model_seed"], m["graph_seed"])
+        models[name] = _lib.Model(md, gd, _lib.default_opts())
+    names, pcms = configs.mixed_utterances()
+    assert len(pcms) == 1024
+    got = shard.decode_mixed_sharded(models, names, pcms)
+    assert sorted(got) == list(range(len(pcms)))
+    for key, tag in (("de_DE-like", "c3_mixed_de"), ("fr_FR-like", "c3_mixed_fr")):
+        idx = [i for i, nm in enumerate(names) if nm == key]
+        _check_against_reference(tag, lambda u: got[idx[u]][0], lambda u: got[idx[u]][1:], len(idx))
+    # the C entry point (rs_decode_batch_sharded) on the same batch, as rank 1 of 2: its half only
+    half = shard.decode_mixed_sharded(models, names, pcms, rank=1, world=2, gather=False)
+    assert sorted(half) == list(range(1, len(pcms), 2))
+    for i in half:
+        assert half[i] == got[i]
+
+
+def test_sharded_entry_point_issues_the_rccl_all_gather(zam_grammar):
+    """rs_decode_batch_sharded with a real ncclComm_t (a one-rank RCCL communicator: the test box has one GPU): the records
+    come back through ncclAllGather on the device and equal the ones of the collective-free call; a too-short utterance
+    travels as a status, not as an exception."""
+    import ctypes as C
+    import torch  # noqa: F401  (loads the process's RCCL, the copy the library binds to)
+    from rhasspy_speech_amd import _lib, shard
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        model = _lib.Model(*zam_grammar, _lib.default_opts())
+        pcms = configs.grammar_utterances(24) + [np.zeros(200, np.int16)]
+        rec, st, msg = _lib.decode_batch_sharded([model], [0] * len(pcms), pcms, 0, 1, comm.value)
+        assert st == 0, msg
+        plain, st2, _ = _lib.decode_batch_sharded([model], [0] * len(pcms), pcms, 0, 1, 0)
+        np.testing.assert_array_equal(rec, plain)
+        got = shard.unpack_records(rec, len(pcms))
+        assert got.errors == {24: _lib.RS_ERR_DECODE}
+        ref_words, ref_g, ref_a = configs.load_golden("c1_grammar")
+        for u in range(24):
+            assert got[u][0] == ref_words[u]
+        # rank / world that contradict the communicator are refused before anything is launched
+        _, st3, msg3 = _lib.decode_batch_sharded([model], [0] * len(pcms), pcms, 1, 2, comm.value)
+        assert st3 != 0 and "communicator" in msg3
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
 
 
 def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
@@ -123,13 +200,13 @@ def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
 
 
 def test_config4_64_streams_30s(zam_grammar):
-    from rhasspy_speech_amd import _lib, synth
+    from rhasspy_speech_amd import _lib
     from oracle import pipeline
     model_dir, graph_dir = zam_grammar
     model = _lib.Model(model_dir, graph_dir, _lib.default_opts(keep_intermediates=1))
-    n_streams, n_samples = 64, 30 * 16000
+    pcms = configs.stream_utterances()
+    n_streams = len(pcms)
     rng = np.random.default_rng(4)
-    pcms = [synth.synth_utterance(12000 + i, n_samples - 160 * int(rng.integers(0, 50))) for i in range(n_streams)]
     streams = [_lib.Stream(model) for _ in pcms]
     # ragged, interleaved delivery (2048-byte reads like transcribe_stream.py, but of varying size per stream)
     pos = [0] * n_streams
@@ -139,15 +216,18 @@ def test_config4_64_streams_30s(zam_grammar):
                 n = int(rng.integers(512, 40000))
                 s.accept(pcms[i][pos[i]:pos[i] + n].tobytes())
                 pos[i] += n
+        _lib.advance_streams(streams)
     batch = _lib.finish_streams(streams)
     assert batch.num_utts == n_streams
+    # every stream against the reference's streaming binary
+    _check_against_reference("c4_streams", batch.words, batch.costs, n_streams)
     for i in (0, 31, 63):          # a stream alone gives the same result, bit for bit
         s = _lib.Stream(model)
         s.accept(pcms[i])
         one = s.finish()
         _same_result(batch, i, one, 0)
         np.testing.assert_array_equal(batch.matrix(i, 2), one.matrix(0, 2))
-    # CPU oracle (streaming semantics of online2-cli-nnet3-decode-faster) on one stream
+    # CPU oracle (streaming semantics of online2-cli-nnet3-decode-faster) on one stream: log-likelihoods
     orc = pipeline.Oracle(model_dir, graph_dir)
     tr = orc.transcribe_stream(pcms[5])
     assert batch.words(5) == tr.nbest[0].words

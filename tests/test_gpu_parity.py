@@ -171,7 +171,7 @@ def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
             np.testing.assert_array_equal(got.matrix(u, 2), ref.matrix(u, 2))
 
 
-STREAM_CASES = [n for n in cases.CASES if n not in ("zam_u1",)]
+STREAM_CASES = list(cases.CASES)
 
 
 @pytest.mark.parametrize("name", STREAM_CASES)

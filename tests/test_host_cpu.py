@@ -130,7 +130,7 @@ rank, world, n = dist.get_rank(), dist.get_world_size(), 11
 idx = shard.shard_indices(n, rank, world)
 words = [[i, i + 1, 7 * i % 13] [: 1 + i % 3] for i in idx]          # stand-in for the decoder's output
 costs = [(float(i) + 0.5, -float(i) * 2.0) for i in idx]
-got = shard.gather_records(shard.pack_records(idx, words, costs), n)
+got = shard.unpack_records(shard.gather_records(shard.pack_records(idx, words, costs), n), n)
 assert sorted(got) == list(range(n)), got
 for i in range(n):
     assert got[i] == ([i, i + 1, 7 * i % 13][: 1 + i % 3], float(i) + 0.5, -float(i) * 2.0), (i, got[i])
@@ -158,6 +158,42 @@ try:
     raise SystemExit("an unknown model name must be an error")
 except KeyError:
     pass
+# a hypothesis longer than the record: cut to MAX_WORDS ids and FLAGGED, not silently shortened
+class Long(Fake):
+    def decode_batch(self, pcm):
+        class R:
+            def words(self, u): return list(range(100 + u))
+            def costs(self, u): return (1.0, 2.0)
+        return R()
+got = shard.decode_mixed_sharded({"de": Long(0)}, ["de"] * 4, pcm[:4], rank, world)
+assert got.truncated == {0, 1, 2, 3} and got.num_words[3] == 101 and got[2][0] == list(range(shard.MAX_WORDS))
+# one utterance fails on one rank (the reference's "decoded no frames"): reported per utterance on every rank, nobody hangs
+class OneBad(Fake):
+    def decode_batch(self, pcm):
+        inner = super().decode_batch(pcm)
+        class R:
+            def words(self, u):
+                if len(pcm[u]) == 5 + 3:
+                    e = RuntimeError("You cannot get a lattice if you decoded no frames."); e.status = -4; raise e
+                return inner.words(u)
+            def costs(self, u): return inner.costs(u)
+        return R()
+got = shard.decode_mixed_sharded({"de": OneBad(1)}, ["de"] * n, pcm, rank, world)
+assert got.errors == {3: -4} and sorted(got) == [i for i in range(n) if i != 3]
+# a whole batch fails on ONE rank only: every rank takes part in the gather and every rank raises
+class RankBad(Fake):
+    def decode_batch(self, pcm):
+        if rank == 1:
+            raise RuntimeError("HIP error: device lost")
+        return super().decode_batch(pcm)
+try:
+    shard.decode_mixed_sharded({"de": RankBad(1)}, ["de"] * n, pcm, rank, world)
+    raise SystemExit("a failed rank must raise on every rank")
+except shard.ShardError as e:
+    assert "utterance 1" in str(e), str(e)
+# gather=False: this rank's utterances only, no collective
+got = shard.decode_mixed_sharded(models, names, pcm, rank, world, gather=False)
+assert sorted(got) == list(range(rank, n, world))
 dist.destroy_process_group()
 print("ok", rank)
 '''
