@@ -78,3 +78,33 @@ def test_oracle_streaming_matches_reference(oracles, name):
     sr, sc = g["loglikes_stride"]          # big cases keep a strided sample of the log-likelihood matrix
     assert np.abs(tr.loglikes[::sr, ::sc] - g["stream_loglikes"]).max() < 1e-4
     assert tr.text() == bytes(g["stream_nbest_text"])
+
+
+# ---- full-size configurations (tests/configs.py): the restatement against the reference's per-utterance goldens on samples
+@pytest.mark.parametrize("config,utts", [("c1_grammar", (0, 131, 255)), ("c2_arpa", (3, 162)), ("c3_mixed_de", (7,)), ("c3_mixed_fr", (500,)),
+                                         ("c4_streams", (5,))])
+def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
+    """c2_arpa utterance 162 is the case where the reference's order-dependent pruning (tokens created under a running
+    next_cutoff, lattice-faster-decoder.cc:774-787) changes the best path's cost: oracle/decoder.c follows the HashList
+    iteration order and must land on the reference's cost there (the HIP kernels do not, see test_gpu_configs.py)."""
+    from oracle import pipeline
+    from tests import configs
+    ref_words, ref_g, ref_a = configs.load_golden(config)
+    root = tmp_path_factory.mktemp(config)
+    if config == "c2_arpa":
+        md, gd = configs.build_arpa_model(root)
+        pcms = configs.arpa_utterances()
+    elif config.startswith("c3_mixed"):
+        key = "de_DE-like" if config.endswith("de") else "fr_FR-like"
+        m = configs.MIXED_MODELS[key]
+        md, gd = configs.build_grammar_model(root, m["model_seed"], m["graph_seed"])
+        names, allp = configs.mixed_utterances()
+        pcms = [p for nm, p in zip(names, allp) if nm == key]
+    else:
+        md, gd = configs.build_grammar_model(root)
+        pcms = configs.stream_utterances() if config == "c4_streams" else configs.grammar_utterances()
+    orc = pipeline.Oracle(md, gd)
+    for u in utts:
+        tr = orc.transcribe_stream(pcms[u]) if config == "c4_streams" else orc.transcribe(pcms[u])
+        assert tr.nbest[0].words == ref_words[u], (config, u)
+        np.testing.assert_allclose([tr.nbest[0].graph_cost, tr.nbest[0].acoustic_cost], [ref_g[u], ref_a[u]], rtol=2e-4, atol=2e-3)
