@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds decoded per wall-second (RTF^-1) of the transcribe hot path.
 
-Workload at N=1 = BASELINE.json configs[1]: "en_US-zamia grammar HCLG, batch of 256 synthetic 3 s utterances on 1
-MI355X".  No real zamia model exists offline, so the model is the synthetic "zamia-like-S" of SURVEY.md section
-8(d) written in genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iVector with a
-512-Gaussian UBM, 7x250 TDNN + prefinal, 2000 pdfs) and a grammar HCLG; audio is synthetic (seeded).  A "step" is
-one pass of the whole path (MFCC -> iVector -> TDNN -> beam search -> word ids) over the 256-utterance batch,
-with the int16 samples already resident in HBM when the timed region starts.  The K timed steps are submitted from a few
-host threads (`--inflight`, default 4) so that consecutive batches overlap on the device, as a serving process would run
-them: the latency-bound search of one batch shares the CUs with the GEMMs of the next.  Every step's result records are
-checked against the first step's (same input), and every step is complete before the closing synchronize + barrier.
-Stage times and the roofline are taken from un-overlapped calls made right after the timed region (`--inflight 1` gives
-the one-call-at-a-time figure for the whole step).
+`--workload` selects one of BASELINE.json's GPU configurations (tests/configs.py holds their inputs; every utterance of
+each is pinned to the reference's transcript in tests/test_gpu_configs.py):
+  grammar (default, configs[1], the headline): zamia-like-S model, grammar HCLG, 256 x 3 s utterances per GPU;
+  arpa    (configs[2]): the same model on the back-off ARPA HCLG, 256 x 3 s;
+  mixed   (configs[3]): 1024 utterances naming two zamia-size models, sharded over the ranks, one gather;
+  streams (configs[4]): 64 concurrent 30 s streams fed in 1024-sample ticks round-robin (rs_stream_* entry points).
+No real zamia model exists offline, so the model is the synthetic "zamia-like-S" of SURVEY.md section 8(d) written in
+genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iVector with a 512-Gaussian UBM, 7x250
+TDNN + prefinal, 2000 pdfs); audio is synthetic (seeded).
 
-Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`):
-utterances shard embarrassingly, one process per GPU, each rank decodes its own 256-utterance batch (weak
-scaling, no data-path collective); fixed-size result records are gathered over RCCL (all_gather) after the
-timed region's compute, inside the timed region.
+A "step" is one pass of the whole path (MFCC -> iVector -> TDNN -> beam search -> word ids) over the workload's batch.
+`value` counts steps whose int16 samples are resident in HBM when the timed region starts (rs_decode_batch_device); the
+same run also times the boundary as SURVEY.md section 8(d) words it -- PCM in HOST memory -> word ids in host memory,
+rs_decode_batch -- and reports it as `host_pcm` (PCIe-inclusive; for `streams` and `mixed` the entry points take host
+buffers, so there `value` IS the host-buffer figure and says so).  The K timed steps are submitted from a few host threads
+(`--inflight`, default 4) so that consecutive batches overlap on the device, as a serving process would run them.  Every
+step's records are checked against the first step's and -- rank 0 -- against the REFERENCE's transcripts
+(tests/golden/configs).  Stage times and the roofline are taken from un-overlapped calls right after the timed region.
+
+Multi-GPU (driver: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): utterances shard
+embarrassingly, one process per GPU, weak scaling, no data-path collective; fixed-size result records are gathered over
+RCCL (all_gather) inside the timed region.
 
 Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
 
 import argparse
+import concurrent.futures
 import json
 import os
 import subprocess
@@ -36,20 +43,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-N_UTTS = 256
-N_SAMPLES = 48000          # 3 s @ 16 kHz
-MAX_WORDS = 62             # result record: 64 x int32 = [n_words, words..., pad] + 2 floats
-
-
-def build_workload(root: Path, n_utts: int, rank: int):
-    from rhasspy_speech_amd import synth
-    spec = synth.ModelSpec()
-    model_dir, graph_dir = root / "model", root / "graph"
-    if not (graph_dir / "HCLG.fst").exists():
-        synth.write_model_dir(model_dir, spec)
-        synth.make_grammar_graph(graph_dir, spec)
-    pcm = np.stack([synth.synth_utterance(rank * 100000 + u, N_SAMPLES) for u in range(n_utts)])
-    return spec, model_dir, graph_dir, pcm
+MAX_WORDS = 62             # rs_result_pack record: status, n_words, 62 word ids, 2 float costs = 264 B
 
 
 def nnet_flops_per_row(desc: str) -> float:
@@ -62,103 +56,110 @@ def nnet_flops_per_row(desc: str) -> float:
     return fl
 
 
-def gemm_traffic_bytes(n_gemm: int):
-    """HBM bytes per nnet GEMM launch from the committed PMC passes (profiles/collect.sh -> profiles/r01/bench_v4_pmc.json):
-    FETCH_SIZE (KB, doubled: this rocprofv3 tallies the 128-B requests of a 16 B/lane streaming read at 64 B) + WRITE_SIZE
-    (KB), averaged over the launches of the nnet stage.  None when the summary is absent."""
-    path = ROOT / "profiles" / "r01" / "bench_v4_pmc.json"
+def pmc_traffic(workload: str, kernel_substr: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round
+    (profiles/collect.sh -> profiles/r02/<workload>_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KB, the doubling per
+    MI355X_MICROARCH.md (128-B requests of streaming reads tallied at 64 B on gfx950).  None when no summary of this round
+    is committed for the workload -- the line never carries a stale figure."""
+    path = ROOT / "profiles" / "r02" / f"{workload}_pmc.json"
     if not path.exists():
-        return None
+        return None, None
     ks = json.loads(path.read_text())["kernels"]
     tot, n = 0.0, 0
     for name, c in ks.items():
-        if "GemmKernel" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c or "<2, 4, 1" in name or "<1, 4, 1" in name or "GemmKernelDma" in name:
-            continue        # the narrow (BN = 64) instantiations are the two iVector LDA launches, not the nnet stage
+        if kernel_substr not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
         tot += (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0 * c["FETCH_SIZE"]["launches"]
         n += c["FETCH_SIZE"]["launches"]
-    return tot / n if n else None
+    return (tot / n, str(path.relative_to(ROOT))) if n else (None, None)
 
 
-def cpu_baseline(model_dir: Path, graph_dir: Path, pcm: np.ndarray, seconds_budget: float = 20.0):
-    """Times the REFERENCE itself (oracle/_ref Kaldi binaries built from /root/reference by oracle/build_ref.sh)
-    on this box's host cores on a bounded sample of the same workload: the 3-process pipeline of
-    transcribe_wav.py:45-75, one utterance per pipeline invocation, one pipeline at a time (1 core)."""
+def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, seconds_budget: float = 20.0):
+    """Times the REFERENCE itself (oracle/_ref Kaldi binaries built from /root/reference by oracle/build_ref.sh) on this
+    box's host cores on a bounded sample of the same workload: the pipeline of transcribe_wav.py:45-75 (or, for streams,
+    transcribe_stream.py:53-99), one utterance per pipeline invocation, one pipeline at a time (1 core)."""
     from rhasspy_speech_amd import synth
     bin_dir = ROOT / "oracle" / "_ref" / "bin"
-    exe = bin_dir / "online2-wav-nnet3-latgen-faster"
-    if not exe.exists():
+    if not (bin_dir / "online2-wav-nnet3-latgen-faster").exists():
         return None
-    # one BLAS thread per process: "cores" below is then what the processes really use (the OpenBLAS the oracle build links
-    # would otherwise start a thread per host core in every process)
+    # one BLAS thread per process: "cores" below is then what the processes really use
     env = dict(os.environ, PATH=f"{bin_dir}:{os.environ['PATH']}", OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
     conf = model_dir / "model" / "online" / "conf" / "online.conf"
+    dec = "--max-active=7000 --lattice-beam=8.0 --acoustic-scale=1.0 --beam=24.0"
+    tail = "lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | nbest-to-linear ark:- ark:/dev/null ark,t:-"
     n_done, audio, t0 = 0, 0.0, time.perf_counter()
     with tempfile.TemporaryDirectory() as td:
-        while n_done < pcm.shape[0] and (time.perf_counter() - t0) < seconds_budget and n_done < 64:
-            wav = Path(td) / "u.wav"
-            synth.write_wav(wav, pcm[n_done])
-            cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false "
-                   f"--word-symbol-table={graph_dir}/words.txt --config={conf} --max-active=7000 --lattice-beam=8.0 "
-                   f"--acoustic-scale=1.0 --beam=24.0 {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst "
-                   f"'ark:echo utt utt|' 'scp:echo utt {wav}|' ark:- | lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | "
-                   f"nbest-to-linear ark:- ark:/dev/null ark,t:-")
-            r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        while n_done < len(pcms) and (time.perf_counter() - t0) < seconds_budget and n_done < 64:
+            p = pcms[n_done]
+            if streaming:
+                cmd = (f"online2-cli-nnet3-decode-faster --config={conf} {dec} {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst "
+                       f"{graph_dir}/words.txt ark:- | {tail}")
+                r = subprocess.run(["bash", "-c", cmd], env=env, input=np.asarray(p, "<i2").tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            else:
+                wav = Path(td) / "u.wav"
+                synth.write_wav(wav, p)
+                cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false --word-symbol-table={graph_dir}/words.txt "
+                       f"--config={conf} {dec} {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst 'ark:echo utt utt|' 'scp:echo utt {wav}|' ark:- | {tail}")
+                r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             if r.returncode != 0:
                 return None
             n_done += 1
-            audio += pcm.shape[1] / 16000.0
+            audio += len(p) / 16000.0
         wall = time.perf_counter() - t0
-        # Beside it: the same binaries fed a table of utterances, so the model and HCLG load once -- the reference's decode
-        # rate without its per-call start-up (not how rhasspy-speech calls them, but the fairer figure for the kernels).
-        n_tab = min(16, pcm.shape[0])
-        for i in range(n_tab):
-            synth.write_wav(Path(td) / f"t{i}.wav", pcm[i])
-        (Path(td) / "wav.scp").write_text("".join(f"utt{i} {td}/t{i}.wav\n" for i in range(n_tab)))
-        (Path(td) / "spk2utt").write_text("".join(f"utt{i} utt{i}\n" for i in range(n_tab)))
-        cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false "
-               f"--word-symbol-table={graph_dir}/words.txt --config={conf} --max-active=7000 --lattice-beam=8.0 "
-               f"--acoustic-scale=1.0 --beam=24.0 {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst "
-               f"ark:{td}/spk2utt scp:{td}/wav.scp ark:- | lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | "
-               f"nbest-to-linear ark:- ark:/dev/null ark,t:-")
-        t1 = time.perf_counter()
-        r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        wall_tab = time.perf_counter() - t1
-        steady = None
-        if r.returncode == 0 and len(r.stdout.decode().splitlines()) == n_tab:
-            steady = {"value": n_tab * pcm.shape[1] / 16000.0 / wall_tab, "unit": "audio-seconds/s", "cores": 1,
-                      "sample": f"{n_tab} utterances through ONE pipeline invocation (model + HCLG loaded once)"}
-        # ... and on all host cores, the way a Kaldi deployment scales: one such single-load pipeline per core, side by side
-        # (SURVEY.md section 8(d)); every worker decodes the same table.
-        n_workers = max(1, min(os.cpu_count() or 1, 64))
-        all_cores = None
-        if steady is not None:
-            t2 = time.perf_counter()
-            procs = [subprocess.Popen(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(n_workers)]
-            outs = [p.communicate()[0] for p in procs]
-            wall_all = time.perf_counter() - t2
-            if all(p.returncode == 0 for p in procs) and all(len(o.decode().splitlines()) == n_tab for o in outs):
-                all_cores = {"value": n_workers * n_tab * pcm.shape[1] / 16000.0 / wall_all, "unit": "audio-seconds/s", "cores": n_workers,
-                             "sample": f"{n_workers} single-load pipelines side by side, {n_tab} utterances each"}
+        steady = all_cores = None
+        if not streaming:
+            # Beside it: the same binaries fed a table of utterances, so the model and HCLG load once -- the reference's decode
+            # rate without its per-call start-up (not how rhasspy-speech calls them, but the fairer figure for the kernels).
+            n_tab = min(16, len(pcms))
+            for i in range(n_tab):
+                synth.write_wav(Path(td) / f"t{i}.wav", pcms[i])
+            (Path(td) / "wav.scp").write_text("".join(f"utt{i} {td}/t{i}.wav\n" for i in range(n_tab)))
+            (Path(td) / "spk2utt").write_text("".join(f"utt{i} utt{i}\n" for i in range(n_tab)))
+            cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false --word-symbol-table={graph_dir}/words.txt "
+                   f"--config={conf} {dec} {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst ark:{td}/spk2utt scp:{td}/wav.scp ark:- | {tail}")
+            tab_audio = sum(len(pcms[i]) for i in range(n_tab)) / 16000.0
+            t1 = time.perf_counter()
+            r = subprocess.run(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall_tab = time.perf_counter() - t1
+            if r.returncode == 0 and len(r.stdout.decode().splitlines()) == n_tab:
+                steady = {"value": tab_audio / wall_tab, "unit": "audio-seconds/s", "cores": 1,
+                          "sample": f"{n_tab} utterances through ONE pipeline invocation (model + HCLG loaded once)"}
+                # ... and on all host cores, the way a Kaldi deployment scales: one such single-load pipeline per core
+                n_workers = max(1, min(os.cpu_count() or 1, 64))
+                t2 = time.perf_counter()
+                procs = [subprocess.Popen(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(n_workers)]
+                outs = [p.communicate()[0] for p in procs]
+                wall_all = time.perf_counter() - t2
+                if all(p.returncode == 0 for p in procs) and all(len(o.decode().splitlines()) == n_tab for o in outs):
+                    all_cores = {"value": n_workers * tab_audio / wall_all, "unit": "audio-seconds/s", "cores": n_workers,
+                                 "sample": f"{n_workers} single-load pipelines side by side, {n_tab} utterances each"}
     return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference",
-            "sample": f"{n_done} of the {pcm.shape[0]} utterances, one transcribe_wav.py-style 3-process pipeline per "
-                      f"utterance (model + HCLG re-loaded every call, as the reference does)",
+            "sample": f"{n_done} of the {len(pcms)} utterances, one reference pipeline per utterance "
+                      f"({'online2-cli-nnet3-decode-faster on stdin' if streaming else 'transcribe_wav.py-style 3-process pipeline'}; model + HCLG "
+                      f"re-loaded every call, as the reference does)",
             "one_load": steady, "all_cores": all_cores}
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--utts", type=int, default=N_UTTS)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: enough for >= 2 s of timed work)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["grammar", "arpa", "mixed", "streams"], default="grammar")
+    ap.add_argument("--utts", type=int, default=None, help="utterances (streams) per GPU; default = the configuration's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="decode calls in flight per rank (host threads on one model; the library gives each its own decode "
                          "context): the latency-bound search of one batch overlaps the GEMMs of the next.  1 = one call at a time")
     ap.add_argument("--prune-output", action="store_true",
                     help="rs_decode_opts.prune_output_pdfs=1: output layer only for the pdfs on HCLG arcs (NOT the default: the "
                          "headline line computes every pdf, as the reference does)")
     args = ap.parse_args()
+    wl = args.workload
+    defaults = {"grammar": (600, 20, 4), "arpa": (40, 3, 2), "mixed": (150, 5, 2), "streams": (12, 2, 1)}[wl]
+    steps = args.steps if args.steps is not None else defaults[0]
+    warmup = args.warmup if args.warmup is not None else defaults[1]
+    inflight = args.inflight if args.inflight is not None else defaults[2]
 
     import torch
     import torch.distributed as dist
@@ -181,50 +182,139 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    from rhasspy_speech_amd import _lib
-    cache = Path(tempfile.gettempdir()) / f"rs_bench_zamia_like_S_rank{rank}"
-    spec, model_dir, graph_dir, pcm = build_workload(cache, args.utts, rank)
-    model = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank, prune_output_pdfs=1 if args.prune_output else 0))
-    model.to_device()
-    desc = model.describe()
-    d_pcm = torch.from_numpy(pcm.reshape(-1)).to(f"cuda:{local_rank}")
-    offsets = np.arange(args.utts + 1, dtype=np.int64) * N_SAMPLES
-    audio_seconds = args.utts * N_SAMPLES / 16000.0
+    from rhasspy_speech_amd import _lib, shard
+    from tests import configs
+    cache = Path(tempfile.gettempdir()) / f"rs_bench_{wl}_rank{rank}"
+    opts = dict(device_id=local_rank, prune_output_pdfs=1 if args.prune_output else 0)
+    golden = None
+    # ---- the workload: models, inputs, one step, and how its records compare with the reference's goldens
+    if wl in ("grammar", "arpa"):
+        n_utts = args.utts or 256
+        model_dir, graph_dir = (configs.build_grammar_model if wl == "grammar" else configs.build_arpa_model)(cache)
+        pcms = configs.grammar_utterances(n_utts, rank) if wl == "grammar" else configs.arpa_utterances(n_utts)
+        model = _lib.Model(model_dir, graph_dir, _lib.default_opts(**opts))
+        model.to_device()
+        models = [model]
+        d_pcm = torch.from_numpy(np.concatenate(pcms)).to(f"cuda:{local_rank}")
+        offsets = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
+        audio_seconds = float(offsets[-1]) / 16000.0
+        if rank == 0 and n_utts == 256:
+            golden = configs.load_golden("c1_grammar" if wl == "grammar" else "c2_arpa")
 
-    def gather(res):
-        rec = res.pack(MAX_WORDS)          # fixed 264-byte records: status, n_words, word ids, graph/acoustic cost
+        def decode():
+            return model.decode_batch_device(d_pcm.data_ptr(), offsets)
+
+        def decode_host():
+            return model.decode_batch(pcms)
+
+        def records(res):
+            return res.pack(MAX_WORDS)
+        workload_name = (f"zamia-like-S synthetic Kaldi model (40-dim MFCC, 100-dim iVector, 7x250 TDNN, 2000 pdfs), "
+                         f"{'grammar' if wl == 'grammar' else 'back-off ARPA-LM'} HCLG, {n_utts} x 3 s utterances per GPU, beam 24 / max-active 7000 / lattice-beam 8")
+    elif wl == "streams":
+        n_utts = args.utts or 64
+        model_dir, graph_dir = configs.build_grammar_model(cache)
+        pcms = configs.stream_utterances(n_utts)
+        model = _lib.Model(model_dir, graph_dir, _lib.default_opts(**opts))
+        model.to_device()
+        models = [model]
+        audio_seconds = sum(len(p) for p in pcms) / 16000.0
+        if rank == 0 and n_utts == 64:
+            golden = configs.load_golden("c4_streams")
+        tick = 1024 * 8          # samples handed over per stream and round: 8 of the binary's 1024-sample reads
+        n_rounds = (max(len(p) for p in pcms) + tick - 1) // tick
+
+        def decode():
+            streams = [_lib.Stream(model) for _ in pcms]
+            for r in range(n_rounds):
+                for s, p in zip(streams, pcms):
+                    if r * tick < len(p):
+                        s.accept(p[r * tick:(r + 1) * tick])
+                _lib.advance_streams(streams)
+            return _lib.finish_streams(streams)
+        decode_host = None
+
+        def records(res):
+            return res.pack(MAX_WORDS)
+        workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU fed in {tick}-sample "
+                         f"rounds (online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one iVector per 24-frame nnet chunk)")
+    else:   # mixed
+        n_per = (args.utts or 1024) // 2
+        names, pcms = configs.mixed_utterances(n_per)
+        by_name = {}
+        for key, m in configs.MIXED_MODELS.items():
+            md, gd = configs.build_grammar_model(Path(str(cache) + "_" + key), m["model_seed"], m["graph_seed"])
+            by_name[key] = _lib.Model(md, gd, _lib.default_opts(**opts))
+            by_name[key].to_device()
+        models = list(by_name.values())
+        model, model_dir, graph_dir = models[0], md, gd
+        n_utts = len(pcms)
+        audio_seconds = sum(len(p) for i, p in enumerate(pcms) if i % world == rank) / 16000.0      # this rank's share (strong split)
+        if rank == 0 and n_per == 512:
+            gd_, gf_ = configs.load_golden("c3_mixed_de"), configs.load_golden("c3_mixed_fr")
+            golden = ([None] * n_utts, np.zeros(n_utts, np.float32), np.zeros(n_utts, np.float32))
+            it = {"de_DE-like": iter(zip(*gd_)), "fr_FR-like": iter(zip(*gf_))}
+            for i, nm in enumerate(names):
+                golden[0][i], golden[1][i], golden[2][i] = next(it[nm])
+        name_idx = {nm: k for k, nm in enumerate(by_name)}
+        utt_model = [name_idx[nm] for nm in names]
+
+        def decode():
+            rec, st, msg = _lib.decode_batch_sharded(models, utt_model, pcms, rank, world, 0)
+            if st != 0:
+                raise SystemExit(f"bench.py: rs_decode_batch_sharded failed: {msg}")
+            return rec
+        decode_host = None
+
+        def records(rec):
+            return rec[rank::world]
+        workload_name = (f"two independently seeded zamia-like-S model + grammar-HCLG sets (de_DE-like / fr_FR-like), {n_utts} x ~3 s utterances "
+                         f"interleaved, utterance i -> rank i % {world} (rs_decode_batch_sharded), one record gather")
+
+    def gather(rec):
         if world > 1:
-            t = torch.from_numpy(rec).to(comm_device)
+            t = torch.from_numpy(np.ascontiguousarray(rec)).to(comm_device)
             out = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(out, t)       # the path's one exchange step: fixed-size result records over RCCL/xGMI
             rec = torch.cat(out).cpu().numpy()
         return rec
 
-    def decode():
-        return model.decode_batch_device(d_pcm.data_ptr(), offsets)
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(inflight, 1))
 
-    import concurrent.futures
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(args.inflight, 1))
-
-    def run_steps(n, check_against=None):
-        """n steps, at most --inflight decode calls in flight; results are consumed (and gathered) in step order."""
-        futures = [pool.submit(decode) for _ in range(n)] if args.inflight > 1 else None
+    def run_steps(n, fn, check_against=None):
+        """n steps, at most `inflight` decode calls in flight; results are consumed (and gathered) in step order."""
+        futures = [pool.submit(fn) for _ in range(n)] if inflight > 1 else None
         last = None
         for k in range(n):
-            res = futures[k].result() if futures else decode()
-            rec = gather(res)
+            res = futures[k].result() if futures else fn()
+            rec = gather(records(res))
             if check_against is not None and not np.array_equal(rec, check_against):
                 raise SystemExit(f"bench.py: step {k} produced different results from the first step on the same input")
             last = (res, rec)
         return last
 
-    res, ref_rec = run_steps(1)
-    run_steps(max(args.warmup - 1, 0), ref_rec)
+    res, ref_rec = run_steps(1, decode)
+    # rank 0's transcripts against the REFERENCE's (tests/golden/configs: oracle/_ref binaries on the same inputs)
+    checked_vs_reference = None
+    if golden is not None:
+        mine = records(res)
+        idx = list(range(rank, n_utts, world)) if wl == "mixed" else list(range(n_utts))
+        wrong = 0
+        for row, i in zip(mine, idx):
+            if wl == "mixed":
+                ok = row[1] == 0 and list(row[3:3 + row[2]]) == list(golden[0][i])
+            else:
+                ok = row[0] == 0 and list(row[2:2 + row[1]]) == list(golden[0][i])
+            wrong += 0 if ok else 1
+        if wrong:
+            raise SystemExit(f"bench.py: {wrong} of {len(idx)} transcripts differ from the reference's (tests/golden/configs)")
+        checked_vs_reference = f"all {len(idx)} transcripts of rank 0 equal the reference's (tests/golden/configs)"
+    run_steps(max(warmup - 1, 0), decode, ref_rec)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, rec = run_steps(args.steps, ref_rec)
+    res, rec = run_steps(steps, decode, ref_rec)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -233,64 +323,82 @@ def main() -> None:
         t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # Stage times and the roofline come from un-overlapped calls made right after the timed region (with two calls in flight
-    # the events around a stage also see the other call's kernels): same process, same buffers, one call at a time.
-    n_iso = 5
-    stage = np.zeros(8)
-    counters = np.zeros(8)
-    for _ in range(n_iso):
-        r1 = decode()
-        stage += np.array(r1.timings())
-    stage /= n_iso
-    for u in range(args.utts):
-        counters += np.array(r1.counters(u), dtype=np.float64)
+    # ---- the same steps from HOST buffers (PCM in host memory -> word ids in host memory)
+    host_pcm = None
+    if decode_host is not None:
+        n_host = max(4, steps // 4)
+        run_steps(2, decode_host, ref_rec)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        run_steps(n_host, decode_host, ref_rec)
+        torch.cuda.synchronize()
+        eh = time.perf_counter() - th
+        host_pcm = {"value": world * audio_seconds * n_host / eh, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * eh / n_host, "steps": n_host,
+                    "note": "rs_decode_batch: int16 PCM in pageable host memory -> word ids in host memory (PCIe-inclusive); this rank's rate x n_gpus"}
+    # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
+    # buffers, one call at a time.
+    stage, counters, n_iso = np.zeros(8), np.zeros(8), 0
+    if wl != "mixed":
+        n_iso = 5 if wl != "streams" else 2
+        for _ in range(n_iso):
+            r1 = decode()
+            stage += np.array(r1.timings())
+        stage /= n_iso
+        for u in range(n_utts):
+            counters += np.array(r1.counters(u), dtype=np.float64)
 
     if rank == 0:
-        ms_per_step = 1000.0 * elapsed / args.steps
-        value = world * audio_seconds * args.steps / elapsed
-        rows = args.utts * 298          # algorithmic: the real frames only (halo rows of the hidden layers are overhead)
-        flops = nnet_flops_per_row(desc) * rows
+        ms_per_step = 1000.0 * elapsed / steps
+        value = (world if wl != "mixed" else 1) * audio_seconds * steps / elapsed
+        if wl == "mixed":
+            value = sum(len(p) for p in pcms) / 16000.0 * steps / elapsed     # the whole 1024-utterance batch per step, all ranks together
+        desc = model.describe()
+        frames = sum(1 + (len(p) - 400) // 160 for p in pcms) if wl != "mixed" else 0
+        flops = nnet_flops_per_row(desc) * frames       # algorithmic: the real frames only (halo rows are overhead)
         n_gemm = sum(1 for l in desc.splitlines() if l.startswith("op: gemm"))
-        # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token
-        # insertions x 16 B (8 B table key read-modify-write twice), tokens alive x 16 B token record
-        dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
-        # dominant kernel: the segmented layer GEMM (one launch per affine layer; GemmKernelB3 for the wide layers: every FP32
-        # product is six bf16 MFMAs on split operands, nnet_gemm_b3.hip).  achieved = ALGORITHMIC FP32 FLOPs of the stage's
-        # launches / their duration, timed with HIP events on the library's stream (rs_result_timings).  peak = the dense
-        # bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 MFMAs per FP32 product = what this formulation can reach;
-        # the exact-FP32 MFMA peak (157.3) is what the previous FP32-input kernel was priced against.
-        split_bf16 = os.environ.get("RS_GEMM_B3", "1") != "0"
-        peak = 2500.0 / 6.0 if split_bf16 else 157.3
-        achieved = flops / (stage[3] * 1e-3) / 1e12
-        roof_mfma = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": gemm_traffic_bytes(n_gemm),
-                     "kernel": (f"GemmKernelB3 (FP32 operands split into 3 bf16 parts, 6 bf16 MFMAs per product, FP32 accumulate), "
-                                f"{n_gemm} launches per step (the nnet stage)") if split_bf16 else f"GemmKernel, {n_gemm} launches per step",
-                     "launches": n_gemm, "avg_launch_ms": float(stage[3]) / n_gemm, "flops_per_launch": flops / n_gemm,
-                     "stage_ms": float(stage[3]), "frac_of_fp32_mfma_peak": achieved / 157.3}
-        roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                    "kernel": "RegDecodeKernel (1 launch, one workgroup per utterance, latency-bound)", "stage_ms": float(stage[4])}
-        roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
         out = {
             "metric": "audio-seconds decoded/sec (RTF^-1) en_US-zamia grammar HCLG", "value": value, "unit": "audio-seconds/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "FP32 results within the same 1e-4 bound as before; the wide layer GEMMs multiply 3-way bf16 splits of the FP32 operands (24 significand bits) on the bf16 matrix cores and accumulate in FP32",
-            "config": {"workload": f"zamia-like-S synthetic Kaldi model (40-dim MFCC, 100-dim iVector, 7x250 TDNN, 2000 pdfs), "
-                                   f"grammar HCLG, {args.utts} x 3 s utterances per GPU, beam 24 / max-active 7000 / lattice-beam 8",
-                       "utts_per_gpu": args.utts, "seconds_per_utt": 3.0, "parallelism": f"utterance-sharded x{world}",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak" if wl != "mixed" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "FP32 results (log-likelihoods within 1e-4 of the reference's); the wide layer GEMMs multiply 3-way bf16 splits of the FP32 operands (24 significand bits) on the bf16 matrix cores and accumulate in FP32",
+            "config": {"workload": workload_name, "utts_per_gpu": n_utts if wl != "mixed" else n_utts // world, "parallelism": f"utterance-sharded x{world}",
                        "output_layer": "pruned to the pdfs on HCLG arcs (--prune-output)" if args.prune_output else "all pdfs",
-                       "calls_in_flight": args.inflight},
-            "results_checked": "every step's result records equal the first step's (same input)",
-            "stages_from": f"{n_iso} un-overlapped calls after the timed region",
-            "roofline": roofline,
-            "stages_ms": {"mfcc": float(stage[1]), "ivector": float(stage[2]), "nnet": float(stage[3]), "decode": float(stage[4]),
-                          "d2h+host": float(stage[5]), "total_call": float(stage[6])},
-            "other_roofline": roof_dec if roofline is roof_mfma else roof_mfma,
+                       "calls_in_flight": inflight,
+                       "inputs": "int16 PCM resident in HBM at the start of the timed region" if decode_host is not None else "int16 PCM in host memory (the entry point takes host buffers)"},
+            "timed_seconds": elapsed,
+            "results_checked": "every step's result records equal the first step's (same input)" + (f"; {checked_vs_reference}" if checked_vs_reference else ""),
+            "host_pcm": host_pcm,
         }
+        if wl != "mixed":
+            # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token insertions x 16 B,
+            # tokens alive x 16 B token record
+            dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
+            split_bf16 = os.environ.get("RS_GEMM_B3", "1") != "0"
+            peak = 2500.0 / 6.0 if split_bf16 else 157.3
+            achieved = flops / (stage[3] * 1e-3) / 1e12 if stage[3] > 0 else 0.0
+            traffic, traffic_from = pmc_traffic(wl, "GemmKernelB3" if split_bf16 else "GemmKernel")
+            roof_mfma = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_from": traffic_from,
+                         "kernel": (f"GemmKernelB3 (FP32 operands split into 3 bf16 parts, 6 bf16 MFMAs per product, FP32 accumulate), "
+                                    f"{n_gemm} launches per step (the nnet stage)") if split_bf16 else f"GemmKernel, {n_gemm} launches per step",
+                         "launches": n_gemm, "avg_launch_ms": float(stage[3]) / n_gemm, "flops_per_launch": flops / n_gemm,
+                         "stage_ms": float(stage[3]), "frac_of_fp32_mfma_peak": achieved / 157.3}
+            dtraffic, dtraffic_from = pmc_traffic(wl, "DecodeKernel")
+            roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9 if stage[4] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                        "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0 if stage[4] > 0 else 0.0, "traffic": dtraffic, "traffic_from": dtraffic_from,
+                        "algorithmic_bytes": dec_bytes,
+                        "kernel": "beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
+            roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
+            out["stages_from"] = f"{n_iso} un-overlapped calls after the timed region"
+            out["roofline"] = roofline
+            out["stages_ms"] = {"mfcc": float(stage[1]), "ivector": float(stage[2]), "nnet": float(stage[3]), "decode": float(stage[4]),
+                                "d2h+host": float(stage[5]), "total_call": float(stage[6])}
+            out["other_roofline"] = roof_dec if roofline is roof_mfma else roof_mfma
+        else:
+            out["roofline"] = None
+            out["roofline_note"] = "the mixed batch runs the grammar workload's kernels on two models side by side; see --workload grammar for the roofline"
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model_dir, graph_dir, pcm)
+            out["cpu_baseline"] = cpu_baseline(model_dir, graph_dir, pcms if wl != "mixed" else [p for nm, p in zip(names, pcms) if nm == list(by_name)[-1]],
+                                               streaming=(wl == "streams"))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

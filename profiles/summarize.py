@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Turns what profiles/collect.sh left under gpurun_out/<tag>/ into the committed summaries profiles/<round>/bench_<ver>_*:
+"""Turns what profiles/collect.sh left under gpurun_out/<tag>_<workload>/ into the committed summaries profiles/<round>/<name>_*
+(name = the workload, optionally with a version suffix, e.g. grammar or grammar_v2):
   *_kernel_stats.csv  rocprofv3 --kernel-trace --stats (copied as is)
   *_line.json         the bench.py line of the un-profiled run
   *_pmc.json          per kernel: mean counter value per launch for every --pmc pass (FETCH_SIZE / WRITE_SIZE in KB as
                       rocprofv3 reports them; bench.py applies the guide's correction)
-usage: python profiles/summarize.py gpurun_out/<tag> profiles/r01 v4
+usage: python profiles/summarize.py gpurun_out/r02_grammar profiles/r02 grammar
 """
 import collections
 import csv
@@ -32,16 +33,16 @@ src, dst, ver = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
 dst.mkdir(parents=True, exist_ok=True)
 stats = glob.glob(str(src / "kt" / "**" / "*kernel_stats.csv"), recursive=True)
 if stats:
-    shutil.copy(stats[0], dst / f"bench_{ver}_kernel_stats.csv")
+    shutil.copy(stats[0], dst / f"{ver}_kernel_stats.csv")
 line = (src / "bench_line.json").read_text().strip().splitlines()[-1]
 json.loads(line)
-(dst / f"bench_{ver}_line.json").write_text(line + "\n")
+(dst / f"{ver}_line.json").write_text(line + "\n")
 for extra in ("pruned_output", "one_call_in_flight"):          # the same bench with one switch changed (collect.sh)
     f = src / f"bench_line_{extra}.json"
     if f.exists() and f.read_text().strip():
         extra_line = f.read_text().strip().splitlines()[-1]
         json.loads(extra_line)
-        (dst / f"bench_{ver}_line_{extra}.json").write_text(extra_line + "\n")
+        (dst / f"{ver}_line_{extra}.json").write_text(extra_line + "\n")
 kernels = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -53,5 +54,5 @@ out = {"note": "rocprofv3 --pmc, separate passes (profiles/collect.sh), bench.py
                "as reported (FETCH_SIZE is doubled by bench.py per MI355X_MICROARCH.md: 128-B requests tallied at 64 B); SQ_* "
                "summed over the device",
        "kernels": {k: {c: {"launches": v[1], "mean": v[0] / v[1]} for c, v in cs.items()} for k, cs in kernels.items()}}
-(dst / f"bench_{ver}_pmc.json").write_text(json.dumps(out, indent=0))
-print("wrote", sorted(p.name for p in dst.glob(f"bench_{ver}_*")))
+(dst / f"{ver}_pmc.json").write_text(json.dumps(out, indent=0))
+print("wrote", sorted(p.name for p in dst.glob(f"{ver}_*")))
