@@ -156,7 +156,7 @@ def main() -> None:
                          "headline line computes every pdf, as the reference does)")
     args = ap.parse_args()
     wl = args.workload
-    defaults = {"grammar": (600, 20, 4), "arpa": (40, 3, 2), "mixed": (150, 5, 2), "streams": (12, 2, 1)}[wl]
+    defaults = {"grammar": (600, 20, 4), "arpa": (40, 3, 2), "mixed": (150, 5, 2), "streams": (40, 2, 1)}[wl]
     steps = args.steps if args.steps is not None else defaults[0]
     warmup = args.warmup if args.warmup is not None else defaults[1]
     inflight = args.inflight if args.inflight is not None else defaults[2]
