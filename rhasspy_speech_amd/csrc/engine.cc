@@ -202,6 +202,7 @@ Model::~Model() {
   for (auto &c : ctx_) {
     if (c->h_pcm_pinned) (void)hipHostFree(c->h_pcm_pinned);
     if (c->d_pcm) (void)hipFree(c->d_pcm);
+    for (auto &ab : c->lat_arcs) if (ab.d) (void)hipFree(ab.d);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream_dec) (void)hipStreamDestroy(c->stream_dec);
@@ -760,15 +761,25 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     need += IvecStatsScratchDoubles(ivec_dev_, n_utts) * 8 + 1024;
   }
   const int S = hclg_.num_states();
+  // decoder selection (before sizing: only the chosen kernel's work buffers are reserved)
+  // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
+  // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
+  const bool unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
+  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || unscale);
+  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
+  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
   int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
   cap_pf = std::min(cap_pf, S);
   const long tok_cap_l = (long)(maxT + 2) * cap_pf;
   if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
   const int tok_cap = (int)tok_cap_l;
   const int max_words = 1024;
-  need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)tok_cap * 16 + (size_t)(maxT + 2) * 4 + (size_t)(maxT + 1) * 16 +
-                            (size_t)max_words * 4 + 4 + 16 + 64) + 65536;
-  need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32) + 4096;   // dense decoder back-pointer rows
+  need += (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
+  if (use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
+    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
+  else                // token-list search: per-state tables, queues, the token arrays of every frame
+    need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
+  if (want_lattice) need += sizeof(float) * (size_t)n_utts * tok_cap + 4096;                                // LatticeKernel's extra_cost
   need += 64 * 256;   // alignment slack
   arena_.Reserve(need + (1u << 20), s);
   arena_.Reset();
@@ -802,19 +813,12 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
   // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
   const int total_frames = frame_base[n_utts];
-  // decoder selection
-  // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
-  // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
   static const int lds_poison = [] { const char *e = std::getenv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
   auto poison = [&]() {
     if (!lds_poison) return;
     static unsigned *sink = [] { unsigned *p = nullptr; (void)hipMalloc((void **)&p, 64); return p; }();
     LaunchLdsPoison(sink, s);
   };
-  const bool unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
-  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || unscale);
-  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
-  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
   // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
   // output GEMM of slab k+1 (MFMA-bound) runs while slab k is searched (latency-bound) on a second, high-priority stream.
   // Measured on the bench batch: 5.07 -> 4.97 ms with 3 slabs -- the search runs at half speed while it shares the CUs
@@ -1100,31 +1104,35 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     auto t_l0 = std::chrono::steady_clock::now();
     LatticeWork lw;
     std::memset(&lw, 0, sizeof(lw));
-    const size_t extra_bytes = sizeof(float) * (size_t)n_utts * tok_cap + 256;
-    size_t cap = 1u << 20;
+    // extra_cost comes from the call's arena; the arc buffer is the context's own, grow-only: no hipMalloc / hipFree (a
+    // device-wide synchronisation that would stall the other calls in flight) in the steady state
+    lw.extra_cost = arena_.AllocT<float>((size_t)n_utts * tok_cap + 64);
+    int *d_count = arena_.AllocT<int>(4);
     std::vector<LatArc> h_arcs;
+    LatArcBuffer &ab = cx.lat_arcs[gi];
     for (int attempt = 0; attempt < 8; attempt++) {
-      float *d_extra = nullptr;
-      LatArc *d_arcs = nullptr;
-      int *d_count = nullptr;
-      RS_HIP(hipMalloc((void **)&d_extra, extra_bytes));
-      RS_HIP(hipMalloc((void **)&d_arcs, sizeof(LatArc) * cap));
-      RS_HIP(hipMalloc((void **)&d_count, sizeof(int)));
-      RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
-      lw.extra_cost = d_extra; lw.arcs = d_arcs; lw.arcs_cap = (int)cap; lw.arcs_count = d_count;
-      LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
-      int count = 0;
-      RS_HIP(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
-      RS_HIP(hipStreamSynchronize(s));
-      bool ok = count <= (int)cap;
-      if (ok) {
-        h_arcs.resize(count);
-        if (count) RS_HIP(hipMemcpy(h_arcs.data(), d_arcs, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost));
+      if (ab.cap == 0) {
+        ab.cap = 1u << 20;
+        RS_HIP(hipMalloc((void **)&ab.d, sizeof(LatArc) * ab.cap));
       }
-      (void)hipFree(d_extra); (void)hipFree(d_arcs); (void)hipFree(d_count);
-      if (ok) break;
-      cap = (size_t)count + (size_t)count / 4 + 1024;
+      RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
+      lw.arcs = static_cast<LatArc *>(ab.d); lw.arcs_cap = (int)ab.cap; lw.arcs_count = d_count;
+      LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
+      int *h_count = harena.AllocT<int>(1);
+      RS_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      RS_HIP(hipStreamSynchronize(s));
+      const int count = *h_count;
+      if (count <= (int)ab.cap) {
+        h_arcs.resize(count);
+        if (count) RS_HIP(hipMemcpyAsync(h_arcs.data(), ab.d, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost, s));
+        RS_HIP(hipStreamSynchronize(s));
+        break;
+      }
       if (attempt == 7) Fail("lattice extraction: arc buffer overflow");
+      RS_HIP(hipFree(ab.d));                     // rare: the lattice outgrew the buffer
+      ab.d = nullptr;
+      ab.cap = (size_t)count + (size_t)count / 4 + 1024;
+      RS_HIP(hipMalloc((void **)&ab.d, sizeof(LatArc) * ab.cap));
     }
     // group by utterance
     std::vector<std::vector<const LatArc *>> per(n_utts);

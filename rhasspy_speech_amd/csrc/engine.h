@@ -78,6 +78,8 @@ struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   std::vector<std::pair<float *, float *>> d_stage;   // scale/offset vectors per stage
 };
 
+struct LatArcBuffer { void *d = nullptr; size_t cap = 0; };      // capacity in LatArc records
+
 class Model {
  public:
   Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf, const rs_decode_opts &opts);
@@ -121,6 +123,7 @@ class Model {
     hipEvent_t slab_ev[9] = {};
     DeviceArena arena[2];                  // one per concurrent utterance group
     HostArena host_arena[2];
+    LatArcBuffer lat_arcs[2];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
     int16_t *h_pcm_pinned = nullptr;       // pinned staging for host-buffer batches
     size_t h_pcm_cap = 0;
     int16_t *d_pcm = nullptr;

@@ -290,14 +290,24 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
   std::map<SubsetKey, int> ids;
   std::vector<SubsetKey> subsets;
   std::vector<double> alpha;          // best forward total of every output state
+  // Subsets are expanded best-first on alpha (as Kaldi's pruned determinisation processes its queue,
+  // determinize-lattice-pruned.cc); a subset that is reached again with a better forward cost after it was expanded is
+  // expanded again, because arcs pruned under the worse alpha may now be inside the beam.
+  std::vector<double> expanded_at;    // alpha the subset was last expanded with (+inf = never)
+  std::priority_queue<std::pair<double, int>, std::vector<std::pair<double, int>>, std::greater<std::pair<double, int>>> todo;
   auto state_of = [&](std::vector<Elem> v, double a) {
     SubsetKey key{std::move(v)};
     auto it = ids.find(key);
-    if (it != ids.end()) { if (a < alpha[it->second]) alpha[it->second] = a; return it->second; }
+    if (it != ids.end()) {
+      if (a < alpha[it->second]) { alpha[it->second] = a; todo.push({a, it->second}); }      // reached more cheaply: expand (again) under the better alpha
+      return it->second;
+    }
     const int id = (int)subsets.size();
     ids.emplace(key, id);
     subsets.push_back(std::move(key));
     alpha.push_back(a);
+    expanded_at.push_back(INF);
+    todo.push({a, id});
     out.arcs.emplace_back();
     out.final_w.emplace_back();
     out.is_final.push_back(0);
@@ -317,16 +327,23 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
       out.is_final.push_back(0);
       subsets.push_back(SubsetKey{});          // placeholder for the extra start state (never expanded)
       alpha.push_back(0.0);
+      expanded_at.push_back(0.0);
       out.start = 0;
       const int s1 = state_of(init, common.graph + common.acoustic);
       out.arcs[0].push_back({s1, 0, common});
     }
   }
-  for (size_t si = 0; si < subsets.size(); si++) {
-    if (subsets[si].elems.empty()) continue;
+  while (!todo.empty()) {
+    const size_t si = (size_t)todo.top().second;
+    const double queued = todo.top().first;
+    todo.pop();
+    if (subsets[si].elems.empty() || queued > alpha[si] || expanded_at[si] <= alpha[si]) continue;      // placeholder / stale entry
     if (subsets.size() > 2000000) Fail("lattice determinisation: too many states");
     const std::vector<Elem> elems = subsets[si].elems;      // copy: `subsets` grows below
     const double a0 = alpha[si];
+    expanded_at[si] = a0;
+    out.arcs[si].clear();
+    out.is_final[si] = 0;
     // final weight
     {
       bool have = false;

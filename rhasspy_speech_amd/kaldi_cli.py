@@ -74,10 +74,13 @@ def read_table(rspecifier: str) -> List[Tuple[str, str]]:
 
 
 def read_wav(path: str) -> np.ndarray:
-    with wave.open(path, "rb") as w:
-        if w.getsampwidth() != 2 or w.getnchannels() != 1:
-            raise ValueError(f"{path}: expected 16-bit mono PCM (wave-reader.cc:199-200)")
-        return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    """WaveData::Read as the binary uses it (16-bit PCM only, wave-reader.cc:199-200; channel 0 of a multi-channel file,
+    online2-wav-nnet3-latgen-faster.cc:216-218) -- the same reader the transcriber uses."""
+    from .transcribe_wav import read_wav_pcm16
+    try:
+        return read_wav_pcm16(path)
+    except RuntimeError as e:
+        raise ValueError(str(e)) from e
 
 
 def open_wspecifier(wspecifier: str):

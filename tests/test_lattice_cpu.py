@@ -151,3 +151,19 @@ def test_reference_tools_list_the_same_paths(seed, tmp_path):
         g, a, tids = want[tuple(p["words"])]
         assert p["ali"] == tids
         assert p["graph"] == pytest.approx(g, abs=1e-3) and p["acoustic"] == pytest.approx(a, abs=1e-3)
+
+
+def test_subset_reached_again_with_a_better_cost_is_expanded_again():
+    """A subset first reached through an expensive arc and expanded under that forward cost, then reached again more cheaply:
+    the arcs pruned the first time must come back (the reference's pruned determinisation works its queue best-first,
+    determinize-lattice-pruned.cc).  S -1(3)-> X, S -2(0)-> Y -3(0)-> X, X -4(0)-> F, X -5(3)-> F, beam 4: the path 2 3 5
+    costs 3 and is inside the beam although 1 5 (cost 6) is not."""
+    from rhasspy_speech_amd import _lib
+    S, Y, X, F = 0, 1, 2, 3
+    arcs = [(S, X, 1, 1, 3.0, 0.0), (S, Y, 2, 2, 0.0, 0.0), (Y, X, 3, 3, 0.0, 0.0), (X, F, 4, 4, 0.0, 0.0), (X, F, 5, 5, 3.0, 0.0)]
+    final = [INF, INF, INF, 0.0]
+    entry = _lib.lattice_entry_from_raw(4, 0, final, arcs, 4.0, key="k")
+    start, finals, carcs = read_compact_lattice(entry, "k")
+    got = {p[0]: p[1] + p[2] for p in paths_of_compact(start, finals, carcs)}
+    # (1 5, cost 6, rides along: the determinised state after `1` and after `2 3` is one shared state, as in the reference's lattice)
+    assert got == {(1, 4): 3.0, (1, 5): 6.0, (2, 3, 4): 0.0, (2, 3, 5): 3.0}, got
