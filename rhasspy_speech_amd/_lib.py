@@ -286,6 +286,11 @@ class Stream:
         a = np.ascontiguousarray(np.frombuffer(pcm, dtype="<i2") if isinstance(pcm, (bytes, bytearray, memoryview)) else pcm, dtype=np.int16)
         _check(lib().rs_stream_accept(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.shape[0]))
 
+    def advance(self) -> None:
+        """Run the device work the audio accepted so far makes possible (rs_streams_advance on this one stream)."""
+        arr = (C.c_void_p * 1)(self._h)
+        _check(lib().rs_streams_advance(arr, 1))
+
     def finish(self, nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
         out = C.c_void_p()
         _check(lib().rs_stream_finish(self._h, nbest, lattice_acoustic_scale, C.byref(out)))

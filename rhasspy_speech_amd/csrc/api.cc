@@ -3,7 +3,9 @@
 // binaries report KALDI_ERR text on stderr with a non-zero exit status (tools.py:138-145).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -145,9 +147,13 @@ int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int
 int rs_stream_open(rs_model *model, rs_stream **out) {
   if (!model || !out) return ArgError("rs_stream_open: null argument");
   return Guard([&]() {
-    rs_stream *st = new rs_stream();
+    std::unique_ptr<rs_stream> st(new rs_stream());
     st->model = model;
-    *out = st;
+    // RS_STREAM_BATCH=1: the cross-check path -- buffer everything, replay the stream as one batch at finish
+    const char *e = std::getenv("RS_STREAM_BATCH");
+    st->keep_pcm = e && std::atoi(e) != 0;
+    if (!st->keep_pcm) model->m->StreamOpen(st.get());
+    *out = st.release();
     return RS_OK;
   });
 }
@@ -157,34 +163,57 @@ int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples) {
   if (stream->finished) return ArgError("rs_stream_accept: stream already finished");
   return Guard([&]() {
     stream->pcm.insert(stream->pcm.end(), pcm, pcm + n_samples);
+    stream->n_samples += n_samples;
     return RS_OK;
   });
 }
 
-int rs_streams_advance(rs_stream *const *streams, int32_t n_streams) {
-  if (n_streams < 0 || (n_streams > 0 && !streams)) return ArgError("rs_streams_advance: bad argument");
-  for (int i = 0; i < n_streams; i++) if (!streams[i]) return ArgError("rs_streams_advance: null stream");
-  g_last_error.clear();
+static int CheckStreams(rs_stream *const *streams, int32_t n_streams, const char *who) {
+  if (n_streams < 0 || (n_streams > 0 && !streams)) return ArgError((std::string(who) + ": bad argument").c_str());
+  for (int i = 0; i < n_streams; i++) {
+    if (!streams[i] || !streams[i]->model) return ArgError((std::string(who) + ": null stream").c_str());
+    if (streams[i]->model != streams[0]->model) return ArgError((std::string(who) + ": all streams must belong to one model").c_str());
+    if (streams[i]->finished) return ArgError((std::string(who) + ": stream already finished").c_str());
+    if (streams[i]->keep_pcm != streams[0]->keep_pcm) return ArgError((std::string(who) + ": streams opened in different modes").c_str());
+    for (int j = 0; j < i; j++) if (streams[j] == streams[i]) return ArgError((std::string(who) + ": a stream is listed twice").c_str());
+  }
   return RS_OK;
 }
 
-int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale, rs_result **out) {
-  if (!out || n_streams < 0 || (n_streams > 0 && !streams)) return ArgError("rs_streams_finish: bad argument");
-  for (int i = 0; i < n_streams; i++) {
-    if (!streams[i] || !streams[i]->model) return ArgError("rs_streams_finish: null stream");
-    if (streams[i]->model != streams[0]->model) return ArgError("rs_streams_finish: all streams must belong to one model");
-    if (streams[i]->finished) return ArgError("rs_streams_finish: stream already finished");
-  }
-  if (n_streams == 0) return ArgError("rs_streams_finish: no streams");
+int rs_streams_advance(rs_stream *const *streams, int32_t n_streams) {
+  const int rc = CheckStreams(streams, n_streams, "rs_streams_advance");
+  if (rc != RS_OK) return rc;
+  if (n_streams == 0 || streams[0]->keep_pcm) { g_last_error.clear(); return RS_OK; }
   return Guard([&]() {
-    std::vector<const int16_t *> ptr(n_streams);
-    std::vector<int32_t> len(n_streams);
-    for (int i = 0; i < n_streams; i++) { ptr[i] = streams[i]->pcm.data(); len[i] = (int32_t)streams[i]->pcm.size(); }
-    auto r = streams[0]->model->m->DecodeBatchHost(ptr.data(), len.data(), n_streams, nbest, lattice_acoustic_scale, /*streaming=*/true);
-    for (int i = 0; i < n_streams; i++) { streams[i]->finished = true; std::vector<int16_t>().swap(streams[i]->pcm); }
-    rs_result *res = new rs_result();
-    res->r = std::move(r);
-    *out = res;
+    streams[0]->model->m->StreamsAdvance(streams, n_streams, /*final=*/false, 1, 1.0f, nullptr);
+    return RS_OK;
+  });
+}
+
+int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale, rs_result **out) {
+  if (!out) return ArgError("rs_streams_finish: bad argument");
+  const int rc = CheckStreams(streams, n_streams, "rs_streams_finish");
+  if (rc != RS_OK) return rc;
+  if (n_streams == 0) return ArgError("rs_streams_finish: no streams");
+  if (nbest < 1) return ArgError("rs_streams_finish: nbest must be >= 1");
+  return Guard([&]() {
+    std::unique_ptr<rs_result> res(new rs_result());
+    if (streams[0]->keep_pcm) {
+      std::vector<const int16_t *> ptr(n_streams);
+      std::vector<int32_t> len(n_streams);
+      for (int i = 0; i < n_streams; i++) { ptr[i] = streams[i]->pcm.data(); len[i] = (int32_t)streams[i]->pcm.size(); }
+      res->r = streams[0]->model->m->DecodeBatchHost(ptr.data(), len.data(), n_streams, nbest, lattice_acoustic_scale, /*streaming=*/true);
+    } else {
+      res->r.reset(new rs::Result());
+      for (int i = 0; i < n_streams; i++) streams[i]->finished = true;      // whatever happens below, these streams are over
+      streams[0]->model->m->StreamsAdvance(streams, n_streams, /*final=*/true, nbest, lattice_acoustic_scale, res->r.get());
+    }
+    for (int i = 0; i < n_streams; i++) {
+      streams[i]->finished = true;
+      std::vector<int16_t>().swap(streams[i]->pcm);
+      if (!streams[i]->keep_pcm) streams[i]->model->m->StreamClose(streams[i]);
+    }
+    *out = res.release();
     return RS_OK;
   });
 }
@@ -194,7 +223,11 @@ int rs_stream_finish(rs_stream *stream, int32_t nbest, float lattice_acoustic_sc
   return rs_streams_finish(one, 1, nbest, lattice_acoustic_scale, out);
 }
 
-void rs_stream_free(rs_stream *stream) { delete stream; }
+void rs_stream_free(rs_stream *stream) {
+  if (!stream) return;
+  if (stream->open && stream->model) { try { stream->model->m->StreamClose(stream); } catch (...) {} }
+  delete stream;
+}
 
 int32_t rs_result_num_utts(const rs_result *r) { return r ? (int32_t)r->r->utts.size() : 0; }
 

@@ -221,7 +221,7 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
                                 const DenseWork &w, const float *cost_cur, const int *bp, const float *finfo, unsigned char *smem,
                                 int smem_bytes, int u, int T, int S, size_t ll_base, int error, unsigned long long n_expanded,
                                 unsigned long long n_arcs, unsigned long long n_insert, unsigned long long n_alive,
-                                int max_active_frames, int min_active_frames) {
+                                int max_active_frames, int min_active_frames, size_t counter_slot) {
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
   const float INF = INFINITY;
@@ -340,7 +340,7 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       w.out_nwords[u] = (!path_ok || truncated) ? -1 : nw;
       float *oc = w.out_costs + (size_t)u * 4;
       oc[0] = (float)graph; oc[1] = (float)ac; oc[2] = reached ? b1 : b2; oc[3] = reached ? 1.f : 0.f;
-      long long *c8 = w.counters + (size_t)u * 8;
+      long long *c8 = w.counters + counter_slot * 8;
       // += : a resumable decoder has already flushed the counts of earlier time slabs (the buffer starts zeroed)
       for (int i = 0; i < 4; i++) c8[i] += (long long)ctr[i];
       c8[4] = 0; c8[5] += max_active_frames; c8[6] += min_active_frames; c8[7] = error ? 2 : 0;

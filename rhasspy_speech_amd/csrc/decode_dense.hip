@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NT) void DenseDecodeKernel(HclgDev h, RevGraphDev r
     RS_T(5);
   }
   FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
-                      n_insert, n_alive, max_active_frames, min_active_frames);
+                      n_insert, n_alive, max_active_frames, min_active_frames, (size_t)u);
 #ifdef RS_DECODE_PROFILE
   RS_T(6);
   if (u == 0 && tid == 0)

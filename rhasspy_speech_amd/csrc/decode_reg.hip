@@ -47,15 +47,20 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = g.d_num_frames[u], S = h.num_states;
   // time slab [f_begin, f_end): an utterance is started by the slab with f_begin == -1, resumed from w.state_cost by later
-  // ones, and finished (traceback, results) by the slab that holds its last frame
-  if (f_begin >= 0 && f_begin >= T) return;
+  // ones, and finished (traceback, results) by the slab that holds its last frame.  Streams bring their own window per
+  // utterance and say explicitly when the stream ends (T is then the number of frames that exist so far).
+  const bool windows = w.win_begin != nullptr;
+  if (windows) { f_begin = w.win_begin[u]; f_end = w.win_end[u]; }
+  const bool finishing = windows ? w.win_final[u] != 0 : f_end >= T;
+  if (windows ? (f_begin >= f_end && !finishing) : (f_begin >= 0 && f_begin >= T)) return;
   const int f_stop = f_end < T ? f_end : T;
-  const bool finishing = f_end >= T;
-  float *state = w.state_cost + (size_t)u * (S + 4);
+  const size_t slot = windows ? (size_t)w.slot[u] : (size_t)u;
+  const size_t frame_row0 = windows ? (size_t)w.pool_row[u] : (size_t)u * (g.max_frames + 1);
+  float *state = w.state_cost + slot * (S + 4);
   float *cost_cur = reinterpret_cast<float *>(smem);                                       // [S + 1], [S] = +inf forever
   unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem + rg.key_base);   // [S + 1], [S] = empty forever
-  int *bp = w.bp + (size_t)u * (g.max_frames + 1) * S;
-  float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
+  int *bp = w.bp + frame_row0 * S;
+  float *finfo = w.frame_info + frame_row0 * 4;
   const float INF = INFINITY;
   const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
   unsigned long long n_expanded = 0, n_arcs = 0, n_insert = 0, n_alive = 0;
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     atomicAdd(&red.ctr[3], n_alive);
     __syncthreads();
     if (tid == 0) {
-      long long *c8 = w.counters + (size_t)u * 8;
+      long long *c8 = w.counters + slot * 8;
       for (int i = 0; i < 4; i++) c8[i] += (long long)red.ctr[i];
       c8[5] += max_active_frames;
       c8[6] += min_active_frames;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     return;
   }
   FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
-                      n_insert, n_alive, max_active_frames, min_active_frames);
+                      n_insert, n_alive, max_active_frames, min_active_frames, slot);
 #ifdef RS_DECODE_PROFILE
   RS_T(6);
   if (u == 0 && tid == 0)
@@ -377,7 +382,7 @@ bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int
 }
 
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
-                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s) {
+                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s, bool any_final) {
   if (g.n_utts == 0) return true;
   size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
   // room to stage back-pointer rows for the traceback.  48 KB, not more: with 128 KB a search workgroup left no room for
@@ -385,7 +390,7 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
   // the feature / iVector stages (3.7 ms per headline batch against 3.35 with 48 KB; the search itself takes the same
   // time).  A slab that finishes no utterance does not trace back and keeps its LDS footprint minimal.
   static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 48; }();
-  const size_t stage = f_end <= g.max_frames ? 0 : stage_kb * 1024;
+  const size_t stage = (w.win_begin ? !any_final : f_end <= g.max_frames) ? 0 : stage_kb * 1024;
   if (smem < stage) smem = stage;
   if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);

@@ -495,17 +495,6 @@ std::string Model::Describe() const {
 
 // ------------------------------------------------------------------------------------------------ batch
 
-namespace {
-struct Timer {
-  hipEvent_t ev[8];
-  int n = 0;
-  hipStream_t s;
-  explicit Timer(hipStream_t st) : s(st) { for (auto &e : ev) (void)hipEventCreate(&e); }
-  ~Timer() { for (auto &e : ev) (void)hipEventDestroy(e); }
-  void Mark() { if (n < 8) (void)hipEventRecord(ev[n++], s); }
-  float Ms(int a, int b) { float ms = 0; if (a < n && b < n) (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; }
-};
-}  // namespace
 
 // Decode calls may overlap on the device: calls on one model up to its number of decode contexts (RS_CONTEXTS, 4), calls
 // on different models freely.  The latency-bound search of one batch leaves the CUs to the GEMMs of the next: 3.3 ms per
@@ -665,336 +654,46 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
   return res;
 }
 
-// One group of utterances, start to finish, on one stream with one arena.  DecodeBatchDevice runs two groups
-// concurrently (two host threads, two streams) so that the latency-bound stages of one group (search, iVector)
-// overlap the MFMA-bound stage (TDNN) of the other.
-void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
-                        hipStream_t s, bool streaming, UttResult *out_utts, float *timings) {
-  DeviceArena &arena_ = cx.arena[gi];
-  HostArena &harena = cx.host_arena[gi];
-  RS_HIP(hipSetDevice(opts_.device_id));
-  auto wall0 = std::chrono::steady_clock::now();
-  if (n_utts == 0) return;
+GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld, float *out,
+                        int ldo, int share) const {
+  GemmDev d;
+  std::memset(&d, 0, sizeof(d));
+  const LayerOp &op = *pl.op;
+  d.nsegs = (int)op.segs.size();
+  for (int i = 0; i < d.nsegs; i++) {
+    const GemmSegment &sg = op.segs[i];
+    GemmSegDev &o = d.segs[i];
+    if (sg.src_buf < 0) { o.src = ivec; o.ld = ivec_ld; o.per_utt = 1; o.row_off = 0; }
+    else { o.src = src[sg.src_buf]; o.ld = src_ld[sg.src_buf]; o.per_utt = 0; o.row_off = sg.offset; }
+    o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
+  }
+  d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
+  d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = share;
+  d.exclusive = (ctx_.size() > 1 && std::getenv("RS_GEMM_B3_EXCLUSIVE")) ? 1 : 0;
+  d.nstages = (int)op.stages.size();
+  for (int i = 0; i < d.nstages; i++) {
+    const EltStage &st = op.stages[i];
+    d.stages[i].kind = st.kind == EltStage::kRelu ? 0 : (st.kind == EltStage::kScaleOffset ? 1 : 4);
+    d.stages[i].scale = pl.d_stage[i].first; d.stages[i].offset = pl.d_stage[i].second; d.stages[i].alpha = st.alpha;
+  }
+  d.out = out; d.ldo = ldo;
+  return d;
+}
+
+// The acoustic model's ops [op_begin, op_end) on one set of frame buffers (kernels.h row layout).  Layers whose halo nobody
+// reads run on the real frames only (frame_rows, when given).
+void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
+                    const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s) const {
   const Nnet &nn = am_.nnet;
-  const int C = fc_.mfcc.nceps, P = nn.output_dim;
-  // ---- geometry
-  std::vector<int> T(n_utts), row_base(n_utts + 1, 0), frame_base(n_utts + 1, 0);
-  int maxT = 0;
-  for (int u = 0; u < n_utts; u++) {
-    long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
-    if (ns < 0) Fail("sample offsets must be non-decreasing");
-    T[u] = NumFrames(ns, fc_.mfcc.opts);
-    maxT = std::max(maxT, T[u]);
-    row_base[u + 1] = row_base[u] + T[u] + L_ + R_;
-    frame_base[u + 1] = frame_base[u] + T[u];
-    out_utts[u].num_frames = T[u];
-  }
-  const int rows = row_base[n_utts];
-  const int guard = L_ + R_ + 8;
-  // ---- iVector schedule.  Offline (--online=false): one estimate per utterance from all frames.  Streaming:
-  // one estimate per nnet chunk, from the frames available at the 1024-sample tick on which
-  // DecodableNnetLoopedOnlineBase::AdvanceChunk runs for that chunk (decodable-online-looped.cc:56-84,186-194;
-  // online2-cli-nnet3-decode-faster.cc:143-161).  The schedule only depends on sample counts, so the streaming
-  // result is reproduced exactly without replaying wall-clock time.
-  const bool has_iv = fc_.ie.present;
-  const int chunk = opts_.frames_per_chunk;
-  std::vector<int> ivrow_base(n_utts + 1, 0);               // first iVector row of each utterance
-  std::vector<std::vector<int>> chunk_last(n_utts);          // streaming: last stats frame of every chunk
-  int max_chunks = 1;
-  for (int u = 0; u < n_utts; u++) {
-    int nrows_u = 1;
-    if (streaming && has_iv) {
-      const long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
-      const int nch = (T[u] + chunk - 1) / chunk;
-      const int Rm = nn.right_context, sr = fc_.ie.splice_right;
-      const long nt = (ns + 1023) / 1024;
-      int k = 0;
-      for (long j = 0; j < nt && k < nch; j++) {
-        const int fr = NumFrames(std::min<long>(1024 * (j + 1), ns), fc_.mfcc.opts);
-        const int ready = std::max(0, fr - Rm) / chunk;
-        while (k < ready && k < nch) { chunk_last[u].push_back(std::min(fr - 1, fr - sr - 1)); k++; }
-      }
-      while (k < nch) { chunk_last[u].push_back(T[u] - 1); k++; }
-      nrows_u = std::max(nch, 1);
-      max_chunks = std::max(max_chunks, nch);
-    }
-    ivrow_base[u + 1] = ivrow_base[u] + nrows_u;
-  }
-  const int n_ivrows = ivrow_base[n_utts];
-  // which iVector row every frame row reads: the chunk that supplied its Round(ivector, chunk) slot
-  // (nnet-compile-looped.cc:164-231: chunk 0 supplies the slots of t in [-L, chunk + R), chunk k the new ones of
-  //  [k*chunk + R, (k+1)*chunk + R))
-  // (offline: every row of an utterance reads its single iVector row -- filled in on the device with the row geometry)
-  harena.Reset();
-  const bool host_row_ivec = streaming && has_iv;
-  int *row_ivec = host_row_ivec ? harena.AllocT<int>(rows) : nullptr;
-  for (int u = 0; host_row_ivec && u < n_utts; u++) {
-    const int nch = (int)chunk_last[u].size();
-    for (int r = row_base[u]; r < row_base[u + 1]; r++) {
-      int k = 0;
-      if (streaming && has_iv && nch > 0) {
-        const int t = r - row_base[u] - L_;
-        const int slot = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
-        // smallest k whose input range [.., (k+1)*chunk + R) contains a time with this slot: slot < (k+1)*chunk + R
-        k = 0;
-        while (k < nch - 1 && slot >= (k + 1) * chunk + nn.right_context) k++;
-      }
-      row_ivec[r] = ivrow_base[u] + k;
-    }
-  }
-  // ---- arena sizing
-  auto fbytes = [&](int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
-  size_t need = 0;
-  need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 3 * sizeof(int) * (size_t)rows + 4096;
-  need += sizeof(int) * ((size_t)frame_base[n_utts] + 8 * (size_t)n_utts + 64) + 1024;     // frame-row map
-  std::vector<int> buf_ld(nn.bufs.size());
-  for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
-  const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
-  const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
-  const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
-  if (fc_.use_cmvn) need += fbytes(ld_c);
-  if (has_iv) {
-    need += fbytes(ld_c) + 2 * fbytes(ld_l);
-    need += (size_t)rows * nsel * 8 + 1024;
-    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192 + 1024;
-    need += (size_t)max_chunks * n_utts * 16 + 4096;
-    need += IvecStatsScratchDoubles(ivec_dev_, n_utts) * 8 + 1024;
-  }
-  const int S = hclg_.num_states();
-  // decoder selection (before sizing: only the chosen kernel's work buffers are reserved)
-  // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
-  // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
-  const bool unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
-  const bool want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || unscale);
-  const bool use_reg = reg_dev_.nt != 0 && !want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
-  const bool use_dense = dense_ok_ && !want_lattice && !force_sparse_ && decoder_choice_ != 3;
-  int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
-  cap_pf = std::min(cap_pf, S);
-  const long tok_cap_l = (long)(maxT + 2) * cap_pf;
-  if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
-  const int tok_cap = (int)tok_cap_l;
-  const int max_words = 1024;
-  need += (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
-  if (use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
-    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
-  else                // token-list search: per-state tables, queues, the token arrays of every frame
-    need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
-  if (want_lattice) need += sizeof(float) * (size_t)n_utts * tok_cap + 4096;                                // LatticeKernel's extra_cost
-  need += 64 * 256;   // alignment slack
-  arena_.Reserve(need + (1u << 20), s);
-  arena_.Reset();
-  // ---- upload geometry
-  int *d_row_ivec = nullptr;
-  BatchGeom g;
-  g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
-  {
-    // one page-locked staging block -> one async copy; the per-row arrays are derived on the device
-    const size_t n1 = (size_t)n_utts + 1;
-    const size_t bytes = n1 * sizeof(int64_t) + 4 * n1 * sizeof(int);
-    char *hp = static_cast<char *>(harena.Alloc(bytes));
-    char *dp = static_cast<char *>(arena_.Alloc(bytes));
-    int64_t *h_so = reinterpret_cast<int64_t *>(hp);
-    int *h_T = reinterpret_cast<int *>(hp + n1 * sizeof(int64_t)), *h_rb = h_T + n1, *h_fb = h_rb + n1, *h_ib = h_fb + n1;
-    std::memcpy(h_so, sample_offsets, n1 * sizeof(int64_t));
-    std::memcpy(h_T, T.data(), sizeof(int) * n_utts);
-    h_T[n_utts] = 0;
-    std::memcpy(h_rb, row_base.data(), sizeof(int) * n1);
-    std::memcpy(h_fb, frame_base.data(), sizeof(int) * n1);
-    std::memcpy(h_ib, ivrow_base.data(), sizeof(int) * n1);
-    RS_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s));
-    int64_t *d_so = reinterpret_cast<int64_t *>(dp);
-    int *d_T = reinterpret_cast<int *>(dp + n1 * sizeof(int64_t)), *d_rb = d_T + n1, *d_fb = d_rb + n1, *d_ib = d_fb + n1;
-    int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
-    d_row_ivec = arena_.AllocT<int>(rows);
-    if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    LaunchRowGeometry(n_utts, rows, L_, d_rb, d_ib, d_ru, d_rt, host_row_ivec ? nullptr : d_row_ivec, s);
-    g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
-  }
-  // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
-  // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
-  const int total_frames = frame_base[n_utts];
-  static const int lds_poison = [] { const char *e = std::getenv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
-  auto poison = [&]() {
-    if (!lds_poison) return;
-    static unsigned *sink = [] { unsigned *p = nullptr; (void)hipMalloc((void **)&p, 64); return p; }();
-    LaunchLdsPoison(sink, s);
-  };
-  // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
-  // output GEMM of slab k+1 (MFMA-bound) runs while slab k is searched (latency-bound) on a second, high-priority stream.
-  // Measured on the bench batch: 5.07 -> 4.97 ms with 3 slabs -- the search runs at half speed while it shares the CUs
-  // with GEMM waves, so most of the overlap is given back; off by default (RS_OVERLAP_SLABS=n turns it on).
-  const int overlap_env = [] { const char *e = std::getenv("RS_OVERLAP_SLABS"); return e ? std::atoi(e) : 1; }();
-  const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
-                            nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
-  const bool pipelined = use_reg && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
-                         s == cx.stream;
-  const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
-  std::vector<int> slab_off(n_slabs + 1, 0);
-  int *d_frame_rows = nullptr;
-  if (total_frames > 0) {
-    const int n_segs = n_slabs * n_utts;
-    int *h_seg = harena.AllocT<int>(n_segs + 1);
-    int acc_rows = 0;
-    for (int k = 0; k < n_slabs; k++) {
-      slab_off[k] = acc_rows;
-      for (int u = 0; u < n_utts; u++) { h_seg[k * n_utts + u] = acc_rows; acc_rows += std::min(std::max(T[u] - k * slab_len, 0), slab_len); }
-    }
-    h_seg[n_segs] = acc_rows;
-    slab_off[n_slabs] = acc_rows;
-    int *d_seg = arena_.AllocT<int>(n_segs + 1);
-    d_frame_rows = arena_.AllocT<int>(total_frames);
-    RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
-    LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
-  }
-  auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
-  Timer tm(s);
-  tm.Mark();
-  // ---- features
-  std::vector<float *> bufp(nn.bufs.size(), nullptr);
-  for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(buf_ld[b]);
-  float *raw = bufp[nn.input_buf];
-  if (fc_.use_cmvn) {
-    raw = falloc(ld_c);
-    poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s, OthersInFlight());
-    poison();
-    LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
-  } else {
-    poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s, OthersInFlight());
-  }
-  const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
-  tm.Mark();
-  // ---- iVector
-  float *d_ivec = nullptr;
-  auto fill_gemm = [&](const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld,
-                       float *out, int ldo) {
-    GemmDev d;
-    std::memset(&d, 0, sizeof(d));
-    const LayerOp &op = *pl.op;
-    d.nsegs = (int)op.segs.size();
-    for (int i = 0; i < d.nsegs; i++) {
-      const GemmSegment &sg = op.segs[i];
-      GemmSegDev &o = d.segs[i];
-      if (sg.src_buf < 0) { o.src = ivec; o.ld = ivec_ld; o.per_utt = 1; o.row_off = 0; }
-      else { o.src = src[sg.src_buf]; o.ld = src_ld[sg.src_buf]; o.per_utt = 0; o.row_off = sg.offset; }
-      o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
-    }
-    d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-    d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = cx.active_groups; d.exclusive = (ctx_.size() > 1 && std::getenv("RS_GEMM_B3_EXCLUSIVE")) ? 1 : 0;
-    d.nstages = (int)op.stages.size();
-    for (int i = 0; i < d.nstages; i++) {
-      const EltStage &st = op.stages[i];
-      d.stages[i].kind = st.kind == EltStage::kRelu ? 0 : (st.kind == EltStage::kScaleOffset ? 1 : 4);
-      d.stages[i].scale = pl.d_stage[i].first; d.stages[i].offset = pl.d_stage[i].second; d.stages[i].alpha = st.alpha;
-    }
-    d.out = out; d.ldo = ldo;
-    return d;
-  };
-  if (has_iv) {
-    float *cm = falloc(ld_c), *lda_raw = falloc(ld_l), *lda_norm = falloc(ld_l);
-    poison();
-    LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
-    poison();
-    LaunchGemm(fill_gemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l), rows, d_row_ivec, s);
-    poison();
-    LaunchGemm(fill_gemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l), rows, d_row_ivec, s);
-    int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
-    float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
-    poison();
-    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, s);
-    double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
-    double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
-    double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
-    d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i + 256);   // + slack: staging loads may read past a row's end
-    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
-    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
-    RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_ivrows * ld_i, s));
-    LaunchIvecInit(ivec_dev_, n_utts, linear, quad, x, numf, s);
-    double *iv_scratch = arena_.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, n_utts));
-    const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
-    if (!streaming) {
-      poison();
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
-      poison();
-      LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
-      LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
-    } else {
-      // per-chunk schedule tables: [step][utt] frame_begin, frame_end, out_row, active
-      std::vector<int> fb((size_t)max_chunks * n_utts, 0), fe((size_t)max_chunks * n_utts, 0), orow((size_t)max_chunks * n_utts, -1),
-          act((size_t)max_chunks * n_utts, 0);
-      for (int u = 0; u < n_utts; u++) {
-        int done = 0;
-        for (size_t k = 0; k < chunk_last[u].size(); k++) {
-          const size_t i = k * n_utts + u;
-          const int last = chunk_last[u][k];
-          orow[i] = ivrow_base[u] + (int)k;
-          if (last + 1 > done) { fb[i] = done; fe[i] = last + 1; act[i] = 1; done = last + 1; }
-        }
-      }
-      int *d_fb = arena_.AllocT<int>(fb.size()), *d_fe = arena_.AllocT<int>(fb.size()), *d_or = arena_.AllocT<int>(fb.size()),
-          *d_ac = arena_.AllocT<int>(fb.size());
-      RS_HIP(hipMemcpyAsync(d_fb, fb.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipMemcpyAsync(d_fe, fe.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipMemcpyAsync(d_or, orow.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipMemcpyAsync(d_ac, act.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
-      RS_HIP(hipStreamSynchronize(s));
-      for (int k = 0; k < max_chunks; k++) {
-        const size_t o = (size_t)k * n_utts;
-        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, s);
-        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
-        LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
-        LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
-      }
-    }
-  }
-  // ---- decoder selection and work buffers (before the acoustic model: the last layer is pipelined with the search)
-  DecodeOptsDev dopts;
-  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
-  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
-  DecodeWork w;
-  std::memset(&w, 0, sizeof(w));
-  w.max_words = max_words;
-  w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
-  w.out_nwords = arena_.AllocT<int>(n_utts);
-  w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
-  w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
-  w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
-  DenseWork dw;
-  std::memset(&dw, 0, sizeof(dw));
-  if (use_dense) {
-    dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
-    dw.out_words = w.out_words; dw.out_nwords = w.out_nwords; dw.out_costs = w.out_costs; dw.counters = w.counters;
-    dw.frame_info = w.frame_info; dw.max_words = max_words;
-    dw.path_cap = 4 * (maxT + 2);
-    dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
-    dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (S + 4));
-    RS_HIP(hipMemsetAsync(w.counters, 0, sizeof(long long) * 8 * (size_t)n_utts, s));
-  }
-  tm.Mark();
-  // ---- acoustic model
-  for (size_t i = 0; i < nn.ops.size(); i++) {
+  for (size_t i = op_begin; i < op_end; i++) {
     const LayerOp &op = nn.ops[i];
     if (op.kind == LayerOp::kGemm) {
-      GemmDev gd = fill_gemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf]);
+      GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf], share);
       const BufferInfo &ob = nn.bufs[op.out_buf];
-      if (pipelined && i + 1 == nn.ops.size()) {
-        // slab k: output layer on the main stream, then the search of that slab on the decode stream
-        for (int k = 0; k < n_slabs; k++) {
-          gd.row_map = d_frame_rows + slab_off[k];
-          LaunchGemm(gd, slab_off[k + 1] - slab_off[k], d_row_ivec, s);
-          RS_HIP(hipEventRecord(cx.slab_ev[k], s));
-          RS_HIP(hipStreamWaitEvent(cx.stream_dec, cx.slab_ev[k], 0));
-          LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, bufp[nn.output_buf], buf_ld[nn.output_buf], dw, k == 0 ? -1 : k * slab_len,
-                          k + 1 == n_slabs ? maxT + 1 : (k + 1) * slab_len, cx.stream_dec);
-        }
-        RS_HIP(hipEventRecord(cx.slab_ev[8], cx.stream_dec));
-      } else if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
+      if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
         gd.row_map = d_frame_rows;
-        poison();
         LaunchGemm(gd, total_frames, d_row_ivec, s);
       } else {
-        poison();
         LaunchGemm(gd, rows, d_row_ivec, s);
       }
     } else {
@@ -1022,35 +721,96 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
         }
       }
       d.nstages = ns;
-      poison();
       LaunchEltwise(d, rows, s);
     }
   }
-  float *ll = bufp[nn.output_buf];
-  const int ll_ld = buf_ld[nn.output_buf];
-  if (d_log_priors_ || opts_.acoustic_scale != 1.0f) LaunchPriorScale(ll, ll_ld, rows, P, d_log_priors_, opts_.acoustic_scale, s);
-  tm.Mark();
-  // ---- decode
-  if (pipelined) {
-    RS_HIP(hipStreamWaitEvent(s, cx.slab_ev[8], 0));       // the search of the last slab
-  } else if (use_dense) {
-    poison();
-    if (use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, ll, ll_ld, dw, -1, maxT + 1, s);
-    else LaunchDecodeDense(hclg_dev_, rev_dev_, dopts, g, ll, ll_ld, P, dw, s);
-  } else {
-    w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
-    w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
-    w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
-    w.queue_a = arena_.AllocT<int>((size_t)n_utts * S);
-    w.queue_b = arena_.AllocT<int>((size_t)n_utts * S);
-    w.in_queue = arena_.AllocT<int>((size_t)n_utts * S);
-    w.tok_cap = tok_cap;
-    w.tokens = arena_.AllocT<int4>((size_t)n_utts * tok_cap);
-    w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
-    poison();
-    LaunchDecode(hclg_dev_, dopts, g, ll, ll_ld, w, s);
+  if (op_end == nn.ops.size() && (d_log_priors_ || opts_.acoustic_scale != 1.0f))
+    LaunchPriorScale(bufp[nn.output_buf], buf_ld[nn.output_buf], rows, nn.output_dim, d_log_priors_, opts_.acoustic_scale, s);
+}
+
+// ------------------------------------------------------------------------------------------------ search
+// Which search kernel a call runs and the work buffers it needs (all from the call's arena).  Shared by the batch path
+// (DecodeGroup) and the end of a stream (stream.cc), whose log-likelihoods live in the stream pool.
+size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, SearchPlan *sp) const {
+  const int S = hclg_.num_states();
+  sp->S = S; sp->n_utts = n_utts; sp->maxT = maxT; sp->max_words = 1024;
+  // The reference un-scales the lattice's acoustic costs before lattice-to-nbest ranks its paths (online2-wav-nnet3-latgen-
+  // faster.cc:290-293), so with a decodable --acoustic-scale other than 1 even the 1-best is chosen on the lattice.
+  sp->unscale = opts_.acoustic_scale != 1.0f && opts_.acoustic_scale != 0.0f;
+  sp->want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || sp->unscale);
+  sp->use_reg = reg_dev_.nt != 0 && !sp->want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
+  sp->use_dense = dense_ok_ && !sp->want_lattice && !force_sparse_ && decoder_choice_ != 3;
+  int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
+  cap_pf = std::min(cap_pf, S);
+  const long tok_cap_l = (long)(maxT + 2) * cap_pf;
+  if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
+  sp->tok_cap = (int)tok_cap_l;
+  sp->dopts.beam = opts_.beam; sp->dopts.lattice_beam = opts_.lattice_beam; sp->dopts.beam_delta = opts_.beam_delta;
+  sp->dopts.max_active = opts_.max_active; sp->dopts.min_active = opts_.min_active;
+  size_t need = (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)sp->max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
+  if (sp->use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
+    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
+  else                    // token-list search: per-state tables, queues, the token arrays of every frame
+    need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
+  if (sp->want_lattice) need += sizeof(float) * (size_t)n_utts * sp->tok_cap + 4096;                                // LatticeKernel's extra_cost
+  return need;
+}
+
+void Model::AllocSearch(SearchPlan *sp, DeviceArena &arena_, hipStream_t s, bool pooled_frames) const {
+  const int n_utts = sp->n_utts, maxT = sp->maxT, S = sp->S, max_words = sp->max_words;
+  DecodeWork &w = sp->w;
+  std::memset(&w, 0, sizeof(w));
+  w.max_words = max_words;
+  w.out_words = arena_.AllocT<int>((size_t)n_utts * max_words);
+  w.out_nwords = arena_.AllocT<int>(n_utts);
+  w.out_costs = arena_.AllocT<float>((size_t)n_utts * 4);
+  w.counters = arena_.AllocT<long long>((size_t)n_utts * 8);
+  if (!pooled_frames) w.frame_info = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * 4);
+  DenseWork &dw = sp->dw;
+  std::memset(&dw, 0, sizeof(dw));
+  if (sp->use_dense) {
+    dw.out_words = w.out_words; dw.out_nwords = w.out_nwords; dw.out_costs = w.out_costs; dw.counters = w.counters;
+    dw.frame_info = w.frame_info; dw.max_words = max_words;
+    dw.path_cap = 4 * (maxT + 2);
+    dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
+    if (!pooled_frames) {      // (streams keep back-pointer rows, frame info, parked costs and counters in their pool)
+      dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
+      dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (S + 4));
+      RS_HIP(hipMemsetAsync(w.counters, 0, sizeof(long long) * 8 * (size_t)n_utts, s));
+    }
   }
-  tm.Mark();
+}
+
+void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g, const float *ll, int ll_ld, hipStream_t s) const {
+  const int n_utts = sp->n_utts, maxT = sp->maxT, S = sp->S;
+  if (sp->use_dense) {
+    if (sp->use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, sp->dopts, g, ll, ll_ld, sp->dw, -1, maxT + 1, s);
+    else LaunchDecodeDense(hclg_dev_, rev_dev_, sp->dopts, g, ll, ll_ld, am_.nnet.output_dim, sp->dw, s);
+    return;
+  }
+  DecodeWork &w = sp->w;
+  w.best = arena_.AllocT<unsigned long long>((size_t)n_utts * S);
+  w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
+  w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
+  w.queue_a = arena_.AllocT<int>((size_t)n_utts * S);
+  w.queue_b = arena_.AllocT<int>((size_t)n_utts * S);
+  w.in_queue = arena_.AllocT<int>((size_t)n_utts * S);
+  w.tok_cap = sp->tok_cap;
+  w.tokens = arena_.AllocT<int4>((size_t)n_utts * sp->tok_cap);
+  w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+  LaunchDecode(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
+}
+
+// Result records to the host, and -- when the call asked for more than the traceback gives -- the reference's
+// determinise | lattice-to-nbest | nbest-to-linear tail on the lattice the token-list search left behind.
+void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const BatchGeom &g, const int *T, const float *ll, int ll_ld, int nbest,
+                           float lat_scale, hipStream_t s, UttResult *out_utts, float *timings) {
+  DeviceArena &arena_ = cx.arena[gi];
+  HostArena &harena = cx.host_arena[gi];
+  const int n_utts = sp.n_utts, max_words = sp.max_words, tok_cap = sp.tok_cap;
+  const bool want_lattice = sp.want_lattice, unscale = sp.unscale;
+  const DecodeOptsDev &dopts = sp.dopts;
+  DecodeWork &w = sp.w;
   // ---- results to host
   // page-locked destination; only the first kWordsInline word ids of every utterance travel with the first copy (longer
   // transcripts fetch their row afterwards)
@@ -1065,7 +825,6 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
                           hipMemcpyDeviceToHost, s));
   RS_HIP(hipStreamSynchronize(s));
   RS_HIP(hipGetLastError());
-  tm.Mark();
   for (int u = 0; u < n_utts; u++) {
     UttResult &ur = out_utts[u];
     for (int k = 0; k < 8; k++) ur.counters[k] = h_ctr[(size_t)u * 8 + k];
@@ -1178,7 +937,283 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       }
     }
     timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
+  }}
+
+// One group of utterances, start to finish, on one stream with one arena.  DecodeBatchDevice runs two groups
+// concurrently (two host threads, two streams) so that the latency-bound stages of one group (search, iVector)
+// overlap the MFMA-bound stage (TDNN) of the other.
+void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest, float lat_scale,
+                        hipStream_t s, bool streaming, UttResult *out_utts, float *timings) {
+  DeviceArena &arena_ = cx.arena[gi];
+  HostArena &harena = cx.host_arena[gi];
+  RS_HIP(hipSetDevice(opts_.device_id));
+  auto wall0 = std::chrono::steady_clock::now();
+  if (n_utts == 0) return;
+  const Nnet &nn = am_.nnet;
+  const int C = fc_.mfcc.nceps, P = nn.output_dim;
+  // ---- geometry
+  std::vector<int> T(n_utts), row_base(n_utts + 1, 0), frame_base(n_utts + 1, 0);
+  int maxT = 0;
+  for (int u = 0; u < n_utts; u++) {
+    long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
+    if (ns < 0) Fail("sample offsets must be non-decreasing");
+    T[u] = NumFrames(ns, fc_.mfcc.opts);
+    maxT = std::max(maxT, T[u]);
+    row_base[u + 1] = row_base[u] + T[u] + L_ + R_;
+    frame_base[u + 1] = frame_base[u] + T[u];
+    out_utts[u].num_frames = T[u];
   }
+  const int rows = row_base[n_utts];
+  const int guard = L_ + R_ + 8;
+  // ---- iVector schedule.  Offline (--online=false): one estimate per utterance from all frames.  Streaming:
+  // one estimate per nnet chunk, from the frames available at the 1024-sample tick on which
+  // DecodableNnetLoopedOnlineBase::AdvanceChunk runs for that chunk (decodable-online-looped.cc:56-84,186-194;
+  // online2-cli-nnet3-decode-faster.cc:143-161).  The schedule only depends on sample counts, so the streaming
+  // result is reproduced exactly without replaying wall-clock time.
+  const bool has_iv = fc_.ie.present;
+  const int chunk = opts_.frames_per_chunk;
+  std::vector<int> ivrow_base(n_utts + 1, 0);               // first iVector row of each utterance
+  std::vector<std::vector<int>> chunk_last(n_utts);          // streaming: last stats frame of every chunk
+  int max_chunks = 1;
+  for (int u = 0; u < n_utts; u++) {
+    int nrows_u = 1;
+    if (streaming && has_iv) {
+      const long ns = (long)(sample_offsets[u + 1] - sample_offsets[u]);
+      const int nch = (T[u] + chunk - 1) / chunk;
+      const int Rm = nn.right_context, sr = fc_.ie.splice_right;
+      const long nt = (ns + 1023) / 1024;
+      int k = 0;
+      for (long j = 0; j < nt && k < nch; j++) {
+        const int fr = NumFrames(std::min<long>(1024 * (j + 1), ns), fc_.mfcc.opts);
+        const int ready = std::max(0, fr - Rm) / chunk;
+        while (k < ready && k < nch) { chunk_last[u].push_back(std::min(fr - 1, fr - sr - 1)); k++; }
+      }
+      while (k < nch) { chunk_last[u].push_back(T[u] - 1); k++; }
+      nrows_u = std::max(nch, 1);
+      max_chunks = std::max(max_chunks, nch);
+    }
+    ivrow_base[u + 1] = ivrow_base[u] + nrows_u;
+  }
+  const int n_ivrows = ivrow_base[n_utts];
+  // which iVector row every frame row reads: the chunk that supplied its Round(ivector, chunk) slot
+  // (nnet-compile-looped.cc:164-231: chunk 0 supplies the slots of t in [-L, chunk + R), chunk k the new ones of
+  //  [k*chunk + R, (k+1)*chunk + R))
+  // (offline: every row of an utterance reads its single iVector row -- filled in on the device with the row geometry)
+  harena.Reset();
+  const bool host_row_ivec = streaming && has_iv;
+  int *row_ivec = host_row_ivec ? harena.AllocT<int>(rows) : nullptr;
+  for (int u = 0; host_row_ivec && u < n_utts; u++) {
+    const int nch = (int)chunk_last[u].size();
+    for (int r = row_base[u]; r < row_base[u + 1]; r++) {
+      int k = 0;
+      if (streaming && has_iv && nch > 0) {
+        const int t = r - row_base[u] - L_;
+        const int slot = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
+        // smallest k whose input range [.., (k+1)*chunk + R) contains a time with this slot: slot < (k+1)*chunk + R
+        k = 0;
+        while (k < nch - 1 && slot >= (k + 1) * chunk + nn.right_context) k++;
+      }
+      row_ivec[r] = ivrow_base[u] + k;
+    }
+  }
+  // ---- arena sizing
+  auto fbytes = [&](int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
+  size_t need = 0;
+  need += (sizeof(int64_t) + 4 * sizeof(int)) * (size_t)(n_utts + 2) + 3 * sizeof(int) * (size_t)rows + 4096;
+  need += sizeof(int) * ((size_t)frame_base[n_utts] + 8 * (size_t)n_utts + 64) + 1024;     // frame-row map
+  std::vector<int> buf_ld(nn.bufs.size());
+  for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
+  const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
+  const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
+  const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
+  if (fc_.use_cmvn) need += fbytes(ld_c);
+  if (has_iv) {
+    need += fbytes(ld_c) + 2 * fbytes(ld_l);
+    need += (size_t)rows * nsel * 8 + 1024;
+    need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192 + 1024;
+    need += (size_t)max_chunks * n_utts * 16 + 4096;
+    need += IvecStatsScratchDoubles(ivec_dev_, n_utts) * 8 + 1024;
+  }
+  SearchPlan sp;
+  need += PlanSearch(n_utts, maxT, nbest, lat_scale, &sp);
+  const bool use_reg = sp.use_reg;
+  need += 64 * 256;   // alignment slack
+  arena_.Reserve(need + (1u << 20), s);
+  arena_.Reset();
+  // ---- upload geometry
+  int *d_row_ivec = nullptr;
+  BatchGeom g;
+  g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
+  {
+    // one page-locked staging block -> one async copy; the per-row arrays are derived on the device
+    const size_t n1 = (size_t)n_utts + 1;
+    const size_t bytes = n1 * sizeof(int64_t) + 4 * n1 * sizeof(int);
+    char *hp = static_cast<char *>(harena.Alloc(bytes));
+    char *dp = static_cast<char *>(arena_.Alloc(bytes));
+    int64_t *h_so = reinterpret_cast<int64_t *>(hp);
+    int *h_T = reinterpret_cast<int *>(hp + n1 * sizeof(int64_t)), *h_rb = h_T + n1, *h_fb = h_rb + n1, *h_ib = h_fb + n1;
+    std::memcpy(h_so, sample_offsets, n1 * sizeof(int64_t));
+    std::memcpy(h_T, T.data(), sizeof(int) * n_utts);
+    h_T[n_utts] = 0;
+    std::memcpy(h_rb, row_base.data(), sizeof(int) * n1);
+    std::memcpy(h_fb, frame_base.data(), sizeof(int) * n1);
+    std::memcpy(h_ib, ivrow_base.data(), sizeof(int) * n1);
+    RS_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s));
+    int64_t *d_so = reinterpret_cast<int64_t *>(dp);
+    int *d_T = reinterpret_cast<int *>(dp + n1 * sizeof(int64_t)), *d_rb = d_T + n1, *d_fb = d_rb + n1, *d_ib = d_fb + n1;
+    int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
+    d_row_ivec = arena_.AllocT<int>(rows);
+    if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    LaunchRowGeometry(n_utts, rows, L_, d_rb, d_ib, d_ru, d_rt, host_row_ivec ? nullptr : d_row_ivec, s);
+    g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
+  }
+  // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
+  // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
+  const int total_frames = frame_base[n_utts];
+  static const int lds_poison = [] { const char *e = std::getenv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
+  auto poison = [&]() {
+    if (!lds_poison) return;
+    static unsigned *sink = [] { unsigned *p = nullptr; (void)hipMalloc((void **)&p, 64); return p; }();
+    LaunchLdsPoison(sink, s);
+  };
+  // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
+  // output GEMM of slab k+1 (MFMA-bound) runs while slab k is searched (latency-bound) on a second, high-priority stream.
+  // Measured on the bench batch: 5.07 -> 4.97 ms with 3 slabs -- the search runs at half speed while it shares the CUs
+  // with GEMM waves, so most of the overlap is given back; off by default (RS_OVERLAP_SLABS=n turns it on).
+  const int overlap_env = [] { const char *e = std::getenv("RS_OVERLAP_SLABS"); return e ? std::atoi(e) : 1; }();
+  const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
+                            nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
+  const bool pipelined = use_reg && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
+                         s == cx.stream;
+  const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
+  std::vector<int> slab_off(n_slabs + 1, 0);
+  int *d_frame_rows = nullptr;
+  if (total_frames > 0) {
+    const int n_segs = n_slabs * n_utts;
+    int *h_seg = harena.AllocT<int>(n_segs + 1);
+    int acc_rows = 0;
+    for (int k = 0; k < n_slabs; k++) {
+      slab_off[k] = acc_rows;
+      for (int u = 0; u < n_utts; u++) { h_seg[k * n_utts + u] = acc_rows; acc_rows += std::min(std::max(T[u] - k * slab_len, 0), slab_len); }
+    }
+    h_seg[n_segs] = acc_rows;
+    slab_off[n_slabs] = acc_rows;
+    int *d_seg = arena_.AllocT<int>(n_segs + 1);
+    d_frame_rows = arena_.AllocT<int>(total_frames);
+    RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
+    LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
+  }
+  auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
+  Timer tm(s);
+  tm.Mark();
+  // ---- features
+  std::vector<float *> bufp(nn.bufs.size(), nullptr);
+  for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(buf_ld[b]);
+  float *raw = bufp[nn.input_buf];
+  if (fc_.use_cmvn) {
+    raw = falloc(ld_c);
+    poison();
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s, OthersInFlight());
+    poison();
+    LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
+  } else {
+    poison();
+    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s, OthersInFlight());
+  }
+  const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
+  tm.Mark();
+  // ---- iVector
+  float *d_ivec = nullptr;
+  if (has_iv) {
+    float *cm = falloc(ld_c), *lda_raw = falloc(ld_l), *lda_norm = falloc(ld_l);
+    poison();
+    LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
+    poison();
+    LaunchGemm(MakeGemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l, cx.active_groups), rows, d_row_ivec, s);
+    poison();
+    LaunchGemm(MakeGemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, cx.active_groups), rows, d_row_ivec, s);
+    int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
+    float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
+    poison();
+    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, s);
+    double *gamma = arena_.AllocT<double>((size_t)n_utts * G), *wfeats = arena_.AllocT<double>((size_t)n_utts * G * Dl);
+    double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
+    double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
+    d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i + 256);   // + slack: staging loads may read past a row's end
+    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
+    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
+    RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_ivrows * ld_i, s));
+    LaunchIvecInit(ivec_dev_, n_utts, linear, quad, x, numf, s);
+    double *iv_scratch = arena_.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, n_utts));
+    const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
+    if (!streaming) {
+      poison();
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
+      poison();
+      LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
+      LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
+    } else {
+      // per-chunk schedule tables: [step][utt] frame_begin, frame_end, out_row, active
+      std::vector<int> fb((size_t)max_chunks * n_utts, 0), fe((size_t)max_chunks * n_utts, 0), orow((size_t)max_chunks * n_utts, -1),
+          act((size_t)max_chunks * n_utts, 0);
+      for (int u = 0; u < n_utts; u++) {
+        int done = 0;
+        for (size_t k = 0; k < chunk_last[u].size(); k++) {
+          const size_t i = k * n_utts + u;
+          const int last = chunk_last[u][k];
+          orow[i] = ivrow_base[u] + (int)k;
+          if (last + 1 > done) { fb[i] = done; fe[i] = last + 1; act[i] = 1; done = last + 1; }
+        }
+      }
+      int *d_fb = arena_.AllocT<int>(fb.size()), *d_fe = arena_.AllocT<int>(fb.size()), *d_or = arena_.AllocT<int>(fb.size()),
+          *d_ac = arena_.AllocT<int>(fb.size());
+      RS_HIP(hipMemcpyAsync(d_fb, fb.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_fe, fe.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_or, orow.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipMemcpyAsync(d_ac, act.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
+      RS_HIP(hipStreamSynchronize(s));
+      for (int k = 0; k < max_chunks; k++) {
+        const size_t o = (size_t)k * n_utts;
+        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, s);
+        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
+        LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
+        LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
+      }
+    }
+  }
+  // ---- search work buffers (before the acoustic model: the last layer can be pipelined with the search)
+  AllocSearch(&sp, arena_, s);
+  const DecodeOptsDev &dopts = sp.dopts;
+  DenseWork &dw = sp.dw;
+  tm.Mark();
+  // ---- acoustic model
+  if (pipelined) {
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size() - 1, s);
+    // slab k: output layer on the main stream, then the search of that slab on the decode stream
+    const size_t i = nn.ops.size() - 1;
+    GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[nn.ops[i].out_buf], buf_ld[nn.ops[i].out_buf], cx.active_groups);
+    for (int k = 0; k < n_slabs; k++) {
+      gd.row_map = d_frame_rows + slab_off[k];
+      LaunchGemm(gd, slab_off[k + 1] - slab_off[k], d_row_ivec, s);
+      RS_HIP(hipEventRecord(cx.slab_ev[k], s));
+      RS_HIP(hipStreamWaitEvent(cx.stream_dec, cx.slab_ev[k], 0));
+      LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, g, bufp[nn.output_buf], buf_ld[nn.output_buf], dw, k == 0 ? -1 : k * slab_len,
+                      k + 1 == n_slabs ? maxT + 1 : (k + 1) * slab_len, cx.stream_dec);
+    }
+    RS_HIP(hipEventRecord(cx.slab_ev[8], cx.stream_dec));
+  } else {
+    poison();
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size(), s);
+  }
+  float *ll = bufp[nn.output_buf];
+  const int ll_ld = buf_ld[nn.output_buf];
+  tm.Mark();
+  // ---- decode
+  if (pipelined) RS_HIP(hipStreamWaitEvent(s, cx.slab_ev[8], 0));       // the search of the last slab
+  else { poison(); LaunchSearch(&sp, arena_, g, ll, ll_ld, s); }
+  tm.Mark();
+  CollectResults(sp, cx, gi, g, T.data(), ll, ll_ld, nbest, lat_scale, s, out_utts, timings);
+  tm.Mark();
   if (opts_.keep_intermediates) {
     for (int u = 0; u < n_utts; u++) {
       UttResult &ur = out_utts[u];

@@ -80,6 +80,29 @@ struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
 
 struct LatArcBuffer { void *d = nullptr; size_t cap = 0; };      // capacity in LatArc records
 
+// HIP events around the stages of a call, on the stream the kernels are launched on
+struct Timer {
+  hipEvent_t ev[8];
+  int n = 0;
+  hipStream_t s;
+  explicit Timer(hipStream_t st) : s(st) { for (auto &e : ev) (void)hipEventCreate(&e); }
+  ~Timer() { for (auto &e : ev) (void)hipEventDestroy(e); }
+  void Mark() { if (n < 8) (void)hipEventRecord(ev[n++], s); }
+  float Ms(int a, int b) { float ms = 0; if (a < n && b < n) (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; }
+};
+
+struct StreamPool;                                                 // stream.cc
+struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
+
+// Which search kernel a call runs and its work buffers (engine.cc: PlanSearch / AllocSearch / LaunchSearch / CollectResults).
+struct SearchPlan {
+  bool unscale = false, want_lattice = false, use_reg = false, use_dense = false;
+  int S = 0, tok_cap = 0, max_words = 1024, maxT = 0, n_utts = 0;
+  DecodeOptsDev dopts{};
+  DecodeWork w{};
+  DenseWork dw{};
+};
+
 class Model {
  public:
   Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf, const rs_decode_opts &opts);
@@ -96,6 +119,11 @@ class Model {
   const FeatureConfig &features() const { return fc_; }
   const AcousticModel &am() const { return am_; }
   const Hclg &hclg() const { return hclg_; }
+  // Streams (stream.cc): a stream owns a slot and a row range of the model's pool from open to close; advance runs the
+  // device work the accepted audio makes possible, batched over the given streams; final = end of input, results to res.
+  void StreamOpen(rs_stream *st);
+  void StreamClose(rs_stream *st);
+  void StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res);
 
  private:
   struct DecodeContext;
@@ -104,6 +132,15 @@ class Model {
   template <typename T> T *Upload(const std::vector<T> &v);
   void *UploadBytes(const void *p, size_t bytes);
   void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
+  GemmDev MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld, float *out, int ldo,
+                   int share) const;
+  size_t PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, SearchPlan *sp) const;
+  void AllocSearch(SearchPlan *sp, DeviceArena &arena, hipStream_t s, bool pooled_frames = false) const;
+  void LaunchSearch(SearchPlan *sp, DeviceArena &arena, const BatchGeom &g, const float *ll, int ll_ld, hipStream_t s) const;
+  void CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const BatchGeom &g, const int *T, const float *ll, int ll_ld, int nbest,
+                      float lat_scale, hipStream_t s, UttResult *out_utts, float *timings);
+  void RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
+               const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s) const;
 
   rs_decode_opts opts_;
   FeatureConfig fc_;
@@ -138,6 +175,12 @@ class Model {
   bool OthersInFlight();
   std::unique_ptr<Result> DecodeInContext(DecodeContext &cx, const int16_t *d_pcm, const int64_t *sample_offsets, int n_utts, int nbest,
                                           float lat_scale, hipStream_t user_stream, bool streaming);
+  friend struct StreamPool;
+  std::unique_ptr<StreamPool, StreamPoolDeleter> pool_;
+  std::unique_ptr<DecodeContext> stream_ctx_;
+  std::mutex pool_mu_;             // pool bookkeeping and advances of this model, one at a time
+  StreamPool *Pool();
+  void StreamGrow(rs_stream *st, int need_frames);
   std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)
   int pruned_from_ = 0;            // number of pdfs before pruning (0 = not pruned)
   void PruneOutputLayer();
@@ -162,4 +205,18 @@ class Model {
 
 struct rs_model { std::unique_ptr<rs::Model> m; };
 struct rs_result { std::unique_ptr<rs::Result> r; };
-struct rs_stream { rs_model *model = nullptr; std::vector<int16_t> pcm; bool finished = false; };
+struct rs_stream {
+  rs_model *model = nullptr;
+  bool finished = false, open = false;
+  bool keep_pcm = false;           // RS_STREAM_BATCH=1: keep every sample and replay the stream as one batch at finish (cross-check path)
+  std::vector<int16_t> pcm;        // samples from absolute index pcm_start on (the ones no complete frame has consumed yet)
+  long pcm_start = 0, n_samples = 0;
+  int slot = -1, row0 = 0, cap = 0;   // the stream's slot and frame-row range in the model's pool
+  int frames_mfcc = 0;             // MFCC (and CMVN) frames produced
+  long ticks_done = 0;             // 1024-sample ticks the chunk schedule has seen
+  int chunks_sched = 0;            // nnet chunks computed
+  int stats_done = 0;              // frames accumulated into the iVector statistics
+  int ll_done = 0;                 // frames with log-likelihoods in the pool
+  int frames_decoded = 0;          // frames the incremental search has consumed
+  bool dec_started = false;
+};

@@ -111,7 +111,7 @@ __device__ __forceinline__ void WaveLdsSync() {
 // perturbs this one's LDS-staged arithmetic when they share a CU).
 template <int NFFT, int WPB>   // padded window (real points)
 __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
-                                                       float *__restrict__ feats, int ld) {
+                                                       float *__restrict__ feats, int ld, const int *__restrict__ out_rows) {
   constexpr int NC = NFFT / 2;        // complex points
   const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
   const float *fft_tw = m.fft_tw;
@@ -223,12 +223,13 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     for (int b = 0; b < m.nbins; b++) c += d[b] * lm[wave][b];
     c *= m.lifter[lane];
     if (m.use_energy && lane == 0) c = fmaxf(raw_energy, m.log_energy_floor);
-    feats[(size_t)row * ld + lane] = c;
+    feats[(size_t)(out_rows ? out_rows[row] : row) * ld + lane] = c;      // out_rows: streams write into their pool rows
   }
 }
 
 template <int NFFT, int WPB>
-static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, bool exclusive, hipStream_t s) {
+static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, bool exclusive, const int *out_rows,
+                        hipStream_t s) {
   const int blocks = (g.total_rows + WPB - 1) / WPB;
   if (!blocks) return;
   constexpr size_t need = sizeof(float) * WPB * (NFFT + 3 * (NFFT / 2) + 1 + 64);
@@ -238,15 +239,16 @@ static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&MfccKernel<NFFT, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = smem;
   }
-  hipLaunchKernelGGL((MfccKernel<NFFT, WPB>), dim3(blocks), dim3(64 * WPB), smem, s, m, g, pcm, feats, ld);
+  hipLaunchKernelGGL((MfccKernel<NFFT, WPB>), dim3(blocks), dim3(64 * WPB), smem, s, m, g, pcm, feats, ld, out_rows);
 }
 
-void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive) {
+void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive,
+                const int *out_rows) {
   if (m.padded == 512) {
-    if (exclusive) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, true, s);
-    else LaunchMfccT<512, 4>(m, g, pcm, feats, ld, false, s);
+    if (exclusive) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, true, out_rows, s);
+    else LaunchMfccT<512, 4>(m, g, pcm, feats, ld, false, out_rows, s);
   } else {
-    LaunchMfccT<2048, 4>(m, g, pcm, feats, ld, exclusive, s);
+    LaunchMfccT<2048, 4>(m, g, pcm, feats, ld, exclusive, out_rows, s);
   }
 }
 
@@ -257,7 +259,12 @@ void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float 
 // threads apply the mean-only ApplyCmvn to the chunk in parallel with coalesced stores.  No speaker stats: the
 // reference starts every utterance from a fresh process.
 constexpr int kCmvnTC = 32, kCmvnMaxDim = 128;
-__global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, const float *__restrict__ in, float *__restrict__ out, int ld) {
+//
+// Streams (t_begin != null): utterance u resumes at frame t_begin[u] with the running sums and the window count parked in
+// state[(D + 1) * state_slot[u]] by the launch that produced frame t_begin[u] - 1, and parks them again at frame T; the frames
+// that leave the window are re-read from `in`, which holds the whole stream.
+__global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, const float *__restrict__ in, float *__restrict__ out, int ld,
+                                                        const int *__restrict__ t_begin, double *__restrict__ state, const int *__restrict__ state_slot) {
   __shared__ float xs[kCmvnTC][kCmvnMaxDim];      // the chunk
   __shared__ float xp[kCmvnTC][kCmvnMaxDim];      // the frames leaving the window while the chunk enters
   __shared__ double ss[kCmvnTC][kCmvnMaxDim];     // running sums after each frame
@@ -269,7 +276,10 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
   const size_t base = (size_t)g.d_row_base[u] + g.L;
   double sum = 0.0, count = 0.0;                  // threads < D
   const double gcount = c.global_stats[D];
-  for (int t0 = 0; t0 < T; t0 += kCmvnTC) {
+  const int t_first = t_begin ? t_begin[u] : 0;
+  double *park = t_begin ? state + (size_t)(D + 1) * state_slot[u] : nullptr;
+  if (park && t_first > 0 && tid < D) { sum = park[tid]; count = park[D]; }
+  for (int t0 = t_first; t0 < T; t0 += kCmvnTC) {
     const int n = T - t0 < kCmvnTC ? T - t0 : kCmvnTC;
     for (int idx = tid; idx < n * D; idx += 256) {
       const int i = idx / D, d = idx % D, tp = t0 + i - W;
@@ -311,15 +321,40 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
     }
     __syncthreads();
   }
-  if (T > 0) {
+  if (park && tid < D) { park[tid] = sum; if (tid == 0) park[D] = count; }
+  if (T > 0 && !t_begin) {
     for (int idx = tid; idx < g.L * D; idx += 256) out[(base - g.L + idx / D) * ld + idx % D] = edge[0][idx % D];
     for (int idx = tid; idx < g.R * D; idx += 256) out[(base + T + idx / D) * ld + idx % D] = edge[1][idx % D];
   }
 }
 
-void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s) {
+void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s, const int *t_begin,
+                      double *state, const int *state_slot) {
   if (g.n_utts == 0) return;
-  hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(256), 0, s, c, g, in, out, ld);
+  hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(256), 0, s, c, g, in, out, ld, t_begin, state, state_slot);
+}
+
+// ------------------------------------------------------------------------------------------ row copies
+// dst row dst_row[i] <- src row src_row[i], `width` 4-byte words each (one workgroup per row).  The streaming engine's
+// glue: pool rows <-> the dense transient buffers of one advance (clamped context gathers, state parking).
+__global__ __launch_bounds__(256) void CopyRowsKernel(const unsigned *__restrict__ src, long src_ld, const int *__restrict__ src_row,
+                                                      unsigned *__restrict__ dst, long dst_ld, const int *__restrict__ dst_row, int width) {
+  const int i = blockIdx.x;
+  const unsigned *sp = src + (size_t)(src_row ? src_row[i] : i) * src_ld;
+  unsigned *dp = dst + (size_t)(dst_row ? dst_row[i] : i) * dst_ld;
+  if (((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp)) & 15) == 0) {
+    const int w4 = width >> 2;
+    for (int k = threadIdx.x; k < w4; k += 256) reinterpret_cast<uint4 *>(dp)[k] = reinterpret_cast<const uint4 *>(sp)[k];
+    for (int k = (w4 << 2) + threadIdx.x; k < width; k += 256) dp[k] = sp[k];
+  } else {
+    for (int k = threadIdx.x; k < width; k += 256) dp[k] = sp[k];
+  }
+}
+void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
+                    hipStream_t s) {
+  if (n <= 0 || width_words <= 0) return;
+  hipLaunchKernelGGL(CopyRowsKernel, dim3(n), dim3(256), 0, s, static_cast<const unsigned *>(src), src_ld_words, src_row,
+                     static_cast<unsigned *>(dst), dst_ld_words, dst_row, width_words);
 }
 
 // ------------------------------------------------------------------------------------------ row geometry

@@ -45,7 +45,12 @@ struct MfccDev {
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
 };
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
-void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive = false);
+// out_rows (null = the row itself): physical row of `feats` that receives dense row i (streams write into pool rows).
+void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive = false,
+                const int *out_rows = nullptr);
+// dst row dst_row[i] (null = i) <- src row src_row[i] (null = i), width_words 4-byte words, leading dimensions in words.
+void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
+                    hipStream_t s);
 
 // frame_rows[i] = physical row of the i-th frame in slab-major order: entry (k, u) of seg_off (n_segs + 1 offsets, n_segs =
 // n_slabs * n_utts) starts the frames [k * slab_len, ...) of utterance u.
@@ -60,7 +65,10 @@ struct CmvnDev {
   const double *global_stats;   // 2 x (dim+1), row 0 used
 };
 // in/out: total_rows x ld, same layout.  Halo rows of `out` replicate its edge frames.
-void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s);
+// Streams: t_begin[u] = first frame to produce (frames before it were produced by earlier launches), state = parked running
+// sums + window count, (dim + 1) doubles per slot, slot of utterance u = state_slot[u].  No halo rows are written then.
+void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s, const int *t_begin = nullptr,
+                      double *state = nullptr, const int *state_slot = nullptr);
 
 // ---------------------------------------------------------------- generic segmented GEMM (FP32 MFMA)
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
@@ -210,6 +218,11 @@ struct DenseWork {
   int path_cap;
   // resumable decoding (decode_reg.hip): token costs and scalars carried between the time slabs of one utterance
   float *state_cost;          // n_utts x (S + 4): S costs, then {closure cutoff, error flag}
+  // Streams (decode_reg.hip, win_begin != null): utterance u decodes frames [win_begin[u], win_end[u]) (win_begin -1 starts the
+  // stream), of which d_num_frames[u] exist so far; win_final[u] != 0 ends it (traceback + results).  Its back-pointer / frame
+  // info rows live at pool row pool_row[u] onwards (bp, frame_info = the pools' bases), its parked costs and counters in slot
+  // slot[u] of state_cost / counters; out_* and path stay indexed by u.
+  const int *win_begin, *win_end, *win_final, *pool_row, *slot;
 };
 // Register-resident variant (decode_reg.hip): the arcs are dealt out to the threads of an NT-thread workgroup (arc i ->
 // thread i % NT, register slot i / NT) and live in VGPRs for the whole utterance.  Tables are [slot][thread] so that
@@ -226,8 +239,10 @@ struct RegGraphDev {
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx);
 // Decodes frames [f_begin, f_end) of every utterance (f_begin = -1 starts an utterance; the slab that contains an
 // utterance's last frame also does its traceback).  w.counters must be zeroed before the first slab.
+// With w.win_begin set (streams) f_begin / f_end are ignored; `any_final` then says whether some utterance ends in this launch
+// (LDS for the traceback staging is only requested then).
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
-                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s);
+                     const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s, bool any_final = true);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,

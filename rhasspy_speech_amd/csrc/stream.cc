@@ -1,0 +1,542 @@
+// Incremental streaming decode: rs_stream_accept / rs_streams_advance / rs_streams_finish.
+//
+// Reference: online2-cli-nnet3-decode-faster.cc:129-170 reads stdin in 1024-sample ticks and, per tick, AcceptWaveform +
+// AdvanceDecoding: MFCC frames are produced as their samples arrive (online-feature.cc:131-204), a nnet chunk of 24 frames
+// is computed on the first tick at which 24 (k + 1) + R feature frames exist (decodable-online-looped.cc:56-84), with the
+// iVector estimated from the frames available on that tick (online-ivector-feature.cc:248-275; CG warm-started from the
+// previous estimate), and the search consumes the new log-likelihood rows.  After stdin closes, the last frames are flushed
+// (right context = copies of the last frame) and the lattice is finalised.
+//
+// Here the same work is done per rs_streams_advance call, BATCHED over the streams of the call: which chunk becomes
+// computable on which tick -- and therefore which frames its iVector has seen -- is a pure function of the number of samples
+// accepted so far, so it does not matter how many ticks' worth of audio one advance covers: the results are those of the
+// tick-by-tick reference (and equal, bit for bit, to the batch replay of DecodeGroup(streaming = true), which the tests use as
+// a cross-check).  What persists between advances lives in a per-model POOL in HBM:
+//   rows (one per frame; a stream owns a contiguous range):  raw MFCCs, CMVN'd MFCCs, log-likelihoods, and -- for graphs the
+//       register-resident search handles -- back-pointer rows and per-frame cutoffs;
+//   slots (one per stream): iVector estimator state (linear / quadratic terms, frame count, CG solution), CMVN running sums,
+//       the search's parked token costs and counters;  per-chunk iVectors.
+// Everything else is transient and comes from the arena of the advance.  One advance =
+//   1. new samples -> device; MFCC of the frames they complete, straight into the stream's pool rows;
+//   2. CMVN resumed from the parked sums (iVector branch; nnet branch if the model has one);
+//   3. for the streams that got new chunks: splice + LDA + UBM posteriors over the not-yet-accumulated frames (context gathered
+//      from the pool with the reference's edge clamping), then chunk by chunk accumulate -> derived terms -> CG solve;
+//   4. the acoustic model over [first new frame - left context, last new frame + right context) of every such stream, gathered
+//      into the batch layout of kernels.h, output rows scattered into the pool;
+//   5. the search resumed over the new rows (RegDecodeKernel windows); graphs it cannot hold are searched at finish.
+// rs_streams_finish = one last advance with end-of-input semantics, then traceback / lattice / result records: its device
+// work is one chunk's worth when the streams were advanced as the audio came in.
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "engine.h"
+
+namespace rs {
+
+struct StreamPool {
+  hipStream_t q = nullptr;       // every advance of the model runs here, in order
+  void *cx = nullptr;            // Model::DecodeContext with the arenas / staging of the advances (never handed to batch calls)
+  int rows = 0;                  // capacity in frame rows
+  int chunk = 24, ld_c = 0, ld_ll = 0, ld_i = 0, S = 0;
+  bool reg = false;              // the register-resident search runs incrementally
+  float *raw = nullptr, *cm = nullptr, *nn_in = nullptr, *ll = nullptr, *finfo = nullptr, *ivec = nullptr, *dec_state = nullptr;
+  int *bp = nullptr;
+  int max_slots = 0;
+  double *lin = nullptr, *quad = nullptr, *numf = nullptr, *x = nullptr, *cmvn_iv = nullptr, *cmvn_nn = nullptr;
+  long long *dec_ctr = nullptr;
+  std::vector<int> free_slots;
+  std::map<int, int> free_rows;  // start -> length
+  std::vector<void *> owned;
+
+  int AllocRows(int n) {
+    for (auto it = free_rows.begin(); it != free_rows.end(); ++it)
+      if (it->second >= n) {
+        const int start = it->first, len = it->second;
+        free_rows.erase(it);
+        if (len > n) free_rows[start + n] = len - n;
+        return start;
+      }
+    return -1;
+  }
+  void FreeRows(int start, int n) {
+    if (n <= 0) return;
+    auto it = free_rows.emplace(start, n).first;
+    auto nx = std::next(it);
+    if (nx != free_rows.end() && it->first + it->second == nx->first) { it->second += nx->second; free_rows.erase(nx); }
+    if (it != free_rows.begin()) {
+      auto pv = std::prev(it);
+      if (pv->first + pv->second == it->first) { pv->second += it->second; free_rows.erase(it); }
+    }
+  }
+};
+
+void StreamPoolDeleter::operator()(StreamPool *p) const {
+  if (!p) return;
+  for (void *d : p->owned) (void)hipFree(d);
+  if (p->q) (void)hipStreamDestroy(p->q);
+  delete p;
+}
+
+namespace {
+int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
+int EnvInt(const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+
+// index arrays of one advance: collected on the host, uploaded with one copy
+struct IntStage {
+  std::vector<int> h;
+  size_t Add(const std::vector<int> &v) {
+    const size_t o = h.size();
+    h.insert(h.end(), v.begin(), v.end());
+    while (h.size() & 3) h.push_back(0);
+    return o;
+  }
+  size_t Add64(const std::vector<int64_t> &v) {
+    const size_t o = h.size();
+    h.resize(o + 2 * v.size());
+    if (!v.empty()) std::memcpy(&h[o], v.data(), 8 * v.size());
+    while (h.size() & 3) h.push_back(0);
+    return o;
+  }
+};
+}  // namespace
+
+StreamPool *Model::Pool() {
+  if (pool_) return pool_.get();
+  ToDevice();
+  RS_HIP(hipSetDevice(opts_.device_id));
+  std::unique_ptr<StreamPool, StreamPoolDeleter> p(new StreamPool());
+  const Nnet &nn = am_.nnet;
+  const int C = fc_.mfcc.nceps, P = nn.output_dim;
+  p->chunk = opts_.frames_per_chunk;
+  p->rows = RoundUp(std::max(EnvInt("RS_STREAM_POOL_ROWS", 1 << 18), 4 * p->chunk), p->chunk);      // 2^18 frames = 44 min of live audio
+  p->max_slots = std::max(EnvInt("RS_STREAM_SLOTS", 512), 1);
+  p->ld_c = RoundUp(C, 4);
+  p->ld_ll = RoundUp(P, 4);
+  p->S = hclg_.num_states();
+  p->reg = reg_dev_.nt != 0 && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
+  RS_HIP(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
+  auto dalloc = [&](size_t bytes) {
+    void *d = nullptr;
+    RS_HIP(hipMalloc(&d, std::max<size_t>(bytes, 256)));
+    RS_HIP(hipMemsetAsync(d, 0, std::max<size_t>(bytes, 256), p->q));
+    p->owned.push_back(d);
+    return d;
+  };
+  const size_t R = (size_t)p->rows + 8;
+  p->raw = static_cast<float *>(dalloc(R * p->ld_c * 4));
+  if (fc_.ie.present) p->cm = static_cast<float *>(dalloc(R * p->ld_c * 4));
+  if (fc_.use_cmvn) p->nn_in = static_cast<float *>(dalloc(R * p->ld_c * 4));
+  p->ll = static_cast<float *>(dalloc(R * p->ld_ll * 4));
+  if (p->reg) {
+    p->bp = static_cast<int *>(dalloc(R * p->S * 4));
+    p->finfo = static_cast<float *>(dalloc(R * 16));
+    p->dec_state = static_cast<float *>(dalloc((size_t)p->max_slots * (p->S + 4) * 4));
+  }
+  p->dec_ctr = static_cast<long long *>(dalloc((size_t)p->max_slots * 64));
+  if (fc_.ie.present) {
+    const int Di = fc_.ie.ivector_dim(), usz = Di * (Di + 1) / 2;
+    p->ld_i = RoundUp(Di, 4);
+    p->ivec = static_cast<float *>(dalloc(((size_t)p->rows / p->chunk + 8) * p->ld_i * 4 + 1024));
+    p->lin = static_cast<double *>(dalloc((size_t)p->max_slots * Di * 8));
+    p->quad = static_cast<double *>(dalloc((size_t)p->max_slots * usz * 8));
+    p->numf = static_cast<double *>(dalloc((size_t)p->max_slots * 8));
+    p->x = static_cast<double *>(dalloc((size_t)p->max_slots * Di * 8));
+    p->cmvn_iv = static_cast<double *>(dalloc((size_t)p->max_slots * (C + 1) * 8));
+  }
+  if (fc_.use_cmvn) p->cmvn_nn = static_cast<double *>(dalloc((size_t)p->max_slots * (C + 1) * 8));
+  for (int s = p->max_slots - 1; s >= 0; s--) p->free_slots.push_back(s);
+  p->free_rows[0] = p->rows;
+  std::unique_ptr<DecodeContext> c(new DecodeContext());
+  c->stream = p->q;
+  stream_ctx_ = std::move(c);
+  p->cx = stream_ctx_.get();
+  RS_HIP(hipStreamSynchronize(p->q));
+  pool_ = std::move(p);
+  return pool_.get();
+}
+
+void Model::StreamOpen(rs_stream *st) {
+  std::lock_guard<std::mutex> lk(pool_mu_);
+  StreamPool *p = Pool();
+  RS_HIP(hipSetDevice(opts_.device_id));
+  if (p->free_slots.empty()) Fail("too many live streams on this model (RS_STREAM_SLOTS=" + std::to_string(p->max_slots) + ")");
+  const int want = RoundUp(std::max(EnvInt("RS_STREAM_INIT_FRAMES", 4096), 2 * p->chunk), p->chunk);
+  const int row0 = p->AllocRows(want);
+  if (row0 < 0) Fail("stream pool exhausted (RS_STREAM_POOL_ROWS=" + std::to_string(p->rows) + " frame rows of live audio)");
+  st->slot = p->free_slots.back();
+  p->free_slots.pop_back();
+  st->row0 = row0;
+  st->cap = want;
+  // fresh estimator / search state in the slot
+  if (fc_.ie.present) {
+    const int Di = fc_.ie.ivector_dim(), usz = Di * (Di + 1) / 2;
+    LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->q);
+  }
+  RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->q));
+  st->open = true;
+}
+
+void Model::StreamClose(rs_stream *st) {
+  if (!st->open) return;
+  std::lock_guard<std::mutex> lk(pool_mu_);
+  if (!pool_) return;
+  pool_->FreeRows(st->row0, st->cap);
+  pool_->free_slots.push_back(st->slot);
+  st->open = false;
+}
+
+// A stream outgrew its row range: move it to a range twice as long (device-to-device copies on the pool's stream).
+void Model::StreamGrow(rs_stream *st, int need_frames) {
+  StreamPool *p = pool_.get();
+  int want = st->cap;
+  while (want < need_frames) want *= 2;
+  const int row0 = p->AllocRows(want);
+  if (row0 < 0) Fail("stream pool exhausted (RS_STREAM_POOL_ROWS=" + std::to_string(p->rows) + " frame rows of live audio)");
+  const size_t n = (size_t)st->cap;
+  auto mv = [&](void *base, size_t row_bytes) {
+    if (base) RS_HIP(hipMemcpyAsync(static_cast<char *>(base) + (size_t)row0 * row_bytes, static_cast<char *>(base) + (size_t)st->row0 * row_bytes, n * row_bytes,
+                                    hipMemcpyDeviceToDevice, p->q));
+  };
+  mv(p->raw, (size_t)p->ld_c * 4); mv(p->cm, (size_t)p->ld_c * 4); mv(p->nn_in, (size_t)p->ld_c * 4); mv(p->ll, (size_t)p->ld_ll * 4);
+  mv(p->bp, (size_t)p->S * 4); mv(p->finfo, 16);
+  if (p->ivec)
+    RS_HIP(hipMemcpyAsync(p->ivec + (size_t)(row0 / p->chunk) * p->ld_i, p->ivec + (size_t)(st->row0 / p->chunk) * p->ld_i,
+                          (size_t)(st->cap / p->chunk) * p->ld_i * 4, hipMemcpyDeviceToDevice, p->q));
+  p->FreeRows(st->row0, st->cap);
+  st->row0 = row0;
+  st->cap = want;
+}
+
+// One advance over `n` streams of this model.  final: end of input for all of them; results go to `res` (n utterances).
+void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res) {
+  std::lock_guard<std::mutex> lk(pool_mu_);
+  StreamPool *p = Pool();
+  RS_HIP(hipSetDevice(opts_.device_id));
+  hipStream_t q = p->q;
+  DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
+  DeviceArena &arena = cx.arena[0];
+  HostArena &harena = cx.host_arena[0];
+  const Nnet &nn = am_.nnet;
+  const bool has_iv = fc_.ie.present;
+  const int C = fc_.mfcc.nceps, P = nn.output_dim, chunk = p->chunk, Rm = nn.right_context;
+  const int shift = fc_.mfcc.shift;
+  const int sl = has_iv ? fc_.ie.splice_left : 0, sr = has_iv ? fc_.ie.splice_right : 0;
+  const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
+  const int ld_c = p->ld_c, ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = p->ld_i, usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
+  auto wall0 = std::chrono::steady_clock::now();
+
+  // ---------------------------------------------------------------- plan (host)
+  struct Plan {
+    int avail = 0;                 // frames computable from the samples accepted so far
+    int mf0 = 0;                   // first new MFCC frame
+    std::vector<std::pair<int, int>> chunks;      // new nnet chunks: (index, last frame its iVector has seen)
+    int sa = 0, sb = 0;            // frames to splice / LDA / score for the iVector statistics: [sa, sb)
+    int t0 = 0, t1 = 0;            // frames that get log-likelihoods in this advance: [t0, t1)
+  };
+  std::vector<Plan> pl(n);
+  int max_new_chunks = 0;
+  for (int i = 0; i < n; i++) {
+    rs_stream &st = *streams[i];
+    Plan &a = pl[i];
+    const long ns = st.n_samples;
+    a.avail = NumFrames(ns, fc_.mfcc.opts);
+    if (a.avail + 2 > st.cap) StreamGrow(&st, a.avail + 2);
+    a.mf0 = st.frames_mfcc;
+    // the tick schedule (DecodeGroup's, resumed): ticks completed by the samples so far; the partial last read counts at EOF
+    const long ticks = final ? (ns + 1023) / 1024 : ns / 1024;
+    const int nch_final = (a.avail + chunk - 1) / chunk;
+    for (long j = st.ticks_done; j < ticks; j++) {
+      const int fr = NumFrames(std::min<long>(1024 * (j + 1), ns), fc_.mfcc.opts);
+      const int ready = std::max(0, fr - Rm) / chunk;
+      while (st.chunks_sched < ready && (!final || st.chunks_sched < nch_final)) {
+        a.chunks.push_back({st.chunks_sched, std::min(fr - 1, fr - sr - 1)});
+        st.chunks_sched++;
+      }
+    }
+    st.ticks_done = ticks;
+    if (final) while (st.chunks_sched < nch_final) { a.chunks.push_back({st.chunks_sched, a.avail - 1}); st.chunks_sched++; }
+    max_new_chunks = std::max(max_new_chunks, (int)a.chunks.size());
+    a.sa = a.sb = st.stats_done;
+    for (auto &c : a.chunks) a.sb = std::max(a.sb, c.second + 1);
+    a.t0 = st.ll_done;
+    a.t1 = a.chunks.empty() ? st.ll_done : (final ? a.avail : std::min(chunk * st.chunks_sched, a.avail));
+  }
+  // ---------------------------------------------------------------- transient geometry of the stages, index arrays
+  IntStage is;
+  std::vector<int> slots(n), row0s(n), avails(n);
+  for (int i = 0; i < n; i++) { slots[i] = streams[i]->slot; row0s[i] = streams[i]->row0; avails[i] = pl[i].avail; }
+  // stage 1: MFCC over the new frames (dense rows, no halo), rows -> pool
+  std::vector<int> m_T, m_rb{0}, m_out;
+  std::vector<int64_t> m_so{0};
+  size_t pcm_total = 0;
+  for (int i = 0; i < n; i++) {
+    const int tn = pl[i].avail - pl[i].mf0;
+    if (tn <= 0) continue;
+    rs_stream &st = *streams[i];
+    const long first = (long)pl[i].mf0 * shift, cnt = st.n_samples - first;
+    m_T.push_back(tn);
+    m_rb.push_back(m_rb.back() + tn);
+    m_so.push_back(m_so.back() + cnt);
+    for (int t = 0; t < tn; t++) m_out.push_back(st.row0 + pl[i].mf0 + t);
+    pcm_total += (size_t)cnt;
+  }
+  const int nM = (int)m_T.size(), rowsM = m_rb.back();
+  m_T.push_back(0);
+  // stage 2: CMVN resumed (same streams)
+  std::vector<int> c_T, c_rb, c_tb, c_slot;
+  for (int i = 0; i < n; i++)
+    if (pl[i].avail > pl[i].mf0) { c_T.push_back(pl[i].avail); c_rb.push_back(streams[i]->row0); c_tb.push_back(pl[i].mf0); c_slot.push_back(streams[i]->slot); }
+  c_rb.push_back(0);
+  // stage 3: iVector segments
+  std::vector<int> I_idx;
+  for (int i = 0; i < n; i++) if (has_iv && !pl[i].chunks.empty()) I_idx.push_back(i);
+  const int nI = (int)I_idx.size();
+  std::vector<int> i_T(nI + 1, 0), i_rb(nI + 1, 0), i_src, i_slot(nI);
+  for (int u = 0; u < nI; u++) {
+    const Plan &a = pl[I_idx[u]];
+    const rs_stream &st = *streams[I_idx[u]];
+    i_T[u] = a.sb - a.sa;
+    i_rb[u + 1] = i_rb[u] + i_T[u] + sl + sr;
+    i_slot[u] = st.slot;
+    for (int r = 0; r < i_T[u] + sl + sr; r++) i_src.push_back(st.row0 + std::min(std::max(a.sa - sl + r, 0), std::max(a.avail - 1, 0)));
+  }
+  const int rowsI = i_rb[nI];
+  std::vector<int> s_fb((size_t)max_new_chunks * std::max(nI, 1), 0), s_fe(s_fb.size(), 0), s_or(s_fb.size(), -1), s_ac(s_fb.size(), 0);
+  for (int u = 0; u < nI; u++) {
+    const Plan &a = pl[I_idx[u]];
+    const rs_stream &st = *streams[I_idx[u]];
+    int done = a.sa;
+    for (size_t k = 0; k < a.chunks.size(); k++) {
+      const size_t o = k * nI + u;
+      s_or[o] = st.row0 / chunk + a.chunks[k].first;
+      if (a.chunks[k].second + 1 > done) { s_fb[o] = done - a.sa; s_fe[o] = a.chunks[k].second + 1 - a.sa; s_ac[o] = 1; done = a.chunks[k].second + 1; }
+    }
+  }
+  // stage 4: nnet segments
+  std::vector<int> N_idx;
+  for (int i = 0; i < n; i++) if (pl[i].t1 > pl[i].t0) N_idx.push_back(i);
+  const int nN = (int)N_idx.size();
+  std::vector<int> n_T(nN + 1, 0), n_rb(nN + 1, 0), n_fb(nN + 1, 0), n_src, n_riv, n_lldst;
+  int maxTn = 0;
+  for (int u = 0; u < nN; u++) {
+    const Plan &a = pl[N_idx[u]];
+    const rs_stream &st = *streams[N_idx[u]];
+    n_T[u] = a.t1 - a.t0;
+    maxTn = std::max(maxTn, n_T[u]);
+    n_rb[u + 1] = n_rb[u] + n_T[u] + L_ + R_;
+    n_fb[u + 1] = n_fb[u] + n_T[u];
+    for (int r = 0; r < n_T[u] + L_ + R_; r++) {
+      const int t = a.t0 - L_ + r;
+      n_src.push_back(st.row0 + std::min(std::max(t, 0), std::max(a.avail - 1, 0)));
+      // the chunk whose iVector this row's Round(ivector, chunk) slot was supplied by (DecodeGroup: row_ivec)
+      const int slot_t = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
+      int k = 0;
+      while (k < st.chunks_sched - 1 && slot_t >= (k + 1) * chunk + Rm) k++;
+      n_riv.push_back(st.row0 / chunk + k);
+    }
+    for (int t = a.t0; t < a.t1; t++) n_lldst.push_back(st.row0 + t);
+  }
+  const int rowsN = n_rb[nN], framesN = n_fb[nN];
+  // stage 5: search windows (every stream of the call: a stream that ends without new rows still needs its traceback)
+  SearchPlan sp;
+  int maxT = 0;
+  for (int i = 0; i < n; i++) maxT = std::max(maxT, pl[i].avail);
+  size_t search_bytes = 0;
+  if (final) search_bytes = PlanSearch(n, maxT, nbest, lat_scale, &sp);
+  const bool reg_windows = p->reg && !(final && sp.want_lattice);
+  std::vector<int> d_T(n + 1, 0), d_rb(n + 1, 0), w_b(n), w_e(n), w_f(n, final ? 1 : 0);
+  for (int i = 0; i < n; i++) {
+    d_T[i] = pl[i].t1; d_rb[i] = streams[i]->row0;
+    w_b[i] = streams[i]->dec_started ? streams[i]->frames_decoded : -1;
+    w_e[i] = pl[i].t1;
+  }
+  const size_t o_mT = is.Add(m_T), o_mrb = is.Add(m_rb), o_mout = is.Add(m_out), o_mso = is.Add64(m_so);
+  const size_t o_cT = is.Add(c_T), o_crb = is.Add(c_rb), o_ctb = is.Add(c_tb), o_cslot = is.Add(c_slot);
+  const size_t o_iT = is.Add(i_T), o_irb = is.Add(i_rb), o_isrc = is.Add(i_src), o_islot = is.Add(i_slot);
+  const size_t o_sfb = is.Add(s_fb), o_sfe = is.Add(s_fe), o_sor = is.Add(s_or), o_sac = is.Add(s_ac);
+  is.Add(n_T);
+  const size_t o_nrb = is.Add(n_rb), o_nfb = is.Add(n_fb), o_nsrc = is.Add(n_src), o_nriv = is.Add(n_riv), o_nll = is.Add(n_lldst);
+  const size_t o_dT = is.Add(d_T), o_drb = is.Add(d_rb), o_wb = is.Add(w_b), o_we = is.Add(w_e), o_wf = is.Add(w_f), o_slots = is.Add(slots), o_row0 = is.Add(row0s);
+  // ---------------------------------------------------------------- arena
+  const int guard = L_ + R_ + 8;
+  auto fbytes = [&](int rows, int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
+  std::vector<int> buf_ld(nn.bufs.size());
+  size_t need = is.h.size() * 4 + pcm_total * 2 + 4096 + 3 * sizeof(int) * (size_t)(rowsM + rowsI + rowsN + 64) + sizeof(int) * (size_t)(framesN + 64);
+  for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(rowsN, buf_ld[b]); }
+  if (has_iv) {
+    need += 2 * fbytes(rowsI, ld_c) + 2 * fbytes(rowsI, ld_l) + (size_t)rowsI * nsel * 8 + 4096;
+    need += (size_t)std::max(nI, 1) * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 16 + (size_t)usz * 8 + 64) + 8192;
+    need += IvecStatsScratchDoubles(ivec_dev_, std::max(nI, 1)) * 8 + 1024;
+  }
+  need += search_bytes + (size_t)n * 64 * 8 + 64 * 256 + (1u << 20);
+  arena.Reserve(need, q);
+  arena.Reset();
+  harena.Reset();
+  // ---------------------------------------------------------------- uploads: index arrays, new samples
+  int *d_is = arena.AllocT<int>(is.h.size() + 16);
+  {
+    int *hp = harena.AllocT<int>(is.h.size() + 16);
+    std::memcpy(hp, is.h.data(), is.h.size() * 4);
+    RS_HIP(hipMemcpyAsync(d_is, hp, is.h.size() * 4, hipMemcpyHostToDevice, q));
+  }
+  auto D = [&](size_t off) { return d_is + off; };
+  int16_t *d_pcm = arena.AllocT<int16_t>(pcm_total + 512);
+  if (pcm_total) {
+    int16_t *hp = harena.AllocT<int16_t>(pcm_total + 512);
+    size_t o = 0;
+    for (int i = 0; i < n; i++) {
+      rs_stream &st = *streams[i];
+      if (pl[i].avail <= pl[i].mf0) continue;
+      const long first = (long)pl[i].mf0 * shift, cnt = st.n_samples - first;
+      std::memcpy(hp + o, st.pcm.data() + (first - st.pcm_start), sizeof(int16_t) * (size_t)cnt);
+      o += (size_t)cnt;
+    }
+    RS_HIP(hipMemcpyAsync(d_pcm, hp, sizeof(int16_t) * pcm_total, hipMemcpyHostToDevice, q));
+  }
+  Timer tm(q);
+  tm.Mark();
+  // ---------------------------------------------------------------- 1. MFCC
+  if (nM > 0) {
+    BatchGeom g;
+    g.n_utts = nM; g.total_rows = rowsM; g.total_frames = rowsM;
+    g.d_sample_off = reinterpret_cast<const int64_t *>(D(o_mso)); g.d_num_frames = D(o_mT); g.d_row_base = D(o_mrb);
+    int *ru = arena.AllocT<int>(rowsM), *rt = arena.AllocT<int>(rowsM);
+    LaunchRowGeometry(nM, rowsM, 0, D(o_mrb), nullptr, ru, rt, nullptr, q);
+    g.d_row_utt = ru; g.d_row_t = rt;
+    LaunchMfcc(mfcc_dev_, g, d_pcm, p->raw, ld_c, q, false, D(o_mout));
+    // ---------------------------------------------------------------- 2. CMVN, resumed
+    BatchGeom gc;
+    gc.n_utts = nM; gc.d_num_frames = D(o_cT); gc.d_row_base = D(o_crb);
+    if (has_iv) LaunchOnlineCmvn(cmvn_iv_dev_, gc, p->raw, p->cm, ld_c, q, D(o_ctb), p->cmvn_iv, D(o_cslot));
+    if (fc_.use_cmvn) LaunchOnlineCmvn(cmvn_nnet_dev_, gc, p->raw, p->nn_in, ld_c, q, D(o_ctb), p->cmvn_nn, D(o_cslot));
+  }
+  tm.Mark();
+  // ---------------------------------------------------------------- 3. iVectors of the new chunks
+  auto falloc = [&](int rows, int ld) { return arena.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
+  if (nI > 0) {
+    float *seg_raw = falloc(rowsI, ld_c), *seg_cm = falloc(rowsI, ld_c), *lda_raw = falloc(rowsI, ld_l), *lda_norm = falloc(rowsI, ld_l);
+    LaunchCopyRows(p->raw, ld_c, D(o_isrc), seg_raw, ld_c, nullptr, rowsI, C, q);
+    LaunchCopyRows(p->cm, ld_c, D(o_isrc), seg_cm, ld_c, nullptr, rowsI, C, q);
+    BatchGeom g;
+    g.n_utts = nI; g.L = sl; g.R = sr; g.total_rows = rowsI; g.guard = guard;
+    g.d_num_frames = D(o_iT); g.d_row_base = D(o_irb);
+    int *ru = arena.AllocT<int>(rowsI + 8), *rt = arena.AllocT<int>(rowsI + 8);
+    LaunchRowGeometry(nI, rowsI, sl, D(o_irb), nullptr, ru, rt, nullptr, q);
+    g.d_row_utt = ru; g.d_row_t = rt;
+    LaunchGemm(MakeGemm(lda_plan_, {seg_raw}, {ld_c}, nullptr, 0, lda_raw, ld_l, 1), rowsI, ru, q);
+    LaunchGemm(MakeGemm(lda_plan_, {seg_cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, 1), rowsI, ru, q);
+    int *post_idx = arena.AllocT<int>((size_t)rowsI * nsel + 64);
+    float *post_w = arena.AllocT<float>((size_t)rowsI * nsel + 64);
+    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, q);
+    double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
+    double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
+    double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
+    double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, nI));
+    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)nI * G, q));
+    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)nI * G * Dl, q));
+    // estimator state: slots -> dense, the steps, dense -> slots
+    LaunchCopyRows(p->lin, 2 * Di, D(o_islot), linear, 2 * Di, nullptr, nI, 2 * Di, q);
+    LaunchCopyRows(p->quad, 2 * usz, D(o_islot), quad, 2 * usz, nullptr, nI, 2 * usz, q);
+    LaunchCopyRows(p->numf, 2, D(o_islot), numf, 2, nullptr, nI, 2, q);
+    LaunchCopyRows(p->x, 2 * Di, D(o_islot), x, 2 * Di, nullptr, nI, 2 * Di, q);
+    const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
+    for (int k = 0; k < max_new_chunks; k++) {
+      const size_t o = (size_t)k * nI;
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, q);
+      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, q);
+      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, q);
+      LaunchIvecClear(ivec_dev_, nI, gamma, wfeats, q);
+    }
+    LaunchCopyRows(linear, 2 * Di, nullptr, p->lin, 2 * Di, D(o_islot), nI, 2 * Di, q);
+    LaunchCopyRows(quad, 2 * usz, nullptr, p->quad, 2 * usz, D(o_islot), nI, 2 * usz, q);
+    LaunchCopyRows(numf, 2, nullptr, p->numf, 2, D(o_islot), nI, 2, q);
+    LaunchCopyRows(x, 2 * Di, nullptr, p->x, 2 * Di, D(o_islot), nI, 2 * Di, q);
+  }
+  tm.Mark();
+  // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context)
+  if (nN > 0) {
+    std::vector<float *> bufp(nn.bufs.size(), nullptr);
+    for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(rowsN, buf_ld[b]);
+    LaunchCopyRows(fc_.use_cmvn ? p->nn_in : p->raw, ld_c, D(o_nsrc), bufp[nn.input_buf], buf_ld[nn.input_buf], nullptr, rowsN, C, q);
+    int *frame_rows = arena.AllocT<int>(framesN + 8);
+    LaunchFrameRows(nN, nN, framesN, L_, std::max(maxTn, 1), D(o_nfb), D(o_nrb), frame_rows, q);
+    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, frame_rows, framesN, 1, 0, nn.ops.size(), q);
+    LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
+  }
+  tm.Mark();
+  // ---------------------------------------------------------------- 5. search
+  BatchGeom gd;
+  gd.n_utts = n; gd.max_frames = maxT; gd.d_num_frames = D(o_dT); gd.d_row_base = D(o_drb);
+  if (final) AllocSearch(&sp, arena, q, /*pooled_frames=*/reg_windows);
+  if (reg_windows) {
+    DenseWork dw;
+    std::memset(&dw, 0, sizeof(dw));
+    if (final) dw = sp.dw;
+    dw.bp = p->bp; dw.frame_info = p->finfo; dw.state_cost = p->dec_state; dw.counters = p->dec_ctr;
+    dw.win_begin = D(o_wb); dw.win_end = D(o_we); dw.win_final = D(o_wf); dw.pool_row = D(o_row0); dw.slot = D(o_slots);
+    DecodeOptsDev dopts;
+    dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
+    dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
+    LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw, 0, 0, q, final);
+    if (final) LaunchCopyRows(p->dec_ctr, 16, D(o_slots), sp.w.counters, 16, nullptr, n, 16, q);
+  } else if (final) {
+    LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, q);
+  }
+  tm.Mark();
+  // ---------------------------------------------------------------- host bookkeeping
+  for (int i = 0; i < n; i++) {
+    rs_stream &st = *streams[i];
+    const Plan &a = pl[i];
+    st.frames_mfcc = a.avail;
+    st.stats_done = a.sb;
+    st.ll_done = a.t1;
+    if (reg_windows) { st.frames_decoded = a.t1; st.dec_started = true; }
+    // samples before the first frame that is not complete yet are not needed again (online-feature.cc:186-203)
+    const long keep_from = (long)a.avail * shift;
+    if (!st.keep_pcm && keep_from > st.pcm_start) {
+      st.pcm.erase(st.pcm.begin(), st.pcm.begin() + std::min<long>(keep_from - st.pcm_start, (long)st.pcm.size()));
+      st.pcm_start = keep_from;
+    }
+  }
+  if (!final) {
+    RS_HIP(hipStreamSynchronize(q));
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+    return;
+  }
+  // ---------------------------------------------------------------- results
+  res->utts.resize(n);
+  for (int i = 0; i < n; i++) res->utts[i].num_frames = pl[i].avail;
+  CollectResults(sp, cx, 0, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, q, res->utts.data(), res->timings);
+  tm.Mark();
+  if (opts_.keep_intermediates) {
+    const float *fin = fc_.use_cmvn ? p->nn_in : p->raw;
+    for (int i = 0; i < n; i++) {
+      UttResult &ur = res->utts[i];
+      const rs_stream &st = *streams[i];
+      const int T = pl[i].avail, nch = std::max((T + chunk - 1) / chunk, 1);
+      ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? nch : 0;
+      if (T == 0) continue;
+      ur.feats.resize((size_t)T * C);
+      ur.loglikes.resize((size_t)T * P);
+      RS_HIP(hipMemcpy2D(ur.feats.data(), sizeof(float) * C, fin + (size_t)st.row0 * ld_c, sizeof(float) * ld_c, sizeof(float) * C, T, hipMemcpyDeviceToHost));
+      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, p->ll + (size_t)st.row0 * p->ld_ll, sizeof(float) * p->ld_ll, sizeof(float) * P, T,
+                         hipMemcpyDeviceToHost));
+      if (has_iv) {
+        ur.ivector.resize((size_t)nch * Di);
+        RS_HIP(hipMemcpy2D(ur.ivector.data(), sizeof(float) * Di, p->ivec + (size_t)(st.row0 / chunk) * ld_i, sizeof(float) * ld_i, sizeof(float) * Di, nch,
+                           hipMemcpyDeviceToHost));
+      }
+    }
+  }
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le)); }
+  res->timings[1] = tm.Ms(0, 1);
+  res->timings[2] = tm.Ms(1, 2);
+  res->timings[3] = tm.Ms(2, 3);
+  res->timings[4] = tm.Ms(3, 4);
+  res->timings[5] = tm.Ms(4, 5);
+  res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+}
+
+}  // namespace rs

@@ -65,7 +65,10 @@ class KaldiNnet3StreamTranscriber:
         try:
             async for chunk in audio_stream:
                 if chunk:
+                    # the reference writes the chunk to the decoder's stdin (transcribe_stream.py:73-76), which decodes as it reads;
+                    # here: hand the samples over and let the device do what they make possible (MFCC, iVector, nnet chunks, search)
                     stream.accept(chunk)
+                    stream.advance()
             _LOGGER.debug("Stream ended")
             loop = asyncio.get_running_loop()
             try:

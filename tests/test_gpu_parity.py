@@ -174,16 +174,26 @@ def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
 STREAM_CASES = list(cases.CASES)
 
 
+@pytest.mark.parametrize("mode", ["finish_only", "advance_every_accept", "advance_irregular"])
 @pytest.mark.parametrize("name", STREAM_CASES)
-def test_streaming_case(case_cache, name):
-    """online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one warm-started iVector per nnet chunk."""
+def test_streaming_case(case_cache, name, mode):
+    """online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one warm-started iVector per nnet chunk.  The device work
+    happens in rs_streams_advance as the audio arrives (finish_only: everything at the end); how the caller slices the audio
+    and when it advances must not change anything -- every mode is held to the same reference goldens."""
     from rhasspy_speech_amd import _lib
     g = load_golden(name)
     model, pcm = make_model(case_cache, name)
     st = _lib.Stream(model)
     # deliberately odd chunking: the result must not depend on it
-    for i in range(0, len(pcm), 777):
-        st.accept(pcm[i:i + 777])
+    rng = np.random.default_rng(len(name))
+    pos, k = 0, 0
+    while pos < len(pcm):
+        step = 777 if mode != "advance_irregular" else int(rng.integers(1, 9000))
+        st.accept(pcm[pos:pos + step])
+        pos += step
+        k += 1
+        if mode == "advance_every_accept" or (mode == "advance_irregular" and k % 3 == 0):
+            st.advance()
     res = st.finish(nbest=cases.NBEST)
     assert res.num_frames(0) == int(g["stream_num_frames"])
     if "stream_ivector" in g:
@@ -196,6 +206,67 @@ def test_streaming_case(case_cache, name):
     ref = parse_nbest(bytes(g["stream_nbest_text"]))
     assert [res.words(0, k) for k in range(res.num_hyps(0))] == ref
     assert res.text(0).split() == bytes(g["stream_nbest_text"]).split()
+
+
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_noiv_u2", "tiny_cmvn_u4", "zam_u1", "zam_s12005", "tiny_arpa_u7"])
+def test_incremental_stream_equals_batch_replay(case_cache, name, monkeypatch):
+    """The incremental engine (stream.cc) against the batch replay of the same stream (DecodeGroup(streaming = true),
+    RS_STREAM_BATCH=1): features, per-chunk iVectors and log-likelihoods bit for bit, same 1-best and n-best."""
+    from rhasspy_speech_amd import _lib
+    model, pcm = make_model(case_cache, name)
+
+    def run(advance):
+        st = _lib.Stream(model)
+        for i in range(0, len(pcm), 2048):
+            st.accept(pcm[i:i + 2048])
+            if advance:
+                st.advance()
+        return st.finish(nbest=1), None
+
+    inc, _ = run(True)
+    monkeypatch.setenv("RS_STREAM_BATCH", "1")
+    rep, _ = run(False)
+    monkeypatch.delenv("RS_STREAM_BATCH")
+    for kind in (0, 1, 2):
+        if kind == 1 and cases.CASES[name]["spec"].get("ivector_dim", 1) == 0:
+            continue
+        np.testing.assert_array_equal(inc.matrix(0, kind), rep.matrix(0, kind))
+    assert inc.words(0) == rep.words(0)
+    assert inc.costs(0) == rep.costs(0)
+    # n-best through the lattice at the end of an incrementally decoded stream (the token-list search then runs at finish)
+    st = _lib.Stream(model)
+    for i in range(0, len(pcm), 5000):
+        st.accept(pcm[i:i + 5000])
+        st.advance()
+    nb = st.finish(nbest=cases.NBEST)
+    ref = parse_nbest(bytes(load_golden(name)["stream_nbest_text"]))
+    assert [nb.words(0, k) for k in range(nb.num_hyps(0))] == ref
+
+
+def test_finish_after_incremental_advances_is_cheap(case_cache):
+    """A 30 s stream advanced as its audio arrives: what is left for finish is the last chunk -- its wall time must be a small
+    fraction of decoding the whole stream at the end (same stream, no advances)."""
+    import time
+    from rhasspy_speech_amd import _lib
+    model, pcm = make_model(case_cache, "zam_long30", keep_intermediates=0)
+
+    def run(advance):
+        st = _lib.Stream(model)
+        for i in range(0, len(pcm), 8192):
+            st.accept(pcm[i:i + 8192])
+            if advance:
+                st.advance()
+        t0 = time.perf_counter()
+        res = st.finish()
+        return res, time.perf_counter() - t0
+
+    run(True), run(False)                       # warm both paths (arenas, pool)
+    inc, t_inc = run(True)
+    full, t_full = run(False)
+    assert inc.words(0) == full.words(0) and inc.costs(0) == full.costs(0)
+    assert t_inc < 0.25 * t_full, (t_inc, t_full)
+    # ... and in device time: the finishing call's stages add up to less than a tenth of the whole stream's
+    assert sum(inc.timings()[1:5]) < 0.1 * sum(full.timings()[1:5]), (inc.timings(), full.timings())
 
 
 def test_many_streams_one_batch(case_cache):
