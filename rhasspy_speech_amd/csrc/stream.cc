@@ -109,7 +109,7 @@ StreamPool *Model::Pool() {
   const Nnet &nn = am_.nnet;
   const int C = fc_.mfcc.nceps, P = nn.output_dim;
   p->chunk = opts_.frames_per_chunk;
-  p->rows = RoundUp(std::max(EnvInt("RS_STREAM_POOL_ROWS", 1 << 18), 4 * p->chunk), p->chunk);      // 2^18 frames = 44 min of live audio
+  p->rows = RoundUp(std::max(EnvInt("RS_STREAM_POOL_ROWS", 1 << 19), 4 * p->chunk), p->chunk);      // 2^19 frames = 87 min of live audio; ~10 KB per row for a 2000-pdf model
   p->max_slots = std::max(EnvInt("RS_STREAM_SLOTS", 512), 1);
   p->ld_c = RoundUp(C, 4);
   p->ld_ll = RoundUp(P, 4);
