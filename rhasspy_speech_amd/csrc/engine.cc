@@ -237,6 +237,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
   // (16-wide k-step, 32-column tile, part) as one 1 KiB MFMA B fragment [k-group 2][column 32][8 bf16].
   plan->n3 = RoundUp(op.out_dim, 256);
   plan->d_W3 = nullptr;
+  plan->d_W3I = nullptr;
   if (op.out_dim >= 192) {
     auto to_bf16 = [](float x) {
       uint32_t u;
@@ -245,7 +246,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
       return (uint16_t)(u >> 16);
     };
     auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
-    const int nct = plan->n3 / 32, nks = plan->k_pad / 16;
+    const int nct = plan->n3 / 32;
     // k-step order: segment after segment, or -- when every segment is a row-shifted view of the same columns of one
     // buffer -- alternating between the segments (step t = segment t % nsegs, columns 16 (t / nsegs))
     const int nsegs = (int)op.segs.size();
@@ -253,24 +254,47 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     for (auto &sg : op.segs)
       plan->interleave = plan->interleave && sg.src_buf >= 0 && sg.src_buf == op.segs[0].src_buf && sg.src_col == op.segs[0].src_col &&
                          sg.ncols == op.segs[0].ncols;
-    std::vector<int> step_k(nks);          // first W column of k-step t
-    for (int t = 0; t < nks; t++)
-      step_k[t] = plan->interleave ? plan->seg_k0[t % nsegs] + (t / nsegs) * 16 : t * 16;
-    std::vector<uint16_t> W3((size_t)(nks + 2) * nct * 3 * 512, 0);      // + 2 k-steps the kernel's pipeline requests past the end
-    for (int n = 0; n < op.out_dim; n++)
-      for (int t = 0; t < nks; t++)
-        for (int kk = 0; kk < 16; kk++) {
-          const float w = W[(size_t)n * plan->k_pad + step_k[t] + kk];
-          if (w == 0.0f) continue;
-          const uint16_t h1 = to_bf16(w);
-          const float r1 = w - from_bf16(h1);
-          const uint16_t h2 = to_bf16(r1);
-          const float r2 = r1 - from_bf16(h2);
-          const uint16_t h3 = to_bf16(r2);
-          const size_t base = ((size_t)t * nct + n / 32) * 3 * 512 + (size_t)(kk / 8) * 256 + (size_t)(n % 32) * 8 + kk % 8;
-          W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
-        }
-    plan->d_W3 = UploadBytes(W3.data(), W3.size() * sizeof(uint16_t));
+    // image of W for a list of k-steps (first W column of each): [k-step][32-column tile][part][k-group 2][column 32][8 bf16]
+    auto build = [&](const std::vector<int> &step_k) {
+      const int nks = (int)step_k.size();
+      std::vector<uint16_t> W3((size_t)(nks + 2) * nct * 3 * 512, 0);      // + 2 k-steps the kernels' pipelines request past the end
+      for (int n = 0; n < op.out_dim; n++)
+        for (int t = 0; t < nks; t++)
+          for (int kk = 0; kk < 16; kk++) {
+            const float w = W[(size_t)n * plan->k_pad + step_k[t] + kk];
+            if (w == 0.0f) continue;
+            const uint16_t h1 = to_bf16(w);
+            const float r1 = w - from_bf16(h1);
+            const uint16_t h2 = to_bf16(r1);
+            const float r2 = r1 - from_bf16(h2);
+            const uint16_t h3 = to_bf16(r2);
+            const size_t base = ((size_t)t * nct + n / 32) * 3 * 512 + (size_t)(kk / 8) * 256 + (size_t)(n % 32) * 8 + kk % 8;
+            W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
+          }
+      return UploadBytes(W3.data(), W3.size() * sizeof(uint16_t));
+    };
+    // (1) GemmKernelB3: every segment spans its width padded to kGemmBK
+    {
+      const int nks = plan->k_pad / 16;
+      std::vector<int> step_k(nks);
+      for (int t = 0; t < nks; t++) step_k[t] = plan->interleave ? plan->seg_k0[t % nsegs] + (t / nsegs) * 16 : t * 16;
+      plan->d_W3 = build(step_k);
+    }
+    // (2) GemmKernelB3I (sources stored as operand images): segments padded to the 16-wide k-step only; needs every source
+    // to be a frame buffer whose first column sits on a k-step boundary
+    bool imageable = true;
+    for (auto &sg : op.segs) imageable = imageable && sg.src_buf >= 0 && sg.src_col % 16 == 0;
+    if (imageable) {
+      std::vector<int> step_k;
+      if (plan->interleave) {
+        const int per = (op.segs[0].ncols + 15) / 16;
+        for (int t = 0; t < per * nsegs; t++) step_k.push_back(plan->seg_k0[t % nsegs] + (t / nsegs) * 16);
+      } else {
+        for (int si = 0; si < nsegs; si++)
+          for (int k = 0; k < (op.segs[si].ncols + 15) / 16; k++) step_k.push_back(plan->seg_k0[si] + k * 16);
+      }
+      plan->d_W3I = build(step_k);
+    }
   }
   plan->d_bias = op.bias.empty() ? nullptr : Upload(op.bias);
   plan->d_stage.clear();
@@ -366,6 +390,27 @@ void Model::ToDevice() {
   // ---- nnet
   gemm_plans_.assign(am_.nnet.ops.size(), GemmPlan());
   for (size_t i = 0; i < am_.nnet.ops.size(); i++) BuildGemmPlan(am_.nnet.ops[i], &gemm_plans_[i]);
+  {
+    // operand images: a buffer gets one when a split-bf16 layer reads it through GemmKernelB3I; it is still stored as plain
+    // floats when anything else reads it (the nnet's input / output, an elementwise op, a layer on another kernel)
+    const Nnet &nn = am_.nnet;
+    buf_image_.assign(nn.bufs.size(), 0);
+    buf_f32_.assign(nn.bufs.size(), 0);
+    buf_f32_[nn.input_buf] = 1;
+    buf_f32_[nn.output_buf] = 1;
+    for (size_t i = 0; i < nn.ops.size(); i++) {
+      const LayerOp &op = nn.ops[i];
+      if (op.kind == LayerOp::kGemm) {
+        // (the nnet's input buffer is written by the feature kernels, not by a layer: a layer that reads it splits on the fly)
+        bool by_image = gemm_plans_[i].d_W3I != nullptr;
+        for (auto &sg : op.segs) by_image = by_image && sg.src_buf >= 0 && sg.src_buf != nn.input_buf;
+        for (auto &sg : op.segs)
+          if (sg.src_buf >= 0) (by_image ? buf_image_ : buf_f32_)[sg.src_buf] = 1;
+      } else {
+        for (auto &t : op.terms) buf_f32_[t.src_buf] = 1;
+      }
+    }
+  }
   if (!am_.nnet.priors.empty()) {
     std::vector<float> lp(am_.nnet.priors.size());
     for (size_t i = 0; i < lp.size(); i++) lp[i] = logf(am_.nnet.priors[i]);
@@ -654,21 +699,53 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
   return res;
 }
 
+size_t Model::ImageBytes(int rows) const {
+  size_t b = 0;
+  const int guard = RoundUp(L_ + R_ + 8, 32);
+  for (size_t i = 0; i < buf_image_.size(); i++)
+    if (buf_image_[i]) b += 3 * ActImagePartBytes(rows, guard, am_.nnet.bufs[i].dim) + 1024;
+  return b;
+}
+
+std::vector<ActImage> Model::AllocImages(DeviceArena &arena, int rows) const {
+  std::vector<ActImage> imgs(buf_image_.size(), ActImage{nullptr, 0, 0, 0});
+  const int guard = RoundUp(L_ + R_ + 8, 32);
+  for (size_t i = 0; i < buf_image_.size(); i++) {
+    if (!buf_image_[i]) continue;
+    ActImage &im = imgs[i];
+    im.part_bytes = ActImagePartBytes(rows, guard, am_.nnet.bufs[i].dim);
+    im.base = static_cast<unsigned char *>(arena.Alloc(3 * im.part_bytes));
+    im.nks = (am_.nnet.bufs[i].dim + 15) / 16;
+    im.guard = guard;
+  }
+  return imgs;
+}
+
 GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld, float *out,
-                        int ldo, int share) const {
+                        int ldo, int share, const std::vector<ActImage> *imgs, int out_buf) const {
   GemmDev d;
   std::memset(&d, 0, sizeof(d));
   const LayerOp &op = *pl.op;
+  const bool images_on = imgs != nullptr && GemmImagesEnabled();
   d.nsegs = (int)op.segs.size();
   for (int i = 0; i < d.nsegs; i++) {
     const GemmSegment &sg = op.segs[i];
     GemmSegDev &o = d.segs[i];
     if (sg.src_buf < 0) { o.src = ivec; o.ld = ivec_ld; o.per_utt = 1; o.row_off = 0; }
-    else { o.src = src[sg.src_buf]; o.ld = src_ld[sg.src_buf]; o.per_utt = 0; o.row_off = sg.offset; }
+    else {
+      o.src = src[sg.src_buf]; o.ld = src_ld[sg.src_buf]; o.per_utt = 0; o.row_off = sg.offset;
+      if (images_on) o.img = (*imgs)[sg.src_buf];
+    }
     o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
   }
   d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
   d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = share;
+  d.W3I = images_on ? pl.d_W3I : nullptr;
+  d.write_f32 = 1;
+  if (images_on && out_buf >= 0 && (*imgs)[out_buf].base) {
+    d.out_img = (*imgs)[out_buf];
+    d.write_f32 = buf_f32_[out_buf] ? 1 : 0;
+  }
   d.exclusive = (ctx_.size() > 1 && std::getenv("RS_GEMM_B3_EXCLUSIVE")) ? 1 : 0;
   d.nstages = (int)op.stages.size();
   for (int i = 0; i < d.nstages; i++) {
@@ -683,12 +760,18 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
 // The acoustic model's ops [op_begin, op_end) on one set of frame buffers (kernels.h row layout).  Layers whose halo nobody
 // reads run on the real frames only (frame_rows, when given).
 void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
-                    const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s) const {
+                    const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s,
+                    const std::vector<ActImage> *imgs) const {
   const Nnet &nn = am_.nnet;
+  const bool images_on = imgs != nullptr && GemmImagesEnabled();
   for (size_t i = op_begin; i < op_end; i++) {
     const LayerOp &op = nn.ops[i];
+    const bool img_out = images_on && (*imgs)[op.out_buf].base != nullptr;
+    bool img_done = false;
     if (op.kind == LayerOp::kGemm) {
-      GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf], share);
+      GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf], share, imgs, (int)op.out_buf);
+      if (img_out && !GemmWritesImage(gd)) gd.write_f32 = 1;      // a kernel without the image epilogue: converted below
+      else img_done = img_out;
       const BufferInfo &ob = nn.bufs[op.out_buf];
       if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
         gd.row_map = d_frame_rows;
@@ -723,6 +806,7 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       d.nstages = ns;
       LaunchEltwise(d, rows, s);
     }
+    if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, rows, (*imgs)[op.out_buf], s);
   }
   if (op_end == nn.ops.size() && (d_log_priors_ || opts_.acoustic_scale != 1.0f))
     LaunchPriorScale(bufp[nn.output_buf], buf_ld[nn.output_buf], rows, nn.output_dim, d_log_priors_, opts_.acoustic_scale, s);
@@ -1023,6 +1107,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   need += sizeof(int) * ((size_t)frame_base[n_utts] + 8 * (size_t)n_utts + 64) + 1024;     // frame-row map
   std::vector<int> buf_ld(nn.bufs.size());
   for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
+  need += ImageBytes(rows);
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
   const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
   const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
@@ -1109,6 +1194,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   // ---- features
   std::vector<float *> bufp(nn.bufs.size(), nullptr);
   for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(buf_ld[b]);
+  const std::vector<ActImage> imgs = AllocImages(arena_, rows);
   float *raw = bufp[nn.input_buf];
   if (fc_.use_cmvn) {
     raw = falloc(ld_c);
@@ -1188,10 +1274,11 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   tm.Mark();
   // ---- acoustic model
   if (pipelined) {
-    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size() - 1, s);
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size() - 1, s, &imgs);
     // slab k: output layer on the main stream, then the search of that slab on the decode stream
     const size_t i = nn.ops.size() - 1;
-    GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[nn.ops[i].out_buf], buf_ld[nn.ops[i].out_buf], cx.active_groups);
+    GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[nn.ops[i].out_buf], buf_ld[nn.ops[i].out_buf], cx.active_groups, &imgs,
+                          (int)nn.ops[i].out_buf);
     for (int k = 0; k < n_slabs; k++) {
       gd.row_map = d_frame_rows + slab_off[k];
       LaunchGemm(gd, slab_off[k + 1] - slab_off[k], d_row_ivec, s);
@@ -1203,7 +1290,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     RS_HIP(hipEventRecord(cx.slab_ev[8], cx.stream_dec));
   } else {
     poison();
-    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size(), s);
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size(), s, &imgs);
   }
   float *ll = bufp[nn.output_buf];
   const int ll_ld = buf_ld[nn.output_buf];

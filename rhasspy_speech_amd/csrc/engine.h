@@ -72,6 +72,7 @@ struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   const LayerOp *op = nullptr;
   float *d_W = nullptr, *d_bias = nullptr;
   void *d_W3 = nullptr;           // split-bf16 image of W for GemmKernelB3 (layers at least 192 columns wide)
+  void *d_W3I = nullptr;          // the same for GemmKernelB3I (every source a frame buffer on a k-step boundary)
   int k_pad = 0, n_pad = 0, n3 = 0;
   bool interleave = false;        // W3 k-steps alternate between the segments (see GemmKernelB3)
   std::vector<int> seg_k0;
@@ -132,15 +133,22 @@ class Model {
   template <typename T> T *Upload(const std::vector<T> &v);
   void *UploadBytes(const void *p, size_t bytes);
   void BuildGemmPlan(const LayerOp &op, GemmPlan *plan);
+  // imgs (may be null): operand images of the frame buffers (kernels.h: ActImage), indexed like src; out_buf = index of the
+  // buffer `out` belongs to (-1: none of them)
   GemmDev MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld, float *out, int ldo,
-                   int share) const;
+                   int share, const std::vector<ActImage> *imgs = nullptr, int out_buf = -1) const;
+  // operand images for the buffers the split-bf16 GEMM reads as images: bytes needed / allocation from a call's arena
+  size_t ImageBytes(int rows) const;
+  std::vector<ActImage> AllocImages(DeviceArena &arena, int rows) const;
+  std::vector<char> buf_image_, buf_f32_;      // per nnet buffer: has an operand image / is (also) read as plain floats
   size_t PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, SearchPlan *sp) const;
   void AllocSearch(SearchPlan *sp, DeviceArena &arena, hipStream_t s, bool pooled_frames = false) const;
   void LaunchSearch(SearchPlan *sp, DeviceArena &arena, const BatchGeom &g, const float *ll, int ll_ld, hipStream_t s) const;
   void CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const BatchGeom &g, const int *T, const float *ll, int ll_ld, int nbest,
                       float lat_scale, hipStream_t s, UttResult *out_utts, float *timings);
   void RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
-               const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s) const;
+               const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s,
+               const std::vector<ActImage> *imgs = nullptr) const;
 
   rs_decode_opts opts_;
   FeatureConfig fc_;

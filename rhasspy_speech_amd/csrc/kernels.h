@@ -72,7 +72,18 @@ void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, flo
 
 // ---------------------------------------------------------------- generic segmented GEMM (FP32 MFMA)
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
+// A frame buffer stored a second time in the operand order of the bf16 matrix cores, already split into the three bf16
+// parts of nnet_gemm_b3.hip: part p at base + p * part_bytes, inside a part [row block of 32][16-wide k-step][k-group 2]
+// [row 32][8 bf16] -- one 1 KiB block is one A fragment of v_mfma_f32_32x32x16_bf16 (lane l: row l & 31, k-group l >> 5).
+// Image row = buffer row + guard (a multiple of 32); columns beyond the buffer's width up to 16 * nks are zero.
+struct ActImage {
+  unsigned char *base;
+  size_t part_bytes;
+  int nks;
+  int guard;
+};
 struct GemmSegDev {
+  ActImage img;       // the source buffer's operand image (base null: none)
   const float *src;   // source buffer base (row 0 of the frame buffer), or iVector matrix if per_utt
   int ld;             // leading dimension of the source
   int col0;           // first source column
@@ -94,6 +105,7 @@ struct GemmDev {
   const float *W;     // n_pad x k_pad, row-major, zero padded (k_pad = sum of segment widths rounded to kGemmBK)
   int k_pad, n, n_pad;
   const void *W3;     // the same weights split into three bf16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
+  const void *W3I;    // the same for GemmKernelB3I: segments padded to the 16-wide k-step instead of to kGemmBK, or null
   int n3;             // columns of W3 (n rounded up to 256)
   int interleave;     // 1: W3's k-steps alternate between the segments (all segments shifted views of one buffer)
   int exclusive;      // 1: GemmKernelB3 keeps every other workgroup off its CU (several decode pipelines in flight)
@@ -103,9 +115,16 @@ struct GemmDev {
   EltStageDev stages[kMaxStages];
   float *out;
   int ldo;
+  ActImage out_img;    // base non-null: the result is (also) written as an operand image for the layers that consume it
+  int write_f32;       // 0: nobody reads `out` as floats (every consumer takes the image): skip that store
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
 };
+// f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, hipStream_t s);
+size_t ActImagePartBytes(int rows, int guard, int dim);      // bytes of one part for a buffer of `rows` rows
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
+bool GemmWritesImage(const GemmDev &d);      // the kernel LaunchGemm picks writes d.out_img (else: LaunchToImage afterwards)
+bool GemmImagesEnabled();                     // RS_GEMM_B3I / RS_GEMM_B3 (read per call)
 
 struct SumTermDev { const float *src; int ld, col0, row_off; float scale; };
 struct EltwiseDev {

@@ -29,5 +29,8 @@ inline int GemmEpiMode(const GemmDev &d, int rows) {
 // nnet_gemm_b3.hip
 bool GemmB3Usable(const GemmDev &d);
 void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
+// nnet_gemm_b3i.hip (sources stored as operand images)
+bool GemmB3IUsable(const GemmDev &d);
+void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s);
 
 }  // namespace rs

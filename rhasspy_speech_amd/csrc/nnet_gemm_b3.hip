@@ -33,20 +33,11 @@
 #include <cstdint>
 #include <cstdlib>
 
-#include "decode_common.h"
-#include "kernels.h"
-#include "nnet_common.h"
+#include "nnet_b3_common.h"
 
 namespace rs {
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kB3BN = 256, kB3KS = 16;
-constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
+using namespace b3;
 
 // WM = 1: 256 threads, two workgroups per CU.  WM = 2: 512 threads = two such wave rows stacked (64 MR rows), launched with
 // (almost) all of the CU's LDS so that no other workgroup shares the CU -- used when several decode pipelines are in flight
@@ -232,68 +223,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
-  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Bias
-  // and the fused stages are applied in registers; each 32-row slab of the tile is then transposed through LDS (free
-  // after the loop; pitch 264 floats keeps both halves of a wave on different banks) and leaves as 16-byte row-contiguous
-  // stores, 1 KiB per row and wave instruction -- storing straight from the accumulators (two rows x 128 bytes per
-  // instruction) cost 40 us of a 200 us hidden layer.
-  constexpr int C_LD = BN + 8;
-  float *Cs = reinterpret_cast<float *>(smem);
-  const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
-  float bias[2], sc[2], of[2];
-  int ccol[2];
-#pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-    const bool cok = col < d.n;
-    ccol[j] = cok ? col : 0;
-    bias[j] = (d.bias && cok) ? d.bias[ccol[j]] : 0.f;
-    sc[j] = 1.f; of[j] = 0.f;
-    if (epi_mode == 2) { sc[j] = d.stages[1].scale[ccol[j]]; of[j] = d.stages[1].offset[ccol[j]]; }
-  }
-#pragma unroll
-  for (int sl = 0; sl < RT; sl++) {                // 32-row slab sl of the tile belongs to wave row sl / MR
-    constexpr int kDummy = 0; (void)kDummy;
-    const int i = sl % MR;
-    if (MIXED && sl >= mr_eff) break;              // workgroup-uniform
-    if (wm == sl / MR) {
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int cl = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float v = __fadd_rn(bias[j], acc[i][j][r]);
-          if (epi_mode == 1) {
-            v = v > 0.f ? v : 0.f;
-          } else if (epi_mode == 2) {               // ReLU then BatchNorm (test mode): MulColsVec, AddVecToRows
-            v = v > 0.f ? v : 0.f;
-            v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);
-          } else if (epi_mode == 3) {
-            for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);
-          }
-          Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;
-        }
-      }
-    }
-    dd::LdsBarrier();
-    if (vec_out) {
-#pragma unroll
-      for (int q = 0; q < 2048 / NT; q++) {
-        const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4;
-        const int row = row0 + sl * 32 + rl, col = n0 + c4;
-        if (row < rows && col < d.n)
-          *reinterpret_cast<f32x4 *>(d.out + (size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col) =
-              *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
-      }
-    } else {
-      for (int idx = tid; idx < 32 * BN; idx += NT) {
-        const int rl = idx / BN, cl = idx % BN;
-        const int row = row0 + sl * 32 + rl, col = n0 + cl;
-        if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl];
-      }
-    }
-    dd::LdsBarrier();
-  }
+  b3::Epilogue<MR, MIXED, WM>(acc, d, rows, row0, n0, mr_eff, epi_mode, smem);
 }
 
 template <int MR, bool MIXED, int WM>

@@ -1,0 +1,265 @@
+// The TDNN layer GEMM of nnet_gemm_b3.hip for sources that already exist as operand images (kernels.h: ActImage): the
+// producing layer's epilogue stored its result split into the three bf16 parts, in A-fragment order, so the consumer's
+// K-loop has no FP32 loads, no splitting and no LDS writes of its own left -- what nnet_gemm_b3.hip spends about half of
+// its loop on (profiles/r01: matrix cores 42 % busy; VALU split + ds_write + a barrier per 16-wide k-step).
+//
+// Same arithmetic (six v_mfma_f32_32x32x16_bf16 per product, smallest terms first, FP32 accumulation) and the same tile:
+// (32 MR) x 256 per workgroup, four waves side by side, each (32 MR) x 64.  Per 16-wide k-step:
+//   activations: 3 MR fragments of 1 KiB, copied verbatim from the image into LDS by global_load_lds_dwordx4 (the image
+//                block IS the fragment: lane l supplies the address of row l & 31, k-group l >> 5, so row-shifted TDNN
+//                segments and row maps cost nothing but address arithmetic); wave w stages row tile w;
+//   weights:     as before, six fragments per wave straight into registers, three register sets rotating;
+//   reads:       conflict-free ds_read_b128 at 16 x lane per fragment.
+// Two k-steps form one LDS stage (BK = 32): one barrier per 32 of K instead of per 16; two stages, the DMA of stage t + 1
+// runs during the MFMAs of stage t.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+#include "nnet_b3_common.h"
+
+namespace rs {
+namespace {
+using namespace b3;
+
+constexpr int kKPS = 2;                               // k-steps per LDS stage
+
+template <int MR, bool MIXED>
+__global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int nbig, int epi_mode) {
+  constexpr int BM = 32 * MR, BN = kB3BN;
+  constexpr int KSTEP_BYTES = MR * 3 * kB3FragBytes, STAGE = kKPS * KSTEP_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave;                               // 64-column slice; also the row tile this wave stages
+  const int ncol = (d.n + BN - 1) / BN;
+  const int big_blocks = (nbig + 7) / 8 * 8 * ncol;
+  const bool small = MIXED && (int)blockIdx.x >= big_blocks;
+  const int mr_eff = small ? MR / 2 : MR;
+  const int bid = small ? blockIdx.x - big_blocks : blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
+  const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
+  if (small ? row0 >= rows : rt >= nbig) return;
+  f32x16 acc[MR][2];
+#pragma unroll
+  for (int i = 0; i < MR; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- activation staging: this wave copies row tile `wave` (all three parts) of every k-step
+  const bool stager = wave < mr_eff;
+  int grow = row0 + wave * 32 + (lane & 31);
+  if (grow >= rows) grow = 0;                          // clamped rows are dropped in the epilogue
+  if (d.row_map) grow = d.row_map[grow];
+  const int kg_off = (lane >> 5) * 512;
+  // per-segment scalars in the lanes of VGPRs (lane s = segment s), fetched with v_readlane (see nnet_gemm_b3.hip)
+  const int sl_ = lane < d.nsegs ? (lane < kMaxSegs ? lane : 0) : 0;
+  const int seg_rowoff_v = lane < d.nsegs ? d.segs[sl_].row_off : 0;
+  const int seg_ks0_v = lane < d.nsegs ? d.segs[sl_].col0 / kB3KS : 0;
+  const int seg_nks_v = lane < d.nsegs ? (d.segs[sl_].ncols + kB3KS - 1) / kB3KS : 0;
+  const int nsegs = d.nsegs;
+  const bool inter = d.interleave != 0;
+  int nt = 0;                                          // k-steps in total
+  for (int sgi = 0; sgi < d.nsegs; sgi++) nt += (d.segs[sgi].ncols + kB3KS - 1) / kB3KS;
+  // (segment, k-step inside it) of the next k-step to stage; interleaved order: step t = segment t % nsegs, k-step t / nsegs
+  int seg = 0, ks = 0;
+  const unsigned char *img_base = d.segs[0].img.base;
+  size_t part_bytes = d.segs[0].img.part_bytes;
+  int img_nks = d.segs[0].img.nks, img_guard = d.segs[0].img.guard;
+  auto stage_kstep = [&](unsigned char *dst) __attribute__((always_inline)) {     // dst: this k-step's 3 MR KiB in LDS
+    if (stager) {
+      const int phys = grow + __builtin_amdgcn_readlane(seg_rowoff_v, seg) + img_guard;
+      const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ks)) * kB3FragBytes +
+                                 kg_off + (phys & 31) * 16;
+#pragma unroll
+      for (int p = 0; p < 3; p++)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * part_bytes),
+                                         (void __attribute__((address_space(3))) *)(dst + (p * MR + wave) * kB3FragBytes), 16, 0, 0);
+    }
+    if (inter) {
+      if (++seg == nsegs) { seg = 0; ks++; }
+    } else if (++ks >= __builtin_amdgcn_readlane(seg_nks_v, seg)) {
+      ks = 0;
+      if (seg + 1 < nsegs) {
+        seg++;
+        if (d.segs[seg].img.base != img_base) {
+          img_base = d.segs[seg].img.base; part_bytes = d.segs[seg].img.part_bytes; img_nks = d.segs[seg].img.nks; img_guard = d.segs[seg].img.guard;
+        }
+      }
+    }
+  };
+  // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3I
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wn * 2) * 3 * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
+  auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
+    wsrc += wstep;
+  };
+  // one k-step of MFMAs from the fragments at `As` (this k-step's image in LDS)
+  auto step = [&](const unsigned char *As, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+    const unsigned char *Al = As + lane * 16;
+    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(Al + (2 * MR) * kB3FragBytes), nxt = cur;
+#pragma unroll
+    for (int idx = 0; idx < 3 * MR; idx++) {
+      const int pa = 2 - idx / MR, i = idx % MR;
+      if (idx + 1 < 3 * MR) {
+        const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
+        nxt = *reinterpret_cast<const bf16x8 *>(Al + (pa2 * MR + i2) * kB3FragBytes);
+      }
+      if (!MIXED || i < mr_eff) {
+#pragma unroll
+        for (int pb = 2; pb >= 0; pb--) {
+          if (pb > 2 - pa) continue;
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, bf[j][pb], acc[i][j], 0, 0, 0);
+        }
+      }
+      cur = nxt;
+    }
+  };
+  if (nt == 0) return;
+  // ---- pipeline: LDS stage s holds k-steps 2 s, 2 s + 1; weights rotate over three register sets two k-steps ahead
+  const int nstage = (nt + kKPS - 1) / kKPS;
+  bf16x8 b0[2][3], b1[2][3], b2[2][3];
+  load_b(b0);
+  load_b(b1);
+  stage_kstep(smem);
+  if (nt > 1) stage_kstep(smem + KSTEP_BYTES);
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // The loop body handles one k-step; the stage protocol (DMA of the next stage issued at the first k-step of a stage, waited
+  // for and fenced by the barrier after its second) is written out per position in the 6-step rotation (2 stages x 3 weight sets).
+  int t = 0;
+#define RS_B3I_KSTEP(BCUR, BNEXT2)                                                                   \
+  {                                                                                                  \
+    const int st = t >> 1, kk = t & 1;                                                               \
+    load_b(BNEXT2);                              /* weights of k-step t + 2 (padding steps past the end) */ \
+    if (kk == 0 && st + 1 < nstage) {            /* DMA of the next stage */                        \
+      unsigned char *nx = smem + ((st + 1) & 1) * STAGE;                                             \
+      stage_kstep(nx);                                                                               \
+      if (2 * (st + 1) + 1 < nt) stage_kstep(nx + KSTEP_BYTES);                                      \
+    }                                                                                                \
+    step(smem + (st & 1) * STAGE + kk * KSTEP_BYTES, BCUR);                                          \
+    if (kk == 1 || t + 1 == nt) {                /* stage done: next stage's DMA landed, everyone done reading this one */ \
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+      __builtin_amdgcn_s_barrier();                                                                  \
+    }                                                                                                \
+    t++;                                                                                             \
+  }
+#pragma nounroll
+  while (t + 6 <= nt) {
+    RS_B3I_KSTEP(b0, b2)
+    RS_B3I_KSTEP(b1, b0)
+    RS_B3I_KSTEP(b2, b1)
+    RS_B3I_KSTEP(b0, b2)
+    RS_B3I_KSTEP(b1, b0)
+    RS_B3I_KSTEP(b2, b1)
+  }
+  // remainder (< 6 k-steps), same rotation
+  if (t < nt) RS_B3I_KSTEP(b0, b2)
+  if (t < nt) RS_B3I_KSTEP(b1, b0)
+  if (t < nt) RS_B3I_KSTEP(b2, b1)
+  if (t < nt) RS_B3I_KSTEP(b0, b2)
+  if (t < nt) RS_B3I_KSTEP(b1, b0)
+#undef RS_B3I_KSTEP
+  b3::Epilogue<MR, MIXED, 1>(acc, d, rows, row0, n0, mr_eff, epi_mode, smem);
+}
+
+template <int MR, bool MIXED>
+void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
+  constexpr int BM = 32 * MR;
+  constexpr size_t stage = 2 * (size_t)kKPS * MR * 3 * kB3FragBytes, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t smem = stage > ctile ? stage : ctile;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3I<MR, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
+  const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
+  hipLaunchKernelGGL((GemmKernelB3I<MR, MIXED>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
+}
+
+// f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, all three parts
+__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int nblocks) {
+  const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;
+  const int rb = blk / img.nks, ks = blk % img.nks;
+  const int row = rb * 32 + (lane & 31) - img.guard, col = ks * 16 + (lane >> 5) * 8;
+  if (row < 0 || row >= rows) return;
+  f32x4 lo, hi;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    lo[e] = col + e < dim ? src[(size_t)row * ld + col + e] : 0.f;
+    hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
+  }
+  bf16x8 p1, p2, p3;
+  Split3(lo, hi, &p1, &p2, &p3);
+  unsigned char *dst = img.base + (size_t)blk * kB3FragBytes + lane * 16;
+  *reinterpret_cast<bf16x8 *>(dst) = p1;
+  *reinterpret_cast<bf16x8 *>(dst + img.part_bytes) = p2;
+  *reinterpret_cast<bf16x8 *>(dst + 2 * img.part_bytes) = p3;
+}
+
+}  // namespace
+
+size_t ActImagePartBytes(int rows, int guard, int dim) {
+  const size_t row_blocks = ((size_t)rows + 2 * (size_t)guard + 31) / 32 + 1;
+  return row_blocks * (size_t)((dim + 15) / 16) * b3::kB3FragBytes;
+}
+
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, hipStream_t s) {
+  const int row_blocks = (rows + img.guard + 31) / 32 + 1;
+  const int nblocks = row_blocks * img.nks;
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(ToImageKernel, dim3((nblocks + 3) / 4), dim3(256), 0, s, src, ld, dim, rows, img, nblocks);
+}
+
+bool GemmImagesEnabled() {
+  const char *e = std::getenv("RS_GEMM_B3I"), *e3 = std::getenv("RS_GEMM_B3");          // read per call (tests flip them)
+  return !(e && std::atoi(e) == 0) && !(e3 && std::atoi(e3) == 0);
+}
+
+bool GemmB3IUsable(const GemmDev &d) {
+  if (!GemmImagesEnabled() || !d.W3I || d.n3 < kB3BN) return false;
+  if ((d.n3 - d.n) * 4 > d.n3) return false;
+  for (int i = 0; i < d.nsegs; i++)
+    if (!d.segs[i].img.base || d.segs[i].per_utt || (d.segs[i].col0 % kB3KS) != 0) return false;
+  if (d.interleave)
+    for (int i = 1; i < d.nsegs; i++) if (d.segs[i].img.base != d.segs[0].img.base) return false;
+  return true;
+}
+
+void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
+  static int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const long slots = std::max(2L * num_cu / std::max(d.share, 1), 8L);      // two workgroups per CU; the device may be shared
+  auto rounds = [&](long row_tiles) { return (double)((row_tiles * ncol + slots - 1) / slots); };
+  // whole rounds of 128-row tiles, the remaining rows as 64-row tiles of the same launch
+  const long full = (long)(rows / 128) * ncol / slots * slots / ncol;
+  const long rest = rows - full * 128;
+  const double c_mixed = rounds(full) * 128 + rounds((rest + 63) / 64) * 64;
+  const double c_128 = rounds((rows + 127) / 128) * 128, c_64 = rounds((rows + 63) / 64) * 64;
+  int mr = 4, nbig = (rows + 127) / 128;
+  bool mixed = false;
+  if (c_64 < c_128 && c_64 <= c_mixed) { mr = 2; nbig = (rows + 63) / 64; }
+  else if (full > 0 && c_mixed < c_128) { mixed = true; nbig = (int)full; }
+  if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
+  if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
+  if (mr == 2) LaunchB3I<2, false>(d, rows, nbig, s);
+  else if (mixed) LaunchB3I<4, true>(d, rows, nbig, s);
+  else LaunchB3I<4, false>(d, rows, nbig, s);
+}
+
+}  // namespace rs

@@ -370,6 +370,7 @@ static void LaunchGemmT(const GemmDev &d, int rows, const int *row_ivec, hipStre
 
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   if (rows <= 0) return;
+  if (GemmB3IUsable(d)) { LaunchGemmB3I(d, rows, s); return; }
   if (GemmB3Usable(d)) { LaunchGemmB3(d, rows, row_ivec, s); return; }
   static int num_cu = [] {
     int dev = 0, n = 256;
@@ -395,6 +396,9 @@ void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) 
   else if (c96 <= c64) LaunchGemmT<3, 2, 2>(d, rows, row_ivec, s);
   else LaunchGemmT<2, 2, 2>(d, rows, row_ivec, s);
 }
+
+// true when the kernel LaunchGemm picks for d writes d.out_img itself (the split-bf16 kernels' epilogue does)
+bool GemmWritesImage(const GemmDev &d) { return GemmB3IUsable(d) || GemmB3Usable(d); }
 
 // ------------------------------------------------------------------------------------------ elementwise
 __global__ void EltwiseKernel(EltwiseDev d, int rows) {

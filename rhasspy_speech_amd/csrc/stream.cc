@@ -364,6 +364,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   std::vector<int> buf_ld(nn.bufs.size());
   size_t need = is.h.size() * 4 + pcm_total * 2 + 4096 + 3 * sizeof(int) * (size_t)(rowsM + rowsI + rowsN + 64) + sizeof(int) * (size_t)(framesN + 64);
   for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(rowsN, buf_ld[b]); }
+  need += ImageBytes(rowsN);
   if (has_iv) {
     need += 2 * fbytes(rowsI, ld_c) + 2 * fbytes(rowsI, ld_l) + (size_t)rowsI * nsel * 8 + 4096;
     need += (size_t)std::max(nI, 1) * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 16 + (size_t)usz * 8 + 64) + 8192;
@@ -458,10 +459,11 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   if (nN > 0) {
     std::vector<float *> bufp(nn.bufs.size(), nullptr);
     for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(rowsN, buf_ld[b]);
+    const std::vector<ActImage> imgs = AllocImages(arena, rowsN);
     LaunchCopyRows(fc_.use_cmvn ? p->nn_in : p->raw, ld_c, D(o_nsrc), bufp[nn.input_buf], buf_ld[nn.input_buf], nullptr, rowsN, C, q);
     int *frame_rows = arena.AllocT<int>(framesN + 8);
     LaunchFrameRows(nN, nN, framesN, L_, std::max(maxTn, 1), D(o_nfb), D(o_nrb), frame_rows, q);
-    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, frame_rows, framesN, 1, 0, nn.ops.size(), q);
+    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, frame_rows, framesN, 1, 0, nn.ops.size(), q, &imgs);
     LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
   }
   tm.Mark();

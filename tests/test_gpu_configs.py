@@ -266,6 +266,22 @@ def test_split_bf16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
     assert 0.0 < worst < 5e-5, worst          # > 0: the two kernels really are different code paths
 
 
+def test_image_sourced_gemm_is_bitwise_the_split_gemm(zam_grammar, monkeypatch):
+    """GemmKernelB3I (nnet_gemm_b3i.hip: the producing layer stored its result as bf16 operand images, the consumer copies
+    fragments) against GemmKernelB3 (FP32 sources split inside the K-loop): the same MFMAs on the same operands in the same
+    order, so log-likelihoods must be equal bit for bit -- on a ragged batch (partial tiles, both tile heights)."""
+    from rhasspy_speech_amd import _lib, synth
+    model = _lib.Model(*zam_grammar, _lib.default_opts(keep_intermediates=1))
+    pcms = [synth.synth_utterance(31000 + u, 48000 - 640 * (u % 7)) for u in range(70)] + [synth.synth_utterance(31999, 1700)]
+    monkeypatch.setenv("RS_GEMM_B3I", "1")
+    img = model.decode_batch(pcms)
+    monkeypatch.setenv("RS_GEMM_B3I", "0")
+    plain = model.decode_batch(pcms)
+    for u in range(len(pcms)):
+        np.testing.assert_array_equal(img.matrix(u, 2), plain.matrix(u, 2))
+        assert img.words(u) == plain.words(u) and img.costs(u) == plain.costs(u)
+
+
 def test_pruned_output_layer_on_a_batch(zam_grammar):
     """prune_output_pdfs on the headline model / graph (362 of the 2000 pdfs are on HCLG arcs): a ragged batch decodes to
     the same words and costs as with the full output layer."""
