@@ -58,8 +58,13 @@ for t in online2bin/online2-wav-nnet3-latgen-faster online2bin/online2-cli-nnet3
          latbin/lattice-to-nbest latbin/nbest-to-linear latbin/lattice-copy \
          gmmbin/gmm-init-mono nnet3bin/nnet3-init nnet3bin/nnet3-am-init nnet3bin/nnet3-am-info \
          nnet3bin/nnet3-am-copy bin/show-transitions bin/copy-matrix featbin/compute-mfcc-feats \
-         gmmbin/gmm-global-copy ivectorbin/ivector-extractor-copy; do
+         gmmbin/gmm-global-copy ivectorbin/ivector-extractor-copy \
+         latbin/lattice-scale latbin/lattice-to-phone-lattice latbin/lattice-compose latbin/lattice-determinize \
+         latbin/lattice-add-trans-probs latbin/lattice-best-path fstbin/fstdeterminizestar fstbin/fstrmsymbols \
+         fstbin/fsttablecompose fstbin/fstminimizeencoded fstbin/fstpushspecial fstbin/fstcomposecontext fstbin/fstrmepslocal \
+         fstbin/fstaddselfloops fstbin/fstisstochastic bin/make-h-transducer bin/add-self-loops; do
   [ -f "$K/$t.cc" ] || { echo "missing $t"; continue; }
+  [ -x "$OUT/bin/$(basename "$t")" ] && [ "$OUT/bin/$(basename "$t")" -nt "$OUT/libkaldi_ref.so" ] && continue      # already linked
   link_tool "$K/$t.cc" "$(basename "$t")" &
   while [ "$(jobs -r | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done
 done

@@ -282,7 +282,9 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     }
     // (2) GemmKernelB3I (sources stored as operand images): segments padded to the 16-wide k-step only; needs every source
     // to be a frame buffer whose first column sits on a k-step boundary
-    bool imageable = true;
+    // ... and the layer to be one the split-bf16 kernels take at all (GemmB3IUsable's padding rule: at most a quarter of the
+    // 256-column tiles may be padding) -- decided HERE, because the producers of its sources stop storing plain floats
+    bool imageable = (plan->n3 - op.out_dim) * 4 <= plan->n3;
     for (auto &sg : op.segs) imageable = imageable && sg.src_buf >= 0 && sg.src_col % 16 == 0;
     if (imageable) {
       std::vector<int> step_k;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
-  b3::Epilogue<MR, MIXED, WM>(acc, d, rows, row0, n0, mr_eff, epi_mode, smem);
+#include "nnet_b3_epilogue.inc"
 }
 
 template <int MR, bool MIXED, int WM>

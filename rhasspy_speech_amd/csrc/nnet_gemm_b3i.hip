@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   if (t < nt) RS_B3I_KSTEP(b0, b2)
   if (t < nt) RS_B3I_KSTEP(b1, b0)
 #undef RS_B3I_KSTEP
-  b3::Epilogue<MR, MIXED, 1>(acc, d, rows, row0, n0, mr_eff, epi_mode, smem);
+  constexpr int RT = MR, NT = 256;
+  const int wm = 0;
+#include "nnet_b3_epilogue.inc"
 }
 
 template <int MR, bool MIXED>
