@@ -177,6 +177,27 @@ int rs_fuzzy_open(const char *fuzzy_fst_path, rs_fuzzy **out);
 int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
 void rs_fuzzy_free(rs_fuzzy *f);
 
+/* ---- rescoring against a NEW language directory (host side; the lattices come from decodes with rs_decode_opts.emit_lattice = 1).
+ * Replaces the tool chain of `async_transcribe_rescore` (rhasspy_speech/transcribe_wav.py:107-232, transcribe_stream.py:131-274):
+ *   [Ldet.fst from L_disambig.fst: fstprint | awk | fstcompile | fstdeterminizestar | fstrmsymbols]   lattice-scale --lm-scale=0.0 |
+ *   lattice-to-phone-lattice | lattice-compose - Ldet.fst | lattice-determinize | lattice-compose --phi-label=#0 - G.fst |
+ *   lattice-add-trans-probs --transition-scale=1.0 --self-loop-scale=0.1 | lattice-to-nbest --n --acoustic-scale | nbest-to-linear
+ * rs_rescorer_open reads <new_lang_dir>/{L_disambig.fst, G.fst, words.txt, phones/disambig.int} once (the reference rebuilds
+ * Ldet.fst and re-reads everything per utterance); it fails like the reference when words.txt has no #0. */
+typedef struct rs_rescorer rs_rescorer;
+int rs_rescorer_open(const rs_model *model, const char *new_lang_dir, rs_rescorer **out);
+/* Rescores utterance `utt` of a result; renders the bytes `nbest-to-linear ... ark,t:-` prints at the end of the chain
+ * ("<key>-<k> id id ... \n", ids of the NEW words.txt; nothing when no path survives) into buf, returns the number of bytes
+ * needed (like snprintf) or a negative status.  graph_cost / acoustic_cost (may be null): up to `nbest` entries, the 4th / 5th
+ * outputs of nbest-to-linear; *n_out = number of hypotheses. */
+int rs_rescore_result(const rs_rescorer *r, const rs_result *res, int32_t utt, int32_t nbest, float acoustic_scale, const char *key,
+                      char *buf, size_t len, float *graph_cost, float *acoustic_cost, int32_t *n_out);
+/* Same on a lattice given as one binary CompactLattice table entry (what online2-wav-nnet3-latgen-faster writes, and what
+ * rs_result_lattice renders): no GPU involved -- for tools and for the host-only parity tests against the reference's chain. */
+int rs_rescore_lattice(const rs_rescorer *r, const char *lattice_entry, size_t n_bytes, int32_t nbest, float acoustic_scale, const char *key,
+                       char *buf, size_t len, float *graph_cost, float *acoustic_cost, int32_t *n_out);
+void rs_rescorer_free(rs_rescorer *r);
+
 /* Host-side entry for tests and tools (no GPU needed): determinises a raw lattice -- the state-level lattice the search
  * leaves behind, given as n_arcs arcs (src, dst, word label, transition-id; graph and acoustic cost), a start state and
  * per-state final costs (+inf = not final) -- with the same code rs_result_lattice uses (lattice beam `beam`) and renders

@@ -34,6 +34,7 @@ EXPORTS = [
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
+    "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
 ]
 
 
@@ -81,6 +82,12 @@ def load_library() -> C.CDLL:
     lib.rs_fuzzy_match.argtypes = [vp, C.c_char_p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     lib.rs_fuzzy_free.argtypes = [vp]
     lib.rs_fuzzy_free.restype = None
+    lib.rs_rescorer_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.rs_rescore_result.argtypes = [vp, vp, i32, i32, f32, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(f32), C.POINTER(f32), C.POINTER(i32)]
+    lib.rs_rescore_lattice.argtypes = [vp, C.c_char_p, C.c_size_t, i32, f32, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(f32), C.POINTER(f32),
+                                       C.POINTER(i32)]
+    lib.rs_rescorer_free.argtypes = [vp]
+    lib.rs_rescorer_free.restype = None
     pf, pi = C.POINTER(f32), C.POINTER(i32)
     lib.rs_lattice_entry_from_raw.argtypes = [i32, i32, pf, i32, pi, pi, pi, pi, pf, pf, f32, C.c_char_p, C.c_char_p, C.c_int64]
     lib.rs_lattice_entry_from_raw.restype = C.c_int64
@@ -341,6 +348,40 @@ class FuzzyMatcher:
     def close(self) -> None:
         if self._h:
             lib().rs_fuzzy_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class Rescorer:
+    """Owns an rs_rescorer: <new_lang_dir>/{L_disambig.fst, G.fst, words.txt, phones/disambig.int} parsed once (host side)."""
+
+    def __init__(self, model: Model, new_lang_dir):
+        self.model = model
+        self._h = C.c_void_p()
+        _check(lib().rs_rescorer_open(model._h, str(new_lang_dir).encode(), C.byref(self._h)))
+
+    def _call(self, fn, *head, nbest: int, acoustic_scale: float, key: str):
+        g, a, n = (C.c_float * nbest)(), (C.c_float * nbest)(), C.c_int32()
+        size = fn(self._h, *head, nbest, acoustic_scale, key.encode(), None, 0, g, a, C.byref(n))
+        if size < 0:
+            _check(size)
+        buf = C.create_string_buffer(size + 1)
+        fn(self._h, *head, nbest, acoustic_scale, key.encode(), buf, size + 1, g, a, C.byref(n))
+        return buf.value, list(g[:n.value]), list(a[:n.value])
+
+    def rescore(self, result: Result, utt: int = 0, nbest: int = 1, acoustic_scale: float = 1.0, key: str = "utt"):
+        """-> (nbest text bytes as nbest-to-linear prints them, graph costs, acoustic costs) for one utterance of a result decoded
+        with emit_lattice = 1."""
+        return self._call(lib().rs_rescore_result, result._h, utt, nbest=nbest, acoustic_scale=acoustic_scale, key=key)
+
+    def rescore_lattice(self, entry: bytes, nbest: int = 1, acoustic_scale: float = 1.0, key: str = "utt"):
+        """The same on one binary CompactLattice table entry (no GPU)."""
+        return self._call(lib().rs_rescore_lattice, entry, len(entry), nbest=nbest, acoustic_scale=acoustic_scale, key=key)
+
+    def close(self) -> None:
+        if self._h:
+            lib().rs_rescorer_free(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

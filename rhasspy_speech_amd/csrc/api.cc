@@ -11,6 +11,7 @@
 
 #include "engine.h"
 #include "fuzzy.h"
+#include "rescore.h"
 
 namespace rs {
 int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
@@ -374,6 +375,57 @@ int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, 
 }
 
 void rs_fuzzy_free(rs_fuzzy *f) { delete f; }
+
+struct rs_rescorer {
+  rs::Rescorer r;
+  const rs_model *model;
+  rs_rescorer(const std::string &dir, const rs_model *m) : r(dir), model(m) {}
+};
+
+int rs_rescorer_open(const rs_model *model, const char *new_lang_dir, rs_rescorer **out) {
+  if (!model || !new_lang_dir || !out) return ArgError("rs_rescorer_open: null argument");
+  return Guard([&]() { *out = new rs_rescorer(new_lang_dir, model); return RS_OK; });
+}
+
+static int RenderRescored(const std::vector<rs::NbestPath> &paths, const char *key, char *buf, size_t len, float *graph_cost,
+                          float *acoustic_cost, int32_t *n_out) {
+  std::string s;
+  const std::string ky = key ? key : "utt";
+  for (size_t k = 0; k < paths.size(); k++) {
+    s += ky + "-" + std::to_string(k + 1) + " ";
+    for (int32_t w : paths[k].words) s += std::to_string(w) + " ";
+    s += "\n";
+    if (graph_cost) graph_cost[k] = (float)paths[k].graph_cost;
+    if (acoustic_cost) acoustic_cost[k] = (float)paths[k].acoustic_cost;
+  }
+  if (n_out) *n_out = (int32_t)paths.size();
+  if (buf && len) {
+    const size_t n = s.size() < len - 1 ? s.size() : len - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return (int)s.size();
+}
+
+int rs_rescore_result(const rs_rescorer *r, const rs_result *res, int32_t utt, int32_t nbest, float acoustic_scale, const char *key,
+                      char *buf, size_t len, float *graph_cost, float *acoustic_cost, int32_t *n_out) {
+  const rs::UttResult *u = Utt(res, utt);
+  if (!r || !u || nbest < 1) return ArgError("rs_rescore_result: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  if (!u->clat) return ArgError("rs_rescore_result: the model was not opened with rs_decode_opts.emit_lattice = 1");
+  return Guard([&]() { return RenderRescored(r->r.Rescore(*u->clat, r->model->m->am().trans, nbest, acoustic_scale), key, buf, len, graph_cost, acoustic_cost, n_out); });
+}
+
+int rs_rescore_lattice(const rs_rescorer *r, const char *lattice_entry, size_t n_bytes, int32_t nbest, float acoustic_scale, const char *key,
+                       char *buf, size_t len, float *graph_cost, float *acoustic_cost, int32_t *n_out) {
+  if (!r || !lattice_entry || nbest < 1) return ArgError("rs_rescore_lattice: bad argument");
+  return Guard([&]() {
+    const rs::CompactLat clat = rs::ParseCompactLatticeEntry(lattice_entry, n_bytes, nullptr);
+    return RenderRescored(r->r.Rescore(clat, r->model->m->am().trans, nbest, acoustic_scale), key, buf, len, graph_cost, acoustic_cost, n_out);
+  });
+}
+
+void rs_rescorer_free(rs_rescorer *r) { delete r; }
 
 int64_t rs_lattice_entry_from_raw(int32_t num_states, int32_t start, const float *final_cost, int32_t n_arcs, const int32_t *arc_src,
                                   const int32_t *arc_dst, const int32_t *arc_word, const int32_t *arc_tid, const float *arc_graph,

@@ -445,6 +445,9 @@ void TransitionModel::Read(KaldiReader &r) {
   // ComputeDerived (transition-model.cc:144-177)
   id2pdf.assign(1, 0);
   id2phone.assign(1, 0);
+  id2hmm_state.assign(1, 0);
+  id2self_loop.assign(1, 0);
+  std::vector<int> self_loop_of(1, 0);      // per transition-id: the self-loop transition-id of its transition-state (0 = none)
   num_pdfs = 0;
   for (int ts = 0; ts < n; ts++) {
     const Tuple &t = tp[ts];
@@ -453,16 +456,31 @@ void TransitionModel::Read(KaldiReader &r) {
     if (t.hmm_state < 0 || t.hmm_state >= (int)entry.size()) Fail("TransitionModel: bad hmm-state");
     const HmmState &hs = entry[t.hmm_state];
     num_pdfs = std::max(num_pdfs, 1 + std::max(t.fwd, t.self));
+    const int first_tid = (int)id2pdf.size();
+    int sl_tid = 0;
     for (size_t k = 0; k < hs.trans.size(); k++) {
       bool self_loop = (hs.trans[k].first == t.hmm_state);
+      if (self_loop && sl_tid == 0) sl_tid = first_tid + (int)k;       // SelfLoopOf (transition-model.cc:360-373)
       id2pdf.push_back(self_loop ? t.self : t.fwd);
       id2phone.push_back(t.phone);
+      id2hmm_state.push_back(t.hmm_state);
+      id2self_loop.push_back(self_loop ? 1 : 0);
     }
+    for (size_t k = 0; k < hs.trans.size(); k++) self_loop_of.push_back(sl_tid);
   }
   r.ExpectToken("<LogProbs>");
   std::vector<float> lp;
   r.ReadVector(&lp);
   if (lp.size() != id2pdf.size()) Fail("TransitionModel: <LogProbs> size does not match the number of transition-ids");
+  log_prob = lp;
+  // ComputeDerivedOfProbs (transition-model.cc:375-392)
+  non_self_loop_log_prob.assign(lp.size(), 0.0f);
+  for (size_t tid = 1; tid < lp.size(); tid++) {
+    if (self_loop_of[tid] == 0) continue;
+    float p = 1.0f - expf(lp[self_loop_of[tid]]);
+    if (p <= 0.0f) p = 1.0e-10f;
+    non_self_loop_log_prob[tid] = logf(p);
+  }
   r.ExpectToken("</LogProbs>");
   r.ExpectToken("</TransitionModel>");
 }

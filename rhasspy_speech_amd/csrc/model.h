@@ -95,6 +95,11 @@ struct TransitionModel {
   int num_pdfs = 0;
   std::vector<int32_t> id2pdf;     // index = transition-id (0 unused)
   std::vector<int32_t> id2phone;
+  // for the lattice tools of the rescoring path (lat/lattice-functions.cc:423-441, hmm/hmm-utils.cc:1065-1084):
+  std::vector<int32_t> id2hmm_state;   // TransitionIdToHmmState
+  std::vector<char> id2self_loop;      // IsSelfLoop
+  std::vector<float> log_prob;         // GetTransitionLogProb
+  std::vector<float> non_self_loop_log_prob;   // GetNonSelfLoopLogProb of the transition-id's transition-state
   void Read(KaldiReader &r);
 };
 

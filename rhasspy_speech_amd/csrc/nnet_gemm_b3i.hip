@@ -247,12 +247,15 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const long slots = std::max(2L * num_cu / std::max(d.share, 1), 8L);      // two workgroups per CU; the device may be shared
+  // Tile height: rounds of `slots` tiles, each as long as the tile is tall, weighted by the per-row cost of the height
+  // (a 64-row tile streams the weights for half as many rows as a 128-row one)
   auto rounds = [&](long row_tiles) { return (double)((row_tiles * ncol + slots - 1) / slots); };
+  static const double eff64 = [] { const char *e = std::getenv("RS_GEMM_B3I_EFF64"); return e ? std::atof(e) : 1.3; }();
   // whole rounds of 128-row tiles, the remaining rows as 64-row tiles of the same launch
   const long full = (long)(rows / 128) * ncol / slots * slots / ncol;
   const long rest = rows - full * 128;
-  const double c_mixed = rounds(full) * 128 + rounds((rest + 63) / 64) * 64;
-  const double c_128 = rounds((rows + 127) / 128) * 128, c_64 = rounds((rows + 63) / 64) * 64;
+  const double c_mixed = rounds(full) * 128 + rounds((rest + 63) / 64) * 64 * eff64;
+  const double c_128 = rounds((rows + 127) / 128) * 128, c_64 = rounds((rows + 63) / 64) * 64 * eff64;
   int mr = 4, nbig = (rows + 127) / 128;
   bool mixed = false;
   if (c_64 < c_128 && c_64 <= c_mixed) { mr = 2; nbig = (rows + 63) / 64; }

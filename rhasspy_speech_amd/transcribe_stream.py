@@ -43,6 +43,8 @@ class KaldiNnet3StreamTranscriber:
         self.device_id = device_id
         self._model: Optional[_lib.Model] = None
         self._words = None
+        self._lat_model: Optional[_lib.Model] = None      # the same files, results keep their lattices (rescoring path)
+        self._rescorers = {}
 
     def _ensure_loaded(self) -> _lib.Model:
         if self._model is None:
@@ -87,6 +89,54 @@ class KaldiNnet3StreamTranscriber:
             text, cost = fuzzy_result
             _LOGGER.debug("Fuzzy cost: %s", cost)
             if cost <= max_fuzzy_cost:       # (like the reference, a TypeError when max_fuzzy_cost is None)
+                return [decode_meta(text)]
+        if require_fuzzy:
+            return []
+        return texts_from_int2sym(int2sym_stdout)
+
+    # ---- rescoring path (transcribe_stream.py:131-274): stream through the old graph, re-rank the lattice with a NEW lexicon + LM
+    async def async_transcribe_rescore(
+        self,
+        audio_stream: AsyncIterable[Optional[bytes]],
+        old_lang_dir: Union[str, Path],
+        new_lang_dir: Union[str, Path],
+        nbest: int = 1,
+        max_fuzzy_cost: Optional[float] = None,
+        require_fuzzy: bool = False,
+    ) -> List[str]:
+        old_lang_dir, new_lang_dir = Path(old_lang_dir), Path(new_lang_dir)
+        if self._lat_model is None:
+            opts = _lib.default_opts(max_active=self.max_active, lattice_beam=self.lattice_beam, beam=self.beam, acoustic_scale=1.0,
+                                     device_id=self.device_id, emit_lattice=1)
+            self._lat_model = _lib.Model(self.model_dir, self.graph_dir, opts)
+        key = str(new_lang_dir)
+        if key not in self._rescorers:
+            try:
+                self._rescorers[key] = _lib.Rescorer(self._lat_model, new_lang_dir)
+            except _lib.RsError as e:
+                if "No value for disambiguation state" in str(e):
+                    raise ValueError("No value for disambiguation state (#0)") from e       # transcribe_stream.py:150-151
+                raise
+        stream = _lib.Stream(self._lat_model)
+        try:
+            async for chunk in audio_stream:
+                if chunk:
+                    stream.accept(chunk)
+                    stream.advance()
+            loop = asyncio.get_running_loop()
+            try:
+                res = await loop.run_in_executor(None, stream.finish, 1, 1.0)
+                nbest_stdout = self._rescorers[key].rescore(res, 0, nbest=nbest, acoustic_scale=self.acoustic_scale, key="utt")[0]
+            except _lib.RsError as e:
+                raise RuntimeError(f"Unexpected error running command online2-cli-nnet3-decode-faster (HIP): {e}") from e
+        finally:
+            stream.close()
+        int2sym_stdout = int2sym(nbest_stdout, read_words_txt(new_lang_dir / "words.txt"))
+        _LOGGER.debug("nbest: %s", int2sym_stdout)
+        fuzzy_result = get_fuzzy_text(nbest_stdout, old_lang_dir)      # transcribe_stream.py:255-260
+        if fuzzy_result is not None:
+            text, cost = fuzzy_result
+            if cost <= max_fuzzy_cost:
                 return [decode_meta(text)]
         if require_fuzzy:
             return []

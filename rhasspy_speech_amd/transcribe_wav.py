@@ -56,6 +56,8 @@ class KaldiNnet3WavTranscriber:
         self.device_id = device_id
         self._model: Optional[_lib.Model] = None
         self._words = None
+        self._lat_model: Optional[_lib.Model] = None      # the same files, results keep their lattices (rescoring path)
+        self._rescorers = {}
 
     # the reference reloads everything per call; here it is loaded once, lazily
     def _ensure_loaded(self) -> _lib.Model:
@@ -97,8 +99,43 @@ class KaldiNnet3WavTranscriber:
         outs = self._nbest_stdout([read_wav_pcm16(p) for p in wav_paths], nbest)
         return [self._finish(o, Path(lang_dir), max_fuzzy_cost, require_fuzzy) for o in outs]
 
-    def _finish(self, nbest_stdout: bytes, lang_dir: Path, max_fuzzy_cost, require_fuzzy: bool) -> List[str]:
-        int2sym_stdout = int2sym(nbest_stdout, self._words)
+    # ---- rescoring path (transcribe_wav.py:107-232): decode with the old graph, re-rank the lattice with a NEW lexicon + LM
+    def _rescored_stdout(self, pcm: np.ndarray, new_lang_dir: Path, nbest: int) -> bytes:
+        if self._lat_model is None:
+            opts = _lib.default_opts(max_active=self.max_active, lattice_beam=self.lattice_beam, beam=self.beam, acoustic_scale=1.0,
+                                     device_id=self.device_id, emit_lattice=1)
+            self._lat_model = _lib.Model(self.model_dir, self.graph_dir, opts)
+        key = str(new_lang_dir)
+        if key not in self._rescorers:
+            try:
+                self._rescorers[key] = _lib.Rescorer(self._lat_model, new_lang_dir)
+            except _lib.RsError as e:
+                if "No value for disambiguation state" in str(e):
+                    raise ValueError("No value for disambiguation state (#0)") from e       # transcribe_wav.py:128-129
+                raise
+        try:
+            res = self._lat_model.decode_batch([pcm], nbest=1)
+            return self._rescorers[key].rescore(res, 0, nbest=nbest, acoustic_scale=self.acoustic_scale, key="utt")[0]
+        except _lib.RsError as e:
+            raise RuntimeError(f"Unexpected error running command online2-wav-nnet3-latgen-faster (HIP): {e}") from e
+
+    async def async_transcribe_rescore(
+        self,
+        wav_path: Union[str, Path],
+        old_lang_dir: Union[str, Path],
+        new_lang_dir: Union[str, Path],
+        nbest: int = 1,
+        max_fuzzy_cost: Optional[float] = None,
+        require_fuzzy: bool = False,
+    ) -> List[str]:
+        pcm = read_wav_pcm16(wav_path)
+        loop = asyncio.get_running_loop()
+        nbest_stdout = await loop.run_in_executor(None, self._rescored_stdout, pcm, Path(new_lang_dir), nbest)
+        # ids -> words with the NEW table, fuzzy matching against the OLD language directory (transcribe_wav.py:204-218)
+        return self._finish(nbest_stdout, Path(old_lang_dir), max_fuzzy_cost, require_fuzzy, read_words_txt(Path(new_lang_dir) / "words.txt"))
+
+    def _finish(self, nbest_stdout: bytes, lang_dir: Path, max_fuzzy_cost, require_fuzzy: bool, words=None) -> List[str]:
+        int2sym_stdout = int2sym(nbest_stdout, self._words if words is None else words)
         _LOGGER.debug("nbest: %s", int2sym_stdout)
         fuzzy_result = get_fuzzy_text(nbest_stdout, lang_dir)      # transcribe_wav.py:87-92
         if fuzzy_result is not None:
