@@ -385,6 +385,25 @@ void Model::ToDevice() {
     ivec_dev_.gconsts = Upload(ie.gconsts);
     ivec_dev_.means_invvars_t = Upload(mt);
     ivec_dev_.inv_vars_t = Upload(vt);
+    ivec_dev_.ubm_bm = ivec_dev_.ubm_bv = nullptr;
+    ivec_dev_.ubm_kg = 0;
+    if (G <= 512 && D <= 48) {      // UbmPostMfmaKernel's operand tables
+      const int kg = D <= 16 ? 1 : 3, nt_real = (G + 15) / 16, nt = nt_real <= 2 ? 2 : (nt_real <= 8 ? 8 : 32);
+      std::vector<float> bm((size_t)nt * kg * 256, 0.f), bv(bm.size(), 0.f);
+      for (int j = 0; j < nt; j++)
+        for (int k = 0; k < kg; k++)
+          for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 4; i++) {
+              const int d = 16 * k + 4 * i + (l >> 4), gi = 16 * j + (l & 15);
+              if (d < D && gi < G) {
+                bm[((size_t)(j * kg + k) * 64 + l) * 4 + i] = ie.means_invvars(gi, d);
+                bv[((size_t)(j * kg + k) * 64 + l) * 4 + i] = ie.inv_vars(gi, d);
+              }
+            }
+      ivec_dev_.ubm_bm = Upload(bm);
+      ivec_dev_.ubm_bv = Upload(bv);
+      ivec_dev_.ubm_kg = kg;
+    }
     ivec_dev_.sigma_inv_M = Upload(ie.sigma_inv_M);
     ivec_dev_.U = Upload(ie.U);
     BuildGemmPlan(lda_op_, &lda_plan_);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "wave_ops.h"
@@ -58,31 +59,29 @@ __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, co
   }
   __syncthreads();
   if (active != 0u) {
-    f32x2 a1[R][NP2], a2[R][NP2];
+    // (scalar FMAs: no packed FP32 VALU arithmetic beside another call's MFMA kernels; this kernel is the
+    // fallback for shapes the matrix-core kernel below does not cover)
+    float a1[R][2 * NP2], a2[R][2 * NP2];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-      for (int j = 0; j < NP2; j++) { a1[r][j] = f32x2{0.f, 0.f}; a2[r][j] = f32x2{0.f, 0.f}; }
+      for (int j = 0; j < 2 * NP2; j++) { a1[r][j] = 0.f; a2[r][j] = 0.f; }
     // clamped Gaussian indices: lanes past G score the last Gaussian again and are ignored at selection
     int gidx[2 * NP2];
 #pragma unroll
     for (int j = 0; j < 2 * NP2; j++) { const int gi = lane + j * 64; gidx[j] = gi < G ? gi : G - 1; }
     for (int d = 0; d < D; d++) {
       const float *mi = iv.means_invvars_t + (size_t)d * G, *vi = iv.inv_vars_t + (size_t)d * G;
-      f32x2 m[NP2], v[NP2];
+      float m[2 * NP2], v[2 * NP2];
 #pragma unroll
-      for (int j = 0; j < NP2; j++) {
-        m[j] = f32x2{mi[gidx[2 * j]], mi[gidx[2 * j + 1]]};
-        v[j] = f32x2{vi[gidx[2 * j]], vi[gidx[2 * j + 1]]};
-      }
+      for (int j = 0; j < 2 * NP2; j++) { m[j] = mi[gidx[j]]; v[j] = vi[gidx[j]]; }
 #pragma unroll
       for (int r = 0; r < R; r++) {
         const float xv = xs[wave][r][d], xq = xv * xv;
-        const f32x2 x1 = f32x2{xv, xv}, x2 = f32x2{xq, xq};
 #pragma unroll
-        for (int j = 0; j < NP2; j++) {
-          a1[r][j] = __builtin_elementwise_fma(x1, m[j], a1[r][j]);
-          a2[r][j] = __builtin_elementwise_fma(x2, v[j], a2[r][j]);
+        for (int j = 0; j < 2 * NP2; j++) {
+          a1[r][j] = fmaf(xv, m[j], a1[r][j]);
+          a2[r][j] = fmaf(xq, v[j], a2[r][j]);
         }
       }
     }
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, co
       unsigned lmax = 0u;
 #pragma unroll
       for (int j = 0; j < 2 * NP2; j++) {
-        const float s1 = (j & 1) ? a1[r][j >> 1].y : a1[r][j >> 1].x, s2 = (j & 1) ? a2[r][j >> 1].y : a2[r][j >> 1].x;
+        const float s1 = a1[r][j], s2 = a2[r][j];
         float v = gc[j] + s1;
         v = v + (-0.5f) * s2;
         key[j] = (lane + j * 64 < G && j < NPL) ? wv::FloatToOrdered(v) : 0u;   // lanes past G: below every real value
@@ -211,9 +210,200 @@ __global__ __launch_bounds__(256) void UbmPostKernel(IvecDev iv, BatchGeom g, co
     if (!((active >> r) & 1u) && row0 + r < g.total_rows && lane < nsel) post_idx[(size_t)(row0 + r) * nsel + lane] = -1;
 }
 
+// ---- the same scoring on the matrix cores.  [rows x D] x [D x G] twice (x . mean/var and x^2 . 1/var) with
+// v_mfma_f32_16x16x4_f32: FP32 in, FP32 out, and -- per MI355X_MICROARCH / the programming guide -- bit for bit a k-ordered
+// fmaf chain, i.e. EXACTLY the sums the kernel above forms with v_pk_fma_f32 (same products, same order, one rounding each),
+// at the matrix pipe's 64 FLOP/clk/SIMD from one wave per SIMD instead of 18 % of the vector peak.  No packed FP32 VALU
+// arithmetic is left in the iVector path (the instructions that a co-resident MFMA kernel of another call corrupted in the
+// feature kernel).
+// A wave scores 16 rows against all G Gaussians: the 16 x 4 A operand of every k-step (x and x^2) stays in registers for the
+// whole wave; the B operands (parameters in MFMA fragment order, prepared on the host: 16 bytes per lane = four k-steps) stream
+// from L1/L2.  C layout of the 16x16 tile: lane l holds Gaussian 16 j + (l & 15) of rows 4 (l >> 4) + q, q = 0..3 -- so the
+// 16 lanes of a DPP row hold ALL Gaussians of four rows, and the top-k selection of a row is a matter of row-wide DPP
+// reductions, four rows at a time.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned RowMaxU(unsigned v) {
+  v = max(v, wv::Dpp<0x121>(v)); v = max(v, wv::Dpp<0x122>(v)); v = max(v, wv::Dpp<0x124>(v)); v = max(v, wv::Dpp<0x128>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned RowMinU(unsigned v) {
+  v = min(v, wv::Dpp<0x121>(v)); v = min(v, wv::Dpp<0x122>(v)); v = min(v, wv::Dpp<0x124>(v)); v = min(v, wv::Dpp<0x128>(v));
+  return v;
+}
+constexpr int kUbmRows = 16;          // rows per wave
+template <int NT, int KG>             // Gaussian tiles of 16; groups of four k-steps (16 feature dims)
+__global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
+                                                         const float *__restrict__ bm, const float *__restrict__ bv,
+                                                         int *__restrict__ post_idx, float *__restrict__ post_w) {
+  constexpr int KS = 4 * KG, KP = 16 * KG + 1;      // k-steps; LDS pitch (odd: the 16 rows of a read hit 16 banks)
+  constexpr int CAP = 16 * NT;                        // candidates per row, worst case
+  __shared__ float xs[4][kUbmRows][KP];
+  __shared__ unsigned ckey[4][4][CAP];
+  __shared__ unsigned short cgi[4][4][CAP];
+  __shared__ float sel_ll[4][kUbmRows][8], sel_max[4][kUbmRows];
+  __shared__ int sel_gi[4][kUbmRows][8], sel_n[4][kUbmRows];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, lg = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * kUbmRows;
+  const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
+  unsigned active = 0;          // bit r: row r is a real frame (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < kUbmRows; r++) {
+    const int row = row0 + r;
+    bool ok = row < g.total_rows;
+    if (ok) {
+      const int u = g.d_row_utt[row], t = g.d_row_t[row];
+      ok = t >= 0 && t < g.d_num_frames[u];
+    }
+    active |= ok ? (1u << r) : 0u;
+    if (lane < 16 * KG) xs[wave][r][lane] = (ok && lane < D) ? feats[(size_t)row * ld + lane] : 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (active != 0u) {
+    float a1[KS], a2[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) { a1[ks] = xs[wave][lg][4 * ks + grp]; a2[ks] = a1[ks] * a1[ks]; }
+    unsigned key[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      f32x4v c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < KG; kg++) {
+        const f32x4v m = *reinterpret_cast<const f32x4v *>(bm + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+        const f32x4v v = *reinterpret_cast<const f32x4v *>(bv + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * kg + i], m[i], c1, 0, 0, 0);
+          c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * kg + i], v[i], c2, 0, 0, 0);
+        }
+      }
+      const int gi = j * 16 + lg;
+      const float gc = iv.gconsts[gi < G ? gi : G - 1];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v = gc + c1[q];
+        v = v + (-0.5f) * c2[q];
+        key[j][q] = gi < G ? wv::FloatToOrdered(v) : 0u;            // columns past G: below every real value
+      }
+    }
+    const float log_min_post = logf(iv.min_post);
+    // ---- phase A: row 4 grp + q of every lane group at once.  Candidates (like > max + log min_post) are compacted into the
+    // group's LDS list, the num_gselect best are taken from it (ties -> lowest Gaussian index)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (!((active >> q) & 0x1111u)) continue;                      // none of the four rows is a frame (wave-uniform)
+      const int r = 4 * grp + q;
+      unsigned lmax = 0u;
+#pragma unroll
+      for (int j = 0; j < NT; j++) lmax = max(lmax, key[j][q]);
+      const unsigned kmax = RowMaxU(lmax);
+      const float max_like = wv::OrderedToFloat(kmax);
+      const unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);
+      int C = 0;                                                     // group-uniform
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const bool cand = key[j][q] > kcut;
+        const unsigned long long mask = __ballot(cand);
+        if (mask != 0ull) {                                          // wave-uniform, rare per j
+          const unsigned gm = (unsigned)(mask >> (16 * grp)) & 0xFFFFu;
+          if (cand) {
+            const int pos = C + __popc(gm & ((1u << lg) - 1u));
+            ckey[wave][grp][pos] = key[j][q];
+            cgi[wave][grp][pos] = (unsigned short)(j * 16 + lg);
+          }
+          C += __popc(gm);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int nfound = 0;
+      const int cmax = (int)wv::MaxU((unsigned)C);                   // longest list of the four groups
+      for (int k = 0; k < nsel; k++) {
+        // best remaining candidate of my group: every lane scans its share of the list, then a row-wide reduction
+        unsigned bv = 0u;
+        int bg = 0x7fffffff, bi = -1;
+        for (int i = lg; i < cmax; i += 16) {
+          if (i < C) {
+            const unsigned kk = ckey[wave][grp][i];
+            const int gg = cgi[wave][grp][i];
+            if (kk > bv || (kk == bv && kk != 0u && gg < bg)) { bv = kk; bg = gg; bi = i; }
+          }
+        }
+        const unsigned wm = RowMaxU(bv);
+        const bool have = wm != 0u && nfound == k;
+        const int gi = (int)RowMinU((bv == wm && have) ? (unsigned)bg : 0x7fffffffu);
+        if (have && bv == wm && bg == gi) ckey[wave][grp][bi] = 0u;
+        if (have && lg == 0) { sel_ll[wave][r][k] = wv::OrderedToFloat(wm); sel_gi[wave][r][k] = gi; }
+        if (have) nfound = k + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lg == 0) { sel_n[wave][r] = nfound; sel_max[wave][r] = max_like; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- phase B: exp(like - max) in double as the reference does (lane = 4 row + slot pair), then lane r prunes and
+    // renormalises row r (posterior.cc:494-507) and writes it
+    {
+      const int r = lane >> 2;
+      const bool row_ok = (active >> r) & 1u;
+      const int nf = row_ok ? sel_n[wave][r] : 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = (lane & 3) + 4 * h;
+        float post = 0.f;
+        if (k < nf) post = (float)exp((double)(sel_ll[wave][r][k] - sel_max[wave][r]));
+        sel_ll[wave][r][k] = post;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < kUbmRows && ((active >> lane) & 1u)) {
+        const int rr = lane;
+        int nfound = sel_n[wave][rr];
+        float sel_w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sel_w[q] = sel_ll[wave][rr][q];
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q < nfound) tot += sel_w[q];
+        const float cutoff = iv.min_post * tot;
+#pragma unroll
+        for (int q = 7; q >= 1; q--)
+          if (nfound == q + 1 && sel_w[q] < cutoff) { tot -= sel_w[q]; nfound = q; }
+        const float inv_tot = (float)(1.0 / (double)tot);
+        const float scale = iv.posterior_scale * 1.0f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (q < nsel) {
+            float w = 0.f;
+            int gi = -1;
+            if (q < nfound) { w = sel_w[q] * inv_tot; w *= scale; gi = sel_gi[wave][rr][q]; }
+            post_idx[(size_t)(row0 + rr) * nsel + q] = gi;
+            post_w[(size_t)(row0 + rr) * nsel + q] = w;
+          }
+        }
+      }
+    }
+  }
+  // rows that are not frames (halo)
+  if (lane < kUbmRows && !((active >> lane) & 1u) && row0 + lane < g.total_rows)
+    for (int q = 0; q < nsel; q++) post_idx[(size_t)(row0 + lane) * nsel + q] = -1;
+}
+
 void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda_norm, int ld, int *post_idx,
                          float *post_w, hipStream_t s) {
   if (g.total_rows <= 0) return;
+  const char *ue = std::getenv("RS_UBM_MFMA");          // read per call: the parity test flips it between two decodes
+  const int use_mfma = ue ? std::atoi(ue) : 1;
+  if (use_mfma && iv.ubm_bm && iv.num_gauss <= 512 && iv.feat_dim <= 48 && iv.num_gselect <= 8) {
+    const int nt = (iv.num_gauss + 15) / 16, kg = iv.ubm_kg;
+    const dim3 grid((g.total_rows + 4 * kUbmRows - 1) / (4 * kUbmRows));
+#define RS_UBM_M(N, K) hipLaunchKernelGGL((UbmPostMfmaKernel<N, K>), grid, dim3(256), 0, s, iv, g, lda_norm, ld, iv.ubm_bm, iv.ubm_bv, post_idx, post_w)
+    if (kg == 1) { if (nt <= 2) RS_UBM_M(2, 1); else if (nt <= 8) RS_UBM_M(8, 1); else RS_UBM_M(32, 1); }
+    else { if (nt <= 2) RS_UBM_M(2, 3); else if (nt <= 8) RS_UBM_M(8, 3); else RS_UBM_M(32, 3); }
+#undef RS_UBM_M
+    return;
+  }
   const int npl = (iv.num_gauss + 63) / 64;
 #define RS_UBM(N, RR)                                                                                                  \
   hipLaunchKernelGGL((UbmPostKernel<N, RR>), dim3((g.total_rows + 4 * RR - 1) / (4 * RR)), dim3(256), 0, s, iv, g, lda_norm, ld, \

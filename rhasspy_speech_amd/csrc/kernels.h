@@ -150,6 +150,11 @@ struct IvecDev {
   const float *gconsts;        // G
   const float *means_invvars_t; // D x G (transposed for coalesced lane-per-Gaussian reads)
   const float *inv_vars_t;      // D x G
+  // the same two tables in the B-fragment order of v_mfma_f32_16x16x4_f32 (UbmPostMfmaKernel): [Gaussian tile of 16][group of
+  // four k-steps][lane 64][4]: lane l, element i = parameter of dimension 16 kg + 4 i + (l >> 4), Gaussian 16 j + (l & 15);
+  // ubm_kg groups (1 for D <= 16, else 3: D <= 48), tiles padded to the kernel instantiation's count; null: not prepared
+  const float *ubm_bm, *ubm_bv;
+  int ubm_kg;
   const double *sigma_inv_M;    // G x D x I
   const double *U;              // G x I(I+1)/2
 };

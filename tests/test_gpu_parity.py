@@ -333,3 +333,22 @@ def test_split_bf16_gemm_odd_shapes_match_oracle(tmp_path, dims):
         diff = np.abs(res.matrix(i, 2) - tr.loglikes).max()
         assert diff < LOGLIKE_TOL, (dims, i, diff)
         assert res.words(i) == tr.nbest[0].words
+
+
+@pytest.mark.parametrize("name", ["tiny_u0", "zam_u0", "zam_long30"])
+def test_ubm_posteriors_on_the_matrix_cores_are_bitwise_the_vector_ones(case_cache, name, monkeypatch):
+    """UbmPostMfmaKernel (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain per element) against UbmPostKernel (the same chain on
+    the vector unit): identical iVectors and log-likelihoods, offline and per streaming chunk."""
+    from rhasspy_speech_amd import _lib
+    model, pcm = make_model(case_cache, name)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RS_UBM_MFMA", flag)
+        off = model.decode_batch([pcm, pcm[: len(pcm) // 3]])
+        st = _lib.Stream(model)
+        st.accept(pcm)
+        out[flag] = (off, st.finish())
+    for a, b in zip(out["1"], out["0"]):
+        for u in range(a.num_utts):
+            np.testing.assert_array_equal(a.matrix(u, 1), b.matrix(u, 1))
+            np.testing.assert_array_equal(a.matrix(u, 2), b.matrix(u, 2))

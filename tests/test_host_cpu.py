@@ -253,14 +253,15 @@ def test_fuzzy_control_flow_of_the_transcriber(tmp_path):
 
 
 @pytest.mark.parametrize("source,extra", [("feat_kernels.hip", ["-ffp-contract=off"]), ("nnet_kernels.hip", []),
-                                           ("nnet_gemm_b3.hip", []), ("decode_reg.hip", ["-ffp-contract=off"]),
+                                           ("nnet_gemm_b3.hip", []), ("nnet_gemm_b3i.hip", []), ("ivector_kernels.hip", []), ("decode_reg.hip", ["-ffp-contract=off"]),
                                            ("decode_kernels.hip", ["-ffp-contract=off"]), ("decode_dense.hip", ["-ffp-contract=off"])])
 def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
     """Kernels that can share a CU with the MFMA GEMM of another decode call must not contain packed FP32 VALU math
     (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): those instructions gave wrong results in 16-lane groups next to
     GemmKernelB3.  The compiler forms them on its own when it vectorises scalar float code, so the
     Makefile builds these files with NOPACK; this test compiles them the same way and looks at the ISA.
-    (ivector_kernels.hip uses v_pk_fma_f32 on purpose in UbmPostKernel and is not covered.)"""
+    (The UBM scoring, once the one deliberate v_pk_fma_f32 user, runs on the matrix cores now -- UbmPostMfmaKernel -- and its
+    vector fallback uses scalar FMAs.)"""
     import re
     import shutil
     import subprocess
@@ -270,7 +271,7 @@ def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
     csrc = Path(__file__).resolve().parent.parent / "rhasspy_speech_amd" / "csrc"
     nopack = re.search(r"^NOPACK\s*=\s*(.*)$", (csrc / "Makefile").read_text(), re.M).group(1).split()
     assert "-fno-slp-vectorize" in nopack and "-fno-vectorize" in nopack
-    flags = nopack if source in ("feat_kernels.hip", "nnet_kernels.hip") else []
+    flags = nopack if source in ("feat_kernels.hip", "nnet_kernels.hip", "ivector_kernels.hip") else []
     out = tmp_path / "k.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, *flags, "-S", "--cuda-device-only", str(csrc / source),
                     "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
