@@ -52,6 +52,8 @@ struct BlockCtx {
   int red_i[NT / 64];
   unsigned hist[256];
   int n_next, q_n[2], overflow, error;
+  unsigned run_min;                  // ordered bits of the smallest candidate cost seen so far in this frame (a bound on next_cutoff)
+  int n_cand;                        // (destination state, arc) pairs recorded by the arc loop
   int pre[kPrefixCap + 1];           // exclusive prefix of the tokens' emitting out-degrees
   float bcast_f[2];
   int bcast_i[4];
@@ -238,6 +240,15 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       // Arc-parallel expansion: the out-degrees of the frame's tokens are prefix-summed in LDS and every thread takes
       // arcs j = tid, tid + NT, ... of the concatenated arc list (binary search for the owning token).  A token-per-thread
       // loop would serialise thousands of L2 atomics on the back-off / unigram states of an n-gram graph.
+      // An arc is relaxed in two steps so that no thread ever waits for an atomic to come back from L2:
+      //   1. atomicMin on best[dst] WITHOUT using the returned value (fire and forget) + the pair (dst, arc) appended to a
+      //      candidate list -- unless the arc is already known to lose: tot >= (smallest candidate seen so far) + adaptive
+      //      beam can only be >= the frame's final next_cutoff, i.e. it would be dropped below anyway;
+      //   2. after a barrier, the candidate whose arc id sits in best[dst] is the one that created / owns the token and
+      //      appends the state to the frame's token list (exactly one winner per state: keys are unique).
+      // Before: one returning 64-bit atomic per arc, ~15 dependent L2 round trips per thread and frame on the ARPA graph.
+      int *cand_s = queue[0], *cand_a = queue[1];
+      const int cand_cap = S;
       auto relax_arc = [&](unsigned a, float cur_cost, bool is_best) __attribute__((always_inline)) {
         const int4 arc = h.arcs[a];
         const float lk = ll_row[arc.x - 1];
@@ -250,10 +261,18 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
           local_min = fminf(local_min, nw);
         }
         local_min = fminf(local_min, tot);
-        Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a);
         cnt_arcs++;
+        const float bound = FromOrdered(c.run_min) + adaptive_beam;
+        if (!(tot < bound)) return;
         cnt_insert++;
+        const unsigned ot = OrderedBits(tot);
+        if (ot < c.run_min) atomicMin(&c.run_min, ot);
+        atomicMin(&best[arc.w], PackKey(tot, a));            // result unused: non-returning
+        const int ci = atomicAdd(&c.n_cand, 1);
+        if (ci < cand_cap) { cand_s[ci] = arc.w; cand_a[ci] = (int)a; }      // (else: the list is full, step 2 scans the table instead)
       };
+      if (tid == 0) { c.run_min = OrderedBits(INF); c.n_cand = 0; }
+      __syncthreads();
       for (int c0 = 0; c0 < n_cur; c0 += kPrefixCap) {         // token chunks whose degree prefix fits LDS
         const int nc = n_cur - c0 < kPrefixCap ? n_cur - c0 : kPrefixCap;
         const int4 *ctok = cur + c0;
@@ -290,6 +309,20 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
           const int4 tk = ctok[lo];
           const unsigned a = h.arc_begin[tk.x] + h.num_ieps[tk.x] + (unsigned)(j - c.pre[lo]);
           relax_arc(a, __int_as_float(tk.y), c0 + lo == best_idx);
+        }
+      }
+      __syncthreads();
+      {
+        const bool listed = c.n_cand <= cand_cap;      // workgroup-uniform
+        const int nc2 = listed ? c.n_cand : S;
+        for (int i = tid; i < nc2; i += NT) {
+          const int s2 = listed ? cand_s[i] : i;
+          const unsigned long long key = LoadKey(&best[s2]);
+          if (listed ? (unsigned)(key & 0xFFFFFFFFull) == (unsigned)cand_a[i] : key != RS_EMPTY) {
+            const int idx = atomicAdd(&c.n_next, 1);
+            if (idx < next_cap) { next_toks[idx].x = s2; map_next[s2] = idx; }
+            else c.overflow = 1;
+          }
         }
       }
       __syncthreads();
