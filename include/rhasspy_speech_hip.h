@@ -49,8 +49,8 @@ typedef struct rs_decode_opts {
   int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
   int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */
   int32_t emit_lattice;        /* 1: results keep the determinised lattice (rs_result_lattice); forces the lattice path */
-  int32_t prune_output_pdfs;   /* 1: evaluate the output layer only for the pdfs that occur on HCLG arcs (the search can read
-                                * no others; transcripts and costs unchanged).  0 (default) computes every pdf like the
+  int32_t prune_output_pdfs;   /* 1 (default): evaluate the output layer only for the pdfs that occur on HCLG arcs (the search
+                                * can read no others; transcripts and costs unchanged).  0 computes every pdf like the
                                 * reference does.  Ignored with keep_intermediates and when the net ends in a log-softmax. */
   int32_t reserved[5];
 } rs_decode_opts;
@@ -161,7 +161,9 @@ int rs_result_matrix(const rs_result *r, int32_t utt, int32_t kind, const float 
  * max_active bound, [6] = frames where min_active bound, [7] = token-capacity overflows. */
 int rs_result_counters(const rs_result *r, int32_t utt, int64_t out[8]);
 /* Wall-clock milliseconds of the stages of the call that produced r: out[0] = H2D, [1] = MFCC,
- * [2] = iVector, [3] = nnet, [4] = decode, [5] = lattice+n-best (host), [6] = total. */
+ * [2] = iVector, [3] = nnet, [4] = decode, [5] = lattice+n-best (host), [6] = total.  For a result of rs_streams_finish the
+ * stages are summed over the finishing call and the rs_streams_advance calls that preceded it on the model, and out[7] is the
+ * wall time of the finishing call alone. */
 int rs_result_timings(const rs_result *r, float out[8]);
 void rs_result_free(rs_result *r);
 

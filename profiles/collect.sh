@@ -26,7 +26,7 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $B --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_sq.log
 python bench.py --workload $WL > $OUT/bench_line.json 2> $OUT/bench.log                       # the default invocation, as the driver runs it
 if [ "$WL" = grammar ]; then
-  $B --prune-output > $OUT/bench_line_pruned_output.json 2>> $OUT/bench.log
+  $B --all-pdfs > $OUT/bench_line_all_pdfs.json 2>> $OUT/bench.log
   $B --inflight 1 > $OUT/bench_line_one_call_in_flight.json 2>> $OUT/bench.log
 fi
 find $OUT -name "*.csv" | head -20

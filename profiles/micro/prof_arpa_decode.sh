@@ -1,0 +1,13 @@
+# per-stage cycle counts of the token-list decoder on the ARPA workload (library rebuilt with -DRS_DECODE_PROFILE in a scratch copy)
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r02n
+cp -r rhasspy_speech_amd /tmp/rs_prof_pkg
+make -C /tmp/rs_prof_pkg/csrc decode_kernels.o EXTRA=-DRS_DECODE_PROFILE -B > /dev/null 2>&1
+make -C /tmp/rs_prof_pkg/csrc > /dev/null 2>&1
+cp /tmp/rs_prof_pkg/librhasspy_speech_hip.so /tmp/librs_prof.so
+cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so
+cp /tmp/librs_prof.so rhasspy_speech_amd/librhasspy_speech_hip.so
+python bench.py --workload arpa --no-cpu-baseline --steps 2 --warmup 1 --inflight 1 2>&1 | grep "token-list" | tail -3 > gpurun_out/r02n/arpa_stages.txt
+cp /tmp/librs_orig.so rhasspy_speech_amd/librhasspy_speech_hip.so
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02n/kt -- python bench.py --steps 5 --warmup 2 --inflight 1 --no-cpu-baseline > /dev/null 2> gpurun_out/r02n/kt.log

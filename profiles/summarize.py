@@ -37,7 +37,7 @@ if stats:
 line = (src / "bench_line.json").read_text().strip().splitlines()[-1]
 json.loads(line)
 (dst / f"{ver}_line.json").write_text(line + "\n")
-for extra in ("pruned_output", "one_call_in_flight"):          # the same bench with one switch changed (collect.sh)
+for extra in ("all_pdfs", "one_call_in_flight"):          # the same bench with one switch changed (collect.sh)
     f = src / f"bench_line_{extra}.json"
     if f.exists() and f.read_text().strip():
         extra_line = f.read_text().strip().splitlines()[-1]

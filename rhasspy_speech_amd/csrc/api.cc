@@ -57,6 +57,10 @@ int rs_default_opts(rs_decode_opts *o) {
   o->frames_per_chunk = 24;  // decodable-simple-looped.h:57 rounded by GetChunkSize
   o->frame_subsampling_factor = 1;
   o->device_id = 0;
+  // The search reads log-likelihoods only for the pdfs that occur on HCLG arcs (decodable-online-looped.cc:213-224): the output
+  // layer is cut down to those rows when that saves at least 30 % of it -- same words, same costs (engine.cc: PruneOutputLayer).
+  // Off automatically with keep_intermediates and for nets that end in a log-softmax; 0 computes every pdf like the reference.
+  o->prune_output_pdfs = 1;
   return RS_OK;
 }
 

@@ -46,6 +46,12 @@ __device__ __forceinline__ void StoreKey(unsigned long long *p, unsigned long lo
 
 constexpr int kPrefixCap = 8192;
 
+#ifdef RS_DECODE_PROFILE
+#define RS_TP(i) do { __syncthreads(); long long _n = clock64(); if (threadIdx.x == 0) prof[i] += _n - t_last; t_last = clock64(); } while (0)
+#else
+#define RS_TP(i) do { } while (0)
+#endif
+
 template <int NT>
 struct BlockCtx {
   float red_f[NT / 64];
@@ -193,6 +199,10 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
   }
   __syncthreads();
   float closure_cutoff = o.beam;    // InitDecoding: ProcessNonemitting(config_.beam)
+#ifdef RS_DECODE_PROFILE
+  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = clock64();
+#endif
 
   for (int f = -1; f < T; f++) {
     int4 *next_toks = tokens + off_next;
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       float best_cost;
       int best_idx;
       BlockMinArg<NT>(c, lv, li, &best_cost, &best_idx);
+      RS_TP(0);
       // ---- GetCutoff
       const float beam_cutoff = best_cost + o.beam;
       float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
           cur_cutoff = beam_cutoff;
         }
       }
+      RS_TP(1);
       const float cost_offset = (n_cur > 0) ? -best_cost : 0.f;
       const float *ll_row = loglikes + (ll_base + f) * ld;
       float local_min = INF;
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         }
       }
       __syncthreads();
+      RS_TP(2);
       {
         const bool listed = c.n_cand <= cand_cap;      // workgroup-uniform
         const int nc2 = listed ? c.n_cand : S;
@@ -326,6 +339,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         }
       }
       __syncthreads();
+      RS_TP(3);
       float mn;
       int dummy;
       BlockMinArg<NT>(c, local_min, tid, &mn, &dummy);
@@ -364,6 +378,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       }
       closure_cutoff = next_cutoff;
       __syncthreads();
+      RS_TP(4);
     }
     // ================================================================ ProcessNonemitting(closure_cutoff)
     {
@@ -411,6 +426,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       }
       __syncthreads();
     }
+    RS_TP(5);
     // ================================================================ materialise frame f+1
     {
       const int nn = c.n_next < next_cap ? c.n_next : next_cap;
@@ -442,9 +458,15 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         if (nn == 0 && c.error == 0) c.error = 1;     // "no surviving tokens"
       }
       __syncthreads();
+      RS_TP(6);
       if (c.error) break;
     }
   }
+#ifdef RS_DECODE_PROFILE
+  if (u == 0 && tid == 0 && T > 0)
+    printf("token-list decode cycles/frame: best %lld cutoff %lld expand %lld winners %lld filter %lld closure %lld materialise %lld (T=%d)\n",
+           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[5] / T, prof[6] / T, T);
+#endif
   // ================================================================ final costs + best-path traceback
   // (frame T's tokens are tokens[off_cur .. off_cur + n_cur))
   {

@@ -48,6 +48,7 @@ struct StreamPool {
   std::vector<int> free_slots;
   std::map<int, int> free_rows;  // start -> length
   std::vector<void *> owned;
+  float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // device time of the stages, summed over the advances since the last finish
 
   int AllocRows(int n) {
     for (auto it = free_rows.begin(); it != free_rows.end(); ++it)
@@ -505,6 +506,8 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     RS_HIP(hipStreamSynchronize(q));
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+    for (int k = 0; k < 4; k++) p->stage_ms[k + 1] += tm.Ms(k, k + 1);
+    p->stage_ms[6] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return;
   }
   // ---------------------------------------------------------------- results
@@ -533,12 +536,12 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     }
   }
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le)); }
-  res->timings[1] = tm.Ms(0, 1);
-  res->timings[2] = tm.Ms(1, 2);
-  res->timings[3] = tm.Ms(2, 3);
-  res->timings[4] = tm.Ms(3, 4);
+  // stage times of the whole stream(s): this call plus the advances since the previous finish on this model; [7] = this call alone
+  res->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  for (int k = 0; k < 4; k++) res->timings[k + 1] = p->stage_ms[k + 1] + tm.Ms(k, k + 1);
   res->timings[5] = tm.Ms(4, 5);
-  res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  res->timings[6] = p->stage_ms[6] + res->timings[7];
+  for (float &v : p->stage_ms) v = 0.f;
 }
 
 }  // namespace rs

@@ -69,7 +69,7 @@ def test_config1_headline_batch_vs_reference(zam_grammar):
     """The bench line's batch (rank 0): all 256 transcripts and costs equal the reference's, through both entry points."""
     import torch
     from rhasspy_speech_amd import _lib
-    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    model = _lib.Model(*zam_grammar, _lib.default_opts(prune_output_pdfs=0))
     pcms = configs.grammar_utterances()
     res = model.decode_batch(pcms)
     _check_against_reference("c1_grammar", res.words, res.costs, len(pcms))
@@ -77,8 +77,10 @@ def test_config1_headline_batch_vs_reference(zam_grammar):
     off = np.arange(len(pcms) + 1, dtype=np.int64) * configs.N_SAMPLES_3S
     dev = model.decode_batch_device(d_pcm.data_ptr(), off)
     _check_against_reference("c1_grammar", dev.words, dev.costs, len(pcms))
-    # the output layer cut down to the pdfs on HCLG arcs: same transcripts
-    pruned = _lib.Model(*zam_grammar, _lib.default_opts(prune_output_pdfs=1)).decode_batch(pcms)
+    # the output layer cut down to the pdfs on HCLG arcs (the library's default): same transcripts
+    pruned_model = _lib.Model(*zam_grammar, _lib.default_opts())
+    assert "pruned to the" in pruned_model.describe()
+    pruned = pruned_model.decode_batch(pcms)
     _check_against_reference("c1_grammar", pruned.words, pruned.costs, len(pcms))
 
 
@@ -287,7 +289,7 @@ def test_pruned_output_layer_on_a_batch(zam_grammar):
     the same words and costs as with the full output layer."""
     from rhasspy_speech_amd import _lib, synth
     model_dir, graph_dir = zam_grammar
-    full = _lib.Model(model_dir, graph_dir, _lib.default_opts())
+    full = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=0))
     pruned = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=1))
     assert "pruned to the" in pruned.describe()
     pcms = [synth.synth_utterance(17000 + u, 48000 - 480 * (u % 9)) for u in range(80)]

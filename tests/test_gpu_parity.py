@@ -294,7 +294,7 @@ def test_pruned_output_layer_gives_the_same_search(case_cache, name):
     from rhasspy_speech_amd import _lib
     model_dir, graph_dir, _, pcm = case_cache(name)
     o = dict(cases.CASES[name].get("opts", {}))
-    full = _lib.Model(model_dir, graph_dir, _lib.default_opts(**o))
+    full = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=0, **o))
     pruned = _lib.Model(model_dir, graph_dir, _lib.default_opts(prune_output_pdfs=1, **o))
     assert "pruned to the" not in full.describe()
     if name == "tinyf_u5":

