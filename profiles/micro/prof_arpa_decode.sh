@@ -1,10 +1,10 @@
 # per-stage cycle counts of the token-list decoder on the ARPA workload (library rebuilt with -DRS_DECODE_PROFILE in a scratch copy)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r02n
-cp -r rhasspy_speech_amd /tmp/rs_prof_pkg
-make -C /tmp/rs_prof_pkg/csrc decode_kernels.o EXTRA=-DRS_DECODE_PROFILE -B > /dev/null 2>&1
-make -C /tmp/rs_prof_pkg/csrc > /dev/null 2>&1
-cp /tmp/rs_prof_pkg/librhasspy_speech_hip.so /tmp/librs_prof.so
+mkdir -p /tmp/rsprof && cp -r rhasspy_speech_amd include /tmp/rsprof/
+rm -f /tmp/rsprof/rhasspy_speech_amd/csrc/decode_kernels.o
+make -C /tmp/rsprof/rhasspy_speech_amd/csrc EXTRA=-DRS_DECODE_PROFILE > gpurun_out/r02n/make.log 2>&1
+cp /tmp/rsprof/rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_prof.so
 cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so
 cp /tmp/librs_prof.so rhasspy_speech_amd/librhasspy_speech_hip.so
 python bench.py --workload arpa --no-cpu-baseline --steps 2 --warmup 1 --inflight 1 2>&1 | grep "token-list" | tail -3 > gpurun_out/r02n/arpa_stages.txt

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
   constexpr int KS = 4 * KG, KP = 16 * KG + 1;      // k-steps; LDS pitch (odd: the 16 rows of a read hit 16 banks)
   constexpr int CAP = 16 * NT;                        // candidates per row, worst case
   __shared__ float xs[4][kUbmRows][KP];
+  __shared__ float gcs[16 * NT];                   // gconsts (read with ds_read: a global load here would make every tile wait vmcnt(0))
   __shared__ unsigned ckey[4][4][CAP];
   __shared__ unsigned short cgi[4][4][CAP];
   __shared__ float sel_ll[4][kUbmRows][8], sel_max[4][kUbmRows];
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
   const int row0 = (blockIdx.x * 4 + wave) * kUbmRows;
   const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
   unsigned active = 0;          // bit r: row r is a real frame (wave-uniform)
+  for (int i = threadIdx.x; i < 16 * NT; i += 256) gcs[i] = iv.gconsts[i < G ? i : G - 1];
 #pragma unroll
   for (int r = 0; r < kUbmRows; r++) {
     const int row = row0 + r;
@@ -257,20 +259,33 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
     active |= ok ? (1u << r) : 0u;
     if (lane < 16 * KG) xs[wave][r][lane] = (ok && lane < D) ? feats[(size_t)row * ld + lane] : 0.f;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
   if (active != 0u) {
     float a1[KS], a2[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) { a1[ks] = xs[wave][lg][4 * ks + grp]; a2[ks] = a1[ks] * a1[ks]; }
     unsigned key[NT][4];
+    // the parameter fragments of tile j + 2 are requested before the MFMAs of tile j: with one or two waves per SIMD nothing
+    // else hides the L2 round trip of a tile's six loads (measured: 193 us for the headline batch without this, all of it
+    // waiting)
+    constexpr int PF = NT > 2 ? 3 : 2;          // register sets in rotation
+    f32x4v pm[PF][KG], pv[PF][KG];
+    auto fetch = [&](int j, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kg = 0; kg < KG; kg++) {
+        pm[set][kg] = *reinterpret_cast<const f32x4v *>(bm + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+        pv[set][kg] = *reinterpret_cast<const f32x4v *>(bv + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < PF - 1 && j < NT; j++) fetch(j, j);
 #pragma unroll
     for (int j = 0; j < NT; j++) {
+      if (j + PF - 1 < NT) fetch(j + PF - 1, (j + PF - 1) % PF);
       f32x4v c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kg = 0; kg < KG; kg++) {
-        const f32x4v m = *reinterpret_cast<const f32x4v *>(bm + ((size_t)(j * KG + kg) * 64 + lane) * 4);
-        const f32x4v v = *reinterpret_cast<const f32x4v *>(bv + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+        const f32x4v m = pm[j % PF][kg], v = pv[j % PF][kg];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * kg + i], m[i], c1, 0, 0, 0);
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
         }
       }
       const int gi = j * 16 + lg;
-      const float gc = iv.gconsts[gi < G ? gi : G - 1];
+      const float gc = gcs[gi];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         float v = gc + c1[q];
