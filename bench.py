@@ -345,14 +345,17 @@ def main() -> None:
         def decode_full():
             return full.decode_batch_device(d_pcm.data_ptr(), offsets)
         n_full = max(4, steps // 4)
-        run_steps(2, decode_full, ref_rec)
+        _, full_rec = run_steps(2, decode_full)
+        # same transcripts (the costs may differ in the last bits: the narrower layer takes another GEMM tile shape)
+        if not np.array_equal(full_rec[:, :2 + MAX_WORDS], ref_rec[:, :2 + MAX_WORDS]):
+            raise SystemExit("bench.py: the all-pdfs model decodes different transcripts")
         torch.cuda.synchronize()
         tf = time.perf_counter()
-        run_steps(n_full, decode_full, ref_rec)
+        run_steps(n_full, decode_full, full_rec)
         torch.cuda.synchronize()
         ef = time.perf_counter() - tf
         all_pdfs = {"value": world * audio_seconds * n_full / ef, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * ef / n_full, "steps": n_full,
-                    "note": "rs_decode_opts.prune_output_pdfs = 0: output layer for all pdfs; identical result records (checked)"}
+                    "note": "rs_decode_opts.prune_output_pdfs = 0: output layer for all pdfs; identical transcripts (checked)"}
         del full
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
