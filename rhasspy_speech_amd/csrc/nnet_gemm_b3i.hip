@@ -12,6 +12,16 @@
 //   reads:       conflict-free ds_read_b128 at 16 x lane per fragment.
 // Two k-steps form one LDS stage (BK = 32): one barrier per 32 of K instead of per 16; two stages, the DMA of stage t + 1
 // runs during the MFMAs of stage t.
+//
+// Measured (profiles/r02): the kernel runs the hidden layers in the same time as nnet_gemm_b3.hip -- the
+// in-loop split and the LDS writes it removes were not what the waves wait for.  Two further experiments on this kernel, both
+// reverted: (1) hipcc puts `s_waitcnt vmcnt(0)` in front of the first use of an ordinary load result while an LDS-DMA is in
+// flight, draining the weight prefetch at every second k-step; hiding the weight loads in inline asm with hand-counted waits
+// is bit-exact only when every wait is vmcnt(0) -- counted waits that leave the DMA in flight behind the weight loads gave
+// wrong tiles, i.e. LDS-DMA and register loads do NOT retire in issue order with respect to each other on this part -- and
+// the all-vmcnt(0) form is no faster (1.64 ms for the nnet stage either way); (2) three instead of two weight register sets
+// beside the asm loads spill.  The tile quantisation (656 row tiles of 128 on 512 slots) and the L2 stream of the weights
+// (24 KiB per k-step and workgroup) are what is left to attack.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -93,23 +103,13 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3I
   const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wn * 2) * 3 * kB3FragBytes + lane * 16;
   const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
-  // The weight loads are hidden from the compiler (inline asm): beside an LDS-DMA in flight hipcc waits vmcnt(0) in front of
-  // the first use of ANY ordinary load result, which drained the whole prefetch queue at every second k-step -- the weights
-  // requested a moment earlier included (the .s showed it; cdna_hip_programming.md section 5, trap (b)).  So the queue is
-  // counted by hand: per k-step a wave issues 6 weight loads, at the first k-step of a stage the staging waves add the DMA of
-  // the next stage behind them (3 per k-step of that stage), and VMEM operations retire in order.
   auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
-    const unsigned char *w1 = wsrc + 4 * kB3FragBytes;      // (immediate offsets reach 4095 bytes: two base registers for the 6 KiB)
-    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[0][0]) : "v"(wsrc) : "memory");
-    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(bf[0][1]) : "v"(wsrc) : "memory");
-    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(bf[0][2]) : "v"(wsrc) : "memory");
-    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(bf[1][0]) : "v"(wsrc) : "memory");
-    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[1][1]) : "v"(w1) : "memory");
-    __asm__ volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(bf[1][2]) : "v"(w1) : "memory");
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
     wsrc += wstep;
   };
-#define RS_B3I_WAIT(N, BF)                                                                                                           \
-  __asm__ volatile("s_waitcnt vmcnt(" #N ")" : "+v"(BF[0][0]), "+v"(BF[0][1]), "+v"(BF[0][2]), "+v"(BF[1][0]), "+v"(BF[1][1]), "+v"(BF[1][2]) : : "memory")
   // one k-step of MFMAs from the fragments at `As` (this k-step's image in LDS)
   auto step = [&](const unsigned char *As, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
     const unsigned char *Al = As + lane * 16;
@@ -133,56 +133,50 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
     }
   };
   if (nt == 0) return;
-  // ---- pipeline: LDS stage s holds k-steps 2 s, 2 s + 1; the weights alternate between two register sets, one k-step ahead
-  // (three sets two steps ahead would not fit beside the 128 accumulators without spilling -- and a spilled asm-load
-  // destination is garbage)
+  // ---- pipeline: LDS stage s holds k-steps 2 s, 2 s + 1; weights rotate over three register sets two k-steps ahead
   const int nstage = (nt + kKPS - 1) / kKPS;
-  bf16x8 b0[2][3], b1[2][3];
+  bf16x8 b0[2][3], b1[2][3], b2[2][3];
   load_b(b0);
+  load_b(b1);
   stage_kstep(smem);
   if (nt > 1) stage_kstep(smem + KSTEP_BYTES);
-  RS_B3I_WAIT(0, b0);
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  // One k-step.  VMEM queue of a wave, oldest first, when the MFMAs of k-step t need their weights W(t):
-  //   first k-step of a stage:   W(t) [issued during the previous stage's second k-step] | W(t+1), DMA of the next stage
-  //   second k-step of a stage:  W(t) | DMA of the next stage, W(t+1)
-  // so W(t) has landed once at most 6 + (DMA instructions of the next stage: 6 when it has two k-steps and this wave stages)
-  // operations are outstanding; a count that is too small only waits longer.
+  // The loop body handles one k-step; the stage protocol (DMA of the next stage issued at the first k-step of a stage, waited
+  // for and fenced by the barrier after its second) is written out per position in the 6-step rotation (2 stages x 3 weight sets).
   int t = 0;
-#define RS_B3I_KSTEP(BCUR, BNEXT)                                                                    \
+#define RS_B3I_KSTEP(BCUR, BNEXT2)                                                                   \
   {                                                                                                  \
     const int st = t >> 1, kk = t & 1;                                                               \
-    load_b(BNEXT);                               /* weights of k-step t + 1 (a padding step past the end) */ \
-    const bool dma = kk == 0 && st + 1 < nstage;                                                     \
-    if (dma) {                                   /* DMA of the next stage */                        \
+    load_b(BNEXT2);                              /* weights of k-step t + 2 (padding steps past the end) */ \
+    if (kk == 0 && st + 1 < nstage) {            /* DMA of the next stage */                        \
       unsigned char *nx = smem + ((st + 1) & 1) * STAGE;                                             \
       stage_kstep(nx);                                                                               \
       if (2 * (st + 1) + 1 < nt) stage_kstep(nx + KSTEP_BYTES);                                      \
     }                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    if (stager && st + 1 < nstage && 2 * (st + 1) + 1 < nt) RS_B3I_WAIT(12, BCUR);                   \
-    else RS_B3I_WAIT(6, BCUR);                                                                       \
     step(smem + (st & 1) * STAGE + kk * KSTEP_BYTES, BCUR);                                          \
-    if (kk == 1) {                               /* stage done: the DMA issued at its first k-step has landed -- only this */ \
-      __asm__ volatile("s_waitcnt vmcnt(6)" ::: "memory");   /* k-step's six weight loads may still be in flight -- */   \
-      __builtin_amdgcn_s_barrier();              /* ... and everyone is done reading this stage */  \
-    } else if (t + 1 == nt) {                                                                        \
+    if (kk == 1 || t + 1 == nt) {                /* stage done: next stage's DMA landed, everyone done reading this one */ \
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
       __builtin_amdgcn_s_barrier();                                                                  \
     }                                                                                                \
     t++;                                                                                             \
   }
 #pragma nounroll
-  while (t + 2 <= nt) {
-    RS_B3I_KSTEP(b0, b1)
+  while (t + 6 <= nt) {
+    RS_B3I_KSTEP(b0, b2)
     RS_B3I_KSTEP(b1, b0)
+    RS_B3I_KSTEP(b2, b1)
+    RS_B3I_KSTEP(b0, b2)
+    RS_B3I_KSTEP(b1, b0)
+    RS_B3I_KSTEP(b2, b1)
   }
-  if (t < nt) RS_B3I_KSTEP(b0, b1)
+  // remainder (< 6 k-steps), same rotation
+  if (t < nt) RS_B3I_KSTEP(b0, b2)
+  if (t < nt) RS_B3I_KSTEP(b1, b0)
+  if (t < nt) RS_B3I_KSTEP(b2, b1)
+  if (t < nt) RS_B3I_KSTEP(b0, b2)
+  if (t < nt) RS_B3I_KSTEP(b1, b0)
 #undef RS_B3I_KSTEP
-  // the padding weight loads of the last k-step may still be in flight: they must land before their registers are reused
-  __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[0][2]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(b0[1][2]),
-                   "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[0][2]), "+v"(b1[1][0]), "+v"(b1[1][1]), "+v"(b1[1][2]) : : "memory");
-#undef RS_B3I_WAIT
   constexpr int RT = MR, NT = 256;
   const int wm = 0;
 #include "nnet_b3_epilogue.inc"
