@@ -238,7 +238,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
   plan->n3 = RoundUp(op.out_dim, 256);
   plan->d_W3 = nullptr;
   plan->d_W3I = nullptr;
-  if (op.out_dim >= 192) {
+  if (op.out_dim >= 192 && GemmB3PaddingOk(op.out_dim, plan->n3)) {
     auto to_bf16 = [](float x) {
       uint32_t u;
       std::memcpy(&u, &x, 4);
@@ -284,7 +284,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     // to be a frame buffer whose first column sits on a k-step boundary
     // ... and the layer to be one the split-bf16 kernels take at all (GemmB3IUsable's padding rule: at most a quarter of the
     // 256-column tiles may be padding) -- decided HERE, because the producers of its sources stop storing plain floats
-    bool imageable = (plan->n3 - op.out_dim) * 4 <= plan->n3;
+    bool imageable = GemmB3PaddingOk(op.out_dim, plan->n3);
     for (auto &sg : op.segs) imageable = imageable && sg.src_buf >= 0 && sg.src_col % 16 == 0;
     if (imageable) {
       std::vector<int> step_k;

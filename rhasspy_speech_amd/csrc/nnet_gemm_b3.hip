@@ -245,10 +245,15 @@ void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStre
 
 }  // namespace
 
+bool GemmB3PaddingOk(int n, int n3) {
+  static const int pct = [] { const char *e = std::getenv("RS_GEMM_B3_PAD"); return e ? std::atoi(e) : 25; }();
+  return (long)(n3 - n) * 100 <= (long)n3 * pct;
+}
+
 bool GemmB3Usable(const GemmDev &d) {
   const char *e = std::getenv("RS_GEMM_B3");          // read per call: the parity test flips it between two decodes
   if ((e && std::atoi(e) == 0) || !d.W3 || d.n3 < kB3BN) return false;
-  if ((d.n3 - d.n) * 4 > d.n3) return false;            // more than a quarter of the 256-column tiles would be padding
+  if (!GemmB3PaddingOk(d.n, d.n3)) return false;
   for (int i = 0; i < d.nsegs; i++)
     if ((d.segs[i].ld & 3) || (d.segs[i].col0 & 3) || (reinterpret_cast<uintptr_t>(d.segs[i].src) & 15)) return false;
   return true;

@@ -240,7 +240,7 @@ bool GemmImagesEnabled() {
 
 bool GemmB3IUsable(const GemmDev &d) {
   if (!GemmImagesEnabled() || !d.W3I || d.n3 < kB3BN) return false;
-  if ((d.n3 - d.n) * 4 > d.n3) return false;
+  if (!GemmB3PaddingOk(d.n, d.n3)) return false;
   for (int i = 0; i < d.nsegs; i++)
     if (!d.segs[i].img.base || d.segs[i].per_utt || (d.segs[i].col0 % kB3KS) != 0) return false;
   if (d.interleave)
