@@ -778,10 +778,11 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
   return d;
 }
 
-// The acoustic model's ops [op_begin, op_end) on one set of frame buffers (kernels.h row layout).  Layers whose halo nobody
-// reads run on the real frames only (frame_rows, when given).
+// The acoustic model's ops [op_begin, op_end) on one set of frame buffers (kernels.h row layout).  A layer is evaluated on the
+// rows its consumers read -- t in [-lext, T + rext) of every utterance, the real frames only for the last layers -- when the
+// caller supplies that row list (row_maps), else on all rows.
 void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
-                    const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s,
+                    const RowMaps &row_maps, int share, size_t op_begin, size_t op_end, hipStream_t s,
                     const std::vector<ActImage> *imgs) const {
   const Nnet &nn = am_.nnet;
   const bool images_on = imgs != nullptr && GemmImagesEnabled();
@@ -794,9 +795,9 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       if (img_out && !GemmWritesImage(gd)) gd.write_f32 = 1;      // a kernel without the image epilogue: converted below
       else img_done = img_out;
       const BufferInfo &ob = nn.bufs[op.out_buf];
-      if (ob.lext == 0 && ob.rext == 0 && d_frame_rows != nullptr) {     // nobody reads this layer's halo rows
-        gd.row_map = d_frame_rows;
-        LaunchGemm(gd, total_frames, d_row_ivec, s);
+      if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext)) {     // only the rows somebody reads
+        gd.row_map = rm->rows;
+        LaunchGemm(gd, rm->count, d_row_ivec, s);
       } else {
         LaunchGemm(gd, rows, d_row_ivec, s);
       }
@@ -1129,6 +1130,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   std::vector<int> buf_ld(nn.bufs.size());
   for (size_t b = 0; b < nn.bufs.size(); b++) { buf_ld[b] = RoundUp(nn.bufs[b].dim, 4); need += fbytes(buf_ld[b]); }
   need += ImageBytes(rows);
+  need += (size_t)nn.ops.size() * (sizeof(int) * ((size_t)rows + n_utts + 64) + 512);      // row lists per output extent
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
   const int ld_c = RoundUp(C, 4), ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = RoundUp(std::max(Di, 1), 4);
   const int usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
@@ -1194,6 +1196,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
   std::vector<int> slab_off(n_slabs + 1, 0);
   int *d_frame_rows = nullptr;
+  RowMaps row_maps;
   if (total_frames > 0) {
     const int n_segs = n_slabs * n_utts;
     int *h_seg = harena.AllocT<int>(n_segs + 1);
@@ -1208,6 +1211,24 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     d_frame_rows = arena_.AllocT<int>(total_frames);
     RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
     LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
+    row_maps.maps.push_back({0, 0, d_frame_rows, total_frames});
+    // the hidden layers: only as much halo as the layers after them reach (15 rows a side for the first, none for the last
+    // of the zamia-like net: 5 % fewer rows over the stack than evaluating the full halo everywhere)
+    static const int trim = [] { const char *e = std::getenv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
+    for (size_t i = 0; trim && i < nn.ops.size(); i++) {
+      if (nn.ops[i].kind != LayerOp::kGemm) continue;
+      const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
+      if ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || ob.lext > L_ || ob.rext > R_ || row_maps.Find(ob.lext, ob.rext)) continue;
+      int *h2 = harena.AllocT<int>(n_utts + 1);
+      int acc = 0;
+      for (int u = 0; u < n_utts; u++) { h2[u] = acc; acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0; }
+      h2[n_utts] = acc;
+      if (acc == 0) continue;
+      int *d2 = arena_.AllocT<int>(n_utts + 1), *d_rows = arena_.AllocT<int>(acc);
+      RS_HIP(hipMemcpyAsync(d2, h2, sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
+      LaunchFrameRows(n_utts, n_utts, acc, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), d2, g.d_row_base, d_rows, s);
+      row_maps.maps.push_back({ob.lext, ob.rext, d_rows, acc});
+    }
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   Timer tm(s);
@@ -1295,7 +1316,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   tm.Mark();
   // ---- acoustic model
   if (pipelined) {
-    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size() - 1, s, &imgs);
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, row_maps, cx.active_groups, 0, nn.ops.size() - 1, s, &imgs);
     // slab k: output layer on the main stream, then the search of that slab on the decode stream
     const size_t i = nn.ops.size() - 1;
     GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[nn.ops[i].out_buf], buf_ld[nn.ops[i].out_buf], cx.active_groups, &imgs,
@@ -1311,7 +1332,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     RS_HIP(hipEventRecord(cx.slab_ev[8], cx.stream_dec));
   } else {
     poison();
-    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, d_frame_rows, total_frames, cx.active_groups, 0, nn.ops.size(), s, &imgs);
+    RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, row_maps, cx.active_groups, 0, nn.ops.size(), s, &imgs);
   }
   float *ll = bufp[nn.output_buf];
   const int ll_ld = buf_ld[nn.output_buf];

@@ -95,6 +95,17 @@ struct Timer {
 struct StreamPool;                                                 // stream.cc
 struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
 
+// Row lists of a batch for the layers that need fewer rows than the full halo: entry (lext, rext) lists, utterance after
+// utterance, the physical rows of t in [-lext, T + rext) (kernels.h row layout).  (0, 0) = the real frames only.
+struct RowMaps {
+  struct Entry { int lext, rext; const int *rows; int count; };
+  std::vector<Entry> maps;
+  const Entry *Find(int lext, int rext) const {
+    for (auto &e : maps) if (e.lext == lext && e.rext == rext) return &e;
+    return nullptr;
+  }
+};
+
 // Which search kernel a call runs and its work buffers (engine.cc: PlanSearch / AllocSearch / LaunchSearch / CollectResults).
 struct SearchPlan {
   bool unscale = false, want_lattice = false, use_reg = false, use_dense = false;
@@ -147,7 +158,7 @@ class Model {
   void CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const BatchGeom &g, const int *T, const float *ll, int ll_ld, int nbest,
                       float lat_scale, hipStream_t s, UttResult *out_utts, float *timings);
   void RunNnet(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, float *d_ivec, int ld_i, const int *d_row_ivec, int rows,
-               const int *d_frame_rows, int total_frames, int share, size_t op_begin, size_t op_end, hipStream_t s,
+               const RowMaps &row_maps, int share, size_t op_begin, size_t op_end, hipStream_t s,
                const std::vector<ActImage> *imgs = nullptr) const;
 
   rs_decode_opts opts_;

@@ -464,7 +464,9 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     LaunchCopyRows(fc_.use_cmvn ? p->nn_in : p->raw, ld_c, D(o_nsrc), bufp[nn.input_buf], buf_ld[nn.input_buf], nullptr, rowsN, C, q);
     int *frame_rows = arena.AllocT<int>(framesN + 8);
     LaunchFrameRows(nN, nN, framesN, L_, std::max(maxTn, 1), D(o_nfb), D(o_nrb), frame_rows, q);
-    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, frame_rows, framesN, 1, 0, nn.ops.size(), q, &imgs);
+    RowMaps row_maps;
+    row_maps.maps.push_back({0, 0, frame_rows, framesN});
+    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, row_maps, 1, 0, nn.ops.size(), q, &imgs);
     LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
   }
   tm.Mark();
