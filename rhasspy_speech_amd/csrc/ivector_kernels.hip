@@ -732,6 +732,106 @@ __global__ __launch_bounds__(128) void IvecQuadKernel(IvecDev iv, int n_utts, co
   }
 }
 
+// ---- the two batch products on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; C/D layout of the f64 form: column = lane & 15,
+// row = (lane >> 4) + 4 * reg -- NOT the f32 map).  Same sums in the same order (Gaussians / feature dims ascending, one
+// accumulator per output element), so the estimator state matches the vector kernels to fp64 rounding; what changes is the
+// operand traffic: a wave multiplies a 64-utterance x 4 slab of the per-utterance statistics (LDS) with a 4 x 16 slab of the
+// model matrix (one 8-byte load per lane) in four MFMAs, instead of one LDS broadcast read per fused multiply-add.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kMmU = 64;           // utterances per workgroup (4 M tiles of 16)
+// quadratic[u][k] += sum_g gamma[u][g] U_g[k]: [n_utts x G] x [G x usz]; workgroup = 4 waves = 4 column tiles of 16
+__global__ __launch_bounds__(256) void IvecQuadMfmaKernel(IvecDev iv, int n_utts, const float *__restrict__ gamma,
+                                                          const double *__restrict__ change, double *__restrict__ quadratic,
+                                                          double *__restrict__ linear) {
+  constexpr int GC = 128;                                   // Gaussians per LDS chunk
+  __shared__ float gml[kMmU][GC + 1];
+  const int G = iv.num_gauss, I = iv.ivec_dim, usz = I * (I + 1) / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int u0 = blockIdx.y * kMmU, k0 = (blockIdx.x * 4 + wave) * 16;
+  const int kcol = k0 + lr < usz ? k0 + lr : usz - 1;
+  f64x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int g0 = 0; g0 < G; g0 += GC) {
+    const int n = G - g0 < GC ? G - g0 : GC;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kMmU * GC; e += 256) {
+      const int uu = e / GC, gi = e % GC;
+      gml[uu][gi] = (u0 + uu < n_utts && gi < n) ? gamma[(size_t)(u0 + uu) * G + g0 + gi] : 0.f;
+    }
+    __syncthreads();
+    if (k0 < usz) {
+      for (int gi = 0; gi < n; gi += 4) {
+        const int gk = gi + lk < n ? gi + lk : n - 1;             // (past the end: gml is zero there)
+        const double b = iv.U[(size_t)(g0 + gk) * usz + kcol];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gi + lk], b, acc[m], 0, 0, 0);
+      }
+    }
+  }
+  if (k0 + lr >= usz) return;
+  const int k = k0 + lr;
+  int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= k) r++;
+  while (r * (r + 1) / 2 > k) r--;
+  const bool diag = (k == r * (r + 1) / 2 + r);
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int u = u0 + 16 * m + lk + 4 * q;
+      if (u >= n_utts) continue;
+      const double ch = change[u];
+      quadratic[(size_t)u * usz + k] += acc[m][q] + ((diag && ch != 0.0) ? ch : 0.0);
+      if (k == 0 && ch != 0.0) linear[(size_t)u * I] += iv.prior_offset * ch;
+    }
+}
+// partial[ks][u][i] = sum over the Gaussians of range ks and all d of Sigma_inv_M[g][d][i] * wfeats[u][g][d]:
+// [n_utts x (G D)] x [(G D) x I], K split into kIvecKS Gaussian ranges (reduced in fixed order by IvecLinearReduceKernel)
+__global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_utts, const double *__restrict__ wfeats,
+                                                            double *__restrict__ partial) {
+  constexpr int KC = 64;                                    // (Gaussian, dim) products per LDS chunk
+  __shared__ double wfl[kMmU][KC + 1];
+  const int D = iv.feat_dim, G = iv.num_gauss, I = iv.ivec_dim;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int u0 = blockIdx.x * kMmU, ks = blockIdx.y;
+  const int per = (G + kIvecKS - 1) / kIvecKS, g_begin = ks * per, g_end = g_begin + per < G ? g_begin + per : G;
+  const long kk_begin = (long)g_begin * D, kk_end = (long)(g_end > g_begin ? g_end : g_begin) * D;      // rows of Sigma_inv_M [G D][I]
+  for (int pass = 0; pass * 64 < I; pass++) {               // 64 columns per pass, 16 per wave (same barrier count for every wave)
+    const int i0 = pass * 64 + wave * 16;
+    const bool live = i0 < I;
+    const int icol = i0 + lr < I ? i0 + lr : I - 1;
+    f64x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // (all four waves walk the K chunks together: the LDS slab is shared)
+    for (long c0 = kk_begin; c0 < kk_end; c0 += KC) {
+      const int n = kk_end - c0 < KC ? (int)(kk_end - c0) : KC;
+      __syncthreads();
+      for (int e = threadIdx.x; e < kMmU * KC; e += 256) {
+        const int uu = e / KC, j = e % KC;
+        wfl[uu][j] = (u0 + uu < n_utts && j < n) ? wfeats[(size_t)(u0 + uu) * G * D + c0 + j] : 0.0;
+      }
+      __syncthreads();
+      for (int j = 0; live && j < n; j += 4) {
+        const int jk = j + lk < n ? j + lk : n - 1;
+        const double b = iv.sigma_inv_M[(size_t)(c0 + jk) * I + icol];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][j + lk], b, acc[m], 0, 0, 0);
+      }
+    }
+    if (i0 + lr < I) {
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int u = u0 + 16 * m + lk + 4 * q;
+          if (u < n_utts) partial[((size_t)ks * n_utts + u) * I + i0 + lr] = acc[m][q];
+        }
+    }
+  }
+}
+
 // zero the per-step accumulators of the Gaussians that were touched (cheaper than a 40 MB memset per chunk)
 __global__ void IvecClearKernel(IvecDev iv, float *__restrict__ gamma, double *__restrict__ wfeats) {
   const int u = blockIdx.y, gi = blockIdx.x * blockDim.y + threadIdx.y;
@@ -756,10 +856,15 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   const float *gm = reinterpret_cast<const float *>(gamma);
   double *partial = scratch, *change = scratch + (size_t)kIvecKS * n_utts * iv.ivec_dim;
   const int ub = (n_utts + kIvecUB - 1) / kIvecUB, usz = iv.ivec_dim * (iv.ivec_dim + 1) / 2;
-  hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
+  const char *me = std::getenv("RS_IVEC_MFMA");          // read per call (tests flip it)
+  const bool mfma = !(me && std::atoi(me) == 0);
+  const int um = (n_utts + kMmU - 1) / kMmU;
+  if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel, dim3(um, kIvecKS), dim3(256), 0, s, iv, n_utts, wfeats, partial);
+  else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
   hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
   hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
-  hipLaunchKernelGGL(IvecQuadKernel, dim3((usz + 127) / 128, ub), dim3(128), 0, s, iv, n_utts, gm, change, quadratic, linear);
+  if (mfma) hipLaunchKernelGGL(IvecQuadMfmaKernel, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear);
+  else hipLaunchKernelGGL(IvecQuadKernel, dim3((usz + 127) / 128, ub), dim3(128), 0, s, iv, n_utts, gm, change, quadratic, linear);
 }
 
 // ------------------------------------------------------------------------------------------ CG solve
