@@ -759,13 +759,24 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaKernel(IvecDev iv, int n_utts
       const int uu = e / GC, gi = e % GC;
       gml[uu][gi] = (u0 + uu < n_utts && gi < n) ? gamma[(size_t)(u0 + uu) * G + g0 + gi] : 0.f;
     }
+    if (threadIdx.x < kMmU) gml[threadIdx.x][GC] = 0.f;
     __syncthreads();
     if (k0 < usz) {
-      for (int gi = 0; gi < n; gi += 4) {
-        const int gk = gi + lk < n ? gi + lk : n - 1;             // (past the end: gml is zero there)
-        const double b = iv.U[(size_t)(g0 + gk) * usz + kcol];
+      // eight k-steps of model-matrix values requested before the first of their MFMAs (one wave per SIMD at most: nothing
+      // else hides the round trip)
+      for (int gi = 0; gi < n; gi += 32) {
+        double b[8];
 #pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gi + lk], b, acc[m], 0, 0, 0);
+        for (int q = 0; q < 8; q++) {
+          const int gk = gi + 4 * q + lk < n ? gi + 4 * q + lk : n - 1;             // (past the end: gml is zero there)
+          b[q] = iv.U[(size_t)(g0 + gk) * usz + kcol];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int gc = gi + 4 * q + lk < GC ? gi + 4 * q + lk : GC;
+#pragma unroll
+          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gc], b[q], acc[m], 0, 0, 0);
+        }
       }
     }
   }
@@ -797,14 +808,13 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
   const int u0 = blockIdx.x * kMmU, ks = blockIdx.y;
   const int per = (G + kIvecKS - 1) / kIvecKS, g_begin = ks * per, g_end = g_begin + per < G ? g_begin + per : G;
   const long kk_begin = (long)g_begin * D, kk_end = (long)(g_end > g_begin ? g_end : g_begin) * D;      // rows of Sigma_inv_M [G D][I]
-  for (int pass = 0; pass * 64 < I; pass++) {               // 64 columns per pass, 16 per wave (same barrier count for every wave)
-    const int i0 = pass * 64 + wave * 16;
+  {
+    const int i0 = blockIdx.z * 64 + wave * 16;               // 64 columns per workgroup, 16 per wave
     const bool live = i0 < I;
     const int icol = i0 + lr < I ? i0 + lr : I - 1;
     f64x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // (all four waves walk the K chunks together: the LDS slab is shared)
     for (long c0 = kk_begin; c0 < kk_end; c0 += KC) {
       const int n = kk_end - c0 < KC ? (int)(kk_end - c0) : KC;
       __syncthreads();
@@ -812,12 +822,21 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
         const int uu = e / KC, j = e % KC;
         wfl[uu][j] = (u0 + uu < n_utts && j < n) ? wfeats[(size_t)(u0 + uu) * G * D + c0 + j] : 0.0;
       }
+      if (threadIdx.x < kMmU) wfl[threadIdx.x][KC] = 0.0;
       __syncthreads();
-      for (int j = 0; live && j < n; j += 4) {
-        const int jk = j + lk < n ? j + lk : n - 1;
-        const double b = iv.sigma_inv_M[(size_t)(c0 + jk) * I + icol];
+      for (int j = 0; live && j < n; j += 32) {
+        double b[8];
 #pragma unroll
-        for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][j + lk], b, acc[m], 0, 0, 0);
+        for (int q = 0; q < 8; q++) {
+          const int jk = j + 4 * q + lk < n ? j + 4 * q + lk : n - 1;
+          b[q] = iv.sigma_inv_M[(size_t)(c0 + jk) * I + icol];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int jc = j + 4 * q + lk < KC ? j + 4 * q + lk : KC;
+#pragma unroll
+          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][jc], b[q], acc[m], 0, 0, 0);
+        }
       }
     }
     if (i0 + lr < I) {
@@ -859,7 +878,7 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   const char *me = std::getenv("RS_IVEC_MFMA");          // read per call (tests flip it)
   const bool mfma = !(me && std::atoi(me) == 0);
   const int um = (n_utts + kMmU - 1) / kMmU;
-  if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel, dim3(um, kIvecKS), dim3(256), 0, s, iv, n_utts, wfeats, partial);
+  if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
   else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
   hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
   hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
