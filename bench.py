@@ -356,6 +356,13 @@ def main() -> None:
         ef = time.perf_counter() - tf
         all_pdfs = {"value": world * audio_seconds * n_full / ef, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * ef / n_full, "steps": n_full,
                     "note": "rs_decode_opts.prune_output_pdfs = 0: output layer for all pdfs; identical transcripts (checked)"}
+        # its nnet stage (un-overlapped calls): EVERY launch of it runs on the split-bf16 kernels -- the stage the roofline prices
+        full_stage = np.zeros(8)
+        for _ in range(5):
+            full_stage += np.array(decode_full().timings())
+        full_stage /= 5
+        all_pdfs["nnet_stage_ms"] = float(full_stage[3])
+        all_pdfs["desc"] = full.describe()
         del full
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
@@ -398,18 +405,27 @@ def main() -> None:
             dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
             split_bf16 = os.environ.get("RS_GEMM_B3", "1") != "0"
             peak = 2500.0 / 6.0 if split_bf16 else 157.3
-            achieved = flops / (stage[3] * 1e-3) / 1e12 if stage[3] > 0 else 0.0
+            nnet_ms, roof_on = float(stage[3]), "this run's model"
+            if all_pdfs is not None:
+                # the default model evaluates its pruned output layer (362 of 2000 columns) on the exact-FP32 kernel; the roofline
+                # is priced on the all-pdfs model of the same run, whose ten launches all run on the split-bf16 kernels
+                # (round 1's definition of the stage)
+                nnet_ms, roof_on = all_pdfs.pop("nnet_stage_ms"), "the all-pdfs model of the same run (every launch of the stage on the split-bf16 kernels)"
+                flops = nnet_flops_per_row(all_pdfs.pop("desc")) * frames
+            achieved = flops / (nnet_ms * 1e-3) / 1e12 if nnet_ms > 0 else 0.0
             traffic, traffic_from = pmc_traffic(wl, "GemmKernelB3" if split_bf16 else "GemmKernel")
             roof_mfma = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_from": traffic_from,
                          "kernel": (f"GemmKernelB3 (FP32 operands split into 3 bf16 parts, 6 bf16 MFMAs per product, FP32 accumulate), "
                                     f"{n_gemm} launches per step (the nnet stage)") if split_bf16 else f"GemmKernel, {n_gemm} launches per step",
-                         "launches": n_gemm, "avg_launch_ms": float(stage[3]) / n_gemm, "flops_per_launch": flops / n_gemm,
-                         "stage_ms": float(stage[3]), "frac_of_fp32_mfma_peak": achieved / 157.3}
+                         "launches": n_gemm, "avg_launch_ms": nnet_ms / n_gemm, "flops_per_launch": flops / n_gemm,
+                         "stage_ms": nnet_ms, "measured_on": roof_on, "frac_of_fp32_mfma_peak": achieved / 157.3}
             dtraffic, dtraffic_from = pmc_traffic(wl, "DecodeKernel")
             roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9 if stage[4] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                         "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0 if stage[4] > 0 else 0.0, "traffic": dtraffic, "traffic_from": dtraffic_from,
                         "algorithmic_bytes": dec_bytes,
                         "kernel": "beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
+            if all_pdfs is not None:
+                all_pdfs.pop("nnet_stage_ms", None); all_pdfs.pop("desc", None)
             roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
             out["stages_from"] = f"{n_iso} un-overlapped calls after the timed region"
             out["roofline"] = roofline
