@@ -41,7 +41,7 @@ def _check_against_reference(name, words_of, costs_of, n):
     utterances: the reference creates tokens while its running `next_cutoff` tightens (lattice-faster-decoder.cc:774-787),
     so which tokens beyond best + adaptive-beam exist depends on its HashList iteration order; the kernels prune with the
     final cutoff.  When max-active / min-active binds, such an order-dependent token occasionally
-    carries a (slightly) cheaper alignment of the SAME words: observed on 2 of the 1792 utterances of configs 1-4 (c2_arpa
+    carries a (slightly) cheaper alignment of the SAME words: observed on 2 of the 1600 utterances of configs 1-4 (c2_arpa
     162, c3_mixed_fr), never a different transcript.  tests/test_oracle_golden.py pins the CPU oracle, which follows the hash
     order, to the reference's costs on exactly those utterances."""
     ref_words, ref_g, ref_a = configs.load_golden(name)
