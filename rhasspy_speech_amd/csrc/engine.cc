@@ -137,6 +137,14 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
       sg.src_buf = 0; sg.src_col = 0; sg.ncols = C; sg.offset = i - ie.splice_left; sg.w_col = i * C;
       lda_op_.segs.push_back(sg);
     }
+    lda_op1_ = lda_op_;
+    lda_op1_.name = "ivector.splice+lda (one run)";
+    lda_op1_.segs.clear();
+    {
+      GemmSegment sg;
+      sg.src_buf = 0; sg.src_col = 0; sg.ncols = C * nsp; sg.offset = -ie.splice_left; sg.w_col = 0;
+      lda_op1_.segs.push_back(sg);
+    }
   }
   PruneOutputLayer();
   for (auto &op : am_.nnet.ops) {
@@ -407,6 +415,7 @@ void Model::ToDevice() {
     ivec_dev_.sigma_inv_M = Upload(ie.sigma_inv_M);
     ivec_dev_.U = Upload(ie.U);
     BuildGemmPlan(lda_op_, &lda_plan_);
+    if (std::getenv("RS_LDA_ONE_RUN") == nullptr || std::atoi(std::getenv("RS_LDA_ONE_RUN")) != 0) BuildGemmPlan(lda_op1_, &lda_plan1_);
   }
   // ---- nnet
   gemm_plans_.assign(am_.nnet.ops.size(), GemmPlan());
@@ -1257,9 +1266,9 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     poison();
     LaunchOnlineCmvn(cmvn_iv_dev_, g, raw, cm, ld_c, s);
     poison();
-    LaunchGemm(MakeGemm(lda_plan_, {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l, cx.active_groups), rows, d_row_ivec, s);
+    LaunchGemm(MakeGemm(LdaPlan(raw_ld), {raw}, {raw_ld}, nullptr, 0, lda_raw, ld_l, cx.active_groups), rows, d_row_ivec, s);
     poison();
-    LaunchGemm(MakeGemm(lda_plan_, {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, cx.active_groups), rows, d_row_ivec, s);
+    LaunchGemm(MakeGemm(LdaPlan(ld_c), {cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, cx.active_groups), rows, d_row_ivec, s);
     int *post_idx = arena_.AllocT<int>((size_t)rows * nsel);
     float *post_w = arena_.AllocT<float>((size_t)rows * nsel);
     poison();

@@ -209,6 +209,11 @@ class Model {
   IvecDev ivec_dev_{};
   LayerOp lda_op_;                    // splice + LDA of the iVector branch, as a segmented GEMM
   GemmPlan lda_plan_;
+  // The same as ONE segment: with a row pitch equal to the feature dim, the spliced vector of frame t is the contiguous run of
+  // floats from row t - left onwards (rows overlap), so the per-frame segments' padding to the k-tile (40 -> 64) disappears
+  LayerOp lda_op1_;
+  GemmPlan lda_plan1_;
+  const GemmPlan &LdaPlan(int ld) const { return (lda_plan1_.op && ld == fc_.mfcc.nceps) ? lda_plan1_ : lda_plan_; }
   std::vector<GemmPlan> gemm_plans_;  // indexed like am_.nnet.ops (unused entries for eltwise ops)
   float *d_log_priors_ = nullptr;
   HclgDev hclg_dev_{};

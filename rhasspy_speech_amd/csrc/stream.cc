@@ -426,8 +426,8 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     int *ru = arena.AllocT<int>(rowsI + 8), *rt = arena.AllocT<int>(rowsI + 8);
     LaunchRowGeometry(nI, rowsI, sl, D(o_irb), nullptr, ru, rt, nullptr, q);
     g.d_row_utt = ru; g.d_row_t = rt;
-    LaunchGemm(MakeGemm(lda_plan_, {seg_raw}, {ld_c}, nullptr, 0, lda_raw, ld_l, 1), rowsI, ru, q);
-    LaunchGemm(MakeGemm(lda_plan_, {seg_cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, 1), rowsI, ru, q);
+    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_raw}, {ld_c}, nullptr, 0, lda_raw, ld_l, 1), rowsI, ru, q);
+    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, 1), rowsI, ru, q);
     int *post_idx = arena.AllocT<int>((size_t)rowsI * nsel + 64);
     float *post_w = arena.AllocT<float>((size_t)rowsI * nsel + 64);
     LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, q);
