@@ -61,6 +61,8 @@ struct BlockCtx {
   unsigned run_min;                  // ordered bits of the smallest candidate cost seen so far in this frame (a bound on next_cutoff)
   int n_cand;                        // (destination state, arc) pairs recorded by the arc loop
   int pre[kPrefixCap + 1];           // exclusive prefix of the tokens' emitting out-degrees
+  unsigned tok_a0[kPrefixCap];       // first emitting arc of each token's state, and the token's cost: the arc loop then needs no
+  float tok_cost[kPrefixCap];        // global access to find out WHICH arc it is working on
   float bcast_f[2];
   int bcast_i[4];
   unsigned long long counters[8];
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       // Before: one returning 64-bit atomic per arc, ~15 dependent L2 round trips per thread and frame on the ARPA graph.
       int *cand_s = queue[0], *cand_a = queue[1];
       const int cand_cap = S;
-      auto relax_arc = [&](unsigned a, float cur_cost, bool is_best) __attribute__((always_inline)) {
-        const int4 arc = h.arcs[a];
-        const float lk = ll_row[arc.x - 1];
+      // (arc record and log-likelihood are loaded by the caller, four arcs at a time: a thread's ~15 arcs per frame used to be 15
+      // serialised chains of dependent L2 round trips -- token, arc range, arc, log-likelihood, atomic)
+      auto relax_arc = [&](unsigned a, const int4 arc, float lk, float cur_cost, bool is_best) __attribute__((always_inline)) {
         const float graph_cost = __int_as_float(arc.z);
         const float ac_cost = cost_offset - lk;
         const float tot = (cur_cost + ac_cost) + graph_cost;
@@ -293,12 +295,23 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         const int seg = (nc + NT - 1) / NT;
         const int i0 = tid * seg < nc ? tid * seg : nc, i1 = i0 + seg < nc ? i0 + seg : nc;
         int lsum = 0;
-        for (int i = i0; i < i1; i++) {
-          const int4 tk = ctok[i];
-          int deg = 0;
-          if (__int_as_float(tk.y) <= cur_cutoff) { deg = (int)(h.arc_begin[tk.x + 1] - h.arc_begin[tk.x] - h.num_ieps[tk.x]); cnt_expanded++; }
-          c.pre[i] = deg;
-          lsum += deg;
+        for (int ib = i0; ib < i1; ib += 4) {
+          int4 tk[4];
+          unsigned ab[4], ae[4], ne[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) tk[q] = ctok[ib + q < i1 ? ib + q : i1 - 1];
+#pragma unroll
+          for (int q = 0; q < 4; q++) { ab[q] = h.arc_begin[tk[q].x]; ae[q] = h.arc_begin[tk[q].x + 1]; ne[q] = h.num_ieps[tk[q].x]; }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (ib + q >= i1) break;
+            int deg = 0;
+            if (__int_as_float(tk[q].y) <= cur_cutoff) { deg = (int)(ae[q] - ab[q] - ne[q]); cnt_expanded++; }
+            c.pre[ib + q] = deg;
+            c.tok_a0[ib + q] = ab[q] + ne[q];
+            c.tok_cost[ib + q] = __int_as_float(tk[q].y);
+            lsum += deg;
+          }
         }
         // exclusive scan of the per-thread sums over the block
         int inc = lsum;
@@ -315,31 +328,33 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         for (int i = i0; i < i1; i++) { const int dgr = c.pre[i]; c.pre[i] = run; run += dgr; }
         if (tid == 0) c.pre[nc] = total;
         __syncthreads();
-        for (int j = tid; j < total; j += NT) {
-          int lo = 0, hi = nc;            // last token with pre[t] <= j
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.pre[mid] <= j) lo = mid; else hi = mid; }
-          const int4 tk = ctok[lo];
-          const unsigned a = h.arc_begin[tk.x] + h.num_ieps[tk.x] + (unsigned)(j - c.pre[lo]);
-          relax_arc(a, __int_as_float(tk.y), c0 + lo == best_idx);
+        for (int jb = tid; jb < total; jb += 4 * NT) {
+          unsigned a[4];
+          float cc[4];
+          bool bst[4], on[4];
+          int4 arc[4];
+          float lk[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int j = jb + q * NT;
+            on[q] = j < total;
+            const int jj = on[q] ? j : total - 1;
+            int lo = 0, hi = nc;            // last token with pre[t] <= j
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.pre[mid] <= jj) lo = mid; else hi = mid; }
+            a[q] = c.tok_a0[lo] + (unsigned)(jj - c.pre[lo]);
+            cc[q] = c.tok_cost[lo];
+            bst[q] = c0 + lo == best_idx;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) arc[q] = h.arcs[a[q]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) lk[q] = ll_row[arc[q].x - 1];
+#pragma unroll
+          for (int q = 0; q < 4; q++) if (on[q]) relax_arc(a[q], arc[q], lk[q], cc[q], bst[q]);
         }
       }
       __syncthreads();
       RS_TP(2);
-      {
-        const bool listed = c.n_cand <= cand_cap;      // workgroup-uniform
-        const int nc2 = listed ? c.n_cand : S;
-        for (int i = tid; i < nc2; i += NT) {
-          const int s2 = listed ? cand_s[i] : i;
-          const unsigned long long key = LoadKey(&best[s2]);
-          if (listed ? (unsigned)(key & 0xFFFFFFFFull) == (unsigned)cand_a[i] : key != RS_EMPTY) {
-            const int idx = atomicAdd(&c.n_next, 1);
-            if (idx < next_cap) { next_toks[idx].x = s2; map_next[s2] = idx; }
-            else c.overflow = 1;
-          }
-        }
-      }
-      __syncthreads();
-      RS_TP(3);
       float mn;
       int dummy;
       BlockMinArg<NT>(c, local_min, tid, &mn, &dummy);
@@ -350,31 +365,41 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         finfo[f * 4 + 2] = next_cutoff;
         finfo[f * 4 + 3] = adaptive_beam;
       }
-      // ---- drop candidates at or above the final cutoff (the reference never keeps a token it creates with
-      //      tot_cost >= next_cutoff alive past the next frame's beam; see header)
-      if (next_cutoff < INF) {
-        int nn = c.n_next < next_cap ? c.n_next : next_cap;
-        __syncthreads();
-        if (tid == 0) c.q_n[0] = 0;
-        __syncthreads();
-        for (int i = tid; i < nn; i += NT) {
-          const int s = next_toks[i].x;
-          if (KeyCost(LoadKey(&best[s])) < next_cutoff) {
-            queue[0][atomicAdd(&c.q_n[0], 1)] = s;
-          } else {
-            StoreKey(&best[s], RS_EMPTY);
-            map_next[s] = -1;
+      RS_TP(3);
+      {
+        // step 2 of the relaxation, and the cutoff in the same pass: the winner of a state either appends it to the frame's token
+        // list or -- at or above the final cutoff, where the reference never keeps a token alive past the next frame's beam
+        // (see header) -- clears the table entry again
+        const bool listed = c.n_cand <= cand_cap;      // workgroup-uniform
+        const int nc2 = listed ? c.n_cand : S;
+        for (int ib = tid; ib < nc2; ib += 4 * NT) {
+          int s2[4], ca[4];
+          unsigned long long key[4];
+          bool on[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = ib + q * NT;
+            on[q] = i < nc2;
+            const int ii = on[q] ? i : nc2 - 1;
+            s2[q] = listed ? cand_s[ii] : ii;
+            ca[q] = listed ? cand_a[ii] : 0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[s2[q]]);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (!on[q]) continue;
+            if (listed ? (unsigned)(key[q] & 0xFFFFFFFFull) == (unsigned)ca[q] : key[q] != RS_EMPTY) {
+              if (KeyCost(key[q]) < next_cutoff) {
+                const int idx = atomicAdd(&c.n_next, 1);
+                if (idx < next_cap) { next_toks[idx].x = s2[q]; map_next[s2[q]] = idx; }
+                else c.overflow = 1;
+              } else {
+                StoreKey(&best[s2[q]], RS_EMPTY);
+              }
+            }
           }
         }
-        __syncthreads();
-        nn = c.q_n[0];
-        for (int i = tid; i < nn; i += NT) {
-          const int s = queue[0][i];
-          next_toks[i].x = s;
-          map_next[s] = i;
-        }
-        __syncthreads();
-        if (tid == 0) { c.n_next = nn; c.q_n[0] = 0; }
       }
       closure_cutoff = next_cutoff;
       __syncthreads();
@@ -387,12 +412,20 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       __syncthreads();
       if (tid == 0) { c.q_n[0] = 0; c.q_n[1] = 0; }
       __syncthreads();
-      for (int i = tid; i < n0; i += NT) {
-        const int s = next_toks[i].x;
-        if (h.num_ieps[s] != 0) {
-          queue[0][atomicAdd(&c.q_n[0], 1)] = s;
-          atomicExch(&in_queue[s], 1);
-        }
+      for (int ib = tid; ib < n0; ib += 4 * NT) {
+        int st[4];
+        unsigned ne[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = ib + q * NT; on[q] = i < n0; st[q] = next_toks[on[q] ? i : n0 - 1].x; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) ne[q] = h.num_ieps[st[q]];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (on[q] && ne[q] != 0) {
+            queue[0][atomicAdd(&c.q_n[0], 1)] = st[q];
+            atomicExch(&in_queue[st[q]], 1);
+          }
       }
       __syncthreads();
       int guard_rounds = 0;
@@ -402,19 +435,50 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         for (int i = tid; i < qn; i += NT) atomicExch(&in_queue[queue[qi][i]], 0);
         if (tid == 0) c.q_n[qi ^ 1] = 0;
         __syncthreads();
-        for (int i = tid; i < qn; i += NT) {
-          const int s = queue[qi][i];
-          const float cur_cost = KeyCost(LoadKey(&best[s]));
-          if (cur_cost >= closure_cutoff) continue;
-          cnt_expanded++;
-          const unsigned a0 = h.arc_begin[s], a1 = a0 + h.num_ieps[s];
-          for (unsigned a = a0; a < a1; a++) {
-            const int4 arc = h.arcs[a];
+        // One queue entry per thread and pass (uniform trip count: the wave votes below).  In an n-gram graph thousands of
+        // history states back off into ONE unigram state: when every relaxing lane of a wave targets the same state the wave
+        // reduces its keys first and issues a single atomic instead of 64 serialised ones on one L2 address.
+        for (int ib = 0; ib < qn; ib += NT) {
+          const int i = ib + tid;
+          const bool have = i < qn;
+          const int s = have ? queue[qi][i] : 0;
+          const float cur_cost = have ? KeyCost(LoadKey(&best[s])) : INF;
+          const bool live = have && cur_cost < closure_cutoff;
+          if (live) cnt_expanded++;
+          const unsigned a0 = live ? h.arc_begin[s] : 0u, ne = live ? h.num_ieps[s] : 0u;
+          unsigned ne_max = ne;
+#pragma unroll
+          for (int o2 = 32; o2 > 0; o2 >>= 1) ne_max = max(ne_max, (unsigned)__shfl_xor((int)ne_max, o2, 64));
+          for (unsigned k = 0; k < ne_max; k++) {
+            const bool has_arc = k < ne;
+            const unsigned a = a0 + (has_arc ? k : 0u);
+            const int4 arc = has_arc ? h.arcs[a] : make_int4(0, 0, 0, 0);
             const float tot = cur_cost + __int_as_float(arc.z);
-            cnt_arcs++;
-            if (tot < closure_cutoff) {
-              cnt_insert++;
-              if (Relax(c, best, map_next, next_toks, next_cap, arc.w, tot, a) && h.num_ieps[arc.w] != 0) {
+            if (has_arc) cnt_arcs++;
+            const bool act = has_arc && tot < closure_cutoff;
+            if (act) cnt_insert++;
+            const unsigned long long m = __ballot(act);
+            if (m == 0ull) continue;
+            const int first = __ffsll((long long)m) - 1;
+            const int d0 = __shfl(arc.w, first, 64);
+            const bool uniform = __ballot(act && arc.w != d0) == 0ull;
+            unsigned long long key = act ? PackKey(tot, a) : RS_EMPTY;
+            bool mine = act;
+            if (uniform && __popcll(m) > 1) {
+              unsigned long long kmin = key;
+#pragma unroll
+              for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)(kmin & 0xFFFFFFFFull), o2, 64);
+                const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(kmin >> 32), o2, 64);
+                const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+                kmin = other < kmin ? other : kmin;
+              }
+              mine = act && key == kmin;          // keys are unique (arc ids): exactly one lane
+              key = kmin;
+            }
+            if (mine) {
+              const unsigned wa = (unsigned)(key & 0xFFFFFFFFull);
+              if (Relax(c, best, map_next, next_toks, next_cap, arc.w, KeyCost(key), wa) && h.num_ieps[arc.w] != 0) {
                 if (atomicExch(&in_queue[arc.w], 1) == 0) queue[qi ^ 1][atomicAdd(&c.q_n[qi ^ 1], 1)] = arc.w;
               }
             }
@@ -430,16 +494,29 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
     // ================================================================ materialise frame f+1
     {
       const int nn = c.n_next < next_cap ? c.n_next : next_cap;
-      for (int i = tid; i < nn; i += NT) {
-        const int s = next_toks[i].x;
-        const unsigned long long key = LoadKey(&best[s]);
-        const unsigned arc = (unsigned)(key & 0xFFFFFFFFull);
-        int bp = -1;
-        if (arc != RS_NOARC) {
-          const int src = h.arc_src[arc];
-          bp = (h.arcs[arc].x == 0) ? map_next[src] : map_cur[src];
+      for (int ib = tid; ib < nn; ib += 4 * NT) {          // four tokens per thread at a time: every load stage of the four in one go
+        int st[4], src[4], isx[4], bp[4];
+        unsigned long long key[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = ib + q * NT; on[q] = i < nn; st[q] = next_toks[on[q] ? i : nn - 1].x; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[st[q]]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
+          const unsigned ac = arc != RS_NOARC ? arc : 0u;
+          src[q] = h.arc_src[ac];
+          isx[q] = h.arcs[ac].x;
         }
-        next_toks[i] = make_int4(s, __float_as_int(KeyCost(key)), bp, (int)arc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
+          bp[q] = arc != RS_NOARC ? ((isx[q] == 0) ? map_next[src[q]] : map_cur[src[q]]) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (on[q]) next_toks[ib + q * NT] = make_int4(st[q], __float_as_int(KeyCost(key[q])), bp[q], (int)(unsigned)(key[q] & 0xFFFFFFFFull));
       }
       __syncthreads();
       // retire frame f: clear its map; clear best[] of the new frame; swap maps
