@@ -157,7 +157,7 @@ __device__ __forceinline__ bool Relax(BlockCtx<NT> &c, unsigned long long *best,
   if (old == RS_EMPTY) {
     int idx = atomicAdd(&c.n_next, 1);
     if (idx < next_cap) {
-      next_toks[idx].x = ns;
+      next_toks[idx] = make_int4(ns, 0, -1, -2);      // .w = -2: not made by an emitting winner, the materialise pass fills it in
       map_next[ns] = idx;
     } else {
       c.overflow = 1;
@@ -175,16 +175,20 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
   const int T = g.d_num_frames[u];
   const int S = h.num_states;
   unsigned long long *best = w.best + (size_t)u * S;
-  int *map_cur = w.map_a + (size_t)u * S, *map_next = w.map_b + (size_t)u * S;
+  // state -> index of its token in the frame under construction.  Never cleared: it is only read for states that own a token of
+  // that frame (the source of a winning epsilon arc), or -- candidate list overflowed -- of the frame just finished.
+  int *map_next = w.map_a + (size_t)u * S;
+  int *cand_t = w.map_b + (size_t)u * S;          // source token of each candidate of the arc loop
   int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
   int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
   float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
   int *queue[2] = {w.queue_a + (size_t)u * S, w.queue_b + (size_t)u * S};
-  int *in_queue = w.in_queue + (size_t)u * S;
+  int *stamp = w.in_queue + (size_t)u * S;         // closure round in which the state was last pushed (no per-round reset pass)
+  int round_id = 0;
   const float INF = INFINITY;
   const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
 
-  for (int i = tid; i < S; i += NT) { StoreKey(&best[i], RS_EMPTY); map_cur[i] = -1; map_next[i] = -1; in_queue[i] = 0; }
+  for (int i = tid; i < S; i += NT) { StoreKey(&best[i], RS_EMPTY); stamp[i] = 0; }
   if (tid == 0) {
     c.n_next = 0; c.overflow = 0; c.error = 0; c.q_n[0] = c.q_n[1] = 0;
     for (int i = 0; i < 8; i++) c.counters[i] = 0;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       const int cand_cap = S;
       // (arc record and log-likelihood are loaded by the caller, four arcs at a time: a thread's ~15 arcs per frame used to be 15
       // serialised chains of dependent L2 round trips -- token, arc range, arc, log-likelihood, atomic)
-      auto relax_arc = [&](unsigned a, const int4 arc, float lk, float cur_cost, bool is_best) __attribute__((always_inline)) {
+      auto relax_arc = [&](unsigned a, const int4 arc, float lk, float cur_cost, bool is_best, int src_tok) __attribute__((always_inline)) {
         const float graph_cost = __int_as_float(arc.z);
         const float ac_cost = cost_offset - lk;
         const float tot = (cur_cost + ac_cost) + graph_cost;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         if (ot < c.run_min) atomicMin(&c.run_min, ot);
         atomicMin(&best[arc.w], PackKey(tot, a));            // result unused: non-returning
         const int ci = atomicAdd(&c.n_cand, 1);
-        if (ci < cand_cap) { cand_s[ci] = arc.w; cand_a[ci] = (int)a; }      // (else: the list is full, step 2 scans the table instead)
+        if (ci < cand_cap) { cand_s[ci] = arc.w; cand_a[ci] = (int)a; cand_t[ci] = src_tok; }   // (else: list full, step 2 scans the table)
       };
       if (tid == 0) { c.run_min = OrderedBits(INF); c.n_cand = 0; }
       __syncthreads();
@@ -297,18 +301,18 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         int lsum = 0;
         for (int ib = i0; ib < i1; ib += 4) {
           int4 tk[4];
-          unsigned ab[4], ae[4], ne[4];
+          uint4 sr[4];
 #pragma unroll
           for (int q = 0; q < 4; q++) tk[q] = ctok[ib + q < i1 ? ib + q : i1 - 1];
 #pragma unroll
-          for (int q = 0; q < 4; q++) { ab[q] = h.arc_begin[tk[q].x]; ae[q] = h.arc_begin[tk[q].x + 1]; ne[q] = h.num_ieps[tk[q].x]; }
+          for (int q = 0; q < 4; q++) sr[q] = h.state_rec[tk[q].x];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             if (ib + q >= i1) break;
             int deg = 0;
-            if (__int_as_float(tk[q].y) <= cur_cutoff) { deg = (int)(ae[q] - ab[q] - ne[q]); cnt_expanded++; }
+            if (__int_as_float(tk[q].y) <= cur_cutoff) { deg = (int)sr[q].z; cnt_expanded++; }
             c.pre[ib + q] = deg;
-            c.tok_a0[ib + q] = ab[q] + ne[q];
+            c.tok_a0[ib + q] = sr[q].x + sr[q].y;
             c.tok_cost[ib + q] = __int_as_float(tk[q].y);
             lsum += deg;
           }
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
           unsigned a[4];
           float cc[4];
           bool bst[4], on[4];
+          int tki[4];
           int4 arc[4];
           float lk[4];
 #pragma unroll
@@ -343,14 +348,15 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.pre[mid] <= jj) lo = mid; else hi = mid; }
             a[q] = c.tok_a0[lo] + (unsigned)(jj - c.pre[lo]);
             cc[q] = c.tok_cost[lo];
-            bst[q] = c0 + lo == best_idx;
+            tki[q] = c0 + lo;
+            bst[q] = tki[q] == best_idx;
           }
 #pragma unroll
           for (int q = 0; q < 4; q++) arc[q] = h.arcs[a[q]];
 #pragma unroll
           for (int q = 0; q < 4; q++) lk[q] = ll_row[arc[q].x - 1];
 #pragma unroll
-          for (int q = 0; q < 4; q++) if (on[q]) relax_arc(a[q], arc[q], lk[q], cc[q], bst[q]);
+          for (int q = 0; q < 4; q++) if (on[q]) relax_arc(a[q], arc[q], lk[q], cc[q], bst[q], tki[q]);
         }
       }
       __syncthreads();
@@ -370,35 +376,57 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
         // step 2 of the relaxation, and the cutoff in the same pass: the winner of a state either appends it to the frame's token
         // list or -- at or above the final cutoff, where the reference never keeps a token alive past the next frame's beam
         // (see header) -- clears the table entry again
+        // The winner knows its source token (the candidate record), so the new token is written complete -- back pointer and
+        // arc -- right here: no second resolution pass through arc -> source state -> token map for emitting arcs.
         const bool listed = c.n_cand <= cand_cap;      // workgroup-uniform
-        const int nc2 = listed ? c.n_cand : S;
-        for (int ib = tid; ib < nc2; ib += 4 * NT) {
-          int s2[4], ca[4];
-          unsigned long long key[4];
-          bool on[4];
+        if (listed) {
+          const int nc2 = c.n_cand;
+          for (int ib = tid; ib < nc2; ib += 4 * NT) {
+            int s2[4], ca[4], ct[4];
+            unsigned long long key[4];
+            bool on[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int i = ib + q * NT;
-            on[q] = i < nc2;
-            const int ii = on[q] ? i : nc2 - 1;
-            s2[q] = listed ? cand_s[ii] : ii;
-            ca[q] = listed ? cand_a[ii] : 0;
-          }
+            for (int q = 0; q < 4; q++) {
+              const int i = ib + q * NT;
+              on[q] = i < nc2;
+              const int ii = on[q] ? i : nc2 - 1;
+              s2[q] = cand_s[ii];
+              ca[q] = cand_a[ii];
+              ct[q] = cand_t[ii];
+            }
 #pragma unroll
-          for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[s2[q]]);
+            for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[s2[q]]);
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            if (!on[q]) continue;
-            if (listed ? (unsigned)(key[q] & 0xFFFFFFFFull) == (unsigned)ca[q] : key[q] != RS_EMPTY) {
+            for (int q = 0; q < 4; q++) {
+              if (!on[q] || (unsigned)(key[q] & 0xFFFFFFFFull) != (unsigned)ca[q]) continue;
               if (KeyCost(key[q]) < next_cutoff) {
                 const int idx = atomicAdd(&c.n_next, 1);
-                if (idx < next_cap) { next_toks[idx].x = s2[q]; map_next[s2[q]] = idx; }
+                if (idx < next_cap) { next_toks[idx] = make_int4(s2[q], __float_as_int(KeyCost(key[q])), ct[q], ca[q]); map_next[s2[q]] = idx; }
                 else c.overflow = 1;
               } else {
                 StoreKey(&best[s2[q]], RS_EMPTY);
               }
             }
           }
+        } else {
+          // more candidates than the list holds: scan the table.  map_next still describes the frame just finished (its tokens
+          // were entered when they were made and nothing has been written since), so the back pointers are read from it first and
+          // the new frame's entries written after a barrier.
+          for (int s2 = tid; s2 < S; s2 += NT) {
+            const unsigned long long key = LoadKey(&best[s2]);
+            if (key == RS_EMPTY) continue;
+            if (KeyCost(key) < next_cutoff) {
+              const int idx = atomicAdd(&c.n_next, 1);
+              const unsigned arc = (unsigned)(key & 0xFFFFFFFFull);
+              if (idx < next_cap) next_toks[idx] = make_int4(s2, __float_as_int(KeyCost(key)), map_next[h.arc_src[arc]], (int)arc);
+              else c.overflow = 1;
+            } else {
+              StoreKey(&best[s2], RS_EMPTY);
+            }
+          }
+          __syncthreads();
+          const int nn2 = c.n_next < next_cap ? c.n_next : next_cap;
+          for (int i = tid; i < nn2; i += NT) map_next[next_toks[i].x] = i;
         }
       }
       closure_cutoff = next_cutoff;
@@ -419,21 +447,18 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
 #pragma unroll
         for (int q = 0; q < 4; q++) { const int i = ib + q * NT; on[q] = i < n0; st[q] = next_toks[on[q] ? i : n0 - 1].x; }
 #pragma unroll
-        for (int q = 0; q < 4; q++) ne[q] = h.num_ieps[st[q]];
+        for (int q = 0; q < 4; q++) ne[q] = h.state_rec[st[q]].y;
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          if (on[q] && ne[q] != 0) {
-            queue[0][atomicAdd(&c.q_n[0], 1)] = st[q];
-            atomicExch(&in_queue[st[q]], 1);
-          }
+          if (on[q] && ne[q] != 0) queue[0][atomicAdd(&c.q_n[0], 1)] = st[q];
       }
       __syncthreads();
       int guard_rounds = 0;
       while (c.q_n[qi] > 0) {
         const int qn = c.q_n[qi];
         __syncthreads();
-        for (int i = tid; i < qn; i += NT) atomicExch(&in_queue[queue[qi][i]], 0);
         if (tid == 0) c.q_n[qi ^ 1] = 0;
+        round_id++;                       // a state is pushed once per round: stamp[s] == round_id says "already on the next queue"
         __syncthreads();
         // One queue entry per thread and pass (uniform trip count: the wave votes below).  In an n-gram graph thousands of
         // history states back off into ONE unigram state: when every relaxing lane of a wave targets the same state the wave
@@ -445,7 +470,8 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
           const float cur_cost = have ? KeyCost(LoadKey(&best[s])) : INF;
           const bool live = have && cur_cost < closure_cutoff;
           if (live) cnt_expanded++;
-          const unsigned a0 = live ? h.arc_begin[s] : 0u, ne = live ? h.num_ieps[s] : 0u;
+          const uint4 sr = live ? h.state_rec[s] : make_uint4(0u, 0u, 0u, 0u);
+          const unsigned a0 = sr.x, ne = sr.y;
           unsigned ne_max = ne;
 #pragma unroll
           for (int o2 = 32; o2 > 0; o2 >>= 1) ne_max = max(ne_max, (unsigned)__shfl_xor((int)ne_max, o2, 64));
@@ -478,8 +504,8 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
             }
             if (mine) {
               const unsigned wa = (unsigned)(key & 0xFFFFFFFFull);
-              if (Relax(c, best, map_next, next_toks, next_cap, arc.w, KeyCost(key), wa) && h.num_ieps[arc.w] != 0) {
-                if (atomicExch(&in_queue[arc.w], 1) == 0) queue[qi ^ 1][atomicAdd(&c.q_n[qi ^ 1], 1)] = arc.w;
+              if (Relax(c, best, map_next, next_toks, next_cap, arc.w, KeyCost(key), wa) && h.state_rec[arc.w].y != 0) {
+                if (atomicExch(&stamp[arc.w], round_id) != round_id) queue[qi ^ 1][atomicAdd(&c.q_n[qi ^ 1], 1)] = arc.w;
               }
             }
           }
@@ -494,37 +520,37 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
     // ================================================================ materialise frame f+1
     {
       const int nn = c.n_next < next_cap ? c.n_next : next_cap;
+      // Final cost of every token of the new frame, the back pointer of those an epsilon arc made or improved (their .w is not the
+      // arc in the table: the source then owns a token of this same frame and map_next names it), and -- same visit -- the table entry
+      // cleared for the next frame.
       for (int ib = tid; ib < nn; ib += 4 * NT) {          // four tokens per thread at a time: every load stage of the four in one go
-        int st[4], src[4], isx[4], bp[4];
+        int4 tk[4];
+        int sx[4], bp[4];
         unsigned long long key[4];
-        bool on[4];
+        bool on[4], eps[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const int i = ib + q * NT; on[q] = i < nn; st[q] = next_toks[on[q] ? i : nn - 1].x; }
+        for (int q = 0; q < 4; q++) { const int i = ib + q * NT; on[q] = i < nn; tk[q] = next_toks[on[q] ? i : nn - 1]; }
 #pragma unroll
-        for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[st[q]]);
+        for (int q = 0; q < 4; q++) key[q] = LoadKey(&best[tk[q].x]);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
-          const unsigned ac = arc != RS_NOARC ? arc : 0u;
-          src[q] = h.arc_src[ac];
-          isx[q] = h.arcs[ac].x;
+          eps[q] = arc != RS_NOARC && (int)arc != tk[q].w;
+          sx[q] = eps[q] ? h.arc_srcx[arc] & 0x7fffffff : 0;
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
-          bp[q] = arc != RS_NOARC ? ((isx[q] == 0) ? map_next[src[q]] : map_cur[src[q]]) : -1;
+          bp[q] = eps[q] ? map_next[sx[q]] : (arc == RS_NOARC ? -1 : tk[q].z);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          if (on[q]) next_toks[ib + q * NT] = make_int4(st[q], __float_as_int(KeyCost(key[q])), bp[q], (int)(unsigned)(key[q] & 0xFFFFFFFFull));
+          if (on[q]) {
+            next_toks[ib + q * NT] = make_int4(tk[q].x, __float_as_int(KeyCost(key[q])), bp[q], (int)(unsigned)(key[q] & 0xFFFFFFFFull));
+            StoreKey(&best[tk[q].x], RS_EMPTY);
+          }
       }
       __syncthreads();
-      // retire frame f: clear its map; clear best[] of the new frame; swap maps
-      const int4 *cur = tokens + off_cur;
-      for (int i = tid; i < n_cur; i += NT) map_cur[cur[i].x] = -1;
-      for (int i = tid; i < nn; i += NT) StoreKey(&best[next_toks[i].x], RS_EMPTY);
-      __syncthreads();
-      int *tmp = map_cur; map_cur = map_next; map_next = tmp;
       off_cur = off_next;
       n_cur = nn;
       off_next = off_cur + n_cur;
@@ -540,8 +566,10 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
     }
   }
 #ifdef RS_DECODE_PROFILE
+  if (tid == 0 && T > 0)
+    printf("token-list block %d: %lld cycles, %d tokens, T=%d\n", u, prof[0] + prof[1] + prof[2] + prof[3] + prof[4] + prof[5] + prof[6], off_next, T);
   if (u == 0 && tid == 0 && T > 0)
-    printf("token-list decode cycles/frame: best %lld cutoff %lld expand %lld winners %lld filter %lld closure %lld materialise %lld (T=%d)\n",
+    printf("token-list decode cycles/frame: best %lld cutoff %lld expand %lld next-min %lld winners+cutoff %lld closure %lld materialise %lld (T=%d)\n",
            prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[5] / T, prof[6] / T, T);
 #endif
   // ================================================================ final costs + best-path traceback
@@ -606,7 +634,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       frame_off[T + 1] = off_next;
     }
     // leave both state->token maps empty (the lattice pass rebuilds them frame by frame)
-    for (int i = tid; i < n_cur; i += NT) map_cur[cur[i].x] = -1;
+    for (int i = tid; i < S; i += NT) { w.map_a[(size_t)u * S + i] = -1; w.map_b[(size_t)u * S + i] = -1; }
   }
 }
 

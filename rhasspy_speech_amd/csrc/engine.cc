@@ -466,6 +466,15 @@ void Model::ToDevice() {
     hclg_dev_.start = hclg_.start;
     hclg_dev_.arc_begin = Upload(hclg_.arc_begin);
     hclg_dev_.num_ieps = Upload(hclg_.num_ieps);
+    {
+      const int S = hclg_.num_states();
+      std::vector<uint4> rec(S);
+      for (int s = 0; s < S; s++) {
+        const uint32_t b = hclg_.arc_begin[s], e = hclg_.arc_begin[s + 1], ne = hclg_.num_ieps[s];
+        rec[s] = make_uint4(b, ne, e - b - ne, 0u);
+      }
+      hclg_dev_.state_rec = static_cast<uint4 *>(UploadBytes(rec.data(), (size_t)S * sizeof(uint4)));
+    }
     hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
     hclg_dev_.arc_src = Upload(src);
     {

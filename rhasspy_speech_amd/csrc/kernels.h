@@ -191,6 +191,7 @@ struct HclgDev {
   int num_states, num_arcs, start;
   const uint32_t *arc_begin;   // S + 1
   const uint32_t *num_ieps;    // S
+  const uint4 *state_rec;      // S : {first arc, epsilon arcs, emitting arcs, 0}: one load where the token-list search needs the ranges
   const int4 *arcs;            // {pdf+1 (0 = epsilon), olabel, weight bits, nextstate}
   const int *arc_src;          // source state of each arc
   const int *arc_srcx;         // source state | (1 << 31 if the arc is an epsilon arc): one load per traceback hop
@@ -209,7 +210,7 @@ struct DecodeWork {
   int *frame_tok_off;         // n_utts x (max_frames + 2): start offset of each frame's tokens
   float *frame_info;          // n_utts x (max_frames + 1) x 4 : {cost_offset, cur_cutoff, next_cutoff, adaptive_beam}
   int *queue_a, *queue_b;     // n_utts x S work lists for the epsilon closure
-  int *in_queue;              // n_utts x S
+  int *in_queue;              // n_utts x S : round stamp of the state's last push onto a closure queue (token-list search)
   // results
   int *out_words;             // n_utts x max_words
   int *out_nwords;            // n_utts
