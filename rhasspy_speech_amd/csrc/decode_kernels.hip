@@ -567,7 +567,9 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
   }
 #ifdef RS_DECODE_PROFILE
   if (tid == 0 && T > 0)
-    printf("token-list block %d: %lld cycles, %d tokens, T=%d\n", u, prof[0] + prof[1] + prof[2] + prof[3] + prof[4] + prof[5] + prof[6], off_next, T);
+    printf("token-list block %d: %lld cycles, %d tokens, T=%d phases %lld %lld %lld %lld %lld %lld %lld\n", u,
+           prof[0] + prof[1] + prof[2] + prof[3] + prof[4] + prof[5] + prof[6], off_next, T, prof[0], prof[1], prof[2], prof[3], prof[4], prof[5],
+           prof[6]);
   if (u == 0 && tid == 0 && T > 0)
     printf("token-list decode cycles/frame: best %lld cutoff %lld expand %lld next-min %lld winners+cutoff %lld closure %lld materialise %lld (T=%d)\n",
            prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[5] / T, prof[6] / T, T);
