@@ -177,6 +177,9 @@ int rs_fuzzy_open(const char *fuzzy_fst_path, rs_fuzzy **out);
  * (<= cap written to olabels, word ids of <lang_dir>/words.txt incl. `__output:` meta words, epsilons removed) and *cost =
  * the value the reference compares with max_fuzzy_cost; *n_out = -1 when the reference would return None. */
 int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
+/* The same match taken straight from a decode result (utterance `utt` of r): what transcribe_wav.py:87-93 /
+ * transcribe_stream.py:117-123 do with the pipeline's stdout, without rendering and re-parsing the n-best text. */
+int rs_result_fuzzy(const rs_result *r, int32_t utt, const rs_fuzzy *f, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
 void rs_fuzzy_free(rs_fuzzy *f);
 
 /* ---- rescoring against a NEW language directory (host side; the lattices come from decodes with rs_decode_opts.emit_lattice = 1).

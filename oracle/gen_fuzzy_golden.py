@@ -53,6 +53,30 @@ def meta(prefix: str, payload: str) -> str:
     return prefix + base64.b32encode(payload.encode()).decode()
 
 
+def compile_fuzzy(lang_dir: Path, vocab, text_fst):
+    """kaldi.py:358-389: copy the transitions, then self loops on every source state: eps:eps/0 and word:eps/1 for every
+    non-meta vocabulary word; compiled by the reference's fstcompile | fstarcsort."""
+    states, fuzzy = [], []
+    for ln in text_fst:
+        fuzzy.append(ln)
+        st = ln.split(maxsplit=1)[0]
+        if st not in states:
+            states.append(st)
+    for st in states:
+        fuzzy.append(f"{st} {st} <eps> <eps> 0.0")
+        for wd in vocab:
+            if wd[0] in ("<", "_"):
+                continue
+            fuzzy.append(f"{st} {st} {wd} <eps> 1.0")
+    txt = lang_dir / "G.fuzzy.fst.txt"
+    txt.write_text("\n".join(fuzzy) + "\n")
+    env = dict(os.environ, PATH=f"{BIN}:{os.environ['PATH']}")
+    cmd = (f"fstcompile --isymbols={lang_dir}/words.txt --osymbols={lang_dir}/words.txt --keep_isymbols=true --keep_osymbols=true "
+           f"{txt} | fstarcsort --sort_type=ilabel - {lang_dir}/G.fuzzy.fst")     # (the vendored fstcompile takes no "-" output)
+    subprocess.run(["bash", "-c", cmd], check=True, env=env)
+    txt.unlink()
+
+
 def build_lang(lang_dir: Path, seed: int, n_words: int, n_sents: int, with_eps_arcs: bool, weighted: bool):
     """A grammar acceptor/transducer in OpenFst text form: one path per sentence from a shared start state, word arcs
     (word:word), optional eps:meta output arcs, eps:eps arcs with a cost, sentence weights."""
@@ -89,27 +113,7 @@ def build_lang(lang_dir: Path, seed: int, n_words: int, n_sents: int, with_eps_a
                 cur = nxt
         finals.append(f"{cur}" + (f" {float(np.round(rng.uniform(0.0, 0.5), 2))}" if weighted and rng.random() < 0.5 else ""))
     text_fst = lines + finals
-    # ---- kaldi.py:358-389: copy the transitions, then self loops on every source state: eps:eps/0 and word:eps/1 for
-    # every non-meta vocabulary word
-    states, fuzzy = [], []
-    for ln in text_fst:
-        fuzzy.append(ln)
-        st = ln.split(maxsplit=1)[0]
-        if st not in states:
-            states.append(st)
-    for st in states:
-        fuzzy.append(f"{st} {st} <eps> <eps> 0.0")
-        for wd in vocab:
-            if wd[0] in ("<", "_"):
-                continue
-            fuzzy.append(f"{st} {st} {wd} <eps> 1.0")
-    txt = lang_dir / "G.fuzzy.fst.txt"
-    txt.write_text("\n".join(fuzzy) + "\n")
-    env = dict(os.environ, PATH=f"{BIN}:{os.environ['PATH']}")
-    cmd = (f"fstcompile --isymbols={lang_dir}/words.txt --osymbols={lang_dir}/words.txt --keep_isymbols=true --keep_osymbols=true "
-           f"{txt} | fstarcsort --sort_type=ilabel - {lang_dir}/G.fuzzy.fst")     # (the vendored fstcompile takes no "-" output)
-    subprocess.run(["bash", "-c", cmd], check=True, env=env)
-    txt.unlink()
+    compile_fuzzy(lang_dir, vocab, text_fst)
     return vocab, sents
 
 
@@ -136,22 +140,29 @@ def nbest_cases(rng, vocab, sents, n_cases):
     return out
 
 
+def reference_tools():
+    """KaldiTools over oracle/_ref.  The reference's Python targets OpenFst >= 1.8 (`fstproject --project_type=output`); the
+    OpenFst vendored under /root/reference/kaldi/openfst is older and spells the same switch `--project_output=true`.  An
+    argument adapter in front of the vendored binary bridges the two spellings -- the projection itself is the vendored
+    tool's.  utils/int2sym.pl is the reference's own script, run where it lies."""
+    import tempfile
+    root = Path(tempfile.mkdtemp())
+    shim = root / "bin"
+    shim.mkdir()
+    (shim / "fstproject").write_text(f"#!/bin/bash\nargs=()\nfor a in \"$@\"; do [ \"$a\" = --project_type=output ] && a=--project_output=true; args+=(\"$a\"); done\n"
+                                     f"exec {BIN}/fstproject \"${{args[@]}}\"\n")
+    (shim / "fstproject").chmod(0o755)
+    (root / "utils").symlink_to(REF / "kaldi" / "egs" / "wsj" / "s5" / "utils")
+    return KaldiTools(kaldi_dir=root, openfst_dir=REPO / "oracle" / "_ref", opengrm_dir=REPO / "oracle" / "_ref",
+                      phonetisaurus_bin=Path("/nonexistent"))
+
+
 def main():
     if OUT.exists():
         import shutil
         shutil.rmtree(OUT)
     OUT.mkdir(parents=True)
-    # The reference's Python targets OpenFst >= 1.8 (`fstproject --project_type=output`); the OpenFst vendored under
-    # /root/reference/kaldi/openfst is older and spells the same switch `--project_output=true`.  An argument adapter in
-    # front of the vendored binary bridges the two spellings -- the projection itself is the vendored tool's.
-    import tempfile
-    shim = Path(tempfile.mkdtemp()) / "bin"
-    shim.mkdir()
-    (shim / "fstproject").write_text(f"#!/bin/bash\nargs=()\nfor a in \"$@\"; do [ \"$a\" = --project_type=output ] && a=--project_output=true; args+=(\"$a\"); done\n"
-                                     f"exec {BIN}/fstproject \"${{args[@]}}\"\n")
-    (shim / "fstproject").chmod(0o755)
-    tools = KaldiTools(kaldi_dir=shim.parent, openfst_dir=REPO / "oracle" / "_ref", opengrm_dir=REPO / "oracle" / "_ref",
-                       phonetisaurus_bin=Path("/nonexistent"))
+    tools = reference_tools()
     all_cases = []
     specs = [("small", 1, 12, 6, False, False), ("eps", 2, 20, 15, True, False), ("weighted", 3, 25, 20, True, True), ("big", 4, 60, 70, True, True)]
     for lang, seed, n_words, n_sents, with_eps, weighted in specs:

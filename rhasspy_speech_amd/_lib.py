@@ -33,7 +33,7 @@ EXPORTS = [
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
-    "rs_fuzzy_open", "rs_fuzzy_match", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
+    "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
     "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
 ]
 
@@ -80,6 +80,7 @@ def load_library() -> C.CDLL:
     lib.rs_result_free.restype = None
     lib.rs_fuzzy_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.rs_fuzzy_match.argtypes = [vp, C.c_char_p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
+    lib.rs_result_fuzzy.argtypes = [vp, i32, vp, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     lib.rs_fuzzy_free.argtypes = [vp]
     lib.rs_fuzzy_free.restype = None
     lib.rs_rescorer_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
@@ -339,6 +340,19 @@ class FuzzyMatcher:
             buf = (C.c_int32 * cap)()
             n, cost = C.c_int32(), C.c_double()
             _check(lib().rs_fuzzy_match(self._h, bytes(nbest_text), buf, cap, C.byref(n), C.byref(cost)))
+            if n.value < 0:
+                return None
+            if n.value <= cap:
+                return list(buf[:n.value]), cost.value
+            cap = n.value
+
+    def match_result(self, result: "Result", utt: int = 0):
+        """The same, on the hypotheses of a decode result (rs_result_fuzzy: no text round trip)."""
+        cap = 256
+        while True:
+            buf = (C.c_int32 * cap)()
+            n, cost = C.c_int32(), C.c_double()
+            _check(lib().rs_result_fuzzy(result._h, utt, self._h, buf, cap, C.byref(n), C.byref(cost)))
             if n.value < 0:
                 return None
             if n.value <= cap:

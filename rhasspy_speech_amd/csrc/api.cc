@@ -378,6 +378,19 @@ int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, 
   });
 }
 
+int rs_result_fuzzy(const rs_result *r, int32_t utt, const rs_fuzzy *f, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost) {
+  const rs::UttResult *u = Utt(r, utt);
+  if (!u || !f || !n_out || !cost || (cap > 0 && !olabels)) return ArgError("rs_result_fuzzy: bad argument");
+  if (u->status != RS_OK) { g_last_error = u->error; return u->status; }
+  std::string s;                       // the hypotheses in rank order, as the fan of get_fuzzy_text reads them
+  for (size_t k = 0; k < u->hyps.size(); k++) {
+    s += "utt-" + std::to_string(k + 1) + " ";
+    for (int32_t w : u->hyps[k].words) s += std::to_string(w) + " ";
+    s += "\n";
+  }
+  return rs_fuzzy_match(f, s.c_str(), olabels, cap, n_out, cost);
+}
+
 void rs_fuzzy_free(rs_fuzzy *f) { delete f; }
 
 struct rs_rescorer {
