@@ -182,6 +182,29 @@ int rs_fuzzy_match(const rs_fuzzy *f, const char *nbest_text, int32_t *olabels, 
 int rs_result_fuzzy(const rs_result *r, int32_t utt, const rs_fuzzy *f, int32_t *olabels, int32_t cap, int32_t *n_out, double *cost);
 void rs_fuzzy_free(rs_fuzzy *f);
 
+/* ---- decoding-graph construction (host side).
+ * Replaces `bash utils/mkgraph.sh --self-loop-scale 1.0 <lang_dir> <model_dir>/model <graph_dir>` (rhasspy_speech/kaldi.py:409-425;
+ * kaldi/egs/wsj/s5/utils/mkgraph.sh:72-170), i.e. the process chain
+ *   fsttablecompose L_disambig.fst G.fst | fstdeterminizestar --use-log=true | fstminimizeencoded | fstpushspecial   (LG)
+ *   fstcomposecontext --context-size=N --central-position=P ... | fstarcsort --sort_type=ilabel                      (CLG, N / P from `tree`)
+ *   make-h-transducer --transition-scale=<transition_scale> ilabels tree final.mdl                                   (Ha)
+ *   fsttablecompose Ha CLG | fstdeterminizestar --use-log=true | fstrmsymbols | fstrmepslocal | fstminimizeencoded   (HCLGa)
+ *   add-self-loops --self-loop-scale=<self_loop_scale> --reorder=true final.mdl | fstconvert --fst_type=const        (HCLG.fst)
+ * Reads lang_dir/{L_disambig.fst,G.fst,words.txt,phones/disambig.int} and model_dir/{tree,final.mdl}; writes
+ * graph_dir/{HCLG.fst,words.txt,disambig_tid.int,phones/...}.  dump_dir (may be NULL): LG.fst, CLG.fst, ilabels, Ha.fst and
+ * HCLGa.fst are written there as well.  The result is the same weighted transducer as the reference chain's (equal weights for
+ * every input / output label sequence up to the 1/1024 quantisation both apply), with this library's own state numbering. */
+int rs_mkgraph(const char *lang_dir, const char *model_dir, const char *graph_dir, float transition_scale, float self_loop_scale,
+               const char *dump_dir);
+/* One step of that chain on files, named like the Kaldi / OpenFst executable it stands for: fsttablecompose (in1, in2 -> out),
+ * fstdeterminizestar (param != 0: --use-log=true), fstminimizeencoded, fstpushspecial, fstrmepslocal, fstrmsymbols (aux = symbol
+ * list), fstarcsort (aux = "ilabel" | "olabel"), fstcomposecontext (in2 = disambig list, aux = ilabels output, param = 16 * N + P),
+ * make-h-transducer (in1 = ilabels, in2 = tree, aux = final.mdl, param = transition scale; the disambiguation transition-ids go to
+ * out + ".disambig"), add-self-loops (aux = final.mdl, param = self-loop scale; --reorder=true), and two checks that fail with a
+ * description of the first difference: fstisomorphic (same transducer up to state numbering, weights within param) and
+ * fstequivalent (fstequivalent --random=true: equal tropical weight, within param, of the label pairs of random paths). */
+int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *out, const char *aux, float param);
+
 /* ---- rescoring against a NEW language directory (host side; the lattices come from decodes with rs_decode_opts.emit_lattice = 1).
  * Replaces the tool chain of `async_transcribe_rescore` (rhasspy_speech/transcribe_wav.py:107-232, transcribe_stream.py:131-274):
  *   [Ldet.fst from L_disambig.fst: fstprint | awk | fstcompile | fstdeterminizestar | fstrmsymbols]   lattice-scale --lm-scale=0.0 |

@@ -62,7 +62,7 @@ for t in online2bin/online2-wav-nnet3-latgen-faster online2bin/online2-cli-nnet3
          latbin/lattice-scale latbin/lattice-to-phone-lattice latbin/lattice-compose latbin/lattice-determinize \
          latbin/lattice-add-trans-probs latbin/lattice-best-path fstbin/fstdeterminizestar fstbin/fstrmsymbols \
          fstbin/fsttablecompose fstbin/fstminimizeencoded fstbin/fstpushspecial fstbin/fstcomposecontext fstbin/fstrmepslocal \
-         fstbin/fstaddselfloops fstbin/fstisstochastic bin/make-h-transducer bin/add-self-loops; do
+         fstbin/fstaddselfloops fstbin/fstisstochastic bin/make-h-transducer bin/add-self-loops bin/tree-info bin/am-info; do
   [ -f "$K/$t.cc" ] || { echo "missing $t"; continue; }
   [ -x "$OUT/bin/$(basename "$t")" ] && [ "$OUT/bin/$(basename "$t")" -nt "$OUT/libkaldi_ref.so" ] && continue      # already linked
   link_tool "$K/$t.cc" "$(basename "$t")" &
@@ -84,7 +84,7 @@ if [ "${RS_BUILD_FST_TOOLS:-1}" = "1" ] && [ -d "$F/script" ]; then
     src="{}"; obj="$OUT/obj_fst/$(basename "${src%.cc}").o"
     if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ]; then eval g++ $FSTFLAGS_STR -c "$src" -o "$obj"; fi'
   g++ -shared -o "$OUT/libfstscript_ref.so" "$OUT"/obj_fst/*.o
-  for t in fstcompile fstarcsort fstcompose fstshortestpath fstrmepsilon fsttopsort fstproject fstprint; do
+  for t in fstcompile fstarcsort fstcompose fstshortestpath fstrmepsilon fsttopsort fstproject fstprint fstconvert fstequivalent fstinfo; do
     if [ ! -f "$OUT/bin/$t" ] || [ "$F/bin/$t.cc" -nt "$OUT/bin/$t" ]; then
       g++ "${FSTFLAGS[@]}" "$F/bin/$t.cc" "$F/bin/$t-main.cc" -o "$OUT/bin/$t" -L"$OUT" -lfstscript_ref -lkaldi_ref -Wl,-rpath,'$ORIGIN/..' \
           -L"$LIBDIR" -l:"$(basename "$BLAS")" -Wl,-rpath,"$LIBDIR" -lpthread -ldl &

@@ -33,7 +33,7 @@ EXPORTS = [
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
-    "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
+    "rs_mkgraph", "rs_fst_tool", "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
     "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
 ]
 
@@ -78,6 +78,8 @@ def load_library() -> C.CDLL:
     lib.rs_result_pack.argtypes = [vp, i32, C.POINTER(i32)]
     lib.rs_result_free.argtypes = [vp]
     lib.rs_result_free.restype = None
+    lib.rs_mkgraph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_float, C.c_float, C.c_char_p]
+    lib.rs_fst_tool.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_float]
     lib.rs_fuzzy_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     lib.rs_fuzzy_match.argtypes = [vp, C.c_char_p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
     lib.rs_result_fuzzy.argtypes = [vp, i32, vp, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_double)]
@@ -324,6 +326,18 @@ def finish_streams(streams: Sequence[Stream], nbest: int = 1, lattice_acoustic_s
     out = C.c_void_p()
     _check(lib().rs_streams_finish(arr, len(streams), nbest, lattice_acoustic_scale, C.byref(out)))
     return Result(out)
+
+
+def mkgraph(lang_dir, model_dir, graph_dir, self_loop_scale: float = 0.1, transition_scale: float = 1.0, dump_dir=None) -> None:
+    """utils/mkgraph.sh [--self-loop-scale S] [--transition-scale T] <lang_dir> <model_dir> <graph_dir> (defaults as the script's)."""
+    _check(lib().rs_mkgraph(str(lang_dir).encode(), str(model_dir).encode(), str(graph_dir).encode(), transition_scale, self_loop_scale,
+                            None if dump_dir is None else str(dump_dir).encode()))
+
+
+def fst_tool(tool: str, in1=None, in2=None, out=None, aux=None, param: float = 0.0) -> None:
+    """One step of the graph-construction chain on files (rs_fst_tool)."""
+    enc = lambda p: None if p is None else str(p).encode()
+    _check(lib().rs_fst_tool(tool.encode(), enc(in1), enc(in2), enc(out), enc(aux), param))
 
 
 class FuzzyMatcher:

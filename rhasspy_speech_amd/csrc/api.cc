@@ -11,6 +11,7 @@
 
 #include "engine.h"
 #include "fuzzy.h"
+#include "graph_build.h"
 #include "rescore.h"
 
 namespace rs {
@@ -392,6 +393,89 @@ int rs_result_fuzzy(const rs_result *r, int32_t utt, const rs_fuzzy *f, int32_t 
 }
 
 void rs_fuzzy_free(rs_fuzzy *f) { delete f; }
+
+// ---- graph construction
+int rs_mkgraph(const char *lang_dir, const char *model_dir, const char *graph_dir, float transition_scale, float self_loop_scale,
+               const char *dump_dir) {
+  if (!lang_dir || !model_dir || !graph_dir) return ArgError("rs_mkgraph: null argument");
+  return Guard([&]() {
+    rs::gb::MkgraphOptions o;
+    o.transition_scale = transition_scale;
+    o.self_loop_scale = self_loop_scale;
+    if (dump_dir) o.dump_dir = dump_dir;
+    rs::gb::Mkgraph(lang_dir, model_dir, graph_dir, o);
+    return RS_OK;
+  });
+}
+
+int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *out, const char *aux, float param) {
+  if (!tool) return ArgError("rs_fst_tool: null argument");
+  return Guard([&]() {
+    namespace gb = rs::gb;
+    const std::string t = tool;
+    auto need = [&](const char *p, const char *what) { if (!p) rs::Fail("rs_fst_tool " + t + ": missing " + what); return std::string(p); };
+    if (t == "fsttablecompose") {
+      gb::WriteFst(gb::Compose(gb::ReadFst(need(in1, "in1")), gb::ReadFst(need(in2, "in2"))), need(out, "out"), false);
+    } else if (t == "fstdeterminizestar") {
+      gb::WriteFst(gb::DeterminizeStar(gb::ReadFst(need(in1, "in1")), param != 0.0f), need(out, "out"), false);
+    } else if (t == "fstminimizeencoded") {
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::MinimizeEncoded(&f);
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstpushspecial") {
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::PushSpecial(&f);
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstrmsymbols") {
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::RemoveInputSymbols(&f, gb::ReadIntList(need(aux, "symbol list")));
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstrmepslocal") {
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::RemoveEpsLocal(&f, true);
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstarcsort") {
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::ArcSort(&f, !(aux && std::string(aux) == "olabel"));
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstcomposecontext") {
+      // in2 = disambig list, aux = ilabels output, param = context width * 16 + central position
+      std::vector<std::vector<int32_t>> ilabels;
+      const int code = (int)param;
+      gb::Fst f = gb::ComposeContext(gb::ReadIntList(need(in2, "disambig list")), code / 16, code % 16, gb::ReadFst(need(in1, "in1")), &ilabels);
+      gb::WriteILabelInfo(ilabels, need(aux, "ilabels output"));
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "make-h-transducer") {
+      // in1 = ilabels, in2 = tree, aux = final.mdl, out = Ha.fst (+ out + ".disambig" = the disambiguation transition-ids), param = transition scale
+      gb::ContextDependency tree;
+      tree.Read(need(in2, "tree"));
+      rs::TransitionModel tm;
+      { rs::KaldiReader r(need(aux, "model")); tm.Read(r); }
+      std::vector<int32_t> dis;
+      gb::Fst h = gb::MakeHTransducer(gb::ReadILabelInfo(need(in1, "ilabels")), tree, tm, param, &dis);
+      gb::WriteFst(h, need(out, "out"), false);
+      std::string list;
+      for (int32_t d : dis) list += std::to_string(d) + "\n";
+      FILE *fp = std::fopen((std::string(out) + ".disambig").c_str(), "w");
+      if (!fp) rs::Fail("make-h-transducer: cannot write the disambiguation symbols");
+      std::fputs(list.c_str(), fp);
+      std::fclose(fp);
+    } else if (t == "add-self-loops") {
+      rs::TransitionModel tm;
+      { rs::KaldiReader r(need(aux, "model")); tm.Read(r); }
+      gb::Fst f = gb::ReadFst(need(in1, "in1"));
+      gb::AddSelfLoops(tm, param, &f);
+      gb::WriteFst(f, need(out, "out"), false);
+    } else if (t == "fstisomorphic" || t == "fstequivalent") {
+      const gb::Fst a = gb::ReadFst(need(in1, "in1")), b = gb::ReadFst(need(in2, "in2"));
+      const std::string d = t == "fstisomorphic" ? gb::Isomorphic(a, b, param) : gb::RandEquivalent(a, b, param, 200, 40, 1);
+      if (!d.empty()) rs::Fail(t + ": " + d);
+    } else {
+      rs::Fail("rs_fst_tool: unknown tool " + t);
+    }
+    return RS_OK;
+  });
+}
 
 struct rs_rescorer {
   rs::Rescorer r;

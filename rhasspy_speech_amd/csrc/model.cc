@@ -359,7 +359,6 @@ void TransitionModel::Read(KaldiReader &r) {
   r.ExpectToken("<TransitionModel>");
   r.ExpectToken("<Topology>");
   // per topology entry: per state: (forward_pdf_class, self_loop_pdf_class, transitions (dst, prob))
-  struct HmmState { int fwd = -1, self = -1; std::vector<std::pair<int, float>> trans; };
   std::vector<std::vector<HmmState>> entries;
   std::vector<int32_t> phones, phone2idx;
   if (r.binary()) {
@@ -430,15 +429,14 @@ void TransitionModel::Read(KaldiReader &r) {
   }
   std::string tok = r.ReadToken();
   if (tok != "<Triples>" && tok != "<Tuples>") Fail("TransitionModel: expected <Triples> or <Tuples>, got " + tok);
-  bool tuples = (tok == "<Tuples>");
+  const bool has_self = (tok == "<Tuples>");
   int n = r.ReadInt32();
-  struct Tuple { int phone, hmm_state, fwd, self; };
   std::vector<Tuple> tp(n);
   for (int i = 0; i < n; i++) {
     tp[i].phone = r.ReadInt32();
     tp[i].hmm_state = r.ReadInt32();
     tp[i].fwd = r.ReadInt32();
-    tp[i].self = tuples ? r.ReadInt32() : tp[i].fwd;
+    tp[i].self = has_self ? r.ReadInt32() : tp[i].fwd;
   }
   tok = r.ReadToken();
   if (tok != "</Triples>" && tok != "</Tuples>") Fail("TransitionModel: expected </Triples> or </Tuples>");
@@ -448,6 +446,11 @@ void TransitionModel::Read(KaldiReader &r) {
   id2hmm_state.assign(1, 0);
   id2self_loop.assign(1, 0);
   std::vector<int> self_loop_of(1, 0);      // per transition-id: the self-loop transition-id of its transition-state (0 = none)
+  topo_entries = entries;
+  phone2entry = phone2idx;
+  tuples = tp;
+  tstate_first_tid.assign(1, 0);
+  id2tstate.assign(1, 0);
   num_pdfs = 0;
   for (int ts = 0; ts < n; ts++) {
     const Tuple &t = tp[ts];
@@ -457,6 +460,7 @@ void TransitionModel::Read(KaldiReader &r) {
     const HmmState &hs = entry[t.hmm_state];
     num_pdfs = std::max(num_pdfs, 1 + std::max(t.fwd, t.self));
     const int first_tid = (int)id2pdf.size();
+    tstate_first_tid.push_back(first_tid);
     int sl_tid = 0;
     for (size_t k = 0; k < hs.trans.size(); k++) {
       bool self_loop = (hs.trans[k].first == t.hmm_state);
@@ -465,9 +469,11 @@ void TransitionModel::Read(KaldiReader &r) {
       id2phone.push_back(t.phone);
       id2hmm_state.push_back(t.hmm_state);
       id2self_loop.push_back(self_loop ? 1 : 0);
+      id2tstate.push_back(ts + 1);
     }
     for (size_t k = 0; k < hs.trans.size(); k++) self_loop_of.push_back(sl_tid);
   }
+  self_loop_of_id = self_loop_of;
   r.ExpectToken("<LogProbs>");
   std::vector<float> lp;
   r.ReadVector(&lp);
@@ -483,6 +489,29 @@ void TransitionModel::Read(KaldiReader &r) {
   }
   r.ExpectToken("</LogProbs>");
   r.ExpectToken("</TransitionModel>");
+}
+
+int TransitionModel::TupleToTransitionState(int phone, int hmm_state, int fwd, int self) const {
+  // transition-model.cc:179-196: binary search in the sorted tuple table
+  size_t lo = 0, hi = tuples.size();
+  auto less = [](const Tuple &a, int p, int h, int f, int s) {
+    if (a.phone != p) return a.phone < p;
+    if (a.hmm_state != h) return a.hmm_state < h;
+    if (a.fwd != f) return a.fwd < f;
+    return a.self < s;
+  };
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (less(tuples[mid], phone, hmm_state, fwd, self)) lo = mid + 1; else hi = mid; }
+  if (lo < tuples.size() && tuples[lo].phone == phone && tuples[lo].hmm_state == hmm_state && tuples[lo].fwd == fwd && tuples[lo].self == self)
+    return (int)lo + 1;
+  return 0;
+}
+
+int TransitionModel::NumPdfClasses(int phone) const {
+  // hmm-topology.cc:275-285: 1 + the largest pdf class of the phone's entry
+  if (phone <= 0 || phone >= (int)phone2entry.size() || phone2entry[phone] < 0) Fail("TransitionModel: phone " + std::to_string(phone) + " has no topology");
+  int mx = -1;
+  for (const HmmState &h : topo_entries[phone2entry[phone]]) mx = std::max(mx, std::max(h.fwd, h.self));
+  return mx + 1;
 }
 
 // =============================================================================== nnet3 parsing

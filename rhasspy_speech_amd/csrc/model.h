@@ -100,6 +100,18 @@ struct TransitionModel {
   std::vector<char> id2self_loop;      // IsSelfLoop
   std::vector<float> log_prob;         // GetTransitionLogProb
   std::vector<float> non_self_loop_log_prob;   // GetNonSelfLoopLogProb of the transition-id's transition-state
+  // for graph construction (hmm/hmm-utils.cc:30-150,470-560): the topology and the tuple table themselves
+  struct HmmState { int fwd = -1, self = -1; std::vector<std::pair<int, float>> trans; };   // pdf classes, (destination, prob)
+  struct Tuple { int phone, hmm_state, fwd, self; };
+  std::vector<std::vector<HmmState>> topo_entries;
+  std::vector<int32_t> phone2entry;            // index = phone, -1 = no topology
+  std::vector<Tuple> tuples;                   // transition-state k (1-based) = tuples[k - 1]
+  std::vector<int32_t> tstate_first_tid;       // per transition-state (1-based; [0] unused): its first transition-id
+  std::vector<int32_t> id2tstate;              // TransitionIdToTransitionState
+  std::vector<int32_t> self_loop_of_id;        // per transition-id: SelfLoopOf(its transition-state), 0 = none
+  int NumTransitionIds() const { return (int)id2pdf.size() - 1; }
+  int TupleToTransitionState(int phone, int hmm_state, int fwd, int self) const;     // 0 = not found
+  int NumPdfClasses(int phone) const;
   void Read(KaldiReader &r);
 };
 

@@ -172,10 +172,14 @@ class ModelSpec:
     xent_branch: bool = True         # extra output-xent branch (ignored by decoding), as chain recipes have
     input_scale: float = 0.04        # lda columns that see raw MFCCs (magnitude ~10-80) are scaled down, like a trained LDA whitens
     output_scale: float = 0.25       # keeps per-frame log-likelihood spread at a realistic few units
+    # phonetic context of the decision tree written beside final.mdl (graph construction):
+    # "mono" (N=1, P=0), "biphone" (N=2, P=1: every third phone has two pdf sets chosen by its left neighbour) or
+    # "triphone" (N=3, P=1: additionally every third phone is split on its right neighbour)
+    context: str = "mono"
 
     @property
     def num_pdfs(self) -> int:
-        return self.num_phones * (2 if self.chain_topology else 1)
+        return len(context_tuples(self)) * (2 if self.chain_topology else 1)
 
 
 TINY = dict(name="tiny", ivector_dim=10, num_gauss=16, lda_dim=12, num_phones=24, hidden_dim=32,
@@ -186,6 +190,57 @@ def tiny_spec(**kw) -> ModelSpec:
     d = dict(TINY)
     d.update(kw)
     return ModelSpec(**d)
+
+
+# --------------------------------------------------------------------------- phonetic context
+
+def context_shape(spec: "ModelSpec") -> Tuple[int, int]:
+    return {"mono": (1, 0), "biphone": (2, 1), "triphone": (3, 1)}[spec.context]
+
+
+def context_splits(spec: "ModelSpec", phone: int):
+    """None, or (tree key, sorted yes-set) of the one question asked about `phone`'s context window."""
+    n = spec.num_phones
+    if spec.context in ("biphone", "triphone") and phone % 3 == 0:
+        return 0, [0] + [q for q in range(1, n + 1) if q % 2 == 1]           # left neighbour (0 = start of utterance)
+    if spec.context == "triphone" and phone % 3 == 1:
+        return 2, [0] + [q for q in range(1, n + 1) if q % 2 == 0]           # right neighbour (0 = end of utterance)
+    return None
+
+
+def context_tuples(spec: "ModelSpec") -> List[Tuple[int, int, int, int]]:
+    """The transition model's (phone, hmm-state, forward pdf, self-loop pdf) table, sorted as transition-model.cc:62-100 sorts
+    it; a phone with a context question has two entries (yes branch first)."""
+    out, pdf = [], 0
+    per = 2 if spec.chain_topology else 1
+    for p in range(1, spec.num_phones + 1):
+        for _ in range(2 if context_splits(spec, p) else 1):
+            out.append((p, 0, pdf, pdf + per - 1))
+            pdf += per
+    return out
+
+
+def write_tree(path: Path, spec: "ModelSpec") -> None:
+    """<model>/tree: a ContextDependency in text form (tree/context-dep.cc:143-156, tree/event-map.cc:55-205): a table on the
+    central phone, under it a split on one neighbour where context_splits() asks one, under that the pdf per pdf-class."""
+    n_ctx, p_ctx = context_shape(spec)
+    tuples = iter(context_tuples(spec))
+
+    def leaf() -> str:
+        _, _, fwd, slf = next(tuples)
+        return f"TE -1 2 ( CE {fwd} CE {slf} ) " if spec.chain_topology else f"CE {fwd} "
+
+    body = f"TE {p_ctx} {spec.num_phones + 1} ( NULL "
+    for p in range(1, spec.num_phones + 1):
+        q = context_splits(spec, p)
+        if q is None:
+            body += leaf()
+        else:
+            key, yes = q
+            body += f"SE {key} [ " + " ".join(map(str, yes)) + " ]\n{ " + leaf() + leaf() + "} "
+    body += ") "
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    Path(path).write_text(f"ContextDependency {n_ctx} {p_ctx} ToPdf {body}\nEndContextDependency ")
 
 
 # --------------------------------------------------------------------------- final.mdl
@@ -227,39 +282,45 @@ def _write_topology(w: KaldiWriter, spec: ModelSpec) -> None:
 def _write_transition_model(w: KaldiWriter, spec: ModelSpec) -> None:
     w.token("<TransitionModel>").nl()
     _write_topology(w, spec)
-    n = spec.num_phones
+    tuples = context_tuples(spec)
+    n = len(tuples)
     if spec.chain_topology:
         w.token("<Tuples>").i32(n).nl()
-        for p in range(1, n + 1):
-            w.i32(p).i32(0).i32(2 * (p - 1)).i32(2 * (p - 1) + 1).nl()
+        for p, hs, fwd, slf in tuples:
+            w.i32(p).i32(hs).i32(fwd).i32(slf).nl()
         w.token("</Tuples>").nl()
     else:
         w.token("<Triples>").i32(n).nl()
-        for p in range(1, n + 1):
-            w.i32(p).i32(0).i32(p - 1).nl()
+        for p, hs, fwd, _slf in tuples:
+            w.i32(p).i32(hs).i32(fwd).nl()
         w.token("</Triples>").nl()
     w.token("<LogProbs>").nl()
     # index 0 unused; one entry per transition-id
-    w.vector(np.concatenate([[0.0], np.full(2 * n, math.log(0.5))]).astype(np.float32))
+    if spec.context == "mono":
+        probs = np.full(2 * n, 0.5)
+    else:        # (context-dependent test models: a different self-loop probability per transition-state)
+        sl = 0.35 + 0.05 * (np.arange(n) % 7)
+        probs = np.stack([sl, 1.0 - sl], axis=1).reshape(-1)
+    w.vector(np.concatenate([[0.0], np.log(probs)]).astype(np.float32))
     w.token("</LogProbs>").nl()
     w.token("</TransitionModel>").nl()
 
 
 def transition_ids(spec: ModelSpec, phone: int) -> Tuple[int, int]:
     """(self-loop tid, forward tid) of 1-based `phone` for the synthetic topology
-    (hmm/transition-model.cc:144-177: ids are assigned in tuple order, topology transition order)."""
+    (hmm/transition-model.cc:144-177: ids are assigned in tuple order, topology transition order).  Context-independent
+    models only: the directly assembled synthetic graphs know nothing of phonetic context."""
+    if spec.context != "mono":
+        raise ValueError("transition_ids: context-dependent model; build its graph with mkgraph")
     return 2 * (phone - 1) + 1, 2 * (phone - 1) + 2
 
 
 def tid_to_pdf(spec: ModelSpec) -> np.ndarray:
-    out = np.zeros(2 * spec.num_phones + 1, dtype=np.int32)
-    for p in range(1, spec.num_phones + 1):
-        sl, fw = transition_ids(spec, p)
-        if spec.chain_topology:
-            out[sl] = 2 * (p - 1) + 1
-            out[fw] = 2 * (p - 1)
-        else:
-            out[sl] = out[fw] = p - 1
+    tuples = context_tuples(spec)
+    out = np.zeros(2 * len(tuples) + 1, dtype=np.int32)
+    for k, (_p, _hs, fwd, slf) in enumerate(tuples):
+        out[2 * k + 1] = slf         # transition 0 of the topology's state is the self loop
+        out[2 * k + 2] = fwd
     return out
 
 
@@ -517,6 +578,7 @@ def write_model_dir(model_dir: Path, spec: ModelSpec) -> None:
     """Writes <model_dir>/model/{model,online} in the layout of SURVEY.md §3.4."""
     model_dir = Path(model_dir).absolute()
     write_final_mdl(model_dir / "model" / "model" / "final.mdl", spec)
+    write_tree(model_dir / "model" / "model" / "tree", spec)
     conf = model_dir / "model" / "online" / "conf"
     conf.mkdir(parents=True, exist_ok=True)
     mfcc = ["--use-energy=false", f"--num-mel-bins={spec.num_mel_bins}", f"--num-ceps={spec.num_ceps}",

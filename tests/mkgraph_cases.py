@@ -1,0 +1,47 @@
+"""Graph-construction test cases shared by oracle/gen_mkgraph_golden.py and the tests.
+
+A case = (synthetic acoustic model with a decision tree of some phonetic context, language-directory style, self-loop scale,
+utterances decoded on the finished graph).  The language directory and the reference's outputs for each step of
+utils/mkgraph.sh live in tests/golden/mkgraph/<case>/; the model directory (final.mdl, tree) is regenerated from the seed.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from rhasspy_speech_amd import synth
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "mkgraph"
+
+CASES = {
+    # monophone tree, grammar G (prefix tree of sentences), the self-loop scale rhasspy passes
+    "mono_grammar": dict(spec=dict(context="mono"), lang="same_vocab", self_loop_scale=1.0, utts=[0, 1]),
+    # left-biphone tree (the zamia chain models' shape), back-off bigram G with #0 arcs
+    "bi_backoff": dict(spec=dict(context="biphone"), lang="backoff", self_loop_scale=1.0, utts=[2, 3]),
+    # triphone tree (subsequential symbol, "#-1" pseudo epsilon), plain HMM topology, mkgraph.sh's default self-loop scale
+    "tri_grammar_hmm": dict(spec=dict(context="triphone", chain_topology=False, seed=3), lang="same_vocab", self_loop_scale=0.1, utts=[4]),
+    "tri_backoff": dict(spec=dict(context="triphone", seed=4), lang="backoff", self_loop_scale=1.0, utts=[5, 6]),
+}
+
+
+def case_spec(case: dict) -> synth.ModelSpec:
+    return synth.tiny_spec(**case["spec"])
+
+
+def case_lexicon(case: dict, spec: synth.ModelSpec) -> synth.Lexicon:
+    """The parity cases' lexicon, plus what makes disambiguation symbols necessary: a pair of homophones and a word whose
+    pronunciation is a prefix of another's."""
+    sents = [s.split() for s in synth.DEFAULT_SENTENCES]
+    lex = synth.make_lexicon(sents, spec, np.random.default_rng(11))
+    ids = {w: i for i, w in enumerate(lex.words)}
+    lex.prons[ids["night"]] = list(lex.prons[ids["light"]])
+    lex.prons[ids["time"]] = list(lex.prons[ids["timer"]][:2])
+    lex.prons[ids["timer"]] = lex.prons[ids["time"]] + [lex.prons[ids["timer"]][-1]]
+    return lex
+
+
+def build_model_dir(case: dict, root: Path) -> Path:
+    """-> <root>/model/model/model holding final.mdl and tree (plus the online conf beside it)."""
+    synth.write_model_dir(root / "model", case_spec(case))
+    return root / "model"
