@@ -51,14 +51,17 @@ def gen_case(name: str, case: dict) -> None:
     mdl_dir = model_dir / "model" / "model"
     lang = td / "lang"
     lex = mc.case_lexicon(case, spec)
-    rg.write_lang(lang, lex, spec, rg.LANGS[case["lang"]], np.random.default_rng(case.get("lang_seed", 7)))
+    rg.write_lang(lang, lex, spec, case.get("lang_conf") or rg.LANGS[case["lang"]], np.random.default_rng(case.get("lang_seed", 7)))
     # the files mkgraph.sh insists on seeing (it only tests that they exist)
     (lang / "phones.txt").write_text("<eps> 0\n" + "".join(f"p{i} {i}\n" for i in range(1, spec.num_phones + 1)))
     (lang / "phones" / "silence.csl").write_text(f"{lex.sil_phone}\n")
     graph = td / "graph"
+    import time
+    t0 = time.time()
     log = sh(f"bash {MKGRAPH} --self-loop-scale {case['self_loop_scale']} {lang} {mdl_dir} {graph} 2>&1", cwd=td)
+    ref_seconds = time.time() - t0
     n_ctx, p_ctx = synth.context_shape(spec)
-    ref = OUT / name / "ref"
+    ref = (td / "ref") if case.get("big") else (OUT / name / "ref")
     ref.mkdir(parents=True)
     shutil.copy(lang / "tmp" / "LG.fst", ref / "LG.fst")
     shutil.copy(lang / "tmp" / f"CLG_{n_ctx}_{p_ctx}.fst", ref / "CLG.fst")
@@ -95,10 +98,17 @@ def gen_case(name: str, case: dict) -> None:
         lm = [float(ln.split()[1]) for ln in (td / "lm.txt").read_text().splitlines() if ln.strip()]
         ac = [float(ln.split()[1]) for ln in (td / "ac.txt").read_text().splitlines() if ln.strip()]
         dec.append({"utt": u, "nbest_text": text, "graph_cost": lm, "acoustic_cost": ac})
-    (OUT / name / "decode.json").write_text(json.dumps({"case": case, "mkgraph_log_tail": log[-300:], "decodes": dec}, indent=1))
     from rhasspy_speech_amd import _lib
-    info = {k: (ref / k).stat().st_size for k in ["LG.fst", "CLG.fst", "Ha.fst", "HCLGa.fst", "HCLG.fst"]}
-    print(name, info, [d["nbest_text"].splitlines()[0] for d in dec])
+    t0 = time.time()
+    _lib.mkgraph(lang, mdl_dir, td / "graph_mine", self_loop_scale=case["self_loop_scale"])
+    my_seconds = time.time() - t0
+    sh(f"fstequivalent --random=true --delta=0.003 {td}/graph_mine/HCLG.fst {graph}/HCLG.fst")       # the reference's own equivalence test
+    sizes = {k: (ref / k).stat().st_size for k in ["LG.fst", "CLG.fst", "Ha.fst", "HCLGa.fst", "HCLG.fst"]}
+    (OUT / name / "decode.json").write_text(json.dumps({
+        "case": case, "mkgraph_log_tail": log[-300:], "decodes": dec, "reference_fst_bytes": sizes,
+        "timing_note": "wall seconds in the build container (8 cores): the reference's mkgraph.sh process chain vs rs_mkgraph, same inputs",
+        "reference_mkgraph_sh_seconds": round(ref_seconds, 2), "rs_mkgraph_seconds": round(my_seconds, 2)}, indent=1))
+    print(name, sizes, f"ref {ref_seconds:.2f}s mine {my_seconds:.2f}s", [d["nbest_text"].splitlines()[0] for d in dec])
     shutil.rmtree(td)
 
 

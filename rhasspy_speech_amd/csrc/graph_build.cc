@@ -162,8 +162,9 @@ struct TripleHash {
 };
 }  // namespace
 
-Fst Compose(const Fst &a, const Fst &b_in, bool connect) {
-  Fst b = b_in;
+Fst Compose(const Fst &a_in, const Fst &b_in, bool connect) {
+  Fst a = a_in, b = b_in;
+  ArcSort(&a, false);        // output epsilons of a state first, then by output label
   ArcSort(&b, true);
   Fst out;
   if (a.start < 0 || b.start < 0) return out;
@@ -192,26 +193,44 @@ Fst Compose(const Fst &a, const Fst &b_in, bool connect) {
   for (size_t n = 0; n < states.size(); n++) {
     const int s1 = states[n].first.first, s2 = states[n].first.second, fs = states[n].second;
     if (a.fin[s1] != kInf && b.fin[s2] != kInf) out.fin[n] = a.fin[s1] + b.fin[s2];
+    const auto &a1 = a.arcs[s1];
     const auto &b2 = b.arcs[s2];
     // the right side moves alone on an input epsilon (the left one stays): not from a state of `a` that can only leave by
     // output epsilons; afterwards the left side may not take an output epsilon of its own until a label has been matched
-    if (!alleps1[s1])
-      for (const Arc &y : b2) {
-        if (y.il != 0) break;
+    size_t b_first = 0;
+    for (; b_first < b2.size() && b2[b_first].il == 0; b_first++)
+      if (!alleps1[s1]) {
+        const Arc &y = b2[b_first];
         const int d = state_of(s1, y.next, noeps1[s1] ? 0 : 1);
         out.arcs[n].push_back({0, y.ol, y.w, d});
       }
-    for (const Arc &x : a.arcs[s1]) {
-      if (x.ol == 0) {
-        if (fs != 0) continue;         // the left side moves alone on an output epsilon
+    // the left side moves alone on an output epsilon
+    size_t a_first = 0;
+    for (; a_first < a1.size() && a1[a_first].ol == 0; a_first++)
+      if (fs == 0) {
+        const Arc &x = a1[a_first];
         const int d = state_of(x.next, s2, 0);
         out.arcs[n].push_back({x.il, 0, x.w, d});
-        continue;
       }
-      auto lo = std::lower_bound(b2.begin(), b2.end(), x.ol, [](const Arc &y, int l) { return y.il < l; });
-      for (; lo != b2.end() && lo->il == x.ol; ++lo) {
-        const int d = state_of(x.next, lo->next, 0);
-        out.arcs[n].push_back({x.il, lo->ol, x.w + lo->w, d});
+    // matching labels: walk the shorter arc list, binary-search the other (the table matcher's job in fsttablecompose: the
+    // loop state of H has an arc per phone-in-context)
+    if (a1.size() - a_first <= b2.size() - b_first) {
+      for (size_t i = a_first; i < a1.size(); i++) {
+        const Arc &x = a1[i];
+        auto lo = std::lower_bound(b2.begin() + b_first, b2.end(), x.ol, [](const Arc &y, int l) { return y.il < l; });
+        for (; lo != b2.end() && lo->il == x.ol; ++lo) {
+          const int d = state_of(x.next, lo->next, 0);
+          out.arcs[n].push_back({x.il, lo->ol, x.w + lo->w, d});
+        }
+      }
+    } else {
+      for (size_t j = b_first; j < b2.size(); j++) {
+        const Arc &y = b2[j];
+        auto lo = std::lower_bound(a1.begin() + a_first, a1.end(), y.il, [](const Arc &x, int l) { return x.ol < l; });
+        for (; lo != a1.end() && lo->ol == y.il; ++lo) {
+          const int d = state_of(lo->next, y.next, 0);
+          out.arcs[n].push_back({lo->il, y.ol, lo->w + y.w, d});
+        }
       }
     }
   }
@@ -743,7 +762,14 @@ Fst ComposeContext(const std::vector<int32_t> &disambig_in, int width, int centr
   // of the window whose central position just became known (context-fst.cc:27-260)
   std::vector<std::vector<int32_t>> &info = *ilabels;
   info.clear();
-  std::map<std::vector<int32_t>, int> label_of, cstate_of;
+  struct VecHash {
+    size_t operator()(const std::vector<int32_t> &v) const {
+      size_t h = 1469598103934665603ull;
+      for (int32_t x : v) h = (h ^ (size_t)(uint32_t)x) * 1099511628211ull;
+      return h;
+    }
+  };
+  std::unordered_map<std::vector<int32_t>, int, VecHash> label_of, cstate_of;
   std::vector<std::vector<int32_t>> cseq;
   auto find_label = [&](const std::vector<int32_t> &v) {
     auto it = label_of.find(v);
@@ -763,6 +789,9 @@ Fst ComposeContext(const std::vector<int32_t> &disambig_in, int width, int centr
   find_cstate(std::vector<int32_t>(width - 1, 0));                   // 0 = nothing seen yet
   int pseudo_eps = 0;
   if (width > central + 1 && !disambig.empty()) pseudo_eps = find_label({0});     // "#-1" (context-fst.cc:62-78)
+  std::vector<char> phone_flag(phones.empty() ? 1 : *phones.rbegin() + 1, 0);
+  for (int32_t p : phones) phone_flag[p] = 1;
+  auto is_phone = [&](int32_t l) { return l > 0 && l < (int32_t)phone_flag.size() && phone_flag[l]; };
   auto c_final = [&](int cs) {
     if (central < width - 1) return cseq[cs][central] == subseq;
     return true;
@@ -774,8 +803,8 @@ Fst ComposeContext(const std::vector<int32_t> &disambig_in, int width, int centr
       *next = cs;
       return true;
     }
-    const std::vector<int32_t> seq = cseq[cs];
-    if (phones.count(il)) {
+    const std::vector<int32_t> seq = cseq[cs];          // (copy: cseq grows below)
+    if (is_phone(il)) {
       if (!seq.empty() && seq.back() == subseq) return false;
     } else if (il == subseq) {
       if (central + 1 == width || seq[central] == subseq) return false;
@@ -794,7 +823,8 @@ Fst ComposeContext(const std::vector<int32_t> &disambig_in, int width, int centr
   // ---- composition, breadth first over (context state, lg state) (deterministic-fst-inl.h:408-505; not trimmed)
   Fst out;
   if (lg.start < 0) return out;
-  std::map<std::pair<int, int>, int> index;
+  struct PairHash2 { size_t operator()(const std::pair<int, int> &k) const { return ((size_t)(uint32_t)k.first << 32) ^ (size_t)(uint32_t)k.second; } };
+  std::unordered_map<std::pair<int, int>, int, PairHash2> index;
   std::deque<std::pair<int, int>> q;
   index[{0, lg.start}] = out.AddState();
   out.start = 0;

@@ -8,7 +8,10 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <map>
 #include <set>
@@ -297,6 +300,14 @@ void Mkgraph(const std::string &lang, const std::string &model_dir, const std::s
     tm.Read(r);
   }
   MakeDirs(dir);
+  const bool timing = std::getenv("RS_MKGRAPH_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what, const Fst &f) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "mkgraph: %-28s %8.1f ms  (%d states, %zu arcs)\n", what, std::chrono::duration<double, std::milli>(now - t_last).count(), f.NumStates(), f.NumArcs());
+    t_last = now;
+  };
   auto dump = [&](const Fst &f, const char *name) { if (!opts.dump_dir.empty()) { MakeDirs(opts.dump_dir); WriteFst(f, opts.dump_dir + "/" + name, false); } };
   // LG
   Fst lg;
@@ -304,19 +315,25 @@ void Mkgraph(const std::string &lang, const std::string &model_dir, const std::s
     Fst l = ReadFst(lang + "/L_disambig.fst"), g = ReadFst(lang + "/G.fst");
     lg = Compose(l, g);
   }
+  lap("L o G", lg);
   lg = DeterminizeStar(lg, true);
+  lap("determinizestar", lg);
   MinimizeEncoded(&lg);
+  lap("minimizeencoded", lg);
   PushSpecial(&lg);
+  lap("pushspecial", lg);
   dump(lg, "LG.fst");
   // CLG
   std::vector<std::vector<int32_t>> ilabels;
   Fst clg = ComposeContext(ReadIntList(lang + "/phones/disambig.int"), tree.width(), tree.central(), std::move(lg), &ilabels);
   ArcSort(&clg, true);
+  lap("composecontext", clg);
   dump(clg, "CLG.fst");
   if (!opts.dump_dir.empty()) WriteILabelInfo(ilabels, opts.dump_dir + "/ilabels");
   // Ha
   std::vector<int32_t> disambig_tid;
   Fst ha = MakeHTransducer(ilabels, tree, tm, opts.transition_scale, &disambig_tid);
+  lap("make-h-transducer", ha);
   dump(ha, "Ha.fst");
   {
     std::ofstream os(dir + "/disambig_tid.int");
@@ -327,15 +344,20 @@ void Mkgraph(const std::string &lang, const std::string &model_dir, const std::s
   Fst hclg = Compose(ha, clg);
   clg = Fst();
   ha = Fst();
+  lap("H o CLG", hclg);
   hclg = DeterminizeStar(hclg, true);
+  lap("determinizestar", hclg);
   RemoveInputSymbols(&hclg, disambig_tid);
   RemoveEpsLocal(&hclg, true);
+  lap("rmsymbols + rmepslocal", hclg);
   MinimizeEncoded(&hclg);
+  lap("minimizeencoded", hclg);
   dump(hclg, "HCLGa.fst");
   // HCLG
   AddSelfLoops(tm, opts.self_loop_scale, &hclg);
   ArcSort(&hclg, true);        // (the decoders want the input epsilons of a state first; fstconvert keeps whatever order it is given)
   WriteFst(hclg, dir + "/HCLG.fst", true);
+  lap("add-self-loops + write", hclg);
   CopyFile(lang + "/words.txt", dir + "/words.txt");
   MakeDirs(dir + "/phones");
   for (const char *opt : {"word_boundary.int", "word_boundary.txt", "align_lexicon.int", "align_lexicon.txt", "disambig.int", "disambig.txt", "silence.csl"})

@@ -22,18 +22,23 @@ CASES = {
     # triphone tree (subsequential symbol, "#-1" pseudo epsilon), plain HMM topology, mkgraph.sh's default self-loop scale
     "tri_grammar_hmm": dict(spec=dict(context="triphone", chain_topology=False, seed=3), lang="same_vocab", self_loop_scale=0.1, utts=[4]),
     "tri_backoff": dict(spec=dict(context="triphone", seed=4), lang="backoff", self_loop_scale=1.0, utts=[5, 6]),
+    # zamia-size model (1000 phones, left-biphone tree: 2668 pdfs), 660-word back-off bigram: only the language directory and
+    # the reference's decodes are kept (its HCLG.fst is several MB)
+    "zam_bi_arpa": dict(big=True, spec=dict(context="biphone"), lang="backoff", lang_conf=dict(keep_every=1, extra_sentences=1500, backoff=True),
+                        extra_words=600, self_loop_scale=1.0, utts=[0, 1, 7]),
 }
+SMALL = [n for n, c in CASES.items() if not c.get("big")]
 
 
 def case_spec(case: dict) -> synth.ModelSpec:
-    return synth.tiny_spec(**case["spec"])
+    return synth.ModelSpec(**case["spec"]) if case.get("big") else synth.tiny_spec(**case["spec"])
 
 
 def case_lexicon(case: dict, spec: synth.ModelSpec) -> synth.Lexicon:
     """The parity cases' lexicon, plus what makes disambiguation symbols necessary: a pair of homophones and a word whose
     pronunciation is a prefix of another's."""
     sents = [s.split() for s in synth.DEFAULT_SENTENCES]
-    lex = synth.make_lexicon(sents, spec, np.random.default_rng(11))
+    lex = synth.make_lexicon(sents, spec, np.random.default_rng(11), extra_words=case.get("extra_words", 0))
     ids = {w: i for i, w in enumerate(lex.words)}
     lex.prons[ids["night"]] = list(lex.prons[ids["light"]])
     lex.prons[ids["time"]] = list(lex.prons[ids["timer"]][:2])

@@ -31,6 +31,9 @@ def test_decoding_on_the_built_graph_equals_the_reference_on_its_graph(name, tmp
             mg, ma = res.costs(u, k)
             # weights of both graphs sit on a 1/1024 grid that each chain reaches by its own float path
             assert abs(mg - gc) < 0.02 and abs(ma - ac) < 2e-3 * max(1.0, abs(ac)), (name, d["utt"], k, mg, gc, ma, ac)
+    if case.get("big"):          # (the reference's multi-megabyte HCLG.fst of this case is not kept)
+        model.close()
+        return
     # the same decode on the reference's own HCLG.fst gives the same records (the two graphs are interchangeable)
     ref_graph = tmp_path / "ref_graph"
     ref_graph.mkdir()
