@@ -31,9 +31,16 @@ def strip_params(name: str) -> str:
 
 src, dst, ver = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
 dst.mkdir(parents=True, exist_ok=True)
-stats = glob.glob(str(src / "kt" / "**" / "*kernel_stats.csv"), recursive=True)
+def newest(pattern: str):
+    """gpurun_out/ is merged across calls, so a directory may hold the files of earlier collections too (one set per profiled
+    process id): the most recently written one is this collection's."""
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=lambda f: Path(f).stat().st_mtime) if files else None
+
+
+stats = newest(str(src / "kt" / "**" / "*kernel_stats.csv"))
 if stats:
-    shutil.copy(stats[0], dst / f"{ver}_kernel_stats.csv")
+    shutil.copy(stats, dst / f"{ver}_kernel_stats.csv")
 line = (src / "bench_line.json").read_text().strip().splitlines()[-1]
 json.loads(line)
 (dst / f"{ver}_line.json").write_text(line + "\n")
@@ -44,7 +51,10 @@ for extra in ("all_pdfs", "one_call_in_flight"):          # the same bench with 
         json.loads(extra_line)
         (dst / f"{ver}_line_{extra}.json").write_text(extra_line + "\n")
 kernels = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
+for d in sorted(glob.glob(str(src / "pmc_*"))):
+    f = newest(str(Path(d) / "**" / "*counter_collection.csv"))
+    if f is None:
+        continue
     for r in csv.DictReader(open(f)):
         name = strip_params(r["Kernel_Name"])
         c = kernels[name][r["Counter_Name"]]
