@@ -32,5 +32,8 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
 // nnet_gemm_b3i.hip (sources stored as operand images)
 bool GemmB3IUsable(const GemmDev &d);
 void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s);
+// nnet_gemm_b3j.hip: the same GEMM with both operands through LDS-DMA, hand-placed waits and a 256 x 256 tile (large launches)
+bool GemmB3JUsable(const GemmDev &d, int rows);
+void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s);
 
 }  // namespace rs

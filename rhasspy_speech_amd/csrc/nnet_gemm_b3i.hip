@@ -34,6 +34,13 @@ namespace {
 using namespace b3;
 
 constexpr int kKPS = 2;                               // k-steps per LDS stage
+// Timing ablations (profiles/micro/b3i_ablate.sh; results are WRONG with any bit set): 1 = the weight pointer never advances
+// (every k-step re-reads the same 24 KiB: no L2 weight stream), 2 = the activation DMA always fetches k-step 0 (no HBM
+// activation stream), 4 = no MFMAs, 8 = no DMA and no weight loads (matrix cores + LDS reads + barriers only), 16 = no
+// per-stage wait / barrier.
+#ifndef RS_B3I_ABLATE
+#define RS_B3I_ABLATE 0
+#endif
 
 template <int MR, bool MIXED>
 __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int nbig, int epi_mode) {
@@ -81,8 +88,9 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   auto stage_kstep = [&](unsigned char *dst) __attribute__((always_inline)) {     // dst: this k-step's 3 MR KiB in LDS
     if (stager) {
       const int phys = grow + __builtin_amdgcn_readlane(seg_rowoff_v, seg) + img_guard;
-      const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ks)) * kB3FragBytes +
+      const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ((RS_B3I_ABLATE & 2) ? 0 : ks))) * kB3FragBytes +
                                  kg_off + (phys & 31) * 16;
+      if (!(RS_B3I_ABLATE & 8))
 #pragma unroll
       for (int p = 0; p < 3; p++)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * part_bytes),
@@ -107,8 +115,11 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
-    wsrc += wstep;
+      for (int p = 0; p < 3; p++) {
+        if (RS_B3I_ABLATE & 8) { if (wsrc == nullptr) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes); }
+        else bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
+      }
+    if (!(RS_B3I_ABLATE & 1)) wsrc += wstep;
   };
   // one k-step of MFMAs from the fragments at `As` (this k-step's image in LDS)
   auto step = [&](const unsigned char *As, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
         const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
         nxt = *reinterpret_cast<const bf16x8 *>(Al + (pa2 * MR + i2) * kB3FragBytes);
       }
-      if (!MIXED || i < mr_eff) {
+      if ((RS_B3I_ABLATE & 4) ? (lane == 99 && cur[0] == 12345) : (!MIXED || i < mr_eff)) {
 #pragma unroll
         for (int pb = 2; pb >= 0; pb--) {
           if (pb > 2 - pa) continue;
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
       if (2 * (st + 1) + 1 < nt) stage_kstep(nx + KSTEP_BYTES);                                      \
     }                                                                                                \
     step(smem + (st & 1) * STAGE + kk * KSTEP_BYTES, BCUR);                                          \
-    if (kk == 1 || t + 1 == nt) {                /* stage done: next stage's DMA landed, everyone done reading this one */ \
+    if (!(RS_B3I_ABLATE & 16) && (kk == 1 || t + 1 == nt)) { /* stage done: next stage's DMA landed, everyone done reading this one */ \
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
       __builtin_amdgcn_s_barrier();                                                                  \
     }                                                                                                \

@@ -1,0 +1,372 @@
+// The image-fed TDNN layer GEMM (nnet_gemm_b3i.hip) with BOTH operands staged through LDS by DMA and every wait placed by
+// hand.  Same arithmetic, bit-identical results.
+//
+// Why: the timing ablations of GemmKernelB3I (profiles/micro/b3i_ablate.sh, profiles/r02/b3i_ablate.txt) show that its
+// data movement and its matrix-core work do not overlap at all -- 106 us with the loads removed, 65 us with the MFMAs removed,
+// 183 us together -- and the ISA shows why: the compiler's wait-count insertion puts `s_waitcnt vmcnt(0)` (a) in front of every
+// LDS-DMA issue that follows ordinary loads (draining the weight prefetch it was just given) and (b) in front of the first
+// ds_read after a DMA issue (draining the DMA of the NEXT stage before the MFMAs of this one start): whatever it cannot prove
+// independent of an in-flight LDS-DMA waits for everything.  Here the loop contains no memory instruction the compiler models:
+//   * weights travel like the activations: global_load_lds_dwordx4 into LDS (the weight image is already in fragment order);
+//     all in-flight memory operations are then DMAs of one kind, counted by vmcnt in issue order;
+//   * fragments are read with ds_read_b128 in inline asm and released with hand-written lgkmcnt waits that carry the registers
+//     they release as operands (the MFMAs that use them cannot be scheduled above the wait);
+//   * one `s_waitcnt vmcnt(N)` per k-step leaves the DMAs of the k-steps ahead in flight.
+// Tile: 256 x 256 per workgroup of eight waves (2 wave rows x 4 wave columns, each wave 128 x 64 as before): the two wave rows
+// share the weight fragments, which halves the L2 weight stream per row (-17 % of the old kernel's time in the ablation).
+// Ring of three k-step stages (16 of K each): 24 KiB activations + 24 KiB weights per stage, 144 KiB, one workgroup per CU,
+// two waves per SIMD.  DMA runs two k-steps ahead; one barrier per k-step.  Rows that do not fill whole rounds of 256-row tiles
+// run as 128-row tiles (each wave 64 x 64) of the same launch.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "nnet_b3_common.h"
+
+namespace rs {
+namespace {
+using namespace b3;
+
+constexpr int kJMR = 4, kJColTiles = 8;                                 // 32-row blocks per wave; 32-column tiles per tile
+constexpr int kJBBytes = kJColTiles * 3 * kB3FragBytes;                 // 24 KiB: [column tile][part] fragments
+// WM wave rows of four waves each: WM = 2 -> 256-row tile, 512 threads, three stages (144 KiB, one workgroup per CU);
+// WM = 1 -> 128-row tile, 256 threads, two stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop)
+template <int WM> struct JShape {
+  static constexpr int kThreads = 256 * WM, kWaves = 4 * WM, kRowBlocks = 4 * WM;
+  static constexpr int kABytes = kRowBlocks * 3 * kB3FragBytes;           // [part][row block] fragments
+  static constexpr int kStage = kABytes + kJBBytes;
+  static constexpr int kStages = WM == 2 ? 3 : 2, kAhead = kStages - 1;
+  static constexpr int kColTilesPerWave = kJColTiles / kWaves;             // weight column tiles a wave stages
+  static constexpr int kDmaPerKstep = 3 + 3 * kColTilesPerWave;            // per staging wave and k-step
+};
+
+// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 32 = no ds_reads
+#ifndef RS_B3J_ABLATE
+#define RS_B3J_ABLATE 0
+#endif
+#define RS_DS_READ(dst, addr, off) __asm__ volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// 64 lanes x 16 bytes from per-lane global addresses to LDS at lds_addr + 16 lane (M0 = wave-uniform LDS byte address).  In asm
+// because the compiler drains vmcnt in front of an LDS-DMA builtin that follows other LDS-DMAs still in flight.
+#define RS_DMA16(lds_addr, gptr) \
+  if (!(RS_B3J_ABLATE & 8)) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(gptr) : "memory")
+
+template <int WM, bool MIXED>
+__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int epi_mode) {
+  typedef JShape<WM> SH;
+  constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJStage = SH::kStage, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
+  constexpr int MR = kJMR, BM = 32 * kJRowBlocks, BN = kB3BN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ncol = (d.n + BN - 1) / BN;
+  const int big_blocks = (nbig + 7) / 8 * 8 * ncol;
+  const bool small = MIXED && (int)blockIdx.x >= big_blocks;
+  const int mr_eff = small ? MR / 2 : MR;                       // 32-row blocks per wave
+  const int bid = small ? blockIdx.x - big_blocks : blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
+  const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
+  if (small ? row0 >= rows : rt >= nbig) return;
+  f32x16 acc[MR][2];
+#pragma unroll
+  for (int i = 0; i < MR; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // ---- staging: wave w copies activation row block w (three parts) and weight column tile w (three parts) of every k-step
+  const int nrb = small ? kJRowBlocks / 2 : kJRowBlocks;
+  const bool stager = wave < nrb;
+  int grow = row0 + wave * 32 + (lane & 31);
+  if (grow >= rows) grow = 0;                          // clamped rows are dropped in the epilogue
+  if (d.row_map) grow = d.row_map[grow];
+  const int kg_off = (lane >> 5) * 512;
+  const int sl_ = lane < d.nsegs ? (lane < kMaxSegs ? lane : 0) : 0;
+  int seg_rowoff_v = lane < d.nsegs ? d.segs[sl_].row_off : 0;
+  int seg_ks0_v = lane < d.nsegs ? d.segs[sl_].col0 / kB3KS : 0;
+  int seg_nks_v = lane < d.nsegs ? (d.segs[sl_].ncols + kB3KS - 1) / kB3KS : 0;
+  const int nsegs = d.nsegs;
+  const bool inter = d.interleave != 0;
+  int nt = 0;
+  for (int sgi = 0; sgi < d.nsegs; sgi++) nt += (d.segs[sgi].ncols + kB3KS - 1) / kB3KS;
+  if (nt == 0) return;
+  int seg = 0, ks = 0;
+  // per-segment image descriptors in lanes too: the loop must not contain scalar memory loads (they share lgkmcnt with the
+  // hand-counted ds_reads and return out of order)
+  const unsigned long long seg_base_u = lane < d.nsegs ? (unsigned long long)(uintptr_t)d.segs[sl_].img.base : 0ull;
+  const unsigned long long seg_part_u = lane < d.nsegs ? (unsigned long long)d.segs[sl_].img.part_bytes : 0ull;
+  int seg_base_lo = (int)(unsigned)seg_base_u, seg_base_hi = (int)(unsigned)(seg_base_u >> 32);
+  int seg_part_lo = (int)(unsigned)seg_part_u, seg_part_hi = (int)(unsigned)(seg_part_u >> 32);
+  int seg_inks_v = lane < d.nsegs ? d.segs[sl_].img.nks : 0, seg_guard_v = lane < d.nsegs ? d.segs[sl_].img.guard : 0;
+  // Everything loaded above is consumed here once, unconditionally: otherwise the compiler's wait-count analysis carries "load
+  // pending" around the loop's back edge and drains vmcnt at the first use in EVERY iteration (seen in the ISA).
+  __asm__ volatile("" : "+v"(grow), "+v"(seg_rowoff_v), "+v"(seg_ks0_v), "+v"(seg_nks_v), "+v"(seg_base_lo), "+v"(seg_base_hi), "+v"(seg_part_lo),
+                   "+v"(seg_part_hi), "+v"(seg_inks_v), "+v"(seg_guard_v));
+  constexpr int CTW = SH::kColTilesPerWave;
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wave * CTW) * 3 * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
+  const bool wtile_ok = n0 / 32 + wave * CTW + CTW <= d.n3 / 32;     // (tiles past the padded width: their columns are dropped in the epilogue)
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  auto stage_kstep = [&](unsigned soff) __attribute__((always_inline)) {     // soff: byte offset of this k-step's stage in LDS
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + soff);
+    if (stager) {
+      const unsigned char *img_base = reinterpret_cast<const unsigned char *>(
+          (uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_base_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_base_lo, seg)));
+      const size_t part_bytes = (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_part_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_part_lo, seg));
+      const int img_nks = __builtin_amdgcn_readlane(seg_inks_v, seg), img_guard = __builtin_amdgcn_readlane(seg_guard_v, seg);
+      const int phys = grow + __builtin_amdgcn_readlane(seg_rowoff_v, seg) + img_guard;
+      const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ks)) * kB3FragBytes +
+                                 kg_off + (phys & 31) * 16;
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        const unsigned char *g = src + p * part_bytes;
+        RS_DMA16(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
+      }
+    }
+    {
+      const unsigned char *ws = wtile_ok ? wsrc : reinterpret_cast<const unsigned char *>(d.W3I) + lane * 16;
+#pragma unroll
+      for (int p = 0; p < 3 * CTW; p++) {
+        const unsigned char *g = ws + p * kB3FragBytes;
+        RS_DMA16(dst + (unsigned)(kJABytes + (wave * 3 * CTW + p) * kB3FragBytes), g);
+      }
+      wsrc += wstep;
+    }
+    if (inter) {
+      if (++seg == nsegs) { seg = 0; ks++; }
+    } else if (++ks >= __builtin_amdgcn_readlane(seg_nks_v, seg)) {
+      ks = 0;
+      if (seg + 1 < nsegs) seg++;
+    }
+  };
+  // ---- one k-step of MFMAs from stage `sbase` (LDS byte address of the stage)
+  const unsigned a_lane = lds0 + (unsigned)(wm * mr_eff) * kB3FragBytes + lane * 16;          // + stage; + (part * 8 + i) KiB
+  const unsigned b_lane = lds0 + kJABytes + (unsigned)(wn * 2) * 3 * kB3FragBytes + lane * 16;      // + stage; + (j * 3 + part) KiB
+  auto step = [&](unsigned soff) __attribute__((always_inline)) {
+    const unsigned aa = a_lane + soff, ba = b_lane + soff;
+    bf16x8 bf[2][3];
+    RS_DS_READ(bf[0][0], ba, 0 * 1024); RS_DS_READ(bf[0][1], ba, 1 * 1024); RS_DS_READ(bf[0][2], ba, 2 * 1024);
+    RS_DS_READ(bf[1][0], ba, 3 * 1024); RS_DS_READ(bf[1][1], ba, 4 * 1024); RS_DS_READ(bf[1][2], ba, 5 * 1024);
+    bf16x8 af[3][MR];
+    // activation fragments in the order they are used: smallest part first (pa = 2, 1, 0), row blocks inside
+#define RS_A_READ(PA, I) RS_DS_READ(af[PA][I], aa, ((PA) * kJRowBlocks + (I)) * 1024)
+    RS_A_READ(2, 0);
+    RS_A_READ(2, 1);
+    __asm__ volatile("s_waitcnt lgkmcnt(1)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(af[2][0]));
+#define RS_MFMAS(PA, I)                                                                                       \
+    if ((RS_B3J_ABLATE & 4) ? false : (!MIXED || (I) < mr_eff)) {                                             \
+      _Pragma("unroll") for (int pb = 2; pb >= 0; pb--) {                                                     \
+        if (pb > 2 - (PA)) continue;                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
+          acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][I], bf[j][pb], acc[I][j], 0, 0, 0);      \
+      }                                                                                                       \
+    }
+    // software pipeline over the 12 fragments: the read of fragment n + 2 is issued before the MFMAs of fragment n; the wait
+    // in front of fragment n + 1 leaves one read in flight
+#define RS_STEP(PA, I, PA1, I1, PA2, I2)                                                                      \
+    RS_A_READ(PA2, I2);                                                                                       \
+    RS_MFMAS(PA, I)                                                                                           \
+    __asm__ volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[PA1][I1]));
+    RS_STEP(2, 0, 2, 1, 2, 2)
+    RS_STEP(2, 1, 2, 2, 2, 3)
+    RS_STEP(2, 2, 2, 3, 1, 0)
+    RS_STEP(2, 3, 1, 0, 1, 1)
+    RS_STEP(1, 0, 1, 1, 1, 2)
+    RS_STEP(1, 1, 1, 2, 1, 3)
+    RS_STEP(1, 2, 1, 3, 0, 0)
+    RS_STEP(1, 3, 0, 0, 0, 1)
+    RS_STEP(0, 0, 0, 1, 0, 2)
+    RS_STEP(0, 1, 0, 2, 0, 3)
+    RS_MFMAS(0, 2)
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][3]));
+    RS_MFMAS(0, 3)
+#undef RS_STEP
+#undef RS_MFMAS
+#undef RS_A_READ
+  };
+  // ---- pipeline: DMA of k-step t + 2 is issued in k-step t (after the barrier that says everybody is done with k-step t - 1,
+  // whose stage it overwrites); before it, this wave waits for its own DMAs of k-step t, leaving those of k-step t + 1 in flight
+  // (with two stages the DMA runs one k-step ahead and the wait is for everything this wave has in flight)
+  stage_kstep(0u);
+  if (kJAhead > 1 && nt > 1) stage_kstep((unsigned)kJStage);
+  int t = 0;
+  constexpr int kOwn = SH::kDmaPerKstep, kOther = 3 * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
+#define RS_VMWAIT(N) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
+#define RS_WAIT_OWN()                                                                                          \
+  if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn * (kJAhead - 1)); else RS_VMWAIT(kOther * (kJAhead - 1)); } \
+  else RS_VMWAIT(0);
+#define RS_B3J_KSTEP(S, S2)                                                                                    \
+  {                                                                                                            \
+    RS_WAIT_OWN()                                                                                              \
+    if (!(RS_B3J_ABLATE & 16)) __builtin_amdgcn_s_barrier();                                                   \
+    if (t + kJAhead < nt) stage_kstep((unsigned)(S2) * kJStage);                                               \
+    step((unsigned)(S) * kJStage);                                                                             \
+    t++;                                                                                                       \
+  }
+  if (SH::kStages == 3) {
+#pragma nounroll
+    while (t + 3 <= nt) {
+      RS_B3J_KSTEP(0, 2)
+      RS_B3J_KSTEP(1, 0)
+      RS_B3J_KSTEP(2, 1)
+    }
+    if (t < nt) RS_B3J_KSTEP(0, 2)
+    if (t < nt) RS_B3J_KSTEP(1, 0)
+  } else {
+#pragma nounroll
+    while (t + 2 <= nt) {
+      RS_B3J_KSTEP(0, 1)
+      RS_B3J_KSTEP(1, 0)
+    }
+    if (t < nt) RS_B3J_KSTEP(0, 1)
+  }
+#undef RS_B3J_KSTEP
+#undef RS_WAIT_OWN
+#undef RS_VMWAIT
+  __builtin_amdgcn_s_barrier();                        // the stages become the epilogue's transpose buffer
+
+  // ---- epilogue (nnet_b3_epilogue.inc for two wave rows): 32-row slab sl of the tile belongs to wave row sl / mr_eff
+  {
+    constexpr int C_LD = BN + 8, NT = kJThreads;
+    float *Cs = reinterpret_cast<float *>(smem);
+    const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
+    float bias[2], sc[2], of[2];
+    int ccol[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      const bool cok = col < d.n;
+      ccol[j] = cok ? col : 0;
+      bias[j] = (d.bias && cok) ? d.bias[ccol[j]] : 0.f;
+      sc[j] = 1.f; of[j] = 0.f;
+      if (epi_mode == 2) { sc[j] = d.stages[1].scale[ccol[j]]; of[j] = d.stages[1].offset[ccol[j]]; }
+    }
+#define RS_PUT_SLAB(A)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                              \
+      const int cl = wn * 64 + j * 32 + (lane & 31);                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                           \
+        float v = __fadd_rn(bias[j], A[j][r]);                                                                   \
+        if (epi_mode == 1) {                                                                                     \
+          v = v > 0.f ? v : 0.f;                                                                                 \
+        } else if (epi_mode == 2) {                                                                              \
+          v = v > 0.f ? v : 0.f;                                                                                 \
+          v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);                                                             \
+        } else if (epi_mode == 3) {                                                                              \
+          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);                       \
+        }                                                                                                        \
+        Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;                                          \
+      }                                                                                                          \
+    }
+    // (the slab number is a macro argument: acc[] must never be indexed by a loop variable the compiler might not unroll -- that put
+    // the accumulators in scratch -- and a lambda capturing `d` makes the compiler copy the 1.2 KB argument block to scratch)
+#define RS_SLAB(SL)                                                                                            \
+    if (!(MIXED && small && (SL) >= WM * MR / 2)) {     /* workgroup-uniform: a half-height tile has half the slabs */ \
+      if (MIXED && small) { if (wm == (SL) / (MR / 2)) { RS_PUT_SLAB(acc[(SL) % (MR / 2)]) } } \
+      else if (wm == (SL) / MR) { RS_PUT_SLAB(acc[(SL) % MR]) } \
+      dd::LdsBarrier(); \
+      if (vec_out && d.write_f32) { \
+_Pragma("unroll") \
+        for (int q = 0; q < 2048 / NT; q++) { \
+          const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \
+          const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
+          if (row < rows && col < d.n) \
+            *reinterpret_cast<f32x4 *>(d.out + (size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col) = \
+                *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]); \
+        } \
+      } else if (d.write_f32) { \
+        for (int idx = tid; idx < 32 * BN; idx += NT) { \
+          const int rl = idx / BN, cl = idx % BN; \
+          const int row = row0 + (SL) * 32 + rl, col = n0 + cl; \
+          if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl]; \
+        } \
+      } \
+      if (d.out_img.base) { \
+_Pragma("unroll") \
+        for (int q = 0; q < 1024 / NT; q++) { \
+          const int unit = tid + NT * q, rl = unit & 31, kg = (unit >> 5) & 1, ksi = unit >> 6; \
+          const int row = row0 + (SL) * 32 + rl, col = n0 + ksi * 16 + kg * 8; \
+          if (row < rows && (col >> 4) < d.out_img.nks) { \
+            f32x4 lo = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + ksi * 16 + kg * 8]); \
+            f32x4 hi = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + ksi * 16 + kg * 8 + 4]); \
+_Pragma("unroll") \
+            for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
+            bf16x8 p1, p2, p3; \
+            Split3(lo, hi, &p1, &p2, &p3); \
+            const int phys = (d.row_map ? d.row_map[row] : row) + d.out_img.guard; \
+            unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
+            *reinterpret_cast<bf16x8 *>(dst) = p1; \
+            *reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes) = p2; \
+            *reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes) = p3; \
+          } \
+        } \
+      } \
+      dd::LdsBarrier(); \
+    }
+    RS_SLAB(0) RS_SLAB(1) RS_SLAB(2) RS_SLAB(3)
+    if constexpr (WM == 2) { RS_SLAB(4) RS_SLAB(5) RS_SLAB(6) RS_SLAB(7) }
+#undef RS_SLAB
+#undef RS_PUT_SLAB
+  }
+}
+
+template <int WM, bool MIXED>
+void LaunchB3J(const GemmDev &d, int rows, int nbig, hipStream_t s) {
+  typedef JShape<WM> SH;
+  constexpr int BM = 32 * SH::kRowBlocks;
+  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t smem = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
+  const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
+}
+
+int JWaveRows() {          // RS_GEMM_B3J_WM = 1 | 2 (read per call)
+  const char *e = std::getenv("RS_GEMM_B3J_WM");
+  return e && std::atoi(e) == 2 ? 2 : 1;
+}
+long JSlots(const GemmDev &d, int wm) {
+  static int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const char *es = std::getenv("RS_GEMM_B3J_SLOTS");          // tests: pretend the device runs this many workgroups at a time
+  if (es) return std::max(std::atol(es), 1L);
+  return std::max((long)(wm == 1 ? 2 : 1) * num_cu / std::max(d.share, 1), 8L);
+}
+
+}  // namespace
+
+// RS_GEMM_B3J=0 switches the kernel off, a value > 1 is the smallest launch (rows) it takes (read per call: tests flip it).
+bool GemmB3JUsable(const GemmDev &d, int rows) {
+  const char *e = std::getenv("RS_GEMM_B3J");
+  if (e && std::atoi(e) == 0) return false;
+  const int wm = JWaveRows();
+  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const long min_default = wm == 2 ? JSlots(d, wm) * 256 / ncol : 1024;      // the 256-row tile needs whole rounds to pay off
+  const int min_rows = e && std::atoi(e) > 1 ? std::atoi(e) : (int)std::min<long>(min_default, 1 << 30);
+  return rows >= min_rows;
+}
+
+void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
+  const int wm = JWaveRows();
+  const int ncol = (d.n + kB3BN - 1) / kB3BN, bm = 128 * wm;
+  const long slots = JSlots(d, wm);
+  // whole rounds of full-height tiles; the remaining rows as half-height tiles of the same launch
+  const long tiles = rows / bm;
+  const long full = tiles * ncol / slots * slots / ncol;
+  const bool all_big = full * bm >= rows;
+  const int nbig = all_big ? (rows + bm - 1) / bm : (int)full;
+  if (wm == 2) { if (all_big) LaunchB3J<2, false>(d, rows, nbig, s); else LaunchB3J<2, true>(d, rows, nbig, s); }
+  else { if (all_big) LaunchB3J<1, false>(d, rows, nbig, s); else LaunchB3J<1, true>(d, rows, nbig, s); }
+}
+
+}  // namespace rs

@@ -370,7 +370,11 @@ static void LaunchGemmT(const GemmDev &d, int rows, const int *row_ivec, hipStre
 
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
   if (rows <= 0) return;
-  if (GemmB3IUsable(d)) { LaunchGemmB3I(d, rows, s); return; }
+  if (GemmB3IUsable(d)) {
+    if (GemmB3JUsable(d, rows)) LaunchGemmB3J(d, rows, s);
+    else LaunchGemmB3I(d, rows, s);
+    return;
+  }
   if (GemmB3Usable(d)) { LaunchGemmB3(d, rows, row_ivec, s); return; }
   static int num_cu = [] {
     int dev = 0, n = 256;

@@ -284,6 +284,27 @@ def test_image_sourced_gemm_is_bitwise_the_split_gemm(zam_grammar, monkeypatch):
         assert img.words(u) == plain.words(u) and img.costs(u) == plain.costs(u)
 
 
+def test_all_dma_gemm_is_bitwise_the_image_gemm(zam_grammar, monkeypatch):
+    """GemmKernelB3J (nnet_gemm_b3j.hip: both operands through LDS-DMA, hand-placed waits; one or two wave rows per workgroup,
+    half-height tiles for the remainder) against GemmKernelB3I: same MFMAs, same order -> equal bit for bit.  The launch is made
+    to believe the device runs 48 workgroups at a time so that this ragged batch (about 21 k rows) has whole rounds of
+    full-height tiles AND a remainder of half-height ones."""
+    from rhasspy_speech_amd import _lib, synth
+    model = _lib.Model(*zam_grammar, _lib.default_opts(keep_intermediates=1))
+    pcms = [synth.synth_utterance(32000 + u, 48000 - 640 * (u % 7)) for u in range(70)] + [synth.synth_utterance(32999, 1700)]
+    monkeypatch.setenv("RS_GEMM_B3J", "0")
+    ref = model.decode_batch(pcms)
+    for wave_rows in ("1", "2"):                           # 128-row tiles, 2 workgroups per CU / 256-row tiles, 1 per CU
+        for slots in ("48", "100000"):                     # full-height + half-height tiles; half-height tiles only
+            monkeypatch.setenv("RS_GEMM_B3J", "2")        # any launch of at least 2 rows
+            monkeypatch.setenv("RS_GEMM_B3J_WM", wave_rows)
+            monkeypatch.setenv("RS_GEMM_B3J_SLOTS", slots)
+            got = model.decode_batch(pcms)
+            for u in range(len(pcms)):
+                np.testing.assert_array_equal(got.matrix(u, 2), ref.matrix(u, 2))
+                assert got.words(u) == ref.words(u) and got.costs(u) == ref.costs(u)
+
+
 def test_pruned_output_layer_on_a_batch(zam_grammar):
     """prune_output_pdfs on the headline model / graph (362 of the 2000 pdfs are on HCLG arcs): a ragged batch decodes to
     the same words and costs as with the full output layer."""
