@@ -12,11 +12,18 @@
 //   * fragments are read with ds_read_b128 in inline asm and released with hand-written lgkmcnt waits that carry the registers
 //     they release as operands (the MFMAs that use them cannot be scheduled above the wait);
 //   * one `s_waitcnt vmcnt(N)` per k-step leaves the DMAs of the k-steps ahead in flight.
-// Tile: 256 x 256 per workgroup of eight waves (2 wave rows x 4 wave columns, each wave 128 x 64 as before): the two wave rows
-// share the weight fragments, which halves the L2 weight stream per row (-17 % of the old kernel's time in the ablation).
-// Ring of three k-step stages (16 of K each): 24 KiB activations + 24 KiB weights per stage, 144 KiB, one workgroup per CU,
-// two waves per SIMD.  DMA runs two k-steps ahead; one barrier per k-step.  Rows that do not fill whole rounds of 256-row tiles
-// run as 128-row tiles (each wave 64 x 64) of the same launch.
+// Two shapes (template parameter WM = wave rows of four waves):
+//   WM = 1 (default): 128 x 256 tile, four waves, ring of two k-step stages (12 KiB activations + 24 KiB weights each, 72 KiB),
+//     two workgroups per CU -- one's epilogue and pipeline fill hide behind the other's loop; the DMA runs one k-step ahead.
+//   WM = 2 (RS_GEMM_B3J_WM=2): 256 x 256 tile, eight waves, the two wave rows share the weight fragments (half the L2 weight
+//     stream per row), ring of three stages (144 KiB), one workgroup per CU, DMA two k-steps ahead with counted vmcnt waits.
+//     Measured slower (232 vs 179 us per hidden layer): with one workgroup per CU nothing hides a tile's epilogue -- all CUs
+//     write their 129 MB of output at the same moment -- nor its pipeline fill (profiles/r02/b3j_wm2_ablate.txt).
+// Rows that do not fill whole rounds of full-height tiles run as half-height tiles of the same launch.
+// What the ablations of the default shape say is left (profiles/r02/b3j_wm1_ablate.txt): data movement alone 118 us, matrix
+// cores alone 122 us, together 179 us.  Two workgroups per CU move 72 KiB per k-step = 56 B/clk/CU of the 64 the L2 -> CU path
+// delivers, so the loads are throughput-bound for as long as the MFMAs run; only a tile that re-uses the weights across more
+// rows per CU (WM = 2 with its epilogue overlapped by a persistent loop over tiles) lowers that.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
