@@ -58,6 +58,13 @@ template <int WM> struct JShape {
 // because the compiler drains vmcnt in front of an LDS-DMA builtin that follows other LDS-DMAs still in flight.
 #define RS_DMA16(lds_addr, gptr) \
   if (!(RS_B3J_ABLATE & 8)) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(gptr) : "memory")
+// the same with a cache policy suffix for the activation stream (profiles/micro/b3j_policy.sh: "", " nt", " sc1", " sc0 sc1" are
+// within 1 % of each other -- the vector L1 does not turn the two workgroups' identical weight reads into one)
+#ifndef RS_B3J_A_POLICY
+#define RS_B3J_A_POLICY ""
+#endif
+#define RS_DMA16_STREAM(lds_addr, gptr) \
+  if (!(RS_B3J_ABLATE & 8)) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RS_B3J_A_POLICY : : "s"(lds_addr), "v"(gptr) : "memory")
 
 template <int WM, bool MIXED>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int epi_mode) {
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
 #pragma unroll
       for (int p = 0; p < 3; p++) {
         const unsigned char *g = src + p * part_bytes;
-        RS_DMA16(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
+        RS_DMA16_STREAM(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
       }
     }
     {
