@@ -49,7 +49,7 @@ template <int WM> struct JShape {
   static constexpr int kDmaPerKstep = 3 + 3 * kColTilesPerWave;            // per staging wave and k-step
 };
 
-// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 32 = no ds_reads
+// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores
 #ifndef RS_B3J_ABLATE
 #define RS_B3J_ABLATE 0
 #endif
@@ -67,7 +67,7 @@ template <int WM> struct JShape {
   if (!(RS_B3J_ABLATE & 8)) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RS_B3J_A_POLICY : : "s"(lds_addr), "v"(gptr) : "memory")
 
 template <int WM, bool MIXED>
-__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int epi_mode) {
+__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   typedef JShape<WM> SH;
   constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJStage = SH::kStage, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
   constexpr int MR = kJMR, BM = 32 * kJRowBlocks, BN = kB3BN;
@@ -75,10 +75,15 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int ncol = (d.n + BN - 1) / BN;
-  const int big_blocks = (nbig + 7) / 8 * 8 * ncol;
-  const bool small = MIXED && (int)blockIdx.x >= big_blocks;
+  // Block order: `nfirst` half-height tiles, then the full-height tiles, then the remaining half-height ones.  With all tiles of
+  // a round the same height every workgroup reaches its epilogue at the same moment and the launch pays for a burst of output
+  // stores HBM cannot absorb (40 us of a 178 us hidden layer, profiles/r02/b3j_wm1_ablate.txt); half-height tiles in the first
+  // round put the rounds of the two halves of the device out of phase, so most stores drain under somebody else's MFMAs.
+  const int big_blocks = (nbig + 7) / 8 * 8 * ncol, first_blocks = MIXED ? (nfirst + 7) / 8 * 8 * ncol : 0;
+  const bool small = MIXED && ((int)blockIdx.x < first_blocks || (int)blockIdx.x >= first_blocks + big_blocks);
   const int mr_eff = small ? MR / 2 : MR;                       // 32-row blocks per wave
-  const int bid = small ? blockIdx.x - big_blocks : blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int bid = small ? ((int)blockIdx.x < first_blocks ? blockIdx.x : blockIdx.x - big_blocks) : blockIdx.x - first_blocks;
+  const int xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
   const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
   if (small ? row0 >= rows : rt >= nbig) return;
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
 #undef RS_VMWAIT
   __builtin_amdgcn_s_barrier();                        // the stages become the epilogue's transpose buffer
 
+  if (RS_B3J_ABLATE & 64) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
   // ---- epilogue (nnet_b3_epilogue.inc for two wave rows): 32-row slab sl of the tile belongs to wave row sl / mr_eff
   {
     constexpr int C_LD = BN + 8, NT = kJThreads;
@@ -310,9 +316,11 @@ _Pragma("unroll") \
             Split3(lo, hi, &p1, &p2, &p3); \
             const int phys = (d.row_map ? d.row_map[row] : row) + d.out_img.guard; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
+            if ((RS_B3J_ABLATE & 128) && p1[0] != (__bf16)12345.f) dst = nullptr; \
+            if (dst) { \
             *reinterpret_cast<bf16x8 *>(dst) = p1; \
             *reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes) = p2; \
-            *reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes) = p3; \
+            *reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes) = p3; } \
           } \
         } \
       } \
@@ -326,7 +334,7 @@ _Pragma("unroll") \
 }
 
 template <int WM, bool MIXED>
-void LaunchB3J(const GemmDev &d, int rows, int nbig, hipStream_t s) {
+void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
   constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
@@ -338,8 +346,10 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, hipStream_t s) {
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
-  const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
+  // the half-height tiles are numbered through both of their block ranges: the first range holds a multiple of 8 of them
+  nfirst = MIXED ? std::min(nfirst / 8 * 8, nsmall) : 0;
+  const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, nfirst, GemmEpiMode(d, rows));
 }
 
 int JWaveRows() {          // RS_GEMM_B3J_WM = 1 | 2 (read per call)
@@ -379,8 +389,10 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   const long full = tiles * ncol / slots * slots / ncol;
   const bool all_big = full * bm >= rows;
   const int nbig = all_big ? (rows + bm - 1) / bm : (int)full;
-  if (wm == 2) { if (all_big) LaunchB3J<2, false>(d, rows, nbig, s); else LaunchB3J<2, true>(d, rows, nbig, s); }
-  else { if (all_big) LaunchB3J<1, false>(d, rows, nbig, s); else LaunchB3J<1, true>(d, rows, nbig, s); }
+  static const int stagger = [] { const char *e = std::getenv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
+  const int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
+  if (wm == 2) { if (all_big) LaunchB3J<2, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true>(d, rows, nbig, nfirst, s); }
+  else { if (all_big) LaunchB3J<1, false>(d, rows, nbig, 0, s); else LaunchB3J<1, true>(d, rows, nbig, nfirst, s); }
 }
 
 }  // namespace rs
