@@ -253,7 +253,7 @@ def test_fuzzy_control_flow_of_the_transcriber(tmp_path):
 
 
 @pytest.mark.parametrize("source,extra", [("feat_kernels.hip", ["-ffp-contract=off"]), ("nnet_kernels.hip", []),
-                                           ("nnet_gemm_b3.hip", []), ("nnet_gemm_b3i.hip", []), ("ivector_kernels.hip", []), ("decode_reg.hip", ["-ffp-contract=off"]),
+                                           ("nnet_gemm_b3.hip", []), ("nnet_gemm_b3i.hip", []), ("nnet_gemm_b3j.hip", []), ("ivector_kernels.hip", []), ("decode_reg.hip", ["-ffp-contract=off"]),
                                            ("decode_kernels.hip", ["-ffp-contract=off"]), ("decode_dense.hip", ["-ffp-contract=off"])])
 def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
     """Kernels that can share a CU with the MFMA GEMM of another decode call must not contain packed FP32 VALU math
