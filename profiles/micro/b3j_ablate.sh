@@ -7,7 +7,7 @@ cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so
 mkdir -p /tmp/rsab && cp -r rhasspy_speech_amd include /tmp/rsab/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-for v in 0 128; do
+for v in 0 256 128; do
   rm -f /tmp/rsab/rhasspy_speech_amd/csrc/nnet_gemm_b3j.o
   make -C /tmp/rsab/rhasspy_speech_amd/csrc EXTRA=-DRS_B3J_ABLATE=$v > $OUT/make_$v.log 2>&1
   cp /tmp/rsab/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/librhasspy_speech_hip.so

@@ -49,7 +49,7 @@ template <int WM> struct JShape {
   static constexpr int kDmaPerKstep = 3 + 3 * kColTilesPerWave;            // per staging wave and k-step
 };
 
-// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores
+// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
 #ifndef RS_B3J_ABLATE
 #define RS_B3J_ABLATE 0
 #endif
@@ -79,10 +79,30 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   // a round the same height every workgroup reaches its epilogue at the same moment and the launch pays for a burst of output
   // stores HBM cannot absorb (40 us of a 178 us hidden layer, profiles/r02/b3j_wm1_ablate.txt); half-height tiles in the first
   // round put the rounds of the two halves of the device out of phase, so most stores drain under somebody else's MFMAs.
+  // (nfirst < 0: the first 2 |nfirst| tiles alternate instead, eight half-height, eight full-height, ... -- which of the two orders
+  // puts the two workgroups of a CU out of phase depends on how the dispatcher places consecutive workgroups)
+  const bool alt = nfirst < 0;
+  if (alt) nfirst = -nfirst;
   const int big_blocks = (nbig + 7) / 8 * 8 * ncol, first_blocks = MIXED ? (nfirst + 7) / 8 * 8 * ncol : 0;
-  const bool small = MIXED && ((int)blockIdx.x < first_blocks || (int)blockIdx.x >= first_blocks + big_blocks);
+  bool small;
+  int bid;
+  if (!MIXED) { small = false; bid = blockIdx.x; }
+  else if (!alt) {
+    small = (int)blockIdx.x < first_blocks || (int)blockIdx.x >= first_blocks + big_blocks;
+    bid = small ? ((int)blockIdx.x < first_blocks ? blockIdx.x : blockIdx.x - big_blocks) : blockIdx.x - first_blocks;
+  } else {
+    const int b = blockIdx.x, gsz = 8 * ncol;
+    if (b < 2 * first_blocks) {
+      const int grp = b / gsz, within = b % gsz;
+      small = (grp & 1) == 0;
+      bid = (grp >> 1) * gsz + within;
+    } else {
+      const int b2 = b - 2 * first_blocks, big_left = big_blocks - first_blocks;
+      small = b2 >= big_left;
+      bid = first_blocks + (small ? b2 - big_left : b2);
+    }
+  }
   const int mr_eff = small ? MR / 2 : MR;                       // 32-row blocks per wave
-  const int bid = small ? ((int)blockIdx.x < first_blocks ? blockIdx.x : blockIdx.x - big_blocks) : blockIdx.x - first_blocks;
   const int xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
   const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
@@ -317,6 +337,7 @@ _Pragma("unroll") \
             const int phys = (d.row_map ? d.row_map[row] : row) + d.out_img.guard; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
             if ((RS_B3J_ABLATE & 128) && p1[0] != (__bf16)12345.f) dst = nullptr; \
+            if (RS_B3J_ABLATE & 256) dst = d.out_img.base + ((size_t)(dst - d.out_img.base) & 0xFFFFFu); \
             if (dst) { \
             *reinterpret_cast<bf16x8 *>(dst) = p1; \
             *reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes) = p2; \
@@ -347,9 +368,11 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
   // the half-height tiles are numbered through both of their block ranges: the first range holds a multiple of 8 of them
-  nfirst = MIXED ? std::min(nfirst / 8 * 8, nsmall) : 0;
+  const bool alt = nfirst < 0;
+  nfirst = MIXED ? std::min(std::abs(nfirst) / 8 * 8, nsmall / 8 * 8) : 0;
+  if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, nfirst, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 }
 
 int JWaveRows() {          // RS_GEMM_B3J_WM = 1 | 2 (read per call)
@@ -390,7 +413,8 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   const bool all_big = full * bm >= rows;
   const int nbig = all_big ? (rows + bm - 1) / bm : (int)full;
   static const int stagger = [] { const char *e = std::getenv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
-  const int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
+  int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
+  if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
   if (wm == 2) { if (all_big) LaunchB3J<2, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true>(d, rows, nbig, nfirst, s); }
   else { if (all_big) LaunchB3J<1, false>(d, rows, nbig, 0, s); else LaunchB3J<1, true>(d, rows, nbig, nfirst, s); }
 }
