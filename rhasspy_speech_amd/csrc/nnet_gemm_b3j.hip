@@ -299,6 +299,21 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;                                          \
       }                                                                                                          \
     }
+    // Destination rows of everything this thread will store, looked up BEFORE the first store: a row-map load between two
+    // stores makes the compiler wait for vmcnt(0) -- which on this ISA also counts the stores in flight -- so every store used
+    // to wait for the previous one to reach memory (seen in the ISA; profiles/r02/b3j_wm1_ablate.txt).
+    int img_phys[WM * MR];                    // image path: a thread's units of a slab all sit on row tid & 31
+    int f32_phys[WM * MR][2048 / NT];         // FP32 path: unit q of a slab sits on row (tid >> 6) + (NT / 64) q
+#pragma unroll
+    for (int sl = 0; sl < WM * MR; sl++) {
+      const int row = row0 + sl * 32 + (tid & 31);
+      img_phys[sl] = (d.out_img.base && row < rows) ? (d.row_map ? d.row_map[row] : row) + d.out_img.guard : 0;
+#pragma unroll
+      for (int q = 0; q < 2048 / NT; q++) {
+        const int r2 = row0 + sl * 32 + ((tid + NT * q) >> 6);
+        f32_phys[sl][q] = (d.write_f32 && r2 < rows) ? (d.row_map ? d.row_map[r2] : r2) : 0;
+      }
+    }
     // (the slab number is a macro argument: acc[] must never be indexed by a loop variable the compiler might not unroll -- that put
     // the accumulators in scratch -- and a lambda capturing `d` makes the compiler copy the 1.2 KB argument block to scratch)
 #define RS_SLAB(SL)                                                                                            \
@@ -312,7 +327,7 @@ _Pragma("unroll") \
           const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \
           const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
           if (row < rows && col < d.n) \
-            *reinterpret_cast<f32x4 *>(d.out + (size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col) = \
+            *reinterpret_cast<f32x4 *>(d.out + (size_t)f32_phys[(SL)][q] * d.ldo + col) = \
                 *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]); \
         } \
       } else if (d.write_f32) { \
@@ -334,7 +349,7 @@ _Pragma("unroll") \
             for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             bf16x8 p1, p2, p3; \
             Split3(lo, hi, &p1, &p2, &p3); \
-            const int phys = (d.row_map ? d.row_map[row] : row) + d.out_img.guard; \
+            const int phys = img_phys[(SL)]; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
             if ((RS_B3J_ABLATE & 128) && p1[0] != (__bf16)12345.f) dst = nullptr; \
             if (RS_B3J_ABLATE & 256) dst = d.out_img.base + ((size_t)(dst - d.out_img.base) & 0xFFFFFu); \
