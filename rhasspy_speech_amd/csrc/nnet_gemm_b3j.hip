@@ -66,6 +66,12 @@ template <int WM> struct JShape {
 #define RS_DMA16_STREAM(lds_addr, gptr) \
   if (!(RS_B3J_ABLATE & 8)) __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RS_B3J_A_POLICY : : "s"(lds_addr), "v"(gptr) : "memory")
 
+#ifdef RS_B3J_NT_STORE
+#define RS_IMG_STORE(ptr, v) __builtin_nontemporal_store(v, ptr)
+#else
+#define RS_IMG_STORE(ptr, v) *(ptr) = (v)
+#endif
+
 template <int WM, bool MIXED>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   typedef JShape<WM> SH;
@@ -354,9 +360,9 @@ _Pragma("unroll") \
             if ((RS_B3J_ABLATE & 128) && p1[0] != (__bf16)12345.f) dst = nullptr; \
             if (RS_B3J_ABLATE & 256) dst = d.out_img.base + ((size_t)(dst - d.out_img.base) & 0xFFFFFu); \
             if (dst) { \
-            *reinterpret_cast<bf16x8 *>(dst) = p1; \
-            *reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes) = p2; \
-            *reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes) = p3; } \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst), p1); \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes), p2); \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes), p3); } \
           } \
         } \
       } \
