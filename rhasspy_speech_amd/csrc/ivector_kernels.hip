@@ -752,32 +752,62 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaKernel(IvecDev iv, int n_utts
   f64x4 acc[4];
 #pragma unroll
   for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // eight k-steps of model-matrix values per request group, and the NEXT group (of this chunk or the first of the next one) is
+  // requested before the MFMAs of the current one: with at most one wave per SIMD nothing else hides the round trip (68 us for
+  // 64 utterances before, all of it a chain of 16 exposed L2 / HBM latencies)
+  auto fetch = [&](int g0, int n, int gi, double (&b)[8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int gk = gi + 4 * q + lk < n ? gi + 4 * q + lk : n - 1;             // (past the end: gml is zero there)
+      b[q] = iv.U[(size_t)(g0 + gk) * usz + kcol];
+    }
+  };
+  // (occupancy chunk of the next step: global -> registers during the MFMAs of this one, to LDS between two barriers afterwards)
+  constexpr int SPT = kMmU * GC / 256;
+  float stg[SPT];
+  auto stage_load = [&](int g0, int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SPT; t++) {
+      const int e = threadIdx.x + 256 * t, uu = e / GC, gi = e % GC;
+      stg[t] = (u0 + uu < n_utts && gi < n) ? gamma[(size_t)(u0 + uu) * G + g0 + gi] : 0.f;
+    }
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SPT; t++) { const int e = threadIdx.x + 256 * t; gml[e / GC][e % GC] = stg[t]; }
+  };
+  double bc[8], bn[8];
+  if (G > 0) {
+    const int n0 = G < GC ? G : GC;
+    stage_load(0, n0);
+    if (k0 < usz) fetch(0, n0, 0, bc);
+    if (threadIdx.x < kMmU) gml[threadIdx.x][GC] = 0.f;
+    stage_store();
+    __syncthreads();
+  }
   for (int g0 = 0; g0 < G; g0 += GC) {
     const int n = G - g0 < GC ? G - g0 : GC;
-    __syncthreads();
-    for (int e = threadIdx.x; e < kMmU * GC; e += 256) {
-      const int uu = e / GC, gi = e % GC;
-      gml[uu][gi] = (u0 + uu < n_utts && gi < n) ? gamma[(size_t)(u0 + uu) * G + g0 + gi] : 0.f;
-    }
-    if (threadIdx.x < kMmU) gml[threadIdx.x][GC] = 0.f;
-    __syncthreads();
+    const bool more = g0 + GC < G;
+    const int n_next = more ? (G - g0 - GC < GC ? G - g0 - GC : GC) : 0;
+    if (more) stage_load(g0 + GC, n_next);
     if (k0 < usz) {
-      // eight k-steps of model-matrix values requested before the first of their MFMAs (one wave per SIMD at most: nothing
-      // else hides the round trip)
       for (int gi = 0; gi < n; gi += 32) {
-        double b[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int gk = gi + 4 * q + lk < n ? gi + 4 * q + lk : n - 1;             // (past the end: gml is zero there)
-          b[q] = iv.U[(size_t)(g0 + gk) * usz + kcol];
-        }
+        if (gi + 32 < n) fetch(g0, n, gi + 32, bn);
+        else if (more) fetch(g0 + GC, n_next, 0, bn);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int gc = gi + 4 * q + lk < GC ? gi + 4 * q + lk : GC;
 #pragma unroll
-          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gc], b[q], acc[m], 0, 0, 0);
+          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gc], bc[q], acc[m], 0, 0, 0);
         }
+#pragma unroll
+        for (int q = 0; q < 8; q++) bc[q] = bn[q];
       }
+    }
+    if (more) {
+      __syncthreads();
+      stage_store();
+      __syncthreads();
     }
   }
   if (k0 + lr >= usz) return;
@@ -815,28 +845,60 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
     f64x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // (request groups of eight k-steps, the next group in flight during the MFMAs of the current one, as in IvecQuadMfmaKernel)
+    auto fetch = [&](long c0, int n, int j, double (&b)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int jk = j + 4 * q + lk < n ? j + 4 * q + lk : n - 1;
+        b[q] = iv.sigma_inv_M[(size_t)(c0 + jk) * I + icol];
+      }
+    };
+    // The statistics chunk of the NEXT step travels global -> registers while the MFMAs of this one run, and is written to LDS
+    // between two barriers afterwards: staged synchronously (load, barrier, use) the ten chunks of a workgroup were ten exposed
+    // memory round trips -- most of the kernel's 78 us.
+    constexpr int SPT = kMmU * KC / 256;                       // staged values per thread and chunk
+    double stg[SPT];
+    auto stage_load = [&](long c0, int n) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < SPT; t++) {
+        const int e = threadIdx.x + 256 * t, uu = e / KC, j = e % KC;
+        stg[t] = (u0 + uu < n_utts && j < n) ? wfeats[(size_t)(u0 + uu) * G * D + c0 + j] : 0.0;
+      }
+    };
+    auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < SPT; t++) { const int e = threadIdx.x + 256 * t; wfl[e / KC][e % KC] = stg[t]; }
+    };
+    double bc[8], bn[8];
+    if (kk_begin < kk_end) {
+      const int n0 = kk_end - kk_begin < KC ? (int)(kk_end - kk_begin) : KC;
+      stage_load(kk_begin, n0);
+      if (live) fetch(kk_begin, n0, 0, bc);
+      if (threadIdx.x < kMmU) wfl[threadIdx.x][KC] = 0.0;
+      stage_store();
+      __syncthreads();
+    }
     for (long c0 = kk_begin; c0 < kk_end; c0 += KC) {
       const int n = kk_end - c0 < KC ? (int)(kk_end - c0) : KC;
-      __syncthreads();
-      for (int e = threadIdx.x; e < kMmU * KC; e += 256) {
-        const int uu = e / KC, j = e % KC;
-        wfl[uu][j] = (u0 + uu < n_utts && j < n) ? wfeats[(size_t)(u0 + uu) * G * D + c0 + j] : 0.0;
-      }
-      if (threadIdx.x < kMmU) wfl[threadIdx.x][KC] = 0.0;
-      __syncthreads();
+      const bool more = c0 + KC < kk_end;
+      const int n_next = more ? (kk_end - c0 - KC < KC ? (int)(kk_end - c0 - KC) : KC) : 0;
+      if (more) stage_load(c0 + KC, n_next);
       for (int j = 0; live && j < n; j += 32) {
-        double b[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int jk = j + 4 * q + lk < n ? j + 4 * q + lk : n - 1;
-          b[q] = iv.sigma_inv_M[(size_t)(c0 + jk) * I + icol];
-        }
+        if (j + 32 < n) fetch(c0, n, j + 32, bn);
+        else if (more) fetch(c0 + KC, n_next, 0, bn);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int jc = j + 4 * q + lk < KC ? j + 4 * q + lk : KC;
 #pragma unroll
-          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][jc], b[q], acc[m], 0, 0, 0);
+          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][jc], bc[q], acc[m], 0, 0, 0);
         }
+#pragma unroll
+        for (int q = 0; q < 8; q++) bc[q] = bn[q];
+      }
+      if (more) {
+        __syncthreads();
+        stage_store();
+        __syncthreads();
       }
     }
     if (i0 + lr < I) {
