@@ -380,10 +380,13 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
   constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
-  constexpr size_t smem = ring > ctile ? ring : ctile;
+  constexpr size_t smem0 = ring > ctile ? ring : ctile;
+  // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
+  static const bool one_per_cu = [] { const char *e = std::getenv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
+  const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
