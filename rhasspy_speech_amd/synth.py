@@ -176,6 +176,7 @@ class ModelSpec:
     # "mono" (N=1, P=0), "biphone" (N=2, P=1: every third phone has two pdf sets chosen by its left neighbour) or
     # "triphone" (N=3, P=1: additionally every third phone is split on its right neighbour)
     context: str = "mono"
+    hmm_states: int = 1              # emitting states per phone (left-to-right; > 1 only with chain_topology = False, graphs by mkgraph)
 
     @property
     def num_pdfs(self) -> int:
@@ -208,36 +209,53 @@ def context_splits(spec: "ModelSpec", phone: int):
     return None
 
 
+def variant_pdfs(spec: "ModelSpec") -> Dict[int, List[List[int]]]:
+    """phone -> context variants (yes branch first) -> pdf per pdf-class.  Pdf-classes: (forward, self-loop) of the one state of
+    the chain topology, or one per emitting state of the HMM topology."""
+    if spec.chain_topology and spec.hmm_states != 1:
+        raise ValueError("hmm_states > 1 needs chain_topology = False")
+    classes = 2 if spec.chain_topology else spec.hmm_states
+    out, pdf = {}, 0
+    for p in range(1, spec.num_phones + 1):
+        out[p] = []
+        for _ in range(2 if context_splits(spec, p) else 1):
+            out[p].append(list(range(pdf, pdf + classes)))
+            pdf += classes
+    return out
+
+
 def context_tuples(spec: "ModelSpec") -> List[Tuple[int, int, int, int]]:
     """The transition model's (phone, hmm-state, forward pdf, self-loop pdf) table, sorted as transition-model.cc:62-100 sorts
-    it; a phone with a context question has two entries (yes branch first)."""
-    out, pdf = [], 0
-    per = 2 if spec.chain_topology else 1
-    for p in range(1, spec.num_phones + 1):
-        for _ in range(2 if context_splits(spec, p) else 1):
-            out.append((p, 0, pdf, pdf + per - 1))
-            pdf += per
-    return out
+    it; a phone with a context question contributes two entries per state."""
+    out = []
+    for p, variants in variant_pdfs(spec).items():
+        for pdfs in variants:
+            if spec.chain_topology:
+                out.append((p, 0, pdfs[0], pdfs[1]))
+            else:
+                out += [(p, hs, pdfs[hs], pdfs[hs]) for hs in range(spec.hmm_states)]
+    return sorted(out)
 
 
 def write_tree(path: Path, spec: "ModelSpec") -> None:
     """<model>/tree: a ContextDependency in text form (tree/context-dep.cc:143-156, tree/event-map.cc:55-205): a table on the
     central phone, under it a split on one neighbour where context_splits() asks one, under that the pdf per pdf-class."""
     n_ctx, p_ctx = context_shape(spec)
-    tuples = iter(context_tuples(spec))
+    vp = variant_pdfs(spec)
 
-    def leaf() -> str:
-        _, _, fwd, slf = next(tuples)
-        return f"TE -1 2 ( CE {fwd} CE {slf} ) " if spec.chain_topology else f"CE {fwd} "
+    def leaf(pdfs: List[int]) -> str:
+        if len(pdfs) == 1:
+            return f"CE {pdfs[0]} "
+        return f"TE -1 {len(pdfs)} ( " + "".join(f"CE {x} " for x in pdfs) + ") "
 
     body = f"TE {p_ctx} {spec.num_phones + 1} ( NULL "
     for p in range(1, spec.num_phones + 1):
         q = context_splits(spec, p)
         if q is None:
-            body += leaf()
+            body += leaf(vp[p][0])
         else:
             key, yes = q
-            body += f"SE {key} [ " + " ".join(map(str, yes)) + " ]\n{ " + leaf() + leaf() + "} "
+            body += f"SE {key} [ " + " ".join(map(str, yes)) + " ]\n{ " + leaf(vp[p][0]) + leaf(vp[p][1]) + "} "
     body += ") "
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     Path(path).write_text(f"ContextDependency {n_ctx} {p_ctx} ToPdf {body}\nEndContextDependency ")
@@ -256,15 +274,16 @@ def _write_topology(w: KaldiWriter, spec: ModelSpec) -> None:
         if spec.chain_topology:
             w.i32(-1)                    # marker: not a plain HMM (separate self-loop pdf class)
         w.i32(1)                         # one topology entry
-        w.i32(2)                         # two states
-        # state 0
-        w.i32(0)                         # forward pdf class
-        if spec.chain_topology:
-            w.i32(1)                     # self-loop pdf class
-        w.i32(2)
-        w.i32(0).f32(0.5)
-        w.i32(1).f32(0.5)
-        # state 1 (final, non-emitting)
+        ns = 1 if spec.chain_topology else spec.hmm_states
+        w.i32(ns + 1)                    # emitting states + the final one
+        for st in range(ns):
+            w.i32(st)                    # forward pdf class
+            if spec.chain_topology:
+                w.i32(1)                 # self-loop pdf class
+            w.i32(2)
+            w.i32(st).f32(0.5)
+            w.i32(st + 1).f32(0.5)
+        # final, non-emitting state
         w.i32(-1)
         if spec.chain_topology:
             w.i32(-1)
@@ -274,9 +293,11 @@ def _write_topology(w: KaldiWriter, spec: ModelSpec) -> None:
         w.raw(b"\n<TopologyEntry>\n<ForPhones>\n" + " ".join(map(str, phones)).encode() + b"\n</ForPhones>\n")
         if spec.chain_topology:
             w.raw(b"<State> 0 <ForwardPdfClass> 0 <SelfLoopPdfClass> 1 <Transition> 0 0.5 <Transition> 1 0.5 </State>\n")
+            w.raw(b"<State> 1 </State>\n</TopologyEntry>\n</Topology>\n")
         else:
-            w.raw(b"<State> 0 <PdfClass> 0 <Transition> 0 0.5 <Transition> 1 0.5 </State>\n")
-        w.raw(b"<State> 1 </State>\n</TopologyEntry>\n</Topology>\n")
+            for st in range(spec.hmm_states):
+                w.raw(f"<State> {st} <PdfClass> {st} <Transition> {st} 0.5 <Transition> {st + 1} 0.5 </State>\n".encode())
+            w.raw(f"<State> {spec.hmm_states} </State>\n</TopologyEntry>\n</Topology>\n".encode())
 
 
 def _write_transition_model(w: KaldiWriter, spec: ModelSpec) -> None:
@@ -296,7 +317,7 @@ def _write_transition_model(w: KaldiWriter, spec: ModelSpec) -> None:
         w.token("</Triples>").nl()
     w.token("<LogProbs>").nl()
     # index 0 unused; one entry per transition-id
-    if spec.context == "mono":
+    if spec.context == "mono" and spec.hmm_states == 1:
         probs = np.full(2 * n, 0.5)
     else:        # (context-dependent test models: a different self-loop probability per transition-state)
         sl = 0.35 + 0.05 * (np.arange(n) % 7)
@@ -310,8 +331,8 @@ def transition_ids(spec: ModelSpec, phone: int) -> Tuple[int, int]:
     """(self-loop tid, forward tid) of 1-based `phone` for the synthetic topology
     (hmm/transition-model.cc:144-177: ids are assigned in tuple order, topology transition order).  Context-independent
     models only: the directly assembled synthetic graphs know nothing of phonetic context."""
-    if spec.context != "mono":
-        raise ValueError("transition_ids: context-dependent model; build its graph with mkgraph")
+    if spec.context != "mono" or spec.hmm_states != 1:
+        raise ValueError("transition_ids: context-dependent or multi-state model; build its graph with mkgraph")
     return 2 * (phone - 1) + 1, 2 * (phone - 1) + 2
 
 

@@ -22,6 +22,9 @@ CASES = {
     # triphone tree (subsequential symbol, "#-1" pseudo epsilon), plain HMM topology, mkgraph.sh's default self-loop scale
     "tri_grammar_hmm": dict(spec=dict(context="triphone", chain_topology=False, seed=3), lang="same_vocab", self_loop_scale=0.1, utts=[4]),
     "tri_backoff": dict(spec=dict(context="triphone", seed=4), lang="backoff", self_loop_scale=1.0, utts=[5, 6]),
+    # Kaldi's classic shape: three emitting states per phone (three pdf-classes under every tree leaf, an HMM of four states per
+    # phone-in-context in H), triphone tree, the script's default scales
+    "tri_hmm3_backoff": dict(spec=dict(context="triphone", chain_topology=False, hmm_states=3, seed=6), lang="backoff", self_loop_scale=0.1, utts=[8, 9]),
     # zamia-size model (1000 phones, left-biphone tree: 2668 pdfs), 660-word back-off bigram: only the language directory and
     # the reference's decodes are kept (its HCLG.fst is several MB)
     "zam_bi_arpa": dict(big=True, spec=dict(context="biphone"), lang="backoff", lang_conf=dict(keep_every=1, extra_sentences=1500, backoff=True),
