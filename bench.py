@@ -415,7 +415,7 @@ def main() -> None:
             achieved = flops / (nnet_ms * 1e-3) / 1e12 if nnet_ms > 0 else 0.0
             traffic, traffic_from = pmc_traffic(wl, "GemmKernelB3" if split_bf16 else "GemmKernel")
             roof_mfma = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_from": traffic_from,
-                         "kernel": (f"GemmKernelB3 (FP32 operands split into 3 bf16 parts, 6 bf16 MFMAs per product, FP32 accumulate), "
+                         "kernel": (f"GemmKernelB3 family (B3 first layer, B3J image-fed layers: FP32 operands split into 3 bf16 parts, 6 bf16 MFMAs per product, FP32 accumulate), "
                                     f"{n_gemm} launches per step (the nnet stage)") if split_bf16 else f"GemmKernel, {n_gemm} launches per step",
                          "launches": n_gemm, "avg_launch_ms": nnet_ms / n_gemm, "flops_per_launch": flops / n_gemm,
                          "stage_ms": nnet_ms, "measured_on": roof_on, "frac_of_fp32_mfma_peak": achieved / 157.3}
