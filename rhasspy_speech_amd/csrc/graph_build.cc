@@ -339,6 +339,9 @@ class Determinizer {
       if (same) return it->second;
     }
     const int id = (int)subsets_.size();
+    // (fstdeterminizestar has --max-states for inputs that are not determinizable -- a lexicon without disambiguation symbols,
+    // say -- and otherwise runs until memory is gone; here the construction gives up with a message)
+    if (id > 100000000) Fail("Determinization aborted since passed 100000000 states (is the input determinizable?)");
     subsets_.push_back(sub);
     temp_.emplace_back();
     table_.emplace(h, id);
