@@ -196,16 +196,25 @@ def tiny_spec(**kw) -> ModelSpec:
 # --------------------------------------------------------------------------- phonetic context
 
 def context_shape(spec: "ModelSpec") -> Tuple[int, int]:
-    return {"mono": (1, 0), "biphone": (2, 1), "triphone": (3, 1)}[spec.context]
+    """(context width N, central position P).  Besides the three named shapes any "N,P" is accepted (graph-construction tests)."""
+    named = {"mono": (1, 0), "biphone": (2, 1), "triphone": (3, 1)}
+    if spec.context in named:
+        return named[spec.context]
+    n, p = (int(x) for x in spec.context.split(","))
+    if not (0 <= p < n):
+        raise ValueError(f"bad context {spec.context}")
+    return n, p
 
 
 def context_splits(spec: "ModelSpec", phone: int):
-    """None, or (tree key, sorted yes-set) of the one question asked about `phone`'s context window."""
+    """None, or (tree key, sorted yes-set) of the one question asked about `phone`'s context window: every third phone is asked
+    about its left neighbour (if the window has one), every third about its right neighbour (if it has one)."""
     n = spec.num_phones
-    if spec.context in ("biphone", "triphone") and phone % 3 == 0:
-        return 0, [0] + [q for q in range(1, n + 1) if q % 2 == 1]           # left neighbour (0 = start of utterance)
-    if spec.context == "triphone" and phone % 3 == 1:
-        return 2, [0] + [q for q in range(1, n + 1) if q % 2 == 0]           # right neighbour (0 = end of utterance)
+    width, central = context_shape(spec)
+    if central > 0 and phone % 3 == 0:
+        return central - 1, [0] + [q for q in range(1, n + 1) if q % 2 == 1]           # left neighbour (0 = start of utterance)
+    if central + 1 < width and phone % 3 == 1:
+        return central + 1, [0] + [q for q in range(1, n + 1) if q % 2 == 0]           # right neighbour (0 = end of utterance)
     return None
 
 
@@ -331,7 +340,7 @@ def transition_ids(spec: ModelSpec, phone: int) -> Tuple[int, int]:
     """(self-loop tid, forward tid) of 1-based `phone` for the synthetic topology
     (hmm/transition-model.cc:144-177: ids are assigned in tuple order, topology transition order).  Context-independent
     models only: the directly assembled synthetic graphs know nothing of phonetic context."""
-    if spec.context != "mono" or spec.hmm_states != 1:
+    if context_shape(spec) != (1, 0) or spec.hmm_states != 1:
         raise ValueError("transition_ids: context-dependent or multi-state model; build its graph with mkgraph")
     return 2 * (phone - 1) + 1, 2 * (phone - 1) + 2
 
