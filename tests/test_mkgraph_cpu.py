@@ -103,3 +103,23 @@ def test_trainer_mkgraph_mirror(tmp_path, models):
     shutil.copytree(mc.GOLDEN / name / "lang", tr.lang_dir("grammar"))
     asyncio.run(tr._mkgraph("grammar"))
     _lib.fst_tool("fstisomorphic", tr.graph_dir("grammar") / "HCLG.fst", mc.GOLDEN / name / "ref" / "HCLG.fst", param=1.5 / 1024)
+
+
+def test_mkgraph_sh_drop_in(tmp_path, models):
+    """rhasspy_speech_amd/bin/utils/mkgraph.sh: the script's name and argv over rs_mkgraph, run the way the reference's trainer runs
+    it (`bash <utils>/mkgraph.sh --self-loop-scale 1.0 <lang> <model> <graph>`, kaldi.py:415-424): same graph, the script's
+    "up to date" shortcut and its usage error."""
+    import subprocess
+    from pathlib import Path
+    sh = Path(_lib.__file__).resolve().parent / "bin" / "utils" / "mkgraph.sh"
+    name = "tri_backoff"
+    argv = ["bash", str(sh), "--self-loop-scale", "1.0", str(mc.GOLDEN / name / "lang"), str(models[name]), str(tmp_path / "graph")]
+    p = subprocess.run(argv, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    _lib.fst_tool("fstisomorphic", tmp_path / "graph" / "HCLG.fst", mc.GOLDEN / name / "ref" / "HCLG.fst", param=1.5 / 1024)
+    p = subprocess.run(argv, capture_output=True, text=True)
+    assert p.returncode == 0 and "is up to date" in p.stdout
+    p = subprocess.run(["bash", str(sh), "only-one-argument"], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stdout.startswith("Usage: utils/mkgraph.sh")
+    p = subprocess.run(["bash", str(sh), str(tmp_path / "nolang"), str(models[name]), str(tmp_path / "g2")], capture_output=True, text=True)
+    assert p.returncode == 1 and "expected" in p.stderr and "to exist" in p.stderr
