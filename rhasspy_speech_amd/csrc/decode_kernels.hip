@@ -44,7 +44,10 @@ __device__ __forceinline__ void StoreKey(unsigned long long *p, unsigned long lo
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr int kPrefixCap = 8192;
+#ifndef RS_PREFIX_CAP
+#define RS_PREFIX_CAP 8192
+#endif
+constexpr int kPrefixCap = RS_PREFIX_CAP;
 
 #ifdef RS_DECODE_PROFILE
 #define RS_TP(i) do { __syncthreads(); long long _n = clock64(); if (threadIdx.x == 0) prof[i] += _n - t_last; t_last = clock64(); } while (0)
