@@ -84,6 +84,11 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
   if (opts_.frame_subsampling_factor != 1)
     Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
   if (opts_.frames_per_chunk <= 0) Fail("frames-per-chunk must be positive");
+  // LatticeFasterDecoderConfig::Check (lattice-faster-decoder.h:86-91): the reference's decoders abort on these
+  if (!(opts_.beam > 0.0f && opts_.max_active > 1 && opts_.lattice_beam > 0.0f && opts_.min_active <= opts_.max_active))
+    Fail("KALDI_ASSERT: at Check:lattice-faster-decoder.h:87, failed: beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && min_active <= max_active"
+         " (beam " + std::to_string(opts_.beam) + ", max-active " + std::to_string(opts_.max_active) + ", min-active " + std::to_string(opts_.min_active) +
+         ", lattice-beam " + std::to_string(opts_.lattice_beam) + ")");
   ReadFeatureConfig(online_conf, &fc_);
   am_.Read(final_mdl);
   hclg_.Read(hclg);

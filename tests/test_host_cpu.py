@@ -277,3 +277,17 @@ def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
                     "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
     packed = re.findall(r"v_pk_(?:add|mul|fma)_f32", out.read_text())
     assert not packed, f"{source}: {len(packed)} packed FP32 instructions"
+
+
+def test_decoder_options_the_reference_asserts_on(tmp_path):
+    """LatticeFasterDecoderConfig::Check (lattice-faster-decoder.h:86-91): the reference's decoder binaries abort on
+    min-active > max-active, a non-positive beam / lattice beam, max-active <= 1; the library refuses the model load with the
+    assertion's text (the randomised decode cases contain such a draw: tests/golden/fuzz_decode.json case 25)."""
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.tiny_spec()
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    for bad in (dict(max_active=100, min_active=200), dict(beam=0.0), dict(lattice_beam=-1.0), dict(max_active=1, min_active=0)):
+        with pytest.raises(_lib.RsError, match="min_active <= max_active"):
+            _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(**bad))
+    _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(max_active=200, min_active=200)).close()

@@ -108,3 +108,21 @@ def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
         tr = orc.transcribe_stream(pcms[u]) if config == "c4_streams" else orc.transcribe(pcms[u])
         assert tr.nbest[0].words == ref_words[u], (config, u)
         np.testing.assert_allclose([tr.nbest[0].graph_cost, tr.nbest[0].acoustic_cost], [ref_g[u], ref_a[u]], rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("i", [0, 5, 11, 17, 23, 31, 37, 41])
+def test_oracle_matches_random_case_goldens(tmp_path, i):
+    """The CPU restatement on a sample of the randomised decode cases (tests/fuzz_cases.py; goldens of the reference's binaries in
+    tests/golden/fuzz_decode.json): 5-best lists and costs."""
+    import json
+    from oracle import pipeline
+    from tests import fuzz_cases
+    case = fuzz_cases.CASES[i]
+    gold = json.loads((cases.GOLDEN / "fuzz_decode.json").read_text())[i]["offline"]
+    assert gold["status"] == 0
+    model_dir, graph_dir, _wav, pcm = cases.build_case_files(case, tmp_path)
+    orc = pipeline.Oracle(model_dir, graph_dir, **case.get("opts", {}))
+    tr = orc.transcribe(pcm, nbest=cases.NBEST)
+    assert tr.text().split() == gold["nbest_text"].encode().split()
+    np.testing.assert_allclose([p.graph_cost for p in tr.nbest], gold["graph_cost"], rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose([p.acoustic_cost for p in tr.nbest], gold["acoustic_cost"], rtol=2e-4, atol=2e-3)
