@@ -61,7 +61,7 @@ def gen_case(name: str, case: dict) -> None:
     log = sh(f"bash {MKGRAPH} --self-loop-scale {case['self_loop_scale']} {lang} {mdl_dir} {graph} 2>&1", cwd=td)
     ref_seconds = time.time() - t0
     n_ctx, p_ctx = synth.context_shape(spec)
-    ref = (td / "ref") if case.get("big") else (OUT / name / "ref")
+    ref = (td / "ref") if (case.get("big") or case.get("light")) else (OUT / name / "ref")
     ref.mkdir(parents=True)
     shutil.copy(lang / "tmp" / "LG.fst", ref / "LG.fst")
     shutil.copy(lang / "tmp" / f"CLG_{n_ctx}_{p_ctx}.fst", ref / "CLG.fst")
@@ -79,6 +79,10 @@ def gen_case(name: str, case: dict) -> None:
     # (check: the re-made HCLGa gives the script's HCLG)
     sh(f"add-self-loops --self-loop-scale={case['self_loop_scale']} --reorder=true {mdl_dir}/final.mdl {ref}/HCLGa.fst | fstconvert --fst_type=const > {td}/HCLG2.fst")
     assert (td / "HCLG2.fst").read_bytes() == (ref / "HCLG.fst").read_bytes(), "re-made chain differs from mkgraph.sh's output"
+    if case.get("light"):          # light cases keep the finished graph only
+        (OUT / name / "ref").mkdir(parents=True)
+        for f in ["HCLG.fst", "disambig_tid.int"]:
+            shutil.copy(ref / f, OUT / name / "ref" / f)
     dst_lang = OUT / name / "lang"
     (dst_lang / "phones").mkdir(parents=True)
     for f in ["L_disambig.fst", "G.fst", "words.txt", "phones/disambig.int"]:

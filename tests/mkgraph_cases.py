@@ -30,7 +30,24 @@ CASES = {
     "zam_bi_arpa": dict(big=True, spec=dict(context="biphone"), lang="backoff", lang_conf=dict(keep_every=1, extra_sentences=1500, backoff=True),
                         extra_words=600, self_loop_scale=1.0, utts=[0, 1, 7]),
 }
-SMALL = [n for n, c in CASES.items() if not c.get("big")]
+
+
+def _random_case(i: int) -> dict:
+    """Seed-drawn tree / topology / lexicon / LM shapes ("light" cases: only the language directory, the reference's HCLG.fst and
+    its decodes are kept, not every intermediate transducer)."""
+    rng = np.random.default_rng(4200 + i)
+    chain = bool(rng.integers(0, 2))
+    spec = dict(context=["mono", "biphone", "triphone", "2,0", "3,2", "3,0", "4,1", "4,2"][int(rng.integers(0, 8))], chain_topology=chain,
+                hmm_states=1 if chain else int(rng.integers(1, 4)), num_phones=int(rng.integers(12, 32)), seed=int(rng.integers(1, 500)))
+    return dict(light=True, spec=spec, lang="backoff" if rng.random() < 0.5 else "same_vocab",
+                lang_conf=dict(keep_every=int(rng.integers(1, 4)), extra_sentences=int(rng.integers(0, 25)), backoff=bool(rng.integers(0, 2))),
+                lang_seed=int(rng.integers(1, 1000)), self_loop_scale=float([1.0, 0.1][int(rng.integers(0, 2))]),
+                utts=[int(x) for x in rng.integers(10, 10000, 2)])
+
+
+CASES.update({f"rnd{i:02d}": _random_case(i) for i in range(12)})
+SMALL = [n for n, c in CASES.items() if not c.get("big")]                      # whole chain on the CPU
+STEPWISE = [n for n, c in CASES.items() if not c.get("big") and not c.get("light")]      # every intermediate transducer committed
 
 
 def case_spec(case: dict) -> synth.ModelSpec:
