@@ -1291,15 +1291,17 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     double *linear = arena_.AllocT<double>((size_t)n_utts * Di), *quad = arena_.AllocT<double>((size_t)n_utts * usz);
     double *numf = arena_.AllocT<double>(n_utts), *x = arena_.AllocT<double>((size_t)n_utts * Di);
     d_ivec = arena_.AllocT<float>((size_t)n_ivrows * ld_i + 256);   // + slack: staging loads may read past a row's end
-    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
-    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
+    if (streaming) {          // (whole utterances: the accumulate kernel starts the sums itself)
+      RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)n_utts * G, s));
+      RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)n_utts * G * Dl, s));
+    }
     RS_HIP(hipMemsetAsync(d_ivec, 0, sizeof(float) * (size_t)n_ivrows * ld_i, s));
     LaunchIvecInit(ivec_dev_, n_utts, linear, quad, x, numf, s);
     double *iv_scratch = arena_.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, n_utts));
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     if (!streaming) {
       poison();
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, s);
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, nullptr, nullptr, gamma, wfeats, true, s);
       poison();
       LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
       LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, nullptr, nullptr, s);
@@ -1325,7 +1327,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       RS_HIP(hipStreamSynchronize(s));
       for (int k = 0; k < max_chunks; k++) {
         const size_t o = (size_t)k * n_utts;
-        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, s);
+        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, false, s);
         LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
         LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
         LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);

@@ -231,7 +231,7 @@ __device__ __forceinline__ unsigned RowMinU(unsigned v) {
   return v;
 }
 constexpr int kUbmRows = 16;          // rows per wave
-template <int NT, int KG>             // Gaussian tiles of 16; groups of four k-steps (16 feature dims)
+template <int NT, int KG, int KU = 4 * KG>   // Gaussian tiles of 16; groups of four k-steps (16 feature dims); k-steps that carry feature dims
 __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
                                                          const float *__restrict__ bm, const float *__restrict__ bv,
                                                          int *__restrict__ post_idx, float *__restrict__ post_w, int ablate) {
@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
         const f32x4v m = pm[j % PF][kg], v = pv[j % PF][kg];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
+          if (4 * kg + i >= KU) continue;          // all-padding k-steps (D = 40: two of twelve) add exact zeros; skipped
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * kg + i], m[i], c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * kg + i], v[i], c2, 0, 0, 0);
         }
@@ -425,6 +426,8 @@ void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda
     static const int ablate = [] { const char *e = std::getenv("RS_UBM_ABLATE"); return e ? std::atoi(e) : 0; }();
 #define RS_UBM_M(N, K) hipLaunchKernelGGL((UbmPostMfmaKernel<N, K>), grid, dim3(256), 0, s, iv, g, lda_norm, ld, iv.ubm_bm, iv.ubm_bv, post_idx, post_w, ablate)
     if (kg == 1) { if (nt <= 2) RS_UBM_M(2, 1); else if (nt <= 8) RS_UBM_M(8, 1); else RS_UBM_M(32, 1); }
+    else if (nt > 8 && iv.feat_dim <= 40)
+      hipLaunchKernelGGL((UbmPostMfmaKernel<32, 3, 10>), grid, dim3(256), 0, s, iv, g, lda_norm, ld, iv.ubm_bm, iv.ubm_bv, post_idx, post_w, ablate);
     else { if (nt <= 2) RS_UBM_M(2, 3); else if (nt <= 8) RS_UBM_M(8, 3); else RS_UBM_M(32, 3); }
 #undef RS_UBM_M
     return;
@@ -467,14 +470,20 @@ void LaunchIvecInit(const IvecDev &iv, int n_utts, double *linear, double *quadr
 //   2. the entries are counting-sorted by Gaussian, stably in frame order: 16 waves histogram 16 frame segments, a
 //      per-Gaussian prefix over the segments gives every segment its write cursor, each wave then walks its segment
 //      frame by frame (the Gaussians of one frame are distinct, so a frame's entries can be placed in parallel);
-//   3. the (Gaussian, dim) sums are independent: each thread takes pairs, walks that Gaussian's entry list in order
-//      and does its read-modify-write of wfeats / gamma exactly once -- instead of one global round trip per frame.
-constexpr int kAccTC = 256;          // frames per chunk
+//   3. the (Gaussian, dim) sums are independent: each wave takes Gaussians (lane = dim), walks that Gaussian's entry list
+//      in order and does its read-modify-write of wfeats / gamma exactly once -- instead of one global round trip per frame.
+#ifndef RS_ACC_TC
+#define RS_ACC_TC 320
+#endif
+#ifndef RS_ACC_ABLATE                // measurement only (profiles/micro/acc_ablate.sh): 1 = no sums, 2 = staging only, 4 = sums without the global read-modify-write
+#define RS_ACC_ABLATE 0
+#endif
+constexpr int kAccTC = RS_ACC_TC;    // frames per chunk
 constexpr int kAccNSeg = 16;         // frame segments sorted in parallel (<= waves per workgroup); fewer when G is large
 __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g, const float *__restrict__ lda, int ld,
                                                          const int *__restrict__ post_idx, const float *__restrict__ post_w,
                                                          const int *frame_begin, const int *frame_end,
-                                                         float *__restrict__ gamma, double *__restrict__ wfeats, int nseg) {
+                                                         float *__restrict__ gamma, double *__restrict__ wfeats, int nseg, int fresh) {
   extern __shared__ __attribute__((aligned(16))) char acc_smem[];
   const int u = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int T = g.d_num_frames[u];
@@ -491,7 +500,14 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
   int *hist = reinterpret_cast<int *>(ew + kAccTC * nsel);            // [kAccNSeg][G]  counts, then write cursors
   int *cnt = hist + nseg * G;                                         // [G]
   int *off = cnt + G;                                                 // [G + 1]
-  unsigned short *order = reinterpret_cast<unsigned short *>(off + G + 1);   // [kAccTC * nsel] entry ids sorted by Gaussian
+  float *ows = reinterpret_cast<float *>(off + G + 1);                // [kAccTC * nsel] posteriors sorted by Gaussian (stable in frame order)
+  unsigned short *ofr = reinterpret_cast<unsigned short *>(ows + kAccTC * nsel);   // [kAccTC * nsel] ... and their frames (within the chunk)
+  // fresh: the statistics start from zero with this launch (whole utterances at once), so the first chunk writes every sum
+  // instead of the caller clearing 8 G D bytes per utterance (42 MB for the headline batch) for this kernel to read back
+  if (fresh && t_begin >= t_end) {
+    for (int i = tid; i < G * D; i += 1024) wf[i] = 0.0;
+    for (int i = tid; i < G; i += 1024) gm[i] = 0.f;
+  }
   for (int t0 = t_begin; t0 < t_end; t0 += kAccTC) {
     const int n = t_end - t0 < kAccTC ? t_end - t0 : kAccTC, ne = n * nsel;
     const int seglen = (n + nseg - 1) / nseg;
@@ -500,6 +516,7 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
     for (int e = tid; e < ne; e += 1024) { eidx[e] = post_idx[(base + t0) * nsel + e]; ew[e] = post_w[(base + t0) * nsel + e]; }
     for (int i = tid; i < nseg * G; i += 1024) hist[i] = 0;
     __syncthreads();
+    if (RS_ACC_ABLATE & 2) continue;
     // 2a. per-segment histograms
     if (wave < nseg) {
       const int f0 = wave * seglen, f1 = f0 + seglen < n ? f0 + seglen : n;
@@ -532,35 +549,52 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
       for (int f = f0; f < f1; f++) {
         if (lane < nsel) {
           const int e = f * nsel + lane, gi = eidx[e];
-          if (gi >= 0) { const int pos = off[gi] + hist[wave * G + gi]; hist[wave * G + gi]++; order[pos] = (unsigned short)e; }
+          if (gi >= 0) { const int pos = off[gi] + hist[wave * G + gi]; hist[wave * G + gi]++; ofr[pos] = (unsigned short)f; ows[pos] = ew[e]; }
         }
       }
     }
     __syncthreads();
-    // 3. independent (Gaussian, dim) sums, each in frame order; the read-modify-write of wfeats is batched so that
-    // PG global loads are in flight at once
-    constexpr int PG = 8;
-    for (int p0 = tid; p0 < G * D; p0 += 1024 * PG) {
-      double acc[PG];
+    // 3. independent (Gaussian, dim) sums, each in frame order.  A wave takes whole Gaussians (lane = feature dim), so
+    // the walk over a Gaussian's entry list is wave-uniform: the list (frame, posterior: LDS broadcasts) is read four
+    // entries ahead of the dependent double adds, and the read-modify-write of wfeats is batched so that PG global loads
+    // are in flight at once.  (The earlier thread-per-(Gaussian, dim) form spent 117 of its 141 us here: lanes of a wave
+    // straddled Gaussians with different list lengths and every entry cost two dependent LDS round trips plus an integer
+    // division -- profiles/r02/acc_ablate.txt.)
+    constexpr int PG = 16;
+    if (RS_ACC_ABLATE & 1) continue;
+    const bool first = fresh && t0 == t_begin;
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int d = d0 + lane;
+      const bool dv = d < D;
+      const float *xd = xs + (dv ? d : 0);
+      for (int j0 = wave; j0 < G; j0 += 16 * PG) {
+        double acc[PG];
 #pragma unroll
-      for (int q = 0; q < PG; q++) { const int p = p0 + q * 1024; acc[q] = p < G * D ? wf[p] : 0.0; }
-#pragma unroll
-      for (int q = 0; q < PG; q++) {
-        const int p = p0 + q * 1024;
-        if (p >= G * D) continue;
-        const int gi = p / D, d = p % D, c = cnt[gi];
-        if (c == 0) continue;
-        const int o0 = off[gi];
-        double a = acc[q];
-        for (int k = 0; k < c; k++) {
-          const int e = order[o0 + k];
-          a += (double)ew[e] * (double)xs[(e / nsel) * D + d];
+        for (int q = 0; q < PG; q++) {
+          const int gi = j0 + 16 * q;
+          acc[q] = (gi < G && dv && !first && !(RS_ACC_ABLATE & 4)) ? wf[(size_t)gi * D + d] : 0.0;
         }
-        wf[p] = a;
-        if (d == 0) {
-          float ga = gm[gi];
-          for (int k = 0; k < c; k++) ga += ew[order[o0 + k]];
-          gm[gi] = ga;
+#pragma unroll
+        for (int q = 0; q < PG; q++) {
+          const int gi = j0 + 16 * q;
+          if (gi >= G) continue;
+          const int c = __builtin_amdgcn_readfirstlane(cnt[gi]);
+          if (c == 0 && !first) continue;
+          const int o0 = __builtin_amdgcn_readfirstlane(off[gi]);
+          const unsigned short *fr = ofr + o0;
+          const float *ws = ows + o0;
+          double a = acc[q];
+          float ga = (d0 == 0 && !first) ? gm[gi] : 0.f;
+          int k = 0;
+          for (; k + 4 <= c; k += 4) {
+            const float w0 = ws[k], w1 = ws[k + 1], w2 = ws[k + 2], w3 = ws[k + 3];
+            const float x0 = xd[fr[k] * D], x1 = xd[fr[k + 1] * D], x2 = xd[fr[k + 2] * D], x3 = xd[fr[k + 3] * D];
+            a += (double)w0 * (double)x0; a += (double)w1 * (double)x1; a += (double)w2 * (double)x2; a += (double)w3 * (double)x3;
+            ga += w0; ga += w1; ga += w2; ga += w3;
+          }
+          for (; k < c; k++) { const float w0 = ws[k]; a += (double)w0 * (double)xd[fr[k] * D]; ga += w0; }
+          if (dv && (!(RS_ACC_ABLATE & 4) || a == 12345.0)) wf[(size_t)gi * D + d] = a;
+          if (d0 == 0 && lane == 0) gm[gi] = ga;
         }
       }
     }
@@ -569,12 +603,12 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
 
 static size_t IvecAccumSmemBytes(const IvecDev &iv, int nseg) {
   const size_t ne = (size_t)kAccTC * iv.num_gselect;
-  return (size_t)kAccTC * iv.feat_dim * 4 + ne * 8 + ((size_t)nseg * iv.num_gauss + 2 * (size_t)iv.num_gauss + 1) * 4 + ne * 2 + 64;
+  return (size_t)kAccTC * iv.feat_dim * 4 + ne * 8 + ((size_t)nseg * iv.num_gauss + 2 * (size_t)iv.num_gauss + 1) * 4 + ne * 6 + 64;
 }
 
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
                           const float *post_w, const int *frame_begin, const int *frame_end, double *gamma,
-                          double *wfeats, hipStream_t s) {
+                          double *wfeats, bool fresh, hipStream_t s) {
   if (g.n_utts == 0) return;
   // gamma is kept in float (GaussInfo::tot_weight is a BaseFloat); the buffer is sized for doubles, we use
   // its first half as floats.
@@ -587,7 +621,7 @@ void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *ld
     attr_set = true;
   }
   hipLaunchKernelGGL(IvecAccumKernel, dim3(g.n_utts), dim3(1024), smem, s, iv, g, lda, ld, post_idx, post_w, frame_begin,
-                     frame_end, reinterpret_cast<float *>(gamma), wfeats, nseg);
+                     frame_end, reinterpret_cast<float *>(gamma), wfeats, nseg, fresh ? 1 : 0);
 }
 
 constexpr int kIvecUB = 8;        // utterances per workgroup in the two batch products

@@ -168,7 +168,7 @@ void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda
 // in frame order (double), for frames [frame_begin[u], frame_end[u]) of each utterance (null = all).
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
                           const float *post_w, const int *frame_begin, const int *frame_end,
-                          double *gamma, double *wfeats, hipStream_t s);
+                          double *gamma, double *wfeats, bool fresh, hipStream_t s);
 // linear (n_utts x I) += sum_g Sigma_inv_M_g^T wfeats_g ; quadratic (n_utts x I(I+1)/2) += sum_g gamma_g U_g,
 // plus the max_count prior rescaling of OnlineIvectorEstimationStats::AccStats; num_frames (n_utts, double).
 // scratch: IvecStatsScratchDoubles() doubles of workspace.

@@ -445,7 +445,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     for (int k = 0; k < max_new_chunks; k++) {
       const size_t o = (size_t)k * nI;
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, q);
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, false, q);
       LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, q);
       LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, q);
       LaunchIvecClear(ivec_dev_, nI, gamma, wfeats, q);
