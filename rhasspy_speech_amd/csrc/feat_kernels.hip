@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
   __shared__ double nn[kCmvnTC], aa[kCmvnTC];     // frame count in the window; weight of the global stats
   __shared__ float al[kCmvnTC];                   // -1 / (smoothed count)
   __shared__ float edge[2][kCmvnMaxDim];          // normalised first / last frame (halo rows replicate them)
+  __shared__ double gs[kCmvnMaxDim];              // global stats (read per element in step 3 while the window is not full)
   const int u = blockIdx.x, tid = threadIdx.x, D = c.dim, W = c.cmn_window;
+  if (tid < D) gs[tid] = c.global_stats[tid];
   const int T = g.d_num_frames[u];
   const size_t base = (size_t)g.d_row_base[u] + g.L;
   double sum = 0.0, count = 0.0;                  // threads < D
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
     }
     __syncthreads();
     if (tid < D) {
+#pragma unroll 8
       for (int i = 0; i < n; i++) {
         sum += (double)xs[i][tid];
         count += 1.0;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
       const int i = idx / D, d = idx % D;
       double sv = ss[i][d];
       const double a = aa[i];
-      if (a > 0.0) sv += a * c.global_stats[d];
+      if (a > 0.0) sv += a * gs[d];
       const float offset = (float)((double)al[i] * sv);
       const float yv = xs[i][d] + offset;
       out[(base + t0 + i) * ld + d] = yv;

@@ -1114,6 +1114,9 @@ __device__ __forceinline__ void BlockSumK(const double (&v)[K], double (&out)[K]
   rb ^= 1;
 }
 
+#ifndef RS_SOLVE_ABLATE               // measurement only (profiles/micro/kernel_ablate.sh): 1 = no CG iterations, 2 = no expansion either,
+#define RS_SOLVE_ABLATE 0            // 4 = one iteration
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const double *__restrict__ linear,
                                                                const double *__restrict__ quadratic, const double *__restrict__ num_frames,
@@ -1133,24 +1136,45 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
   const bool have = num_frames[u] > 0.0;
   double x = mine ? xio[(size_t)u * n + tid] : 0.0;
   if (solve && have) {
-    // expand the packed lower triangle: element k = r(r+1)/2 + c  (c <= r)
-    for (int k = tid; k < usz; k += 64 * NW) {
-      int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
-      while ((r + 1) * (r + 2) / 2 <= k) r++;
-      while (r * (r + 1) / 2 > k) r--;
-      const int cc = k - r * (r + 1) / 2;
-      const double v = quadratic[(size_t)u * usz + k];
-      A[(size_t)r * n + cc] = v;
-      A[(size_t)cc * n + r] = v;
+    // expand the packed lower triangle: element k = r(r+1)/2 + c  (c <= r); EB loads per thread in flight (the expansion was
+    // 13 of the kernel's 57 us: a double-precision square root per element and the 40 KB read a few loads at a time)
+    constexpr int EB = 10;
+    const double *qu = quadratic + (size_t)u * usz;
+    for (int k0 = tid; k0 < ((RS_SOLVE_ABLATE & 2) ? 0 : usz); k0 += 64 * NW * EB) {
+      double v[EB];
+#pragma unroll
+      for (int j = 0; j < EB; j++) { const int k = k0 + j * 64 * NW; v[j] = k < usz ? qu[k] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < EB; j++) {
+        const int k = k0 + j * 64 * NW;
+        if (k >= usz) continue;
+        int r = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= k) r++;
+        while (r * (r + 1) / 2 > k) r--;
+        const int cc = k - r * (r + 1) / 2;
+        A[(size_t)r * n + cc] = v[j];
+        A[(size_t)cc * n + r] = v[j];
+      }
     }
     const double b = mine ? linear[(size_t)u * n + tid] : 0.0;
     if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
     if (mine) xs[tid] = x;
     __syncthreads();
     auto matvec = [&](const double *vec) __attribute__((always_inline)) {
+      // one accumulator, columns ascending (the sums the scalar loop formed); MB columns are read ahead of the dependent adds
+      constexpr int MB = 20;
       double acc = 0.0;
-      if (mine)
-        for (int c = 0; c < n; c++) acc += A[(size_t)c * n + tid] * vec[c];
+      if (mine) {
+        int c = 0;
+        for (; c + MB <= n; c += MB) {
+          double a[MB], w[MB];
+#pragma unroll
+          for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + tid]; w[i] = vec[c + i]; }
+#pragma unroll
+          for (int i = 0; i < MB; i++) acc += a[i] * w[i];
+        }
+        for (; c < n; c++) acc += A[(size_t)c * n + tid] * vec[c];
+      }
       return acc;
     };
     // p0 = b - A x0 ; r0 = -p0
@@ -1160,7 +1184,7 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
     BlockSumK<1, NW>(in1, out1, xch, rb);
     double r_cur = out1[0], r_recompute = r_cur;
     const double max_error_sq = DBL_MIN, residual_factor = (double)(0.01f * 0.01f), inv_residual_factor = 1.0 / residual_factor;
-    for (int k = 0; k < n + 5 && k != iv.num_cg_iters; k++) {
+    for (int k = 0; k < n + 5 && k != ((RS_SOLVE_ABLATE & 3) ? 0 : (RS_SOLVE_ABLATE & 4) ? 1 : iv.num_cg_iters); k++) {
       if (mine) ps[tid] = p;
       __syncthreads();
       const double ap = matvec(ps);
@@ -1207,11 +1231,12 @@ void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const 
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr_set = true;
     }
     if (n <= 64) hipLaunchKernelGGL(IvecSolveFullKernel<1>, dim3(n_utts), dim3(64), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
-    else hipLaunchKernelGGL(IvecSolveFullKernel<2>, dim3(n_utts), dim3(128), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
+    else      // (four waves: the two past ivec_dim only help expanding the matrix; they add exact zeros to the reductions)
+      hipLaunchKernelGGL(IvecSolveFullKernel<4>, dim3(n_utts), dim3(256), smem, s, iv, linear, quadratic, num_frames, x, ivec_out, ldo, out_row, active);
     return;
   }
   int threads = 64;
