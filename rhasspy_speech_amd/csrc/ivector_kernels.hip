@@ -861,6 +861,111 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaKernel(IvecDev iv, int n_utts
       if (k == 0 && ch != 0.0) linear[(size_t)u * I] += iv.prior_offset * ch;
     }
 }
+// ---- the same product with the model-matrix loads in inline asm and hand-placed waits (num_gauss a multiple of 128).  In the
+// kernel above the compiler puts s_waitcnt vmcnt(0) in front of the MFMAs of every request group -- the group requested a moment
+// earlier "for the next step" is waited for at once, so the 16 groups of a workgroup are 16 exposed memory round trips (39 us for a
+// round of 64 streams against 15.6 us of fp64 MFMA time; profiles/r02/acc_ablate.txt).  Here the two register sets alternate
+// without copies (a copy would read a set still in flight), the compiler does not see the loads, and each wait leaves exactly the
+// newest group outstanding.  Same products, same order.
+#define RS_GLOAD8(dst, ptr) __asm__ volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#define RS_WAIT_SET(CNT, b)                                                                                                          \
+  __asm__ volatile("s_waitcnt vmcnt(" #CNT ")"                                                                                       \
+                   : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : : "memory")
+template <int NCH>                                          // num_gauss = 128 NCH; the chunk loop is unrolled: a register set that is
+                                                            // live around a loop's back edge gets copied there, in flight or not
+__global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_utts, const float *__restrict__ gamma,
+                                                          const double *__restrict__ change, double *__restrict__ quadratic,
+                                                          double *__restrict__ linear) {
+  constexpr int GC = 128;                                   // Gaussians per LDS chunk
+  __shared__ float gml[kMmU][GC + 1];
+  const int G = iv.num_gauss, I = iv.ivec_dim, usz = I * (I + 1) / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int u0 = blockIdx.y * kMmU, k0 = (blockIdx.x * 4 + wave) * 16;
+  const int kcol = k0 + lr < usz ? k0 + lr : usz - 1;
+  f64x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // eight k-steps of model-matrix values per request group, and the NEXT group (of this chunk or the first of the next one) is
+  // requested before the MFMAs of the current one: with at most one wave per SIMD nothing else hides the round trip (68 us for
+  // 64 utterances before, all of it a chain of 16 exposed L2 / HBM latencies)
+#define RS_QFETCH(b, gfirst)                                                                 \
+  _Pragma("unroll") for (int q = 0; q < 8; q++) RS_GLOAD8(b[q], iv.U + (size_t)((gfirst) + 4 * q + lk) * usz + kcol)
+#define RS_QMMA(b, gi)                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 8; q++) {                                           \
+    const int gc = (gi) + 4 * q + lk;                                                        \
+    _Pragma("unroll") for (int m = 0; m < 4; m++)                                           \
+      acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gc], b[q], acc[m], 0, 0, 0); \
+  }
+  // (occupancy chunk of the next step: global -> registers during the MFMAs of this one, to LDS between two barriers afterwards)
+  constexpr int SPT = kMmU * GC / 256;
+  float stg[SPT];
+  // (also in asm, all of them always issued -- rows past n_utts re-read the last utterance, their results are never stored -- so
+  // that the waits below can count them: a load the compiler knows about makes it wait vmcnt(0) before the LDS store, request
+  // group in flight included)
+  auto stage_load = [&](int g0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SPT; t++) {
+      const int e = threadIdx.x + 256 * t, uu = e / GC, gi = e % GC;
+      const int ur = u0 + uu < n_utts ? u0 + uu : n_utts - 1;
+      __asm__ volatile("global_load_dword %0, %1, off" : "=v"(stg[t]) : "v"(gamma + (size_t)ur * G + g0 + gi) : "memory");
+    }
+  };
+  auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < SPT; t++) { const int e = threadIdx.x + 256 * t; gml[e / GC][e % GC] = stg[t]; }
+  };
+  // Three register sets in rotation, two request groups ahead of the MFMAs: one group of MFMAs is about 1 us, a model-matrix
+  // round trip about 2 (one group ahead: 58 -> 49 us for the headline batch, 39.5 -> 31.5 us for 64 streams, still a chain of
+  // round trips).  Wait counts: 8 per group requested after the awaited one, + the 32 staging loads where they were issued in
+  // between (the two steps after a chunk's first).
+  double bq[3][8];                                          // (column tiles past usz compute on the clamped column and store nothing)
+#define RS_WAIT_N(n, b)                                                                                                 \
+  do {                                                                                                                  \
+    if ((n) == 0) { RS_WAIT_SET(0, b); } else if ((n) == 8) { RS_WAIT_SET(8, b); } else if ((n) == 16) { RS_WAIT_SET(16, b); } \
+    else if ((n) == 40) { RS_WAIT_SET(40, b); } else { RS_WAIT_SET(48, b); }                                            \
+  } while (0)
+  constexpr int NG = 4 * NCH;
+  stage_load(0);
+  RS_QFETCH(bq[0], 0);
+  if (NG > 1) { RS_QFETCH(bq[1], 32); }
+  __asm__ volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the staged chunk; the two groups stay in flight
+  stage_store();
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NG; t++) {
+    const int ch = t / 4, r = t % 4;
+    const bool more = ch + 1 < NCH;
+    if (t + 2 < NG) { RS_QFETCH(bq[(t + 2) % 3], (t + 2) * 32); }
+    const int newer = NG - 1 - t < 2 ? NG - 1 - t : 2;
+    RS_WAIT_N(8 * newer + ((more && (r == 1 || r == 2)) ? 32 : 0), bq[t % 3]);
+    if (r == 0 && more) stage_load((ch + 1) * GC);
+    RS_QMMA(bq[t % 3], r * 32);
+    if (r == 3 && more) {
+      __syncthreads();
+      stage_store();
+      __syncthreads();
+    }
+  }
+#undef RS_WAIT_N
+#undef RS_QFETCH
+#undef RS_QMMA
+  if (k0 + lr >= usz) return;
+  const int k = k0 + lr;
+  int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= k) r++;
+  while (r * (r + 1) / 2 > k) r--;
+  const bool diag = (k == r * (r + 1) / 2 + r);
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int u = u0 + 16 * m + lk + 4 * q;
+      if (u >= n_utts) continue;
+      const double ch = change[u];
+      quadratic[(size_t)u * usz + k] += acc[m][q] + ((diag && ch != 0.0) ? ch : 0.0);
+      if (k == 0 && ch != 0.0) linear[(size_t)u * I] += iv.prior_offset * ch;
+    }
+}
 // partial[ks][u][i] = sum over the Gaussians of range ks and all d of Sigma_inv_M[g][d][i] * wfeats[u][g][d]:
 // [n_utts x (G D)] x [(G D) x I], K split into kIvecKS Gaussian ranges (reduced in fixed order by IvecLinearReduceKernel)
 __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_utts, const double *__restrict__ wfeats,
@@ -978,7 +1083,14 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
   hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
   hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
-  if (mfma) hipLaunchKernelGGL(IvecQuadMfmaKernel, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear);
+  static const int quad_asm = [] { const char *e = std::getenv("RS_IVEC_ASM"); return e ? std::atoi(e) : 1; }();
+#define RS_QUAD_ASM(N) hipLaunchKernelGGL(IvecQuadMfmaAsmKernel<N>, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear)
+  if (mfma && quad_asm && iv.num_gauss == 512) RS_QUAD_ASM(4);
+  else if (mfma && quad_asm && iv.num_gauss == 256) RS_QUAD_ASM(2);
+  else if (mfma && quad_asm && iv.num_gauss == 1024) RS_QUAD_ASM(8);
+  else if (mfma && quad_asm && iv.num_gauss == 128) RS_QUAD_ASM(1);
+#undef RS_QUAD_ASM
+  else if (mfma) hipLaunchKernelGGL(IvecQuadMfmaKernel, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear);
   else hipLaunchKernelGGL(IvecQuadKernel, dim3((usz + 127) / 128, ub), dim3(128), 0, s, iv, n_utts, gm, change, quadratic, linear);
 }
 
