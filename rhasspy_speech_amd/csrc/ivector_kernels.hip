@@ -6,14 +6,17 @@
 //   online2/online-ivector-feature.cc:225-330,440-442 (what is accumulated when)
 //
 // Shape of the work (zamia-like: D = 40, G = 512, I = 100, 5 Gaussians kept per frame):
-//   * UBM scoring is a [rows x 2D] x [2D x G] product followed by a per-row top-k: a wave scores R rows at once so
-//     every Gaussian parameter fetched is used R times (packed fp32 FMAs), then selects with DPP reductions;
-//   * the statistics are two batch products over the utterances, in double as the reference keeps them:
+//   * UBM scoring is a [rows x 2D] x [2D x G] product followed by a per-row top-k: UbmPostMfmaKernel, a wave scores 16 rows
+//     against all Gaussians on the FP32 matrix cores and selects with DPP row reductions (UbmPostKernel: the scalar-FMA form it
+//     is bit-identical to, kept for shapes the MFMA form does not cover);
+//   * the first-order statistics: IvecAccumKernel, a counting sort of each chunk's posteriors by Gaussian in LDS, then a wave per
+//     Gaussian adds in frame order;
+//   * two batch products over the utterances, in double as the reference keeps them:
 //     linear[u] = sum_{g,d} Sigma^-1 M_g[d,:] * wfeats[u,g,d]   ([U x G D] x [G D x I])
 //     quadratic[u] = sum_g gamma[u,g] * U_g                    ([U x G] x [G x I(I+1)/2])
-//     both are tiled over 8 utterances per workgroup so the model matrices stream through L2 n_utts/8 times
-//     instead of n_utts times;
-//   * the solve is one workgroup per utterance with the packed quadratic term in LDS.
+//     on v_mfma_f64_16x16x4_f64, 64 utterances per workgroup (IvecLinearMfmaKernel, IvecQuadMfmaAsmKernel / IvecQuadMfmaKernel;
+//     the vector forms IvecLinearPartialKernel / IvecQuadKernel remain as the cross-check RS_IVEC_MFMA=0 selects);
+//   * the solve is one workgroup per utterance with the quadratic term expanded to a full matrix in LDS (IvecSolveFullKernel).
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>
