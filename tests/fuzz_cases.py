@@ -3,7 +3,7 @@ tests/cases.py drawn from a seed -- model shape, graph kind, utterance, decoder 
 in the build container where the reference produced tests/golden/fuzz_decode.json."""
 import numpy as np
 
-N_CASES = 48
+N_CASES = 96
 
 
 def _draw(i: int) -> dict:
