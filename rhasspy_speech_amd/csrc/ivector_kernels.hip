@@ -1086,7 +1086,8 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
   hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
   hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
-  static const int quad_asm = [] { const char *e = std::getenv("RS_IVEC_ASM"); return e ? std::atoi(e) : 1; }();
+  const char *ae = std::getenv("RS_IVEC_ASM");           // read per call (a test compares the two forms)
+  const int quad_asm = ae ? std::atoi(ae) : 1;
 #define RS_QUAD_ASM(N) hipLaunchKernelGGL(IvecQuadMfmaAsmKernel<N>, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear)
   if (mfma && quad_asm && iv.num_gauss == 512) RS_QUAD_ASM(4);
   else if (mfma && quad_asm && iv.num_gauss == 256) RS_QUAD_ASM(2);

@@ -375,3 +375,24 @@ def test_ivector_batch_products_on_the_fp64_matrix_cores(case_cache, name, monke
             np.testing.assert_allclose(a.matrix(u, 1), b.matrix(u, 1), rtol=0, atol=1e-6)
             assert np.abs(a.matrix(u, 2) - b.matrix(u, 2)).max() < 1e-5
             assert a.words(u) == b.words(u)
+
+
+@pytest.mark.parametrize("name", ["zam_u0", "zam_long30"])
+def test_ivector_quadratic_product_with_hand_placed_waits(case_cache, name, monkeypatch):
+    """IvecQuadMfmaAsmKernel (loads in inline asm, counted s_waitcnt, num_gauss a multiple of 128) forms the sums of
+    IvecQuadMfmaKernel in the same order: iVectors bit for bit, offline (a batch that leaves rows of the 64-utterance tile empty)
+    and per streaming chunk."""
+    from rhasspy_speech_amd import _lib
+    model, pcm = make_model(case_cache, name)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RS_IVEC_ASM", flag)
+        off = model.decode_batch([pcm, pcm[: len(pcm) // 3], pcm[: len(pcm) // 2]])
+        st = _lib.Stream(model)
+        st.accept(pcm)
+        out[flag] = (off, st.finish())
+    for a, b in zip(out["1"], out["0"]):
+        for u in range(a.num_utts):
+            np.testing.assert_array_equal(a.matrix(u, 1), b.matrix(u, 1))
+            np.testing.assert_array_equal(a.matrix(u, 2), b.matrix(u, 2))
+            assert a.words(u) == b.words(u)
