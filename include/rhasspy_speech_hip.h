@@ -205,6 +205,23 @@ int rs_mkgraph(const char *lang_dir, const char *model_dir, const char *graph_di
  * fstequivalent (fstequivalent --random=true: equal tropical weight, within param, of the label pairs of random paths). */
 int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *out, const char *aux, float param);
 
+/* ---- what the reference's decoder binaries do to a model before the first frame (host side; no device needed).
+ * Both binaries (kaldi/src/online2bin/online2-wav-nnet3-latgen-faster.cc:160-176, online2-cli-nnet3-decode-faster.cc:97-111)
+ * run CollapseModel on the network they read and, while computing the network's context and compiling its looped computation,
+ * call glibc's rand() a model-dependent number of times -- which decides the noise Dither() adds to every frame afterwards
+ * (kaldi/src/feat/feature-window.cc:90-98; the default mfcc configuration has --dither=1 and rhasspy starts one process per
+ * utterance, so the noise of frame t is a constant of the model).  rs_model_load replays both; these two entry points expose
+ * the replay for inspection and tests:
+ *   rs_nnet3_setup: *rand_calls = number of rand() calls before the first frame for `final_mdl` under --frames-per-chunk;
+ *     *certain = 0 when the count assumes a looped compilation the reference may have to retry (rs_model_load refuses such a
+ *     model unless its mfcc.conf says --dither=0); collapsed_config (may be NULL) receives the config lines of the collapsed
+ *     network, '\n'-separated and NUL-terminated, truncated to buf_len.
+ *   rs_dither_noise: out[(t - t0) * window + i] = the value Dither() adds, for --dither=1, to sample i of frame t in a process
+ *     that called rand() `rand_calls` times before its first frame. */
+int rs_nnet3_setup(const char *final_mdl, int32_t frames_per_chunk, int64_t *rand_calls, int32_t *certain, char *collapsed_config,
+                   size_t buf_len);
+int rs_dither_noise(int64_t rand_calls, int32_t t0, int32_t t1, int32_t window, float *out);
+
 /* ---- rescoring against a NEW language directory (host side; the lattices come from decodes with rs_decode_opts.emit_lattice = 1).
  * Replaces the tool chain of `async_transcribe_rescore` (rhasspy_speech/transcribe_wav.py:107-232, transcribe_stream.py:131-274):
  *   [Ldet.fst from L_disambig.fst: fstprint | awk | fstcompile | fstdeterminizestar | fstrmsymbols]   lattice-scale --lm-scale=0.0 |

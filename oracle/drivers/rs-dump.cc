@@ -13,13 +13,16 @@
 //                  rebuilt from the same reference classes OnlineIvectorFeature wires together
 //                  (online2/online-ivector-feature.cc:412-438)
 //
-// Usage: rs-dump [kaldi options] <offline|stream> <final.mdl> <wav> <out-dir>
+// Usage: rs-dump [kaldi options] <offline|stream|randpos|collapsed> <final.mdl> <wav> <out-dir>
+//   dither <num-frames> <window> <out.npy>: the noise of the reference's Dither() in a fresh process
+//   randpos: prints the number of rand() calls consumed before the first feature frame and exits (wav / out-dir unused)
 #include <cstdio>
 #include <fstream>
 #include <string>
 #include <vector>
 
 #include "base/kaldi-common.h"
+#include "feat/feature-window.h"
 #include "feat/wave-reader.h"
 #include "nnet3/decodable-online-looped.h"
 #include "nnet3/nnet-utils.h"
@@ -45,6 +48,23 @@ static void WriteNpy(const std::string &path, const Matrix<BaseFloat> &m) {
     os.write(reinterpret_cast<const char *>(m.RowData(r)), sizeof(BaseFloat) * m.NumCols());
 }
 
+// Number of rand() calls made so far in this process (which never calls srand() elsewhere): the position of the next
+// two values in glibc's default-seed sequence.  Leaves the generator where it found it.
+static long RandPosition() {
+  const int r1 = rand(), r2 = rand();
+  srand(1);
+  long pos = 0;
+  int a = rand(), b = rand();
+  while (!(a == r1 && b == r2)) {
+    a = b;
+    b = rand();
+    if (++pos > 200000000) return -1;
+  }
+  srand(1);
+  for (long i = 0; i < pos; i++) (void)rand();
+  return pos;
+}
+
 int main(int argc, char *argv[]) {
   try {
     ParseOptions po("rs-dump [options] <offline|stream> <final.mdl> <wav> <out-dir>");
@@ -60,6 +80,18 @@ int main(int argc, char *argv[]) {
     if (po.NumArgs() != 4) { po.PrintUsage(); return 1; }
     std::string mode = po.GetArg(1), mdl = po.GetArg(2), wav = po.GetArg(3), out = po.GetArg(4);
     bool offline = (mode == "offline");
+    if (mode == "dither") {
+      // rs-dump dither <num-frames> <window> <out.npy>: what the reference's own Dither() (feat/feature-window.cc:90-98) adds,
+      // for --dither=1, to the frames of a process that has not called rand() before (pins oracle/dither.c)
+      const int32 T = std::atoi(mdl.c_str()), W = std::atoi(wav.c_str());
+      Matrix<BaseFloat> m(T, W);
+      for (int32 t = 0; t < T; t++) {
+        SubVector<BaseFloat> row(m, t);
+        Dither(&row, 1.0);
+      }
+      WriteNpy(out, m);
+      return 0;
+    }
 
     OnlineNnet2FeaturePipelineInfo feature_info(feature_opts);
     if (offline) {
@@ -77,7 +109,21 @@ int main(int argc, char *argv[]) {
       SetDropoutTestMode(true, &(am_nnet.GetNnet()));
       nnet3::CollapseModel(nnet3::CollapseModelConfig(), &(am_nnet.GetNnet()));
     }
+    if (mode == "collapsed") {   // the network's config lines after CollapseModel (what the graph builder will see)
+      std::vector<std::string> lines;
+      am_nnet.GetNnet().GetConfigLines(false, &lines);
+      for (size_t i = 0; i < lines.size(); i++) std::printf("%s\n", lines[i].c_str());
+      return 0;
+    }
     nnet3::DecodableNnetSimpleLoopedInfo info(decodable_opts, &am_nnet);
+    if (mode == "randpos") {
+      // How many rand() calls the set-up both decoder binaries share (model read, CollapseModel, looped compilation:
+      // nnet-computation-graph.cc:481-555, nnet-utils.cc:107, nnet-optimize-utils.cc:4654, AffineComponent::Init) has
+      // consumed.  The dither of frame t is seeded by value number (this + t) of glibc's default-seed sequence
+      // (feature-window.cc:95, kaldi-math.cc:59-70).
+      std::printf("%ld\n", RandPosition());
+      return 0;
+    }
 
     WaveData wave_data;
     {
@@ -87,6 +133,7 @@ int main(int argc, char *argv[]) {
     }
     SubVector<BaseFloat> data(wave_data.Data(), 0);
 
+    const long rand_pos_at_first_frame = RandPosition();
     OnlineNnet2FeaturePipeline pipeline(feature_info);
     nnet3::DecodableNnetLoopedOnline decodable(info, pipeline.InputFeature(), pipeline.IvectorFeature());
     int32 P = info.output_dim, chunk = info.frames_per_chunk;
@@ -151,6 +198,8 @@ int main(int argc, char *argv[]) {
     if (offline && feature_info.use_ivectors) {
       // Same wiring as OnlineIvectorFeature's constructor, on a fresh MFCC.
       const OnlineIvectorExtractionInfo &ii = feature_info.ivector_extractor_info;
+      srand(1);   // our second pass must see the dither of the first: rewind rand() to where the first frame found it
+      for (long i = 0; i < rand_pos_at_first_frame; i++) (void)rand();
       OnlineMfcc mfcc(feature_info.mfcc_opts);
       mfcc.AcceptWaveform(wave_data.SampFreq(), data);
       mfcc.InputFinished();

@@ -4,11 +4,11 @@
 
 Every utterance of tests/configs.py's workloads goes through the REFERENCE binaries with the argv of
 rhasspy_speech/transcribe_wav.py:45-75 (offline: online2-wav-nnet3-latgen-faster --online=false | lattice-to-nbest |
-nbest-to-linear) or transcribe_stream.py:53-99 (streams: online2-cli-nnet3-decode-faster fed s16le on stdin).  The
-offline binary is handed a table of utterances (one speaker per utterance, so nothing carries over) to pay the model
-load once per worker instead of once per utterance; the streaming binary decodes one stdin per process, as it must.
-Stored per config: the 1-best word ids of every utterance and nbest-to-linear's graph / acoustic cost
-(tests/golden/configs/<name>.npz, a few KB each).
+nbest-to-linear) or transcribe_stream.py:53-99 (streams: online2-cli-nnet3-decode-faster fed s16le on stdin).  ONE
+PROCESS PER UTTERANCE, like rhasspy (tools.py:117-147): the dither of every frame is seeded from rand(), whose state a
+process shared by several utterances would carry from one to the next (feature-window.cc:90-98).
+Stored per config: the 5-best word ids of every utterance and nbest-to-linear's graph / acoustic costs
+(tests/golden/configs/<name>.npz, a few KB each); `words` / `graph_cost` / `acoustic_cost` are the 1-best of that list.
 
 Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams]
 """
@@ -32,7 +32,8 @@ from tests import configs  # noqa: E402
 BIN = REPO / "oracle" / "_ref" / "bin"
 ENV = dict(os.environ, PATH=f"{BIN}:{os.environ['PATH']}", OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1")
 DEC = "--max-active=7000 --lattice-beam=8.0 --acoustic-scale=1.0 --beam=24.0"
-TAIL = "lattice-to-nbest --n=1 --acoustic-scale=1.0 ark:- ark:- | nbest-to-linear ark:- ark:/dev/null ark,t:- ark,t:{d}/lm.txt ark,t:{d}/ac.txt"
+NBEST = 5
+TAIL = "lattice-to-nbest --n=5 --acoustic-scale=1.0 ark:- ark:- | nbest-to-linear ark:- ark:/dev/null ark,t:- ark,t:{d}/lm.txt ark,t:{d}/ac.txt"
 
 
 def parse_vec(text: str):
@@ -44,25 +45,27 @@ def parse_vec(text: str):
     return out
 
 
+def collect(words: dict, lm: dict, ac: dict):
+    """{key-k: ...} of one utterance -> [(word ids, graph cost, acoustic cost)] in n-best order."""
+    keys = sorted(words, key=lambda k: int(k.rsplit("-", 1)[1]))
+    return [([int(x) for x in words[k]], float(lm[k][0]), float(ac[k][0])) for k in keys]
+
+
 def offline_part(model_dir: Path, graph_dir: Path, pcms, ids, work: Path):
     work.mkdir(parents=True, exist_ok=True)
-    for i, p in zip(ids, pcms):
-        synth.write_wav(work / f"u{i:05d}.wav", p)
-    (work / "wav.scp").write_text("".join(f"u{i:05d} {work}/u{i:05d}.wav\n" for i in ids))
-    (work / "spk2utt").write_text("".join(f"u{i:05d} u{i:05d}\n" for i in ids))
     conf = model_dir / "model" / "online" / "conf" / "online.conf"
-    cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false --word-symbol-table={graph_dir}/words.txt "
-           f"--config={conf} {DEC} {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst ark:{work}/spk2utt scp:{work}/wav.scp ark:- | "
-           + TAIL.format(d=work))
-    r = subprocess.run(["bash", "-c", cmd], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr.decode()[-2000:])
-    words = parse_vec(r.stdout.decode())
-    lm, ac = parse_vec((work / "lm.txt").read_text()), parse_vec((work / "ac.txt").read_text())
     out = {}
-    for i in ids:
-        k = f"u{i:05d}-1"
-        out[i] = ([int(x) for x in words[k]], float(lm[k][0]), float(ac[k][0]))
+    for i, p in zip(ids, pcms):
+        wav = work / f"u{i:05d}.wav"
+        synth.write_wav(wav, p)
+        cmd = (f"online2-wav-nnet3-latgen-faster --online=false --do-endpointing=false --word-symbol-table={graph_dir}/words.txt "
+               f"--config={conf} {DEC} {model_dir}/model/model/final.mdl {graph_dir}/HCLG.fst 'ark:echo utt utt|' 'scp:echo utt {wav}|' ark:- | "
+               + TAIL.format(d=work))
+        r = subprocess.run(["bash", "-c", cmd], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr.decode()[-2000:])
+        out[i] = collect(parse_vec(r.stdout.decode()), parse_vec((work / "lm.txt").read_text()), parse_vec((work / "ac.txt").read_text()))
+        wav.unlink()
     return out
 
 
@@ -74,24 +77,31 @@ def stream_one(model_dir: Path, graph_dir: Path, pcm, i: int, work: Path):
     r = subprocess.run(["bash", "-c", cmd], env=ENV, input=pcm.astype("<i2").tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     if r.returncode != 0:
         raise RuntimeError(r.stderr.decode()[-2000:])
-    words = parse_vec(r.stdout.decode())
-    lm, ac = parse_vec((work / "lm.txt").read_text()), parse_vec((work / "ac.txt").read_text())
-    (k,) = list(words)
-    return {i: ([int(x) for x in words[k]], float(lm[k][0]), float(ac[k][0]))}
+    return {i: collect(parse_vec(r.stdout.decode()), parse_vec((work / "lm.txt").read_text()), parse_vec((work / "ac.txt").read_text()))}
 
 
 def save(name: str, res: dict, n: int, note: str):
     words, off = [], [0]
+    nb_words, nb_off, nb_utt, nb_g, nb_a = [], [0], [0], [], []
     for i in range(n):
-        words += res[i][0]
+        words += res[i][0][0]
         off.append(len(words))
+        for w, g, a in res[i]:
+            nb_words += w
+            nb_off.append(len(nb_words))
+            nb_g.append(g)
+            nb_a.append(a)
+        nb_utt.append(len(nb_g))
     configs.GOLDEN.mkdir(parents=True, exist_ok=True)
     np.savez_compressed(configs.GOLDEN / f"{name}.npz", words=np.array(words, np.int32), word_offsets=np.array(off, np.int32),
-                        graph_cost=np.array([res[i][1] for i in range(n)], np.float32),
-                        acoustic_cost=np.array([res[i][2] for i in range(n)], np.float32),
-                        note=np.frombuffer(note.encode(), np.uint8))
-    nonempty = sum(1 for i in range(n) if res[i][0])
-    print(f"{name}: {n} utterances, {nonempty} non-empty transcripts, {len(set(tuple(res[i][0]) for i in range(n)))} distinct")
+                        graph_cost=np.array([res[i][0][1] for i in range(n)], np.float32),
+                        acoustic_cost=np.array([res[i][0][2] for i in range(n)], np.float32),
+                        nbest_words=np.array(nb_words, np.int32), nbest_word_offsets=np.array(nb_off, np.int32),
+                        nbest_utt_offsets=np.array(nb_utt, np.int32), nbest_graph_cost=np.array(nb_g, np.float32),
+                        nbest_acoustic_cost=np.array(nb_a, np.float32), note=np.frombuffer(note.encode(), np.uint8))
+    nonempty = sum(1 for i in range(n) if res[i][0][0])
+    print(f"{name}: {n} utterances, {nonempty} non-empty transcripts, {len(set(tuple(res[i][0][0]) for i in range(n)))} distinct, "
+          f"{len(nb_g)} hypotheses")
 
 
 def run_offline(name: str, model_dir: Path, graph_dir: Path, pcms, td: Path, workers: int = 8):
@@ -103,7 +113,7 @@ def run_offline(name: str, model_dir: Path, graph_dir: Path, pcms, td: Path, wor
         futs = [ex.submit(offline_part, model_dir, graph_dir, [pcms[i] for i in ids], ids, td / f"{name}_w{w}") for w, ids in enumerate(parts) if ids]
         for f in futs:
             res.update(f.result())
-    save(name, res, n, "reference: online2-wav-nnet3-latgen-faster --online=false | lattice-to-nbest --n=1 | nbest-to-linear")
+    save(name, res, n, "reference: online2-wav-nnet3-latgen-faster --online=false, one process per utterance | lattice-to-nbest --n=5 | nbest-to-linear")
     print(f"  reference wall {time.time() - t0:.1f} s on {workers} processes")
 
 
@@ -134,7 +144,7 @@ def main():
                 futs = [ex.submit(stream_one, md, gd, p, i, td / f"s{i}") for i, p in enumerate(pcms)]
                 for f in futs:
                     res.update(f.result())
-            save("c4_streams", res, len(pcms), "reference: online2-cli-nnet3-decode-faster (stdin s16le) | lattice-to-nbest --n=1 | nbest-to-linear")
+            save("c4_streams", res, len(pcms), "reference: online2-cli-nnet3-decode-faster (stdin s16le) | lattice-to-nbest --n=5 | nbest-to-linear")
             print(f"  reference wall {time.time() - t0:.1f} s on 8 processes")
 
 

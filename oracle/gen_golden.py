@@ -112,6 +112,10 @@ def gen_case(name: str, case: dict) -> None:
                 out["cmvn"] = np.load(dump / "cmvn.npy")
                 out["lda"] = np.load(dump / "lda.npy")
                 out["lda_norm"] = np.load(dump / "lda_norm.npy")
+        # rand() calls of the reference's model set-up (decides the dither seeds): oracle/nnet3_rand.py and
+        # rhasspy_speech_amd/csrc/nnet3_setup.cc are checked against this
+        rp = run(["rs-dump", f"--config={conf}", "randpos", str(mdl), "-", "-"], env=env)
+        out["rand_calls"] = np.int64(int(rp.stdout))
         out["case_json"] = np.frombuffer(json.dumps(case, sort_keys=True).encode(), dtype=np.uint8)
         GOLDEN.mkdir(parents=True, exist_ok=True)
         np.savez_compressed(GOLDEN / f"{name}.npz", **out)
@@ -126,6 +130,14 @@ def main() -> None:
             fn = c["audio"].split(":")[1]
             if not (GOLDEN / "wav" / fn).exists():
                 shutil.copy(REF_WAVS / fn, GOLDEN / "wav" / fn)   # data files of the reference's own tests
+    # the reference's own Dither() noise in a fresh process (pins oracle/dither.c and rs_dither_noise bit for bit)
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, PATH=f"{BIN}:{os.environ['PATH']}")
+        ref = {}
+        for T, W in ((6, 400), (5, 200), (3, 275)):
+            run(["rs-dump", "dither", str(T), str(W), f"{td}/d.npy"], env=env)
+            ref[f"noise_{W}"] = np.load(f"{td}/d.npy")
+        np.savez_compressed(GOLDEN / "dither_ref.npz", **ref)
     names = sys.argv[1:] or list(CASES)
     for n in names:
         gen_case(n, CASES[n])

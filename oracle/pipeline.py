@@ -239,10 +239,38 @@ class SplitRadixRealFft:
         return power
 
 
+def frame_sum(fr: np.ndarray) -> np.ndarray:
+    """Row sums of a float32 matrix in the order of cblas_sdot(n, x, 1, &one, 0) of OpenBLAS 0.3.x on x86-64."""
+    n = fr.shape[1]
+    pairs = (fr[:, 0:n - (n & 1):2] + fr[:, 1::2]).astype(F32).astype(np.float64)
+    if n & 1:
+        pairs = np.concatenate([pairs, fr[:, -1:].astype(np.float64)], axis=1)
+    return np.add.accumulate(pairs, axis=1)[:, -1].astype(F32)
+
+
+_dither_cache: dict = {}
+
+
+def dither_table(T: int, win: int, offset: int = 0) -> np.ndarray:
+    """[T, win] float32: RandGauss values Dither() draws for frame t, sample i in a reference process whose set-up called rand()
+    `offset` times (oracle/dither.c)."""
+    have = _dither_cache.get((win, offset))
+    if have is None or have.shape[0] < T:
+        n = max(T, 512, 2 * (have.shape[0] if have is not None else 0))
+        have = np.zeros((n, win), F32)
+        lib = decoder_lib()
+        lib.oracle_dither_table.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.oracle_dither_table.restype = None
+        lib.oracle_dither_table(offset, 0, n, win, have.ctypes.data_as(C.c_void_p))
+        _dither_cache[(win, offset)] = have
+    return have[:T]
+
+
 class Mfcc:
-    def __init__(self, o: MfccOpts):
-        assert o.dither == 0.0 and not o.use_energy and o.window_type == "povey"
+    def __init__(self, o: MfccOpts, rand_offset: int = 0):
+        assert not o.use_energy and o.window_type == "povey"
         self.o = o
+        self.rand_offset = rand_offset
         self.win = int(o.samp_freq * 0.001 * o.frame_length_ms)
         self.shift = int(o.samp_freq * 0.001 * o.frame_shift_ms)
         self.padded = 1 << (self.win - 1).bit_length()
@@ -291,8 +319,18 @@ class Mfcc:
         x = pcm.astype(F32)
         idx = np.arange(T)[:, None] * self.shift + np.arange(self.win)[None, :]
         fr = x[idx]
+        if self.o.dither != 0.0:
+            # feature-window.cc:90-98 via ProcessWindow (:145-146): before DC removal; the noise of frame t is the same for every
+            # utterance because the reference starts a fresh process (rand() at its default seed) per utterance -- oracle/dither.c
+            fr = fr + dither_table(T, self.win, self.rand_offset) * F32(self.o.dither)
         if self.o.remove_dc:
-            fr = fr - (fr.sum(1, dtype=F32) / F32(self.win))[:, None]
+            # window->Add(-window->Sum() / frame_length) (feature-window.cc:148-149).  VectorBase::Sum() is cblas_sdot against a
+            # stride-0 one (kaldi-vector.cc), i.e. OpenBLAS's strided loop (kernel/x86_64/sdot.c, 0.3.x): adjacent pairs added in
+            # float, the pair sums accumulated in a double, the result rounded to float.  Irrelevant while the samples were
+            # integers; with dither a different rounding of the mean re-rounds every sample of a loud frame, which moves the
+            # cepstra by 1e-3 wherever a mel bin sits in a spectral valley (pinned against the library itself in
+            # tests/test_oracle_golden.py::test_frame_sum_is_the_blas_order)
+            fr = fr - (frame_sum(fr) / F32(self.win))[:, None]
         pre = fr.copy()
         pre[:, 1:] = fr[:, 1:] - F32(self.o.preemph) * fr[:, :-1]
         pre[:, 0] = fr[:, 0] - F32(self.o.preemph) * fr[:, 0]
@@ -723,8 +761,12 @@ class Oracle:
         self.chunk = frames_per_chunk
         conf = dict(kf.read_config(model_dir / "model" / "online" / "conf" / "online.conf"))
         assert conf.get("feature-type", "mfcc") == "mfcc"
-        self.mfcc = Mfcc(MfccOpts.from_conf(conf["mfcc-config"]) if "mfcc-config" in conf else MfccOpts())
         self.id2pdf, nf = kf.read_final_mdl(model_dir / "model" / "model" / "final.mdl")
+        # the dither of frame t is seeded by rand() value number (calls of the model set-up + t): oracle/nnet3_rand.py
+        from . import nnet3_rand
+        mo = MfccOpts.from_conf(conf["mfcc-config"]) if "mfcc-config" in conf else MfccOpts()
+        self.rand_calls = nnet3_rand.setup_rand_calls(nf, frames_per_chunk) if mo.dither != 0.0 else 0
+        self.mfcc = Mfcc(mo, self.rand_calls)
         self.nnet = Nnet3(nf)
         self.fst = kf.read_fst(graph_dir / "HCLG.fst")
         self.nnet_cmvn = None

@@ -12,6 +12,7 @@
 #include "engine.h"
 #include "fuzzy.h"
 #include "graph_build.h"
+#include "nnet3_setup.h"
 #include "rescore.h"
 
 namespace rs {
@@ -475,6 +476,45 @@ int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *
     }
     return RS_OK;
   });
+}
+
+int rs_nnet3_setup(const char *final_mdl, int32_t frames_per_chunk, int64_t *rand_calls, int32_t *certain, char *collapsed_config,
+                   size_t buf_len) {
+  if (!final_mdl || !rand_calls) return ArgError("rs_nnet3_setup: null argument");
+  return Guard([&]() {
+    // the network section of final.mdl, read the way Model does, without compiling a layer plan
+    rs::KaldiReader r(final_mdl);
+    rs::TransitionModel trans;
+    trans.Read(r);
+    r.ExpectToken("<Nnet3>");
+    (void)r.ReadLine();
+    std::vector<std::string> cfg;
+    for (;;) {
+      if (r.RawEof()) rs::Fail(std::string(final_mdl) + ": EOF inside <Nnet3> config section");
+      std::string line = r.ReadLine();
+      if (line.empty()) break;
+      cfg.push_back(line);
+    }
+    std::vector<std::string> names;
+    std::vector<rs::Component> comps;
+    rs::ReadNnetComponents(r, &names, &comps);
+    const rs::Nnet3SetupResult su = rs::Nnet3Setup(cfg, &names, &comps, frames_per_chunk > 0 ? frames_per_chunk : 24, 0);
+    *rand_calls = su.rand_calls;
+    if (certain) *certain = su.rand_calls_certain ? 1 : 0;
+    if (collapsed_config && buf_len) {
+      std::string s;
+      for (auto &l : su.config) s += l + "\n";
+      const size_t n = std::min(buf_len - 1, s.size());
+      std::memcpy(collapsed_config, s.data(), n);
+      collapsed_config[n] = 0;
+    }
+    return RS_OK;
+  });
+}
+
+int rs_dither_noise(int64_t rand_calls, int32_t t0, int32_t t1, int32_t window, float *out) {
+  if (!out || t0 < 0 || t1 < t0 || window <= 0 || rand_calls < 0) return ArgError("rs_dither_noise: bad argument");
+  return Guard([&]() { rs::DitherNoise((long)rand_calls, t0, t1, window, out); return RS_OK; });
 }
 
 struct rs_rescorer {

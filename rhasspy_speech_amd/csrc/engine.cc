@@ -1,4 +1,5 @@
 #include "engine.h"
+#include "nnet3_setup.h"
 #include "srfft_plan.h"
 #include "lattice.h"
 
@@ -90,12 +91,15 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
          " (beam " + std::to_string(opts_.beam) + ", max-active " + std::to_string(opts_.max_active) + ", min-active " + std::to_string(opts_.min_active) +
          ", lattice-beam " + std::to_string(opts_.lattice_beam) + ")");
   ReadFeatureConfig(online_conf, &fc_);
-  am_.Read(final_mdl);
+  am_.Read(final_mdl, opts_.frames_per_chunk, 0);
   hclg_.Read(hclg);
-  if (fc_.mfcc.opts.dither != 0.0f)
-    Fail("mfcc.conf has --dither=" + std::to_string(fc_.mfcc.opts.dither) +
-         ": the reference's dither draws from glibc rand() (feature-window.cc:90-98) and is not reproduced on the "
-         "device; set --dither=0 in the mfcc config");
+  dither_rand_calls_ = am_.nnet.setup_rand_calls;
+  if (const char *e = std::getenv("RS_DITHER_RAND_CALLS")) dither_rand_calls_ = std::atol(e);
+  else if (fc_.mfcc.opts.dither != 0.0f && !am_.nnet.setup_rand_certain)
+    Fail("mfcc.conf has --dither=" + std::to_string(fc_.mfcc.opts.dither) + " and the reference seeds that noise from rand() after a model "
+         "set-up whose number of rand() calls cannot be derived for this network (" + am_.nnet.setup_rand_uncertain_why +
+         ": its looped compilation may need a second attempt, nnet-compile-looped.cc:326-345); set --dither=0 in the mfcc config, or "
+         "RS_DITHER_RAND_CALLS=<n> to the count `rs-dump randpos` reports for the reference");
   const Nnet &n = am_.nnet;
   if (n.input_dim != fc_.mfcc.nceps)
     Fail("Input feature dimension mismatch: got " + std::to_string(fc_.mfcc.nceps) + " but network expects " + std::to_string(n.input_dim));
@@ -212,6 +216,7 @@ void Model::PruneOutputLayer() {
 
 Model::~Model() {
   for (void *p : owned_) (void)hipFree(p);
+  for (void *p : dither_bufs_) (void)hipFree(p);
   for (auto &c : ctx_) {
     if (c->h_pcm_pinned) (void)hipHostFree(c->h_pcm_pinned);
     if (c->d_pcm) (void)hipFree(c->d_pcm);
@@ -221,6 +226,38 @@ Model::~Model() {
     if (c->stream_dec) (void)hipStreamDestroy(c->stream_dec);
     for (auto &e : c->slab_ev) if (e) (void)hipEventDestroy(e);
   }
+}
+
+MfccDev Model::MfccWithDither(int frames) {
+  MfccDev m = mfcc_dev_;
+  m.dither = nullptr;
+  m.dither_value = fc_.mfcc.opts.dither;
+  if (m.dither_value == 0.0f || frames <= 0) return m;
+  std::lock_guard<std::mutex> lk(dither_mu_);
+  if (frames > dither_frames_) {
+    const int old = dither_frames_, want = std::max({frames, 2 * old, 1024});
+    const size_t win = (size_t)fc_.mfcc.win;
+    std::vector<float> host((size_t)(want - old) * win);
+    {
+      // host libm like the reference (the values are those of its RandGauss to the bit); a few worker threads for long audio
+      const int nthr = std::min(8, std::max(1, (want - old) / 512));
+      std::vector<std::thread> thr;
+      for (int k = 0; k < nthr; k++) {
+        const int a = old + (int)((long)(want - old) * k / nthr), b = old + (int)((long)(want - old) * (k + 1) / nthr);
+        thr.emplace_back([&, a, b]() { DitherNoise(dither_rand_calls_, a, b, (int)win, host.data() + (size_t)(a - old) * win); });
+      }
+      for (auto &t : thr) t.join();
+    }
+    float *d = nullptr;
+    RS_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)want * win));
+    dither_bufs_.push_back(d);
+    if (old) RS_HIP(hipMemcpy(d, d_dither_, sizeof(float) * (size_t)old * win, hipMemcpyDeviceToDevice));
+    RS_HIP(hipMemcpy(d + (size_t)old * win, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    d_dither_ = d;
+    dither_frames_ = want;
+  }
+  m.dither = d_dither_;
+  return m;
 }
 
 void *Model::UploadBytes(const void *p, size_t bytes) {
@@ -1264,12 +1301,12 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   if (fc_.use_cmvn) {
     raw = falloc(ld_c);
     poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, ld_c, s, OthersInFlight());
+    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, raw, ld_c, s, OthersInFlight());
     poison();
     LaunchOnlineCmvn(cmvn_nnet_dev_, g, raw, bufp[nn.input_buf], buf_ld[nn.input_buf], s);
   } else {
     poison();
-    LaunchMfcc(mfcc_dev_, g, d_pcm, raw, buf_ld[nn.input_buf], s, OthersInFlight());
+    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, raw, buf_ld[nn.input_buf], s, OthersInFlight());
   }
   const int raw_ld = fc_.use_cmvn ? ld_c : buf_ld[nn.input_buf];
   tm.Mark();

@@ -205,6 +205,14 @@ class Model {
   void PruneOutputLayer();
 
   MfccDev mfcc_dev_{};
+  // Dither noise of frames [0, dither_frames_) on the device (nnet3_setup.h: the reference's draws for frame t are a constant of
+  // the model).  Grows on demand; superseded buffers stay alive until the model goes (launches in flight may still read them).
+  MfccDev MfccWithDither(int frames);
+  std::mutex dither_mu_;
+  const float *d_dither_ = nullptr;
+  int dither_frames_ = 0;
+  long dither_rand_calls_ = 0;
+  std::vector<void *> dither_bufs_;
   CmvnDev cmvn_iv_dev_{}, cmvn_nnet_dev_{};
   IvecDev ivec_dev_{};
   LayerOp lda_op_;                    // splice + LDA of the iVector branch, as a segmented GEMM

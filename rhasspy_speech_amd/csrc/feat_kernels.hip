@@ -2,7 +2,7 @@
 // ivector_kernels.hip).  One 64-lane wavefront per frame for the per-frame kernels (CDNA4 wave64; never 32).
 //
 // Reference behaviour being reproduced (kaldi/src):
-//   feat/feature-window.cc:90-224 (DC removal, pre-emphasis, window, zero padding)
+//   feat/feature-window.cc:90-224 (dither, DC removal, pre-emphasis, window, zero padding)
 //   matrix/srfft.cc:356-432 + feat/feature-functions.cc:29-51 (real FFT -> 257-bin power spectrum)
 //   feat/mel-computations.cc:226-251, feat/feature-mfcc.cc:28-80 (mel, log, DCT, lifter)
 //   feat/online-feature.cc:337-452 + transform/cmvn.cc:64-91 (OnlineCmvn)
@@ -135,15 +135,33 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   float raw_energy = 0.f;
   if (active) {
     const int16_t *src = pcm + g.d_sample_off[u] + (int64_t)t * m.shift;
-    // 1. load (int16 -> float, unscaled), DC removal
-    float part = 0.f;
-    for (int i = lane; i < m.win; i += RS_WAVE) {
-      float v = (float)src[i];
-      x[i] = v;
-      part += v;
+    // 1. load (int16 -> float, unscaled), dither, DC removal.  The frame sum follows the reference's BLAS call
+    // (VectorBase::Sum() = cblas_sdot(n, x, 1, &one, 0), OpenBLAS kernel/x86_64/sdot.c strided loop): adjacent pairs are added
+    // in float and the pair sums accumulated in a double.  With integer samples every order gives the same sum; with the
+    // dither noise in, a differently rounded mean re-rounds every sample of a loud frame and moves the cepstra by 1e-3.  The
+    // double accumulation is a wave reduction here: the pair sums of a frame span far fewer than 53 bits, so it is exact in
+    // any order (it would take a pair cancelling to below 2^-33 of the frame's peak to make the order matter).
+    double dsum = 0.0;
+    const float *noise = m.dither ? m.dither + (size_t)(t + (g.d_frame0 ? g.d_frame0[u] : 0)) * m.win : nullptr;
+    for (int k = lane; 2 * k < m.win; k += RS_WAVE) {
+      const int i0 = 2 * k, i1 = i0 + 1;
+      float v0 = (float)src[i0];
+      if (noise) v0 += noise[i0] * m.dither_value;   // Dither(): data[i] += RandGauss(&rstate) * dither_value (no FMA: -ffp-contract=off)
+      x[i0] = v0;
+      if (i1 < m.win) {
+        float v1 = (float)src[i1];
+        if (noise) v1 += noise[i1] * m.dither_value;
+        x[i1] = v1;
+        dsum += (double)(v0 + v1);
+      } else {
+        dsum += (double)v0;
+      }
     }
     for (int i = m.win + lane; i < NFFT; i += RS_WAVE) x[i] = 0.f;
-    float mean = WaveSum(part) / (float)m.win;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, RS_WAVE);
+    const float mean = (float)dsum / (float)m.win;
+    WaveLdsSync();      // the sample pairs were written by other lanes than the ones that read them below
     if (m.remove_dc)
       for (int i = lane; i < m.win; i += RS_WAVE) x[i] -= mean;
     if (m.use_energy && m.raw_energy) {

@@ -23,6 +23,9 @@ struct BatchGeom {
   const int *d_frame_base = nullptr;      // n_utts + 1 (prefix sum of T_u; compact per-frame arrays)
   const int *d_row_utt = nullptr;         // total_rows: utterance of each row
   const int *d_row_t = nullptr;           // total_rows: clamped frame index t in [0, T_u) of each row
+  // streams: the launch covers frames [frame0[u], frame0[u] + T_u) of stream u, its sample_off points at frame0[u]'s first
+  // sample; what depends on the absolute frame index (the dither noise) adds it back.  null = 0.
+  const int *d_frame0 = nullptr;          // n_utts
 };
 
 // ---------------------------------------------------------------- MFCC
@@ -43,6 +46,10 @@ struct MfccDev {
   const float *fft_tw;       // 6 floats per twiddled butterfly
   const int *fft_perm;       // padded/2: bit-reversal pass as a gather
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
+  // Dither (feature-window.cc:90-98): sample i of frame t += dither[t * win + i] * dither_value, before DC removal.  The
+  // table holds the reference's own RandGauss draws for frame t of a fresh decoder process (nnet3_setup.h); null = off.
+  const float *dither;
+  float dither_value;
 };
 // feats: total_rows x ld (C columns used).  Writes every row (halo rows replicate edge frames).
 // out_rows (null = the row itself): physical row of `feats` that receives dense row i (streams write into pool rows).

@@ -1,4 +1,5 @@
 #include "model.h"
+#include "nnet3_setup.h"
 
 #include <algorithm>
 #include <cmath>
@@ -716,7 +717,21 @@ int Nnet::FindNode(const std::string &name) const {
   return -1;
 }
 
-void Nnet::Read(KaldiReader &r) {
+void ReadNnetComponents(KaldiReader &r, std::vector<std::string> *names, std::vector<Component> *comps) {
+  r.ExpectToken("<NumComponents>");
+  int nc = r.ReadInt32();
+  if (nc < 0 || nc >= 100000) Fail("bad <NumComponents>");
+  names->resize(nc);
+  comps->resize(nc);
+  for (int c = 0; c < nc; c++) {
+    r.ExpectToken("<ComponentName>");
+    (*names)[c] = r.ReadToken();
+    (*comps)[c] = ReadComponent(r);
+  }
+  r.ExpectToken("</Nnet3>");
+}
+
+void Nnet::Read(KaldiReader &r, int frames_per_chunk, int extra_left_context_initial) {
   r.ExpectToken("<Nnet3>");
   std::string line = r.ReadLine();
   if (!line.empty() && line.find_first_not_of(" \t") != std::string::npos) Fail("Expected newline in config file, got " + line);
@@ -727,17 +742,21 @@ void Nnet::Read(KaldiReader &r) {
     if (line.empty()) break;
     cfg.push_back(line);
   }
-  r.ExpectToken("<NumComponents>");
-  int nc = r.ReadInt32();
-  if (nc < 0 || nc >= 100000) Fail("bad <NumComponents>");
-  component_names.resize(nc);
-  components.resize(nc);
-  for (int c = 0; c < nc; c++) {
-    r.ExpectToken("<ComponentName>");
-    component_names[c] = r.ReadToken();
-    components[c] = ReadComponent(r);
+  ReadNnetComponents(r, &component_names, &components);
+  {
+    // CollapseModel + the rand() calls of the reference's set-up (nnet3_setup.h); RS_NO_COLLAPSE=1 keeps the layers as
+    // written (A/B of the rounding difference; the rand() count is that of the reference either way)
+    std::vector<std::string> names = component_names;
+    std::vector<Component> comps = components;
+    const char *e = std::getenv("RS_NO_COLLAPSE");
+    const bool keep_layers = e && e[0] == '1';
+    Nnet3SetupResult su = Nnet3Setup(cfg, keep_layers ? &names : &component_names, keep_layers ? &comps : &components, frames_per_chunk,
+                                     extra_left_context_initial);
+    setup_rand_calls = su.rand_calls;
+    setup_rand_certain = su.rand_calls_certain;
+    setup_rand_uncertain_why = su.uncertain_why;
+    if (!keep_layers) cfg = su.config;
   }
-  r.ExpectToken("</Nnet3>");
   // first pass: create nodes (names + dims), second pass: descriptors
   std::vector<std::map<std::string, std::string>> kvs;
   std::vector<std::string> firsts;
@@ -1079,10 +1098,10 @@ void Nnet::Compile() {
   }
 }
 
-void AcousticModel::Read(const std::string &final_mdl) {
+void AcousticModel::Read(const std::string &final_mdl, int frames_per_chunk, int extra_left_context_initial) {
   KaldiReader r(final_mdl);
   trans.Read(r);
-  nnet.Read(r);
+  nnet.Read(r, frames_per_chunk, extra_left_context_initial);
   r.ExpectToken("<LeftContext>");
   r.ReadInt32();
   r.ExpectToken("<RightContext>");

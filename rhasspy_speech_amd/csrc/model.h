@@ -198,15 +198,23 @@ struct Nnet {
   std::vector<BufferInfo> bufs;
   int input_buf = -1, output_buf = -1;
   int left_context = 0, right_context = 0;
-  void Read(KaldiReader &r);
+  // What the reference's binaries do to the network before the first frame (nnet3_setup.h): the network is the one
+  // CollapseModel leaves behind, and rand() has been called `setup_rand_calls` times (the dither seeds follow from that).
+  long setup_rand_calls = 0;
+  bool setup_rand_certain = true;
+  std::string setup_rand_uncertain_why;
+  void Read(KaldiReader &r, int frames_per_chunk = 24, int extra_left_context_initial = 0);
   void Compile();   // builds ops/bufs for the "output" node
   int FindNode(const std::string &name) const;
 };
 
+// <NumComponents> ... </Nnet3> (nnet-nnet.cc:608-621)
+void ReadNnetComponents(KaldiReader &r, std::vector<std::string> *names, std::vector<Component> *comps);
+
 struct AcousticModel {
   TransitionModel trans;
   Nnet nnet;
-  void Read(const std::string &final_mdl);
+  void Read(const std::string &final_mdl, int frames_per_chunk = 24, int extra_left_context_initial = 0);
 };
 
 // ---------------------------------------------------------------- HCLG

@@ -268,7 +268,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   std::vector<int> slots(n), row0s(n), avails(n);
   for (int i = 0; i < n; i++) { slots[i] = streams[i]->slot; row0s[i] = streams[i]->row0; avails[i] = pl[i].avail; }
   // stage 1: MFCC over the new frames (dense rows, no halo), rows -> pool
-  std::vector<int> m_T, m_rb{0}, m_out;
+  std::vector<int> m_T, m_rb{0}, m_out, m_f0;
   std::vector<int64_t> m_so{0};
   size_t pcm_total = 0;
   for (int i = 0; i < n; i++) {
@@ -277,6 +277,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     rs_stream &st = *streams[i];
     const long first = (long)pl[i].mf0 * shift, cnt = st.n_samples - first;
     m_T.push_back(tn);
+    m_f0.push_back(pl[i].mf0);
     m_rb.push_back(m_rb.back() + tn);
     m_so.push_back(m_so.back() + cnt);
     for (int t = 0; t < tn; t++) m_out.push_back(st.row0 + pl[i].mf0 + t);
@@ -284,6 +285,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   }
   const int nM = (int)m_T.size(), rowsM = m_rb.back();
   m_T.push_back(0);
+  m_f0.push_back(0);
   // stage 2: CMVN resumed (same streams)
   std::vector<int> c_T, c_rb, c_tb, c_slot;
   for (int i = 0; i < n; i++)
@@ -352,7 +354,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     w_b[i] = streams[i]->dec_started ? streams[i]->frames_decoded : -1;
     w_e[i] = pl[i].t1;
   }
-  const size_t o_mT = is.Add(m_T), o_mrb = is.Add(m_rb), o_mout = is.Add(m_out), o_mso = is.Add64(m_so);
+  const size_t o_mT = is.Add(m_T), o_mrb = is.Add(m_rb), o_mout = is.Add(m_out), o_mf0 = is.Add(m_f0), o_mso = is.Add64(m_so);
   const size_t o_cT = is.Add(c_T), o_crb = is.Add(c_rb), o_ctb = is.Add(c_tb), o_cslot = is.Add(c_slot);
   const size_t o_iT = is.Add(i_T), o_irb = is.Add(i_rb), o_isrc = is.Add(i_src), o_islot = is.Add(i_slot);
   const size_t o_sfb = is.Add(s_fb), o_sfe = is.Add(s_fe), o_sor = is.Add(s_or), o_sac = is.Add(s_ac);
@@ -403,10 +405,11 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     BatchGeom g;
     g.n_utts = nM; g.total_rows = rowsM; g.total_frames = rowsM;
     g.d_sample_off = reinterpret_cast<const int64_t *>(D(o_mso)); g.d_num_frames = D(o_mT); g.d_row_base = D(o_mrb);
+    g.d_frame0 = D(o_mf0);
     int *ru = arena.AllocT<int>(rowsM), *rt = arena.AllocT<int>(rowsM);
     LaunchRowGeometry(nM, rowsM, 0, D(o_mrb), nullptr, ru, rt, nullptr, q);
     g.d_row_utt = ru; g.d_row_t = rt;
-    LaunchMfcc(mfcc_dev_, g, d_pcm, p->raw, ld_c, q, false, D(o_mout));
+    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, p->raw, ld_c, q, false, D(o_mout));
     // ---------------------------------------------------------------- 2. CMVN, resumed
     BatchGeom gc;
     gc.n_utts = nM; gc.d_num_frames = D(o_cT); gc.d_row_base = D(o_crb);

@@ -166,7 +166,7 @@ class ModelSpec:
     tdnnf: bool = False              # use TdnnComponent + LinearComponent bottlenecks (coverage net)
     bottleneck_dim: int = 64
     chain_topology: bool = True      # forward/self-loop pdf classes (nnet3 chain models)
-    dither: float = 0.0
+    dither: Optional[float] = None   # None: no --dither line, i.e. the reference's default 1.0 like conf/mfcc_hires.conf (feature-window.h:57)
     nnet_cmvn: bool = False          # --cmvn-config on the nnet input branch
     binary: bool = True
     xent_branch: bool = True         # extra output-xent branch (ignored by decoding), as chain recipes have
@@ -612,9 +612,10 @@ def write_model_dir(model_dir: Path, spec: ModelSpec) -> None:
     conf = model_dir / "model" / "online" / "conf"
     conf.mkdir(parents=True, exist_ok=True)
     mfcc = ["--use-energy=false", f"--num-mel-bins={spec.num_mel_bins}", f"--num-ceps={spec.num_ceps}",
-            "--low-freq=20", "--high-freq=-400", "--sample-frequency=16000",
-            f"--dither={spec.dither}"]
-    (conf / "mfcc.conf").write_text("# hires MFCC (egs/wsj/s5/conf/mfcc_hires.conf) + explicit dither\n" + "\n".join(mfcc) + "\n")
+            "--low-freq=20", "--high-freq=-400", "--sample-frequency=16000"]
+    if spec.dither is not None:
+        mfcc.append(f"--dither={spec.dither}")
+    (conf / "mfcc.conf").write_text("# hires MFCC (egs/wsj/s5/conf/mfcc_hires.conf)\n" + "\n".join(mfcc) + "\n")
     online = ["--feature-type=mfcc", f"--mfcc-config={conf / 'mfcc.conf'}"]
     if spec.ivector_dim > 0:
         ie = model_dir / "model" / "online" / "ivector_extractor"

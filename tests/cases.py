@@ -37,6 +37,13 @@ CASES = {
     # 30 s: the CMVN window (600 frames) slides, max-count prior rescaling of the iVector stats saturates, 123 nnet chunks
     "zam_long30": dict(big=True, spec=dict(), graph="grammar", audio="synth:20:480000"),
     "zam_s12005": dict(big=True, spec=dict(), graph="grammar", audio="synth:12005:472320"),
+    # dither (feature-window.cc:90-98; on by default): digital silence -- the features are the reference's noise and nothing else --
+    # a few-LSB signal, --dither=0 and a --dither other than 1; every other case runs with the stock default 1.0
+    "tiny_silence": dict(spec=dict(), graph="grammar", audio="zeros:32000"),
+    "tiny_quiet_u10": dict(spec=dict(seed=7), graph="grammar", audio="synth:10:40000:0.002"),
+    "tiny_nodither_u11": dict(spec=dict(dither=0.0), graph="grammar", audio="synth:11:36000"),
+    "tiny_dither05_u12": dict(spec=dict(dither=0.5, ivector_dim=0), graph="grammar", audio="synth:12:36000:0.01"),
+    "zam_quiet_u13": dict(big=True, spec=dict(), graph="grammar", audio="synth:13:48000:0.003"),
 }
 NBEST = 5
 
@@ -48,7 +55,12 @@ def case_spec(case: dict) -> synth.ModelSpec:
 def case_audio(case: dict, golden_dir: Path = GOLDEN) -> np.ndarray:
     kind, *rest = case["audio"].split(":")
     if kind == "synth":
-        return synth.synth_utterance(int(rest[0]), int(rest[1]))
+        pcm = synth.synth_utterance(int(rest[0]), int(rest[1]))
+        if len(rest) > 2:      # scaled down to a few LSB
+            pcm = np.round(pcm.astype(np.float64) * float(rest[2])).astype(np.int16)
+        return pcm
+    if kind == "zeros":
+        return np.zeros(int(rest[0]), np.int16)
     with wave.open(str(golden_dir / "wav" / rest[0]), "rb") as w:
         assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
         return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()

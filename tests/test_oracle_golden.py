@@ -6,7 +6,8 @@ import pytest
 from tests import cases
 
 FAST = ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tiny_real_time", "tiny_text_u1", "tiny_noiv_u2", "tiny_cmvn_u4", "tinyf_u5",
-        "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold", "zam_long30", "zam_s12005"]
+        "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold", "zam_long30", "zam_s12005",
+        "tiny_silence", "tiny_quiet_u10", "tiny_nodither_u11", "tiny_dither05_u12", "zam_quiet_u13"]
 
 
 def parse_nbest(text: bytes):
@@ -35,9 +36,11 @@ def test_oracle_matches_reference(oracles, name):
     tr = orc.transcribe(pcm, nbest=cases.NBEST)
     assert tr.num_frames == int(g["offline_num_frames"])
     fd = np.abs(tr.feats - g["input"])
+    # the dither is the reference's to the bit (oracle/dither.c), so is the frame sum behind the DC offset (pipeline.frame_sum),
     # the FFT is the reference's own, operation for operation, and the mel filter edges come from the same libm logf; what is
     # left is the order of the BLAS sums (mel, DCT) times the cepstral lifter (up to 12)
     assert fd.max() < 2e-4 and np.quantile(fd, 0.99) < 1e-4
+    assert int(g["rand_calls"]) == orc.rand_calls or orc.mfcc.o.dither == 0.0
     if "offline_ivector" in g:
         assert np.abs(tr.ivector - g["offline_ivector"][0]).max() < 1e-4
     sr, sc = g["loglikes_stride"]
@@ -64,7 +67,8 @@ def test_oracle_intermediate_ivector_features(oracles):
     assert np.abs(nrm - g["lda_norm"]).max() < 2e-4
 
 
-@pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7", "zam_long30", "zam_s12005"])
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tinyf_u5", "tiny_noiv_u2", "tiny_cmvn_u4", "tiny_arpa_u7", "zam_long30", "zam_s12005",
+                                  "tiny_silence", "tiny_quiet_u10", "tiny_dither05_u12"])
 def test_oracle_streaming_matches_reference(oracles, name):
     """online2-cli-nnet3-decode-faster goldens: per-chunk iVectors, log-likelihoods, n-best text."""
     g = np.load(cases.GOLDEN / f"{name}.npz")
@@ -126,3 +130,94 @@ def test_oracle_matches_random_case_goldens(tmp_path, i):
     assert tr.text().split() == gold["nbest_text"].encode().split()
     np.testing.assert_allclose([p.graph_cost for p in tr.nbest], gold["graph_cost"], rtol=2e-4, atol=2e-3)
     np.testing.assert_allclose([p.acoustic_cost for p in tr.nbest], gold["acoustic_cost"], rtol=2e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------ dither
+
+def test_dither_table_is_the_references():
+    """oracle/dither.c (glibc rand() + rand_r() + RandGauss restated) against the noise the reference's own Dither() produced in a
+    fresh process (rs-dump dither, oracle/gen_golden.py): bit for bit."""
+    from oracle import pipeline
+    g = np.load(cases.GOLDEN / "dither_ref.npz")
+    for key in g.files:
+        ref = g[key]
+        got = pipeline.dither_table(ref.shape[0], ref.shape[1], 0)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), key
+
+
+def test_glibc_rand_restated():
+    """The TYPE_3 generator of oracle/dither.c against libc itself (srand(1) = the state of a fresh process)."""
+    import ctypes
+    from oracle import nnet3_rand
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    want = [libc.rand() for _ in range(5000)]
+    r = nnet3_rand.GlibcRand()
+    assert [r.rand() for _ in range(5000)] == want
+
+
+def test_frame_sum_is_the_blas_order():
+    """pipeline.frame_sum against cblas_sdot(n, x, 1, &one, 0) of the OpenBLAS the reference build links (the one inside SciPy):
+    VectorBase::Sum() of the reference, which decides the rounding of the DC offset once the samples carry dither noise."""
+    import ctypes, glob, os
+    import scipy
+    from oracle import pipeline
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if not libs:
+        pytest.skip("SciPy's OpenBLAS not found")
+    f = ctypes.CDLL(libs[0]).scipy_cblas_sdot
+    f.restype = ctypes.c_float
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    one = np.ones(1, np.float32)
+    rng = np.random.default_rng(5)
+    for n in (400, 200, 275):
+        x = (rng.integers(-8000, 8000, (64, n)) * (rng.random((64, 1)) < 0.8) + rng.standard_normal((64, n))).astype(np.float32)
+        want = np.array([f(n, np.ascontiguousarray(r).ctypes.data, 1, one.ctypes.data, 0) for r in x], np.float32)
+        assert np.array_equal(pipeline.frame_sum(x).view(np.uint32), want.view(np.uint32)), n
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_setup_rand_calls_match_reference(name):
+    """How often the reference's model set-up calls rand() before the first frame (rs-dump randpos on the reference's own
+    classes, stored by gen_golden.py): the oracle's restatement (oracle/nnet3_rand.py) and the library's (rs_nnet3_setup,
+    csrc/nnet3_setup.cc; host code, no device needed) both reproduce it exactly, and the library's collapsed network is the
+    reference's (one GEMM less: lda folded into the first affine layer)."""
+    import ctypes as C
+    import tempfile
+    from pathlib import Path
+    from oracle import kaldi_formats as kf, nnet3_rand
+    from rhasspy_speech_amd import synth
+    from rhasspy_speech_amd._lib import load_library
+    g = np.load(cases.GOLDEN / f"{name}.npz")
+    want = int(g["rand_calls"])
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_model_dir(Path(td) / "m", cases.case_spec(cases.CASES[name]))
+        mdl = Path(td) / "m" / "model" / "model" / "final.mdl"
+        _, nf = kf.read_final_mdl(mdl)
+        assert nnet3_rand.setup_rand_calls(nf) == want
+        lib = load_library()
+        lib.rs_nnet3_setup.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
+        n, cert, buf = C.c_int64(), C.c_int32(), C.create_string_buffer(1 << 16)
+        assert lib.rs_nnet3_setup(str(mdl).encode(), 24, C.byref(n), C.byref(cert), buf, len(buf)) == 0
+        assert (n.value, cert.value) == (want, 1)
+        cfg = buf.value.decode()
+        assert "component-node name=lda " not in cfg and "component=lda.tdnn1.affine" in cfg
+
+
+def test_library_dither_noise_is_the_references():
+    """rs_dither_noise (the table the MFCC kernel reads) against the reference's Dither() and, at an offset, the oracle's table."""
+    import ctypes as C
+    from oracle import pipeline
+    from rhasspy_speech_amd._lib import load_library
+    lib = load_library()
+    lib.rs_dither_noise.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    g = np.load(cases.GOLDEN / "dither_ref.npz")
+    for key in g.files:
+        ref = g[key]
+        got = np.zeros_like(ref)
+        assert lib.rs_dither_noise(0, 0, ref.shape[0], ref.shape[1], got.ctypes.data) == 0
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), key
+    want = pipeline.dither_table(40, 400, 7741)[30:40]
+    got = np.zeros_like(want)
+    assert lib.rs_dither_noise(7741, 30, 40, 400, got.ctypes.data) == 0
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
