@@ -12,17 +12,20 @@ genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iV
 TDNN + prefinal, 2000 pdfs); audio is synthetic (seeded).
 
 A "step" is one pass of the whole path (MFCC -> iVector -> TDNN -> beam search -> word ids) over the workload's batch.
-`value` counts steps whose int16 samples are resident in HBM when the timed region starts (rs_decode_batch_device); the
-same run also times the boundary as SURVEY.md section 8(d) words it -- PCM in HOST memory -> word ids in host memory,
-rs_decode_batch -- and reports it as `host_pcm` (PCIe-inclusive; for `streams` and `mixed` the entry points take host
-buffers, so there `value` IS the host-buffer figure and says so).  The K timed steps are submitted from a few host threads
-(`--inflight`, default 4) so that consecutive batches overlap on the device, as a serving process would run them.  Every
-step's records are checked against the first step's and -- rank 0 -- against the REFERENCE's transcripts
-(tests/golden/configs).  Stage times and the roofline are taken from un-overlapped calls right after the timed region.
+`value` is SURVEY.md section 8(d)'s timed region: int16 PCM in pageable HOST memory -> word ids in host memory, model and
+graph resident (rs_decode_batch; rs_decode_batch_sharded at N > 1; rs_stream_* for `streams`) -- PCIe-inclusive.  Beside it,
+each over the same number of steps: `hbm_resident` (the samples already in HBM when the timed region starts,
+rs_decode_batch_device), `reference_output_layer` (host PCM AND the output layer evaluated for all 2000 pdfs, which is
+literally what the reference computes; the library default evaluates the 362 pdfs that occur on HCLG arcs: same words, same
+costs) and `hbm_resident_all_pdfs`.  The K timed steps are submitted from a few host threads (`--inflight`, default 4) so
+that consecutive batches overlap on the device, as a serving process would run them.  Every step's records are checked
+against the first step's and -- rank 0 -- against the REFERENCE's transcripts (tests/golden/configs).  Stage times and the
+roofline are taken from un-overlapped calls right after the timed region.
 
 Multi-GPU (driver: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): utterances shard
-embarrassingly, one process per GPU, weak scaling, no data-path collective; fixed-size result records are gathered over
-RCCL (all_gather) inside the timed region.
+embarrassingly (utterance i -> rank i % N, rs_decode_batch_sharded), one process per GPU, weak scaling, no data-path
+collective; the fixed-size result records are gathered inside the timed region by ONE ncclAllGather per step issued by the
+library itself (rs_shard_gather on torch.distributed's RCCL communicator; torch's all_gather when that is not available).
 
 Prints ONE JSON line (rank 0) with the fields the driver expects plus `roofline` and `cpu_baseline`.
 """
@@ -58,10 +61,10 @@ def nnet_flops_per_row(desc: str) -> float:
 
 def pmc_traffic(workload: str, kernel_substr: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round
-    (profiles/collect.sh -> profiles/r02/<workload>_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KB, the doubling per
+    (profiles/collect.sh -> profiles/r03/<workload>_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KB, the doubling per
     MI355X_MICROARCH.md (128-B requests of streaming reads tallied at 64 B on gfx950).  None when no summary of this round
     is committed for the workload -- the line never carries a stale figure."""
-    path = ROOT / "profiles" / "r02" / f"{workload}_pmc.json"
+    path = ROOT / "profiles" / "r03" / f"{workload}_pmc.json"
     if not path.exists():
         return None, None
     ks = json.loads(path.read_text())["kernels"]
@@ -148,13 +151,14 @@ def main() -> None:
     ap.add_argument("--workload", choices=["grammar", "arpa", "mixed", "streams"], default="grammar")
     ap.add_argument("--utts", type=int, default=None, help="utterances (streams) per GPU; default = the configuration's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-figures", action="store_true", help="time the headline only (profiling runs)")
     ap.add_argument("--inflight", type=int, default=None,
                     help="decode calls in flight per rank (host threads on one model; the library gives each its own decode "
                          "context): the latency-bound search of one batch overlaps the GEMMs of the next.  1 = one call at a time")
     ap.add_argument("--all-pdfs", action="store_true",
-                    help="rs_decode_opts.prune_output_pdfs=0: evaluate the output layer for every pdf like the reference does.  The "
-                         "library's default evaluates it for the pdfs that occur on HCLG arcs only (the search can read no others; "
-                         "same words, same costs); a default run reports the all-pdfs figure beside the headline as `all_pdfs`")
+                    help="rs_decode_opts.prune_output_pdfs=0 for the headline too: evaluate the output layer for every pdf like the "
+                         "reference does.  The library's default evaluates it for the pdfs that occur on HCLG arcs only (the search can "
+                         "read no others; same words, same costs); a default run reports the all-pdfs figure as `reference_output_layer`")
     args = ap.parse_args()
     wl = args.workload
     defaults = {"grammar": (600, 20, 4), "arpa": (40, 3, 2), "mixed": (150, 5, 2), "streams": (40, 2, 1)}[wl]
@@ -177,17 +181,39 @@ def main() -> None:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     comm_device = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+    comm_ptr, gather_by = 0, "none (one rank)"
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        gather_by = f"torch.distributed.all_gather ({backend})"
+        if backend == "nccl" and os.environ.get("RS_BENCH_GATHER", "rccl") == "rccl":
+            # the library issues the ncclAllGather itself on torch's communicator (the same librccl.so.1 in this process); every
+            # rank has to agree on the route, so the ranks vote
+            try:
+                t = torch.zeros(1, device=comm_device)
+                dist.all_reduce(t)                       # the communicator exists after the first collective
+                torch.cuda.synchronize()
+                pg = dist.distributed_c10d._get_default_group()
+                comm_ptr = int(pg._get_backend(torch.device("cuda", local_rank))._comm_ptr())
+            except Exception:                            # older torch: no _comm_ptr
+                comm_ptr = 0
+            ok = torch.tensor([1 if comm_ptr else 0], device=comm_device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm_ptr = 0
+            else:
+                gather_by = "rs_shard_gather: one ncclAllGather per step issued by the library on torch.distributed's RCCL communicator"
 
     from rhasspy_speech_amd import _lib, shard
     from tests import configs
     cache = Path(tempfile.gettempdir()) / f"rs_bench_{wl}_rank{rank}"
     opts = dict(device_id=local_rank, prune_output_pdfs=0 if args.all_pdfs else 1)
     golden = None
+    sharded = world > 1 or wl == "mixed"        # through rs_decode_batch_sharded: records are (global utterances, 68)
+    decode_dev = None
+    d_pcm = offsets = None
     # ---- the workload: models, inputs, one step, and how its records compare with the reference's goldens
     if wl in ("grammar", "arpa"):
         n_utts = args.utts or 256
@@ -196,21 +222,30 @@ def main() -> None:
         model = _lib.Model(model_dir, graph_dir, _lib.default_opts(**opts))
         model.to_device()
         models = [model]
-        d_pcm = torch.from_numpy(np.concatenate(pcms)).to(f"cuda:{local_rank}")
-        offsets = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
-        audio_seconds = float(offsets[-1]) / 16000.0
+        audio_seconds = sum(len(p) for p in pcms) / 16000.0
         if rank == 0 and n_utts == 256:
             golden = configs.load_golden("c1_grammar" if wl == "grammar" else "c2_arpa")
+        n_global = n_utts * world
+        if not sharded:
+            d_pcm = torch.from_numpy(np.concatenate(pcms)).to(f"cuda:{local_rank}")
+            offsets = np.concatenate([[0], np.cumsum([len(p) for p in pcms])]).astype(np.int64)
 
-        def decode():
-            return model.decode_batch_device(d_pcm.data_ptr(), offsets)
+            def decode():
+                return model.decode_batch(pcms)
 
-        def decode_host():
-            return model.decode_batch(pcms)
+            def decode_dev():
+                return model.decode_batch_device(d_pcm.data_ptr(), offsets)
+        else:
+            # weak scaling: 256 utterances per rank; global utterance i belongs to rank i % world and is that rank's utterance i // world
+            g_pcms = [pcms[i // world] if i % world == rank else None for i in range(n_global)]
+            g_model = [0] * n_global
 
-        def records(res):
-            return res.pack(MAX_WORDS)
-        workload_name = (f"zamia-like-S synthetic Kaldi model (40-dim MFCC, 100-dim iVector, 7x250 TDNN, 2000 pdfs), "
+            def decode():
+                rec, st, msg = _lib.decode_batch_sharded(models, g_model, g_pcms, rank, world, 0)
+                if st != 0:
+                    raise SystemExit(f"bench.py: rs_decode_batch_sharded failed: {msg}")
+                return rec
+        workload_name = (f"zamia-like-S synthetic Kaldi model (40-dim MFCC with the reference's default dither, 100-dim iVector, 7x250 TDNN, 2000 pdfs), "
                          f"{'grammar' if wl == 'grammar' else 'back-off ARPA-LM'} HCLG, {n_utts} x 3 s utterances per GPU, beam 24 / max-active 7000 / lattice-beam 8")
     elif wl == "streams":
         n_utts = args.utts or 64
@@ -224,6 +259,8 @@ def main() -> None:
             golden = configs.load_golden("c4_streams")
         tick = 1024 * 8          # samples handed over per stream and round: 8 of the binary's 1024-sample reads
         n_rounds = (max(len(p) for p in pcms) + tick - 1) // tick
+        sharded = False          # streams stay on their rank; at N > 1 the ranks run replicas and the records are gathered by torch
+        n_global = n_utts * world
 
         def decode():
             streams = [_lib.Stream(model) for _ in pcms]
@@ -233,10 +270,6 @@ def main() -> None:
                         s.accept(p[r * tick:(r + 1) * tick])
                 _lib.advance_streams(streams)
             return _lib.finish_streams(streams)
-        decode_host = None
-
-        def records(res):
-            return res.pack(MAX_WORDS)
         workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU fed in {tick}-sample "
                          f"rounds (online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one iVector per 24-frame nnet chunk)")
     else:   # mixed
@@ -249,7 +282,7 @@ def main() -> None:
             by_name[key].to_device()
         models = list(by_name.values())
         model, model_dir, graph_dir = models[0], md, gd
-        n_utts = len(pcms)
+        n_utts = n_global = len(pcms)
         audio_seconds = sum(len(p) for i, p in enumerate(pcms) if i % world == rank) / 16000.0      # this rank's share (strong split)
         if rank == 0 and n_per == 512:
             gd_, gf_ = configs.load_golden("c3_mixed_de"), configs.load_golden("c3_mixed_fr")
@@ -265,20 +298,24 @@ def main() -> None:
             if st != 0:
                 raise SystemExit(f"bench.py: rs_decode_batch_sharded failed: {msg}")
             return rec
-        decode_host = None
-
-        def records(rec):
-            return rec[rank::world]
         workload_name = (f"two independently seeded zamia-like-S model + grammar-HCLG sets (de_DE-like / fr_FR-like), {n_utts} x ~3 s utterances "
                          f"interleaved, utterance i -> rank i % {world} (rs_decode_batch_sharded), one record gather")
 
+    def records(res):
+        """this step's records of THIS rank: sharded -> the (global, 68) array with the rank's rows filled; else rs_result_pack."""
+        return res if sharded else res.pack(MAX_WORDS)
+
     def gather(rec):
-        if world > 1:
-            t = torch.from_numpy(np.ascontiguousarray(rec)).to(comm_device)
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)       # the path's one exchange step: fixed-size result records over RCCL/xGMI
-            rec = torch.cat(out).cpu().numpy()
-        return rec
+        """the path's one exchange step: fixed-size result records to every rank (RCCL over xGMI)"""
+        if world == 1:
+            return rec
+        if sharded and comm_ptr:
+            return _lib.shard_gather(rec, local_rank, rank, world, comm_ptr)
+        local = rec[rank::world] if sharded else rec
+        t = torch.from_numpy(np.ascontiguousarray(local)).to(comm_device)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).cpu().numpy()
 
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(inflight, 1))
 
@@ -294,18 +331,31 @@ def main() -> None:
             last = (res, rec)
         return last
 
+    def timed(n, fn, check_against):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        run_steps(n, fn, check_against)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
     res, ref_rec = run_steps(1, decode)
     # rank 0's transcripts against the REFERENCE's (tests/golden/configs: oracle/_ref binaries on the same inputs)
     checked_vs_reference = None
     if golden is not None:
         mine = records(res)
-        idx = list(range(rank, n_utts, world)) if wl == "mixed" else list(range(n_utts))
+        if sharded:
+            idx = list(range(rank, n_global, world))
+            mine = mine[rank::world]
+            gold_of = (lambda i: i) if wl == "mixed" else (lambda i: i // world)
+        else:
+            idx = list(range(n_utts))
+            gold_of = lambda i: i
         wrong = 0
         for row, i in zip(mine, idx):
-            if wl == "mixed":
-                ok = row[1] == 0 and list(row[3:3 + row[2]]) == list(golden[0][i])
+            if sharded:
+                ok = row[1] == 0 and list(row[3:3 + row[2]]) == list(golden[0][gold_of(i)])
             else:
-                ok = row[0] == 0 and list(row[2:2 + row[1]]) == list(golden[0][i])
+                ok = row[0] == 0 and list(row[2:2 + row[1]]) == list(golden[0][gold_of(i)])
             wrong += 0 if ok else 1
         if wrong:
             raise SystemExit(f"bench.py: {wrong} of {len(idx)} transcripts differ from the reference's (tests/golden/configs)")
@@ -324,53 +374,50 @@ def main() -> None:
         t = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # ---- the same steps from HOST buffers (PCM in host memory -> word ids in host memory)
-    host_pcm = None
-    if decode_host is not None:
-        n_host = max(4, steps // 4)
-        run_steps(2, decode_host, ref_rec)
-        torch.cuda.synchronize()
-        th = time.perf_counter()
-        run_steps(n_host, decode_host, ref_rec)
-        torch.cuda.synchronize()
-        eh = time.perf_counter() - th
-        host_pcm = {"value": world * audio_seconds * n_host / eh, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * eh / n_host, "steps": n_host,
-                    "note": "rs_decode_batch: int16 PCM in pageable host memory -> word ids in host memory (PCIe-inclusive); this rank's rate x n_gpus"}
-    # ---- the same steps with the output layer evaluated for every pdf, as the reference does (a second model; grammar / arpa only)
-    all_pdfs = None
-    if wl in ("grammar", "arpa") and not args.all_pdfs:
-        full = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank, prune_output_pdfs=0))
-        full.to_device()
 
-        def decode_full():
-            return full.decode_batch_device(d_pcm.data_ptr(), offsets)
-        n_full = max(4, steps // 4)
-        _, full_rec = run_steps(2, decode_full)
-        # same transcripts (the costs may differ in the last bits: the narrower layer takes another GEMM tile shape)
-        if not np.array_equal(full_rec[:, :2 + MAX_WORDS], ref_rec[:, :2 + MAX_WORDS]):
-            raise SystemExit("bench.py: the all-pdfs model decodes different transcripts")
-        torch.cuda.synchronize()
-        tf = time.perf_counter()
-        run_steps(n_full, decode_full, full_rec)
-        torch.cuda.synchronize()
-        ef = time.perf_counter() - tf
-        all_pdfs = {"value": world * audio_seconds * n_full / ef, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * ef / n_full, "steps": n_full,
-                    "note": "rs_decode_opts.prune_output_pdfs = 0: output layer for all pdfs; identical transcripts (checked)"}
-        # its nnet stage (un-overlapped calls): EVERY launch of it runs on the split-bf16 kernels -- the stage the roofline prices
-        full_stage = np.zeros(8)
-        for _ in range(5):
-            full_stage += np.array(decode_full().timings())
-        full_stage /= 5
-        all_pdfs["nnet_stage_ms"] = float(full_stage[3])
-        all_pdfs["desc"] = full.describe()
-        del full
+    def figure(n, secs, note):
+        return {"value": audio_seconds * n / secs, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * secs / n, "steps": n, "note": note}
+
+    # ---- side figures (one GPU, grammar / arpa), each over the same number of steps as the headline
+    side = {}
+    all_pdfs_stage = None
+    if decode_dev is not None and not args.no_side_figures:
+        run_steps(2, decode_dev, ref_rec)
+        side["hbm_resident"] = figure(steps, timed(steps, decode_dev, ref_rec),
+                                      "rs_decode_batch_device: the int16 samples are resident in HBM when the timed region starts")
+        if not args.all_pdfs:
+            full = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank, prune_output_pdfs=0))
+            full.to_device()
+
+            def full_host():
+                return full.decode_batch(pcms)
+
+            def full_dev():
+                return full.decode_batch_device(d_pcm.data_ptr(), offsets)
+            _, full_rec = run_steps(2, full_host)
+            # same transcripts (the costs may differ in the last bits: the narrower layer takes another GEMM tile shape)
+            if not np.array_equal(full_rec[:, :2 + MAX_WORDS], ref_rec[:, :2 + MAX_WORDS]):
+                raise SystemExit("bench.py: the all-pdfs model decodes different transcripts")
+            side["reference_output_layer"] = figure(steps, timed(steps, full_host, full_rec),
+                                                    "host PCM -> host word ids AND rs_decode_opts.prune_output_pdfs = 0 (output layer for all pdfs): "
+                                                    "the reference's own computation; identical transcripts (checked)")
+            run_steps(2, full_dev, full_rec)
+            side["hbm_resident_all_pdfs"] = figure(steps, timed(steps, full_dev, full_rec), "rs_decode_batch_device, output layer for all pdfs")
+            # its nnet stage (un-overlapped calls): EVERY launch of it runs on the split-bf16 kernels -- the stage the roofline prices
+            full_stage = np.zeros(8)
+            for _ in range(5):
+                full_stage += np.array(full_dev().timings())
+            all_pdfs_stage = (float(full_stage[3] / 5), full.describe())
+            del full
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
     stage, counters, n_iso = np.zeros(8), np.zeros(8), 0
-    if wl != "mixed":
+    staged = not sharded and world == 1
+    if staged:
         n_iso = 5 if wl != "streams" else 2
+        iso = decode_dev if decode_dev is not None else decode
         for _ in range(n_iso):
-            r1 = decode()
+            r1 = iso()
             stage += np.array(r1.timings())
         stage /= n_iso
         for u in range(n_utts):
@@ -393,25 +440,27 @@ def main() -> None:
             "config": {"workload": workload_name, "utts_per_gpu": n_utts if wl != "mixed" else n_utts // world, "parallelism": f"utterance-sharded x{world}",
                        "output_layer": "all pdfs (--all-pdfs)" if args.all_pdfs else "the pdfs that occur on HCLG arcs (library default)",
                        "calls_in_flight": inflight,
-                       "inputs": "int16 PCM resident in HBM at the start of the timed region" if decode_host is not None else "int16 PCM in host memory (the entry point takes host buffers)"},
+                       "inputs": "int16 PCM in pageable host memory -> word ids in host memory (SURVEY 8(d)'s timed region; PCIe-inclusive)",
+                       "entry_point": ("rs_stream_accept / rs_streams_advance / rs_streams_finish" if wl == "streams" else
+                                       "rs_decode_batch_sharded" if sharded else "rs_decode_batch"),
+                       "record_gather": gather_by},
             "timed_seconds": elapsed,
             "results_checked": "every step's result records equal the first step's (same input)" + (f"; {checked_vs_reference}" if checked_vs_reference else ""),
-            "host_pcm": host_pcm,
-            "all_pdfs": all_pdfs,
         }
-        if wl != "mixed":
+        out.update(side)
+        if staged:
             # decoder algorithmic bytes: arcs examined x (16 B arc + 4 B loglike), token insertions x 16 B,
             # tokens alive x 16 B token record
             dec_bytes = counters[1] * 20.0 + counters[2] * 16.0 + counters[3] * 16.0
             split_bf16 = os.environ.get("RS_GEMM_B3", "1") != "0"
             peak = 2500.0 / 6.0 if split_bf16 else 157.3
             nnet_ms, roof_on = float(stage[3]), "this run's model"
-            if all_pdfs is not None:
+            if all_pdfs_stage is not None:
                 # the default model evaluates its pruned output layer (362 of 2000 columns) on the exact-FP32 kernel; the roofline
-                # is priced on the all-pdfs model of the same run, whose ten launches all run on the split-bf16 kernels
+                # is priced on the all-pdfs model of the same run, whose launches all run on the split-bf16 kernels
                 # (round 1's definition of the stage)
-                nnet_ms, roof_on = all_pdfs.pop("nnet_stage_ms"), "the all-pdfs model of the same run (every launch of the stage on the split-bf16 kernels)"
-                flops = nnet_flops_per_row(all_pdfs.pop("desc")) * frames
+                nnet_ms, roof_on = all_pdfs_stage[0], "the all-pdfs model of the same run (every launch of the stage on the split-bf16 kernels)"
+                flops = nnet_flops_per_row(all_pdfs_stage[1]) * frames
             achieved = flops / (nnet_ms * 1e-3) / 1e12 if nnet_ms > 0 else 0.0
             traffic, traffic_from = pmc_traffic(wl, "GemmKernelB3" if split_bf16 else "GemmKernel")
             roof_mfma = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_from": traffic_from,
@@ -424,17 +473,16 @@ def main() -> None:
                         "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0 if stage[4] > 0 else 0.0, "traffic": dtraffic, "traffic_from": dtraffic_from,
                         "algorithmic_bytes": dec_bytes,
                         "kernel": "beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
-            if all_pdfs is not None:
-                all_pdfs.pop("nnet_stage_ms", None); all_pdfs.pop("desc", None)
             roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
-            out["stages_from"] = f"{n_iso} un-overlapped calls after the timed region"
+            out["stages_from"] = f"{n_iso} un-overlapped calls after the timed region (samples resident in HBM)"
             out["roofline"] = roofline
             out["stages_ms"] = {"mfcc": float(stage[1]), "ivector": float(stage[2]), "nnet": float(stage[3]), "decode": float(stage[4]),
                                 "d2h+host": float(stage[5]), "total_call": float(stage[6])}
             out["other_roofline"] = roof_dec if roofline is roof_mfma else roof_mfma
         else:
             out["roofline"] = None
-            out["roofline_note"] = "the mixed batch runs the grammar workload's kernels on two models side by side; see --workload grammar for the roofline"
+            out["roofline_note"] = ("the mixed batch runs the grammar workload's kernels on two models side by side; see --workload grammar for the roofline"
+                                    if wl == "mixed" else "stage times and the roofline are measured at N = 1 (un-overlapped calls)")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model_dir, graph_dir, pcms if wl != "mixed" else [p for nm, p in zip(names, pcms) if nm == list(by_name)[-1]],
                                                streaming=(wl == "streams"))

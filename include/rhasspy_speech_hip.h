@@ -101,9 +101,11 @@ void rs_stream_free(rs_stream *stream);
 /* Many concurrent streams (BASELINE.json config 5).  The reference's streaming result is a deterministic function
  * of the sample sequence: which frames each nnet chunk's iVector has seen follows from the 1024-sample tick
  * schedule alone (decodable-online-looped.cc:56-84,186-194), not from wall-clock time.  The library therefore
- * reproduces it exactly from the buffered samples; rs_streams_advance is a scheduling hint (currently a no-op that
- * validates its arguments) and rs_streams_finish ends all listed streams (stdin EOF) and decodes them as ONE
- * device batch; result utterance i belongs to streams[i]. */
+ * reproduces it exactly from the samples accepted so far: rs_streams_advance does, batched over the listed streams, all the
+ * device work those samples make possible (MFCC of the completed frames, the iVector estimates and nnet chunks of the ticks
+ * reached, the search over the new rows -- what online2-cli-nnet3-decode-faster.cc:143-161 does per tick), so that
+ * rs_streams_finish (stdin EOF for all listed streams) only has the tail left; result utterance i belongs to streams[i].
+ * An advance that fails leaves the streams it listed unusable (every later call on them except rs_stream_free is refused). */
 int rs_streams_advance(rs_stream *const *streams, int32_t n_streams);
 int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale,
                       rs_result **out);
@@ -151,6 +153,12 @@ int rs_result_pack(const rs_result *r, int32_t max_words, int32_t *out);
 int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int32_t *utt_model, const int16_t *const *pcm,
                             const int32_t *n_samples, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm,
                             int32_t *records);
+/* The exchange step of rs_decode_batch_sharded on its own: `records` holds this rank's records at their utterance indices (what
+ * rs_decode_batch_sharded leaves when called with rccl_comm = NULL); ONE ncclAllGather over `rccl_comm` later it holds every
+ * rank's.  For hosts that keep several decode calls in flight: the collectives of one communicator must be issued in the same
+ * order on every rank, so such a host decodes from its worker threads and gathers from one thread in step order.  The
+ * reference has no counterpart (one process per utterance, tools.py:117-147); `device_id` = the rank's GPU. */
+int rs_shard_gather(int32_t device_id, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm, int32_t *records);
 
 /* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
  * (n x D_iv: one row offline, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */

@@ -84,7 +84,8 @@ if [ "${RS_BUILD_FST_TOOLS:-1}" = "1" ] && [ -d "$F/script" ]; then
     src="{}"; obj="$OUT/obj_fst/$(basename "${src%.cc}").o"
     if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ]; then eval g++ $FSTFLAGS_STR -c "$src" -o "$obj"; fi'
   g++ -shared -o "$OUT/libfstscript_ref.so" "$OUT"/obj_fst/*.o
-  for t in fstcompile fstarcsort fstcompose fstshortestpath fstrmepsilon fsttopsort fstproject fstprint fstconvert fstequivalent fstinfo; do
+  for t in fstcompile fstarcsort fstcompose fstshortestpath fstrmepsilon fsttopsort fstproject fstprint fstconvert fstequivalent fstinfo \
+           fstdeterminize fstminimize; do      # (the last two: KaldiTrainer._create_grammar, kaldi.py:321-341)
     if [ ! -f "$OUT/bin/$t" ] || [ "$F/bin/$t.cc" -nt "$OUT/bin/$t" ]; then
       g++ "${FSTFLAGS[@]}" "$F/bin/$t.cc" "$F/bin/$t-main.cc" -o "$OUT/bin/$t" -L"$OUT" -lfstscript_ref -lkaldi_ref -Wl,-rpath,'$ORIGIN/..' \
           -L"$LIBDIR" -l:"$(basename "$BLAS")" -Wl,-rpath,"$LIBDIR" -lpthread -ldl &

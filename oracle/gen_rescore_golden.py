@@ -43,8 +43,12 @@ LANGS = {
     "same_vocab": dict(keep_every=2, extra_sentences=6, backoff=False),
     # a back-off bigram G over the new sentences (phi arcs are taken), fewer words than the old graph knows
     "backoff": dict(keep_every=3, extra_sentences=10, backoff=True),
+    # a grammar the way hassil_fst + KaldiTrainer._create_grammar (kaldi.py:311-341) make it: <eps> arcs (the weighted arc from the
+    # start into each intent, bypasses of optional words, joins into the shared final state) run through
+    # fstproject | fstdeterminize | fstminimize, which treat <eps> as a symbol and so KEEP it: G.fst has input-epsilon arcs
+    "eps_grammar": dict(keep_every=2, extra_sentences=6, backoff=False, eps=True),
 }
-RUNS = [("tiny_u0", "same_vocab"), ("tiny_u0", "backoff"), ("tiny_real_hot", "same_vocab"), ("tiny_arpa_u7", "backoff"),
+RUNS = [("tiny_u0", "eps_grammar"), ("zam_u0", "eps_grammar"), ("tiny_real_hot", "eps_grammar"), ("tiny_u0", "same_vocab"), ("tiny_u0", "backoff"), ("tiny_real_hot", "same_vocab"), ("tiny_arpa_u7", "backoff"),
         ("zam_u0", "same_vocab"), ("zam_u1", "backoff"), ("zam_real_cold", "backoff"), ("tinyf_u5", "same_vocab")]
 
 
@@ -108,6 +112,29 @@ def write_lang(lang_dir: Path, lex: synth.Lexicon, spec: synth.ModelSpec, conf: 
     subprocess.run(["bash", "-c", f"fstarcsort --sort_type=olabel {lang_dir}/L_disambig.fst {lang_dir}/L_disambig.fst"], env=ENV, check=True)
     # ---- G
     g = []
+    if conf.get("eps"):
+        # intents = groups of sentences; start --<eps>/-log p(intent)--> intent start; words in sequence, every third word of a
+        # sentence optional through an <eps> bypass; sentence end --<eps>--> one shared final state
+        n_int = 3
+        final = 1
+        nxt_g = 2 + n_int
+        for k in range(n_int):
+            g.append(f"0 {2 + k} 0 0 {-math.log((k + 1.0) / (n_int * (n_int + 1) / 2.0))}")
+        for i, s_ in enumerate(sents):
+            cur = 2 + (i % n_int)
+            for j, w in enumerate(s_):
+                g.append(f"{cur} {nxt_g} {wid[w]} {wid[w]}")
+                if j % 3 == 2:
+                    g.append(f"{cur} {nxt_g} 0 0 {-math.log(0.25)}")
+                cur = nxt_g
+                nxt_g += 1
+            g.append(f"{cur} {final} 0 0")
+        g.append(f"{final} 0")
+        # (the vendored OpenFst spells --project_type=input as the default of fstproject)
+        sh = (f"fstcompile --keep_state_numbering=true - | fstproject | fstdeterminize | fstminimize | "
+              f"fstarcsort --sort_type=ilabel - {lang_dir}/G.fst")
+        subprocess.run(["bash", "-c", sh], input="\n".join(g).encode() + b"\n", env=ENV, check=True)
+        return
     if not conf["backoff"]:
         # prefix tree of the sentences with relative-frequency costs (what rhasspy's grammar G looks like after determinisation)
         trie = {(): 0}
@@ -203,8 +230,13 @@ def reference_rescore(model_dir: Path, graph_dir: Path, wav: Path, lang_dir: Pat
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     index = []
+    only = set(sys.argv[1:])            # e.g. `gen_rescore_golden.py eps_grammar`: (re)generate that language style only
+    if only and (OUT / "cases.json").exists():
+        index = [e for e in json.loads((OUT / "cases.json").read_text()) if e["lang"] not in only]
     with tempfile.TemporaryDirectory() as tds:
         for case_name, lang in RUNS:
+            if only and lang not in only:
+                continue
             case = cases.CASES[case_name]
             td = Path(tds) / f"{case_name}_{lang}"
             td.mkdir()

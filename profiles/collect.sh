@@ -16,14 +16,15 @@ case $WL in
   mixed)   KT_STEPS=6;  PMC_STEPS=2;;
 esac
 B="python bench.py --workload $WL --no-cpu-baseline"
+P="$B --no-side-figures"      # under the profiler: the headline steps and the un-overlapped stage calls only
 $B --steps 2 --warmup 1 > /dev/null 2>&1      # page the image in
 # (bench.py measures stage times and the roofline on un-overlapped calls, so the kernel trace and the counters are taken with one call
 # in flight; the headline line at the end uses the workload's default)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B --steps $KT_STEPS --warmup 2 --inflight 1 > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $P --steps $KT_STEPS --warmup 2 --inflight 1 > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.log
 # PMC passes, each on its own (no trace domains besides the counters)
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_write.log
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $B --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_sq.log
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $P --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_fetch.log
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $P --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_write.log
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $P --steps $PMC_STEPS --warmup 1 --inflight 1 > /dev/null 2> $OUT/pmc_sq.log
 python bench.py --workload $WL > $OUT/bench_line.json 2> $OUT/bench.log                       # the default invocation, as the driver runs it
 if [ "$WL" = grammar ]; then
   $B --all-pdfs > $OUT/bench_line_all_pdfs.json 2>> $OUT/bench.log

@@ -29,12 +29,13 @@ class DecodeOpts(C.Structure):
 
 EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
-    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_stream_open", "rs_stream_accept",
+    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_shard_gather", "rs_stream_open", "rs_stream_accept",
     "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_mkgraph", "rs_fst_tool", "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
     "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
+    "rs_nnet3_setup", "rs_dither_noise",
 ]
 
 
@@ -57,6 +58,7 @@ def load_library() -> C.CDLL:
     lib.rs_decode_batch_device.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, i32, f32, vp, C.POINTER(vp)]
     lib.rs_decode_batch_sharded.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, i32, vp,
                                             C.POINTER(i32)]
+    lib.rs_shard_gather.argtypes = [i32, i32, i32, i32, vp, C.POINTER(i32)]
     lib.rs_stream_open.argtypes = [vp, C.POINTER(vp)]
     lib.rs_stream_accept.argtypes = [vp, C.POINTER(C.c_int16), i32]
     lib.rs_stream_finish.argtypes = [vp, i32, f32, C.POINTER(vp)]
@@ -282,6 +284,14 @@ def decode_batch_sharded(models: Sequence[Model], utt_model: Sequence[int], pcm:
     if st == RS_ERR_ARG:
         _check(st)
     return rec, st, ("" if st == RS_OK else lib().rs_last_error().decode("utf-8", "replace"))
+
+
+def shard_gather(records: np.ndarray, device_id: int, rank: int, world: int, rccl_comm: int) -> np.ndarray:
+    """rs_shard_gather: this rank's records (at their utterance indices, as decode_batch_sharded(..., rccl_comm=0) returns
+    them) -> every rank's, by ONE ncclAllGather on `rccl_comm`.  Call it from one thread, in the same order on every rank."""
+    rec = np.ascontiguousarray(records, dtype=np.int32).copy()
+    _check(lib().rs_shard_gather(device_id, rec.shape[0], rank, world, C.c_void_p(rccl_comm), rec.ctypes.data_as(C.POINTER(C.c_int32))))
+    return rec
 
 
 class Stream:

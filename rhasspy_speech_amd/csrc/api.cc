@@ -18,6 +18,7 @@
 namespace rs {
 int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
                        int n_utts, int rank, int world, void *comm, int32_t *records, std::string *error);
+void ShardGather(int device_id, int n_utts, int rank, int world, void *comm, int32_t *records);
 }
 
 namespace {
@@ -151,6 +152,15 @@ int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int
   });
 }
 
+int rs_shard_gather(int32_t device_id, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm, int32_t *records) {
+  if (n_utts < 0 || world < 1 || rank < 0 || rank >= world || !rccl_comm || (n_utts > 0 && !records) || device_id < 0)
+    return ArgError("rs_shard_gather: bad argument");
+  return Guard([&]() {
+    rs::ShardGather(device_id, n_utts, rank, world, rccl_comm, records);
+    return RS_OK;
+  });
+}
+
 int rs_stream_open(rs_model *model, rs_stream **out) {
   if (!model || !out) return ArgError("rs_stream_open: null argument");
   return Guard([&]() {
@@ -181,6 +191,7 @@ static int CheckStreams(rs_stream *const *streams, int32_t n_streams, const char
     if (!streams[i] || !streams[i]->model) return ArgError((std::string(who) + ": null stream").c_str());
     if (streams[i]->model != streams[0]->model) return ArgError((std::string(who) + ": all streams must belong to one model").c_str());
     if (streams[i]->finished) return ArgError((std::string(who) + ": stream already finished").c_str());
+    if (streams[i]->failed) return ArgError((std::string(who) + ": stream was part of an advance that failed; its device state is undefined, close it").c_str());
     if (streams[i]->keep_pcm != streams[0]->keep_pcm) return ArgError((std::string(who) + ": streams opened in different modes").c_str());
     for (int j = 0; j < i; j++) if (streams[j] == streams[i]) return ArgError((std::string(who) + ": a stream is listed twice").c_str());
   }
@@ -192,7 +203,14 @@ int rs_streams_advance(rs_stream *const *streams, int32_t n_streams) {
   if (rc != RS_OK) return rc;
   if (n_streams == 0 || streams[0]->keep_pcm) { g_last_error.clear(); return RS_OK; }
   return Guard([&]() {
-    streams[0]->model->m->StreamsAdvance(streams, n_streams, /*final=*/false, 1, 1.0f, nullptr);
+    // An advance that throws (pool exhausted for a later stream, arena growth, a HIP error) has already moved the chunk schedule
+    // of some streams forward without their iVector / log-likelihood rows being written: none of the call's streams may go on.
+    try {
+      streams[0]->model->m->StreamsAdvance(streams, n_streams, /*final=*/false, 1, 1.0f, nullptr);
+    } catch (...) {
+      for (int i = 0; i < n_streams; i++) streams[i]->failed = true;
+      throw;
+    }
     return RS_OK;
   });
 }

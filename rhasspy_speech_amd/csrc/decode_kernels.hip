@@ -560,6 +560,11 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
       if (tid == 0) {
         frame_off[f + 2] = off_next;
         c.counters[3] += (unsigned long long)nn;
+        {      // [4]: largest frame of the utterance: tokens (low half), candidate records of its arc loop (high half)
+          const unsigned long long mt = c.counters[4] & 0xFFFFFFFFull, mc = c.counters[4] >> 32;
+          const unsigned long long nc_ = f >= 0 ? (unsigned long long)c.n_cand : 0ull;
+          c.counters[4] = ((nc_ > mc ? nc_ : mc) << 32) | ((unsigned long long)nn > mt ? (unsigned long long)nn : mt);
+        }
         c.n_next = 0;
         if (nn == 0 && c.error == 0) c.error = 1;     // "no surviving tokens"
       }

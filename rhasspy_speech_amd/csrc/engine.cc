@@ -690,10 +690,18 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
       RS_HIP(hipMalloc((void **)&cx->d_pcm, cx->h_pcm_cap * sizeof(int16_t)));
     }
     auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < n_utts; i++)
+    // Pageable caller buffers -> pinned staging -> HBM in spans of about 2 MB: the DMA of one span runs under the host copy of
+    // the next, and nothing waits here -- the feature kernel is ordered behind the last span on the context's stream.
+    const int64_t span = 1 << 20;      // samples
+    for (int i = 0, first = 0; i < n_utts; i++) {
       if (n_samples[i]) std::memcpy(cx->h_pcm_pinned + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
-    RS_HIP(hipMemcpyAsync(cx->d_pcm, cx->h_pcm_pinned, sizeof(int16_t) * (size_t)off[n_utts], hipMemcpyHostToDevice, cx->stream));
-    RS_HIP(hipStreamSynchronize(cx->stream));
+      if (off[i + 1] - off[first] >= span || i + 1 == n_utts) {
+        if (off[i + 1] > off[first])
+          RS_HIP(hipMemcpyAsync(cx->d_pcm + off[first], cx->h_pcm_pinned + off[first], sizeof(int16_t) * (size_t)(off[i + 1] - off[first]),
+                                hipMemcpyHostToDevice, cx->stream));
+        first = i + 1;
+      }
+    }
     const float h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     res = DecodeInContext(*cx, cx->d_pcm, off.data(), n_utts, nbest, lat_scale, nullptr, streaming);
     res->timings[0] = h2d_ms;

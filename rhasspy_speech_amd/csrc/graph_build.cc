@@ -81,6 +81,7 @@ void WriteFst(const Fst &f, const std::string &path, bool const_type) {
   }
   std::ofstream os(path, std::ios::binary);
   os.write(o.data(), (std::streamsize)o.size());
+  os.close();                                   // a full disk shows at the flush
   if (!os.good()) Fail("Error writing FST to " + path);
 }
 

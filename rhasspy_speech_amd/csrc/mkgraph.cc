@@ -6,6 +6,7 @@
 //   AddSelfLoops        hmm/hmm-utils.cc:425-560 (reorder = true); fstext/fstext-utils-inl.h:577-650 (MakePrecedingInputSymbolsSameClass)
 //   Mkgraph             egs/wsj/s5/utils/mkgraph.sh:72-170
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -356,7 +357,14 @@ void Mkgraph(const std::string &lang, const std::string &model_dir, const std::s
   // HCLG
   AddSelfLoops(tm, opts.self_loop_scale, &hclg);
   ArcSort(&hclg, true);        // (the decoders want the input epsilons of a state first; fstconvert keeps whatever order it is given)
-  WriteFst(hclg, dir + "/HCLG.fst", true);
+  // mkgraph.sh:151-164: the graph appears under its final name only when it is complete (a run killed mid-write must not leave a
+  // file the up-to-date test of the next run accepts), and an empty result is an error
+  if (hclg.start < 0 || hclg.NumStates() == 0) Fail("it looks like the result in " + dir + "/HCLG.fst is empty");
+  {
+    const std::string tmp = dir + "/HCLG.fst." + std::to_string((long)getpid());
+    WriteFst(hclg, tmp, true);
+    if (std::rename(tmp.c_str(), (dir + "/HCLG.fst").c_str()) != 0) { std::remove(tmp.c_str()); Fail("cannot move " + tmp + " to " + dir + "/HCLG.fst"); }
+  }
   lap("add-self-loops + write", hclg);
   CopyFile(lang + "/words.txt", dir + "/words.txt");
   MakeDirs(dir + "/phones");

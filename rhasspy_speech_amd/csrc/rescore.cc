@@ -195,33 +195,51 @@ std::vector<NbestPath> Rescorer::Rescore(const CompactLat &clat, const Transitio
   };
   RawLattice fin;
   {
-    std::unordered_map<std::pair<int, int>, int, PairHash> id;
-    std::vector<std::pair<int, int>> todo;
-    auto sid = [&](int a, int b) {
-      auto it = id.find({a, b});
+    // States are (lattice state, G state, filter state): ComposeFst's sequence filter (compose-filter.h, SequenceComposeFilter)
+    // orders moves along G's input-epsilon arcs -- hassil's grammars keep <eps> arcs: kaldi.py:321-341 never removes them --
+    // before epsilon moves of the lattice, so every pair of paths is composed exactly once.  Filter state 1 = "a G epsilon was
+    // taken at a lattice state that has epsilon arcs of its own"; the lattice's epsilon arcs may be taken in state 0 only.
+    struct Key { int ds, gs, f; };
+    std::unordered_map<uint64_t, int> id;
+    std::vector<Key> todo;
+    const uint64_t ng = (uint64_t)g_arcs_.size();
+    auto sid = [&](int a, int b, int f) {
+      const uint64_t k = ((uint64_t)a * ng + (uint64_t)b) * 2 + (uint64_t)f;
+      auto it = id.find(k);
       if (it != id.end()) return it->second;
-      const int k = (int)id.size();
-      id.emplace(std::make_pair(a, b), k);
-      todo.push_back({a, b});
-      return k;
+      const int n = (int)id.size();
+      id.emplace(k, n);
+      todo.push_back({a, b, f});
+      return n;
     };
-    fin.start = sid(det.start, g_start_);
+    fin.start = sid(det.start, g_start_, 0);
     for (size_t i = 0; i < todo.size(); i++) {
-      const int ds = todo[i].first, src = (int)i;
+      if (todo.size() > 4000000) Fail("rescoring: the word lattice composed with G grew beyond 4 M states");
+      const int ds = todo[i].ds, gs0 = todo[i].gs, fs = todo[i].f, src = (int)i;
+      size_t n_eps = 0;
+      for (auto &a : det.arcs[ds]) n_eps += a.label == 0;
+      const bool alleps1 = n_eps == det.arcs[ds].size() && !det.is_final[ds], noeps1 = n_eps == 0;
+      // G moves alone along an input-epsilon arc (the matcher's implicit loop on the lattice side comes first in ComposeFst)
+      if (!alleps1)
+        for (const FstArc &ga : g_arcs_[gs0])
+          if (ga.ilabel == 0) fin.arcs.push_back({src, sid(ds, ga.nextstate, noeps1 ? 0 : 1), ga.olabel, (double)ga.weight, 0.0, 0});
       for (auto &a : det.arcs[ds]) {
         const double tc = trans_cost(a.w.tids);
-        if (a.label == 0) { fin.arcs.push_back({src, sid(a.dst, todo[i].second), 0, a.w.graph + tc, a.w.acoustic, 0}); continue; }
-        // PhiMatcher: the word's own arc, else follow the back-off arc (paying it) and look again
-        int gs = todo[i].second;
+        if (a.label == 0) {
+          if (fs == 0) fin.arcs.push_back({src, sid(a.dst, gs0, 0), 0, a.w.graph + tc, a.w.acoustic, 0});
+          continue;
+        }
+        // PhiMatcher: the word's own arcs, else follow the back-off arc (paying it) and look again
+        int gs = gs0;
         double backoff = 0.0;
         for (int hops = 0; hops <= (int)g_arcs_.size(); hops++) {
-          const FstArc *hit = nullptr;
-          for (const FstArc &ga : g_arcs_[gs]) if (ga.ilabel == a.label && ga.ilabel != phi_) { hit = &ga; break; }
-          if (hit) {
-            fin.arcs.push_back({src, sid(a.dst, hit->nextstate), hit->olabel, a.w.graph + tc + backoff + hit->weight, a.w.acoustic, 0});
-            break;
-          }
-          if (g_phi_[gs] < 0) break;
+          bool hit = false;
+          for (const FstArc &ga : g_arcs_[gs])
+            if (ga.ilabel == a.label && ga.ilabel != phi_) {
+              hit = true;
+              fin.arcs.push_back({src, sid(a.dst, ga.nextstate, 0), ga.olabel, a.w.graph + tc + backoff + ga.weight, a.w.acoustic, 0});
+            }
+          if (hit || g_phi_[gs] < 0) break;
           const FstArc &pa = g_arcs_[gs][g_phi_[gs]];
           backoff += pa.weight;
           gs = pa.nextstate;
@@ -230,9 +248,8 @@ std::vector<NbestPath> Rescorer::Rescore(const CompactLat &clat, const Transitio
     }
     fin.num_states = (int)todo.size();
     fin.final_cost.assign(fin.num_states, kInf);
-    std::vector<std::pair<int, double>> extra_final;      // final weights that carry an alignment: through one more arc
-    for (size_t i = 0; i < todo.size(); i++) {
-      const int ds = todo[i].first, gs = todo[i].second;
+    for (size_t i = 0; i < todo.size(); i++) {      // final weights carry an alignment: through one more arc
+      const int ds = todo[i].ds, gs = todo[i].gs;
       if (!det.is_final[ds] || !std::isfinite(g_final_[gs])) continue;
       const CompactLat::Weight &fw = det.final_w[ds];
       const int f = fin.num_states++;

@@ -76,20 +76,93 @@ void FillRecord(int32_t *rec, int utt, const UttResult &ur) {
   std::memcpy(rec + 4 + RS_SHARD_MAX_WORDS, &h.acoustic_cost, 4);
 }
 
+// The exchange step's resources for `per` records per rank on device `dev`; called with gb.mu held.  Everything that can fail
+// (device, stream, buffers) happens here, BEFORE a rank decodes: a rank that cannot take part in the collective fails where
+// every rank of a broken node fails alike, and after the decode nothing stands between a rank and the collective.
+void PrepareGather(GatherBuffers &gb, int dev, size_t send_bytes, size_t recv_bytes) {
+  auto release = [&]() {
+    if (gb.stream) (void)hipStreamSynchronize(gb.stream);      // no gather is still reading the old buffers
+    if (gb.d_send) (void)hipFree(gb.d_send);
+    if (gb.d_recv) (void)hipFree(gb.d_recv);
+    if (gb.h_stage) (void)hipHostFree(gb.h_stage);
+    gb.d_send = gb.d_recv = gb.h_stage = nullptr;
+    gb.send_cap = gb.recv_cap = 0;
+  };
+  if (gb.device != dev) {                                      // the buffers of another device go back to that device
+    if (gb.device >= 0 && hipSetDevice(gb.device) == hipSuccess) {
+      release();
+      if (gb.stream) (void)hipStreamDestroy(gb.stream);
+    }
+    gb.d_send = gb.d_recv = gb.h_stage = nullptr; gb.send_cap = gb.recv_cap = 0; gb.stream = nullptr;
+    gb.device = dev;
+  }
+  RS_HIP(hipSetDevice(dev));
+  if (!gb.stream) RS_HIP(hipStreamCreateWithFlags(&gb.stream, hipStreamNonBlocking));
+  if (send_bytes > gb.send_cap || recv_bytes > gb.recv_cap) {
+    release();
+    RS_HIP(hipMalloc((void **)&gb.d_send, send_bytes * 2));
+    RS_HIP(hipMalloc((void **)&gb.d_recv, recv_bytes * 2));
+    RS_HIP(hipHostMalloc((void **)&gb.h_stage, recv_bytes * 2, hipHostMallocDefault));
+    gb.send_cap = send_bytes * 2; gb.recv_cap = recv_bytes * 2;
+  }
+}
+
+void CheckComm(void *comm, int rank, int world, const char *who) {
+  // a communicator that contradicts rank / world is refused before anything is launched (nobody would be left waiting)
+  const Rccl &nc = Rccl::Get();
+  if (!nc.load_error.empty()) throw DeviceError(nc.load_error);
+  int cn = 0, cr = -1;
+  if (nc.comm_count(comm, &cn) != 0 || nc.comm_rank(comm, &cr) != 0 || cn != world || cr != rank)
+    throw Error(std::string(who) + ": rank/world (" + std::to_string(rank) + "/" + std::to_string(world) +
+                ") do not match the communicator's (" + std::to_string(cr) + "/" + std::to_string(cn) + ")");
+}
+
+void InitRecords(int32_t *records, int n_utts) {
+  for (int i = 0; i < n_utts; i++) {
+    int32_t *rec = records + (size_t)i * RS_SHARD_RECORD_INTS;
+    std::memset(rec, 0, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+    rec[0] = i; rec[1] = RS_SHARD_ABSENT;
+  }
+}
+
+void Scatter(const int32_t *block, int nrec, int n_utts, int32_t *records) {
+  for (int k = 0; k < nrec; k++) {
+    const int32_t *rec = block + (size_t)k * RS_SHARD_RECORD_INTS;
+    if (rec[0] >= 0 && rec[0] < n_utts) std::memcpy(records + (size_t)rec[0] * RS_SHARD_RECORD_INTS, rec, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+  }
+}
+
+// ONE ncclAllGather of `per` records per rank; gb.mu held, PrepareGather done.  `local`: per * RS_SHARD_RECORD_INTS ints.
+void Gather(GatherBuffers &gb, const int32_t *local, int per, int n_utts, int world, void *comm, int32_t *records) {
+  const Rccl &nc = Rccl::Get();
+  const size_t n_ints = (size_t)per * RS_SHARD_RECORD_INTS, send_bytes = n_ints * sizeof(int32_t), recv_bytes = send_bytes * world;
+  (void)hipSetDevice(gb.device);
+  std::memcpy(gb.h_stage, local, send_bytes);
+  // Should the upload fail, this rank still joins the collective -- with records marked absent -- and reports afterwards.
+  const hipError_t up = hipMemcpyAsync(gb.d_send, gb.h_stage, send_bytes, hipMemcpyHostToDevice, gb.stream);
+  if (up != hipSuccess) (void)hipMemsetAsync(gb.d_send, 0xFF, send_bytes, gb.stream);      // utterance index -1: skipped by every reader
+  const int nr = nc.all_gather(gb.d_send, gb.d_recv, n_ints, kNcclInt32, comm, gb.stream);
+  if (nr != 0) throw DeviceError(std::string("ncclAllGather failed: ") + (nc.error_string ? nc.error_string(nr) : std::to_string(nr).c_str()));
+  RS_HIP(hipMemcpyAsync(gb.h_stage, gb.d_recv, recv_bytes, hipMemcpyDeviceToHost, gb.stream));
+  RS_HIP(hipStreamSynchronize(gb.stream));
+  if (up != hipSuccess) throw DeviceError(std::string("uploading this rank's records for the gather failed: ") + hipGetErrorString(up));
+  InitRecords(records, n_utts);
+  Scatter(gb.h_stage, per * world, n_utts, records);
+}
+
 }  // namespace
 
 // returns RS_OK, or the first per-model failure of this rank (after the collective has run)
 int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
                        int n_utts, int rank, int world, void *comm, int32_t *records, std::string *error) {
-  if (comm) {     // a communicator that contradicts rank / world is refused before anything is launched (nobody would be left waiting)
-    const Rccl &nc = Rccl::Get();
-    if (!nc.load_error.empty()) throw DeviceError(nc.load_error);
-    int cn = 0, cr = -1;
-    if (nc.comm_count(comm, &cn) != 0 || nc.comm_rank(comm, &cr) != 0 || cn != world || cr != rank)
-      throw Error("rs_decode_batch_sharded: rank/world (" + std::to_string(rank) + "/" + std::to_string(world) +
-                  ") do not match the communicator's (" + std::to_string(cr) + "/" + std::to_string(cn) + ")");
-  }
+  if (comm) CheckComm(comm, rank, world, "rs_decode_batch_sharded");
   const int per = (n_utts + world - 1) / world;           // records per rank in the gather (short shards are padded)
+  const size_t send_bytes = (size_t)per * RS_SHARD_RECORD_INTS * sizeof(int32_t);
+  GatherBuffers &gb = Buffers();
+  if (comm) {
+    std::lock_guard<std::mutex> lk(gb.mu);
+    PrepareGather(gb, models[0]->m->opts().device_id, send_bytes, send_bytes * world);
+  }
   std::vector<std::vector<int>> mine(n_models);
   for (int i = rank; i < n_utts; i += world) mine[utt_model[i]].push_back(i);
   // ---- this rank's utterances: one device batch per model, the batches of different models concurrently
@@ -127,43 +200,37 @@ int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt
     }
   }
   // ---- the exchange step
-  for (int i = 0; i < n_utts; i++) {
-    int32_t *rec = records + (size_t)i * RS_SHARD_RECORD_INTS;
-    std::memset(rec, 0, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
-    rec[0] = i; rec[1] = RS_SHARD_ABSENT;
-  }
-  auto scatter = [&](const int32_t *block, int nrec) {
-    for (int k = 0; k < nrec; k++) {
-      const int32_t *rec = block + (size_t)k * RS_SHARD_RECORD_INTS;
-      if (rec[0] >= 0 && rec[0] < n_utts) std::memcpy(records + (size_t)rec[0] * RS_SHARD_RECORD_INTS, rec, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
-    }
-  };
-  if (comm == nullptr) {     // one rank without a communicator, or the caller gathers by other means: this rank's records only
-    scatter(local.data(), per);
+  if (comm == nullptr) {     // one rank without a communicator, or the caller gathers later (rs_shard_gather) or by other means
+    InitRecords(records, n_utts);
+    Scatter(local.data(), per, n_utts, records);
     return rc;
   }
-  const Rccl &nc = Rccl::Get();
+  std::lock_guard<std::mutex> lk(gb.mu);
+  if (gb.device != models[0]->m->opts().device_id || send_bytes > gb.send_cap)      // another thread's call re-sized them meanwhile
+    PrepareGather(gb, models[0]->m->opts().device_id, send_bytes, send_bytes * world);
+  Gather(gb, local.data(), per, n_utts, world, comm, records);
+  return rc;
+}
+
+// The exchange step alone: `records` holds this rank's records at their utterance indices (what rs_decode_batch_sharded leaves
+// when it is called without a communicator); on return it holds every rank's.  For callers that keep several decode calls in
+// flight: the collectives of one communicator have to be issued in the same order on every rank, so such a caller decodes from
+// its worker threads and gathers from one thread in step order.
+void ShardGather(int device_id, int n_utts, int rank, int world, void *comm, int32_t *records) {
+  CheckComm(comm, rank, world, "rs_shard_gather");
+  const int per = (n_utts + world - 1) / world;
+  const size_t send_bytes = (size_t)per * RS_SHARD_RECORD_INTS * sizeof(int32_t);
   GatherBuffers &gb = Buffers();
   std::lock_guard<std::mutex> lk(gb.mu);
-  const int dev = models[0]->m->opts().device_id;
-  RS_HIP(hipSetDevice(dev));
-  if (gb.device != dev) { gb.device = dev; gb.d_send = gb.d_recv = gb.h_stage = nullptr; gb.send_cap = gb.recv_cap = 0; gb.stream = nullptr; }
-  if (!gb.stream) RS_HIP(hipStreamCreateWithFlags(&gb.stream, hipStreamNonBlocking));
-  const size_t send_bytes = local.size() * sizeof(int32_t), recv_bytes = send_bytes * world;
-  if (send_bytes > gb.send_cap || recv_bytes > gb.recv_cap) {
-    gb.send_cap = send_bytes * 2; gb.recv_cap = recv_bytes * 2;
-    RS_HIP(hipMalloc((void **)&gb.d_send, gb.send_cap));
-    RS_HIP(hipMalloc((void **)&gb.d_recv, gb.recv_cap));
-    RS_HIP(hipHostMalloc((void **)&gb.h_stage, gb.recv_cap, hipHostMallocDefault));
+  PrepareGather(gb, device_id, send_bytes, send_bytes * world);
+  std::vector<int32_t> local((size_t)per * RS_SHARD_RECORD_INTS, 0);
+  for (int k = 0; k < per; k++) {
+    int32_t *rec = &local[(size_t)k * RS_SHARD_RECORD_INTS];
+    const int i = rank + k * world;
+    if (i < n_utts) std::memcpy(rec, records + (size_t)i * RS_SHARD_RECORD_INTS, sizeof(int32_t) * RS_SHARD_RECORD_INTS);
+    else { rec[0] = -1; rec[1] = RS_SHARD_ABSENT; }
   }
-  std::memcpy(gb.h_stage, local.data(), send_bytes);
-  RS_HIP(hipMemcpyAsync(gb.d_send, gb.h_stage, send_bytes, hipMemcpyHostToDevice, gb.stream));
-  const int nr = nc.all_gather(gb.d_send, gb.d_recv, local.size(), kNcclInt32, comm, gb.stream);
-  if (nr != 0) throw DeviceError(std::string("ncclAllGather failed: ") + (nc.error_string ? nc.error_string(nr) : std::to_string(nr).c_str()));
-  RS_HIP(hipMemcpyAsync(gb.h_stage, gb.d_recv, recv_bytes, hipMemcpyDeviceToHost, gb.stream));
-  RS_HIP(hipStreamSynchronize(gb.stream));
-  scatter(gb.h_stage, per * world);
-  return rc;
+  Gather(gb, local.data(), per, n_utts, world, comm, records);
 }
 
 }  // namespace rs

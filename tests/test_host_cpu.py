@@ -19,7 +19,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_library_exports_every_declared_symbol():
     from rhasspy_speech_amd import _lib
     header = (ROOT / "include" / "rhasspy_speech_hip.h").read_text()
-    declared = set(re.findall(r"\b(rs_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", header))
     lib = _lib.load_library()
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
