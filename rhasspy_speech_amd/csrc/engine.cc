@@ -79,8 +79,10 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
   if (const char *e = std::getenv("RS_SUBBATCHES")) max_groups_ = std::atoi(e);
   if (const char *e = std::getenv("RS_DECODER")) {
     const std::string v(e);
-    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : 0;
-    if (decoder_choice_ == 3) force_sparse_ = true;
+    // reg / dense: the LDS-resident searches of small graphs; sparse: DecodeKernel alone (dense per-state tables in HBM); hash: the
+    // token-list search with the live-state table, which is what "auto" runs on graphs the first two cannot hold
+    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : v == "hash" ? 4 : 0;
+    if (decoder_choice_ == 3 || decoder_choice_ == 4) force_sparse_ = true;
   }
   if (opts_.frame_subsampling_factor != 1)
     Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
@@ -924,8 +926,11 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   size_t need = (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)sp->max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
   if (sp->use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
     need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
-  else                    // token-list search: per-state tables, queues, the token arrays of every frame
+  else {                  // token-list search: per-state tables, queues, the token arrays of every frame
     need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
+    sp->use_hash = decoder_choice_ != 3 && DecodeHashUsable(hclg_dev_);
+    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeHashSlotCap() * (8 + 4 + 4 + 16 + 16) + (size_t)kHashCandCap * 12 + 4) + 8192;
+  }
   if (sp->want_lattice) need += sizeof(float) * (size_t)n_utts * sp->tok_cap + 4096;                                // LatticeKernel's extra_cost
   return need;
 }
@@ -972,6 +977,25 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   w.tok_cap = sp->tok_cap;
   w.tokens = arena_.AllocT<int4>((size_t)n_utts * sp->tok_cap);
   w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+  if (sp->use_hash) {
+    // live states of a frame in an LDS table, their per-state records in slot-indexed arrays (decode_kernels.hip); the dense tables
+    // above are only touched for utterances that outgrow the table (w.redo)
+    const size_t cap = (size_t)DecodeHashSlotCap();
+    w.h_keys = arena_.AllocT<unsigned long long>((size_t)n_utts * cap);
+    w.h_slot_tok = arena_.AllocT<int>((size_t)n_utts * cap);
+    w.h_stamp = arena_.AllocT<int>((size_t)n_utts * cap);
+    w.h_cand_cap = kHashCandCap;
+    { const char *e = std::getenv("RS_HASH_SLOT_LIMIT"); w.h_slot_limit = e ? std::atoi(e) : DecodeHashSlotCap(); }
+    w.h_cand = arena_.AllocT<int>((size_t)n_utts * 3 * kHashCandCap);
+    w.h_queue = arena_.AllocT<int2>((size_t)n_utts * 2 * cap);
+    w.h_comp = arena_.AllocT<int4>((size_t)n_utts * cap);
+    w.redo = arena_.AllocT<int>(n_utts);
+    LaunchDecodeHash(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
+    if (sp->want_lattice) {      // LatticeKernel expects both state -> token maps empty (DecodeKernel leaves them so for the utterances it decodes)
+      RS_HIP(hipMemsetAsync(w.map_a, 0xFF, sizeof(int) * (size_t)n_utts * S, s));
+      RS_HIP(hipMemsetAsync(w.map_b, 0xFF, sizeof(int) * (size_t)n_utts * S, s));
+    }
+  }
   LaunchDecode(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
 }
 

@@ -108,7 +108,7 @@ struct RowMaps {
 
 // Which search kernel a call runs and its work buffers (engine.cc: PlanSearch / AllocSearch / LaunchSearch / CollectResults).
 struct SearchPlan {
-  bool unscale = false, want_lattice = false, use_reg = false, use_dense = false;
+  bool unscale = false, want_lattice = false, use_reg = false, use_dense = false, use_hash = false;
   int S = 0, tok_cap = 0, max_words = 1024, maxT = 0, n_utts = 0;
   DecodeOptsDev dopts{};
   DecodeWork w{};

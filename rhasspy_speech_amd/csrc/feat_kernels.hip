@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     u = g.d_row_utt[row];
     t = g.d_row_t[row];
     int T = g.d_num_frames[u];
-    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    t = t >= T ? T - 1 : t;
+    t = t < 0 ? 0 : t;          // (also the halo rows of an utterance too short for one frame: frame 0 of whatever follows it, never read back)
   }
   float *x = xbuf[wave];
   float raw_energy = 0.f;

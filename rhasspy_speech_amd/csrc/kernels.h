@@ -218,6 +218,15 @@ struct DecodeWork {
   float *frame_info;          // n_utts x (max_frames + 1) x 4 : {cost_offset, cur_cutoff, next_cutoff, adaptive_beam}
   int *queue_a, *queue_b;     // n_utts x S work lists for the epsilon closure
   int *in_queue;              // n_utts x S : round stamp of the state's last push onto a closure queue (token-list search)
+  // live-state-table search (HashDecodeKernel): slot-indexed arrays instead of the state-indexed ones above; null = not in use
+  unsigned long long *h_keys; // n_utts x DecodeHashSlotCap() : packed (cost, arc) of the slot's state in the frame under construction
+  int *h_slot_tok, *h_stamp;  // n_utts x slot cap : token index of the slot / closure round of its last push
+  int *h_cand;                // n_utts x 3 x h_cand_cap : candidate records of the arc loop (arc, destination state, slot << 16 | source token)
+  int h_cand_cap;
+  int h_slot_limit;           // live states a frame may hold before the utterance is handed to DecodeKernel (<= DecodeHashSlotCap())
+  int2 *h_queue;              // n_utts x 2 x slot cap : closure work lists (state, slot)
+  int4 *h_comp;               // n_utts x slot cap : the tokens a frame expands, compacted {first emitting arc, cost, token index, out-degree}
+  int *redo;                  // n_utts : 1 = the utterance outgrew the live-state table, DecodeKernel decodes it (null: DecodeKernel decodes all)
   // results
   int *out_words;             // n_utts x max_words
   int *out_nwords;            // n_utts
@@ -227,6 +236,14 @@ struct DecodeWork {
 };
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                   const DecodeWork &w, hipStream_t s);
+// The same search with the live states of a frame in an LDS hash (see decode_kernels.hip); usable when the graph's state ids fit
+// the table's tag field.  Utterances that outgrow the table are flagged in w.redo and decoded by LaunchDecode, which the caller
+// issues behind it on the same stream.
+constexpr int kHashCandCap = 65536;      // candidate records per utterance and frame (the ARPA workload's largest frame: 24 k)
+bool DecodeHashUsable(const HclgDev &h);
+int DecodeHashSlotCap();
+void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                      const DecodeWork &w, hipStream_t s);
 
 // Dense ("pull") variant for graphs whose per-state tables fit in LDS: one thread per destination state walks
 // its incoming arcs (reverse graph), so there are no atomics and no token lists; the frame's token costs live

@@ -277,13 +277,20 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   const long rest = rows - full * 128;
   const double c_mixed = rounds(full) * 128 + rounds((rest + 63) / 64) * 64 * eff64;
   const double c_128 = rounds((rows + 127) / 128) * 128, c_64 = rounds((rows + 63) / 64) * 64 * eff64;
+  // a launch of less than one round (a stream advance: a few thousand rows) is as long as ONE tile is: the 32-row tile spreads it
+  // over four times as many CUs as the 128-row one, each streaming the same weights for a quarter of the rows
+  static const double eff32 = [] { const char *e = std::getenv("RS_GEMM_B3I_EFF32"); return e ? std::atof(e) : 1.7; }();
+  const double c_32 = rounds((rows + 31) / 32) * 32 * eff32;
   int mr = 4, nbig = (rows + 127) / 128;
   bool mixed = false;
-  if (c_64 < c_128 && c_64 <= c_mixed) { mr = 2; nbig = (rows + 63) / 64; }
+  if (c_32 < c_64 && c_32 < c_128 && c_32 <= c_mixed) { mr = 1; nbig = (rows + 31) / 32; }
+  else if (c_64 < c_128 && c_64 <= c_mixed) { mr = 2; nbig = (rows + 63) / 64; }
   else if (full > 0 && c_mixed < c_128) { mixed = true; nbig = (int)full; }
+  if (force_mr == 1) { mr = 1; nbig = (rows + 31) / 32; mixed = false; }
   if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
   if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
-  if (mr == 2) LaunchB3I<2, false>(d, rows, nbig, s);
+  if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);
+  else if (mr == 2) LaunchB3I<2, false>(d, rows, nbig, s);
   else if (mixed) LaunchB3I<4, true>(d, rows, nbig, s);
   else LaunchB3I<4, false>(d, rows, nbig, s);
 }

@@ -422,7 +422,9 @@ bool GemmB3JUsable(const GemmDev &d, int rows) {
   if (e && std::atoi(e) == 0) return false;
   const int wm = JWaveRows();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
-  const long min_default = wm == 2 ? JSlots(d, wm) * 256 / ncol : 1024;      // the 256-row tile needs whole rounds to pay off
+  // the 256-row tile needs whole rounds to pay off; a launch that GemmKernelB3I's 32-row tiles finish in one round (a stream
+  // advance: a few thousand rows) is faster there -- one tile's worth of time on four times as many CUs
+  const long min_default = wm == 2 ? JSlots(d, wm) * 256 / ncol : JSlots(d, 1) * 32 / ncol + 1;
   const int min_rows = e && std::atoi(e) > 1 ? std::atoi(e) : (int)std::min<long>(min_default, 1 << 30);
   return rows >= min_rows;
 }

@@ -135,16 +135,17 @@ VARIANT_CASES = [("tiny_u0", {}), ("tiny_arpa_u7", {}), ("tiny_arpa_prune_u8", {
 
 @pytest.mark.parametrize("name,extra", VARIANT_CASES)
 def test_decoder_variants_agree(case_cache, name, extra, monkeypatch):
-    """The register-resident, the LDS-resident (pull) and the general token-list decoder are the same search."""
+    """The register-resident, the LDS-resident (pull) and the two general token-list decoders (dense per-state tables in HBM;
+    live-state table in LDS) are the same search."""
     from rhasspy_speech_amd import synth
     models = {}
-    for variant in ("sparse", "dense", "reg"):
+    for variant in ("sparse", "dense", "reg", "hash"):
         monkeypatch.setenv("RS_DECODER", variant)
         models[variant], pcm = make_model(case_cache, name, **extra)
     monkeypatch.delenv("RS_DECODER")
     pcms = [pcm] + [synth.synth_utterance(300 + i, n) for i, n in enumerate([48000, 17000, 33000])]
     ref = models["sparse"].decode_batch(pcms)
-    for variant in ("dense", "reg"):
+    for variant in ("dense", "reg", "hash"):
         got = models[variant].decode_batch(pcms)
         for u in range(len(pcms)):
             assert got.words(u) == ref.words(u), variant
@@ -153,6 +154,31 @@ def test_decoder_variants_agree(case_cache, name, extra, monkeypatch):
             assert got.counters(u)[3] == ref.counters(u)[3], variant
             # the pruning branches were actually taken the same number of times
             assert got.counters(u)[5] == ref.counters(u)[5] and got.counters(u)[6] == ref.counters(u)[6], variant
+
+
+@pytest.mark.parametrize("name,extra", [("tiny_arpa_u7", {}), ("tiny_arpa_prune_u8", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0))])
+def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra, monkeypatch):
+    """n-best lists (LatticeKernel on the token lists the search leaves behind) from the live-state-table search, from the dense-table
+    search, and from the former with a table so small that some or all utterances are handed to the latter on the device."""
+    from rhasspy_speech_amd import synth
+    monkeypatch.setenv("RS_DECODER", "sparse")
+    ref_model, pcm = make_model(case_cache, name, **extra)
+    pcms = [pcm] + [synth.synth_utterance(500 + i, n) for i, n in enumerate([48000, 9000, 33000])]
+    ref = ref_model.decode_batch(pcms, nbest=5)
+    monkeypatch.setenv("RS_DECODER", "hash")
+    for limit in (None, "40", "6"):
+        if limit is None:
+            monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("RS_HASH_SLOT_LIMIT", limit)
+        got = make_model(case_cache, name, **extra)[0].decode_batch(pcms, nbest=5)
+        for u in range(len(pcms)):
+            assert got.num_hyps(u) == ref.num_hyps(u), (limit, u)
+            for k in range(ref.num_hyps(u)):
+                assert got.words(u, k) == ref.words(u, k), (limit, u, k)
+                np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
+            assert got.counters(u)[3] == ref.counters(u)[3], (limit, u)
+    monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
 
 
 def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
