@@ -265,9 +265,8 @@ def main() -> None:
         def decode():
             streams = [_lib.Stream(model) for _ in pcms]
             for r in range(n_rounds):
-                for s, p in zip(streams, pcms):
-                    if r * tick < len(p):
-                        s.accept(p[r * tick:(r + 1) * tick])
+                live = [(s, p[r * tick:(r + 1) * tick]) for s, p in zip(streams, pcms) if r * tick < len(p)]
+                _lib.accept_streams([s for s, _ in live], [a for _, a in live])       # one round of audio for every stream: one call
                 _lib.advance_streams(streams)
             return _lib.finish_streams(streams)
         workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU fed in {tick}-sample "
@@ -442,7 +441,7 @@ def main() -> None:
                        "output_layer": "all pdfs (--all-pdfs)" if args.all_pdfs else "the pdfs that occur on HCLG arcs (library default)",
                        "calls_in_flight": inflight,
                        "inputs": "int16 PCM in pageable host memory -> word ids in host memory (SURVEY 8(d)'s timed region; PCIe-inclusive)",
-                       "entry_point": ("rs_stream_accept / rs_streams_advance / rs_streams_finish" if wl == "streams" else
+                       "entry_point": ("rs_streams_accept / rs_streams_advance / rs_streams_finish" if wl == "streams" else
                                        "rs_decode_batch_sharded" if sharded else "rs_decode_batch"),
                        "record_gather": gather_by},
             "timed_seconds": elapsed,

@@ -106,6 +106,9 @@ void rs_stream_free(rs_stream *stream);
  * reached, the search over the new rows -- what online2-cli-nnet3-decode-faster.cc:143-161 does per tick), so that
  * rs_streams_finish (stdin EOF for all listed streams) only has the tail left; result utterance i belongs to streams[i].
  * An advance that fails leaves the streams it listed unusable (every later call on them except rs_stream_free is refused). */
+int rs_streams_accept(rs_stream *const *streams, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_streams);
+    /* rs_stream_accept for many streams in one call: pcm[i] / n_samples[i] go to streams[i] (a host that serves hundreds of streams
+     * hands over a round of audio per call; the samples are copied, like stdin is read, online2-cli-nnet3-decode-faster.cc:143-148) */
 int rs_streams_advance(rs_stream *const *streams, int32_t n_streams);
 int rs_streams_finish(rs_stream *const *streams, int32_t n_streams, int32_t nbest, float lattice_acoustic_scale,
                       rs_result **out);

@@ -30,7 +30,7 @@ class DecodeOpts(C.Structure):
 EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
     "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_shard_gather", "rs_stream_open", "rs_stream_accept",
-    "rs_stream_finish", "rs_stream_free", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
+    "rs_stream_finish", "rs_stream_free", "rs_streams_accept", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_mkgraph", "rs_fst_tool", "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
@@ -64,6 +64,7 @@ def load_library() -> C.CDLL:
     lib.rs_stream_finish.argtypes = [vp, i32, f32, C.POINTER(vp)]
     lib.rs_stream_free.argtypes = [vp]
     lib.rs_stream_free.restype = None
+    lib.rs_streams_accept.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32]
     lib.rs_streams_advance.argtypes = [C.POINTER(vp), i32]
     lib.rs_streams_finish.argtypes = [C.POINTER(vp), i32, i32, f32, C.POINTER(vp)]
     lib.rs_result_num_utts.argtypes = [vp]
@@ -322,6 +323,22 @@ class Stream:
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+def accept_streams(streams: Sequence[Stream], chunks: Sequence[np.ndarray]) -> None:
+    """rs_streams_accept: chunks[i] (int16 samples, contiguous) to streams[i], one call for all of them."""
+    n = len(streams)
+    arr = (C.c_void_p * n)(*[s._h for s in streams])
+    ptrs = (C.c_void_p * n)()
+    lens = (C.c_int32 * n)()
+    keep = []
+    for i, a in enumerate(chunks):
+        if a.dtype != np.int16 or not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a, dtype=np.int16)
+            keep.append(a)
+        ptrs[i] = a.ctypes.data
+        lens[i] = a.shape[0]
+    _check(lib().rs_streams_accept(arr, ptrs, lens, n))
 
 
 def advance_streams(streams: Sequence[Stream]) -> None:

@@ -185,6 +185,21 @@ int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples) {
   });
 }
 
+int rs_streams_accept(rs_stream *const *streams, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_streams) {
+  if (n_streams < 0 || (n_streams > 0 && (!streams || !pcm || !n_samples))) return ArgError("rs_streams_accept: bad argument");
+  for (int i = 0; i < n_streams; i++) {
+    if (!streams[i] || n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return ArgError("rs_streams_accept: bad argument");
+    if (streams[i]->finished) return ArgError("rs_streams_accept: stream already finished");
+  }
+  return Guard([&]() {
+    for (int i = 0; i < n_streams; i++) {
+      streams[i]->pcm.insert(streams[i]->pcm.end(), pcm[i], pcm[i] + n_samples[i]);
+      streams[i]->n_samples += n_samples[i];
+    }
+    return RS_OK;
+  });
+}
+
 static int CheckStreams(rs_stream *const *streams, int32_t n_streams, const char *who) {
   if (n_streams < 0 || (n_streams > 0 && !streams)) return ArgError((std::string(who) + ": bad argument").c_str());
   for (int i = 0; i < n_streams; i++) {

@@ -89,6 +89,7 @@ struct Timer {
   explicit Timer(hipStream_t st) : s(st) { for (auto &e : ev) (void)hipEventCreate(&e); }
   ~Timer() { for (auto &e : ev) (void)hipEventDestroy(e); }
   void Mark() { if (n < 8) (void)hipEventRecord(ev[n++], s); }
+  void Reset() { n = 0; }
   float Ms(int a, int b) { float ms = 0; if (a < n && b < n) (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; }
 };
 
@@ -199,6 +200,7 @@ class Model {
   std::unique_ptr<DecodeContext> stream_ctx_;
   std::mutex pool_mu_;             // pool bookkeeping and advances of this model, one at a time
   StreamPool *Pool();
+  void StreamsDrain(StreamPool *p, float *extra);
   void StreamGrow(rs_stream *st, int need_frames);
   std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)
   int pruned_from_ = 0;            // number of pdfs before pruning (0 = not pruned)

@@ -372,6 +372,25 @@ __global__ __launch_bounds__(256) void CopyRowsKernel(const unsigned *__restrict
     for (int k = threadIdx.x; k < width; k += 256) dp[k] = sp[k];
   }
 }
+// up to four such copies with the same row lists in one launch (blockIdx.y = which)
+__global__ __launch_bounds__(256) void CopyRowsMultiKernel(CopyRowsSet set, const int *__restrict__ src_row, const int *__restrict__ dst_row) {
+  const int i = blockIdx.x;
+  const CopyRowsSet::One c = set.a[blockIdx.y];
+  const unsigned *sp = static_cast<const unsigned *>(c.src) + (size_t)(src_row ? src_row[i] : i) * c.ld;
+  unsigned *dp = static_cast<unsigned *>(c.dst) + (size_t)(dst_row ? dst_row[i] : i) * c.ld;
+  if (((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp)) & 15) == 0) {
+    const int w4 = c.width >> 2;
+    for (int k = threadIdx.x; k < w4; k += 256) reinterpret_cast<uint4 *>(dp)[k] = reinterpret_cast<const uint4 *>(sp)[k];
+    for (int k = (w4 << 2) + threadIdx.x; k < c.width; k += 256) dp[k] = sp[k];
+  } else {
+    for (int k = threadIdx.x; k < c.width; k += 256) dp[k] = sp[k];
+  }
+}
+void LaunchCopyRowsMulti(const CopyRowsSet &set, const int *src_row, const int *dst_row, int n, hipStream_t s) {
+  if (n <= 0 || set.count <= 0) return;
+  hipLaunchKernelGGL(CopyRowsMultiKernel, dim3(n, set.count), dim3(256), 0, s, set, src_row, dst_row);
+}
+
 void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
                     hipStream_t s) {
   if (n <= 0 || width_words <= 0) return;

@@ -56,6 +56,12 @@ struct MfccDev {
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive = false,
                 const int *out_rows = nullptr);
 // dst row dst_row[i] (null = i) <- src row src_row[i] (null = i), width_words 4-byte words, leading dimensions in words.
+// the same for up to four arrays that share the row lists and whose rows are as wide as their pitch (the per-stream estimator state)
+struct CopyRowsSet {
+  struct One { const void *src; void *dst; long ld; int width; } a[4];
+  int count;
+};
+void LaunchCopyRowsMulti(const CopyRowsSet &set, const int *src_row, const int *dst_row, int n, hipStream_t s);
 void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
                     hipStream_t s);
 

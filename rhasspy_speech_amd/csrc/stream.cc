@@ -35,7 +35,15 @@
 namespace rs {
 
 struct StreamPool {
-  hipStream_t q = nullptr;       // every advance of the model runs here, in order
+  // Two queues, so that consecutive advances overlap on the device: `qa` runs an advance's feature and iVector stages, `q` its
+  // acoustic model and search (behind an event of `qa`).  Stage A of advance n + 1 touches rows and slots stage B of advance n
+  // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
+  hipStream_t q = nullptr, qa = nullptr;
+  hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // per arena parity: stage A issued / the advance finished
+  bool pending[2] = {false, false};                                            // an advance that used this parity's arenas may still run
+  std::unique_ptr<Timer> tm_a[2], tm_b[2];
+  long n_adv = 0;
+  bool sync_each = false;        // RS_STREAM_SYNC=1: wait for every advance before returning (the behaviour before the two queues)
   void *cx = nullptr;            // Model::DecodeContext with the arenas / staging of the advances (never handed to batch calls)
   int rows = 0;                  // capacity in frame rows
   int chunk = 24, ld_c = 0, ld_ll = 0, ld_i = 0, S = 0;
@@ -74,8 +82,12 @@ struct StreamPool {
 
 void StreamPoolDeleter::operator()(StreamPool *p) const {
   if (!p) return;
+  if (p->qa) (void)hipStreamSynchronize(p->qa);
+  if (p->q) (void)hipStreamSynchronize(p->q);
+  for (int k = 0; k < 2; k++) { p->tm_a[k].reset(); p->tm_b[k].reset(); if (p->ev_a[k]) (void)hipEventDestroy(p->ev_a[k]); if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]); }
   for (void *d : p->owned) (void)hipFree(d);
   if (p->q) (void)hipStreamDestroy(p->q);
+  if (p->qa) (void)hipStreamDestroy(p->qa);
   delete p;
 }
 
@@ -117,6 +129,14 @@ StreamPool *Model::Pool() {
   p->S = hclg_.num_states();
   p->reg = reg_dev_.nt != 0 && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
   RS_HIP(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
+  RS_HIP(hipStreamCreateWithFlags(&p->qa, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) {
+    RS_HIP(hipEventCreateWithFlags(&p->ev_a[k], hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
+    p->tm_a[k].reset(new Timer(p->qa));
+    p->tm_b[k].reset(new Timer(p->q));
+  }
+  p->sync_each = EnvInt("RS_STREAM_SYNC", 0) != 0;
   auto dalloc = [&](size_t bytes) {
     void *d = nullptr;
     RS_HIP(hipMalloc(&d, std::max<size_t>(bytes, 256)));
@@ -153,8 +173,25 @@ StreamPool *Model::Pool() {
   stream_ctx_ = std::move(c);
   p->cx = stream_ctx_.get();
   RS_HIP(hipStreamSynchronize(p->q));
+  RS_HIP(hipStreamSynchronize(p->qa));
   pool_ = std::move(p);
   return pool_.get();
+}
+
+// Waits for the advances still in flight and adds their stage times to the pool's totals (and to `extra`, if given: the finishing
+// call's own share).  Device errors of those advances surface here.
+void Model::StreamsDrain(StreamPool *p, float *extra) {
+  for (int k = 0; k < 2; k++) {
+    const int par = (int)((p->n_adv + k) & 1);      // the older advance first
+    if (!p->pending[par]) continue;
+    RS_HIP(hipEventSynchronize(p->ev_done[par]));
+    p->pending[par] = false;
+    Timer &ta = *p->tm_a[par], &tb = *p->tm_b[par];
+    const float ms[4] = {ta.Ms(0, 1), ta.Ms(1, 2), tb.Ms(0, 1), tb.Ms(1, 2)};
+    for (int j = 0; j < 4; j++) { p->stage_ms[j + 1] += ms[j]; if (extra) extra[j] += ms[j]; }
+  }
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
 }
 
 void Model::StreamOpen(rs_stream *st) {
@@ -172,7 +209,7 @@ void Model::StreamOpen(rs_stream *st) {
   // fresh estimator / search state in the slot
   if (fc_.ie.present) {
     const int Di = fc_.ie.ivector_dim(), usz = Di * (Di + 1) / 2;
-    LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->q);
+    LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->qa);      // (stage A's queue: the estimator state is its)
   }
   RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->q));
   st->open = true;
@@ -182,6 +219,7 @@ void Model::StreamClose(rs_stream *st) {
   if (!st->open) return;
   std::lock_guard<std::mutex> lk(pool_mu_);
   if (!pool_) return;
+  StreamsDrain(pool_.get(), nullptr);       // an advance that still uses the stream's rows / slot finishes first
   pool_->FreeRows(st->row0, st->cap);
   pool_->free_slots.push_back(st->slot);
   st->open = false;
@@ -190,6 +228,7 @@ void Model::StreamClose(rs_stream *st) {
 // A stream outgrew its row range: move it to a range twice as long (device-to-device copies on the pool's stream).
 void Model::StreamGrow(rs_stream *st, int need_frames) {
   StreamPool *p = pool_.get();
+  StreamsDrain(p, nullptr);                 // both queues idle: the rows move under nobody's feet
   int want = st->cap;
   while (want < need_frames) want *= 2;
   const int row0 = p->AllocRows(want);
@@ -204,6 +243,7 @@ void Model::StreamGrow(rs_stream *st, int need_frames) {
   if (p->ivec)
     RS_HIP(hipMemcpyAsync(p->ivec + (size_t)(row0 / p->chunk) * p->ld_i, p->ivec + (size_t)(st->row0 / p->chunk) * p->ld_i,
                           (size_t)(st->cap / p->chunk) * p->ld_i * 4, hipMemcpyDeviceToDevice, p->q));
+  RS_HIP(hipStreamSynchronize(p->q));       // ... and stage A of the next advance (other queue) finds them in place
   p->FreeRows(st->row0, st->cap);
   st->row0 = row0;
   st->cap = want;
@@ -214,10 +254,21 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   std::lock_guard<std::mutex> lk(pool_mu_);
   StreamPool *p = Pool();
   RS_HIP(hipSetDevice(opts_.device_id));
-  hipStream_t q = p->q;
+  // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive
+  // advances alternate between two arena / staging sets, so the host plans and issues advance n + 1 while advance n still runs
+  hipStream_t qa = p->qa, q = p->q;
   DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
-  DeviceArena &arena = cx.arena[0];
-  HostArena &harena = cx.host_arena[0];
+  const int par = (int)(p->n_adv & 1);
+  DeviceArena &arena = cx.arena[par];
+  HostArena &harena = cx.host_arena[par];
+  if (p->pending[par]) {       // the advance before the previous one used this set: it has to be over (it normally is)
+    RS_HIP(hipEventSynchronize(p->ev_done[par]));
+    p->pending[par] = false;
+    Timer &ta = *p->tm_a[par], &tb = *p->tm_b[par];
+    p->stage_ms[1] += ta.Ms(0, 1); p->stage_ms[2] += ta.Ms(1, 2); p->stage_ms[3] += tb.Ms(0, 1); p->stage_ms[4] += tb.Ms(1, 2);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+  }
   const Nnet &nn = am_.nnet;
   const bool has_iv = fc_.ie.present;
   const int C = fc_.mfcc.nceps, P = nn.output_dim, chunk = p->chunk, Rm = nn.right_context;
@@ -374,7 +425,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     need += IvecStatsScratchDoubles(ivec_dev_, std::max(nI, 1)) * 8 + 1024;
   }
   need += search_bytes + (size_t)n * 64 * 8 + 64 * 256 + (1u << 20);
-  arena.Reserve(need, q);
+  arena.Reserve(need, qa);
   arena.Reset();
   harena.Reset();
   // ---------------------------------------------------------------- uploads: index arrays, new samples
@@ -382,7 +433,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   {
     int *hp = harena.AllocT<int>(is.h.size() + 16);
     std::memcpy(hp, is.h.data(), is.h.size() * 4);
-    RS_HIP(hipMemcpyAsync(d_is, hp, is.h.size() * 4, hipMemcpyHostToDevice, q));
+    RS_HIP(hipMemcpyAsync(d_is, hp, is.h.size() * 4, hipMemcpyHostToDevice, qa));
   }
   auto D = [&](size_t off) { return d_is + off; };
   int16_t *d_pcm = arena.AllocT<int16_t>(pcm_total + 512);
@@ -396,10 +447,11 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
       std::memcpy(hp + o, st.pcm.data() + (first - st.pcm_start), sizeof(int16_t) * (size_t)cnt);
       o += (size_t)cnt;
     }
-    RS_HIP(hipMemcpyAsync(d_pcm, hp, sizeof(int16_t) * pcm_total, hipMemcpyHostToDevice, q));
+    RS_HIP(hipMemcpyAsync(d_pcm, hp, sizeof(int16_t) * pcm_total, hipMemcpyHostToDevice, qa));
   }
-  Timer tm(q);
-  tm.Mark();
+  Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par];
+  tma.Reset(); tmb.Reset();
+  tma.Mark();
   // ---------------------------------------------------------------- 1. MFCC
   if (nM > 0) {
     BatchGeom g;
@@ -407,58 +459,56 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     g.d_sample_off = reinterpret_cast<const int64_t *>(D(o_mso)); g.d_num_frames = D(o_mT); g.d_row_base = D(o_mrb);
     g.d_frame0 = D(o_mf0);
     int *ru = arena.AllocT<int>(rowsM), *rt = arena.AllocT<int>(rowsM);
-    LaunchRowGeometry(nM, rowsM, 0, D(o_mrb), nullptr, ru, rt, nullptr, q);
+    LaunchRowGeometry(nM, rowsM, 0, D(o_mrb), nullptr, ru, rt, nullptr, qa);
     g.d_row_utt = ru; g.d_row_t = rt;
-    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, p->raw, ld_c, q, false, D(o_mout));
+    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, p->raw, ld_c, qa, false, D(o_mout));
     // ---------------------------------------------------------------- 2. CMVN, resumed
     BatchGeom gc;
     gc.n_utts = nM; gc.d_num_frames = D(o_cT); gc.d_row_base = D(o_crb);
-    if (has_iv) LaunchOnlineCmvn(cmvn_iv_dev_, gc, p->raw, p->cm, ld_c, q, D(o_ctb), p->cmvn_iv, D(o_cslot));
-    if (fc_.use_cmvn) LaunchOnlineCmvn(cmvn_nnet_dev_, gc, p->raw, p->nn_in, ld_c, q, D(o_ctb), p->cmvn_nn, D(o_cslot));
+    if (has_iv) LaunchOnlineCmvn(cmvn_iv_dev_, gc, p->raw, p->cm, ld_c, qa, D(o_ctb), p->cmvn_iv, D(o_cslot));
+    if (fc_.use_cmvn) LaunchOnlineCmvn(cmvn_nnet_dev_, gc, p->raw, p->nn_in, ld_c, qa, D(o_ctb), p->cmvn_nn, D(o_cslot));
   }
-  tm.Mark();
+  tma.Mark();
   // ---------------------------------------------------------------- 3. iVectors of the new chunks
   auto falloc = [&](int rows, int ld) { return arena.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   if (nI > 0) {
     float *seg_raw = falloc(rowsI, ld_c), *seg_cm = falloc(rowsI, ld_c), *lda_raw = falloc(rowsI, ld_l), *lda_norm = falloc(rowsI, ld_l);
-    LaunchCopyRows(p->raw, ld_c, D(o_isrc), seg_raw, ld_c, nullptr, rowsI, C, q);
-    LaunchCopyRows(p->cm, ld_c, D(o_isrc), seg_cm, ld_c, nullptr, rowsI, C, q);
+    LaunchCopyRows(p->raw, ld_c, D(o_isrc), seg_raw, ld_c, nullptr, rowsI, C, qa);
+    LaunchCopyRows(p->cm, ld_c, D(o_isrc), seg_cm, ld_c, nullptr, rowsI, C, qa);
     BatchGeom g;
     g.n_utts = nI; g.L = sl; g.R = sr; g.total_rows = rowsI; g.guard = guard;
     g.d_num_frames = D(o_iT); g.d_row_base = D(o_irb);
     int *ru = arena.AllocT<int>(rowsI + 8), *rt = arena.AllocT<int>(rowsI + 8);
-    LaunchRowGeometry(nI, rowsI, sl, D(o_irb), nullptr, ru, rt, nullptr, q);
+    LaunchRowGeometry(nI, rowsI, sl, D(o_irb), nullptr, ru, rt, nullptr, qa);
     g.d_row_utt = ru; g.d_row_t = rt;
-    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_raw}, {ld_c}, nullptr, 0, lda_raw, ld_l, 1), rowsI, ru, q);
-    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, 1), rowsI, ru, q);
+    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_raw}, {ld_c}, nullptr, 0, lda_raw, ld_l, 1), rowsI, ru, qa);
+    LaunchGemm(MakeGemm(LdaPlan(ld_c), {seg_cm}, {ld_c}, nullptr, 0, lda_norm, ld_l, 1), rowsI, ru, qa);
     int *post_idx = arena.AllocT<int>((size_t)rowsI * nsel + 64);
     float *post_w = arena.AllocT<float>((size_t)rowsI * nsel + 64);
-    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, q);
+    LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, qa);
     double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
     double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
     double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
     double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, nI));
-    RS_HIP(hipMemsetAsync(gamma, 0, sizeof(double) * (size_t)nI * G, q));
-    RS_HIP(hipMemsetAsync(wfeats, 0, sizeof(double) * (size_t)nI * G * Dl, q));
-    // estimator state: slots -> dense, the steps, dense -> slots
-    LaunchCopyRows(p->lin, 2 * Di, D(o_islot), linear, 2 * Di, nullptr, nI, 2 * Di, q);
-    LaunchCopyRows(p->quad, 2 * usz, D(o_islot), quad, 2 * usz, nullptr, nI, 2 * usz, q);
-    LaunchCopyRows(p->numf, 2, D(o_islot), numf, 2, nullptr, nI, 2, q);
-    LaunchCopyRows(p->x, 2 * Di, D(o_islot), x, 2 * Di, nullptr, nI, 2 * Di, q);
+    // estimator state: slots -> dense, the steps, dense -> slots (one launch each way for the four arrays)
+    CopyRowsSet in_set{{{p->lin, linear, 2L * Di, 2 * Di}, {p->quad, quad, 2L * usz, 2 * usz}, {p->numf, numf, 2, 2}, {p->x, x, 2L * Di, 2 * Di}}, 4};
+    LaunchCopyRowsMulti(in_set, D(o_islot), nullptr, nI, qa);
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     for (int k = 0; k < max_new_chunks; k++) {
       const size_t o = (size_t)k * nI;
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, false, q);
-      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, q);
-      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, q);
-      LaunchIvecClear(ivec_dev_, nI, gamma, wfeats, q);
+      // (the first step starts the sums itself -- no clear of the 21 MB in front of it -- and nothing reads them after the last)
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, k == 0, qa);
+      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, qa);
+      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, qa);
+      if (k + 1 < max_new_chunks) LaunchIvecClear(ivec_dev_, nI, gamma, wfeats, qa);
     }
-    LaunchCopyRows(linear, 2 * Di, nullptr, p->lin, 2 * Di, D(o_islot), nI, 2 * Di, q);
-    LaunchCopyRows(quad, 2 * usz, nullptr, p->quad, 2 * usz, D(o_islot), nI, 2 * usz, q);
-    LaunchCopyRows(numf, 2, nullptr, p->numf, 2, D(o_islot), nI, 2, q);
-    LaunchCopyRows(x, 2 * Di, nullptr, p->x, 2 * Di, D(o_islot), nI, 2 * Di, q);
+    CopyRowsSet out_set{{{linear, p->lin, 2L * Di, 2 * Di}, {quad, p->quad, 2L * usz, 2 * usz}, {numf, p->numf, 2, 2}, {x, p->x, 2L * Di, 2 * Di}}, 4};
+    LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qa);
   }
-  tm.Mark();
+  tma.Mark();
+  RS_HIP(hipEventRecord(p->ev_a[par], qa));
+  RS_HIP(hipStreamWaitEvent(q, p->ev_a[par], 0));
+  tmb.Mark();
   // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context)
   if (nN > 0) {
     std::vector<float *> bufp(nn.bufs.size(), nullptr);
@@ -472,7 +522,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, row_maps, 1, 0, nn.ops.size(), q, &imgs);
     LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
   }
-  tm.Mark();
+  tmb.Mark();
   // ---------------------------------------------------------------- 5. search
   BatchGeom gd;
   gd.n_utts = n; gd.max_frames = maxT; gd.d_num_frames = D(o_dT); gd.d_row_base = D(o_drb);
@@ -491,7 +541,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   } else if (final) {
     LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, q);
   }
-  tm.Mark();
+  tmb.Mark();
   // ---------------------------------------------------------------- host bookkeeping
   for (int i = 0; i < n; i++) {
     rs_stream &st = *streams[i];
@@ -507,19 +557,38 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
       st.pcm_start = keep_from;
     }
   }
+  RS_HIP(hipEventRecord(p->ev_done[par], q));
+  p->pending[par] = true;
+  p->n_adv++;
   if (!final) {
-    RS_HIP(hipStreamSynchronize(q));
-    const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
-    for (int k = 0; k < 4; k++) p->stage_ms[k + 1] += tm.Ms(k, k + 1);
+    // No wait here: the next advance is planned and issued while this one runs.  What it did on the device is accounted for --
+    // and a device error of it reported -- by whichever later call of this model waits for it.
+    if (p->sync_each) StreamsDrain(p, nullptr);
     p->stage_ms[6] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return;
+  }
+  float own[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    // every earlier advance first (their time is the stream's, not this call's), then this one
+    const int other = par ^ 1;
+    if (p->pending[other]) {
+      RS_HIP(hipEventSynchronize(p->ev_done[other]));
+      p->pending[other] = false;
+      Timer &ta = *p->tm_a[other], &tb = *p->tm_b[other];
+      p->stage_ms[1] += ta.Ms(0, 1); p->stage_ms[2] += ta.Ms(1, 2); p->stage_ms[3] += tb.Ms(0, 1); p->stage_ms[4] += tb.Ms(1, 2);
+    }
+    RS_HIP(hipEventSynchronize(p->ev_done[par]));
+    p->pending[par] = false;
+    own[0] = tma.Ms(0, 1); own[1] = tma.Ms(1, 2); own[2] = tmb.Ms(0, 1); own[3] = tmb.Ms(1, 2);
+    for (int k = 0; k < 4; k++) p->stage_ms[k + 1] += own[k];
   }
   // ---------------------------------------------------------------- results
   res->utts.resize(n);
   for (int i = 0; i < n; i++) res->utts[i].num_frames = pl[i].avail;
-  CollectResults(sp, cx, 0, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, q, res->utts.data(), res->timings);
-  tm.Mark();
+  Timer tmr(q);
+  tmr.Mark();
+  CollectResults(sp, cx, par, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, q, res->utts.data(), res->timings);
+  tmr.Mark();
   if (opts_.keep_intermediates) {
     const float *fin = fc_.use_cmvn ? p->nn_in : p->raw;
     for (int i = 0; i < n; i++) {
@@ -543,8 +612,8 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le)); }
   // stage times of the whole stream(s): this call plus the advances since the previous finish on this model; [7] = this call alone
   res->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  for (int k = 0; k < 4; k++) res->timings[k + 1] = p->stage_ms[k + 1] + tm.Ms(k, k + 1);
-  res->timings[5] = tm.Ms(4, 5);
+  for (int k = 0; k < 4; k++) res->timings[k + 1] = p->stage_ms[k + 1];
+  res->timings[5] = tmr.Ms(0, 1);
   res->timings[6] = p->stage_ms[6] + res->timings[7];
   for (float &v : p->stage_ms) v = 0.f;
 }
