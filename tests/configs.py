@@ -79,3 +79,15 @@ def load_golden(name: str):
     off = g["word_offsets"]
     words = [g["words"][off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
     return words, g["graph_cost"], g["acoustic_cost"]
+
+
+def load_golden_nbest(name: str):
+    """-> per utterance: list of (word ids, graph cost, acoustic cost), best first, as `lattice-to-nbest --n=5 | nbest-to-linear`
+    printed them for the reference's lattice (oracle/gen_config_golden.py)."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    wo, uo = g["nbest_word_offsets"], g["nbest_utt_offsets"]
+    out = []
+    for u in range(len(uo) - 1):
+        out.append([(g["nbest_words"][wo[k]:wo[k + 1]].tolist(), float(g["nbest_graph_cost"][k]), float(g["nbest_acoustic_cost"][k]))
+                    for k in range(uo[u], uo[u + 1])])
+    return out

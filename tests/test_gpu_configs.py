@@ -84,6 +84,71 @@ def test_config1_headline_batch_vs_reference(zam_grammar):
     _check_against_reference("c1_grammar", pruned.words, pruned.costs, len(pcms))
 
 
+# The utterances of the full-size configs on which an order-dependent token of the reference (see _check_against_reference) changes a
+# COST: same 5-best word sequences in the same order, the total of some hypothesis off by the amount noted (ours minus the
+# reference's; the negative one is the reference pruning, with its larger token count, a token the kernels keep).  3 of 1600.
+ORDER_DEPENDENT_COSTS = {"c2_arpa": {162: 2.05}, "c3_mixed_de": {238: 0.21}, "c3_mixed_fr": {110: -0.93}}
+
+
+def _check_nbest_against_reference(name, res, n):
+    """5-best lists of every utterance against the reference's (`lattice-to-nbest --n=5` on its own lattice, one process per
+    utterance): the same word sequences in the same order for ALL utterances; costs within tolerance except on the utterances
+    listed above, where the difference must be the one recorded."""
+    ref = configs.load_golden_nbest(name)
+    assert len(ref) == n
+    wrong, off = [], {}
+    for u in range(n):
+        got = [(res.words(u, k),) + tuple(res.costs(u, k)) for k in range(res.num_hyps(u))]
+        if [g[0] for g in got] != [r[0] for r in ref[u]]:
+            wrong.append(u)
+            continue
+        for g, r in zip(got, ref[u]):
+            if not (np.isclose(g[1], r[1], rtol=COST_RTOL, atol=COST_ATOL) and np.isclose(g[2], r[2], rtol=COST_RTOL, atol=COST_ATOL)):
+                off[u] = (g[1] + g[2]) - (r[1] + r[2])
+                break
+    assert not wrong, f"{name}: the 5-best lists of {len(wrong)} of {n} utterances differ from the reference's, first {wrong[:8]}"
+    known = ORDER_DEPENDENT_COSTS.get(name, {})
+    assert set(off) <= set(known), f"{name}: 5-best costs differ from the reference's on {sorted(set(off) - set(known))}"
+    for u, d in off.items():
+        assert abs(d - known[u]) < 0.02, (name, u, d)
+
+
+def test_config1_five_best_of_every_utterance(zam_grammar):
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    pcms = configs.grammar_utterances()
+    _check_nbest_against_reference("c1_grammar", model.decode_batch(pcms, nbest=5), len(pcms))
+
+
+def test_config2_five_best_of_every_utterance(zam_arpa):
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_arpa, _lib.default_opts())
+    pcms = configs.arpa_utterances()
+    _check_nbest_against_reference("c2_arpa", model.decode_batch(pcms, nbest=5), len(pcms))
+
+
+def test_config3_five_best_of_every_utterance(tmp_path_factory):
+    from rhasspy_speech_amd import _lib
+    names, pcms = configs.mixed_utterances()
+    for key, tag in (("de_DE-like", "c3_mixed_de"), ("fr_FR-like", "c3_mixed_fr")):
+        m = configs.MIXED_MODELS[key]
+        md, gd = configs.build_grammar_model(tmp_path_factory.mktemp("nb_" + tag), m["model_seed"], m["graph_seed"])
+        mine = [p for nm, p in zip(names, pcms) if nm == key]
+        _check_nbest_against_reference(tag, _lib.Model(md, gd, _lib.default_opts()).decode_batch(mine, nbest=5), len(mine))
+
+
+def test_config4_five_best_of_every_stream(zam_grammar):
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    pcms = configs.stream_utterances()
+    streams = [_lib.Stream(model) for _ in pcms]
+    tick = 8 * 1024
+    for r in range((max(len(p) for p in pcms) + tick - 1) // tick):
+        _lib.accept_streams(streams, [p[r * tick:(r + 1) * tick] for p in pcms])
+        _lib.advance_streams(streams)
+    _check_nbest_against_reference("c4_streams", _lib.finish_streams(streams, nbest=5), len(pcms))
+
+
 def test_config2_arpa_hclg_256x3s(zam_arpa):
     from rhasspy_speech_amd import _lib
     model_dir, graph_dir = zam_arpa
