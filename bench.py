@@ -468,11 +468,12 @@ def main() -> None:
                                     f"{n_gemm} launches per step (the nnet stage)") if split_bf16 else f"GemmKernel, {n_gemm} launches per step",
                          "launches": n_gemm, "avg_launch_ms": nnet_ms / n_gemm, "flops_per_launch": flops / n_gemm,
                          "stage_ms": nnet_ms, "measured_on": roof_on, "frac_of_fp32_mfma_peak": achieved / 157.3}
-            dtraffic, dtraffic_from = pmc_traffic(wl, "DecodeKernel")
+            # (the search kernel the workload runs: the register-resident one on the grammar graph, the live-state-table one on the ARPA graph)
+            dtraffic, dtraffic_from = pmc_traffic(wl, "HashDecodeKernel" if wl == "arpa" else "RegDecodeKernel")
             roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9 if stage[4] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                         "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0 if stage[4] > 0 else 0.0, "traffic": dtraffic, "traffic_from": dtraffic_from,
                         "algorithmic_bytes": dec_bytes,
-                        "kernel": "beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
+                        "kernel": ("HashDecodeKernel" if wl == "arpa" else "RegDecodeKernel") + ": beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
             roofline = roof_mfma if stage[3] >= stage[4] else roof_dec
             out["stages_from"] = f"{n_iso} un-overlapped calls after the timed region (samples resident in HBM)"
             out["roofline"] = roofline

@@ -964,13 +964,14 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
       {
         // the winner of a slot (= the candidate whose arc id is left in the key) appends the token, complete with back pointer
         // and arc, or -- at or above the final cutoff -- empties the key again
+        constexpr int WB = 4;
         const int nc2 = c.n_cand;
-        for (int ib = tid; ib < nc2; ib += 4 * NT) {
-          int s2[4], ca[4], cx[4];
-          unsigned long long key[4];
-          bool on[4];
+        for (int ib = tid; ib < nc2; ib += WB * NT) {       // WB candidates per thread with every load stage of all of them in flight together
+          int s2[WB], ca[WB], cx[WB];
+          unsigned long long key[WB];
+          bool on[WB];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
+          for (int q = 0; q < WB; q++) {
             const int i = ib + q * NT;
             on[q] = i < nc2;
             const int ii = on[q] ? i : nc2 - 1;
@@ -979,12 +980,12 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
             cx[q] = cand_x[ii];
           }
 #pragma unroll
-          for (int q = 0; q < 4; q++) key[q] = LoadKey(&keys[cx[q] >> 16]);
-          unsigned ne[4];
+          for (int q = 0; q < WB; q++) key[q] = LoadKey(&keys[cx[q] >> 16]);
+          unsigned ne[WB];
 #pragma unroll
-          for (int q = 0; q < 4; q++) ne[q] = h.state_rec[s2[q]].y;       // (epsilon arcs of the state: the closure's first work list is filled here)
+          for (int q = 0; q < WB; q++) ne[q] = h.state_rec[s2[q]].y;       // (epsilon arcs of the state: the closure's first work list is filled here)
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
+          for (int q = 0; q < WB; q++) {
             if (!on[q] || (unsigned)(key[q] & 0xFFFFFFFFull) != (unsigned)ca[q]) continue;
             const int sl = cx[q] >> 16;
             if (KeyCost(key[q]) < next_cutoff) {
@@ -1088,35 +1089,36 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
       const int nn = c.n_next < next_cap ? c.n_next : next_cap;
       float lv = INF;                                     // cheapest token of the new frame (lowest index on ties)
       int li = 0x7fffffff;
-      for (int ib = tid; ib < nn; ib += 4 * NT) {
-        int4 tk[4];
-        int sx[4], bp[4];
-        unsigned long long key[4];
-        bool on[4], eps[4];
+      constexpr int MB = 4;                               // tokens per thread and trip, every load stage of all of them in flight together
+      for (int ib = tid; ib < nn; ib += MB * NT) {
+        int4 tk[MB];
+        int sx[MB], bp[MB];
+        unsigned long long key[MB];
+        bool on[MB], eps[MB];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < MB; q++) {
           const int i = ib + q * NT;
           on[q] = i < nn;
           tk[q] = next_toks[on[q] ? i : nn - 1];
           if (!on[q]) tk[q].y = 0;       // (the stand-in token may have been rewritten by its owner already: its .y is then a cost, not a slot)
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) key[q] = LoadKey(&keys[tk[q].y]);
+        for (int q = 0; q < MB; q++) key[q] = LoadKey(&keys[tk[q].y]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < MB; q++) {
           const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
           eps[q] = arc != RS_NOARC && (int)arc != tk[q].w;     // an epsilon arc made or improved it: its source owns a token of this frame
           sx[q] = eps[q] ? h.arc_srcx[arc] & 0x7fffffff : 0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < MB; q++) {
           const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
           int b = arc == RS_NOARC ? -1 : tk[q].z;
           if (eps[q]) { const int ss = SlotFind(tags, (unsigned)sx[q]); b = ss >= 0 ? slot_tok[ss] : -1; }
           bp[q] = b;
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < MB; q++)
           if (on[q]) {
             const float cst = KeyCost(key[q]);
             const int i = ib + q * NT;

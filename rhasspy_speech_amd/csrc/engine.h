@@ -178,9 +178,9 @@ class Model {
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipStream_t stream_dec = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on `stream`
     hipEvent_t slab_ev[9] = {};
-    DeviceArena arena[2];                  // one per concurrent utterance group
-    HostArena host_arena[2];
-    LatArcBuffer lat_arcs[2];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
+    DeviceArena arena[3];                  // one per concurrent utterance group (batch calls use two; stream advances rotate over three)
+    HostArena host_arena[3];
+    LatArcBuffer lat_arcs[3];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
     int16_t *h_pcm_pinned = nullptr;       // pinned staging for host-buffer batches
     size_t h_pcm_cap = 0;
     int16_t *d_pcm = nullptr;

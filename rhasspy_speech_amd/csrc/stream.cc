@@ -39,9 +39,10 @@ struct StreamPool {
   // acoustic model and search (behind an event of `qa`).  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
   hipStream_t q = nullptr, qa = nullptr;
-  hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // per arena parity: stage A issued / the advance finished
-  bool pending[2] = {false, false};                                            // an advance that used this parity's arenas may still run
-  std::unique_ptr<Timer> tm_a[2], tm_b[2];
+  static constexpr int kDepth = 3;                                             // advances in flight at most = arena / staging sets
+  hipEvent_t ev_a[kDepth] = {}, ev_done[kDepth] = {};                          // per set: stage A issued / the advance finished
+  bool pending[kDepth] = {};                                                   // an advance that used this set may still run
+  std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth];
   long n_adv = 0;
   bool sync_each = false;        // RS_STREAM_SYNC=1: wait for every advance before returning (the behaviour before the two queues)
   void *cx = nullptr;            // Model::DecodeContext with the arenas / staging of the advances (never handed to batch calls)
@@ -84,7 +85,7 @@ void StreamPoolDeleter::operator()(StreamPool *p) const {
   if (!p) return;
   if (p->qa) (void)hipStreamSynchronize(p->qa);
   if (p->q) (void)hipStreamSynchronize(p->q);
-  for (int k = 0; k < 2; k++) { p->tm_a[k].reset(); p->tm_b[k].reset(); if (p->ev_a[k]) (void)hipEventDestroy(p->ev_a[k]); if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]); }
+  for (int k = 0; k < StreamPool::kDepth; k++) { p->tm_a[k].reset(); p->tm_b[k].reset(); if (p->ev_a[k]) (void)hipEventDestroy(p->ev_a[k]); if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]); }
   for (void *d : p->owned) (void)hipFree(d);
   if (p->q) (void)hipStreamDestroy(p->q);
   if (p->qa) (void)hipStreamDestroy(p->qa);
@@ -130,7 +131,7 @@ StreamPool *Model::Pool() {
   p->reg = reg_dev_.nt != 0 && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
   RS_HIP(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
   RS_HIP(hipStreamCreateWithFlags(&p->qa, hipStreamNonBlocking));
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < StreamPool::kDepth; k++) {
     RS_HIP(hipEventCreateWithFlags(&p->ev_a[k], hipEventDisableTiming));
     RS_HIP(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
     p->tm_a[k].reset(new Timer(p->qa));
@@ -181,8 +182,8 @@ StreamPool *Model::Pool() {
 // Waits for the advances still in flight and adds their stage times to the pool's totals (and to `extra`, if given: the finishing
 // call's own share).  Device errors of those advances surface here.
 void Model::StreamsDrain(StreamPool *p, float *extra) {
-  for (int k = 0; k < 2; k++) {
-    const int par = (int)((p->n_adv + k) & 1);      // the older advance first
+  for (int k = 0; k < StreamPool::kDepth; k++) {
+    const int par = (int)((p->n_adv + k) % StreamPool::kDepth);      // the oldest advance first
     if (!p->pending[par]) continue;
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
@@ -255,13 +256,13 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   StreamPool *p = Pool();
   RS_HIP(hipSetDevice(opts_.device_id));
   // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive
-  // advances alternate between two arena / staging sets, so the host plans and issues advance n + 1 while advance n still runs
+  // advances rotate over kDepth arena / staging sets, so the host plans and issues the next advances while earlier ones still run
   hipStream_t qa = p->qa, q = p->q;
   DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
-  const int par = (int)(p->n_adv & 1);
+  const int par = (int)(p->n_adv % StreamPool::kDepth);
   DeviceArena &arena = cx.arena[par];
   HostArena &harena = cx.host_arena[par];
-  if (p->pending[par]) {       // the advance before the previous one used this set: it has to be over (it normally is)
+  if (p->pending[par]) {       // the advance kDepth calls ago used this set: it has to be over (it normally is)
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
     Timer &ta = *p->tm_a[par], &tb = *p->tm_b[par];
@@ -570,8 +571,9 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   float own[4] = {0.f, 0.f, 0.f, 0.f};
   {
     // every earlier advance first (their time is the stream's, not this call's), then this one
-    const int other = par ^ 1;
-    if (p->pending[other]) {
+    for (int k = 1; k < StreamPool::kDepth; k++) {
+      const int other = (par + k) % StreamPool::kDepth;       // oldest first
+      if (!p->pending[other]) continue;
       RS_HIP(hipEventSynchronize(p->ev_done[other]));
       p->pending[other] = false;
       Timer &ta = *p->tm_a[other], &tb = *p->tm_b[other];
