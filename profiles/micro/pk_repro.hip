@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -o pk_repro pk_repro.hip && ./pk_repro
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,6 +55,38 @@ __global__ __launch_bounds__(256, 2) void victim(unsigned *errors, unsigned *fir
   if (bad) { atomicAdd(errors, bad); atomicMin(first_bad, (unsigned)(blockIdx.x * 256 + threadIdx.x)); }
 }
 
+// The operand forms hipcc actually emits in the feature kernel when it may vectorize (disassembly of MfccKernel<512, 4> built
+// without -fno-slp-vectorize -fno-vectorize): negated second operands, op_sel half swaps, an SGPR pair and an inline constant as
+// sources, v_pk_mov_b32.  No closed-form answer here: the kernel is deterministic, so a run beside the burner must give the bits
+// a run alone gave.
+__global__ __launch_bounds__(256, 2) void victim_forms(v2f *out, int rounds, float sa, float sb) {
+  const int lane = threadIdx.x & 63;
+  v2f s = {sa, sb};
+  __asm__ volatile("v_readfirstlane_b32 s40, %0\n\tv_readfirstlane_b32 s41, %1" : : "v"(s.x), "v"(s.y) : "s40", "s41");
+  unsigned x0 = 0, x1 = 0, x2 = 0, x3 = 0;          // checksums (XOR of result bits): no floating-point feedback, nothing can overflow
+  for (int it = 0; it < rounds; it++) {
+    // fresh, finite inputs every round
+    const float f = (float)((it * 37 + lane * 11) & 1023) * 0.0078125f;
+    v2f a = {1.0f + f, 2.0f - f}, b = {0.25f + f, 0.75f - 0.5f * f}, c = {0.5f - f, 1.5f + f}, d = {1.25f, 0.125f + f};
+    v2f t, u, v, w, z;
+    __asm__ volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    __asm__ volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(u) : "v"(c), "v"(d));
+    __asm__ volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(t), "v"(u));
+    __asm__ volatile("v_pk_mul_f32 %0, %1, s[40:41] op_sel_hi:[1,0]" : "=v"(w) : "v"(u));
+    __asm__ volatile("v_pk_mul_f32 %0, %1, s[40:41]" : "=v"(z) : "v"(t));
+    __asm__ volatile("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(d) : "v"(v));
+    __asm__ volatile("s_nop 0\n\tv_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "=v"(t) : "v"(w));
+    __asm__ volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(u) : "v"(z), "v"(d));
+    __asm__ volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a) : "v"(v), "v"(t));
+    __asm__ volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(b) : "v"(w), "v"(u));
+    x0 ^= __float_as_uint(a.x) + (unsigned)it; x1 ^= __float_as_uint(a.y); x2 ^= __float_as_uint(b.x); x3 ^= __float_as_uint(b.y) + __float_as_uint(d.x) + __float_as_uint(u.y);
+  }
+  v2f *o = out + ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  o[0] = v2f{__uint_as_float(x0 & 0x007fffffu), __uint_as_float(x1 & 0x007fffffu)};      // (stored as denormal bit patterns: compared bitwise on the host)
+  o[1] = v2f{__uint_as_float(x2 & 0x007fffffu), __uint_as_float(x3 & 0x007fffffu)};
+  o[2] = v2f{0.f, 0.f}; o[3] = v2f{0.f, 0.f};
+}
+
 __global__ __launch_bounds__(256, 2) void burner(float *out, int iters) {
   f32x16 acc[4];
   for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
@@ -94,5 +127,29 @@ int main() {
              with_burner ? "MFMA burner on every CU" : "alone", total, total ? " (first bad thread below)" : "");
       if (total) printf("  first bad thread %u\n", first);
     }
+  // ---- the compiler's operand forms: bits beside the burner against bits alone
+  {
+    const size_t n = (size_t)512 * 256 * 4;
+    v2f *d_forms;
+    CHECK(hipMalloc(&d_forms, n * sizeof(v2f)));
+    std::vector<v2f> alone(n), beside(n);
+    hipLaunchKernelGGL(victim_forms, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+    CHECK(hipMemcpyAsync(alone.data(), d_forms, n * sizeof(v2f), hipMemcpyDeviceToHost, sv));
+    CHECK(hipStreamSynchronize(sv));
+    size_t wrong = 0, nonfinite = 0;
+    for (int rep = 0; rep < 5; rep++) {
+      for (int l = 0; l < 6; l++) hipLaunchKernelGGL(burner, dim3(512), dim3(256), 0, sb, d_out, 150000);
+      hipLaunchKernelGGL(victim_forms, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+      CHECK(hipMemcpyAsync(beside.data(), d_forms, n * sizeof(v2f), hipMemcpyDeviceToHost, sv));
+      CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sb));
+      for (size_t i = 0; i < n; i++) {
+        unsigned a[2], b[2];
+        memcpy(a, &alone[i], 8); memcpy(b, &beside[i], 8);
+        wrong += (a[0] != b[0]) + (a[1] != b[1]);
+      }
+    }
+    for (size_t i = 0; i < n; i++) { const float x0 = alone[i][0], x1 = alone[i][1]; nonfinite += !(x0 == x0) + !(x1 == x1); }
+    printf("victim with the compiler's operand forms (neg, op_sel, SGPR pair, inline constant, v_pk_mov_b32): %zu values differ from the run alone in 5 launches beside the burner (%zu NaNs in the reference run; first value %g)\n", wrong, nonfinite, (double)alone[0][0]);
+  }
   return 0;
 }
