@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256, 2) void victim(unsigned *errors, unsigned *fir
 // without -fno-slp-vectorize -fno-vectorize): negated second operands, op_sel half swaps, an SGPR pair and an inline constant as
 // sources, v_pk_mov_b32.  No closed-form answer here: the kernel is deterministic, so a run beside the burner must give the bits
 // a run alone gave.
+// PARTIAL: the packed operations run under EXEC masks that change every round (single lanes, half rows, whole 16-lane quarters off),
+// as in the feature kernel, where they sit inside divergent branches of the butterfly tasks.
+template <bool PARTIAL>
 __global__ __launch_bounds__(256, 2) void victim_forms(v2f *out, int rounds, float sa, float sb) {
   const int lane = threadIdx.x & 63;
   v2f s = {sa, sb};
@@ -69,6 +72,13 @@ __global__ __launch_bounds__(256, 2) void victim_forms(v2f *out, int rounds, flo
     const float f = (float)((it * 37 + lane * 11) & 1023) * 0.0078125f;
     v2f a = {1.0f + f, 2.0f - f}, b = {0.25f + f, 0.75f - 0.5f * f}, c = {0.5f - f, 1.5f + f}, d = {1.25f, 0.125f + f};
     v2f t, u, v, w, z;
+    if (PARTIAL) {
+      const unsigned h = (unsigned)it * 2654435761u;
+      const unsigned long long quarters = ((h >> 3) & 1 ? 0xFFFFull : 0) | ((h >> 4) & 1 ? 0xFFFF0000ull : 0) | ((h >> 5) & 1 ? 0xFFFF00000000ull : 0) |
+                                          ((h >> 6) & 1 ? 0xFFFF000000000000ull : 0);
+      const unsigned long long mask = (h & 1) ? quarters : ((h & 2) ? 0x5555555555555555ull << ((h >> 7) & 1) : ~(1ull << ((h >> 8) & 63)));
+      if (!((mask >> lane) & 1ull)) continue;
+    }
     __asm__ volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
     __asm__ volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(u) : "v"(c), "v"(d));
     __asm__ volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(v) : "v"(t), "v"(u));
@@ -133,13 +143,16 @@ int main() {
     v2f *d_forms;
     CHECK(hipMalloc(&d_forms, n * sizeof(v2f)));
     std::vector<v2f> alone(n), beside(n);
-    hipLaunchKernelGGL(victim_forms, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+    for (int partial = 0; partial < 2; partial++) {
+    if (partial) hipLaunchKernelGGL(victim_forms<true>, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+    else hipLaunchKernelGGL(victim_forms<false>, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
     CHECK(hipMemcpyAsync(alone.data(), d_forms, n * sizeof(v2f), hipMemcpyDeviceToHost, sv));
     CHECK(hipStreamSynchronize(sv));
     size_t wrong = 0, nonfinite = 0;
     for (int rep = 0; rep < 5; rep++) {
       for (int l = 0; l < 6; l++) hipLaunchKernelGGL(burner, dim3(512), dim3(256), 0, sb, d_out, 150000);
-      hipLaunchKernelGGL(victim_forms, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+      if (partial) hipLaunchKernelGGL(victim_forms<true>, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
+      else hipLaunchKernelGGL(victim_forms<false>, dim3(512), dim3(256), 0, sv, d_forms, 100000, 0.75f, 1.25f);
       CHECK(hipMemcpyAsync(beside.data(), d_forms, n * sizeof(v2f), hipMemcpyDeviceToHost, sv));
       CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sb));
       for (size_t i = 0; i < n; i++) {
@@ -149,7 +162,8 @@ int main() {
       }
     }
     for (size_t i = 0; i < n; i++) { const float x0 = alone[i][0], x1 = alone[i][1]; nonfinite += !(x0 == x0) + !(x1 == x1); }
-    printf("victim with the compiler's operand forms (neg, op_sel, SGPR pair, inline constant, v_pk_mov_b32): %zu values differ from the run alone in 5 launches beside the burner (%zu NaNs in the reference run; first value %g)\n", wrong, nonfinite, (double)alone[0][0]);
+    printf("victim with the compiler's operand forms (neg, op_sel, SGPR pair, inline constant, v_pk_mov_b32)%s: %zu values differ from the run alone in 5 launches beside the burner (%zu NaNs in the reference run; first value %g)\n", partial ? ", under changing partial EXEC masks" : "", wrong, nonfinite, (double)alone[0][0]);
+    }
   }
   return 0;
 }
