@@ -874,20 +874,21 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaKernel(IvecDev iv, int n_utts
 #define RS_WAIT_SET(CNT, b)                                                                                                          \
   __asm__ volatile("s_waitcnt vmcnt(" #CNT ")"                                                                                       \
                    : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : : "memory")
-template <int NCH>                                          // num_gauss = 128 NCH; the chunk loop is unrolled: a register set that is
+template <int NCH, int MT>                                          // num_gauss = 128 NCH; the chunk loop is unrolled: a register set that is
                                                             // live around a loop's back edge gets copied there, in flight or not
 __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_utts, const float *__restrict__ gamma,
                                                           const double *__restrict__ change, double *__restrict__ quadratic,
                                                           double *__restrict__ linear) {
   constexpr int GC = 128;                                   // Gaussians per LDS chunk
-  __shared__ float gml[kMmU][GC + 1];
+  constexpr int MU = 16 * MT;                               // utterances per workgroup (MT = 1: a few dozen streams over four times the workgroups)
+  __shared__ float gml[MU][GC + 1];
   const int G = iv.num_gauss, I = iv.ivec_dim, usz = I * (I + 1) / 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  const int u0 = blockIdx.y * kMmU, k0 = (blockIdx.x * 4 + wave) * 16;
+  const int u0 = blockIdx.y * MU, k0 = (blockIdx.x * 4 + wave) * 16;
   const int kcol = k0 + lr < usz ? k0 + lr : usz - 1;
-  f64x4 acc[4];
+  f64x4 acc[MT];
 #pragma unroll
-  for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int m = 0; m < MT; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
   // eight k-steps of model-matrix values per request group, and the NEXT group (of this chunk or the first of the next one) is
   // requested before the MFMAs of the current one: with at most one wave per SIMD nothing else hides the round trip (68 us for
   // 64 utterances before, all of it a chain of 16 exposed L2 / HBM latencies)
@@ -896,11 +897,11 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_u
 #define RS_QMMA(b, gi)                                                                       \
   _Pragma("unroll") for (int q = 0; q < 8; q++) {                                           \
     const int gc = (gi) + 4 * q + lk;                                                        \
-    _Pragma("unroll") for (int m = 0; m < 4; m++)                                           \
+    _Pragma("unroll") for (int m = 0; m < MT; m++)                                          \
       acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)gml[16 * m + lr][gc], b[q], acc[m], 0, 0, 0); \
   }
   // (occupancy chunk of the next step: global -> registers during the MFMAs of this one, to LDS between two barriers afterwards)
-  constexpr int SPT = kMmU * GC / 256;
+  constexpr int SPT = MU * GC / 256;
   float stg[SPT];
   // (also in asm, all of them always issued -- rows past n_utts re-read the last utterance, their results are never stored -- so
   // that the waits below can count them: a load the compiler knows about makes it wait vmcnt(0) before the LDS store, request
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_u
 #define RS_WAIT_N(n, b)                                                                                                 \
   do {                                                                                                                  \
     if ((n) == 0) { RS_WAIT_SET(0, b); } else if ((n) == 8) { RS_WAIT_SET(8, b); } else if ((n) == 16) { RS_WAIT_SET(16, b); } \
-    else if ((n) == 40) { RS_WAIT_SET(40, b); } else { RS_WAIT_SET(48, b); }                                            \
+    else if ((n) == 24) { RS_WAIT_SET(24, b); } else if ((n) == 40) { RS_WAIT_SET(40, b); } else { RS_WAIT_SET(48, b); }  \
   } while (0)
   constexpr int NG = 4 * NCH;
   stage_load(0);
@@ -940,7 +941,8 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_u
     const bool more = ch + 1 < NCH;
     if (t + 2 < NG) { RS_QFETCH(bq[(t + 2) % 3], (t + 2) * 32); }
     const int newer = NG - 1 - t < 2 ? NG - 1 - t : 2;
-    RS_WAIT_N(8 * newer + ((more && (r == 1 || r == 2)) ? 32 : 0), bq[t % 3]);
+    static_assert(SPT == 8 || SPT == 32, "wait counts below");
+    RS_WAIT_N(8 * newer + ((more && (r == 1 || r == 2)) ? SPT : 0), bq[t % 3]);
     if (r == 0 && more) stage_load((ch + 1) * GC);
     RS_QMMA(bq[t % 3], r * 32);
     if (r == 3 && more) {
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_u
   while (r * (r + 1) / 2 > k) r--;
   const bool diag = (k == r * (r + 1) / 2 + r);
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+  for (int m = 0; m < MT; m++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int u = u0 + 16 * m + lk + 4 * q;
@@ -971,22 +973,24 @@ __global__ __launch_bounds__(256) void IvecQuadMfmaAsmKernel(IvecDev iv, int n_u
 }
 // partial[ks][u][i] = sum over the Gaussians of range ks and all d of Sigma_inv_M[g][d][i] * wfeats[u][g][d]:
 // [n_utts x (G D)] x [(G D) x I], K split into kIvecKS Gaussian ranges (reduced in fixed order by IvecLinearReduceKernel)
+template <int MT>      // M tiles of 16 utterances per workgroup: 4 for batches, 1 for a few dozen streams (four times the workgroups, a quarter of the MFMAs each)
 __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_utts, const double *__restrict__ wfeats,
                                                             double *__restrict__ partial) {
   constexpr int KC = 64;                                    // (Gaussian, dim) products per LDS chunk
-  __shared__ double wfl[kMmU][KC + 1];
+  constexpr int MU = 16 * MT;
+  __shared__ double wfl[MU][KC + 1];
   const int D = iv.feat_dim, G = iv.num_gauss, I = iv.ivec_dim;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-  const int u0 = blockIdx.x * kMmU, ks = blockIdx.y;
+  const int u0 = blockIdx.x * MU, ks = blockIdx.y;
   const int per = (G + kIvecKS - 1) / kIvecKS, g_begin = ks * per, g_end = g_begin + per < G ? g_begin + per : G;
   const long kk_begin = (long)g_begin * D, kk_end = (long)(g_end > g_begin ? g_end : g_begin) * D;      // rows of Sigma_inv_M [G D][I]
   {
     const int i0 = blockIdx.z * 64 + wave * 16;               // 64 columns per workgroup, 16 per wave
     const bool live = i0 < I;
     const int icol = i0 + lr < I ? i0 + lr : I - 1;
-    f64x4 acc[4];
+    f64x4 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < MT; m++) acc[m] = f64x4{0.0, 0.0, 0.0, 0.0};
     // (request groups of eight k-steps, the next group in flight during the MFMAs of the current one, as in IvecQuadMfmaKernel)
     auto fetch = [&](long c0, int n, int j, double (&b)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
     // The statistics chunk of the NEXT step travels global -> registers while the MFMAs of this one run, and is written to LDS
     // between two barriers afterwards: staged synchronously (load, barrier, use) the ten chunks of a workgroup were ten exposed
     // memory round trips -- most of the kernel's 78 us.
-    constexpr int SPT = kMmU * KC / 256;                       // staged values per thread and chunk
+    constexpr int SPT = MU * KC / 256;                       // staged values per thread and chunk
     double stg[SPT];
     auto stage_load = [&](long c0, int n) __attribute__((always_inline)) {
 #pragma unroll
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
       const int n0 = kk_end - kk_begin < KC ? (int)(kk_end - kk_begin) : KC;
       stage_load(kk_begin, n0);
       if (live) fetch(kk_begin, n0, 0, bc);
-      if (threadIdx.x < kMmU) wfl[threadIdx.x][KC] = 0.0;
+      if (threadIdx.x < MU) wfl[threadIdx.x][KC] = 0.0;
       stage_store();
       __syncthreads();
     }
@@ -1032,7 +1036,7 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
         for (int q = 0; q < 8; q++) {
           const int jc = j + 4 * q + lk < KC ? j + 4 * q + lk : KC;
 #pragma unroll
-          for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][jc], bc[q], acc[m], 0, 0, 0);
+          for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(wfl[16 * m + lr][jc], bc[q], acc[m], 0, 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) bc[q] = bn[q];
@@ -1045,7 +1049,7 @@ __global__ __launch_bounds__(256) void IvecLinearMfmaKernel(IvecDev iv, int n_ut
     }
     if (i0 + lr < I) {
 #pragma unroll
-      for (int m = 0; m < 4; m++)
+      for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int u = u0 + 16 * m + lk + 4 * q;
@@ -1081,20 +1085,25 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   const int ub = (n_utts + kIvecUB - 1) / kIvecUB, usz = iv.ivec_dim * (iv.ivec_dim + 1) / 2;
   const char *me = std::getenv("RS_IVEC_MFMA");          // read per call (tests flip it)
   const bool mfma = !(me && std::atoi(me) == 0);
-  const int um = (n_utts + kMmU - 1) / kMmU;
-  if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
+  // a few dozen utterances (a round of streams): 16 per workgroup instead of 64, so that four times as many CUs share the two
+  // products (same sums in the same order per element: the M tiling does not touch the k order)
+  const bool narrow = n_utts <= 64;
+  const int um64 = (n_utts + kMmU - 1) / kMmU, um = narrow ? (n_utts + 15) / 16 : um64;
+  if (mfma && narrow) hipLaunchKernelGGL(IvecLinearMfmaKernel<1>, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
+  else if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel<4>, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
   else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
   hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
   hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
   const char *ae = std::getenv("RS_IVEC_ASM");           // read per call (a test compares the two forms)
   const int quad_asm = ae ? std::atoi(ae) : 1;
-#define RS_QUAD_ASM(N) hipLaunchKernelGGL(IvecQuadMfmaAsmKernel<N>, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear)
+#define RS_QUAD_ASM(N) do { if (narrow) hipLaunchKernelGGL((IvecQuadMfmaAsmKernel<N, 1>), dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear); \
+                            else hipLaunchKernelGGL((IvecQuadMfmaAsmKernel<N, 4>), dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear); } while (0)
   if (mfma && quad_asm && iv.num_gauss == 512) RS_QUAD_ASM(4);
   else if (mfma && quad_asm && iv.num_gauss == 256) RS_QUAD_ASM(2);
   else if (mfma && quad_asm && iv.num_gauss == 1024) RS_QUAD_ASM(8);
   else if (mfma && quad_asm && iv.num_gauss == 128) RS_QUAD_ASM(1);
 #undef RS_QUAD_ASM
-  else if (mfma) hipLaunchKernelGGL(IvecQuadMfmaKernel, dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear);
+  else if (mfma) hipLaunchKernelGGL(IvecQuadMfmaKernel, dim3((usz + 63) / 64, um64), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear);
   else hipLaunchKernelGGL(IvecQuadKernel, dim3((usz + 127) / 128, ub), dim3(128), 0, s, iv, n_utts, gm, change, quadratic, linear);
 }
 

@@ -38,11 +38,16 @@ struct StreamPool {
   // Two queues, so that consecutive advances overlap on the device: `qa` runs an advance's feature and iVector stages, `q` its
   // acoustic model and search (behind an event of `qa`).  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
-  hipStream_t q = nullptr, qa = nullptr;
+  hipStream_t q = nullptr, qa = nullptr, qc = nullptr;      // qc: the search of an advance (behind q's event), under the next advance's acoustic model
   static constexpr int kDepth = 3;                                             // advances in flight at most = arena / staging sets
-  hipEvent_t ev_a[kDepth] = {}, ev_done[kDepth] = {};                          // per set: stage A issued / the advance finished
+  hipEvent_t ev_a[kDepth] = {}, ev_b[kDepth] = {}, ev_done[kDepth] = {};       // per set: stage A issued / log-likelihoods issued / the advance finished
   bool pending[kDepth] = {};                                                   // an advance that used this set may still run
-  std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth];
+  std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth], tm_c[kDepth];
+  // device time of set `par`'s advance into the pool's totals (its done event has been waited for)
+  void Account(int par, float *extra) {
+    const float ms[4] = {tm_a[par]->Ms(0, 1), tm_a[par]->Ms(1, 2), tm_b[par]->Ms(0, 1), tm_c[par]->Ms(0, 1)};
+    for (int j = 0; j < 4; j++) { stage_ms[j + 1] += ms[j]; if (extra) extra[j] += ms[j]; }
+  }
   long n_adv = 0;
   bool sync_each = false;        // RS_STREAM_SYNC=1: wait for every advance before returning (the behaviour before the two queues)
   void *cx = nullptr;            // Model::DecodeContext with the arenas / staging of the advances (never handed to batch calls)
@@ -85,10 +90,15 @@ void StreamPoolDeleter::operator()(StreamPool *p) const {
   if (!p) return;
   if (p->qa) (void)hipStreamSynchronize(p->qa);
   if (p->q) (void)hipStreamSynchronize(p->q);
-  for (int k = 0; k < StreamPool::kDepth; k++) { p->tm_a[k].reset(); p->tm_b[k].reset(); if (p->ev_a[k]) (void)hipEventDestroy(p->ev_a[k]); if (p->ev_done[k]) (void)hipEventDestroy(p->ev_done[k]); }
+  if (p->qc) (void)hipStreamSynchronize(p->qc);
+  for (int k = 0; k < StreamPool::kDepth; k++) {
+    p->tm_a[k].reset(); p->tm_b[k].reset(); p->tm_c[k].reset();
+    for (hipEvent_t e : {p->ev_a[k], p->ev_b[k], p->ev_done[k]}) if (e) (void)hipEventDestroy(e);
+  }
   for (void *d : p->owned) (void)hipFree(d);
   if (p->q) (void)hipStreamDestroy(p->q);
   if (p->qa) (void)hipStreamDestroy(p->qa);
+  if (p->qc) (void)hipStreamDestroy(p->qc);
   delete p;
 }
 
@@ -131,11 +141,14 @@ StreamPool *Model::Pool() {
   p->reg = reg_dev_.nt != 0 && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
   RS_HIP(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
   RS_HIP(hipStreamCreateWithFlags(&p->qa, hipStreamNonBlocking));
+  RS_HIP(hipStreamCreateWithFlags(&p->qc, hipStreamNonBlocking));
   for (int k = 0; k < StreamPool::kDepth; k++) {
     RS_HIP(hipEventCreateWithFlags(&p->ev_a[k], hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&p->ev_b[k], hipEventDisableTiming));
     RS_HIP(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
     p->tm_a[k].reset(new Timer(p->qa));
     p->tm_b[k].reset(new Timer(p->q));
+    p->tm_c[k].reset(new Timer(p->qc));
   }
   p->sync_each = EnvInt("RS_STREAM_SYNC", 0) != 0;
   auto dalloc = [&](size_t bytes) {
@@ -187,9 +200,7 @@ void Model::StreamsDrain(StreamPool *p, float *extra) {
     if (!p->pending[par]) continue;
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
-    Timer &ta = *p->tm_a[par], &tb = *p->tm_b[par];
-    const float ms[4] = {ta.Ms(0, 1), ta.Ms(1, 2), tb.Ms(0, 1), tb.Ms(1, 2)};
-    for (int j = 0; j < 4; j++) { p->stage_ms[j + 1] += ms[j]; if (extra) extra[j] += ms[j]; }
+    p->Account(par, extra);
   }
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
@@ -212,7 +223,7 @@ void Model::StreamOpen(rs_stream *st) {
     const int Di = fc_.ie.ivector_dim(), usz = Di * (Di + 1) / 2;
     LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->qa);      // (stage A's queue: the estimator state is its)
   }
-  RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->q));
+  RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->qc));      // (the search's queue)
   st->open = true;
 }
 
@@ -257,7 +268,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   RS_HIP(hipSetDevice(opts_.device_id));
   // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive
   // advances rotate over kDepth arena / staging sets, so the host plans and issues the next advances while earlier ones still run
-  hipStream_t qa = p->qa, q = p->q;
+  hipStream_t qa = p->qa, q = p->q, qc = p->qc;
   DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
   const int par = (int)(p->n_adv % StreamPool::kDepth);
   DeviceArena &arena = cx.arena[par];
@@ -265,8 +276,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   if (p->pending[par]) {       // the advance kDepth calls ago used this set: it has to be over (it normally is)
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
-    Timer &ta = *p->tm_a[par], &tb = *p->tm_b[par];
-    p->stage_ms[1] += ta.Ms(0, 1); p->stage_ms[2] += ta.Ms(1, 2); p->stage_ms[3] += tb.Ms(0, 1); p->stage_ms[4] += tb.Ms(1, 2);
+    p->Account(par, nullptr);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
   }
@@ -450,8 +460,8 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     }
     RS_HIP(hipMemcpyAsync(d_pcm, hp, sizeof(int16_t) * pcm_total, hipMemcpyHostToDevice, qa));
   }
-  Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par];
-  tma.Reset(); tmb.Reset();
+  Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par], &tmc = *p->tm_c[par];
+  tma.Reset(); tmb.Reset(); tmc.Reset();
   tma.Mark();
   // ---------------------------------------------------------------- 1. MFCC
   if (nM > 0) {
@@ -524,10 +534,13 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
   }
   tmb.Mark();
-  // ---------------------------------------------------------------- 5. search
+  // ---------------------------------------------------------------- 5. search (its own queue: the next advance's acoustic model does not wait for it)
+  RS_HIP(hipEventRecord(p->ev_b[par], q));
+  RS_HIP(hipStreamWaitEvent(qc, p->ev_b[par], 0));
+  tmc.Mark();
   BatchGeom gd;
   gd.n_utts = n; gd.max_frames = maxT; gd.d_num_frames = D(o_dT); gd.d_row_base = D(o_drb);
-  if (final) AllocSearch(&sp, arena, q, /*pooled_frames=*/reg_windows);
+  if (final) AllocSearch(&sp, arena, qc, /*pooled_frames=*/reg_windows);
   if (reg_windows) {
     DenseWork dw;
     std::memset(&dw, 0, sizeof(dw));
@@ -537,12 +550,12 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     DecodeOptsDev dopts;
     dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
     dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
-    LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw, 0, 0, q, final);
-    if (final) LaunchCopyRows(p->dec_ctr, 16, D(o_slots), sp.w.counters, 16, nullptr, n, 16, q);
+    LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw, 0, 0, qc, final);
+    if (final) LaunchCopyRows(p->dec_ctr, 16, D(o_slots), sp.w.counters, 16, nullptr, n, 16, qc);
   } else if (final) {
-    LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, q);
+    LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, qc);
   }
-  tmb.Mark();
+  tmc.Mark();
   // ---------------------------------------------------------------- host bookkeeping
   for (int i = 0; i < n; i++) {
     rs_stream &st = *streams[i];
@@ -558,7 +571,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
       st.pcm_start = keep_from;
     }
   }
-  RS_HIP(hipEventRecord(p->ev_done[par], q));
+  RS_HIP(hipEventRecord(p->ev_done[par], qc));
   p->pending[par] = true;
   p->n_adv++;
   if (!final) {
@@ -576,20 +589,18 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
       if (!p->pending[other]) continue;
       RS_HIP(hipEventSynchronize(p->ev_done[other]));
       p->pending[other] = false;
-      Timer &ta = *p->tm_a[other], &tb = *p->tm_b[other];
-      p->stage_ms[1] += ta.Ms(0, 1); p->stage_ms[2] += ta.Ms(1, 2); p->stage_ms[3] += tb.Ms(0, 1); p->stage_ms[4] += tb.Ms(1, 2);
+      p->Account(other, nullptr);
     }
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
-    own[0] = tma.Ms(0, 1); own[1] = tma.Ms(1, 2); own[2] = tmb.Ms(0, 1); own[3] = tmb.Ms(1, 2);
-    for (int k = 0; k < 4; k++) p->stage_ms[k + 1] += own[k];
+    p->Account(par, own);
   }
   // ---------------------------------------------------------------- results
   res->utts.resize(n);
   for (int i = 0; i < n; i++) res->utts[i].num_frames = pl[i].avail;
-  Timer tmr(q);
+  Timer tmr(qc);
   tmr.Mark();
-  CollectResults(sp, cx, par, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, q, res->utts.data(), res->timings);
+  CollectResults(sp, cx, par, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, qc, res->utts.data(), res->timings);
   tmr.Mark();
   if (opts_.keep_intermediates) {
     const float *fin = fc_.use_cmvn ? p->nn_in : p->raw;
