@@ -85,10 +85,10 @@ def test_oracle_streaming_matches_reference(oracles, name):
 
 
 # ---- full-size configurations (tests/configs.py): the restatement against the reference's per-utterance goldens on samples
-@pytest.mark.parametrize("config,utts", [("c1_grammar", (0, 131, 255)), ("c2_arpa", (3, 162)), ("c3_mixed_de", (7,)), ("c3_mixed_fr", (500,)),
+@pytest.mark.parametrize("config,utts", [("c1_grammar", (0, 131, 255)), ("c2_arpa", (3, 162)), ("c3_mixed_de", (7,)), ("c3_mixed_fr", (110, 500)),
                                          ("c4_streams", (5,))])
 def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
-    """c2_arpa utterance 162 is the case where the reference's order-dependent pruning (tokens created under a running
+    """c2_arpa utterance 162 and c3_mixed_fr utterance 110 are the cases where the reference's order-dependent pruning (tokens created under a running
     next_cutoff, lattice-faster-decoder.cc:774-787) changes the best path's cost: oracle/decoder.c follows the HashList
     iteration order and must land on the reference's cost there (the HIP kernels do not, see test_gpu_configs.py)."""
     from oracle import pipeline
