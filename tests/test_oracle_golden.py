@@ -202,6 +202,10 @@ def test_setup_rand_calls_match_reference(name):
         assert (n.value, cert.value) == (want, 1)
         cfg = buf.value.decode()
         assert "component-node name=lda " not in cfg and "component=lda.tdnn1.affine" in cfg
+        # ... line for line the network the reference's CollapseModel leaves (oracle/gen_collapsed_golden.py)
+        import json
+        want_cfg = json.loads((cases.GOLDEN / "collapsed_configs.json").read_text())[name]
+        assert [l for l in cfg.splitlines() if l.strip()] == want_cfg
 
 
 def test_library_dither_noise_is_the_references():
