@@ -297,6 +297,32 @@ def test_finish_after_incremental_advances_is_cheap(case_cache):
     assert sum(inc.timings()[1:5]) > 0.5 * sum(full.timings()[1:5])
 
 
+def test_failed_advance_poisons_its_streams(case_cache, monkeypatch):
+    """An advance that throws after the chunk schedule of some streams has moved on (here: the pool has no room for a stream
+    that outgrew its row range) must not leave streams that look usable: every later call on the streams of that advance
+    except rs_stream_free is refused; other streams and new ones work, and the pool's rows come back."""
+    from rhasspy_speech_amd import _lib, synth
+    monkeypatch.setenv("RS_STREAM_POOL_ROWS", "8192")
+    monkeypatch.setenv("RS_STREAM_INIT_FRAMES", "4096")
+    model, pcm = make_model(case_cache, "tiny_u0")
+    ref = model.decode_batch([pcm]).words(0)
+    a, b = _lib.Stream(model), _lib.Stream(model)           # 2 x 4096 rows: the pool is full
+    long_audio = synth.synth_utterance(77, 16000 * 45)      # 4498 frames: stream a needs 8192 contiguous rows
+    a.accept(long_audio)
+    b.accept(pcm)
+    with pytest.raises(_lib.RsError, match="pool exhausted"):
+        _lib.advance_streams([a, b])
+    for call in (lambda: _lib.advance_streams([a]), lambda: _lib.advance_streams([b]), lambda: a.finish(), lambda: _lib.finish_streams([a, b])):
+        with pytest.raises(_lib.RsError, match="advance that failed"):
+            call()
+    a.close()
+    b.close()
+    c = _lib.Stream(model)                                   # the rows and slots are back
+    c.accept(pcm)
+    c.advance()
+    assert c.finish().words(0) == ref
+
+
 def test_many_streams_one_batch(case_cache):
     from rhasspy_speech_amd import _lib, synth
     model, _ = make_model(case_cache, "tiny_u0")
