@@ -692,9 +692,9 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
       RS_HIP(hipMalloc((void **)&cx->d_pcm, cx->h_pcm_cap * sizeof(int16_t)));
     }
     auto t0 = std::chrono::steady_clock::now();
-    // Pageable caller buffers -> pinned staging -> HBM in spans of about 2 MB: the DMA of one span runs under the host copy of
+    // Pageable caller buffers -> pinned staging -> HBM in spans of about 16 MB: the DMA of one span runs under the host copy of
     // the next, and nothing waits here -- the feature kernel is ordered behind the last span on the context's stream.
-    const int64_t span = 1 << 20;      // samples
+    static const int64_t span = [] { const char *e = std::getenv("RS_UPLOAD_SPAN_KB"); return (int64_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) * 512; }();      // samples per span (16 MB: 2 MB spans cost the mixed workload 5 % in copy calls, one span for everything 6 % in lost overlap)
     for (int i = 0, first = 0; i < n_utts; i++) {
       if (n_samples[i]) std::memcpy(cx->h_pcm_pinned + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
       if (off[i + 1] - off[first] >= span || i + 1 == n_utts) {
