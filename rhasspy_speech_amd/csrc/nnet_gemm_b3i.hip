@@ -33,7 +33,7 @@ namespace rs {
 namespace {
 using namespace b3;
 
-constexpr int kKPS = 2;                               // k-steps per LDS stage
+constexpr int kKPS = 2;                               // k-steps per LDS stage (template parameter KPS of the kernel; 8 for the 32-row tile)
 // Timing ablations (profiles/micro/b3i_ablate.sh; results are WRONG with any bit set): 1 = the weight pointer never advances
 // (every k-step re-reads the same 24 KiB: no L2 weight stream), 2 = the activation DMA always fetches k-step 0 (no HBM
 // activation stream), 4 = no MFMAs, 8 = no DMA and no weight loads (matrix cores + LDS reads + barriers only), 16 = no
@@ -42,10 +42,14 @@ constexpr int kKPS = 2;                               // k-steps per LDS stage
 #define RS_B3I_ABLATE 0
 #endif
 
-template <int MR, bool MIXED>
+// KPS = k-steps per LDS stage.  A stage is waited for (vmcnt(0): the compiler drains everything in front of the first use of a
+// weight register while an LDS-DMA is in flight anyway) and fenced by one barrier; the DMA of stage s + 1 is issued at the start of
+// stage s.  With the 32-row tile of a small launch (one workgroup per CU, 12 MFMAs per k-step) a two-k-step stage is over long
+// before its successor has arrived: 24 exposed round trips per layer (38 us for 5000 rows); eight k-steps per stage leave six.
+template <int MR, bool MIXED, int KPS = kKPS>
 __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int nbig, int epi_mode) {
   constexpr int BM = 32 * MR, BN = kB3BN;
-  constexpr int KSTEP_BYTES = MR * 3 * kB3FragBytes, STAGE = kKPS * KSTEP_BYTES;
+  constexpr int KSTEP_BYTES = MR * 3 * kB3FragBytes, STAGE = KPS * KSTEP_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave;                               // 64-column slice; also the row tile this wave stages
@@ -145,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   };
   if (nt == 0) return;
   // ---- pipeline: LDS stage s holds k-steps 2 s, 2 s + 1; weights rotate over three register sets two k-steps ahead
-  const int nstage = (nt + kKPS - 1) / kKPS;
+  const int nstage = (nt + KPS - 1) / KPS;
   bf16x8 b0[2][3], b1[2][3], b2[2][3];
   load_b(b0);
   load_b(b1);
-  stage_kstep(smem);
-  if (nt > 1) stage_kstep(smem + KSTEP_BYTES);
+#pragma unroll
+  for (int q = 0; q < KPS; q++) if (q < nt) stage_kstep(smem + q * KSTEP_BYTES);
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // The loop body handles one k-step; the stage protocol (DMA of the next stage issued at the first k-step of a stage, waited
@@ -158,15 +162,15 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   int t = 0;
 #define RS_B3I_KSTEP(BCUR, BNEXT2)                                                                   \
   {                                                                                                  \
-    const int st = t >> 1, kk = t & 1;                                                               \
+    const int st = t / KPS, kk = t % KPS;                                                            \
     load_b(BNEXT2);                              /* weights of k-step t + 2 (padding steps past the end) */ \
     if (kk == 0 && st + 1 < nstage) {            /* DMA of the next stage */                        \
       unsigned char *nx = smem + ((st + 1) & 1) * STAGE;                                             \
-      stage_kstep(nx);                                                                               \
-      if (2 * (st + 1) + 1 < nt) stage_kstep(nx + KSTEP_BYTES);                                      \
+      _Pragma("unroll") for (int q = 0; q < KPS; q++)                                                \
+        if (KPS * (st + 1) + q < nt) stage_kstep(nx + q * KSTEP_BYTES);                              \
     }                                                                                                \
     step(smem + (st & 1) * STAGE + kk * KSTEP_BYTES, BCUR);                                          \
-    if (!(RS_B3I_ABLATE & 16) && (kk == 1 || t + 1 == nt)) { /* stage done: next stage's DMA landed, everyone done reading this one */ \
+    if (!(RS_B3I_ABLATE & 16) && (kk == KPS - 1 || t + 1 == nt)) { /* stage done: next stage's DMA landed, everyone done reading this one */ \
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
       __builtin_amdgcn_s_barrier();                                                                  \
     }                                                                                                \
@@ -193,20 +197,20 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
 #include "nnet_b3_epilogue.inc"
 }
 
-template <int MR, bool MIXED>
+template <int MR, bool MIXED, int KPS = kKPS>
 void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
   constexpr int BM = 32 * MR;
-  constexpr size_t stage = 2 * (size_t)kKPS * MR * 3 * kB3FragBytes, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t stage = 2 * (size_t)KPS * MR * 3 * kB3FragBytes, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3I<MR, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3I<MR, MIXED, KPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
   const int blocks = ((nbig + 7) / 8 * 8 + (nsmall + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3I<MR, MIXED>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3I<MR, MIXED, KPS>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
 }
 
 // f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, all three parts
@@ -289,7 +293,10 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   if (force_mr == 1) { mr = 1; nbig = (rows + 31) / 32; mixed = false; }
   if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
   if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
-  if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);
+  static const int kps1 = [] { const char *e = std::getenv("RS_GEMM_B3I_KPS"); return e ? std::atoi(e) : 8; }();
+  if (mr == 1 && kps1 == 8) LaunchB3I<1, false, 8>(d, rows, nbig, s);
+  else if (mr == 1 && kps1 == 4) LaunchB3I<1, false, 4>(d, rows, nbig, s);
+  else if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);
   else if (mr == 2) LaunchB3I<2, false>(d, rows, nbig, s);
   else if (mixed) LaunchB3I<4, true>(d, rows, nbig, s);
   else LaunchB3I<4, false>(d, rows, nbig, s);
