@@ -238,13 +238,18 @@ class Model:
         return buf.value.decode()
 
     def decode_batch(self, pcm: Sequence[np.ndarray], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
-        arrs = [np.ascontiguousarray(p, dtype=np.int16) for p in pcm]
-        n = len(arrs)
-        ptrs = (C.POINTER(C.c_int16) * max(n, 1))()
-        lens = (C.c_int32 * max(n, 1))()
-        for i, a in enumerate(arrs):
-            ptrs[i] = a.ctypes.data_as(C.POINTER(C.c_int16))
-            lens[i] = a.shape[0]
+        n = len(pcm)
+        addr = np.zeros(max(n, 1), np.uintp)
+        lens_np = np.zeros(max(n, 1), np.int32)
+        keep = []
+        for i, p in enumerate(pcm):       # (buffers that are int16 and contiguous already are handed over as they are)
+            if not (isinstance(p, np.ndarray) and p.dtype == np.int16 and p.flags.c_contiguous):
+                p = np.ascontiguousarray(p, dtype=np.int16)
+                keep.append(p)
+            addr[i] = p.__array_interface__["data"][0]
+            lens_np[i] = p.shape[0]
+        ptrs = addr.ctypes.data_as(C.POINTER(C.POINTER(C.c_int16)))
+        lens = lens_np.ctypes.data_as(C.POINTER(C.c_int32))
         out = C.c_void_p()
         _check(lib().rs_decode_batch(self._h, ptrs, lens, n, nbest, lattice_acoustic_scale, C.byref(out)))
         return Result(out)
@@ -270,13 +275,21 @@ def decode_batch_sharded(models: Sequence[Model], utt_model: Sequence[int], pcm:
     pcm[i] may be None for utterances of other ranks.  rccl_comm = ncclComm_t as an integer (0: no collective, own records
     only).  Never raises for a decode failure: the status travels in the records so that every rank sees it."""
     n = len(pcm)
-    arrs = [None if (p is None or i % world != rank) else np.ascontiguousarray(p, dtype=np.int16) for i, p in enumerate(pcm)]
-    ptrs = (C.POINTER(C.c_int16) * max(n, 1))()
-    lens = (C.c_int32 * max(n, 1))()
-    for i, a in enumerate(arrs):
-        if a is not None:
-            ptrs[i] = a.ctypes.data_as(C.POINTER(C.c_int16))
-            lens[i] = a.shape[0]
+    # (a thousand utterances per call: no per-utterance numpy / ctypes object is made for buffers that are usable as they are)
+    addr = np.zeros(max(n, 1), np.uintp)
+    lens_np = np.zeros(max(n, 1), np.int32)
+    keep = []
+    for i in range(rank, n, world):
+        p = pcm[i]
+        if p is None:
+            continue
+        if not (isinstance(p, np.ndarray) and p.dtype == np.int16 and p.flags.c_contiguous):
+            p = np.ascontiguousarray(p, dtype=np.int16)
+            keep.append(p)
+        addr[i] = p.__array_interface__["data"][0]
+        lens_np[i] = p.shape[0]
+    ptrs = addr.ctypes.data_as(C.POINTER(C.POINTER(C.c_int16)))
+    lens = lens_np.ctypes.data_as(C.POINTER(C.c_int32))
     um = np.ascontiguousarray(utt_model, dtype=np.int32)
     handles = (C.c_void_p * len(models))(*[m._h for m in models])
     rec = np.zeros((n, SHARD_RECORD_INTS), np.int32)
