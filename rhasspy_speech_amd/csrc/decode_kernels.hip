@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -674,7 +675,11 @@ constexpr int kHashPrefixCap = 7168;            // expanded tokens per frame who
 __device__ __forceinline__ unsigned HashOf(unsigned s) { return (s * 2654435761u) >> (32 - kHashLog); }
 __device__ __forceinline__ unsigned TagLoad(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// slot of `state`, claiming a fresh one if the state is not in the table yet; -1: the table is full
+// slot of `state`, claiming a fresh one if the state is not in the table yet; -1: the table is full.
+// WIDE = false: entry = state << 15 | slot, slots are handed out consecutively (compact slot arrays; graphs below 131 071 states).
+// WIDE = true (any graph): entry = the state id, the slot IS the entry's position -- the slot-indexed arrays are then as long as the
+// table (32 768) and touched sparsely, still a footprint that follows the beam and not the millions of states of a large LM graph.
+template <bool WIDE>
 __device__ __forceinline__ int SlotFindOrInsert(unsigned *tags, int *n_slots, unsigned state, int slot_limit) {
   unsigned hp = HashOf(state);
   int mine = -1;
@@ -685,27 +690,30 @@ __device__ __forceinline__ int SlotFindOrInsert(unsigned *tags, int *n_slots, un
         mine = atomicAdd(n_slots, 1);
         if (mine >= slot_limit) return -1;
       }
-      e = atomicCAS(&tags[hp], kHashFree, (state << kSlotBits) | (unsigned)mine);
-      if (e == kHashFree) return mine;
+      e = atomicCAS(&tags[hp], kHashFree, WIDE ? state : ((state << kSlotBits) | (unsigned)mine));
+      if (e == kHashFree) return WIDE ? (int)hp : mine;
       // another lane claimed this entry first (possibly for the same state: then `mine` stays unused, its key stays empty)
     }
-    if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
+    if (WIDE) { if (e == state) return (int)hp; }
+    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
     hp = (hp + 1) & (kHashSize - 1);
   }
   return -1;
 }
+template <bool WIDE>
 __device__ __forceinline__ int SlotFind(const unsigned *tags, unsigned state) {
   unsigned hp = HashOf(state);
   for (int probe = 0; probe < 512; probe++) {
     const unsigned e = TagLoad(&tags[hp]);
     if (e == kHashFree) return -1;
-    if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
+    if (WIDE) { if (e == state) return (int)hp; }
+    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
     hp = (hp + 1) & (kHashSize - 1);
   }
   return -1;
 }
 
-template <int NT>
+template <int NT, bool WIDE>
 __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
                                                        const float *__restrict__ loglikes, int ld, DecodeWork w) {
   using Ctx = BlockCtx<NT, 1>;
@@ -719,9 +727,9 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = blockIdx.x, tid = threadIdx.x;
   const int T = g.d_num_frames[u];
-  unsigned long long *keys = w.h_keys + (size_t)u * kSlotCap;
-  int *slot_tok = w.h_slot_tok + (size_t)u * kSlotCap;       // slot -> index of its token in the frame under construction
-  int *stamp = w.h_stamp + (size_t)u * kSlotCap;             // closure round in which the slot was last pushed
+  unsigned long long *keys = w.h_keys + (size_t)u * kHashSize;
+  int *slot_tok = w.h_slot_tok + (size_t)u * kHashSize;      // slot -> index of its token in the frame under construction
+  int *stamp = w.h_stamp + (size_t)u * kHashSize;            // closure round in which the slot was last pushed
   int *cand_a = w.h_cand + (size_t)u * 3 * w.h_cand_cap, *cand_s = cand_a + w.h_cand_cap, *cand_x = cand_s + w.h_cand_cap;
   int2 *queue[2] = {w.h_queue + (size_t)u * 2 * kSlotCap, w.h_queue + (size_t)u * 2 * kSlotCap + kSlotCap};
   int4 *comp = w.h_comp + (size_t)u * kSlotCap;             // the frame's expanded tokens, compacted: {first emitting arc, cost, token index, out-degree}
@@ -734,7 +742,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
   const int cand_cap = w.h_cand_cap;
   const int slot_limit = w.h_slot_limit < kSlotCap ? w.h_slot_limit : kSlotCap;      // (tests lower it to send utterances to DecodeKernel)
 
-  for (int i = tid; i < kSlotCap; i += NT) { StoreKey(&keys[i], RS_EMPTY); stamp[i] = 0; }
+  for (int i = tid; i < (WIDE ? kHashSize : kSlotCap); i += NT) { StoreKey(&keys[i], RS_EMPTY); stamp[i] = 0; }
   for (int i = tid; i < kHashSize; i += NT) tags[i] = kHashFree;
   if (tid == 0) {
     c.n_next = 0; c.overflow = 0; c.error = 0; c.q_n[0] = c.q_n[1] = 0;
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
   int off_cur = 0, n_cur = 0;       // frame f's token list
   int off_next = 0;                 // frame under construction
   if (tid == 0) {                   // InitDecoding: the start state's token
-    const int sl = SlotFindOrInsert(tags, &n_slots, (unsigned)h.start, slot_limit);
+    const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)h.start, slot_limit);
     StoreKey(&keys[sl], PackKey(0.0f, RS_NOARC));
     tokens[0] = make_int4(h.start, sl, -1, -2);
     slot_tok[sl] = 0;
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
         cnt_insert++;
         const unsigned ot = OrderedBits(tot);
         if (ot < c.run_min) atomicMin(&c.run_min, ot);
-        const int sl = SlotFindOrInsert(tags, &n_slots, (unsigned)arc.w, slot_limit);
+        const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)arc.w, slot_limit);
         if (sl < 0) { s_redo = 1; return; }
         atomicMin(&keys[sl], PackKey(tot, a));                 // result unused: non-returning
         const int ci = atomicAdd(&c.n_cand, 1);
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
               key = kmin;
             }
             if (mine) {
-              const int sl = SlotFindOrInsert(tags, &n_slots, (unsigned)arc.w, slot_limit);
+              const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)arc.w, slot_limit);
               if (sl < 0) { s_redo = 1; continue; }
               const unsigned long long old = atomicMin(&keys[sl], key);
               if (old == RS_EMPTY) {              // FindOrAddToken made a token
@@ -1114,7 +1122,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
         for (int q = 0; q < MB; q++) {
           const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
           int b = arc == RS_NOARC ? -1 : tk[q].z;
-          if (eps[q]) { const int ss = SlotFind(tags, (unsigned)sx[q]); b = ss >= 0 ? slot_tok[ss] : -1; }
+          if (eps[q]) { const int ss = SlotFind<WIDE>(tags, (unsigned)sx[q]); b = ss >= 0 ? slot_tok[ss] : -1; }
           bp[q] = b;
         }
 #pragma unroll
@@ -1415,12 +1423,18 @@ void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeo
   hipLaunchKernelGGL(LatticeKernel<256>, dim3(g.n_utts), dim3(256), 0, s, h, o, g, loglikes, ld, w, lw);
 }
 
-bool DecodeHashUsable(const HclgDev &h) { return h.num_states > 0 && (unsigned)h.num_states < (1u << (32 - kSlotBits)) - 1u; }
+bool DecodeHashUsable(const HclgDev &h) { return h.num_states > 0; }
 int DecodeHashSlotCap() { return kSlotCap; }
+int DecodeHashTableSize() { return kHashSize; }
 void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DecodeWork &w, hipStream_t s) {
   if (g.n_utts == 0) return;
-  hipLaunchKernelGGL(HashDecodeKernel<1024>, dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
+  // graphs whose state ids do not fit beside a slot number in one table word use the position-addressed form (RS_HASH_WIDE=1 forces it)
+  const char *we = std::getenv("RS_HASH_WIDE");          // (read per launch: a test flips it)
+  const bool force_wide = we && std::atoi(we) != 0;
+  const bool wide = force_wide || (unsigned)h.num_states >= (1u << (32 - kSlotBits)) - 1u;
+  if (wide) hipLaunchKernelGGL((HashDecodeKernel<1024, true>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
+  else hipLaunchKernelGGL((HashDecodeKernel<1024, false>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
 }
 
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,

@@ -929,7 +929,7 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   else {                  // token-list search: per-state tables, queues, the token arrays of every frame
     need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
     sp->use_hash = decoder_choice_ != 3 && DecodeHashUsable(hclg_dev_);
-    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeHashSlotCap() * (8 + 4 + 4 + 16 + 16) + (size_t)kHashCandCap * 12 + 4) + 8192;
+    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeHashTableSize() * (8 + 4 + 4) + (size_t)DecodeHashSlotCap() * (16 + 16) + (size_t)kHashCandCap * 12 + 4) + 8192;
   }
   if (sp->want_lattice) need += sizeof(float) * (size_t)n_utts * sp->tok_cap + 4096;                                // LatticeKernel's extra_cost
   return need;
@@ -980,10 +980,10 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   if (sp->use_hash) {
     // live states of a frame in an LDS table, their per-state records in slot-indexed arrays (decode_kernels.hip); the dense tables
     // above are only touched for utterances that outgrow the table (w.redo)
-    const size_t cap = (size_t)DecodeHashSlotCap();
-    w.h_keys = arena_.AllocT<unsigned long long>((size_t)n_utts * cap);
-    w.h_slot_tok = arena_.AllocT<int>((size_t)n_utts * cap);
-    w.h_stamp = arena_.AllocT<int>((size_t)n_utts * cap);
+    const size_t cap = (size_t)DecodeHashSlotCap(), tab = (size_t)DecodeHashTableSize();
+    w.h_keys = arena_.AllocT<unsigned long long>((size_t)n_utts * tab);
+    w.h_slot_tok = arena_.AllocT<int>((size_t)n_utts * tab);
+    w.h_stamp = arena_.AllocT<int>((size_t)n_utts * tab);
     w.h_cand_cap = kHashCandCap;
     { const char *e = std::getenv("RS_HASH_SLOT_LIMIT"); w.h_slot_limit = e ? std::atoi(e) : DecodeHashSlotCap(); }
     w.h_cand = arena_.AllocT<int>((size_t)n_utts * 3 * kHashCandCap);

@@ -225,8 +225,8 @@ struct DecodeWork {
   int *queue_a, *queue_b;     // n_utts x S work lists for the epsilon closure
   int *in_queue;              // n_utts x S : round stamp of the state's last push onto a closure queue (token-list search)
   // live-state-table search (HashDecodeKernel): slot-indexed arrays instead of the state-indexed ones above; null = not in use
-  unsigned long long *h_keys; // n_utts x DecodeHashSlotCap() : packed (cost, arc) of the slot's state in the frame under construction
-  int *h_slot_tok, *h_stamp;  // n_utts x slot cap : token index of the slot / closure round of its last push
+  unsigned long long *h_keys; // n_utts x DecodeHashTableSize() : packed (cost, arc) of the slot's state in the frame under construction
+  int *h_slot_tok, *h_stamp;  // n_utts x table size : token index of the slot / closure round of its last push
   int *h_cand;                // n_utts x 3 x h_cand_cap : candidate records of the arc loop (arc, destination state, slot << 16 | source token)
   int h_cand_cap;
   int h_slot_limit;           // live states a frame may hold before the utterance is handed to DecodeKernel (<= DecodeHashSlotCap())
@@ -247,7 +247,8 @@ void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, 
 // issues behind it on the same stream.
 constexpr int kHashCandCap = 65536;      // candidate records per utterance and frame (the ARPA workload's largest frame: 24 k)
 bool DecodeHashUsable(const HclgDev &h);
-int DecodeHashSlotCap();
+int DecodeHashSlotCap();      // live states per frame
+int DecodeHashTableSize();    // entries of the LDS table = length of the slot-indexed arrays
 void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DecodeWork &w, hipStream_t s);
 

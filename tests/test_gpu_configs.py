@@ -232,6 +232,43 @@ def test_sharded_entry_point_issues_the_rccl_all_gather(zam_grammar):
         rccl.ncclCommDestroy(comm)
 
 
+def test_shard_gather_on_torch_distributed_communicator(zam_grammar):
+    """The route bench.py takes at N > 1: torch.distributed's own RCCL communicator (ProcessGroupNCCL._comm_ptr(), here a one-rank
+    group: the box has one GPU) handed to rs_shard_gather / rs_decode_batch_sharded -- the library binds the librccl.so.1 torch
+    loaded, so the pointer is valid in it -- while torch keeps using the same communicator for its own collectives."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rhasspy_speech_amd import _lib
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.ones(1, device="cuda:0")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        comm = int(dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda", 0))._comm_ptr())
+        assert comm != 0
+        model = _lib.Model(*zam_grammar, _lib.default_opts())
+        pcms = configs.grammar_utterances(16)
+        own, st, msg = _lib.decode_batch_sharded([model], [0] * len(pcms), pcms, 0, 1, 0)
+        assert st == 0, msg
+        np.testing.assert_array_equal(_lib.shard_gather(own, 0, 0, 1, comm), own)
+        both, st, msg = _lib.decode_batch_sharded([model], [0] * len(pcms), pcms, 0, 1, comm)
+        assert st == 0, msg
+        np.testing.assert_array_equal(both, own)
+        dist.all_reduce(t)                  # torch's next collective on the same communicator
+        torch.cuda.synchronize()
+        assert float(t.item()) == 1.0
+        with pytest.raises(_lib.RsError, match="communicator"):
+            _lib.shard_gather(own, 0, 1, 2, comm)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_config3_mixed_models_side_by_side(zam_grammar, case_cache):
     """Two different models resident on the GPU, their batches decoded concurrently from two host threads (what a
     rank serving a mixed-model shard does).  Each result must equal the model's own sequential result."""

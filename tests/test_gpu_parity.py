@@ -166,10 +166,13 @@ def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra
     pcms = [pcm] + [synth.synth_utterance(500 + i, n) for i, n in enumerate([48000, 9000, 33000])]
     ref = ref_model.decode_batch(pcms, nbest=5)
     monkeypatch.setenv("RS_DECODER", "hash")
-    for limit in (None, "40", "6"):
-        if limit is None:
-            monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
-        else:
+    # (limit "wide": the table form large graphs get -- state id per entry, the slot is the entry's position -- forced on this graph)
+    for limit in (None, "40", "6", "wide"):
+        monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
+        monkeypatch.delenv("RS_HASH_WIDE", raising=False)
+        if limit == "wide":
+            monkeypatch.setenv("RS_HASH_WIDE", "1")
+        elif limit is not None:
             monkeypatch.setenv("RS_HASH_SLOT_LIMIT", limit)
         got = make_model(case_cache, name, **extra)[0].decode_batch(pcms, nbest=5)
         for u in range(len(pcms)):
@@ -179,6 +182,7 @@ def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra
                 np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
             assert got.counters(u)[3] == ref.counters(u)[3], (limit, u)
     monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
+    monkeypatch.delenv("RS_HASH_WIDE", raising=False)
 
 
 def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
