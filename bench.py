@@ -161,7 +161,7 @@ def main() -> None:
                          "read no others; same words, same costs); a default run reports the all-pdfs figure as `reference_output_layer`")
     args = ap.parse_args()
     wl = args.workload
-    defaults = {"grammar": (600, 20, 4), "arpa": (45, 7, 3), "mixed": (150, 5, 2), "streams": (40, 2, 1)}[wl]
+    defaults = {"grammar": (600, 20, 4), "arpa": (45, 7, 3), "mixed": (150, 9, 4), "streams": (40, 2, 1)}[wl]
     steps = args.steps if args.steps is not None else defaults[0]
     warmup = args.warmup if args.warmup is not None else defaults[1]
     inflight = args.inflight if args.inflight is not None else defaults[2]
