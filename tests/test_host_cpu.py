@@ -71,6 +71,23 @@ def test_no_gpu_means_loud_failure_not_fallback(case_cache):
     assert ei.value.status == _lib.RS_ERR_DEVICE and "no CPU fallback" in str(ei.value)
 
 
+def test_new_entry_points_validate_their_arguments():
+    """rs_streams_accept / rs_shard_gather (round 3) refuse bad arguments before touching a device: status RS_ERR_ARG and a message."""
+    import ctypes as C
+    from rhasspy_speech_amd import _lib
+    lib = _lib.lib()
+    assert lib.rs_streams_accept(None, None, None, 0) == 0                       # nothing to hand over is not an error
+    assert lib.rs_streams_accept(None, None, None, 3) == _lib.RS_ERR_ARG
+    assert b"rs_streams_accept" in lib.rs_last_error()
+    rec = (C.c_int32 * (2 * _lib.SHARD_RECORD_INTS))()
+    for args in ((0, 2, 0, 1, None, rec),            # no communicator
+                 (0, 2, 1, 1, C.c_void_p(1), rec),   # rank outside the world
+                 (-1, 2, 0, 1, C.c_void_p(1), rec),  # no device
+                 (0, 2, 0, 1, C.c_void_p(1), None)): # no records
+        assert lib.rs_shard_gather(*args) == _lib.RS_ERR_ARG, args
+        assert b"rs_shard_gather" in lib.rs_last_error()
+
+
 def test_bad_model_files_fail_like_kaldi(tmp_path, case_cache):
     from rhasspy_speech_amd import _lib
     model_dir, graph_dir, _, _ = case_cache("tiny_u0")
