@@ -797,8 +797,24 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
       }
       int m_wave = n_le;                   // tokens of this wave's range that the frame expands, if the beam decides the cutoff
       if (tid == 0) { c.bcast_i[2] = 0; c.bcast_i[3] = 0; c.run_min = OrderedBits(INF); c.n_cand = 0; s_min_bits = OrderedBits(INF); }
+      // A first bound for the arc loop's early-out (an arc at or above "cheapest candidate so far + adaptive beam" cannot end up
+      // below the frame's next_cutoff): the best token's own arcs, looked at by one wave while the others count.  Any candidate's
+      // cost is an upper bound of the minimum, so this only removes candidates that would lose anyway.
+      float first_bound = INF;
+      if (wave == NW - 1 && n_cur > 0) {
+        const int4 bt = cur[best_idx];
+        const uint4 bsr = h.state_rec[bt.x];
+        const float *llr = loglikes + (ll_base + f) * ld;
+        for (unsigned k = lane; k < bsr.z; k += 64) {
+          const int4 arc = h.arcs[bsr.x + bsr.y + k];
+          first_bound = fminf(first_bound, (__int_as_float(bt.y) + ((-best_cost) - llr[arc.x - 1])) + __int_as_float(arc.z));
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) first_bound = fminf(first_bound, __shfl_xor(first_bound, o2, 64));
+      }
       __syncthreads();
       if (lane == 0) { atomicAdd(&c.bcast_i[2], n_lt); atomicAdd(&c.bcast_i[3], n_le); }
+      if (wave == NW - 1 && lane == 0 && first_bound < INF) atomicMin(&c.run_min, OrderedBits(first_bound));
       __syncthreads();
       n_lt = c.bcast_i[2]; n_le = c.bcast_i[3];
       float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
