@@ -152,6 +152,57 @@ __device__ float BlockKthSmallest(Ctx &c, const int4 *toks, int n, int k, float 
   return FromOrdered(prefix);
 }
 
+// The same k-th smallest cost when it is known to lie in [lo, hi) and the frame is large: ONE histogram sweep over 256 linear bins
+// of that range (float subtract / multiply / truncate are monotone, so bins are in value order), then a sweep that collects the
+// values of the bin holding rank k (a few dozen of 16 k) and ranks them directly -- two sweeps over the frame's tokens instead of
+// the radix select's six.  Falls back to the radix select when that bin is crowded.  cand: 256 floats of LDS.
+template <int NT, class Ctx>
+__device__ float BlockKthSmallestHist(Ctx &c, const int4 *toks, int n, int k, float lo, float hi, float *cand, int *cand_n) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float scale = hi > lo ? 256.0f / (hi - lo) : 0.f;
+  for (int i = tid; i < 256; i += NT) c.hist[i] = 0;
+  if (tid == 0) *cand_n = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) {
+    const float v = __int_as_float(toks[i].y);
+    if (v < hi) { int b = (int)((v - lo) * scale); b = b > 255 ? 255 : (b < 0 ? 0 : b); atomicAdd(&c.hist[b], 1u); }
+  }
+  __syncthreads();
+  if (tid < 64) {      // wave 0: the bin that holds rank k (four bins per lane)
+    const int h0 = (int)c.hist[4 * lane], h1 = (int)c.hist[4 * lane + 1], h2 = (int)c.hist[4 * lane + 2], h3 = (int)c.hist[4 * lane + 3];
+    const int tot = h0 + h1 + h2 + h3;
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    const int exc = inc - tot;
+    if (exc <= k && k < inc) {
+      int acc = exc, b = 4 * lane, cnt = h0;
+      if (acc + h0 <= k) { acc += h0; b++; cnt = h1; if (acc + h1 <= k) { acc += h1; b++; cnt = h2; if (acc + h2 <= k) { acc += h2; b++; cnt = h3; } } }
+      c.bcast_i[0] = b; c.bcast_i[1] = k - acc; c.bcast_i[2] = cnt;
+    }
+    if (lane == 63 && inc <= k) c.bcast_i[2] = -1;      // fewer than k + 1 values below hi (caller error): radix select
+  }
+  __syncthreads();
+  const int bin = c.bcast_i[0], kk = c.bcast_i[1], cnt = c.bcast_i[2];
+  __syncthreads();
+  if (cnt < 0 || cnt > 256) return BlockKthSmallest<NT>(c, toks, n, k, lo);
+  for (int i = tid; i < n; i += NT) {
+    const float v = __int_as_float(toks[i].y);
+    if (v < hi) { int b = (int)((v - lo) * scale); b = b > 255 ? 255 : (b < 0 ? 0 : b); if (b == bin) cand[atomicAdd(cand_n, 1)] = v; }
+  }
+  __syncthreads();
+  if (tid < cnt) {
+    const float v = cand[tid];
+    int lt = 0, le = 0;
+    for (int j = 0; j < cnt; j++) { const float x = cand[j]; lt += (int)(x < v); le += (int)(x <= v); }
+    if (lt <= kk && kk < le) c.bcast_f[1] = v;
+  }
+  __syncthreads();
+  const float ans = c.bcast_f[1];
+  __syncthreads();
+  return ans;
+}
+
 // Relax one arc into the frame under construction (FindOrAddToken).  Returns true if the table entry improved.
 template <int NT>
 __device__ __forceinline__ bool Relax(BlockCtx<NT> &c, unsigned long long *best, int *map_next, int4 *next_toks,
@@ -722,6 +773,8 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
   __shared__ int pre[kHashPrefixCap + 1];              // exclusive prefix of the expanded tokens' emitting out-degrees
   __shared__ int n_slots, s_redo;
   __shared__ unsigned s_min_bits;                      // ordered bits of the cheapest candidate of the frame (next_cutoff - adaptive beam)
+  __shared__ float kth_cand[256];                      // GetCutoff's selection: the values of the histogram bin that holds the rank
+  __shared__ int kth_n;
   __shared__ unsigned long long s_best_key;            // (ordered cost bits << 32 | index) of the cheapest token of the frame just completed
   constexpr int NW = NT / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -820,7 +873,7 @@ __global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev 
       float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
       bool decided = false;
       // sorted[max_active] < beam_cutoff  <=>  more than max_active costs lie below beam_cutoff
-      if (n_cur > o.max_active && n_lt > o.max_active) max_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.max_active, best_cost);
+      if (n_cur > o.max_active && n_lt > o.max_active) max_active_cutoff = BlockKthSmallestHist<NT>(c, cur, n_cur, o.max_active, best_cost, beam_cutoff, kth_cand, &kth_n);
       if (max_active_cutoff < beam_cutoff) {
         adaptive_beam = max_active_cutoff - best_cost + o.beam_delta;
         cur_cutoff = max_active_cutoff;
