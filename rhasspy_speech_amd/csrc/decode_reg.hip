@@ -78,13 +78,13 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   if (tid == 0) red.ncand = 0;
   // log-likelihoods of my emitting arcs, fetched one frame ahead (padding arcs read pdf 0 and never pass the cutoff)
   const int f_first = f_begin < 0 ? 0 : f_begin;
-  float ll_nxt[KE];
+  float llv[KE];
 #pragma unroll
-  for (int a = 0; a < KE; a++) ll_nxt[a] = 0.f;
+  for (int a = 0; a < KE; a++) llv[a] = 0.f;
   if (f_first < T) {
     const float *row = loglikes + (ll_base + f_first) * ld;
 #pragma unroll
-    for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
+    for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
   }
   __syncthreads();
   if (f_begin < 0 && tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
@@ -111,14 +111,6 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 
   for (int f = f_begin; f < f_stop && !error; f++) {
     if (f >= 0) {
-      float llv[KE];
-#pragma unroll
-      for (int a = 0; a < KE; a++) llv[a] = ll_nxt[a];
-      if (f + 1 < T) {
-        const float *row = loglikes + (ll_base + f + 1) * ld;
-#pragma unroll
-        for (int a = 0; a < KE; a++) ll_nxt[a] = row[ea[a].y];
-      }
       // ---- best token (ties: smallest state), token count
       float best_cost;
       int best_state, N;
@@ -248,6 +240,17 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           atomicMin(reinterpret_cast<unsigned long long *>(smem + ((unsigned)ea[a].x >> 16)),
                     ((unsigned long long)wv::FloatToOrdered(tot) << 32) | (unsigned)ea[a].w);
       }
+      // The next frame's log-likelihoods are requested here, into the registers this frame has just finished with, and are first
+      // touched by the next frame's arc pass.  (Requested at the top of the frame into a second set of registers, the copy at the
+      // loop's back edge made the compiler wait for vmcnt(0) there -- which on this ISA also counts the back-pointer stores the
+      // commit pass has just issued: every frame waited for its own stores to be acknowledged.)
+      // (unconditional -- the last frame asks for its own row again: a load under a branch left the compiler with a copy of
+      // the registers, and a wait for the loads, right behind their issue)
+      {
+        const float *row = loglikes + (ll_base + (f + 1 < T ? f + 1 : f)) * ld;
+#pragma unroll
+        for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
+      }
       float next_cutoff;
       {
         const unsigned wm = wv::MinU(wv::FloatToOrdered(local_min));
@@ -369,7 +372,9 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state
 // grammar graph, 298 frames): 64 threads 7.5 us/frame, 256 -> 4.2, 512 -> 3.7, 1024 -> 5.1: the per-lane instruction count
 // dominates until the barriers of 16 waves take over.
-static const int kRegConfigs[][3] = {{512, 4, 2}, {512, 8, 4}, {256, 16, 8}, {256, 32, 16}, {256, 8, 4}};
+// (RS_REG_NT=256 on a graph that fits {512, 4, 2} runs {256, 8, 4}: with one workgroup per CU -- the 256-utterance headline batch --
+// the step with four calls in flight is the same within noise, 2.81 ms either way)
+static const int kRegConfigs[][3] = {{512, 4, 2}, {256, 8, 4}, {512, 8, 4}, {256, 16, 8}, {256, 32, 16}};
 
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx) {
   if (num_states > kRegMaxStates) return false;
