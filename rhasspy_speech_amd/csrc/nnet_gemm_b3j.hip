@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       _Pragma("unroll") for (int pb = 2; pb >= 0; pb--) {                                                     \
         if (pb > 2 - (PA)) continue;                                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
-          acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA][I], bf[j][pb], acc[I][j], 0, 0, 0);      \
+          acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], af[PA][I], acc[I][j], 0, 0, 0);      \
       }                                                                                                       \
     }
     // software pipeline over the 12 fragments: the read of fragment n + 2 is issued before the MFMAs of fragment n; the wait
@@ -273,36 +273,101 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   __builtin_amdgcn_s_barrier();                        // the stages become the epilogue's transpose buffer
 
   if (RS_B3J_ABLATE & 64) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
-  // ---- epilogue (nnet_b3_epilogue.inc for two wave rows): 32-row slab sl of the tile belongs to wave row sl / mr_eff
+  // ---- epilogue.  The MFMAs take the WEIGHT fragment as their first operand, so the accumulators hold the tile transposed:
+  // a lane owns output row (lane & 31) of a 32-row block and register r is column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the
+  // 32-column tile -- the same products summed in the same order as with the operands the other way round, bit for bit.  Four
+  // consecutive registers are then four consecutive columns of one row, and what a lane lacks of a 16-byte image unit (eight
+  // consecutive columns of a row) sits in the lane 32 above / below it: one v_permlane32_swap per register pair and the
+  // accumulators ARE the image units.  A layer whose result is only read as an image (every hidden layer) goes from registers to
+  // HBM with no LDS transposition, no barrier and no second pass over the tile; the FP32 rows of an output layer still go
+  // through LDS, now written four columns at a time.
   {
-    constexpr int C_LD = BN + 8, NT = kJThreads;
+    constexpr int C_LD = BN + 4, NT = kJThreads;
     float *Cs = reinterpret_cast<float *>(smem);
-    const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
-    float bias[2], sc[2], of[2];
-    int ccol[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    float *eb = Cs + 32 * C_LD;                   // [3][BN]: bias, scale, offset of the tile's columns
+    const int half = lane >> 5;
+    for (int c = tid; c < BN; c += NT) {
+      const int col = n0 + c;
       const bool cok = col < d.n;
-      ccol[j] = cok ? col : 0;
-      bias[j] = (d.bias && cok) ? d.bias[ccol[j]] : 0.f;
-      sc[j] = 1.f; of[j] = 0.f;
-      if (epi_mode == 2) { sc[j] = d.stages[1].scale[ccol[j]]; of[j] = d.stages[1].offset[ccol[j]]; }
+      eb[c] = (d.bias && cok) ? d.bias[col] : 0.f;
+      eb[BN + c] = (epi_mode == 2 && cok) ? d.stages[1].scale[col] : 1.f;
+      eb[2 * BN + c] = (epi_mode == 2 && cok) ? d.stages[1].offset[col] : 0.f;
     }
+    dd::LdsBarrier();
+    // the fused stages on four consecutive columns (tile-local column CL0 .. CL0 + 3) of one row
+#define RS_EPI4(V, CL0)                                                                                        \
+    {                                                                                                            \
+      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&eb[(CL0)]);                                             \
+      _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = __fadd_rn(b4[e], V[e]);                             \
+      if (epi_mode == 1 || epi_mode == 2) {                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = V[e] > 0.f ? V[e] : 0.f;                          \
+      }                                                                                                          \
+      if (epi_mode == 2) {                                                                                       \
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(&eb[BN + (CL0)]);                                      \
+        const f32x4 o4 = *reinterpret_cast<const f32x4 *>(&eb[2 * BN + (CL0)]);                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = __fadd_rn(__fmul_rn(V[e], s4[e]), o4[e]);         \
+      } else if (epi_mode == 3) {                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                        \
+          const int gc = n0 + (CL0) + e < d.n ? n0 + (CL0) + e : 0;                                              \
+          for (int st = 0; st < d.nstages; st++) V[e] = ApplyStage(d.stages[st], V[e], gc);                     \
+        }                                                                                                        \
+      }                                                                                                          \
+    }
+    const bool direct = d.out_img.base && !d.write_f32 && !(RS_B3J_ABLATE & (128 | 256));
+    if (direct) {
+      // destination rows first: a row-map load between two stores makes the compiler wait for vmcnt(0), stores included
+      int phys[MR];
+      bool rok[MR];
+#pragma unroll
+      for (int i = 0; i < MR; i++) {
+        const int row = row0 + (wm * mr_eff + i) * 32 + (lane & 31);
+        rok[i] = row < rows && i < mr_eff;
+        phys[i] = rok[i] ? (d.row_map ? d.row_map[row] : row) + d.out_img.guard : 0;
+      }
+      // (the block numbers are macro arguments: acc[] must never be indexed by a variable the compiler might not unroll)
+#define RS_DIRECT(I, J)                                                                                        \
+      if (!MIXED || (I) < mr_eff) {                                                                              \
+        const int cb = wn * 64 + (J) * 32;                                                                       \
+        f32x4 q[4];                                                                                              \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                        \
+          _Pragma("unroll") for (int e = 0; e < 4; e++) q[g][e] = acc[I][J][4 * g + e];                        \
+          RS_EPI4(q[g], cb + 8 * g + 4 * half)                                                                   \
+        }                                                                                                        \
+        /* lanes 32..63 of q[0] <-> lanes 0..31 of q[1] (and q[2] <-> q[3]): q[2 k], q[2 k + 1] = columns 16 k + 8 half .. + 7 */ \
+        _Pragma("unroll") for (int g = 0; g < 4; g += 2)                                                       \
+          _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                      \
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q[g][e]), __float_as_uint(q[g + 1][e]), false, false); \
+            q[g][e] = __uint_as_float(sw[0]);                                                                    \
+            q[g + 1][e] = __uint_as_float(sw[1]);                                                                \
+          }                                                                                                      \
+        _Pragma("unroll") for (int ksi = 0; ksi < 2; ksi++) {                                                  \
+          const int col = n0 + cb + 16 * ksi + 8 * half;                                                         \
+          if (rok[I] && (col >> 4) < d.out_img.nks) {                                                            \
+            f32x4 lo = q[2 * ksi], hi = q[2 * ksi + 1];                                                          \
+            _Pragma("unroll") for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
+            bf16x8 p1, p2, p3;                                                                                   \
+            Split3(lo, hi, &p1, &p2, &p3);                                                                       \
+            unsigned char *dst = d.out_img.base + ((size_t)(phys[I] >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (phys[I] & 31) * 16; \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst), p1);                                                   \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes), p2);                            \
+            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes), p3);                        \
+          }                                                                                                      \
+        }                                                                                                        \
+      }
+      RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
+      RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
+#undef RS_DIRECT
+      return;
+    }
+    const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
 #define RS_PUT_SLAB(A)                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                              \
-      const int cl = wn * 64 + j * 32 + (lane & 31);                                                             \
-      _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                           \
-        float v = __fadd_rn(bias[j], A[j][r]);                                                                   \
-        if (epi_mode == 1) {                                                                                     \
-          v = v > 0.f ? v : 0.f;                                                                                 \
-        } else if (epi_mode == 2) {                                                                              \
-          v = v > 0.f ? v : 0.f;                                                                                 \
-          v = __fadd_rn(__fmul_rn(v, sc[j]), of[j]);                                                             \
-        } else if (epi_mode == 3) {                                                                              \
-          for (int st = 0; st < d.nstages; st++) v = ApplyStage(d.stages[st], v, ccol[j]);                       \
-        }                                                                                                        \
-        Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C_LD + cl] = v;                                          \
+      _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                            \
+        const int cl0 = wn * 64 + j * 32 + 8 * g + 4 * half;                                                     \
+        f32x4 v;                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 4; e++) v[e] = A[j][4 * g + e];                                  \
+        RS_EPI4(v, cl0)                                                                                          \
+        *reinterpret_cast<f32x4 *>(&Cs[(lane & 31) * C_LD + cl0]) = v;                                           \
       }                                                                                                          \
     }
     // Destination rows of everything this thread will store, looked up BEFORE the first store: a row-map load between two
@@ -372,6 +437,7 @@ _Pragma("unroll") \
     if constexpr (WM == 2) { RS_SLAB(4) RS_SLAB(5) RS_SLAB(6) RS_SLAB(7) }
 #undef RS_SLAB
 #undef RS_PUT_SLAB
+#undef RS_EPI4
   }
 }
 
@@ -379,7 +445,7 @@ template <int WM, bool MIXED>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
-  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)(32 * (kB3BN + 4) + 3 * kB3BN) * sizeof(float);
   constexpr size_t smem0 = ring > ctile ? ring : ctile;
   // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
   static const bool one_per_cu = [] { const char *e = std::getenv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
