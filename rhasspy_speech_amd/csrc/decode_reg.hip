@@ -152,6 +152,9 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       // the counting pass, its barrier and the histogram are skipped; they are still needed when max-active can bind.
       const bool need_pass = need_counts && (!(closure_cutoff <= beam_cutoff) || N > o.max_active);
       if (need_counts && !need_pass) { c_le = N; c_lt = N; }
+#ifdef RS_DECODE_PROFILE
+      prof[7] += need_pass ? 1 : 0;
+#endif
       if (need_pass) {
         if (!(hist_hi < INF)) {
           float mx = -INF;
@@ -353,8 +356,8 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 #ifdef RS_DECODE_PROFILE
   RS_T(6);
   if (u == 0 && tid == 0)
-    printf("reg decode cycles/frame: stats %lld cutoff %lld emit %lld closure %lld commit %lld | finish total %lld (T=%d)\n",
-           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[6], T);
+    printf("reg decode cycles/frame: stats %lld cutoff %lld emit %lld closure %lld commit %lld | finish total %lld (T=%d) | counting passes %lld, max-active frames %d, min-active frames %d\n",
+           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[6], T, prof[7], max_active_frames, min_active_frames);
 #endif
 }
 

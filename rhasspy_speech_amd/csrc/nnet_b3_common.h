@@ -18,6 +18,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kB3BN = 256, kB3KS = 16;
 constexpr int kB3FragBytes = 1024;                    // one 32 x 16 bf16 operand fragment
+// LDS of the epilogue (nnet_b3_epilogue.inc): one 32-row slab at a pitch of kB3BN + 4 floats + bias / scale / offset of the tile's columns
+constexpr size_t kB3EpiBytes = (size_t)(32 * (kB3BN + 4) + 3 * kB3BN) * sizeof(float);
 
 // x = p1 + p2 + p3 (bf16 parts, round to nearest even), 8 values at a time
 __device__ __forceinline__ void Split3(const f32x4 &lo, const f32x4 &hi, bf16x8 *p1, bf16x8 *p2, bf16x8 *p3) {

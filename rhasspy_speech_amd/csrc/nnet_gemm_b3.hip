@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
         for (int pb = 2; pb >= 0; pb--) {
           if (pb > 2 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, bf[j][pb], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
         }
       }
       cur = nxt;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
 template <int MR, bool MIXED, int WM>
 void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 32 * MR * WM;
-  constexpr size_t stage = 2 * (size_t)(MR * WM * 3 * kB3FragBytes), ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t stage = 2 * (size_t)(MR * WM * 3 * kB3FragBytes), ctile = kB3EpiBytes;
   // WM = 2 asks for all but 1 KiB of the CU's LDS: no other workgroup fits beside it
   constexpr size_t smem = WM == 1 ? (stage > ctile ? stage : ctile) : (size_t)159 * 1024;
   static bool attr_set = false;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
         for (int pb = 2; pb >= 0; pb--) {
           if (pb > 2 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, bf[j][pb], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
         }
       }
       cur = nxt;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
 template <int MR, bool MIXED, int KPS = kKPS>
 void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
   constexpr int BM = 32 * MR;
-  constexpr size_t stage = 2 * (size_t)KPS * MR * 3 * kB3FragBytes, ctile = (size_t)32 * (kB3BN + 8) * sizeof(float);
+  constexpr size_t stage = 2 * (size_t)KPS * MR * 3 * kB3FragBytes, ctile = kB3EpiBytes;
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr_set = false;
   if (!attr_set) {

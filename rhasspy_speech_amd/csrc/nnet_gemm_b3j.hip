@@ -445,7 +445,7 @@ template <int WM, bool MIXED>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
-  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = (size_t)(32 * (kB3BN + 4) + 3 * kB3BN) * sizeof(float);
+  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
   constexpr size_t smem0 = ring > ctile ? ring : ctile;
   // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
   static const bool one_per_cu = [] { const char *e = std::getenv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
