@@ -27,8 +27,10 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "nnet_b3_common.h"
 
@@ -72,8 +74,22 @@ template <int WM> struct JShape {
 #define RS_IMG_STORE(ptr, v) *(ptr) = (v)
 #endif
 
+// -DRS_B3J_TRACE: every workgroup leaves {start, end of the k loop, end of the epilogue} (s_memrealtime, 10 ns ticks) and the
+// hardware id of its CU; RS_B3J_TRACE_FILE=<path> makes the launcher dump the records of one hidden-layer launch
+// (profiles/micro/b3j_trace.sh, b3j_trace_read.py)
+#ifdef RS_B3J_TRACE
+__device__ unsigned long long g_b3j_trace[8192 * 4];
+#define RS_TRACE(SLOT) if (threadIdx.x == 0 && blockIdx.x < 8192) g_b3j_trace[blockIdx.x * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime()
+#define RS_TRACE_ID() if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned hw; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_b3j_trace[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw; }
+#else
+#define RS_TRACE(SLOT) do { } while (0)
+#define RS_TRACE_ID() do { } while (0)
+#endif
+
 template <int WM, bool MIXED>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
+  RS_TRACE(0);
+  RS_TRACE_ID();
   typedef JShape<WM> SH;
   constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJStage = SH::kStage, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
   constexpr int MR = kJMR, BM = 32 * kJRowBlocks, BN = kB3BN;
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
 #undef RS_WAIT_OWN
 #undef RS_VMWAIT
   __builtin_amdgcn_s_barrier();                        // the stages become the epilogue's transpose buffer
+  RS_TRACE(1);
 
   if (RS_B3J_ABLATE & 64) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
   // ---- epilogue.  The MFMAs take the WEIGHT fragment as their first operand, so the accumulators hold the tile transposed:
@@ -357,6 +374,11 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
       RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
 #undef RS_DIRECT
+#ifdef RS_B3J_TRACE
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      RS_TRACE(2);
+#endif
       return;
     }
     const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
@@ -463,6 +485,21 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
   hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
+#ifdef RS_B3J_TRACE
+  static int traced = 0;
+  const char *tf = std::getenv("RS_B3J_TRACE_FILE");
+  if (tf && d.out_img.base && !d.write_f32 && ++traced == 40) {       // one hidden-layer launch well after warm-up
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(8192 * 4);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_b3j_trace), h.size() * sizeof(unsigned long long));
+    if (FILE *f = std::fopen(tf, "w")) {
+      std::fprintf(f, "# blocks %d rows %d nbig %d nfirst %d ncol %d\n", blocks, rows, nbig, nfirst, ncol);
+      for (int b = 0; b < blocks && b < 8192; b++)
+        std::fprintf(f, "%d %llu %llu %llu %llx\n", b, h[b * 4], h[b * 4 + 1], h[b * 4 + 2], h[b * 4 + 3]);
+      std::fclose(f);
+    }
+  }
+#endif
 }
 
 int JWaveRows() {          // RS_GEMM_B3J_WM = 1 | 2 (read per call)
