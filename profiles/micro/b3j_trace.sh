@@ -6,7 +6,7 @@ OUT=gpurun_out/${1:-b3j_trace}
 mkdir -p $OUT
 rm -rf /tmp/rstr && mkdir -p /tmp/rstr && cp -a rhasspy_speech_amd include /tmp/rstr/
 rm -f /tmp/rstr/rhasspy_speech_amd/csrc/nnet_gemm_b3j.o
-make -C /tmp/rstr/rhasspy_speech_amd/csrc EXTRA=-DRS_B3J_TRACE > $OUT/make.log 2>&1
+make -C /tmp/rstr/rhasspy_speech_amd/csrc EXTRA="-DRS_B3J_TRACE -DRS_B3J_ABLATE=${ABLATE:-0}" > $OUT/make.log 2>&1
 cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so
 cp /tmp/rstr/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/librhasspy_speech_hip.so
 RS_B3J_TRACE_FILE=$OUT/trace.txt python bench.py --no-cpu-baseline --no-side-figures --steps 8 --warmup 4 --inflight 1 > $OUT/bench.json 2> $OUT/bench.log

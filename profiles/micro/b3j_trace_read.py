@@ -22,6 +22,10 @@ cu = collections.defaultdict(list)
 for i, h in enumerate(hw):
     xcc = h >> 32; w = h & 0xFFFFFFFF
     cu[(xcc & 0xF, (w >> 13) & 7, (w >> 12) & 1, (w >> 8) & 0xF)].append(i)
+if len(rows[0]) > 5:
+    clk = np.array([int(r[5]) for r in rows], dtype=np.float64)
+    ghz = clk / ((b[:, 2] - b[:, 1]) * 10.0)            # shader clocks per ns of the k loop
+    print(f"shader clock during the k loops: mean {ghz.mean():.3f} GHz (min {ghz.min():.3f} max {ghz.max():.3f})")
 print(f"distinct CUs {len(cu)}; workgroups per CU: {collections.Counter(len(v) for v in cu.values())}")
 busy = []
 for key, idx in cu.items():

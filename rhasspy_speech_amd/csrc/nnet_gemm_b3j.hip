@@ -51,7 +51,7 @@ template <int WM> struct JShape {
   static constexpr int kDmaPerKstep = 3 + 3 * kColTilesPerWave;            // per staging wave and k-step
 };
 
-// Timing ablations (results WRONG with a bit set): 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
+// Timing ablations (results WRONG with a bit set): 512 = weight DMAs of different workgroups ask for different k-steps, 1024 = no weight DMA, 2048 = no activation DMA, 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
 #ifndef RS_B3J_ABLATE
 #define RS_B3J_ABLATE 0
 #endif
@@ -74,13 +74,13 @@ template <int WM> struct JShape {
 #define RS_IMG_STORE(ptr, v) *(ptr) = (v)
 #endif
 
-// -DRS_B3J_TRACE: every workgroup leaves {start, end of the k loop, end of the epilogue} (s_memrealtime, 10 ns ticks) and the
-// hardware id of its CU; RS_B3J_TRACE_FILE=<path> makes the launcher dump the records of one hidden-layer launch
+// -DRS_B3J_TRACE: every workgroup leaves {start, end of the k loop, end of the epilogue} (s_memrealtime, 10 ns ticks), the
+// hardware id of its CU and the shader clocks its k loop took (s_memtime); RS_B3J_TRACE_FILE=<path> makes the launcher dump the records of one hidden-layer launch
 // (profiles/micro/b3j_trace.sh, b3j_trace_read.py)
 #ifdef RS_B3J_TRACE
-__device__ unsigned long long g_b3j_trace[8192 * 4];
-#define RS_TRACE(SLOT) if (threadIdx.x == 0 && blockIdx.x < 8192) g_b3j_trace[blockIdx.x * 4 + (SLOT)] = __builtin_amdgcn_s_memrealtime()
-#define RS_TRACE_ID() if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned hw; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_b3j_trace[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw; }
+__device__ unsigned long long g_b3j_trace[8192 * 6];
+#define RS_TRACE(SLOT) if (threadIdx.x == 0 && blockIdx.x < 8192) { g_b3j_trace[blockIdx.x * 6 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); if ((SLOT) < 2) g_b3j_trace[blockIdx.x * 6 + 4 + (SLOT)] = __builtin_amdgcn_s_memtime(); }
+#define RS_TRACE_ID() if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned hw; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_b3j_trace[blockIdx.x * 6 + 3] = ((unsigned long long)xcc << 32) | hw; }
 #else
 #define RS_TRACE(SLOT) do { } while (0)
 #define RS_TRACE_ID() do { } while (0)
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto stage_kstep = [&](unsigned soff) __attribute__((always_inline)) {     // soff: byte offset of this k-step's stage in LDS
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + soff);
-    if (stager) {
+    if (stager && !(RS_B3J_ABLATE & 2048)) {
       const unsigned char *img_base = reinterpret_cast<const unsigned char *>(
           (uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_base_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_base_lo, seg)));
       const size_t part_bytes = (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_part_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_part_lo, seg));
@@ -186,8 +186,12 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         RS_DMA16_STREAM(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
       }
     }
-    {
+    if (!(RS_B3J_ABLATE & 1024)) {
       const unsigned char *ws = wtile_ok ? wsrc : reinterpret_cast<const unsigned char *>(d.W3I) + lane * 16;
+      if (RS_B3J_ABLATE & 512) {      // every workgroup asks for a different k-step's weights at any moment (is it the same L2 lines for all?)
+        const size_t off = (size_t)(ws - reinterpret_cast<const unsigned char *>(d.W3I)) + (size_t)(bid % 16) * 2 * wstep;
+        ws = reinterpret_cast<const unsigned char *>(d.W3I) + off % ((size_t)nt * wstep);
+      }
 #pragma unroll
       for (int p = 0; p < 3 * CTW; p++) {
         const unsigned char *g = ws + p * kB3FragBytes;
@@ -488,14 +492,15 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
 #ifdef RS_B3J_TRACE
   static int traced = 0;
   const char *tf = std::getenv("RS_B3J_TRACE_FILE");
-  if (tf && d.out_img.base && !d.write_f32 && ++traced == 40) {       // one hidden-layer launch well after warm-up
+  static const int trace_at = [] { const char *e = std::getenv("RS_B3J_TRACE_AT"); return e ? std::atoi(e) : 40; }();
+  if (tf && d.out_img.base && !d.write_f32 && ++traced == trace_at) {       // one hidden-layer launch well after warm-up
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(8192 * 4);
+    std::vector<unsigned long long> h(8192 * 6);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_b3j_trace), h.size() * sizeof(unsigned long long));
     if (FILE *f = std::fopen(tf, "w")) {
       std::fprintf(f, "# blocks %d rows %d nbig %d nfirst %d ncol %d\n", blocks, rows, nbig, nfirst, ncol);
       for (int b = 0; b < blocks && b < 8192; b++)
-        std::fprintf(f, "%d %llu %llu %llu %llx\n", b, h[b * 4], h[b * 4 + 1], h[b * 4 + 2], h[b * 4 + 3]);
+        std::fprintf(f, "%d %llu %llu %llu %llx %llu\n", b, h[b * 6], h[b * 6 + 1], h[b * 6 + 2], h[b * 6 + 3], h[b * 6 + 5] - h[b * 6 + 4]);
       std::fclose(f);
     }
   }
