@@ -12,7 +12,7 @@ for v in ${VARIANTS:-0 64}; do
   make -C /tmp/rsab/rhasspy_speech_amd/csrc EXTRA=-DRS_B3J_ABLATE=$v > $OUT/make_$v.log 2>&1
   cp /tmp/rsab/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/librhasspy_speech_hip.so
   rm -rf $OUT/kt_$v
-  RS_GEMM_B3J_ONE_PER_CU=${ONE:-0} timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$v -- python bench.py --steps 6 --warmup 2 --inflight 1 --no-cpu-baseline --no-side-figures > $OUT/bench_$v.json 2> $OUT/bench_$v.log
+  RS_GEMM_B3J_ONE_PER_CU=${ONE:-0} timeout -k 5 -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$v -- python bench.py --steps 6 --warmup 2 --inflight 1 --no-cpu-baseline --no-side-figures > $OUT/bench_$v.json 2> $OUT/bench_$v.log
   f=$(find $OUT/kt_$v -name "*kernel_stats.csv" | head -1)
   echo "ablate=$v $(grep GemmKernelB3J $f | head -1 | awk -F'","|",|,' '{print "calls", $(NF-6), "avg_ns", $(NF-4)}')" >> $OUT/summary.txt
 done
