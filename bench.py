@@ -320,10 +320,13 @@ def main() -> None:
 
     def run_steps(n, fn, check_against=None):
         """n steps, at most `inflight` decode calls in flight; results are consumed (and gathered) in step order."""
+        t_start = time.perf_counter()
         futures = [pool.submit(fn) for _ in range(n)] if inflight > 1 else None
         last = None
         for k in range(n):
             res = futures[k].result() if futures else fn()
+            if os.environ.get("RS_BENCH_TRACE"):
+                sys.stderr.write(f"step {k} done at {(time.perf_counter() - t_start) * 1e3:.2f} ms\n")
             rec = gather(records(res))
             if check_against is not None and not np.array_equal(rec, check_against):
                 raise SystemExit(f"bench.py: step {k} produced different results from the first step on the same input")

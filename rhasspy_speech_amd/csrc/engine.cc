@@ -227,6 +227,7 @@ Model::~Model() {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream_dec) (void)hipStreamDestroy(c->stream_dec);
     for (auto &e : c->slab_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->stage_ev) if (e) (void)hipEventDestroy(e);
   }
 }
 
@@ -385,6 +386,7 @@ void Model::ToDevice() {
       RS_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
       RS_HIP(hipStreamCreateWithPriority(&c->stream_dec, hipStreamNonBlocking, prio_high));
       for (auto &ev : c->slab_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      for (auto &ev : c->stage_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       ctx_.push_back(std::move(c));
     }
   }
@@ -1323,8 +1325,23 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     }
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
+  static const bool chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return !e || std::atoi(e) != 0; }();
+  const bool chained = chain && !streaming;
   Timer tm(s);
   tm.Mark();
+  std::unique_lock<std::mutex> stage_lock;
+  auto stage_begin = [&](int st) {
+    if (!chained) return;
+    stage_lock = std::unique_lock<std::mutex>(stage_mu_[st]);
+    if (stage_tail_[st] && stage_tail_[st] != cx.stage_ev[st]) RS_HIP(hipStreamWaitEvent(s, stage_tail_[st], 0));
+  };
+  auto stage_end = [&](int st) {
+    if (!chained) return;
+    RS_HIP(hipEventRecord(cx.stage_ev[st], s));
+    stage_tail_[st] = cx.stage_ev[st];
+    stage_lock.unlock();
+  };
+  stage_begin(0);
   // ---- features
   std::vector<float *> bufp(nn.bufs.size(), nullptr);
   for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(buf_ld[b]);
@@ -1403,12 +1420,14 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       }
     }
   }
+  stage_end(0);
   // ---- search work buffers (before the acoustic model: the last layer can be pipelined with the search)
   AllocSearch(&sp, arena_, s);
   const DecodeOptsDev &dopts = sp.dopts;
   DenseWork &dw = sp.dw;
   tm.Mark();
   // ---- acoustic model
+  stage_begin(1);
   if (pipelined) {
     RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, row_maps, cx.active_groups, 0, nn.ops.size() - 1, s, &imgs);
     // slab k: output layer on the main stream, then the search of that slab on the decode stream
@@ -1428,6 +1447,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     poison();
     RunNnet(bufp, buf_ld, d_ivec, ld_i, d_row_ivec, rows, row_maps, cx.active_groups, 0, nn.ops.size(), s, &imgs);
   }
+  stage_end(1);
   float *ll = bufp[nn.output_buf];
   const int ll_ld = buf_ld[nn.output_buf];
   tm.Mark();
