@@ -1325,20 +1325,25 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     }
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
-  static const bool chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return !e || std::atoi(e) != 0; }();
-  const bool chained = chain && !streaming;
+  static const int chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return e ? std::atoi(e) : 1; }();
+  // (RS_STAGE_CHAIN=2: one chain for all models of the process instead of one per model)
+  static std::mutex g_stage_mu[2];
+  static hipEvent_t g_stage_tail[2] = {nullptr, nullptr};
+  std::mutex *const smu = chain == 2 ? g_stage_mu : stage_mu_;
+  hipEvent_t *const stail = chain == 2 ? g_stage_tail : stage_tail_;
+  const bool chained = chain != 0 && !streaming;
   Timer tm(s);
   tm.Mark();
   std::unique_lock<std::mutex> stage_lock;
   auto stage_begin = [&](int st) {
     if (!chained) return;
-    stage_lock = std::unique_lock<std::mutex>(stage_mu_[st]);
-    if (stage_tail_[st] && stage_tail_[st] != cx.stage_ev[st]) RS_HIP(hipStreamWaitEvent(s, stage_tail_[st], 0));
+    stage_lock = std::unique_lock<std::mutex>(smu[st]);
+    if (stail[st] && stail[st] != cx.stage_ev[st]) RS_HIP(hipStreamWaitEvent(s, stail[st], 0));
   };
   auto stage_end = [&](int st) {
     if (!chained) return;
     RS_HIP(hipEventRecord(cx.stage_ev[st], s));
-    stage_tail_[st] = cx.stage_ev[st];
+    stail[st] = cx.stage_ev[st];
     stage_lock.unlock();
   };
   stage_begin(0);
