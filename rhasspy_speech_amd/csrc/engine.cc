@@ -1326,11 +1326,10 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   static const int chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return e ? std::atoi(e) : 1; }();
-  // (RS_STAGE_CHAIN=2: one chain for all models of the process instead of one per model)
-  static std::mutex g_stage_mu[2];
-  static hipEvent_t g_stage_tail[2] = {nullptr, nullptr};
-  std::mutex *const smu = chain == 2 ? g_stage_mu : stage_mu_;
-  hipEvent_t *const stail = chain == 2 ? g_stage_tail : stage_tail_;
+  // (one chain per model: a single chain for all models of the process was no better on the two-model batch -- 10.75-10.96 ms
+  // against 10.56-10.70 -- and its tail event would have to outlive the model that recorded it)
+  std::mutex *const smu = stage_mu_;
+  hipEvent_t *const stail = stage_tail_;
   const bool chained = chain != 0 && !streaming;
   Timer tm(s);
   tm.Mark();
