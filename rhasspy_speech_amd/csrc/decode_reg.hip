@@ -375,8 +375,6 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state
 // grammar graph, 298 frames): 64 threads 7.5 us/frame, 256 -> 4.2, 512 -> 3.7, 1024 -> 5.1: the per-lane instruction count
 // dominates until the barriers of 16 waves take over.
-// (RS_REG_NT=256 on a graph that fits {512, 4, 2} runs {256, 8, 4}: with one workgroup per CU -- the 256-utterance headline batch --
-// the step with four calls in flight is the same within noise, 2.81 ms either way)
 static const int kRegConfigs[][3] = {{512, 4, 2}, {256, 8, 4}, {512, 8, 4}, {256, 16, 8}, {256, 32, 16}};
 
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx) {
@@ -397,10 +395,24 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
   // the GEMM workgroups (33 KB each) of the next decode call on its CU, and the overlap of calls in flight was limited to
   // the feature / iVector stages (3.7 ms per headline batch against 3.35 with 48 KB; the search itself takes the same
   // time).  A slab that finishes no utterance does not trace back and keeps its LDS footprint minimal.
-  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 48; }();
+  // (12 KB since the calls' stages are chained, engine.cc: 2.51 -> 2.47-2.49 ms per headline step; 4-16 KB are within 1 % of each other)
+  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 12; }();
   const size_t stage = (w.win_begin ? !any_final : f_end <= g.max_frames) ? 0 : stage_kb * 1024;
   if (smem < stage) smem = stage;
-  if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  // A batch that puts a search workgroup on (nearly) every CU shares those CUs with the GEMM workgroups of the next call: with
+  // half the waves and twice the arcs per thread the search alone is 8 % slower (1.12 -> 1.21 ms for 256 x 3 s) and the step with
+  // calls in flight 2.5 % faster (2.51 -> 2.45 ms together with the smaller traceback staging below).  The tables are the same --
+  // arc i sits in slot i of e_tab / x_tab whatever the shape.  RS_REG_NT pins the shape chosen at load.
+  static const bool pinned = std::getenv("RS_REG_NT") != nullptr;
+  static const int num_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const bool crowded = !pinned && !w.win_begin && 4 * (long)g.n_utts >= 3 * (long)num_cu;
+  if (crowded && r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<256, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (crowded && r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
+  else if (r.nt == 512 && r.ke == 4 && r.kx == 2) LaunchOne<512, 4, 2>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else if (r.nt == 512 && r.ke == 8 && r.kx == 4) LaunchOne<512, 8, 4>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else if (r.nt == 256 && r.ke == 16 && r.kx == 8) LaunchOne<256, 16, 8>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
   else if (r.nt == 256 && r.ke == 32 && r.kx == 16) LaunchOne<256, 32, 16>(h, r, o, g, loglikes, ld, w, smem, f_begin, f_end, s);
