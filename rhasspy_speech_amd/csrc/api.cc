@@ -15,6 +15,16 @@
 #include "nnet3_setup.h"
 #include "rescore.h"
 
+// Loaded before the HIP runtime has started (the usual case for a host program that links or dlopens the library first): ask the
+// runtime for 8 hardware queues instead of 4, unless the environment already says otherwise.  A model keeps up to four calls in
+// flight on three streams each, and streams that share a hardware queue serialise on each other's event waits (headline step
+// 2.45 -> 2.31 ms).  Without effect when HIP is already initialised.
+namespace {
+struct HipQueuesDefault {
+  HipQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hip_queues_default;
+}  // namespace
+
 namespace rs {
 int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt_model, const int16_t *const *pcm, const int32_t *n_samples,
                        int n_utts, int rank, int world, void *comm, int32_t *records, std::string *error);
