@@ -288,7 +288,8 @@ def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
     csrc = Path(__file__).resolve().parent.parent / "rhasspy_speech_amd" / "csrc"
     nopack = re.search(r"^NOPACK\s*=\s*(.*)$", (csrc / "Makefile").read_text(), re.M).group(1).split()
     assert "-fno-slp-vectorize" in nopack and "-fno-vectorize" in nopack
-    flags = nopack if source in ("feat_kernels.hip", "nnet_kernels.hip", "ivector_kernels.hip", "decode_kernels.hip") else []
+    flags = nopack if source in ("feat_kernels.hip", "nnet_kernels.hip", "ivector_kernels.hip", "decode_kernels.hip", "nnet_gemm_b3.hip",
+                                 "nnet_gemm_b3i.hip", "nnet_gemm_b3j.hip") else []
     out = tmp_path / "k.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *extra, *flags, "-S", "--cuda-device-only", str(csrc / source),
                     "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
