@@ -330,7 +330,8 @@ def main() -> None:
         for k in range(n):
             res = futures[k].result() if futures else fn()
             if os.environ.get("RS_BENCH_TRACE"):
-                sys.stderr.write(f"step {k} done at {(time.perf_counter() - t_start) * 1e3:.2f} ms\n")
+                tm_ = res.timings() if hasattr(res, "timings") else []
+                sys.stderr.write(f"step {k} done at {(time.perf_counter() - t_start) * 1e3:.2f} ms  timings {[round(x, 2) for x in tm_]}\n")
             rec = gather(records(res))
             if check_against is not None and not np.array_equal(rec, check_against):
                 raise SystemExit(f"bench.py: step {k} produced different results from the first step on the same input")
