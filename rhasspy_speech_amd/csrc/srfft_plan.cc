@@ -85,6 +85,31 @@ SrfftPlan BuildSrfftPlan(int padded_window) {
     if ((int)pl.tasks.size() > pl.level_begin.back()) pl.level_begin.push_back((int)pl.tasks.size());
     cur.swap(next);
   }
+  // ---- A 64-lane wave runs a level in ceil(tasks / 64) rounds.  The whole small blocks (kinds 1 and 2) are leaves -- nothing
+  // reads their results before the bit-reversal pass -- so the few of them that would cost a level an extra round move to a
+  // later level that has lanes to spare (512-point window: levels of 64 64 64 64 68 28 3 tasks become 64 64 64 64 64 32 3:
+  // seven rounds instead of eight; same operations on the same values).
+  {
+    const int nl = (int)pl.level_begin.size() - 1;
+    std::vector<std::vector<SrfftTask>> lv(nl);
+    for (int l = 0; l < nl; l++) lv[l].assign(pl.tasks.begin() + pl.level_begin[l], pl.tasks.begin() + pl.level_begin[l + 1]);
+    for (int l = 0; l + 1 < nl; l++) {
+      int excess = (int)lv[l].size() % 64;
+      if (excess == 0 || (int)lv[l].size() < 64) continue;
+      for (int to = l + 1; to < nl && excess > 0; to++) {
+        int room = (64 - (int)lv[to].size() % 64) % 64;
+        for (int i = (int)lv[l].size() - 1; i >= 0 && excess > 0 && room > 0; i--) {
+          if ((lv[l][i].kind_logm & 0xFF) == 0) continue;
+          lv[to].push_back(lv[l][i]);
+          lv[l].erase(lv[l].begin() + i);
+          excess--; room--;
+        }
+      }
+    }
+    pl.tasks.clear();
+    pl.level_begin.assign(1, 0);
+    for (int l = 0; l < nl; l++) { pl.tasks.insert(pl.tasks.end(), lv[l].begin(), lv[l].end()); pl.level_begin.push_back((int)pl.tasks.size()); }
+  }
   pl.perm = BitReverseGather(pl.logn);
   // ---- srfft.cc:379-385: exp(-2 pi i k / padded) advanced by a float complex multiplication per k
   const int NR = padded_window;
