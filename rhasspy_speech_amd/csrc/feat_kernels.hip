@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     t = t < 0 ? 0 : t;          // (also the halo rows of an utterance too short for one frame: frame 0 of whatever follows it, never read back)
   }
   float *x = xbuf[wave];
-  float raw_energy = 0.f;
+  float raw_energy = 0.f, dc = 0.f;
   if (active) {
     const int16_t *src = pcm + g.d_sample_off[u] + (int64_t)t * m.shift;
     // 1. load (int16 -> float, unscaled), dither, DC removal.  The frame sum follows the reference's BLAS call
@@ -161,13 +161,13 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     for (int i = m.win + lane; i < NFFT; i += RS_WAVE) x[i] = 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, RS_WAVE);
-    const float mean = (float)dsum / (float)m.win;
-    WaveLdsSync();      // the sample pairs were written by other lanes than the ones that read them below
-    if (m.remove_dc)
-      for (int i = lane; i < m.win; i += RS_WAVE) x[i] -= mean;
+    // DC removal (x[i] += -mean) is applied where the samples are read below -- the same subtraction on the same operands, once
+    // for a sample itself and once as its right neighbour's predecessor -- instead of in a pass of its own over the LDS copy
+    dc = m.remove_dc ? (float)dsum / (float)m.win : 0.f;
     if (m.use_energy && m.raw_energy) {
+      WaveLdsSync();      // the sample pairs were written by other lanes than the ones that read them here
       float e = 0.f;
-      for (int i = lane; i < m.win; i += RS_WAVE) e += x[i] * x[i];
+      for (int i = lane; i < m.win; i += RS_WAVE) { const float v = m.remove_dc ? x[i] - dc : x[i]; e += v * v; }
       raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
     }
   }
@@ -180,8 +180,9 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     for (int i = lane; i < NFFT; i += RS_WAVE) {
       float y = 0.f;
       if (i < m.win) {
-        const float prev = x[i > 0 ? i - 1 : 0];
-        const float v = x[i] - m.preemph * prev;
+        float prev = x[i > 0 ? i - 1 : 0], cur = x[i];
+        if (m.remove_dc) { prev -= dc; cur -= dc; }
+        const float v = cur - m.preemph * prev;
         y = v * m.window[i];
         e += y * y;
       }
