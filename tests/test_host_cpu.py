@@ -309,3 +309,28 @@ def test_decoder_options_the_reference_asserts_on(tmp_path):
         with pytest.raises(_lib.RsError, match="min_active <= max_active"):
             _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(**bad))
     _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(max_active=200, min_active=200)).close()
+
+
+def test_library_asks_for_eight_hardware_queues_unless_told_otherwise():
+    """Loading the library puts GPU_MAX_HW_QUEUES=8 into the process environment (api.cc: calls in flight use three streams each and
+    the runtime's default of four hardware queues serialises them), and leaves a value that is already there alone.  (The C
+    library's environment is read back through its own getenv: os.environ is a snapshot Python took at start-up.)"""
+    import subprocess
+    import sys
+    code = """
+import ctypes, os, sys
+preset = sys.argv[1]
+if preset == "-":
+    os.environ.pop("GPU_MAX_HW_QUEUES", None)
+else:
+    os.environ["GPU_MAX_HW_QUEUES"] = preset
+from rhasspy_speech_amd import _lib
+_lib.lib()
+getenv = ctypes.CDLL(None).getenv
+getenv.restype = ctypes.c_char_p
+print(getenv(b"GPU_MAX_HW_QUEUES").decode())
+"""
+    root = str(Path(__file__).resolve().parent.parent)
+    for preset, want in (("-", "8"), ("5", "5")):
+        out = subprocess.run([sys.executable, "-c", code, preset], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
+        assert out == want, (preset, out)
