@@ -267,12 +267,26 @@ def main() -> None:
         n_global = n_utts * world
 
         def decode():
+            trace = bool(os.environ.get("RS_BENCH_TRACE"))
+            t_open = time.perf_counter()
             streams = [_lib.Stream(model) for _ in pcms]
+            t_acc = t_adv = t_py = 0.0
+            t_open = time.perf_counter() - t_open
             for r in range(n_rounds):
+                t0 = time.perf_counter()
                 live = [(s, p[r * tick:(r + 1) * tick]) for s, p in zip(streams, pcms) if r * tick < len(p)]
+                t1 = time.perf_counter()
                 _lib.accept_streams([s for s, _ in live], [a for _, a in live])       # one round of audio for every stream: one call
+                t2 = time.perf_counter()
                 _lib.advance_streams(streams)
-            return _lib.finish_streams(streams)
+                t3 = time.perf_counter()
+                t_py += t1 - t0; t_acc += t2 - t1; t_adv += t3 - t2
+            t0 = time.perf_counter()
+            out = _lib.finish_streams(streams)
+            if trace:
+                sys.stderr.write(f"streams step: open {t_open * 1e3:.2f} ms, slicing {t_py * 1e3:.2f}, accept {t_acc * 1e3:.2f}, advance {t_adv * 1e3:.2f}, "
+                                 f"finish {(time.perf_counter() - t0) * 1e3:.2f} ({n_rounds} rounds)\n")
+            return out
         workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU fed in {tick}-sample "
                          f"rounds (online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one iVector per 24-frame nnet chunk)")
     else:   # mixed
