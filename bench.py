@@ -262,6 +262,9 @@ def main() -> None:
         if rank == 0 and n_utts == 64:
             golden = configs.load_golden("c4_streams")
         tick = 1024 * 8          # samples handed over per stream and round: 8 of the binary's 1024-sample reads
+        pcms = [np.ascontiguousarray(p, dtype=np.int16) for p in pcms]
+        pcm_base = np.array([p.__array_interface__["data"][0] for p in pcms], dtype=np.uintp)
+        pcm_len = np.array([len(p) for p in pcms], dtype=np.int64)
         n_rounds = (max(len(p) for p in pcms) + tick - 1) // tick
         sharded = False          # streams stay on their rank; at N > 1 the ranks run replicas and the records are gathered by torch
         n_global = n_utts * world
@@ -272,13 +275,19 @@ def main() -> None:
             streams = [_lib.Stream(model) for _ in pcms]
             t_acc = t_adv = t_py = 0.0
             t_open = time.perf_counter() - t_open
+            handles = _lib.stream_handles(streams)
             for r in range(n_rounds):
                 t0 = time.perf_counter()
-                live = [(s, p[r * tick:(r + 1) * tick]) for s, p in zip(streams, pcms) if r * tick < len(p)]
+                # one round of audio for every stream that still has some: addresses and lengths by array arithmetic, as a host
+                # program in C would (per-stream Python objects cost 85 us per round, more than the library call)
+                left = pcm_len - r * tick
+                live = left > 0
+                addrs = (pcm_base + np.uintp(2 * r * tick))[live]
+                lens = np.minimum(left[live], tick).astype(np.int32)
                 t1 = time.perf_counter()
-                _lib.accept_streams([s for s, _ in live], [a for _, a in live])       # one round of audio for every stream: one call
+                _lib.accept_streams_raw(handles[live], addrs, lens)
                 t2 = time.perf_counter()
-                _lib.advance_streams(streams)
+                _lib.advance_streams_raw(handles)
                 t3 = time.perf_counter()
                 t_py += t1 - t0; t_acc += t2 - t1; t_adv += t3 - t2
             t0 = time.perf_counter()

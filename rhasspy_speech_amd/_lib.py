@@ -360,6 +360,27 @@ def advance_streams(streams: Sequence[Stream]) -> None:
     _check(lib().rs_streams_advance(arr, len(streams)))
 
 
+def stream_handles(streams: Sequence[Stream]) -> np.ndarray:
+    """The streams' rs_stream handles as an array of addresses, for the *_raw calls below."""
+    return np.fromiter((s._h.value or 0 for s in streams), dtype=np.uintp, count=len(streams))
+
+
+def accept_streams_raw(handles: np.ndarray, addrs: np.ndarray, lens: np.ndarray) -> None:
+    """rs_streams_accept on arrays the caller keeps: handles[i] (stream_handles), addrs[i] = address of int16 samples, lens[i] =
+    their number.  A host program that feeds many streams per round does this pointer arithmetic itself; building the arrays
+    from Python objects per round (accept_streams) costs more than the call."""
+    n = int(handles.shape[0])
+    assert handles.dtype == np.uintp and addrs.dtype == np.uintp and lens.dtype == np.int32 and addrs.shape[0] == n and lens.shape[0] == n
+    _check(lib().rs_streams_accept(handles.ctypes.data_as(C.POINTER(C.c_void_p)), addrs.ctypes.data_as(C.POINTER(C.c_void_p)),
+                                   lens.ctypes.data_as(C.POINTER(C.c_int32)), n))
+
+
+def advance_streams_raw(handles: np.ndarray) -> None:
+    """rs_streams_advance on an array of handles (stream_handles)."""
+    assert handles.dtype == np.uintp
+    _check(lib().rs_streams_advance(handles.ctypes.data_as(C.POINTER(C.c_void_p)), int(handles.shape[0])))
+
+
 def finish_streams(streams: Sequence[Stream], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
     """Ends all streams (EOF) and decodes them as one device batch; utterance i of the result = streams[i]."""
     arr = (C.c_void_p * len(streams))(*[s._h for s in streams])

@@ -151,6 +151,34 @@ def test_config4_five_best_of_every_stream(zam_grammar):
     _check_nbest_against_reference("c4_streams", _lib.finish_streams(streams, nbest=5), len(pcms))
 
 
+def test_streams_fed_through_the_array_entry_points(zam_grammar):
+    """stream_handles / accept_streams_raw / advance_streams_raw (addresses and lengths as arrays the caller keeps, ragged rounds:
+    streams that have run out of audio drop out of the accept call) against the per-object calls on the same audio."""
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    pcms = [np.ascontiguousarray(p[:len(p) - 5000 * (i % 4)], dtype=np.int16) for i, p in enumerate(configs.stream_utterances()[:12])]
+    tick = 8 * 1024
+    n_rounds = (max(len(p) for p in pcms) + tick - 1) // tick
+    ref_streams = [_lib.Stream(model) for _ in pcms]
+    for r in range(n_rounds):
+        live = [(s, p[r * tick:(r + 1) * tick]) for s, p in zip(ref_streams, pcms) if r * tick < len(p)]
+        _lib.accept_streams([s for s, _ in live], [a for _, a in live])
+        _lib.advance_streams(ref_streams)
+    ref = _lib.finish_streams(ref_streams)
+    streams = [_lib.Stream(model) for _ in pcms]
+    handles = _lib.stream_handles(streams)
+    base = np.array([p.__array_interface__["data"][0] for p in pcms], dtype=np.uintp)
+    length = np.array([len(p) for p in pcms], dtype=np.int64)
+    for r in range(n_rounds):
+        left = length - r * tick
+        live = left > 0
+        _lib.accept_streams_raw(handles[live], (base + np.uintp(2 * r * tick))[live], np.minimum(left[live], tick).astype(np.int32))
+        _lib.advance_streams_raw(handles)
+    got = _lib.finish_streams(streams)
+    for u in range(len(pcms)):
+        assert got.words(u) == ref.words(u) and got.costs(u) == ref.costs(u)
+
+
 def test_config2_arpa_hclg_256x3s(zam_arpa):
     from rhasspy_speech_amd import _lib
     model_dir, graph_dir = zam_arpa
