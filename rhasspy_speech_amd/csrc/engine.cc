@@ -697,6 +697,16 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
     // Pageable caller buffers -> pinned staging -> HBM in spans of about 16 MB: the DMA of one span runs under the host copy of
     // the next, and nothing waits here -- the feature kernel is ordered behind the last span on the context's stream.
     static const int64_t span = [] { const char *e = std::getenv("RS_UPLOAD_SPAN_KB"); return (int64_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) * 512; }();      // samples per span (16 MB: 2 MB spans cost the mixed workload 5 % in copy calls, one span for everything 6 % in lost overlap)
+    // The copies of consecutive calls are chained like the stages (engine.h: stage 2): a call's hipMemcpyAsync waits, on the
+    // device, for the previous call's.  Calls that start at the same moment otherwise submit their copies at the same moment, and
+    // one of them was then seen to spend 6.6-9 ms INSIDE hipMemcpyAsync (profiles/r03/soak.txt); with the copies ordered that does
+    // not happen: 20 steps from a standing start 2.70 -> 2.55 ms per step on average, steady state unchanged.
+    static const bool up_chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return !e || std::atoi(e) != 0; }();
+    std::unique_lock<std::mutex> up_lock;
+    if (up_chain) {
+      up_lock = std::unique_lock<std::mutex>(stage_mu_[2]);
+      if (stage_tail_[2] && stage_tail_[2] != cx->stage_ev[2]) RS_HIP(hipStreamWaitEvent(cx->stream, stage_tail_[2], 0));
+    }
     for (int i = 0, first = 0; i < n_utts; i++) {
       if (n_samples[i]) std::memcpy(cx->h_pcm_pinned + off[i], pcm[i], sizeof(int16_t) * (size_t)n_samples[i]);
       if (off[i + 1] - off[first] >= span || i + 1 == n_utts) {
@@ -705,6 +715,11 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
                                 hipMemcpyHostToDevice, cx->stream));
         first = i + 1;
       }
+    }
+    if (up_chain) {
+      RS_HIP(hipEventRecord(cx->stage_ev[2], cx->stream));
+      stage_tail_[2] = cx->stage_ev[2];
+      up_lock.unlock();
     }
     const float h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     res = DecodeInContext(*cx, cx->d_pcm, off.data(), n_utts, nbest, lat_scale, nullptr, streaming);

@@ -178,7 +178,7 @@ class Model {
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipStream_t stream_dec = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on `stream`
     hipEvent_t slab_ev[9] = {};
-    hipEvent_t stage_ev[2] = {};           // end of this call's feature + iVector stage / of its acoustic-model stage (StageChain)
+    hipEvent_t stage_ev[3] = {};           // end of this call's feature + iVector stage / of its acoustic-model stage / of its sample upload (StageChain)
     DeviceArena arena[3];                  // one per concurrent utterance group (batch calls use two; stream advances rotate over three)
     HostArena host_arena[3];
     LatArcBuffer lat_arcs[3];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
@@ -195,8 +195,8 @@ class Model {
   // at the same moment come out staggered -- the first after one call's latency, not all of them after four -- and the pipeline
   // of stages is full from the second call on.  Device-side only: the next call's stream waits for the event the previous
   // call recorded behind its stage; the host holds the stage's mutex just while it enqueues.  RS_STAGE_CHAIN=0 switches it off.
-  std::mutex stage_mu_[2];
-  hipEvent_t stage_tail_[2] = {nullptr, nullptr};
+  std::mutex stage_mu_[3];
+  hipEvent_t stage_tail_[3] = {nullptr, nullptr, nullptr};      // [2]: the copies of a call's samples to the device (DecodeBatchHost)
   std::condition_variable ctx_cv_;
   DecodeContext *AcquireContext();
   void ReleaseContext(DecodeContext *cx);
