@@ -228,7 +228,10 @@ Model::~Model() {
     if (c->stream_dec) (void)hipStreamDestroy(c->stream_dec);
     for (auto &e : c->slab_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->stage_ev) if (e) (void)hipEventDestroy(e);
+    if (c->split_ev) (void)hipEventDestroy(c->split_ev);
+    if (c->gemm_ovf) (void)hipHostFree(c->gemm_ovf);
   }
+  if (stream_ctx_ && stream_ctx_->gemm_ovf) (void)hipHostFree(stream_ctx_->gemm_ovf);
 }
 
 MfccDev Model::MfccWithDither(int frames) {
@@ -286,19 +289,57 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
       std::memcpy(&W[(size_t)r * plan->k_pad + plan->seg_k0[si]], &op.W.d[(size_t)r * op.W.cols + sg.w_col], sizeof(float) * sg.ncols);
   }
   plan->d_W = Upload(W);
-  // Split-bf16 image (nnet_gemm_b3.hip): w = w1 + w2 + w3 with bf16 parts (round to nearest even), stored per
-  // (16-wide k-step, 32-column tile, part) as one 1 KiB MFMA B fragment [k-group 2][column 32][8 bf16].
+  // Split-fp16 image (nnet_gemm_b3.hip): column n of W times a power of two s_n that puts its largest weight into [2^14, 2^15)
+  // (both fp16 parts of every weight that matters are then normal numbers), w s_n = w1 + w2 with fp16 parts (round to nearest
+  // even), stored per (16-wide k-step, 32-column tile, part) as one 1 KiB MFMA B fragment [k-group 2][column 32][8 fp16].  The
+  // kernels' epilogue multiplies column n by 1 / s_n (exact).
   plan->n3 = RoundUp(op.out_dim, 256);
   plan->d_W3 = nullptr;
   plan->d_W3I = nullptr;
+  plan->d_w3_inv_scale = nullptr;
   if (op.out_dim >= 192 && GemmB3PaddingOk(op.out_dim, plan->n3)) {
-    auto to_bf16 = [](float x) {
+    auto to_f16 = [](float x) -> uint16_t {          // round to nearest even, subnormals kept; |x| < 65520 here
       uint32_t u;
       std::memcpy(&u, &x, 4);
-      u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (weights are finite)
-      return (uint16_t)(u >> 16);
+      const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+      const int e = (int)((u >> 23) & 0xff) - 127;
+      uint32_t m = u & 0x7fffffu;
+      if (e < -25) return sign;
+      if (e < -14) {                                  // subnormal result: value = q 2^-24
+        m |= 0x800000u;
+        const int sh = -e - 1;                        // q = m >> sh (14 .. 24)
+        uint32_t q = m >> sh;
+        const uint32_t rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+        if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+        return (uint16_t)(sign | q);
+      }
+      uint32_t h = ((uint32_t)(e + 15) << 10) | (m >> 13);
+      const uint32_t rem = m & 0x1fffu;
+      if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;      // a carry into the exponent is the right answer
+      return (uint16_t)(sign | h);
     };
-    auto from_bf16 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; };
+    auto from_f16 = [](uint16_t h) -> float {
+      const int e = (h >> 10) & 0x1f;
+      const uint32_t m = h & 0x3ffu;
+      const float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(m | 0x400u), e - 25);
+      return (h & 0x8000u) ? -v : v;
+    };
+    std::vector<float> col_scale(plan->n3, 1.0f), inv_scale(plan->n3, 1.0f);
+    bool finite = true;
+    for (int n = 0; n < op.out_dim; n++) {
+      float mx = 0.0f;
+      for (int k = 0; k < plan->k_pad; k++) {
+        const float a = std::fabs(W[(size_t)n * plan->k_pad + k]);
+        if (!std::isfinite(a)) finite = false;
+        mx = std::max(mx, a);
+      }
+      if (!(mx > 0.0f) || !finite) continue;
+      int ex;
+      std::frexp(mx, &ex);                            // mx = f 2^ex, f in [0.5, 1)
+      const int sh = std::min(std::max(15 - ex, -100), 100);
+      col_scale[n] = std::ldexp(1.0f, sh);
+      inv_scale[n] = std::ldexp(1.0f, -sh);
+    }
     const int nct = plan->n3 / 32;
     // k-step order: segment after segment, or -- when every segment is a row-shifted view of the same columns of one
     // buffer -- alternating between the segments (step t = segment t % nsegs, columns 16 (t / nsegs))
@@ -307,27 +348,26 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     for (auto &sg : op.segs)
       plan->interleave = plan->interleave && sg.src_buf >= 0 && sg.src_buf == op.segs[0].src_buf && sg.src_col == op.segs[0].src_col &&
                          sg.ncols == op.segs[0].ncols;
-    // image of W for a list of k-steps (first W column of each): [k-step][32-column tile][part][k-group 2][column 32][8 bf16]
+    // image of W for a list of k-steps (first W column of each): [k-step][32-column tile][part][k-group 2][column 32][8 fp16]
+    constexpr int P = kActImageParts;
     auto build = [&](const std::vector<int> &step_k) {
       const int nks = (int)step_k.size();
-      std::vector<uint16_t> W3((size_t)(nks + 2) * nct * 3 * 512, 0);      // + 2 k-steps the kernels' pipelines request past the end
+      std::vector<uint16_t> W3((size_t)(nks + 2) * nct * P * 512, 0);      // + 2 k-steps the kernels' pipelines request past the end
       for (int n = 0; n < op.out_dim; n++)
         for (int t = 0; t < nks; t++)
           for (int kk = 0; kk < 16; kk++) {
-            const float w = W[(size_t)n * plan->k_pad + step_k[t] + kk];
+            const float w = W[(size_t)n * plan->k_pad + step_k[t] + kk] * col_scale[n];
             if (w == 0.0f) continue;
-            const uint16_t h1 = to_bf16(w);
-            const float r1 = w - from_bf16(h1);
-            const uint16_t h2 = to_bf16(r1);
-            const float r2 = r1 - from_bf16(h2);
-            const uint16_t h3 = to_bf16(r2);
-            const size_t base = ((size_t)t * nct + n / 32) * 3 * 512 + (size_t)(kk / 8) * 256 + (size_t)(n % 32) * 8 + kk % 8;
-            W3[base] = h1; W3[base + 512] = h2; W3[base + 1024] = h3;
+            const uint16_t h1 = to_f16(w);
+            const uint16_t h2 = to_f16(w - from_f16(h1));
+            const size_t base = ((size_t)t * nct + n / 32) * P * 512 + (size_t)(kk / 8) * 256 + (size_t)(n % 32) * 8 + kk % 8;
+            W3[base] = h1; W3[base + 512] = h2;
           }
       return UploadBytes(W3.data(), W3.size() * sizeof(uint16_t));
     };
     // (1) GemmKernelB3: every segment spans its width padded to kGemmBK
-    {
+    if (finite) {
+      plan->d_w3_inv_scale = Upload(inv_scale);
       const int nks = plan->k_pad / 16;
       std::vector<int> step_k(nks);
       for (int t = 0; t < nks; t++) step_k[t] = plan->interleave ? plan->seg_k0[t % nsegs] + (t / nsegs) * 16 : t * 16;
@@ -337,7 +377,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
     // to be a frame buffer whose first column sits on a k-step boundary
     // ... and the layer to be one the split-bf16 kernels take at all (GemmB3IUsable's padding rule: at most a quarter of the
     // 256-column tiles may be padding) -- decided HERE, because the producers of its sources stop storing plain floats
-    bool imageable = GemmB3PaddingOk(op.out_dim, plan->n3);
+    bool imageable = finite && GemmB3PaddingOk(op.out_dim, plan->n3);
     for (auto &sg : op.segs) imageable = imageable && sg.src_buf >= 0 && sg.src_col % 16 == 0;
     if (imageable) {
       std::vector<int> step_k;
@@ -387,6 +427,10 @@ void Model::ToDevice() {
       RS_HIP(hipStreamCreateWithPriority(&c->stream_dec, hipStreamNonBlocking, prio_high));
       for (auto &ev : c->slab_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       for (auto &ev : c->stage_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      RS_HIP(hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming));
+      RS_HIP(hipHostMalloc((void **)&c->gemm_ovf, 64, hipHostMallocMapped));
+      *c->gemm_ovf = 0;
+      RS_HIP(hipHostGetDevicePointer((void **)&c->gemm_ovf_dev, c->gemm_ovf, 0));
       ctx_.push_back(std::move(c));
     }
   }
@@ -751,6 +795,17 @@ std::unique_ptr<Result> Model::DecodeBatchDevice(const int16_t *d_pcm, const int
 
 static std::atomic<int> g_calls_in_flight{0};      // decode calls of any model of this process
 
+// Which layer GEMMs the work this thread is enqueueing uses: sampled from the model once per utterance group / stream advance
+// (a call must not change kernels half way: producers and consumers agree on who stores operand images).
+thread_local bool tls_exact_gemm = false;
+thread_local int *tls_gemm_ovf_dev = nullptr;
+void SampleGemmMode(bool exact, int *ovf_dev) { tls_exact_gemm = exact; tls_gemm_ovf_dev = ovf_dev; }
+bool Model::CheckGemmRange(DecodeContext &cx) {
+  if (tls_exact_gemm || !cx.gemm_ovf || *static_cast<volatile int *>(cx.gemm_ovf) == 0) return false;
+  if (range_retries_.fetch_add(1) + 1 >= 3) exact_gemm_.store(true);
+  return true;
+}
+
 Model::DecodeContext *Model::AcquireContext() {
   std::unique_lock<std::mutex> lk(ctx_mu_);
   for (;;) {
@@ -781,6 +836,10 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
   // two concurrent groups unless the caller pinned a stream, the batch is small, or RS_SUBBATCHES=1
   const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
   cx.active_groups = ngroups;
+  for (int attempt = 0;; attempt++) {
+  *cx.gemm_ovf = 0;
+  cx.force_exact = attempt > 0;
+  try {
   if (ngroups == 1) {
     DecodeGroup(cx, 0, d_pcm, sample_offsets, n_utts, nbest, lat_scale, user_stream ? user_stream : cx.stream, streaming,
                 res->utts.data(), res->timings);
@@ -788,6 +847,10 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
     const int half = (n_utts + 1) / 2;
     float t2[2][8] = {{0}, {0}};
     std::exception_ptr err[2];
+    // the second group's stream starts behind whatever the first one's holds for this call (DecodeBatchHost: the copies of the
+    // samples to the device, which nothing else orders group 1's feature kernel behind)
+    RS_HIP(hipEventRecord(cx.split_ev, cx.stream));
+    RS_HIP(hipStreamWaitEvent(cx.stream2, cx.split_ev, 0));
     auto run = [&](int gi) {
       try {
         const int u0 = gi == 0 ? 0 : half, n = gi == 0 ? half : n_utts - half;
@@ -803,6 +866,13 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
     for (int gi = 0; gi < 2; gi++) if (err[gi]) std::rethrow_exception(err[gi]);
     for (int k = 0; k < 8; k++) res->timings[k] = t2[0][k] + t2[1][k];   // stage times add up; they overlap in wall time
   }
+  break;
+  } catch (const RangeRetry &) {
+    // (both groups are over: the throwing group's exception is only rethrown after the join)
+    if (attempt > 0) Fail("layer GEMM range check failed on the exact-FP32 kernels");
+    for (auto &u : res->utts) u = UttResult();
+  }
+  }
   res->timings[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   return res;
 }
@@ -811,7 +881,7 @@ size_t Model::ImageBytes(int rows) const {
   size_t b = 0;
   const int guard = RoundUp(L_ + R_ + 8, 32);
   for (size_t i = 0; i < buf_image_.size(); i++)
-    if (buf_image_[i]) b += 3 * ActImagePartBytes(rows, guard, am_.nnet.bufs[i].dim) + 1024;
+    if (buf_image_[i]) b += kActImageParts * ActImagePartBytes(rows, guard, am_.nnet.bufs[i].dim) + 1024;
   return b;
 }
 
@@ -822,11 +892,40 @@ std::vector<ActImage> Model::AllocImages(DeviceArena &arena, int rows) const {
     if (!buf_image_[i]) continue;
     ActImage &im = imgs[i];
     im.part_bytes = ActImagePartBytes(rows, guard, am_.nnet.bufs[i].dim);
-    im.base = static_cast<unsigned char *>(arena.Alloc(3 * im.part_bytes));
+    im.base = static_cast<unsigned char *>(arena.Alloc(kActImageParts * im.part_bytes));
     im.nks = (am_.nnet.bufs[i].dim + 15) / 16;
     im.guard = guard;
   }
   return imgs;
+}
+
+void Model::ZeroGuards(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, int rows, const std::vector<ActImage> *imgs, hipStream_t s) const {
+  ZeroRegions z;
+  z.count = 0;
+  auto add = [&](void *p, size_t bytes) {
+    if (bytes == 0) return;
+    if (z.count == ZeroRegions::kMax) { LaunchZeroRegions(z, s); z.count = 0; }
+    z.r[z.count].p = p; z.r[z.count].bytes = bytes; z.count++;
+  };
+  const int guard = L_ + R_ + 8;                            // rows in front of / behind a frame buffer (DecodeGroup, StreamsAdvance: falloc)
+  for (size_t b = 0; b < bufp.size(); b++) {
+    if (!bufp[b]) continue;
+    const size_t g = (size_t)guard * buf_ld[b] * sizeof(float);
+    add(bufp[b] - (size_t)guard * buf_ld[b], g);
+    add(bufp[b] + (size_t)rows * buf_ld[b], g);
+  }
+  if (imgs)
+    for (const ActImage &im : *imgs) {
+      if (!im.base) continue;
+      // image rows [0, guard) and from the row block that holds image row guard + rows on (its rows of real frames are
+      // written after this by their producer)
+      const size_t blk = (size_t)im.nks * 1024, head = (size_t)(im.guard / 32) * blk, tail0 = (size_t)((im.guard + rows) / 32) * blk;
+      for (int p = 0; p < kActImageParts; p++) {
+        add(im.base + p * im.part_bytes, head);
+        add(im.base + p * im.part_bytes + tail0, im.part_bytes - tail0);
+      }
+    }
+  if (z.count) LaunchZeroRegions(z, s);
 }
 
 GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, const std::vector<int> &src_ld, float *ivec, int ivec_ld, float *out,
@@ -834,7 +933,7 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
   GemmDev d;
   std::memset(&d, 0, sizeof(d));
   const LayerOp &op = *pl.op;
-  const bool images_on = imgs != nullptr && GemmImagesEnabled();
+  const bool images_on = imgs != nullptr && GemmImagesEnabled() && !tls_exact_gemm && tls_gemm_ovf_dev != nullptr;
   d.nsegs = (int)op.segs.size();
   for (int i = 0; i < d.nsegs; i++) {
     const GemmSegment &sg = op.segs[i];
@@ -847,7 +946,8 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
     o.col0 = sg.src_col; o.ncols = sg.ncols; o.k0 = pl.seg_k0[i];
   }
   d.W = pl.d_W; d.k_pad = pl.k_pad; d.n = op.out_dim; d.n_pad = pl.n_pad; d.bias = pl.d_bias;
-  d.W3 = pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = share;
+  d.W3 = (tls_exact_gemm || !tls_gemm_ovf_dev) ? nullptr : pl.d_W3; d.n3 = pl.n3; d.interleave = pl.interleave ? 1 : 0; d.share = share;
+  d.w3_inv_scale = pl.d_w3_inv_scale; d.ovf = tls_gemm_ovf_dev;
   d.W3I = images_on ? pl.d_W3I : nullptr;
   d.write_f32 = 1;
   if (images_on && out_buf >= 0 && (*imgs)[out_buf].base) {
@@ -872,7 +972,8 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
                     const RowMaps &row_maps, int share, size_t op_begin, size_t op_end, hipStream_t s,
                     const std::vector<ActImage> *imgs) const {
   const Nnet &nn = am_.nnet;
-  const bool images_on = imgs != nullptr && GemmImagesEnabled();
+  const bool images_on = imgs != nullptr && GemmImagesEnabled() && !tls_exact_gemm && tls_gemm_ovf_dev != nullptr;
+  if (op_begin == 0 && !tls_exact_gemm) ZeroGuards(bufp, buf_ld, rows, images_on ? imgs : nullptr, s);
   for (size_t i = op_begin; i < op_end; i++) {
     const LayerOp &op = nn.ops[i];
     const bool img_out = images_on && (*imgs)[op.out_buf].base != nullptr;
@@ -915,7 +1016,7 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       d.nstages = ns;
       LaunchEltwise(d, rows, s);
     }
-    if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, rows, (*imgs)[op.out_buf], s);
+    if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, rows, (*imgs)[op.out_buf], tls_gemm_ovf_dev, s);
   }
   if (op_end == nn.ops.size() && (d_log_priors_ || opts_.acoustic_scale != 1.0f))
     LaunchPriorScale(bufp[nn.output_buf], buf_ld[nn.output_buf], rows, nn.output_dim, d_log_priors_, opts_.acoustic_scale, s);
@@ -1040,6 +1141,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
                           hipMemcpyDeviceToHost, s));
   RS_HIP(hipStreamSynchronize(s));
   RS_HIP(hipGetLastError());
+  if (CheckGemmRange(cx)) throw RangeRetry{};      // an activation beyond the fp16 split's range: the call is repeated on the exact-FP32 GEMMs
   for (int u = 0; u < n_utts; u++) {
     UttResult &ur = out_utts[u];
     for (int k = 0; k < 8; k++) ur.counters[k] = h_ctr[(size_t)u * 8 + k];
@@ -1164,6 +1266,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   RS_HIP(hipSetDevice(opts_.device_id));
   auto wall0 = std::chrono::steady_clock::now();
   if (n_utts == 0) return;
+  SampleGemmMode(exact_gemm_.load() || cx.force_exact, cx.gemm_ovf_dev);
   const Nnet &nn = am_.nnet;
   const int C = fc_.mfcc.nceps, P = nn.output_dim;
   // ---- geometry

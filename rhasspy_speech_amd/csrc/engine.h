@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -71,8 +72,9 @@ struct Result {
 struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   const LayerOp *op = nullptr;
   float *d_W = nullptr, *d_bias = nullptr;
-  void *d_W3 = nullptr;           // split-bf16 image of W for GemmKernelB3 (layers at least 192 columns wide)
+  void *d_W3 = nullptr;           // split-fp16 image of W for GemmKernelB3 (layers at least 192 columns wide)
   void *d_W3I = nullptr;          // the same for GemmKernelB3I (every source a frame buffer on a k-step boundary)
+  float *d_w3_inv_scale = nullptr;   // inverse of the images' column scales (n3 floats)
   int k_pad = 0, n_pad = 0, n3 = 0;
   bool interleave = false;        // W3 k-steps alternate between the segments (see GemmKernelB3)
   std::vector<int> seg_k0;
@@ -94,6 +96,7 @@ struct Timer {
 };
 
 struct StreamPool;                                                 // stream.cc
+void SampleGemmMode(bool exact, int *ovf_dev);                   // engine.cc: which layer GEMMs this thread's launches use, and whose range flag they raise
 struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
 
 // Row lists of a batch for the layers that need fewer rows than the full halo: entry (lext, rext) lists, utterance after
@@ -179,6 +182,8 @@ class Model {
     hipStream_t stream_dec = nullptr;      // the search of a time slab runs here while the next slab's output layer runs on `stream`
     hipEvent_t slab_ev[9] = {};
     hipEvent_t stage_ev[3] = {};           // end of this call's feature + iVector stage / of its acoustic-model stage / of its sample upload (StageChain)
+    int *gemm_ovf = nullptr, *gemm_ovf_dev = nullptr;      // pinned + mapped word and the device's address of it (see exact_gemm_)
+    hipEvent_t split_ev = nullptr;         // what `stream` held when a call split into two utterance groups (the second group's stream waits for it)
     DeviceArena arena[3];                  // one per concurrent utterance group (batch calls use two; stream advances rotate over three)
     HostArena host_arena[3];
     LatArcBuffer lat_arcs[3];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
@@ -186,6 +191,7 @@ class Model {
     size_t h_pcm_cap = 0;
     int16_t *d_pcm = nullptr;
     int active_groups = 1;
+    bool force_exact = false;              // this call is the repetition of one that left the split-fp16 kernels' range
     bool busy = false;
   };
   std::vector<std::unique_ptr<DecodeContext>> ctx_;
@@ -210,6 +216,18 @@ class Model {
   StreamPool *Pool();
   void StreamsDrain(StreamPool *p, float *extra);
   void StreamGrow(rs_stream *st, int need_frames);
+  // The split-fp16 layer GEMMs carry activations below 65520 in magnitude (nnet_gemm_b3.hip).  A kernel that meets a larger
+  // one sets the flag of the decode context it runs for (DecodeContext::gemm_ovf: host memory the device writes to); a batch
+  // call that finds it set after its wait repeats itself on the exact-FP32 kernels (a model whose calls keep doing that changes
+  // to them for good); a stream advance cannot be repeated: its call fails and the model changes kernels at once.
+  std::atomic<bool> exact_gemm_{false};
+  std::atomic<int> range_retries_{0};     // batch calls repeated so far; the third makes the change permanent
+  struct RangeRetry {};             // thrown by a batch call that has to be repeated on the exact kernels
+  void StreamsCheckRange();         // the same for stream advances (stream.cc)
+  bool CheckGemmRange(DecodeContext &cx);      // after a wait: true if this call ran on the split-fp16 kernels and one of them overflowed
+  // Guard rows of the frame buffers / operand images of a call: layers evaluated on all rows read up to their context beyond
+  // the first and last row; what they compute from those rows is never used, but it passes through the range check above.
+  void ZeroGuards(const std::vector<float *> &bufp, const std::vector<int> &buf_ld, int rows, const std::vector<ActImage> *imgs, hipStream_t s) const;
   std::vector<int> pdf_remap_;     // prune_output_pdfs: pdf id -> column of the pruned output layer (-1 = never read)
   int pruned_from_ = 0;            // number of pdfs before pruning (0 = not pruned)
   void PruneOutputLayer();

@@ -392,6 +392,23 @@ void LaunchCopyRowsMulti(const CopyRowsSet &set, const int *src_row, const int *
   hipLaunchKernelGGL(CopyRowsMultiKernel, dim3(n, set.count), dim3(256), 0, s, set, src_row, dst_row);
 }
 
+// zero fill of a list of regions (blockIdx.y = region, 16 workgroups per region)
+__global__ __launch_bounds__(256) void ZeroRegionsKernel(ZeroRegions z) {
+  const ZeroRegions::One r = z.r[blockIdx.y];
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+  if (((reinterpret_cast<uintptr_t>(r.p) | r.bytes) & 15) == 0) {
+    uint4 *p = static_cast<uint4 *>(r.p);
+    for (size_t k = t; k < r.bytes / 16; k += nthreads) p[k] = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    unsigned *p = static_cast<unsigned *>(r.p);
+    for (size_t k = t; k < r.bytes / 4; k += nthreads) p[k] = 0u;
+  }
+}
+void LaunchZeroRegions(const ZeroRegions &z, hipStream_t s) {
+  if (z.count <= 0) return;
+  hipLaunchKernelGGL(ZeroRegionsKernel, dim3(16, z.count), dim3(256), 0, s, z);
+}
+
 void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
                     hipStream_t s) {
   if (n <= 0 || width_words <= 0) return;

@@ -65,6 +65,14 @@ void LaunchCopyRowsMulti(const CopyRowsSet &set, const int *src_row, const int *
 void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
                     hipStream_t s);
 
+// zero fill of a list of 16-byte aligned regions in one launch
+struct ZeroRegions {
+  static constexpr int kMax = 48;
+  struct One { void *p; size_t bytes; } r[kMax];
+  int count;
+};
+void LaunchZeroRegions(const ZeroRegions &z, hipStream_t s);
+
 // frame_rows[i] = physical row of the i-th frame in slab-major order: entry (k, u) of seg_off (n_segs + 1 offsets, n_segs =
 // n_slabs * n_utts) starts the frames [k * slab_len, ...) of utterance u.
 void LaunchFrameRows(int n_utts, int n_segs, int total, int L, int slab_len, const int *seg_off, const int *row_base, int *frame_rows,
@@ -85,9 +93,9 @@ void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, flo
 
 // ---------------------------------------------------------------- generic segmented GEMM (FP32 MFMA)
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
-// A frame buffer stored a second time in the operand order of the bf16 matrix cores, already split into the three bf16
+// A frame buffer stored a second time in the operand order of the fp16 matrix cores, already split into the two fp16
 // parts of nnet_gemm_b3.hip: part p at base + p * part_bytes, inside a part [row block of 32][16-wide k-step][k-group 2]
-// [row 32][8 bf16] -- one 1 KiB block is one A fragment of v_mfma_f32_32x32x16_bf16 (lane l: row l & 31, k-group l >> 5).
+// [row 32][8 fp16] -- one 1 KiB block is one A fragment of v_mfma_f32_32x32x16_f16 (lane l: row l & 31, k-group l >> 5).
 // Image row = buffer row + guard (a multiple of 32); columns beyond the buffer's width up to 16 * nks are zero.
 struct ActImage {
   unsigned char *base;
@@ -117,8 +125,10 @@ struct GemmDev {
   GemmSegDev segs[kMaxSegs];
   const float *W;     // n_pad x k_pad, row-major, zero padded (k_pad = sum of segment widths rounded to kGemmBK)
   int k_pad, n, n_pad;
-  const void *W3;     // the same weights split into three bf16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
+  const void *W3;     // the same weights, every output column scaled by a power of two (w3_inv_scale) and split into two fp16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
   const void *W3I;    // the same for GemmKernelB3I: segments padded to the 16-wide k-step instead of to kGemmBK, or null
+  const float *w3_inv_scale;   // n3 floats: what the accumulators of column c are multiplied by (the inverse of W3's column scale)
+  int *ovf;           // set to 1 by a kernel that met an activation the fp16 split cannot carry (|x| >= 65520): the host repeats the call on the exact-FP32 kernels
   int n3;             // columns of W3 (n rounded up to 256)
   int interleave;     // 1: W3's k-steps alternate between the segments (all segments shifted views of one buffer)
   int exclusive;      // 1: GemmKernelB3 keeps every other workgroup off its CU (several decode pipelines in flight)
@@ -133,10 +143,11 @@ struct GemmDev {
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
 };
 // f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue
-void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, hipStream_t s);
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s);
+constexpr int kActImageParts = 2;
 size_t ActImagePartBytes(int rows, int guard, int dim);      // bytes of one part for a buffer of `rows` rows
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
-// The split-bf16 kernels work on 256-column tiles: a layer takes them only while the padding stays below this share of the
+// The split-fp16 kernels work on 256-column tiles: a layer takes them only while the padding stays below this share of the
 // padded width (above it the exact-FP32 kernel with its 128-column tiles wins).  RS_GEMM_B3_PAD overrides (percent).
 bool GemmB3PaddingOk(int n, int n3);
 bool GemmWritesImage(const GemmDev &d);      // the kernel LaunchGemm picks writes d.out_img (else: LaunchToImage afterwards)

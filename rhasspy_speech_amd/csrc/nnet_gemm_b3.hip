@@ -1,33 +1,33 @@
-// The TDNN layer GEMM on the bf16 matrix cores with FP32 results: every FP32 operand is split into three bf16 parts
-//        x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)        (round to nearest even)
-// which together carry the full 24-bit significand (3 x 8 bits, plus a sign each), and a product is accumulated as
-//        a b ~= a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1
-// by six v_mfma_f32_32x32x16_bf16 with FP32 accumulation.  Each partial product is exact in FP32 (8 x 8 significand
-// bits); the three dropped terms are below 2^-25 |a b|, i.e. under the rounding error of one FP32 multiply.  The bf16
-// matrix cores run 16x the rate of the FP32-input MFMA (MI355X_MICROARCH.md), so six of them per k-step cost 6/16 of the
-// exact-FP32 path: the ceiling of this kernel is 2.67x the 157 TF FP32-MFMA peak.  tests/test_gpu_parity.py holds the
-// result to the same 1e-4 log-likelihood bound against the reference as the FP32 path (nnet_kernels.hip), which stays
-// selectable (RS_GEMM_B3=0) and is what small layers use.
+// The TDNN layer GEMM on the fp16 matrix cores with FP32 results: every FP32 operand is split into two fp16 parts
+//        x = x1 + x2 (+ at most 2^-22 |x|),   x1 = fp16(x), x2 = fp16(x - x1)        (round to nearest even)
+// which together carry 22 bits of the significand, and a product is accumulated as
+//        a b ~= a2 b1 + a1 b2 + a1 b1
+// by three v_mfma_f32_32x32x16_f16 with FP32 accumulation (smallest terms first).  Each partial product is exact in FP32
+// (11 x 11 significand bits); what is dropped (a2 b2 and the two representation errors) is below 2^-21 |a b|, and measured
+// against the reference's goldens the log-likelihoods are as close as those of an FP32 BLAS (the order of the FP32 sums is
+// what the error is made of: 1.9e-5 against 1.6e-5 on the zamia-size model, profiles/r04/split_numerics.txt).  Rounds 1-3 used
+// three bf16 parts and six products per element: twice the matrix-core work and 6 instead of 4 bytes per operand element.
+// Range: fp16 ends at 65504.  Weights are static: every output column is scaled by a power of two so that its largest
+// weight lies in [2^14, 2^15) (low parts normal; the epilogue multiplies the accumulators by the inverse, exactly).
+// Activations are split as they are: anything below 65520 in magnitude is carried with an absolute error below 2^-25 (low
+// parts may be subnormal -- the matrix cores keep fp16 subnormal inputs, profiles/micro/mfma_f16_denorm.hip); a kernel that
+// meets a larger one raises GemmDev::ovf and the host repeats the call on the exact-FP32 kernels (engine.cc), which stay
+// selectable (RS_GEMM_B3=0) and are what small layers use.  The fp16 matrix cores run 16x the rate of the FP32-input MFMA
+// (MI355X_MICROARCH.md), so three of them per k-step cost 3/16 of the exact-FP32 path.
+// tests/test_gpu_parity.py holds the result to the same 1e-4 log-likelihood bound against the reference as the FP32 path.
 //
 // Same segmented-K contract as nnet_kernels.hip (GemmDev: the splice never exists in memory).  Block tile (32 MR) x 256:
 // four waves side by side, each (32 MR) x 64 = MR x 2 accumulator tiles of 32x32.  K advances 16 per step:
 //   weights: split ONCE on the host into the fragment order of the MFMA B operand -- for every (k-step, 32-column tile,
-//            part) one 1 KiB block [k-group 2][column 32][8 bf16].  A wave is the only consumer of its 64 columns, so its
-//            six B fragments never touch LDS: each is one global_load_dwordx4 (lane l takes bytes 16 l .. 16 l + 15 of
+//            part) one 1 KiB block [k-group 2][column 32][8 fp16].  A wave is the only consumer of its 64 columns, so its
+//            four B fragments never touch LDS: each is one global_load_dwordx4 (lane l takes bytes 16 l .. 16 l + 15 of
 //            the block: 1 KiB of consecutive memory per instruction);
 //   activations (shared by the four waves): FP32 rows from the producer's buffer -> registers (16 bytes per lane) ->
-//            split -> three 8-byte LDS writes into fragment order [k-group][row][8 bf16] (two LDS stages, one barrier per
+//            split -> two 8-byte LDS writes into fragment order [k-group][row][8 fp16] (two LDS stages, one barrier per
 //            step), read back with one conflict-free ds_read_b128 at 16 x lane per fragment, used and dropped;
 //   pipeline: three register sets rotate -- during step t the weights of step t + 2 and the activations of step t + 3 are
 //            requested and the activations of step t + 1 are split into LDS.
-// Measured on the 256 x 3 s headline batch (76288 rows; profiles/r01): hidden layer (K 3 x 250, N 250) 200 us vs 245 us
-// for the FP32-MFMA kernel, output layer (K 250, N 2000) 590-620 vs 800 us.  What bounds it (rocprofv3 PMC, per-part
-// ablation): the matrix cores are busy 41 % of the time; the block's 24 KiB of weights per k-step stream from L2 for only
-// 64-128 rows (about 2.5 GB of L2 requests per hidden layer, 12 TB/s), and MFMA / weight stream / activation staging add
-// up rather than overlap across the per-step barrier.  Tried and dropped: weights through LDS with global_load_lds
-// (slower: LDS at 80 %), a 256-row 8-wave tile that quarters the weight stream (no faster per row, and its second round
-// on 298 tiles is mostly empty), 160-row tiles (spill), no LDS at all (every wave loading and splitting the activation rows
-// of its own fragments, no barrier: 256 us, the four-fold repeated loads and splits cost more than the barrier).
+// (History of the three-bf16 form of this kernel: profiles/r01)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -46,7 +46,7 @@ template <int MR, bool MIXED, int WM>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
   static_assert(!(MIXED && WM > 1), "two tile heights only with one wave row");
   constexpr int RT = MR * WM, BM = 32 * RT, BN = kB3BN, NT = 256 * WM;
-  constexpr int STAGE = RT * 3 * kB3FragBytes;      // activations only: the weights go straight to registers
+  constexpr int STAGE = RT * kB3Parts * kB3FragBytes;      // activations only: the weights go straight to registers
   constexpr int UNITS = BM * 4, NA = (UNITS + NT - 1) / NT;      // 16-byte activation loads per k-step and thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
     grow[h] = row0 + (a_on[h] ? r : 0);
     if (grow[h] >= rows) grow[h] = 0;          // clamped rows are dropped in the epilogue
     if (d.row_map) grow[h] = d.row_map[grow[h]];
-    // fragment image of row tile r / 32, part p at + p * RT KiB: [k-group][row][8 bf16]
+    // fragment image of row tile r / 32, part p at + p * RT KiB: [k-group][row][8 fp16]
     a_lds[h] = (r >> 5) * kB3FragBytes + (kq >> 1) * 512 + (r & 31) * 16 + (kq & 1) * 8;
   }
   const float *aptr[NA];
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
       }
     }
   };
+  float amax = 0.f;                            // largest |activation| this thread has split
   auto store_a = [&](int stage, const f32x4 (&av)[NA], int staged_lim) __attribute__((always_inline)) {
     unsigned char *As = smem + stage * STAGE;
 #pragma unroll
@@ -146,45 +147,42 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
       if (!a_on[h]) continue;
       const f32x4 x0 = av[h];
       const f32x4 x = f32x4{staged_lim > 0 ? x0[0] : 0.f, staged_lim > 1 ? x0[1] : 0.f, staged_lim > 2 ? x0[2] : 0.f, staged_lim > 3 ? x0[3] : 0.f};
-      const bf16x4 p1 = __builtin_convertvector(x, bf16x4);
-      const f32x4 r1 = x - __builtin_convertvector(p1, f32x4);
-      const bf16x4 p2 = __builtin_convertvector(r1, bf16x4);
-      const f32x4 r2 = r1 - __builtin_convertvector(p2, f32x4);
-      const bf16x4 p3 = __builtin_convertvector(r2, bf16x4);
-      *reinterpret_cast<bf16x4 *>(As + a_lds[h]) = p1;
-      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
-      *reinterpret_cast<bf16x4 *>(As + a_lds[h] + 2 * RT * kB3FragBytes) = p3;
+      f16x4 p1, p2;
+      amax = fmaxf(amax, Split2(x, &p1, &p2));
+      *reinterpret_cast<f16x4 *>(As + a_lds[h]) = p1;
+      *reinterpret_cast<f16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
     }
   };
-  // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3
-  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3) + (size_t)(n0 / 32 + wn * 2) * 3 * kB3FragBytes + lane * 16;
-  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
-  auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+  // weights: k-step t, this wave's 2 column tiles x 2 parts = 4 consecutive KiB of W3
+  constexpr int P = kB3Parts;
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3) + (size_t)(n0 / 32 + wn * 2) * P * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * P * kB3FragBytes;
+  auto load_b = [&](f16x8 (&bf)[2][P]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int p = 0; p < 3; p++) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
+      for (int p = 0; p < P; p++) bf[j][p] = *reinterpret_cast<const f16x8 *>(wsrc + (j * P + p) * kB3FragBytes);
     wsrc += wstep;
   };
-  // One k-step of MFMAs.  Activation fragments are transient (read, used, dropped): part 3 meets weight part 1, part 2
-  // meets parts 2 and 1, part 1 meets all three -- smallest terms first for every accumulator.
-  auto step = [&](int t, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+  // One k-step of MFMAs.  Activation fragments are transient (read, used, dropped): the low part meets the weights' high
+  // part, the high part meets both -- smallest terms first for every accumulator.
+  auto step = [&](int t, const f16x8 (&bf)[2][P]) __attribute__((always_inline)) {
     const unsigned char *As = smem + (t & 1) * STAGE + lane * 16;
     // fragment reads run one fragment ahead of the MFMAs that use them
-    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(As + (2 * RT + wm * MR) * kB3FragBytes), nxt = cur;
+    f16x8 cur = *reinterpret_cast<const f16x8 *>(As + ((P - 1) * RT + wm * MR) * kB3FragBytes), nxt = cur;
 #pragma unroll
-    for (int idx = 0; idx < 3 * MR; idx++) {
-      const int pa = 2 - idx / MR, i = idx % MR;
-      if (idx + 1 < 3 * MR) {
-        const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
-        nxt = *reinterpret_cast<const bf16x8 *>(As + (pa2 * RT + wm * MR + i2) * kB3FragBytes);
+    for (int idx = 0; idx < P * MR; idx++) {
+      const int pa = P - 1 - idx / MR, i = idx % MR;
+      if (idx + 1 < P * MR) {
+        const int pa2 = P - 1 - (idx + 1) / MR, i2 = (idx + 1) % MR;
+        nxt = *reinterpret_cast<const f16x8 *>(As + (pa2 * RT + wm * MR + i2) * kB3FragBytes);
       }
       if (!MIXED || i < mr_eff) {
 #pragma unroll
-        for (int pb = 2; pb >= 0; pb--) {
-          if (pb > 2 - pa) continue;
+        for (int pb = P - 1; pb >= 0; pb--) {
+          if (pb > P - 1 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
         }
       }
       cur = nxt;
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   // A lone workgroup on a CU (the last, partly filled round of a launch) then still has two full steps of latency cover.
   // The requests run unconditionally: past the end they re-read the last activations (never stored) and two padding
   // k-steps of W3 (never multiplied).
-  bf16x8 b0[2][3], b1[2][3], b2[2][3];
+  f16x8 b0[2][P], b1[2][P], b2[2][P];
   if (nt == 0) return;
   enter_segment();
   load_b(b0);
@@ -223,13 +221,14 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
+  if (amax >= kB3Overflow) *d.ovf = 1;
 #include "nnet_b3_epilogue.inc"
 }
 
 template <int MR, bool MIXED, int WM>
 void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStream_t s) {
   constexpr int BM = 32 * MR * WM;
-  constexpr size_t stage = 2 * (size_t)(MR * WM * 3 * kB3FragBytes), ctile = kB3EpiBytes;
+  constexpr size_t stage = 2 * (size_t)(MR * WM * kB3Parts * kB3FragBytes), ctile = kB3EpiBytes;
   // WM = 2 asks for all but 1 KiB of the CU's LDS: no other workgroup fits beside it
   constexpr size_t smem = WM == 1 ? (stage > ctile ? stage : ctile) : (size_t)159 * 1024;
   static bool attr_set = false;

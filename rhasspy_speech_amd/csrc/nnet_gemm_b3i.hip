@@ -1,14 +1,14 @@
 // The TDNN layer GEMM of nnet_gemm_b3.hip for sources that already exist as operand images (kernels.h: ActImage): the
-// producing layer's epilogue stored its result split into the three bf16 parts, in A-fragment order, so the consumer's
+// producing layer's epilogue stored its result split into the two fp16 parts, in A-fragment order, so the consumer's
 // K-loop has no FP32 loads, no splitting and no LDS writes of its own left -- what nnet_gemm_b3.hip spends about half of
 // its loop on (profiles/r01: matrix cores 42 % busy; VALU split + ds_write + a barrier per 16-wide k-step).
 //
-// Same arithmetic (six v_mfma_f32_32x32x16_bf16 per product, smallest terms first, FP32 accumulation) and the same tile:
+// Same arithmetic (three v_mfma_f32_32x32x16_f16 per product, smallest terms first, FP32 accumulation) and the same tile:
 // (32 MR) x 256 per workgroup, four waves side by side, each (32 MR) x 64.  Per 16-wide k-step:
-//   activations: 3 MR fragments of 1 KiB, copied verbatim from the image into LDS by global_load_lds_dwordx4 (the image
+//   activations: 2 MR fragments of 1 KiB, copied verbatim from the image into LDS by global_load_lds_dwordx4 (the image
 //                block IS the fragment: lane l supplies the address of row l & 31, k-group l >> 5, so row-shifted TDNN
 //                segments and row maps cost nothing but address arithmetic); wave w stages row tile w;
-//   weights:     as before, six fragments per wave straight into registers, three register sets rotating;
+//   weights:     as before, four fragments per wave straight into registers, three register sets rotating;
 //   reads:       conflict-free ds_read_b128 at 16 x lane per fragment.
 // Two k-steps form one LDS stage (BK = 32): one barrier per 32 of K instead of per 16; two stages, the DMA of stage t + 1
 // runs during the MFMAs of stage t.
@@ -49,7 +49,7 @@ constexpr int kKPS = 2;                               // k-steps per LDS stage (
 template <int MR, bool MIXED, int KPS = kKPS>
 __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int nbig, int epi_mode) {
   constexpr int BM = 32 * MR, BN = kB3BN;
-  constexpr int KSTEP_BYTES = MR * 3 * kB3FragBytes, STAGE = KPS * KSTEP_BYTES;
+  constexpr int P = kB3Parts, KSTEP_BYTES = MR * P * kB3FragBytes, STAGE = KPS * KSTEP_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave;                               // 64-column slice; also the row tile this wave stages
@@ -89,14 +89,14 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   const unsigned char *img_base = d.segs[0].img.base;
   size_t part_bytes = d.segs[0].img.part_bytes;
   int img_nks = d.segs[0].img.nks, img_guard = d.segs[0].img.guard;
-  auto stage_kstep = [&](unsigned char *dst) __attribute__((always_inline)) {     // dst: this k-step's 3 MR KiB in LDS
+  auto stage_kstep = [&](unsigned char *dst) __attribute__((always_inline)) {     // dst: this k-step's 2 MR KiB in LDS
     if (stager) {
       const int phys = grow + __builtin_amdgcn_readlane(seg_rowoff_v, seg) + img_guard;
       const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ((RS_B3I_ABLATE & 2) ? 0 : ks))) * kB3FragBytes +
                                  kg_off + (phys & 31) * 16;
       if (!(RS_B3I_ABLATE & 8))
 #pragma unroll
-      for (int p = 0; p < 3; p++)
+      for (int p = 0; p < P; p++)
         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + p * part_bytes),
                                          (void __attribute__((address_space(3))) *)(dst + (p * MR + wave) * kB3FragBytes), 16, 0, 0);
     }
@@ -112,36 +112,36 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
       }
     }
   };
-  // weights: k-step t, this wave's 2 column tiles x 3 parts = 6 consecutive KiB of W3I
-  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wn * 2) * 3 * kB3FragBytes + lane * 16;
-  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
-  auto load_b = [&](bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+  // weights: k-step t, this wave's 2 column tiles x 2 parts = 4 consecutive KiB of W3I
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wn * 2) * P * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * P * kB3FragBytes;
+  auto load_b = [&](f16x8 (&bf)[2][P]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int p = 0; p < 3; p++) {
-        if (RS_B3I_ABLATE & 8) { if (wsrc == nullptr) bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes); }
-        else bf[j][p] = *reinterpret_cast<const bf16x8 *>(wsrc + (j * 3 + p) * kB3FragBytes);
+      for (int p = 0; p < P; p++) {
+        if (RS_B3I_ABLATE & 8) { if (wsrc == nullptr) bf[j][p] = *reinterpret_cast<const f16x8 *>(wsrc + (j * P + p) * kB3FragBytes); }
+        else bf[j][p] = *reinterpret_cast<const f16x8 *>(wsrc + (j * P + p) * kB3FragBytes);
       }
     if (!(RS_B3I_ABLATE & 1)) wsrc += wstep;
   };
   // one k-step of MFMAs from the fragments at `As` (this k-step's image in LDS)
-  auto step = [&](const unsigned char *As, const bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
+  auto step = [&](const unsigned char *As, const f16x8 (&bf)[2][P]) __attribute__((always_inline)) {
     const unsigned char *Al = As + lane * 16;
-    bf16x8 cur = *reinterpret_cast<const bf16x8 *>(Al + (2 * MR) * kB3FragBytes), nxt = cur;
+    f16x8 cur = *reinterpret_cast<const f16x8 *>(Al + ((P - 1) * MR) * kB3FragBytes), nxt = cur;
 #pragma unroll
-    for (int idx = 0; idx < 3 * MR; idx++) {
-      const int pa = 2 - idx / MR, i = idx % MR;
-      if (idx + 1 < 3 * MR) {
-        const int pa2 = 2 - (idx + 1) / MR, i2 = (idx + 1) % MR;
-        nxt = *reinterpret_cast<const bf16x8 *>(Al + (pa2 * MR + i2) * kB3FragBytes);
+    for (int idx = 0; idx < P * MR; idx++) {
+      const int pa = P - 1 - idx / MR, i = idx % MR;
+      if (idx + 1 < P * MR) {
+        const int pa2 = P - 1 - (idx + 1) / MR, i2 = (idx + 1) % MR;
+        nxt = *reinterpret_cast<const f16x8 *>(Al + (pa2 * MR + i2) * kB3FragBytes);
       }
-      if ((RS_B3I_ABLATE & 4) ? (lane == 99 && cur[0] == 12345) : (!MIXED || i < mr_eff)) {
+      if ((RS_B3I_ABLATE & 4) ? (lane == 99 && cur[0] == (_Float16)12345.f) : (!MIXED || i < mr_eff)) {
 #pragma unroll
-        for (int pb = 2; pb >= 0; pb--) {
-          if (pb > 2 - pa) continue;
+        for (int pb = P - 1; pb >= 0; pb--) {
+          if (pb > P - 1 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
         }
       }
       cur = nxt;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
   if (nt == 0) return;
   // ---- pipeline: LDS stage s holds k-steps 2 s, 2 s + 1; weights rotate over three register sets two k-steps ahead
   const int nstage = (nt + KPS - 1) / KPS;
-  bf16x8 b0[2][3], b1[2][3], b2[2][3];
+  f16x8 b0[2][P], b1[2][P], b2[2][P];
   load_b(b0);
   load_b(b1);
 #pragma unroll
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void GemmKernelB3I(GemmDev d, int rows, int
 template <int MR, bool MIXED, int KPS = kKPS>
 void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
   constexpr int BM = 32 * MR;
-  constexpr size_t stage = 2 * (size_t)KPS * MR * 3 * kB3FragBytes, ctile = kB3EpiBytes;
+  constexpr size_t stage = 2 * (size_t)KPS * MR * kB3Parts * kB3FragBytes, ctile = kB3EpiBytes;
   constexpr size_t smem = stage > ctile ? stage : ctile;
   static bool attr_set = false;
   if (!attr_set) {
@@ -213,8 +213,8 @@ void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
   hipLaunchKernelGGL((GemmKernelB3I<MR, MIXED, KPS>), dim3(blocks), dim3(256), smem, s, d, rows, nbig, GemmEpiMode(d, rows));
 }
 
-// f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, all three parts
-__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int nblocks) {
+// f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, both parts
+__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int nblocks, int *ovf) {
   const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= nblocks) return;
   const int rb = blk / img.nks, ks = blk % img.nks;
@@ -226,12 +226,11 @@ __global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ s
     lo[e] = col + e < dim ? src[(size_t)row * ld + col + e] : 0.f;
     hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
   }
-  bf16x8 p1, p2, p3;
-  Split3(lo, hi, &p1, &p2, &p3);
+  f16x8 p1, p2;
+  if (Split2(lo, hi, &p1, &p2) >= kB3Overflow) *ovf = 1;
   unsigned char *dst = img.base + (size_t)blk * kB3FragBytes + lane * 16;
-  *reinterpret_cast<bf16x8 *>(dst) = p1;
-  *reinterpret_cast<bf16x8 *>(dst + img.part_bytes) = p2;
-  *reinterpret_cast<bf16x8 *>(dst + 2 * img.part_bytes) = p3;
+  *reinterpret_cast<f16x8 *>(dst) = p1;
+  *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
 }
 
 }  // namespace
@@ -241,11 +240,11 @@ size_t ActImagePartBytes(int rows, int guard, int dim) {
   return row_blocks * (size_t)((dim + 15) / 16) * b3::kB3FragBytes;
 }
 
-void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, hipStream_t s) {
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s) {
   const int row_blocks = (rows + img.guard + 31) / 32 + 1;
   const int nblocks = row_blocks * img.nks;
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(ToImageKernel, dim3((nblocks + 3) / 4), dim3(256), 0, s, src, ld, dim, rows, img, nblocks);
+  hipLaunchKernelGGL(ToImageKernel, dim3((nblocks + 3) / 4), dim3(256), 0, s, src, ld, dim, rows, img, nblocks, ovf);
 }
 
 bool GemmImagesEnabled() {

@@ -13,10 +13,11 @@
 //     they release as operands (the MFMAs that use them cannot be scheduled above the wait);
 //   * one `s_waitcnt vmcnt(N)` per k-step leaves the DMAs of the k-steps ahead in flight.
 // Two shapes (template parameter WM = wave rows of four waves):
-//   WM = 1 (default): 128 x 256 tile, four waves, ring of two k-step stages (12 KiB activations + 24 KiB weights each, 72 KiB),
-//     two workgroups per CU -- one's epilogue and pipeline fill hide behind the other's loop; the DMA runs one k-step ahead.
+//   WM = 1 (default): 128 x 256 tile, four waves, ring of three k-step stages (8 KiB activations + 16 KiB weights each, 72 KiB),
+//     two workgroups per CU -- one's epilogue and pipeline fill hide behind the other's loop; the DMA runs two k-steps ahead
+//     with counted vmcnt waits (rounds 2-3, three bf16 parts: 36 KiB per stage, two stages, one k-step ahead).
 //   WM = 2 (RS_GEMM_B3J_WM=2): 256 x 256 tile, eight waves, the two wave rows share the weight fragments (half the L2 weight
-//     stream per row), ring of three stages (144 KiB), one workgroup per CU, DMA two k-steps ahead with counted vmcnt waits.
+//     stream per row), ring of three stages (96 KiB), one workgroup per CU, DMA two k-steps ahead with counted vmcnt waits.
 //     Measured slower (232 vs 179 us per hidden layer): with one workgroup per CU nothing hides a tile's epilogue -- all CUs
 //     write their 129 MB of output at the same moment -- nor its pipeline fill (profiles/r02/b3j_wm2_ablate.txt).
 // Rows that do not fill whole rounds of full-height tiles run as half-height tiles of the same launch.
@@ -39,16 +40,20 @@ namespace {
 using namespace b3;
 
 constexpr int kJMR = 4, kJColTiles = 8;                                 // 32-row blocks per wave; 32-column tiles per tile
-constexpr int kJBBytes = kJColTiles * 3 * kB3FragBytes;                 // 24 KiB: [column tile][part] fragments
-// WM wave rows of four waves each: WM = 2 -> 256-row tile, 512 threads, three stages (144 KiB, one workgroup per CU);
-// WM = 1 -> 128-row tile, 256 threads, two stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop)
+constexpr int kJP = kB3Parts;
+constexpr int kJBBytes = kJColTiles * kJP * kB3FragBytes;               // 16 KiB: [column tile][part] fragments
+// WM wave rows of four waves each: WM = 2 -> 256-row tile, 512 threads, three stages (96 KiB, one workgroup per CU);
+// WM = 1 -> 128-row tile, 256 threads, three stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop)
 template <int WM> struct JShape {
   static constexpr int kThreads = 256 * WM, kWaves = 4 * WM, kRowBlocks = 4 * WM;
-  static constexpr int kABytes = kRowBlocks * 3 * kB3FragBytes;           // [part][row block] fragments
+  static constexpr int kABytes = kRowBlocks * kJP * kB3FragBytes;         // [part][row block] fragments
   static constexpr int kStage = kABytes + kJBBytes;
-  static constexpr int kStages = WM == 2 ? 3 : 2, kAhead = kStages - 1;
+#ifndef RS_B3J_STAGES
+#define RS_B3J_STAGES 3
+#endif
+  static constexpr int kStages = RS_B3J_STAGES, kAhead = kStages - 1;
   static constexpr int kColTilesPerWave = kJColTiles / kWaves;             // weight column tiles a wave stages
-  static constexpr int kDmaPerKstep = 3 + 3 * kColTilesPerWave;            // per staging wave and k-step
+  static constexpr int kDmaPerKstep = kJP + kJP * kColTilesPerWave;        // per staging wave and k-step
 };
 
 // Timing ablations (results WRONG with a bit set): 512 = weight DMAs of different workgroups ask for different k-steps, 1024 = no weight DMA, 2048 = no activation DMA, 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   __asm__ volatile("" : "+v"(grow), "+v"(seg_rowoff_v), "+v"(seg_ks0_v), "+v"(seg_nks_v), "+v"(seg_base_lo), "+v"(seg_base_hi), "+v"(seg_part_lo),
                    "+v"(seg_part_hi), "+v"(seg_inks_v), "+v"(seg_guard_v));
   constexpr int CTW = SH::kColTilesPerWave;
-  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wave * CTW) * 3 * kB3FragBytes + lane * 16;
-  const size_t wstep = (size_t)(d.n3 / 32) * 3 * kB3FragBytes;
+  const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wave * CTW) * kJP * kB3FragBytes + lane * 16;
+  const size_t wstep = (size_t)(d.n3 / 32) * kJP * kB3FragBytes;
   const bool wtile_ok = n0 / 32 + wave * CTW + CTW <= d.n3 / 32;     // (tiles past the padded width: their columns are dropped in the epilogue)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto stage_kstep = [&](unsigned soff) __attribute__((always_inline)) {     // soff: byte offset of this k-step's stage in LDS
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       const unsigned char *src = img_base + ((size_t)(phys >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ks)) * kB3FragBytes +
                                  kg_off + (phys & 31) * 16;
 #pragma unroll
-      for (int p = 0; p < 3; p++) {
+      for (int p = 0; p < kJP; p++) {
         const unsigned char *g = src + p * part_bytes;
         RS_DMA16_STREAM(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
       }
@@ -193,9 +198,9 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         ws = reinterpret_cast<const unsigned char *>(d.W3I) + off % ((size_t)nt * wstep);
       }
 #pragma unroll
-      for (int p = 0; p < 3 * CTW; p++) {
+      for (int p = 0; p < kJP * CTW; p++) {
         const unsigned char *g = ws + p * kB3FragBytes;
-        RS_DMA16(dst + (unsigned)(kJABytes + (wave * 3 * CTW + p) * kB3FragBytes), g);
+        RS_DMA16(dst + (unsigned)(kJABytes + (wave * kJP * CTW + p) * kB3FragBytes), g);
       }
       wsrc += wstep;
     }
@@ -207,43 +212,41 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     }
   };
   // ---- one k-step of MFMAs from stage `sbase` (LDS byte address of the stage)
-  const unsigned a_lane = lds0 + (unsigned)(wm * mr_eff) * kB3FragBytes + lane * 16;          // + stage; + (part * 8 + i) KiB
-  const unsigned b_lane = lds0 + kJABytes + (unsigned)(wn * 2) * 3 * kB3FragBytes + lane * 16;      // + stage; + (j * 3 + part) KiB
+  const unsigned a_lane = lds0 + (unsigned)(wm * mr_eff) * kB3FragBytes + lane * 16;          // + stage; + (part * row blocks + i) KiB
+  const unsigned b_lane = lds0 + kJABytes + (unsigned)(wn * 2) * kJP * kB3FragBytes + lane * 16;    // + stage; + (j * parts + part) KiB
   auto step = [&](unsigned soff) __attribute__((always_inline)) {
     const unsigned aa = a_lane + soff, ba = b_lane + soff;
-    bf16x8 bf[2][3];
-    RS_DS_READ(bf[0][0], ba, 0 * 1024); RS_DS_READ(bf[0][1], ba, 1 * 1024); RS_DS_READ(bf[0][2], ba, 2 * 1024);
-    RS_DS_READ(bf[1][0], ba, 3 * 1024); RS_DS_READ(bf[1][1], ba, 4 * 1024); RS_DS_READ(bf[1][2], ba, 5 * 1024);
-    bf16x8 af[3][MR];
-    // activation fragments in the order they are used: smallest part first (pa = 2, 1, 0), row blocks inside
+    f16x8 bf[2][kJP];
+    RS_DS_READ(bf[0][0], ba, 0 * 1024); RS_DS_READ(bf[1][0], ba, 2 * 1024);
+    f16x8 af[kJP][MR];
+    // activation fragments in the order they are used: low part first (pa = 1, 0), row blocks inside
 #define RS_A_READ(PA, I) RS_DS_READ(af[PA][I], aa, ((PA) * kJRowBlocks + (I)) * 1024)
-    RS_A_READ(2, 0);
-    RS_A_READ(2, 1);
-    __asm__ volatile("s_waitcnt lgkmcnt(1)" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(af[2][0]));
+    RS_A_READ(1, 0);
+    RS_A_READ(1, 1);
+    RS_DS_READ(bf[0][1], ba, 1 * 1024); RS_DS_READ(bf[1][1], ba, 3 * 1024);
+    __asm__ volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[0][0]), "+v"(bf[1][0]), "+v"(af[1][0]));
 #define RS_MFMAS(PA, I)                                                                                       \
     if ((RS_B3J_ABLATE & 4) ? false : (!MIXED || (I) < mr_eff)) {                                             \
-      _Pragma("unroll") for (int pb = 2; pb >= 0; pb--) {                                                     \
-        if (pb > 2 - (PA)) continue;                                                                          \
+      _Pragma("unroll") for (int pb = kJP - 1; pb >= 0; pb--) {                                               \
+        if (pb > kJP - 1 - (PA)) continue;                                                                    \
         _Pragma("unroll") for (int j = 0; j < 2; j++)                                                         \
-          acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][pb], af[PA][I], acc[I][j], 0, 0, 0);      \
+          acc[I][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pb], af[PA][I], acc[I][j], 0, 0, 0);       \
       }                                                                                                       \
     }
-    // software pipeline over the 12 fragments: the read of fragment n + 2 is issued before the MFMAs of fragment n; the wait
-    // in front of fragment n + 1 leaves one read in flight
-#define RS_STEP(PA, I, PA1, I1, PA2, I2)                                                                      \
+    // software pipeline over the 8 fragments: the read of fragment n + 2 is issued before the MFMAs of fragment n; the wait
+    // in front of fragment n + 1 leaves one read in flight (the weights' low parts, first needed by fragment (0, 0), arrive behind
+    // the first two activation fragments)
+#define RS_STEP(PA, I, PA1, I1, PA2, I2, N)                                                                   \
     RS_A_READ(PA2, I2);                                                                                       \
     RS_MFMAS(PA, I)                                                                                           \
-    __asm__ volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[PA1][I1]));
-    RS_STEP(2, 0, 2, 1, 2, 2)
-    RS_STEP(2, 1, 2, 2, 2, 3)
-    RS_STEP(2, 2, 2, 3, 1, 0)
-    RS_STEP(2, 3, 1, 0, 1, 1)
-    RS_STEP(1, 0, 1, 1, 1, 2)
-    RS_STEP(1, 1, 1, 2, 1, 3)
-    RS_STEP(1, 2, 1, 3, 0, 0)
-    RS_STEP(1, 3, 0, 0, 0, 1)
-    RS_STEP(0, 0, 0, 1, 0, 2)
-    RS_STEP(0, 1, 0, 2, 0, 3)
+    __asm__ volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(af[PA1][I1]));
+    RS_STEP(1, 0, 1, 1, 1, 2, 3)          // still in flight behind (1, 1): the weights' two low parts and (1, 2)
+    RS_STEP(1, 1, 1, 2, 1, 3, 1)
+    __asm__ volatile("" : "+v"(bf[0][1]), "+v"(bf[1][1]));          // (that wait covered them too)
+    RS_STEP(1, 2, 1, 3, 0, 0, 1)
+    RS_STEP(1, 3, 0, 0, 0, 1, 1)
+    RS_STEP(0, 0, 0, 1, 0, 2, 1)
+    RS_STEP(0, 1, 0, 2, 0, 3, 1)
     RS_MFMAS(0, 2)
     __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][3]));
     RS_MFMAS(0, 3)
@@ -253,11 +256,11 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   };
   // ---- pipeline: DMA of k-step t + 2 is issued in k-step t (after the barrier that says everybody is done with k-step t - 1,
   // whose stage it overwrites); before it, this wave waits for its own DMAs of k-step t, leaving those of k-step t + 1 in flight
-  // (with two stages the DMA runs one k-step ahead and the wait is for everything this wave has in flight)
+  // (-DRS_B3J_STAGES=2: the DMA runs one k-step ahead and the wait is for everything this wave has in flight)
   stage_kstep(0u);
   if (kJAhead > 1 && nt > 1) stage_kstep((unsigned)kJStage);
   int t = 0;
-  constexpr int kOwn = SH::kDmaPerKstep, kOther = 3 * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
+  constexpr int kOwn = SH::kDmaPerKstep, kOther = kJP * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
 #define RS_VMWAIT(N) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
 #define RS_WAIT_OWN()                                                                                          \
   if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn * (kJAhead - 1)); else RS_VMWAIT(kOther * (kJAhead - 1)); } \
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   {
     constexpr int C_LD = BN + 4, NT = kJThreads;
     float *Cs = reinterpret_cast<float *>(smem);
-    float *eb = Cs + 32 * C_LD;                   // [3][BN]: bias, scale, offset of the tile's columns
+    float *eb = Cs + 32 * C_LD;                   // [4][BN]: bias, scale, offset of the tile's columns; inverse of the weight image's column scale
     const int half = lane >> 5;
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
@@ -313,13 +316,16 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       eb[c] = (d.bias && cok) ? d.bias[col] : 0.f;
       eb[BN + c] = (epi_mode == 2 && cok) ? d.stages[1].scale[col] : 1.f;
       eb[2 * BN + c] = (epi_mode == 2 && cok) ? d.stages[1].offset[col] : 0.f;
+      eb[3 * BN + c] = cok ? d.w3_inv_scale[col] : 0.f;
     }
+    float xmax = 0.f;                              // largest |value| this thread split into fp16 parts
     dd::LdsBarrier();
     // the fused stages on four consecutive columns (tile-local column CL0 .. CL0 + 3) of one row
 #define RS_EPI4(V, CL0)                                                                                        \
     {                                                                                                            \
       const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&eb[(CL0)]);                                             \
-      _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = __fadd_rn(b4[e], V[e]);                             \
+      const f32x4 w4 = *reinterpret_cast<const f32x4 *>(&eb[3 * BN + (CL0)]);                                    \
+      _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = __fadd_rn(b4[e], __fmul_rn(V[e], w4[e]));           \
       if (epi_mode == 1 || epi_mode == 2) {                                                                      \
         _Pragma("unroll") for (int e = 0; e < 4; e++) V[e] = V[e] > 0.f ? V[e] : 0.f;                          \
       }                                                                                                          \
@@ -366,18 +372,18 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
           if (rok[I] && (col >> 4) < d.out_img.nks) {                                                            \
             f32x4 lo = q[2 * ksi], hi = q[2 * ksi + 1];                                                          \
             _Pragma("unroll") for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
-            bf16x8 p1, p2, p3;                                                                                   \
-            Split3(lo, hi, &p1, &p2, &p3);                                                                       \
+            f16x8 p1, p2;                                                                                        \
+            xmax = fmaxf(xmax, Split2(lo, hi, &p1, &p2));                                                        \
             unsigned char *dst = d.out_img.base + ((size_t)(phys[I] >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (phys[I] & 31) * 16; \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst), p1);                                                   \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes), p2);                            \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes), p3);                        \
+            RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst), p1);                                                    \
+            RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst + d.out_img.part_bytes), p2);                             \
           }                                                                                                      \
         }                                                                                                        \
       }
       RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
       RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
 #undef RS_DIRECT
+      if (xmax >= kB3Overflow) *d.ovf = 1;
 #ifdef RS_B3J_TRACE
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -444,16 +450,15 @@ _Pragma("unroll") \
             f32x4 hi = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + ksi * 16 + kg * 8 + 4]); \
 _Pragma("unroll") \
             for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
-            bf16x8 p1, p2, p3; \
-            Split3(lo, hi, &p1, &p2, &p3); \
+            f16x8 p1, p2; \
+            xmax = fmaxf(xmax, Split2(lo, hi, &p1, &p2)); \
             const int phys = img_phys[(SL)]; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
-            if ((RS_B3J_ABLATE & 128) && p1[0] != (__bf16)12345.f) dst = nullptr; \
+            if ((RS_B3J_ABLATE & 128) && p1[0] != (_Float16)12345.f) dst = nullptr; \
             if (RS_B3J_ABLATE & 256) dst = d.out_img.base + ((size_t)(dst - d.out_img.base) & 0xFFFFFu); \
             if (dst) { \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst), p1); \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + d.out_img.part_bytes), p2); \
-            RS_IMG_STORE(reinterpret_cast<bf16x8 *>(dst + 2 * d.out_img.part_bytes), p3); } \
+            RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst), p1); \
+            RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst + d.out_img.part_bytes), p2); } \
           } \
         } \
       } \
@@ -464,6 +469,7 @@ _Pragma("unroll") \
 #undef RS_SLAB
 #undef RS_PUT_SLAB
 #undef RS_EPI4
+    if (xmax >= kB3Overflow) *d.ovf = 1;
   }
 }
 

@@ -184,6 +184,9 @@ StreamPool *Model::Pool() {
   p->free_rows[0] = p->rows;
   std::unique_ptr<DecodeContext> c(new DecodeContext());
   c->stream = p->q;
+  RS_HIP(hipHostMalloc((void **)&c->gemm_ovf, 64, hipHostMallocMapped));
+  *c->gemm_ovf = 0;
+  RS_HIP(hipHostGetDevicePointer((void **)&c->gemm_ovf_dev, c->gemm_ovf, 0));
   stream_ctx_ = std::move(c);
   p->cx = stream_ctx_.get();
   RS_HIP(hipStreamSynchronize(p->q));
@@ -204,6 +207,16 @@ void Model::StreamsDrain(StreamPool *p, float *extra) {
   }
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+  StreamsCheckRange();
+}
+
+// An advance cannot be repeated (its rows are written, the chunk schedule has moved on): when a layer GEMM met an activation
+// the fp16 split cannot carry, the model changes to the exact-FP32 kernels for everything that follows and this call fails.
+void Model::StreamsCheckRange() {
+  DecodeContext *cx = stream_ctx_.get();
+  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0 && !exact_gemm_.exchange(true))
+    Fail("an activation exceeded the range of the split-fp16 layer GEMMs (|x| >= 65520) during a stream advance; the model now uses the "
+         "exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");
 }
 
 void Model::StreamOpen(rs_stream *st) {
@@ -279,7 +292,9 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     p->Account(par, nullptr);
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+    StreamsCheckRange();
   }
+  SampleGemmMode(exact_gemm_.load(), cx.gemm_ovf_dev);
   const Nnet &nn = am_.nnet;
   const bool has_iv = fc_.ie.present;
   const int C = fc_.mfcc.nceps, P = nn.output_dim, chunk = p->chunk, Rm = nn.right_context;
@@ -594,6 +609,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->pending[par] = false;
     p->Account(par, own);
+    StreamsCheckRange();
   }
   // ---------------------------------------------------------------- results
   res->utts.resize(n);
