@@ -147,8 +147,8 @@ void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &
 constexpr int kActImageParts = 2;
 size_t ActImagePartBytes(int rows, int guard, int dim);      // bytes of one part for a buffer of `rows` rows
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
-// The split-fp16 kernels work on 256-column tiles: a layer takes them only while the padding stays below this share of the
-// padded width (above it the exact-FP32 kernel with its 128-column tiles wins).  RS_GEMM_B3_PAD overrides (percent).
+// The split-fp16 kernels work on 256-column tiles: a layer takes them only while the padding stays below a share of the
+// padded width (45 %; above it the exact-FP32 kernel with its 128-column tiles wins).  RS_GEMM_B3_PAD overrides (percent).
 bool GemmB3PaddingOk(int n, int n3);
 bool GemmWritesImage(const GemmDev &d);      // the kernel LaunchGemm picks writes d.out_img (else: LaunchToImage afterwards)
 bool GemmImagesEnabled();                     // RS_GEMM_B3I / RS_GEMM_B3 (read per call)

@@ -1,47 +1,74 @@
 """Transcript post-processing shared by both transcribers.
 
-`decode_meta` mirrors rhasspy_speech/hassil_fst.py:849-872: words of the form `__output:<BASE32>` carry a JSON
-object {"text": ..., "list": ...} (slot value / list name), and `__sentence_output:<BASE32>` carries a Python
-format string filled from the collected slots.  `int2sym` replaces the reference's extra
+`decode_meta` gives the results of rhasspy_speech/hassil_fst.py:849-872 (written from the format, checked against
+tests/golden/python_api.json): words of the form `__output:<BASE32>` carry a JSON object {"text": ..., "list": ...}
+(slot value / list name), and `__sentence_output:<BASE32>` carries a Python format string filled from the collected slots.  `int2sym` replaces the reference's extra
 `utils/int2sym.pl -f 2- words.txt` subprocess (transcribe_wav.py:77-85).
 """
 from __future__ import annotations
 
 import base64
 import json
-import re
 from pathlib import Path
-from typing import Dict, List, Sequence, Union
+from typing import Dict, Iterator, List, Tuple, Union
 
 OUTPUT_PREFIX = "__output:"
 SENTENCE_OUTPUT = "__sentence_output:"
 
 
+# Characters a payload may consist of: the RFC 4648 base32 alphabet is A-Z 2-7 with '=' padding; like the reference's pattern
+# (hassil_fst.py:861,866) every digit is accepted, so that a malformed payload fails in the decoder rather than being cut short.
+_PAYLOAD_CHARS = frozenset("ABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789=")
+
+
+def _payloads(text: str, marker: str) -> Iterator[Tuple[int, int, str]]:
+    """(start, end, payload) of every `marker` + non-empty payload in `text`, left to right, non-overlapping."""
+    at = text.find(marker)
+    while at >= 0:
+        first = at + len(marker)
+        last = first
+        while last < len(text) and text[last] in _PAYLOAD_CHARS:
+            last += 1
+        if last > first:
+            yield at, last, text[first:last]
+            at = text.find(marker, last)
+        else:
+            at = text.find(marker, at + 1)
+
+
 def decode_meta_single(text: str) -> str:
-    return base64.b32decode(text.encode("utf-8")).strip().decode("utf-8")
+    """One base32 payload -> the UTF-8 string it carries (surrounding whitespace of the decoded bytes dropped)."""
+    raw = base64.b32decode(bytes(text, "utf-8"))
+    return raw.strip().decode("utf-8")
 
 
 def encode_meta(text: str, prefix: str = OUTPUT_PREFIX) -> str:
-    return prefix + (base64.b32encode(text.encode("utf-8")).strip().decode("utf-8"))
+    """The word the trainer puts on an output arc for `text` (hassil_fst.py:875-876): `prefix` + base32 of its UTF-8 bytes."""
+    return prefix + str(base64.b32encode(bytes(text, "utf-8")).strip(), "utf-8")
 
 
 def decode_meta(text: str) -> str:
+    """A transcript with meta words -> what the user sees (the reference's behaviour, hassil_fst.py:849-872).
+
+    Every `__output:<payload>` word is a JSON record {"text": value, "list": slot name or null}: it is replaced by its value,
+    and a named slot remembers it (the last one wins).  If a `__sentence_output:<payload>` word is present after that, the
+    whole transcript becomes its payload, a str.format template over the slot names; otherwise the substituted text is it."""
+    out: List[str] = []
     slots: Dict[str, str] = {}
-
-    def handle_match(m) -> str:
-        data = json.loads(decode_meta_single(m.group(1)))
-        slot_name = data.get("list")
-        slot_value = data["text"]
-        if slot_name:
-            slots[slot_name] = slot_value
-        return slot_value
-
-    text = re.sub(re.escape(OUTPUT_PREFIX) + "([0-9A-Z=]+)", handle_match, text)
-    match = re.search(re.escape(SENTENCE_OUTPUT) + "([0-9A-Z=]+)", text)
-    if match is None:
-        return text
-    sentence_output = decode_meta_single(match.group(1))
-    return sentence_output.format(**slots)
+    done = 0
+    for start, end, payload in _payloads(text, OUTPUT_PREFIX):
+        record = json.loads(decode_meta_single(payload))
+        value = record["text"]
+        if record.get("list"):
+            slots[record["list"]] = value
+        out.append(text[done:start])
+        out.append(value)
+        done = end
+    out.append(text[done:])
+    plain = "".join(out)
+    for _, _, payload in _payloads(plain, SENTENCE_OUTPUT):
+        return decode_meta_single(payload).format(**slots)
+    return plain
 
 
 def read_words_txt(path: Union[str, Path]) -> Dict[int, str]:

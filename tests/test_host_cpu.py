@@ -117,6 +117,23 @@ def test_python_layer_matches_reference_python():
     assert meta.decode_meta_single(g["encode_meta"]["output"].split(":", 1)[1]) == g["encode_meta"]["input"]
 
 
+def test_meta_words_decode_like_the_reference():
+    """200 random transcripts with `__output:` / `__sentence_output:` words (oracle/gen_meta_golden.py: the reference's own
+    decode_meta on each, including the ones it raises on: a template naming a slot the transcript did not fill)."""
+    from rhasspy_speech_amd import meta
+    g = json.loads((cases.GOLDEN / "meta_vectors.json").read_text())
+    assert len(g["decode_meta"]) == 200
+    for v in g["decode_meta"]:
+        if "raises" in v:
+            with pytest.raises(Exception) as ei:
+                meta.decode_meta(v["input"])
+            assert type(ei.value).__name__ == v["raises"], v
+        else:
+            assert meta.decode_meta(v["input"]) == v["output"], v
+    for v in g["encode_meta"]:
+        assert meta.encode_meta(v["input"]) == v["output"]
+
+
 def test_transcriber_signature_matches_reference():
     import inspect
     from rhasspy_speech_amd import KaldiNnet3WavTranscriber
