@@ -556,6 +556,12 @@ class Nnet3:
         return max(l, 0), max(r, 0)
 
     # ---- descriptor evaluation on the padded time axis (rows = t in [-halo, T + halo))
+    @staticmethod
+    def matmul(x: np.ndarray, wt: np.ndarray) -> np.ndarray:
+        """The layers' matrix products (FP32 BLAS, like the reference).  Tests that ask how far FP32 itself is from the exact
+        result replace this with a float64 product."""
+        return (x @ wt).astype(F32)
+
     def _shift(self, a: np.ndarray, o: int) -> np.ndarray:
         if o == 0:
             return a
@@ -633,9 +639,9 @@ class Nnet3:
             x = self._desc(kv["input"])
             f = c.fields
             if c.type in ("AffineComponent", "NaturalGradientAffineComponent", "FixedAffineComponent"):
-                out = (x @ np.asarray(f["<LinearParams>"], F32).T + np.asarray(f["<BiasParams>"], F32)[None, :]).astype(F32)
+                out = (self.matmul(x, np.asarray(f["<LinearParams>"], F32).T) + np.asarray(f["<BiasParams>"], F32)[None, :]).astype(F32)
             elif c.type == "LinearComponent":
-                out = (x @ np.asarray(f["<Params>"], F32).T).astype(F32)
+                out = self.matmul(x, np.asarray(f["<Params>"], F32).T)
             elif c.type == "TdnnComponent":
                 W = np.asarray(f["<LinearParams>"], F32)
                 b = np.asarray(f["<BiasParams>"], F32)
@@ -644,7 +650,7 @@ class Nnet3:
                 if b.size:
                     out += b[None, :]
                 for i, o in enumerate(np.asarray(f["<TimeOffsets>"])):
-                    out = (out + self._shift(x, int(o)) @ W[:, i * d:(i + 1) * d].T).astype(F32)
+                    out = (out + self.matmul(self._shift(x, int(o)), W[:, i * d:(i + 1) * d].T)).astype(F32)
             elif c.type == "RectifiedLinearComponent":
                 out = np.maximum(x, F32(0.0))
             elif c.type == "BatchNormComponent":

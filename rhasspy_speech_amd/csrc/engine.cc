@@ -664,6 +664,9 @@ std::string Model::Describe() const {
   if (pruned_from_) os << "output layer: pruned to the " << am_.nnet.output_dim << " of " << pruned_from_ << " pdfs that occur on HCLG arcs\n";
   os << "hclg: states=" << hclg_.num_states() << " arcs=" << hclg_.arcs.size() << " start=" << hclg_.start << "\n";
   os << "halo: L=" << L_ << " R=" << R_ << "\n";
+  // (state, not structure: calls repeated on the exact-FP32 layer GEMMs because an activation left the fp16 split's range, and
+  // whether the model has changed to those kernels for good)
+  os << "layer_gemm: range_retries=" << range_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0) << "\n";
   return os.str();
 }
 

@@ -176,6 +176,11 @@ class ModelSpec:
     # "mono" (N=1, P=0), "biphone" (N=2, P=1: every third phone has two pdf sets chosen by its left neighbour) or
     # "triphone" (N=3, P=1: additionally every third phone is split on its right neighbour)
     context: str = "mono"
+    # layer weights: "normal" = N(0, 1 / fan_in); "heavy" = Student t with 2 degrees of freedom / sqrt(fan_in), clipped to
+    # +-1000: rows with a few weights hundreds of times the typical one (the split-precision GEMMs scale every output column by
+    # its largest weight)
+    weight_dist: str = "normal"
+    hidden_gain: float = 1.0         # the second hidden layer's weights times this (activations beyond fp16's range for ~1e5)
     hmm_states: int = 1              # emitting states per phone (left-to-right; > 1 only with chain_topology = False, graphs by mkgraph)
 
     @property
@@ -436,6 +441,8 @@ def build_nnet(spec: ModelSpec, rng: np.random.Generator):
         cfg.append(f"input-node name=ivector dim={D}")
 
     def randw(o, i):
+        if spec.weight_dist == "heavy":
+            return np.clip(rng.standard_t(2.0, (o, i)) / math.sqrt(i), -1000.0, 1000.0).astype(np.float32)
         return (rng.standard_normal((o, i)) / math.sqrt(i)).astype(np.float32)
 
     def randb(o, s=0.1):
@@ -483,6 +490,8 @@ def build_nnet(spec: ModelSpec, rng: np.random.Generator):
             prev, prev_dim = f"tdnnf{li}.noop", H
             continue
         W, b = randw(H, prev_dim * len(offs)), randb(H)
+        if li == 2 and spec.hidden_gain != 1.0:
+            W = (W * np.float32(spec.hidden_gain)).astype(np.float32)
         comps.append((f"tdnn{li}.affine", lambda w, W=W, b=b: _w_affine(w, "NaturalGradientAffineComponent", W, b)))
         cfg.append(f"component-node name=tdnn{li}.affine component=tdnn{li}.affine input={_append_desc(prev, offs)}")
         comps.append((f"tdnn{li}.relu", lambda w, d=H: _w_nonlinear(w, "RectifiedLinearComponent", d)))

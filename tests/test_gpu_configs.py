@@ -379,8 +379,8 @@ def test_config4_64_streams_30s(zam_grammar):
     assert np.abs(batch.matrix(5, 2) - tr.loglikes).max() < LOGLIKE_TOL
 
 
-def test_split_bf16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
-    """The wide layers run on the bf16 matrix cores with every FP32 operand split into three bf16 parts (nnet_gemm_b3.hip).
+def test_split_fp16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
+    """The wide layers run on the fp16 matrix cores with every FP32 operand split into two fp16 parts (nnet_gemm_b3.hip).
     Same batch through that kernel and through the exact-FP32 MFMA kernel (RS_GEMM_B3=0): transcripts identical,
     log-likelihoods within half the 1e-4 bound (both are checked against the reference's values in test_gpu_parity)."""
     from rhasspy_speech_amd import _lib, synth
@@ -401,7 +401,7 @@ def test_split_bf16_gemm_matches_fp32_gemm(zam_grammar, monkeypatch):
 
 
 def test_image_sourced_gemm_is_bitwise_the_split_gemm(zam_grammar, monkeypatch):
-    """GemmKernelB3I (nnet_gemm_b3i.hip: the producing layer stored its result as bf16 operand images, the consumer copies
+    """GemmKernelB3I (nnet_gemm_b3i.hip: the producing layer stored its result as fp16 operand images, the consumer copies
     fragments) against GemmKernelB3 (FP32 sources split inside the K-loop): the same MFMAs on the same operands in the same
     order, so log-likelihoods must be equal bit for bit -- on a ragged batch (partial tiles, both tile heights)."""
     from rhasspy_speech_amd import _lib, synth

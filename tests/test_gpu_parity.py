@@ -372,8 +372,8 @@ def test_pruned_output_layer_gives_the_same_search(case_cache, name):
 @pytest.mark.parametrize("dims", [dict(hidden_dim=200, prefinal_dim=216, num_phones=100),       # n = 200/216/200: 256-column tile, padded
                                   dict(hidden_dim=328, prefinal_dim=250, num_phones=260),       # n = 328 (fp32 path), 520 pdfs (3 tiles)
                                   dict(hidden_dim=250, prefinal_dim=250, num_phones=1000, ivector_dim=0)])
-def test_split_bf16_gemm_odd_shapes_match_oracle(tmp_path, dims):
-    """Layer shapes around the split-bf16 kernel's tile edges (output widths that leave padding in the 256-column tile,
+def test_split_fp16_gemm_odd_shapes_match_oracle(tmp_path, dims):
+    """Layer shapes around the split-fp16 kernel's tile edges (output widths that leave padding in the 256-column tile,
     segment widths that are not multiples of the 16-wide k-step, a net without iVector input): log-likelihoods against the
     CPU oracle on a ragged batch, which also runs tiles with fewer than 64 live rows."""
     from oracle import pipeline
@@ -391,6 +391,81 @@ def test_split_bf16_gemm_odd_shapes_match_oracle(tmp_path, dims):
         diff = np.abs(res.matrix(i, 2) - tr.loglikes).max()
         assert diff < LOGLIKE_TOL, (dims, i, diff)
         assert res.words(i) == tr.nbest[0].words
+
+
+def test_split_fp16_gemm_is_as_close_to_exact_as_fp32_on_heavy_tailed_weights(tmp_path, monkeypatch):
+    """The layer GEMMs emulate FP32 with two fp16 parts per operand.  Weights drawn from a heavy-tailed distribution (Student t,
+    2 degrees of freedom, |w| up to 1000 times the typical one in a row: the per-column weight scale is set by an outlier)
+    instead of N(0, 1 / fan_in): the log-likelihoods must be as close to the EXACT ones (oracle with float64 products) as an
+    FP32 BLAS and the library's own exact-FP32 kernels are -- within a factor of two of the larger of their errors -- and no call
+    may have left the split kernels' range."""
+    from oracle import pipeline
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.ModelSpec(hidden_dim=256, prefinal_dim=256, num_phones=130, ivector_dim=10, num_gauss=16, lda_dim=12, weight_dist="heavy",
+                           layer_offsets=((0,), (-1, 0, 1), (-3, 0, 3)), seed=21)
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    pcms = [synth.synth_utterance(500 + i, n) for i, n in enumerate([24000, 16000])]
+    orc = pipeline.Oracle(tmp_path / "model", tmp_path / "graph")
+    f32 = [orc.transcribe(p).loglikes for p in pcms]
+    monkeypatch.setattr(pipeline.Nnet3, "matmul", staticmethod(lambda x, wt: (x.astype(np.float64) @ wt.astype(np.float64)).astype(np.float32)))
+    f64 = [orc.transcribe(p).loglikes for p in pcms]
+    monkeypatch.undo()
+    model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    split = model.decode_batch(pcms)
+    assert "range_retries=0 exact_fp32=0" in model.describe()
+    monkeypatch.setenv("RS_GEMM_B3", "0")
+    exact = model.decode_batch(pcms)
+    monkeypatch.delenv("RS_GEMM_B3")
+    for i in range(len(pcms)):
+        scale = np.abs(f64[i]).max()
+        e_blas = np.abs(f32[i] - f64[i]).max()
+        e_exact = np.abs(exact.matrix(i, 2) - f64[i]).max()
+        e_split = np.abs(split.matrix(i, 2) - f64[i]).max()
+        assert np.abs(split.matrix(i, 2) - exact.matrix(i, 2)).max() > 0       # (two different kernels did run)
+        assert e_split <= 2.0 * max(e_blas, e_exact) + 1e-7 * scale, (i, scale, e_blas, e_exact, e_split)
+        assert split.words(i) == exact.words(i)
+
+
+def test_activation_beyond_fp16_range_repeats_the_call_on_the_exact_kernels(tmp_path, monkeypatch):
+    """A layer whose output exceeds 65504 in magnitude cannot be carried by the two-fp16 split: the kernels raise the call's
+    range flag, the call is repeated on the exact-FP32 kernels (its results are THEIR results, bit for bit), and a model whose
+    calls keep doing that changes kernels for good.  A stream advance cannot be repeated: it fails, and the model changes at once."""
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.tiny_spec(hidden_dim=256, prefinal_dim=256, hidden_gain=3.0e5, seed=9)
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    pcm = synth.synth_utterance(41, 32000)
+    monkeypatch.setenv("RS_GEMM_B3", "0")
+    ref_model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    ref = ref_model.decode_batch([pcm])
+    rs = _lib.Stream(ref_model)
+    rs.accept(pcm)
+    ref_stream = rs.finish()
+    rs.close()
+    monkeypatch.delenv("RS_GEMM_B3")
+    model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    for k in range(1, 4):
+        res = model.decode_batch([pcm])
+        assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2))
+        assert res.words(0) == ref.words(0)
+        assert f"range_retries={k} exact_fp32={1 if k >= 3 else 0}" in model.describe(), model.describe()
+    res = model.decode_batch([pcm])                                  # no further repetitions: the model is on the exact kernels
+    assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2)) and "range_retries=3 exact_fp32=1" in model.describe()
+    # streams
+    model2 = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    st = _lib.Stream(model2)
+    st.accept(pcm)
+    with pytest.raises(_lib.RsError, match="range of the split-fp16"):
+        st.advance()
+        st.finish()
+    st.close()
+    assert "exact_fp32=1" in model2.describe()
+    st = _lib.Stream(model2)                                          # a new stream of the model runs on the exact kernels
+    st.accept(pcm)
+    got = st.finish()
+    assert np.array_equal(got.matrix(0, 2), ref_stream.matrix(0, 2)) and got.words(0) == ref_stream.words(0)
+    st.close()
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "zam_u0", "zam_long30"])
