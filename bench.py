@@ -374,7 +374,20 @@ def main() -> None:
         dist.all_gather(out, t)
         return torch.cat(out).cpu().numpy()
 
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(inflight, 1))
+    # Host placement: this rank's threads -- the workers that copy the step's PCM into pinned staging and the thread that gathers --
+    # stay on the CPUs of the GPU's NUMA node (rs_bind_host_thread; RS_BENCH_BIND=0 switches it off).  At one rank the whole box
+    # is the rank's and it changes nothing measurable; at eight, every rank's 10 GB/s of staging traffic stays off the socket links.
+    bound = {"cpus": 0}
+    bind_on = os.environ.get("RS_BENCH_BIND", "1") != "0"
+
+    def bind_here():
+        if bind_on:
+            try:
+                bound["cpus"] = _lib.bind_host_thread(local_rank)
+            except Exception as e:           # placement is an optimisation: a box without the sysfs entries still runs the bench
+                bound["error"] = str(e)
+    bind_here()
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(inflight, 1), initializer=bind_here)
 
     def run_steps(n, fn, check_against=None):
         """n steps, at most `inflight` decode calls in flight; results are consumed (and gathered) in step order."""
@@ -511,7 +524,9 @@ def main() -> None:
                        "inputs": "int16 PCM in pageable host memory -> word ids in host memory (SURVEY 8(d)'s timed region; PCIe-inclusive)",
                        "entry_point": ("rs_streams_accept / rs_streams_advance / rs_streams_finish" if wl == "streams" else
                                        "rs_decode_batch_sharded" if sharded else "rs_decode_batch"),
-                       "record_gather": gather_by},
+                       "record_gather": gather_by,
+                       "host_affinity": (f"threads bound to the {bound['cpus']} CPUs local to the GPU (rs_bind_host_thread)" if bound["cpus"] else
+                                         "not bound" + (f" ({bound['error']})" if "error" in bound else ""))},
             "timed_seconds": elapsed,
             "results_checked": "every step's result records equal the first step's (same input)" + (f"; {checked_vs_reference}" if checked_vs_reference else ""),
         }

@@ -162,6 +162,13 @@ int rs_decode_batch_sharded(rs_model *const *models, int32_t n_models, const int
  * order on every rank, so such a host decodes from its worker threads and gathers from one thread in step order.  The
  * reference has no counterpart (one process per utterance, tools.py:117-147); `device_id` = the rank's GPU. */
 int rs_shard_gather(int32_t device_id, int32_t n_utts, int32_t rank, int32_t world, void *rccl_comm, int32_t *records);
+/* Host-side placement for one-process-per-GPU hosts (no counterpart in the reference, which never shares a box between GPUs):
+ * restricts the CALLING thread -- and every thread it creates afterwards, the library's own helper threads included -- to the
+ * CPUs local to GPU `device_id` (`/sys/bus/pci/devices/<bus id>/local_cpulist`: the cores of its NUMA node), so that a rank's
+ * staging copies (24.6 MB of PCM per 2.3 ms step on the headline workload) read and write node-local memory instead of crossing
+ * the socket interconnect at eight ranks.  Returns the number of CPUs in the mask (0: the system names none -- nothing changed),
+ * or a negative RS_ERR_*.  RS_BIND_CPULIST=<list> (e.g. "0-15,64-79") overrides the list and needs no device. */
+int rs_bind_host_thread(int32_t device_id);
 
 /* Parity taps (only with opts.keep_intermediates): kind 0 = nnet input features (T x C), 1 = iVector
  * (n x D_iv: one row offline, one row per nnet chunk for streams), 2 = log-likelihoods (T x P). */

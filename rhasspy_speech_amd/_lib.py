@@ -35,7 +35,7 @@ EXPORTS = [
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_mkgraph", "rs_fst_tool", "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
     "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
-    "rs_nnet3_setup", "rs_dither_noise",
+    "rs_nnet3_setup", "rs_dither_noise", "rs_bind_host_thread",
 ]
 
 
@@ -306,6 +306,16 @@ def shard_gather(records: np.ndarray, device_id: int, rank: int, world: int, rcc
     rec = np.ascontiguousarray(records, dtype=np.int32).copy()
     _check(lib().rs_shard_gather(device_id, rec.shape[0], rank, world, C.c_void_p(rccl_comm), rec.ctypes.data_as(C.POINTER(C.c_int32))))
     return rec
+
+
+def bind_host_thread(device_id: int) -> int:
+    """rs_bind_host_thread: the calling thread (and the threads it starts from now on) stays on the CPUs local to GPU
+    `device_id`; returns how many CPUs that is (0: the system names none, nothing changed).  RS_BIND_CPULIST overrides."""
+    lib().rs_bind_host_thread.argtypes = [C.c_int32]
+    n = lib().rs_bind_host_thread(device_id)
+    if n < 0:
+        _check(n)
+    return n
 
 
 class Stream:

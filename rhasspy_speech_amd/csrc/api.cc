@@ -1,7 +1,11 @@
 // extern "C" surface of librhasspy_speech_hip.so (see include/rhasspy_speech_hip.h).  No exception crosses
 // the boundary: every failure becomes a status code + thread-local message, mirroring how the reference's
 // binaries report KALDI_ERR text on stderr with a non-zero exit status (tools.py:138-145).
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,10 +22,15 @@
 // Loaded before the HIP runtime has started (the usual case for a host program that links or dlopens the library first): ask the
 // runtime for 8 hardware queues instead of 4, unless the environment already says otherwise.  A model keeps up to four calls in
 // flight on three streams each, and streams that share a hardware queue serialise on each other's event waits (headline step
-// 2.45 -> 2.31 ms).  Without effect when HIP is already initialised.
+// 2.45 -> 2.31 ms).  Without effect when HIP is already initialised.  This changes the environment of the host
+// PROCESS (every HIP user in it sees the variable) from inside dlopen: RS_NO_HW_QUEUES_DEFAULT=1 switches it off, a host that sets
+// GPU_MAX_HW_QUEUES itself is left alone either way; INTEGRATION.md section 4 says so where an integrator reads first.
 namespace {
 struct HipQueuesDefault {
-  HipQueuesDefault() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+  HipQueuesDefault() {
+    const char *off = std::getenv("RS_NO_HW_QUEUES_DEFAULT");
+    if (!(off && std::atoi(off) != 0)) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  }
 } g_hip_queues_default;
 }  // namespace
 
@@ -171,6 +180,53 @@ int rs_shard_gather(int32_t device_id, int32_t n_utts, int32_t rank, int32_t wor
   });
 }
 
+int rs_bind_host_thread(int32_t device_id) {
+  return Guard([&]() {
+    std::string list;
+    if (const char *e = std::getenv("RS_BIND_CPULIST")) {
+      list = e;
+    } else {
+      if (device_id < 0) return ArgError("rs_bind_host_thread: bad device id");
+      char bus[64] = {0};
+      const hipError_t he = hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_id);
+      if (he != hipSuccess) throw rs::DeviceError(std::string("rs_bind_host_thread: hipDeviceGetPCIBusId: ") + hipGetErrorString(he));
+      std::string id(bus);
+      for (char &c : id) c = (char)std::tolower((unsigned char)c);
+      if (FILE *f = std::fopen(("/sys/bus/pci/devices/" + id + "/local_cpulist").c_str(), "r")) {
+        char buf[4096] = {0};
+        if (std::fgets(buf, sizeof(buf), f)) list = buf;
+        std::fclose(f);
+      }
+    }
+    // "a-b,c,d-e"
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    const char *p = list.c_str();
+    while (*p) {
+      while (*p == ',' || *p == ' ' || *p == '\n' || *p == '\t') p++;
+      if (!*p) break;
+      char *end = nullptr;
+      const long a = std::strtol(p, &end, 10);
+      if (end == p || a < 0) return ArgError("rs_bind_host_thread: cannot parse the CPU list");
+      long b = a;
+      p = end;
+      if (*p == '-') {
+        b = std::strtol(p + 1, &end, 10);
+        if (end == p + 1 || b < a) return ArgError("rs_bind_host_thread: cannot parse the CPU list");
+        p = end;
+      }
+      for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (!CPU_ISSET((int)c, &set)) { CPU_SET((int)c, &set); n++; }
+    }
+    if (n == 0) return 0;
+    if (sched_setaffinity(0, sizeof(set), &set) != 0) {
+      g_last_error = std::string("rs_bind_host_thread: sched_setaffinity: ") + std::strerror(errno);
+      return (int)RS_ERR_ARG;
+    }
+    return n;
+  });
+}
+
 int rs_stream_open(rs_model *model, rs_stream **out) {
   if (!model || !out) return ArgError("rs_stream_open: null argument");
   return Guard([&]() {
@@ -188,6 +244,7 @@ int rs_stream_open(rs_model *model, rs_stream **out) {
 int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples) {
   if (!stream || n_samples < 0 || (n_samples > 0 && !pcm)) return ArgError("rs_stream_accept: bad argument");
   if (stream->finished) return ArgError("rs_stream_accept: stream already finished");
+  if (stream->failed) return ArgError("rs_stream_accept: stream was part of an advance that failed; its device state is undefined, close it");
   return Guard([&]() {
     stream->pcm.insert(stream->pcm.end(), pcm, pcm + n_samples);
     stream->n_samples += n_samples;
@@ -200,6 +257,7 @@ int rs_streams_accept(rs_stream *const *streams, const int16_t *const *pcm, cons
   for (int i = 0; i < n_streams; i++) {
     if (!streams[i] || n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return ArgError("rs_streams_accept: bad argument");
     if (streams[i]->finished) return ArgError("rs_streams_accept: stream already finished");
+    if (streams[i]->failed) return ArgError("rs_streams_accept: stream was part of an advance that failed; its device state is undefined, close it");
   }
   return Guard([&]() {
     for (int i = 0; i < n_streams; i++) {

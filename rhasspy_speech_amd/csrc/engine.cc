@@ -239,9 +239,22 @@ MfccDev Model::MfccWithDither(int frames) {
   m.dither = nullptr;
   m.dither_value = fc_.mfcc.opts.dither;
   if (m.dither_value == 0.0f || frames <= 0) return m;
-  std::lock_guard<std::mutex> lk(dither_mu_);
-  if (frames > dither_frames_) {
-    const int old = dither_frames_, want = std::max({frames, 2 * old, 1024});
+  {
+    std::lock_guard<std::mutex> lk(dither_mu_);
+    if (frames <= dither_frames_) { m.dither = d_dither_; return m; }
+  }
+  // Growth (rare: the table doubles).  One grower at a time; calls that fit the current table are not held up while the noise is
+  // generated (dither_mu_ is only taken to read or publish the pointer).  Size: win floats per frame of the longest utterance or
+  // stream so far -- 1.6 KB per frame, 0.58 GB per hour of audio.
+  std::lock_guard<std::mutex> grow(dither_grow_mu_);
+  int old;
+  const float *d_old;
+  {
+    std::lock_guard<std::mutex> lk(dither_mu_);
+    old = dither_frames_; d_old = d_dither_;
+  }
+  if (frames > old) {
+    const int want = std::max({frames, 2 * old, 1024});
     const size_t win = (size_t)fc_.mfcc.win;
     std::vector<float> host((size_t)(want - old) * win);
     {
@@ -256,12 +269,20 @@ MfccDev Model::MfccWithDither(int frames) {
     }
     float *d = nullptr;
     RS_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)want * win));
-    dither_bufs_.push_back(d);
-    if (old) RS_HIP(hipMemcpy(d, d_dither_, sizeof(float) * (size_t)old * win, hipMemcpyDeviceToDevice));
+    if (old) RS_HIP(hipMemcpy(d, d_old, sizeof(float) * (size_t)old * win, hipMemcpyDeviceToDevice));
     RS_HIP(hipMemcpy(d + (size_t)old * win, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    // Launches in flight may still read the table this one supersedes, so that one stays; the ones before it go -- after a
+    // device-wide wait, which a handful of growth steps in a model's life can afford.
+    if (dither_bufs_.size() >= 2) {
+      RS_HIP(hipDeviceSynchronize());
+      while (dither_bufs_.size() >= 2) { (void)hipFree(dither_bufs_.front()); dither_bufs_.erase(dither_bufs_.begin()); }
+    }
+    dither_bufs_.push_back(d);
+    std::lock_guard<std::mutex> lk(dither_mu_);
     d_dither_ = d;
     dither_frames_ = want;
   }
+  std::lock_guard<std::mutex> lk(dither_mu_);
   m.dither = d_dither_;
   return m;
 }

@@ -140,6 +140,8 @@ class Model {
   void StreamOpen(rs_stream *st);
   void StreamClose(rs_stream *st);
   void StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res);
+  void StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res);      // pool_mu_ held
+  void StreamsPoisonAll();          // pool_mu_ held
 
  private:
   struct DecodeContext;
@@ -234,9 +236,10 @@ class Model {
 
   MfccDev mfcc_dev_{};
   // Dither noise of frames [0, dither_frames_) on the device (nnet3_setup.h: the reference's draws for frame t are a constant of
-  // the model).  Grows on demand; superseded buffers stay alive until the model goes (launches in flight may still read them).
+  // the model).  Grows on demand by doubling; the table a growth step supersedes stays alive until the next step (launches in flight may still read it).
   MfccDev MfccWithDither(int frames);
-  std::mutex dither_mu_;
+  std::mutex dither_mu_;           // guards d_dither_ / dither_frames_ (read, publish)
+  std::mutex dither_grow_mu_;      // one thread grows the table at a time
   const float *d_dither_ = nullptr;
   int dither_frames_ = 0;
   long dither_rand_calls_ = 0;

@@ -206,8 +206,9 @@ int DecodeBatchSharded(rs_model *const *models, int n_models, const int32_t *utt
     return rc;
   }
   std::lock_guard<std::mutex> lk(gb.mu);
-  if (gb.device != models[0]->m->opts().device_id || send_bytes > gb.send_cap)      // another thread's call re-sized them meanwhile
-    PrepareGather(gb, models[0]->m->opts().device_id, send_bytes, send_bytes * world);
+  // again, under the lock that is held until the gather is over: another thread's call may have re-sized the buffers since (for
+  // another device, or a larger `per` with a smaller world: both capacities are checked; nothing happens when they suffice)
+  PrepareGather(gb, models[0]->m->opts().device_id, send_bytes, send_bytes * world);
   Gather(gb, local.data(), per, n_utts, world, comm, records);
   return rc;
 }

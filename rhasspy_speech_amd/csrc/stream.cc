@@ -42,6 +42,7 @@ struct StreamPool {
   static constexpr int kDepth = 3;                                             // advances in flight at most = arena / staging sets
   hipEvent_t ev_a[kDepth] = {}, ev_b[kDepth] = {}, ev_done[kDepth] = {};       // per set: stage A issued / log-likelihoods issued / the advance finished
   bool pending[kDepth] = {};                                                   // an advance that used this set may still run
+  std::vector<rs_stream *> open_streams;                                       // every stream that holds a slot (a device failure nobody can attribute poisons them all)
   std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth], tm_c[kDepth];
   // device time of set `par`'s advance into the pool's totals (its done event has been waited for)
   void Account(int par, float *extra) {
@@ -214,9 +215,11 @@ void Model::StreamsDrain(StreamPool *p, float *extra) {
 // the fp16 split cannot carry, the model changes to the exact-FP32 kernels for everything that follows and this call fails.
 void Model::StreamsCheckRange() {
   DecodeContext *cx = stream_ctx_.get();
-  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0 && !exact_gemm_.exchange(true))
+  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0 && !exact_gemm_.exchange(true)) {
+    StreamsPoisonAll();        // (any of the advances in flight may be the one: their log-likelihood rows are not numbers)
     Fail("an activation exceeded the range of the split-fp16 layer GEMMs (|x| >= 65520) during a stream advance; the model now uses the "
          "exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");
+  }
 }
 
 void Model::StreamOpen(rs_stream *st) {
@@ -238,16 +241,33 @@ void Model::StreamOpen(rs_stream *st) {
   }
   RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->qc));      // (the search's queue)
   st->open = true;
+  p->open_streams.push_back(st);
 }
 
 void Model::StreamClose(rs_stream *st) {
   if (!st->open) return;
   std::lock_guard<std::mutex> lk(pool_mu_);
   if (!pool_) return;
-  StreamsDrain(pool_.get(), nullptr);       // an advance that still uses the stream's rows / slot finishes first
+  // an advance that still uses the stream's rows / slot finishes first (a device error of it is the other streams' to report:
+  // this one is going away either way)
+  try { StreamsDrain(pool_.get(), nullptr); } catch (...) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
   pool_->FreeRows(st->row0, st->cap);
   pool_->free_slots.push_back(st->slot);
   st->open = false;
+  auto &os = pool_->open_streams;
+  os.erase(std::remove(os.begin(), os.end(), st), os.end());
+}
+
+// A failure that cannot be pinned on one advance's streams -- a device error that surfaced at a wait, up to three advances
+// after the one that caused it; a layer GEMM that left its range in any of the advances in flight: no stream of the pool can
+// trust its rows.  Everything queued is waited for, every set is free again, every open stream refuses further calls.
+void Model::StreamsPoisonAll() {
+  StreamPool *p = pool_.get();
+  if (!p) return;
+  (void)hipStreamSynchronize(p->qa); (void)hipStreamSynchronize(p->q); (void)hipStreamSynchronize(p->qc);
+  (void)hipGetLastError();
+  for (int k = 0; k < StreamPool::kDepth; k++) p->pending[k] = false;
+  for (rs_stream *st : p->open_streams) st->failed = true;
 }
 
 // A stream outgrew its row range: move it to a range twice as long (device-to-device copies on the pool's stream).
@@ -277,6 +297,20 @@ void Model::StreamGrow(rs_stream *st, int need_frames) {
 // One advance over `n` streams of this model.  final: end of input for all of them; results go to `res` (n utterances).
 void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res) {
   std::lock_guard<std::mutex> lk(pool_mu_);
+  try {
+    StreamsAdvanceLocked(streams, n, final, nbest, lat_scale, res);
+  } catch (const DeviceError &) {
+    StreamsPoisonAll();        // a HIP error: which advance, which streams -- unknown
+    throw;
+  } catch (...) {
+    // The advance may have queued part of its work on a set it never marked pending: whatever is queued finishes before the set
+    // can be handed out again (the call's own streams are poisoned by the caller, api.cc).
+    if (pool_) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
+    throw;
+  }
+}
+
+void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res) {
   StreamPool *p = Pool();
   RS_HIP(hipSetDevice(opts_.device_id));
   // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive

@@ -245,6 +245,56 @@ def test_sharded_gather_two_ranks_gloo(tmp_path):
         assert b"ok" in out
 
 
+_WORKER8 = r'''
+import concurrent.futures, os, sys, threading
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from rhasspy_speech_amd import _lib, shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+want = set(int(c) for c in os.environ["RS_BIND_CPULIST"].split(","))
+assert _lib.bind_host_thread(0) == len(want) and os.sched_getaffinity(0) == want
+seen = []
+def init():
+    _lib.bind_host_thread(0)
+pool = concurrent.futures.ThreadPoolExecutor(max_workers=3, initializer=init)
+n, steps = 37, 7                         # utterances per step (ragged over 8 ranks), steps; three decode calls in flight
+def decode(step):                        # stand-in for rs_decode_batch_sharded(..., rccl_comm = NULL): this rank's records only
+    seen.append((threading.get_ident(), frozenset(os.sched_getaffinity(0))))
+    idx = shard.shard_indices(n, rank, world)
+    words = [[step, i, (i * 7 + step) % 11][: 1 + (i + step) % 3] for i in idx]
+    costs = [(float(i) + step, -float(i) * step) for i in idx]
+    return shard.pack_records(idx, words, costs)
+futures = [pool.submit(decode, k) for k in range(steps)]
+for k in range(steps):                   # the gathers: one thread, step order, the same on every rank
+    got = shard.unpack_records(shard.gather_records(futures[k].result(), n), n)
+    assert sorted(got) == list(range(n))
+    for i in range(n):
+        assert got[i] == ([k, i, (i * 7 + k) % 11][: 1 + (i + k) % 3], float(i) + k, -float(i) * k), (k, i, got[i])
+assert len({t for t, _ in seen}) >= 1 and all(a == want for _, a in seen), seen
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_eight_ranks_three_steps_in_flight_bound_to_their_cpus(tmp_path):
+    """The host side of an 8-GPU node without the GPUs: eight gloo ranks, each with three decode calls in flight on worker
+    threads (stand-in decodes: the real ones need a GPU) and one thread gathering the records in step order, every thread of a
+    rank restricted to the rank's CPUs by rs_bind_host_thread (RS_BIND_CPULIST stands in for the GPU's local_cpulist)."""
+    ncpu = len(os.sched_getaffinity(0))
+    cpus = sorted(os.sched_getaffinity(0))
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="8")
+    procs = [subprocess.Popen([sys.executable, str(script), str(ROOT)], env=dict(env, RANK=str(r), RS_BIND_CPULIST=str(cpus[r % ncpu])),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(8)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()[-2000:]
+        assert b"ok" in out
+
+
 # ------------------------------------------------------------------------------------------ fuzzy matcher (host side)
 def _fuzzy_cases():
     import json
