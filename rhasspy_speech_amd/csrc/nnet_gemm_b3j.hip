@@ -51,7 +51,10 @@ template <int WM> struct JShape {
 #ifndef RS_B3J_STAGES
 #define RS_B3J_STAGES 3
 #endif
-  static constexpr int kStages = RS_B3J_STAGES, kAhead = kStages - 1;
+#ifndef RS_B3J_STAGES_WM2
+#define RS_B3J_STAGES_WM2 4
+#endif
+  static constexpr int kStages = WM == 2 ? RS_B3J_STAGES_WM2 : RS_B3J_STAGES, kAhead = kStages - 1;
   static constexpr int kColTilesPerWave = kJColTiles / kWaves;             // weight column tiles a wave stages
   static constexpr int kDmaPerKstep = kJP + kJP * kColTilesPerWave;        // per staging wave and k-step
 };
@@ -259,11 +262,13 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   // (-DRS_B3J_STAGES=2: the DMA runs one k-step ahead and the wait is for everything this wave has in flight)
   stage_kstep(0u);
   if (kJAhead > 1 && nt > 1) stage_kstep((unsigned)kJStage);
+  if (kJAhead > 2 && nt > 2) stage_kstep(2u * (unsigned)kJStage);
   int t = 0;
   constexpr int kOwn = SH::kDmaPerKstep, kOther = kJP * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
 #define RS_VMWAIT(N) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
 #define RS_WAIT_OWN()                                                                                          \
-  if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn * (kJAhead - 1)); else RS_VMWAIT(kOther * (kJAhead - 1)); } \
+  if (kJAhead > 2 && t + 2 < nt) { if (stager) RS_VMWAIT(kOwn * 2); else RS_VMWAIT(kOther * 2); }               \
+  else if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn); else RS_VMWAIT(kOther); }                   \
   else RS_VMWAIT(0);
 #define RS_B3J_KSTEP(S, S2)                                                                                    \
   {                                                                                                            \
@@ -273,7 +278,19 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     step((unsigned)(S) * kJStage);                                                                             \
     t++;                                                                                                       \
   }
-  if (SH::kStages == 3) {
+  static_assert(SH::kStages >= 2 && SH::kStages <= 4, "ring of two to four stages");
+  if (SH::kStages == 4) {
+#pragma nounroll
+    while (t + 4 <= nt) {
+      RS_B3J_KSTEP(0, 3)
+      RS_B3J_KSTEP(1, 0)
+      RS_B3J_KSTEP(2, 1)
+      RS_B3J_KSTEP(3, 2)
+    }
+    if (t < nt) RS_B3J_KSTEP(0, 3)
+    if (t < nt) RS_B3J_KSTEP(1, 0)
+    if (t < nt) RS_B3J_KSTEP(2, 1)
+  } else if (SH::kStages == 3) {
 #pragma nounroll
     while (t + 3 <= nt) {
       RS_B3J_KSTEP(0, 2)
