@@ -143,20 +143,25 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     // double accumulation is a wave reduction here: the pair sums of a frame span far fewer than 53 bits, so it is exact in
     // any order (it would take a pair cancelling to below 2^-33 of the frame's peak to make the order matter).
     double dsum = 0.0;
-    const float *noise = m.dither ? m.dither + (size_t)(t + (g.d_frame0 ? g.d_frame0[u] : 0)) * m.win : nullptr;
-    for (int k = lane; 2 * k < m.win; k += RS_WAVE) {
-      const int i0 = 2 * k, i1 = i0 + 1;
-      float v0 = (float)src[i0];
-      if (noise) v0 += noise[i0] * m.dither_value;   // Dither(): data[i] += RandGauss(&rstate) * dither_value (no FMA: -ffp-contract=off)
-      x[i0] = v0;
-      if (i1 < m.win) {
-        float v1 = (float)src[i1];
-        if (noise) v1 += noise[i1] * m.dither_value;
-        x[i1] = v1;
-        dsum += (double)(v0 + v1);
-      } else {
-        dsum += (double)v0;
-      }
+    // (dither off: finite stand-ins multiplied by 0 -- v + 0 is v -- so that the loads below carry no condition: written as
+    // `if (noise) v += ...` the compiler put every load under a branch with a full wait behind it, 16 dependent round trips per frame)
+    const float *noise = m.dither ? m.dither + (size_t)(t + (g.d_frame0 ? g.d_frame0[u] : 0)) * m.win : m.window;
+    const float dv = m.dither ? m.dither_value : 0.f;
+    constexpr int JP = NFFT / 128;                      // sample pairs per lane
+    float s0[JP], s1[JP], n0[JP], n1[JP];
+#pragma unroll
+    for (int j = 0; j < JP; j++) {                      // all requests first ...
+      const int i0 = 2 * (lane + RS_WAVE * j), c0 = i0 < m.win ? i0 : m.win - 1, c1 = i0 + 1 < m.win ? i0 + 1 : m.win - 1;
+      s0[j] = (float)src[c0]; s1[j] = (float)src[c1];
+      n0[j] = noise[c0]; n1[j] = noise[c1];
+    }
+#pragma unroll
+    for (int j = 0; j < JP; j++) {                      // ... then Dither(): data[i] += RandGauss(&rstate) * dither_value (no FMA: -ffp-contract=off)
+      const int i0 = 2 * (lane + RS_WAVE * j), i1 = i0 + 1;
+      const float v0 = s0[j] + n0[j] * dv, v1 = s1[j] + n1[j] * dv;
+      if (i0 < m.win) x[i0] = v0;
+      if (i1 < m.win) { x[i1] = v1; dsum += (double)(v0 + v1); }
+      else if (i0 < m.win) dsum += (double)v0;
     }
     for (int i = m.win + lane; i < NFFT; i += RS_WAVE) x[i] = 0.f;
 #pragma unroll
