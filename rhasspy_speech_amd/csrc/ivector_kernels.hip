@@ -706,13 +706,42 @@ __global__ __launch_bounds__(128) void IvecLinearPartialKernel(IvecDev iv, int n
         if (u0 + uu < n_utts) partial[((size_t)ks * n_utts + u0 + uu) * I + i] = acc[uu];
   }
 }
-// linear[u][i] += sum_ks partial[ks][u][i] (fixed order)
-__global__ void IvecLinearReduceKernel(IvecDev iv, int n_utts, const double *__restrict__ partial, double *__restrict__ linear) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x, I = iv.ivec_dim;
-  if (idx >= n_utts * I) return;
-  double acc = 0.0;
-  for (int ks = 0; ks < kIvecKS; ks++) acc += partial[(size_t)ks * n_utts * I + idx];
-  linear[idx] += acc;
+// linear[u][i] += sum_ks partial[ks][u][i] (fixed order) -- and, by the workgroups behind those (blockIdx.x >= reduce_blocks), what
+// IvecTotKernel does for one utterance each (one launch instead of two in front of the quadratic product, which needs both)
+__global__ __launch_bounds__(256) void IvecLinearReduceKernel(IvecDev iv, int n_utts, const double *__restrict__ partial, double *__restrict__ linear,
+                                                              int reduce_blocks, const float *__restrict__ gamma, double *__restrict__ num_frames,
+                                                              double *__restrict__ change) {
+  const int I = iv.ivec_dim;
+  if ((int)blockIdx.x < reduce_blocks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_utts * I) return;
+    double acc = 0.0;
+    for (int ks = 0; ks < kIvecKS; ks++) acc += partial[(size_t)ks * n_utts * I + idx];
+    linear[idx] += acc;
+    return;
+  }
+  // tot = sum_g gamma_g in double: g ascending within each of 256 contiguous runs, then the runs' sums ascending (IvecTotKernel
+  // walked all of them on one thread: 10 us for 512 Gaussians; a double sum of a few hundred floats is exact to 1e-16 either way)
+  __shared__ double part[256];
+  const int u = blockIdx.x - reduce_blocks, G = iv.num_gauss, tid = threadIdx.x;
+  const int per = (G + 255) / 256, g0 = tid * per, g1 = g0 + per < G ? g0 + per : G;
+  double t = 0.0;
+  for (int gi = g0; gi < g1; gi++) t += (double)gamma[(size_t)u * G + gi];
+  part[tid] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < 256; i++) tot += part[i];
+    double ch = 0.0;
+    const double oldn = num_frames[u], newn = oldn + tot;
+    if (iv.max_count > 0.0f) {
+      const double mc = (double)iv.max_count;
+      const double old_scale = (oldn > mc ? oldn : mc) / mc, new_scale = (newn > mc ? newn : mc) / mc;
+      ch = new_scale - old_scale;
+    }
+    change[u] = ch;
+    num_frames[u] = newn;
+  }
 }
 
 // quadratic[u][k] += sum_g gamma[u][g] U_g[k] (+ the prior rescaling on the diagonal and on linear[0])
@@ -1092,8 +1121,8 @@ void LaunchIvecStats(const IvecDev &iv, int n_utts, const double *gamma, const d
   if (mfma && narrow) hipLaunchKernelGGL(IvecLinearMfmaKernel<1>, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
   else if (mfma) hipLaunchKernelGGL(IvecLinearMfmaKernel<4>, dim3(um, kIvecKS, (iv.ivec_dim + 63) / 64), dim3(256), 0, s, iv, n_utts, wfeats, partial);
   else hipLaunchKernelGGL(IvecLinearPartialKernel, dim3(ub, kIvecKS), dim3(128), 0, s, iv, n_utts, wfeats, partial);
-  hipLaunchKernelGGL(IvecLinearReduceKernel, dim3((n_utts * iv.ivec_dim + 255) / 256), dim3(256), 0, s, iv, n_utts, partial, linear);
-  hipLaunchKernelGGL(IvecTotKernel, dim3(n_utts), dim3(64), 0, s, iv, gm, num_frames, change);
+  const int reduce_blocks = (n_utts * iv.ivec_dim + 255) / 256;
+  hipLaunchKernelGGL(IvecLinearReduceKernel, dim3(reduce_blocks + n_utts), dim3(256), 0, s, iv, n_utts, partial, linear, reduce_blocks, gm, num_frames, change);
   const char *ae = std::getenv("RS_IVEC_ASM");           // read per call (a test compares the two forms)
   const int quad_asm = ae ? std::atoi(ae) : 1;
 #define RS_QUAD_ASM(N) do { if (narrow) hipLaunchKernelGGL((IvecQuadMfmaAsmKernel<N, 1>), dim3((usz + 63) / 64, um), dim3(256), 0, s, iv, n_utts, gm, change, quadratic, linear); \
@@ -1286,9 +1315,11 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
     if (mine) xs[tid] = x;
     __syncthreads();
     auto matvec = [&](const double *vec) __attribute__((always_inline)) {
-      // one accumulator, columns ascending (the sums the scalar loop formed); MB columns are read ahead of the dependent adds
+      // four accumulators over the columns c = 4 q + j, summed pairwise at the end: a single one (round 3) made a row product a
+      // chain of n dependent fp64 FMAs -- 45 us for 15 iterations of n = 100; the order of an fp64 sum is free at the 1e-4 the
+      // iVector is held to (batch and stream paths run this same kernel and stay bit-equal to each other)
       constexpr int MB = 20;
-      double acc = 0.0;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       if (mine) {
         int c = 0;
         for (; c + MB <= n; c += MB) {
@@ -1296,11 +1327,11 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
 #pragma unroll
           for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + tid]; w[i] = vec[c + i]; }
 #pragma unroll
-          for (int i = 0; i < MB; i++) acc += a[i] * w[i];
+          for (int i = 0; i < MB; i += 4) { a0 += a[i] * w[i]; a1 += a[i + 1] * w[i + 1]; a2 += a[i + 2] * w[i + 2]; a3 += a[i + 3] * w[i + 3]; }
         }
-        for (; c < n; c++) acc += A[(size_t)c * n + tid] * vec[c];
+        for (; c < n; c++) a0 += A[(size_t)c * n + tid] * vec[c];
       }
-      return acc;
+      return (a0 + a1) + (a2 + a3);
     };
     // p0 = b - A x0 ; r0 = -p0
     double p = b - matvec(xs), r = -p;
