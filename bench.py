@@ -490,6 +490,32 @@ def main() -> None:
                 full_stage += np.array(full_dev().timings())
             all_pdfs_stage = (float(full_stage[3] / 5), full.describe())
             del full
+    # ---- the n-best / lattice tail (what every rescoring or fuzzy-matching call of the Python API asks for: nbest = 5; and the
+    # determinised lattice itself): device-side lattice extraction + host determinisation and n-best, utterances of a call on a
+    # few host threads.  Short runs: the tail is host work, an order of magnitude slower than the 1-best step.
+    if wl == "grammar" and world == 1 and not args.no_side_figures and not sharded:
+        n_tail = max(6, min(steps, 24))
+
+        def nbest5():
+            return model.decode_batch(pcms, nbest=5)
+        r5 = nbest5()
+        if [r5.words(u, 0) for u in range(n_utts)] != [res.words(u, 0) for u in range(n_utts)]:
+            raise SystemExit("bench.py: the first of the 5-best differs from the 1-best")
+        run_steps(2, nbest5)
+        t5 = time.perf_counter()
+        run_steps(n_tail, nbest5)
+        side["nbest5"] = figure(n_tail, time.perf_counter() - t5, "rs_decode_batch(nbest = 5): lattice extraction on the device, determinisation + 5-best per utterance on host threads; "
+                                f"{sum(r5.num_hyps(u) for u in range(n_utts)) / n_utts:.2f} hypotheses per utterance on average")
+        lat_model = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank, prune_output_pdfs=0 if args.all_pdfs else 1, emit_lattice=1))
+        lat_model.to_device()
+
+        def with_lattice():
+            return lat_model.decode_batch(pcms, nbest=1)
+        run_steps(2, with_lattice)
+        tl = time.perf_counter()
+        run_steps(n_tail, with_lattice)
+        side["emit_lattice"] = figure(n_tail, time.perf_counter() - tl, "rs_decode_opts.emit_lattice = 1: every utterance's determinised CompactLattice kept with the result")
+        del lat_model
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
     stage, counters, n_iso = np.zeros(8), np.zeros(8), 0

@@ -1237,9 +1237,9 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
     // group by utterance
     std::vector<std::vector<const LatArc *>> per(n_utts);
     for (auto &a : h_arcs) if (a.utt >= 0 && a.utt < n_utts) per[a.utt].push_back(&a);
-    for (int u = 0; u < n_utts; u++) {
+    auto one = [&](int u) {
       UttResult &ur = out_utts[u];
-      if (ur.status != RS_OK) continue;
+      if (ur.status != RS_OK) return;
       RawLattice lat;
       std::unordered_map<int, int> id;
       auto sid = [&](int tok) {
@@ -1267,7 +1267,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
           for (auto &fw : ur.clat->final_w) fw.acoustic *= inv;
         }
       }
-      if (paths.empty()) continue;   // keep the traceback result (cannot happen for a consistent lattice)
+      if (paths.empty()) return;     // keep the traceback result (cannot happen for a consistent lattice)
       ur.hyps.clear();
       for (auto &p : paths) {
         Hypothesis hy;
@@ -1276,6 +1276,31 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
         hy.acoustic_cost = (float)(unscale ? p.acoustic_cost / opts_.acoustic_scale : p.acoustic_cost);
         ur.hyps.push_back(std::move(hy));
       }
+    };
+    // The reference runs one determinise | lattice-to-nbest process per utterance (tools.py:117-147); here the utterances of a call
+    // are independent jobs for a few host threads (lat/determinize-lattice-pruned.cc:1488-1513 and latbin/lattice-to-nbest.cc:80-110
+    // per job, host code in the reference too).  The threads inherit the caller's CPU mask (rs_bind_host_thread).
+    static const int max_threads = [] {
+      const char *e = std::getenv("RS_LATTICE_THREADS");
+      const int hw = (int)std::thread::hardware_concurrency();
+      return std::max(1, e ? std::atoi(e) : std::min(hw > 0 ? hw : 1, 16));
+    }();
+    const int nthr = std::min(max_threads, n_utts);
+    if (nthr <= 1) {
+      for (int u = 0; u < n_utts; u++) one(u);
+    } else {
+      std::atomic<int> next{0};
+      std::vector<std::exception_ptr> errs(nthr);
+      auto run = [&](int k) {
+        try {
+          for (int u = next.fetch_add(1); u < n_utts; u = next.fetch_add(1)) one(u);
+        } catch (...) { errs[k] = std::current_exception(); }
+      };
+      std::vector<std::thread> th;
+      for (int k = 1; k < nthr; k++) th.emplace_back(run, k);
+      run(0);
+      for (auto &t : th) t.join();
+      for (auto &e : errs) if (e) std::rethrow_exception(e);
     }
     timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
   }}
