@@ -52,7 +52,12 @@ typedef struct rs_decode_opts {
   int32_t prune_output_pdfs;   /* 1 (default): evaluate the output layer only for the pdfs that occur on HCLG arcs (the search
                                 * can read no others; transcripts and costs unchanged).  0 computes every pdf like the
                                 * reference does.  Ignored with keep_intermediates and when the net ends in a log-softmax. */
-  int32_t reserved[5];
+  int32_t exact_token_order;   /* 1: the grammar-graph search creates tokens in the reference's order (the running `next_cutoff` of
+                                * lattice-faster-decoder.cc:774-787 over its HashList order, hash-list-inl.h:125-165) -- costs equal the
+                                * reference's on the frames where min-active / max-active binds, about 40 % more search time; graphs it
+                                * does not apply to (more than 1000 states, chained epsilon arcs) are searched as with 0.  Default 0;
+                                * RS_EXACT_ORDER=0|1 overrides. */
+  int32_t reserved[4];
 } rs_decode_opts;
 
 /* Fills `opts` with the values the reference's Python passes / Kaldi defaults. */

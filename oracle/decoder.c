@@ -454,6 +454,7 @@ Dec *rs_oracle_decode(int num_states, int start, const float *final, const int64
   d->frames[0].toks = st;
   hl_insert(d, start, st);
   process_nonemitting(d, d->beam);
+  for (int t = d->frames[0].toks; t != -1; t = d->tok[t].next) d->counters[7]++;      /* tokens of frame 0 (the start state's closure) */
   /* AdvanceDecoding */
   while (d->nframes - 1 < T) {
     if ((d->nframes - 1) % d->prune_interval == 0) prune_active_tokens(d, d->lattice_beam * d->prune_scale);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   const int f_stop = f_end < T ? f_end : T;
   const size_t slot = windows ? (size_t)w.slot[u] : (size_t)u;
   const size_t frame_row0 = windows ? (size_t)w.pool_row[u] : (size_t)u * (g.max_frames + 1);
-  float *state = w.state_cost + slot * (S + 4);
+  float *state = w.state_cost + slot * (2 * (size_t)S + 4);
   float *cost_cur = reinterpret_cast<float *>(smem);                                       // [S + 1], [S] = +inf forever
   unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem + rg.key_base);   // [S + 1], [S] = empty forever
   int *bp = w.bp + frame_row0 * S;
@@ -361,13 +361,409 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same search with the reference's ORDER-DEPENDENT token creation (lattice-faster-decoder.cc:734-787, hash-list-inl.h:125-165).
+//
+// The reference walks a frame's tokens in the order its HashList holds them and lowers `next_cutoff` as it goes: arc i creates
+// (or improves) a token iff tot_i < c_i, where c_i is the cutoff at the moment the arc is looked at -- the seed from the best
+// token's arcs, lowered by every arc looked at before (tot_j + adaptive_beam).  RegDecodeKernel tests against the FINAL cutoff, so
+// the reference owns a few tokens more ("extras": final cutoff <= cost < c_i).  They are never expanded by the closure, but the
+// next frame's GetCutoff counts them, and when min-active / max-active binds the k-th smallest cost -- the cutoff -- can be one
+// of theirs.  Here:
+//   * c_i is an exclusive PREFIX MINIMUM over the arcs in the reference's order.  An arc that fails its test cannot lower the
+//     cutoff (tot_j + adaptive_beam > c_j >= every later c), so the prefix runs over ALL arcs of the expanded tokens: per token the
+//     minimum over its arcs (LDS atomic at the token's list position), one block scan over the positions, and inside a token the
+//     handful of arcs before arc i (their values sit in LDS in arc order).
+//   * The order.  With at most 1000 states the reference's table (1000 buckets at least, grown by doubling the token count) never
+//     collides: bucket = state, and the list is the order in which the frame's states were first inserted -- by the emitting arcs in
+//     (position of the source token, arc number) order, then by ProcessNonemitting, which pops its queue from the BACK: source
+//     tokens in reverse list order, arcs in order (graphs whose epsilon arcs never chain: the queue only shrinks).  Every state
+//     keeps the smallest such key among the arcs that passed (LDS atomic min); dense positions follow from a bit mask per source
+//     position + one prefix sum of the masks' populations.
+// Everything else -- GetCutoff on all tokens of the list, the closure against the final cutoff, ties, back-pointers -- is the
+// reference's already.  Costs equal the CPU oracle's (oracle/decoder.c follows the hash order too) bit for bit.
+// Eligible graphs: <= 1000 states, epsilon depth <= 1, at most 32 emitting and 32 epsilon arcs per state (RegGraphDev::exact_ok).
+// Seven block-wide steps more per frame than RegDecodeKernel and 14 S + 4 E bytes of LDS: rs_decode_opts.exact_token_order.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned DppId(unsigned v, unsigned ident) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned WaveScanInclMinU(unsigned v) {
+  const unsigned I = 0xFFFFFFFFu;
+  v = min(v, DppId<0x111, 0xF>(v, I));
+  v = min(v, DppId<0x112, 0xF>(v, I));
+  v = min(v, DppId<0x114, 0xF>(v, I));
+  v = min(v, DppId<0x118, 0xF>(v, I));
+  v = min(v, DppId<0x142, 0xA>(v, I));
+  v = min(v, DppId<0x143, 0xC>(v, I));
+  return v;
+}
+// exclusive scan (minimum of ordered keys, or sum) of arr[0 .. n) in place, n <= 4 NT; returns the total; one barrier inside, one after
+template <int NT, bool IS_MIN>
+__device__ __forceinline__ unsigned BlockScanExcl(unsigned *arr, int n, int4 (*xr)[NT / 64], int &rb) {
+  constexpr int NW = NT / 64, PER = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned I = IS_MIN ? 0xFFFFFFFFu : 0u;
+  unsigned v[PER], run = I;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int idx = tid * PER + j;
+    v[j] = idx < n ? arr[idx] : I;
+    run = IS_MIN ? min(run, v[j]) : run + v[j];
+  }
+  const unsigned incl = IS_MIN ? WaveScanInclMinU(run) : (unsigned)WaveScanIncl((int)run);
+  unsigned excl = (unsigned)__shfl_up((int)incl, 1, 64);
+  if (lane == 0) excl = I;
+  if (lane == 63) xr[rb][wave] = make_int4((int)incl, 0, 0, 0);
+  LdsBarrier();
+  unsigned before = I, total = I;
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    const unsigned t = (unsigned)xr[rb][k].x;
+    if (k < wave) before = IS_MIN ? min(before, t) : before + t;
+    total = IS_MIN ? min(total, t) : total + t;
+  }
+  rb ^= 1;
+  unsigned acc = IS_MIN ? min(before, excl) : before + excl;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const int idx = tid * PER + j;
+    if (idx < n) arr[idx] = acc;
+    acc = IS_MIN ? min(acc, v[j]) : acc + v[j];
+  }
+  LdsBarrier();
+  return total;
+}
+
+template <int NT, int KE, int KX>
+__global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDev rg, DecodeOptsDev o, BatchGeom g,
+                                                           const float *__restrict__ loglikes, int ld, DenseWork w, int smem_bytes,
+                                                           int f_begin, int f_end) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);
+  constexpr int NW = NT / 64, E = NT * KE;
+  __shared__ Red<NW> red;
+  __shared__ int4 xr[2][NW];
+  __shared__ unsigned seed_u;
+  int rb = 0;
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = g.d_num_frames[u], S = h.num_states;
+  const bool windows = w.win_begin != nullptr;
+  if (windows) { f_begin = w.win_begin[u]; f_end = w.win_end[u]; }
+  const bool finishing = windows ? w.win_final[u] != 0 : f_end >= T;
+  if (windows ? (f_begin >= f_end && !finishing) : (f_begin >= 0 && f_begin >= T)) return;
+  const int f_stop = f_end < T ? f_end : T;
+  const size_t slot = windows ? (size_t)w.slot[u] : (size_t)u;
+  const size_t frame_row0 = windows ? (size_t)w.pool_row[u] : (size_t)u * (g.max_frames + 1);
+  float *state = w.state_cost + slot * (2 * (size_t)S + 4);
+  float *cost_cur = reinterpret_cast<float *>(smem);
+  unsigned long long *key_next = reinterpret_cast<unsigned long long *>(smem + rg.key_base);
+  // the order's arrays, behind the keys
+  const int xb = (rg.key_base + 8 * (S + 1) + 15) & ~15;
+  unsigned short *rank16 = reinterpret_cast<unsigned short *>(smem + xb);                       // position of a state's token in the frame's list
+  unsigned *fkey = reinterpret_cast<unsigned *>(smem + xb + ((2 * S + 15) & ~15));               // smallest insertion key of the frame under construction
+  unsigned *ordm = fkey + S;                                                                     // per list position: min over the token's arcs of tot + adaptive_beam; later the prefix sums
+  unsigned *maskE = ordm + S;                                                                    // per source position: which of its arcs inserted a state first
+  float *arcv = reinterpret_cast<float *>(maskE + S);                                            // per emitting arc (table order): tot + adaptive_beam
+  unsigned *maskX = reinterpret_cast<unsigned *>(arcv);                                          // (after the arc pass) the same for the closure's arcs
+  int *bp = w.bp + frame_row0 * S;
+  float *finfo = w.frame_info + frame_row0 * 4;
+  const float INF = INFINITY;
+  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
+  unsigned long long n_expanded = 0, n_arcs = 0, n_insert = 0, n_alive = 0;
+  int max_active_frames = 0, min_active_frames = 0;
+  int4 ea[KE], xa[KX];
+  int eaux[KE], xaux[KX];
+#pragma unroll
+  for (int a = 0; a < KE; a++) { ea[a] = rg.e_tab[(size_t)a * NT + tid]; eaux[a] = rg.e_aux[(size_t)a * NT + tid]; }
+#pragma unroll
+  for (int a = 0; a < KX; a++) { xa[a] = rg.x_tab[(size_t)a * NT + tid]; xaux[a] = rg.x_aux[(size_t)a * NT + tid]; }
+  for (int s = tid; s <= S; s += NT) { cost_cur[s] = (f_begin >= 0 && s < S) ? state[s] : INF; key_next[s] = RS_EMPTY; }
+  for (int s = tid; s < S; s += NT) {
+    rank16[s] = f_begin >= 0 ? (unsigned short)state[S + 4 + s] : (unsigned short)0;
+    fkey[s] = 0xFFFFFFFFu; ordm[s] = 0xFFFFFFFFu; maskE[s] = 0u;
+  }
+  for (int i = tid; i < (E > S ? E : S); i += NT) maskX[i] = 0u;
+  for (int i = tid; i < 256; i += NT) red.hist[i] = 0;
+  if (tid == 0) { red.ncand = 0; seed_u = 0xFFFFFFFFu; }
+  const int f_first = f_begin < 0 ? 0 : f_begin;
+  float llv[KE];
+#pragma unroll
+  for (int a = 0; a < KE; a++) llv[a] = 0.f;
+  if (f_first < T) {
+    const float *row = loglikes + (ll_base + f_first) * ld;
+#pragma unroll
+    for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
+  }
+  __syncthreads();
+  if (f_begin < 0 && tid == 0) { key_next[h.start] = PackKey(0.0f, RS_NOARC); fkey[h.start] = 0u; rank16[h.start] = 0; }
+  float closure_cutoff = f_begin < 0 ? o.beam : state[S];
+  int error = f_begin < 0 ? 0 : (int)state[S + 1];
+  float st_min = INF, st_max = -INF;
+  int st_arg = 0x7fffffff, st_cnt = 0;
+  if (f_begin >= 0) {
+    for (int s = tid; s < S; s += NT) {
+      const float c = cost_cur[s];
+      const bool alive = c < INF;
+      st_cnt += (int)alive;
+      st_max = alive ? fmaxf(st_max, c) : st_max;
+      const bool better = alive & (c < st_min);
+      st_min = better ? c : st_min;
+      st_arg = better ? s : st_arg;
+    }
+  }
+  __syncthreads();
+  int n_emit = 1;                                 // tokens the emitting arcs put on the list (the start token for the first closure)
+
+  for (int f = f_begin; f < f_stop && !error; f++) {
+    if (f >= 0) {
+      // ---- best token (ties: smallest state), token count, largest cost (the list holds tokens beyond last frame's cutoff)
+      float best_cost, hist_hi;
+      int best_state, N;
+      {
+        const unsigned ub = wv::FloatToOrdered(st_min);
+        const unsigned wm = wv::MinU(ub);
+        const unsigned long long tie = __ballot(ub == wm);
+        unsigned wa;
+        if (__popcll(tie) == 1) wa = (unsigned)__builtin_amdgcn_readlane(st_arg, __ffsll((long long)tie) - 1);
+        else wa = wv::MinU(ub == wm ? (unsigned)st_arg : 0x7fffffffu);
+        const int wn = wv::Sum(st_cnt);
+        const unsigned wx = wv::MaxU(wv::FloatToOrdered(st_max));
+        if (lane == 0) xr[rb][wave] = make_int4((int)wm, (int)wa, wn, (int)wx);
+        LdsBarrier();
+        unsigned long long bk = ~0ull;
+        unsigned bx = 0u;
+        N = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          const int4 e = xr[rb][k];
+          const unsigned long long kk = ((unsigned long long)(unsigned)e.x << 32) | (unsigned)e.y;
+          bk = kk < bk ? kk : bk;
+          N += e.z;
+          bx = max(bx, (unsigned)e.w);
+        }
+        rb ^= 1;
+        best_cost = wv::OrderedToFloat((unsigned)(bk >> 32));
+        best_state = (int)(unsigned)(bk & 0xFFFFFFFFull);
+        hist_hi = wv::OrderedToFloat(bx);
+      }
+      if (N == 0) { error = 1; break; }
+      // ---- GetCutoff over every token of the list (:644-711)
+      const float beam_cutoff = best_cost + o.beam;
+      int c_le = 0, c_lt = 0;
+      const bool need_pass = N > o.max_active || N > o.min_active;      // workgroup-uniform
+      if (need_pass) {
+        const float hscale = hist_hi > best_cost ? 255.0f / (hist_hi - best_cost) : 0.f;
+        for (int s = tid; s < S; s += NT) {
+          const float c = cost_cur[s];
+          c_le += (int)(c <= beam_cutoff) & (int)(c < INF);
+          c_lt += (int)(c < beam_cutoff);
+          if (c < INF) atomicAdd(&red.hist[KthBin(c, best_cost, hscale)], 1u);
+        }
+        const int wa = wv::Sum(c_le), wb = wv::Sum(c_lt);
+        if (lane == 0) xr[rb][wave] = make_int4(wa, wb, 0, 0);
+        LdsBarrier();
+        c_le = 0; c_lt = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) { const int4 e = xr[rb][k]; c_le += e.x; c_lt += e.y; }
+        rb ^= 1;
+      }
+      int kth = -1;
+      if (N > o.max_active && c_lt > o.max_active) kth = o.max_active;
+      else if (N > o.min_active && !(o.min_active == 0 || c_le > o.min_active)) kth = o.min_active;
+      float kth_cost = 0.f;
+      int kth_le = 0;
+      if (need_pass) {
+        if (kth >= 0) kth_cost = KthFromHist<NT>(red, cost_cur, S, kth, best_cost, hist_hi, &kth_le);
+        else for (int i = tid; i < 256; i += NT) red.hist[i] = 0;
+      }
+      float cur_cutoff, adaptive_beam;
+      int n_exp;
+      if (N > o.max_active && c_lt > o.max_active) {
+        adaptive_beam = kth_cost - best_cost + o.beam_delta;
+        cur_cutoff = kth_cost;
+        n_exp = kth_le;
+        max_active_frames++;
+      } else {
+        float min_active_cutoff = INF;
+        bool loosened;
+        if (N > o.min_active) {
+          min_active_cutoff = kth >= 0 ? kth_cost : best_cost;
+          loosened = min_active_cutoff > beam_cutoff;
+        } else {
+          loosened = true;
+        }
+        if (loosened) {
+          adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;
+          cur_cutoff = min_active_cutoff;
+          n_exp = N > o.min_active ? kth_le : N;
+          if (N > o.min_active) min_active_frames++;
+        } else {
+          adaptive_beam = o.beam;
+          cur_cutoff = beam_cutoff;
+          n_exp = need_pass ? c_le : N;
+        }
+      }
+      const float cost_offset = -best_cost;
+      if (tid == 0) n_expanded += (unsigned)n_exp;
+      // ---- arc pass A: every expanded token's arcs -- tot + adaptive_beam per arc and (minimum) per list position, the seed
+      float tot_a[KE];
+      bool exp_a[KE];
+      const int best_addr = best_state * 4;
+#pragma unroll
+      for (int a = 0; a < KE; a++) {
+        const int saddr = ea[a].x & 0xFFFF;
+        const float c = *reinterpret_cast<const float *>(smem + saddr);
+        const bool expd = (c < INF) & (c <= cur_cutoff);
+        const float lk = llv[a];
+        const float gc = __int_as_float(ea[a].z);
+        const float tot = (c + (cost_offset - lk)) + gc;
+        const float alt = ((gc + cost_offset) - lk) + c;                           // :752-757, the seed's own expression
+        const float v = tot + adaptive_beam;
+        tot_a[a] = tot;
+        exp_a[a] = expd;
+        arcv[a * NT + tid] = expd ? v : INF;
+        if (expd) {
+          atomicMin(&ordm[rank16[saddr >> 2]], wv::FloatToOrdered(v));
+          if (saddr == best_addr) atomicMin(&seed_u, wv::FloatToOrdered(alt + adaptive_beam));
+        }
+      }
+      {
+        const float *row = loglikes + (ll_base + (f + 1 < T ? f + 1 : f)) * ld;
+#pragma unroll
+        for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
+      }
+      LdsBarrier();
+      // ---- the cutoff in front of every list position; the frame's final one
+      const unsigned tot_min_u = BlockScanExcl<NT, true>(ordm, N, xr, rb);
+      const unsigned seed_now = seed_u;
+      const float next_cutoff = wv::OrderedToFloat(min(seed_now, tot_min_u));
+      // ---- arc pass B: the reference's test, arc by arc
+#pragma unroll
+      for (int a = 0; a < KE; a++) {
+        if (exp_a[a]) {
+          const int saddr = ea[a].x & 0xFFFF, first = eaux[a] >> 8, local = eaux[a] & 255;
+          const unsigned r_src = rank16[saddr >> 2];
+          unsigned cu = min(seed_now, ordm[r_src]);
+          for (int k = 0; k < local; k++) cu = min(cu, wv::FloatToOrdered(arcv[first + k]));
+          const unsigned tu = wv::FloatToOrdered(tot_a[a]);
+          n_arcs++;
+          if (tu < cu) {
+            const unsigned daddr = (unsigned)ea[a].x >> 16;
+            atomicMin(reinterpret_cast<unsigned long long *>(smem + daddr), ((unsigned long long)tu << 32) | (unsigned)ea[a].w);
+            atomicMin(&fkey[(daddr - (unsigned)rg.key_base) >> 3], (r_src << 8) | (unsigned)local);
+          }
+        }
+      }
+      if (tid == 0) *reinterpret_cast<float4 *>(finfo + (size_t)f * 4) = make_float4(cost_offset, cur_cutoff, next_cutoff, adaptive_beam);
+      closure_cutoff = next_cutoff;
+      LdsBarrier();          // every emitting insertion has landed
+      // ---- list positions of the states the emitting arcs inserted
+      for (int s = tid; s < S; s += NT) { const unsigned k = fkey[s]; if (k != 0xFFFFFFFFu) atomicOr(&maskE[k >> 8], 1u << (k & 255u)); }
+      for (int i = tid; i < (E > S ? E : S); i += NT) maskX[i] = 0u;      // (arcv is done)
+      LdsBarrier();
+      for (int r = tid; r < N; r += NT) ordm[r] = (unsigned)__popc(maskE[r]);
+      LdsBarrier();
+      n_emit = (int)BlockScanExcl<NT, false>(ordm, N, xr, rb);
+      for (int s = tid; s < S; s += NT) {
+        const unsigned k = fkey[s];
+        if (k != 0xFFFFFFFFu) rank16[s] = (unsigned short)(ordm[k >> 8] + (unsigned)__popc(maskE[k >> 8] & ((1u << (k & 255u)) - 1u)));
+      }
+      LdsBarrier();
+    }
+    // ---- ProcessNonemitting: source tokens in reverse list order, one round (no epsilon chains)
+    int n_eps = 0;
+    if (KX > 0 && rg.eps_depth != 0) {
+#pragma unroll
+      for (int a = 0; a < KX; a++) {
+        const unsigned saddr = (unsigned)xa[a].x & 0xFFFFu;
+        const float c = wv::OrderedToFloat(*reinterpret_cast<const unsigned *>(smem + saddr));      // empty key -> NaN -> fails both tests
+        const float tot = c + __int_as_float(xa[a].z);
+        const bool live = c < closure_cutoff;
+        n_arcs += (unsigned)live;
+        if (live & (tot < closure_cutoff)) {
+          const unsigned daddr = (unsigned)xa[a].x >> 16;
+          atomicMin(reinterpret_cast<unsigned long long *>(smem + daddr), ((unsigned long long)wv::FloatToOrdered(tot) << 32) | (unsigned)xa[a].w);
+          const unsigned rs = rank16[(saddr - 4u - (unsigned)rg.key_base) >> 3];
+          atomicMin(&fkey[(daddr - (unsigned)rg.key_base) >> 3], 0x80000000u | (((unsigned)n_emit - 1u - rs) << 8) | (unsigned)xaux[a]);
+        }
+      }
+      LdsBarrier();
+      for (int s = tid; s < S; s += NT) { const unsigned k = fkey[s]; if (k != 0xFFFFFFFFu && (k & 0x80000000u)) atomicOr(&maskX[(k & 0x7FFFFFFFu) >> 8], 1u << (k & 255u)); }
+      LdsBarrier();
+      for (int r = tid; r < n_emit; r += NT) ordm[r] = (unsigned)__popc(maskX[r]);
+      LdsBarrier();
+      n_eps = (int)BlockScanExcl<NT, false>(ordm, n_emit, xr, rb);
+      for (int s = tid; s < S; s += NT) {
+        const unsigned k = fkey[s];
+        if (k != 0xFFFFFFFFu && (k & 0x80000000u)) {
+          const unsigned r = (k & 0x7FFFFFFFu) >> 8;
+          rank16[s] = (unsigned short)((unsigned)n_emit + ordm[r] + (unsigned)__popc(maskX[r] & ((1u << (k & 255u)) - 1u)));
+        }
+      }
+      LdsBarrier();
+    }
+    (void)n_eps;
+    // ---- commit frame f+1: every token of the list (the ones at or beyond the cutoff too), statistics for the next frame
+    int *bp_row = bp + (size_t)(f + 1) * S;
+    st_min = INF; st_max = -INF; st_arg = 0x7fffffff; st_cnt = 0;
+    for (int s = tid; s < S; s += NT) {
+      const unsigned long long k = key_next[s];
+      const bool exists = k != RS_EMPTY;
+      const float c = wv::OrderedToFloat((unsigned)(k >> 32));
+      bp_row[s] = exists ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
+      cost_cur[s] = exists ? c : INF;
+      key_next[s] = RS_EMPTY;
+      fkey[s] = 0xFFFFFFFFu; ordm[s] = 0xFFFFFFFFu; maskE[s] = 0u;
+      st_cnt += (int)exists;
+      st_max = exists ? fmaxf(st_max, c) : st_max;
+      const bool better = exists & (c < st_min);
+      st_min = better ? c : st_min;
+      st_arg = better ? s : st_arg;
+    }
+    if (tid == 0) seed_u = 0xFFFFFFFFu;
+    n_alive += (unsigned)st_cnt;
+  }
+  __syncthreads();
+  if (!finishing) {
+    for (int s = tid; s < S; s += NT) { state[s] = cost_cur[s]; state[S + 4 + s] = (float)rank16[s]; }
+    if (tid == 0) { state[S] = closure_cutoff; state[S + 1] = (float)error; }
+    for (int i = tid; i < 8; i += NT) red.ctr[i] = 0;
+    __syncthreads();
+    atomicAdd(&red.ctr[0], n_expanded);
+    atomicAdd(&red.ctr[1], n_arcs);
+    atomicAdd(&red.ctr[2], n_insert);
+    atomicAdd(&red.ctr[3], n_alive);
+    __syncthreads();
+    if (tid == 0) {
+      long long *c8 = w.counters + slot * 8;
+      for (int i = 0; i < 4; i++) c8[i] += (long long)red.ctr[i];
+      c8[5] += max_active_frames;
+      c8[6] += min_active_frames;
+    }
+    return;
+  }
+  FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
+                      n_insert, n_alive, max_active_frames, min_active_frames, slot);
+}
+
 template <int NT, int KE, int KX>
 static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DenseWork &w, size_t smem, int f_begin, int f_end, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeKernel<NT, KE, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&RegDecodeExactKernel<NT, KE, KX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
+  }
+  if (o.exact_order && r.exact_ok && h.num_states <= 4 * NT) {
+    // the order's arrays behind the keys (RegDecodeExactKernel): list positions, insertion keys, per-position minima / sums, masks, per-arc values
+    const int S = h.num_states, E = NT * KE;
+    const size_t xb = ((size_t)r.key_base + 8 * (size_t)(S + 1) + 15) & ~(size_t)15;
+    const size_t need = xb + (((size_t)2 * S + 15) & ~(size_t)15) + (size_t)12 * S + (size_t)4 * (E > S ? E : S);
+    const size_t sm = smem > need ? smem : need;
+    hipLaunchKernelGGL((RegDecodeExactKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), sm, s, h, r, o, g, loglikes, ld, w, (int)sm, f_begin, f_end);
+    return;
   }
   hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem, f_begin, f_end);
 }

@@ -625,13 +625,23 @@ void Model::ToDevice() {
         const int key_base = (int)(((size_t)(S + 1) * 4 + 15) & ~(size_t)15);
         const int pad_e = (4 * S) | ((key_base + 8 * S) << 16), pad_x = (key_base + 8 * S + 4) | ((key_base + 8 * S) << 16);
         std::vector<int4> et((size_t)ke * nt, make_int4(pad_e, 0, 0, 0)), xt((size_t)kx * nt, make_int4(pad_x, 0, 0, 0));
+        std::vector<int> eaux((size_t)ke * nt, 0), xaux((size_t)kx * nt, 0);
+        std::vector<int> first_e(S, -1), cnt_e(S, 0), cnt_x(S, 0);
         size_t ne = 0, nx = 0;
         for (size_t a = 0; a < A; a++) {
           const int4 &fa = arcs[a];
           const int dst_addr = (key_base + 8 * fa.w) << 16;
-          if (fa.x == 0) xt[nx++] = make_int4((key_base + 8 * src[a] + 4) | dst_addr, 0, fa.z, (int)a);
-          else et[ne++] = make_int4((4 * src[a]) | dst_addr, fa.x - 1, fa.z, (int)a);
+          if (fa.x == 0) {
+            xaux[nx] = cnt_x[src[a]]++;
+            xt[nx++] = make_int4((key_base + 8 * src[a] + 4) | dst_addr, 0, fa.z, (int)a);
+          } else {
+            if (first_e[src[a]] < 0) first_e[src[a]] = (int)ne;
+            eaux[ne] = (first_e[src[a]] << 8) | (cnt_e[src[a]]++ & 255);
+            et[ne++] = make_int4((4 * src[a]) | dst_addr, fa.x - 1, fa.z, (int)a);
+          }
         }
+        int max_e = 0, max_x = 0;
+        for (int st = 0; st < S; st++) { max_e = std::max(max_e, cnt_e[st]); max_x = std::max(max_x, cnt_x[st]); }
         // longest path of the epsilon subgraph = number of closure rounds; cyclic or deep -> the kernel votes instead
         int depth = 0;
         {
@@ -649,6 +659,11 @@ void Model::ToDevice() {
         reg_dev_.key_base = key_base;
         reg_dev_.e_tab = static_cast<int4 *>(UploadBytes(et.data(), et.size() * sizeof(int4)));
         reg_dev_.x_tab = static_cast<int4 *>(UploadBytes(xt.data(), xt.size() * sizeof(int4)));
+        reg_dev_.e_aux = Upload(eaux);
+        reg_dev_.x_aux = Upload(xaux);
+        // the reference's token order can be followed exactly where its hash table cannot collide (it starts with 1000 buckets),
+        // the closure is one round, and a state's arcs fit one 32-bit mask (decode_reg.hip: RegDecodeExactKernel)
+        reg_dev_.exact_ok = (S <= 1000 && depth >= 0 && depth <= 1 && max_e <= 32 && max_x <= 32) ? 1 : 0;
       }
     }
   }
@@ -687,6 +702,8 @@ std::string Model::Describe() const {
   os << "halo: L=" << L_ << " R=" << R_ << "\n";
   // (state, not structure: calls repeated on the exact-FP32 layer GEMMs because an activation left the fp16 split's range, and
   // whether the model has changed to those kernels for good)
+  os << "token_order: " << (ExactOrder() && reg_dev_.exact_ok ? "exact (the reference's running cutoff in its hash order)" : "final cutoff")
+     << (ExactOrder() && !reg_dev_.exact_ok ? " (exact_token_order asked for: not applicable to this graph)" : "") << "\n";
   os << "layer_gemm: range_retries=" << range_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0) << "\n";
   return os.str();
 }
@@ -1065,6 +1082,7 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   sp->tok_cap = (int)tok_cap_l;
   sp->dopts.beam = opts_.beam; sp->dopts.lattice_beam = opts_.lattice_beam; sp->dopts.beam_delta = opts_.beam_delta;
   sp->dopts.max_active = opts_.max_active; sp->dopts.min_active = opts_.min_active;
+  sp->dopts.exact_order = ExactOrder() ? 1 : 0;
   size_t need = (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)sp->max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
   if (sp->use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
     need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
@@ -1096,7 +1114,7 @@ void Model::AllocSearch(SearchPlan *sp, DeviceArena &arena_, hipStream_t s, bool
     dw.path = arena_.AllocT<int>((size_t)n_utts * dw.path_cap * 2);
     if (!pooled_frames) {      // (streams keep back-pointer rows, frame info, parked costs and counters in their pool)
       dw.bp = arena_.AllocT<int>((size_t)n_utts * (maxT + 1) * S);
-      dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (S + 4));
+      dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (2 * (size_t)S + 4));
       RS_HIP(hipMemsetAsync(w.counters, 0, sizeof(long long) * 8 * (size_t)n_utts, s));
     }
   }

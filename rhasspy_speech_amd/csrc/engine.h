@@ -4,6 +4,7 @@
 
 #include <condition_variable>
 #include <atomic>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -132,6 +133,8 @@ class Model {
   std::unique_ptr<Result> DecodeBatchHost(const int16_t *const *pcm, const int32_t *n_samples, int n_utts, int nbest,
                                           float lat_scale, bool streaming = false);
   const rs_decode_opts &opts() const { return opts_; }
+  // rs_decode_opts.exact_token_order, RS_EXACT_ORDER overriding (read per call: tests compare the two searches on one model)
+  bool ExactOrder() const { const char *e = std::getenv("RS_EXACT_ORDER"); return e ? std::atoi(e) != 0 : opts_.exact_token_order != 0; }
   const FeatureConfig &features() const { return fc_; }
   const AcousticModel &am() const { return am_; }
   const Hclg &hclg() const { return hclg_; }

@@ -224,6 +224,7 @@ struct HclgDev {
 struct DecodeOptsDev {
   float beam, lattice_beam, beam_delta;
   int max_active, min_active;
+  int exact_order;            // rs_decode_opts.exact_token_order: the reference's order-dependent token creation (decode_reg.hip), where the graph allows it
 };
 struct DecodeWork {
   // per utterance
@@ -287,7 +288,7 @@ struct DenseWork {
   int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
   int path_cap;
   // resumable decoding (decode_reg.hip): token costs and scalars carried between the time slabs of one utterance
-  float *state_cost;          // n_utts x (S + 4): S costs, then {closure cutoff, error flag}
+  float *state_cost;          // n_utts x (2 S + 4): S costs, then {closure cutoff, error flag, -, -}, then S list positions (exact token order)
   // Streams (decode_reg.hip, win_begin != null): utterance u decodes frames [win_begin[u], win_end[u]) (win_begin -1 starts the
   // stream), of which d_num_frames[u] exist so far; win_final[u] != 0 ends it (traceback + results).  Its back-pointer / frame
   // info rows live at pool row pool_row[u] onwards (bp, frame_info = the pools' bases), its parked costs and counters in slot
@@ -305,6 +306,11 @@ struct RegGraphDev {
   int key_base = 0;           // byte offset of key_next[] in the dynamic LDS region
   const int4 *e_tab;          // [ke][nt] {4*src | (key_base + 8*dst) << 16, pdf, weight bits, forward arc index}
   const int4 *x_tab;          // [kx][nt] {(key_base + 8*src + 4) | (key_base + 8*dst) << 16, 0, weight bits, forward arc index}
+  // RegDecodeExactKernel: per emitting arc (table position of its source state's first emitting arc) << 8 | its number among
+  // them; per epsilon arc its number among its source's epsilon arcs.  exact_ok: <= 1000 states, epsilon depth <= 1, <= 32 arcs of
+  // either kind per state.
+  const int *e_aux, *x_aux;
+  int exact_ok = 0;
 };
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx);
 // Decodes frames [f_begin, f_end) of every utterance (f_begin = -1 starts an utterance; the slab that contains an

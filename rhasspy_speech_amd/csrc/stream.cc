@@ -167,7 +167,7 @@ StreamPool *Model::Pool() {
   if (p->reg) {
     p->bp = static_cast<int *>(dalloc(R * p->S * 4));
     p->finfo = static_cast<float *>(dalloc(R * 16));
-    p->dec_state = static_cast<float *>(dalloc((size_t)p->max_slots * (p->S + 4) * 4));
+    p->dec_state = static_cast<float *>(dalloc((size_t)p->max_slots * (2 * (size_t)p->S + 4) * 4));
   }
   p->dec_ctr = static_cast<long long *>(dalloc((size_t)p->max_slots * 64));
   if (fc_.ie.present) {
@@ -599,6 +599,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     DecodeOptsDev dopts;
     dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
     dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
+    dopts.exact_order = ExactOrder() ? 1 : 0;
     LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw, 0, 0, qc, final);
     if (final) LaunchCopyRows(p->dec_ctr, 16, D(o_slots), sp.w.counters, 16, nullptr, n, 16, qc);
   } else if (final) {

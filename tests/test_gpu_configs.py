@@ -223,6 +223,29 @@ def test_config3_mixed_batch_1024_two_zamia_size_models(tmp_path_factory):
         assert half[i] == got[i]
 
 
+def test_exact_token_order_closes_the_grammar_graph_deviation(tmp_path_factory):
+    """Config 3 with rs_decode_opts.exact_token_order = 1 (the reference's running cutoff in its hash order, decode_reg.hip): of
+    the two utterances of the 1024 whose costs differ from the reference's without it, c3_mixed_fr 110 -- the order-dependent one
+    -- now has the reference's cost; c3_mixed_de 238 stays: the CPU oracle, which follows the order too, also lands on the
+    kernels' cost there (a decision at the resolution of the log-likelihoods).  No other utterance moves."""
+    from rhasspy_speech_amd import _lib
+    names, pcms = configs.mixed_utterances()
+    for key, tag, still in (("de_DE-like", "c3_mixed_de", {238}), ("fr_FR-like", "c3_mixed_fr", set())):
+        m = configs.MIXED_MODELS[key]
+        md, gd = configs.build_grammar_model(tmp_path_factory.mktemp(tag), m["model_seed"], m["graph_seed"])
+        model = _lib.Model(md, gd, _lib.default_opts(exact_token_order=1))
+        utts = [p for nm, p in zip(names, pcms) if nm == key]
+        res = model.decode_batch(utts)
+        ref_words, ref_g, ref_a = configs.load_golden(tag)
+        off = set()
+        for u in range(len(utts)):
+            assert res.words(u) == ref_words[u]
+            g, a = res.costs(u)
+            if not (np.isclose(g, ref_g[u], rtol=COST_RTOL, atol=COST_ATOL) and np.isclose(a, ref_a[u], rtol=COST_RTOL, atol=COST_ATOL)):
+                off.add(u)
+        assert off == still, (tag, off)
+
+
 def test_sharded_entry_point_issues_the_rccl_all_gather(zam_grammar):
     """rs_decode_batch_sharded with a real ncclComm_t (a one-rank RCCL communicator: the test box has one GPU): the records
     come back through ncclAllGather on the device and equal the ones of the collective-free call; a too-short utterance

@@ -156,6 +156,47 @@ def test_decoder_variants_agree(case_cache, name, extra, monkeypatch):
             assert got.counters(u)[5] == ref.counters(u)[5] and got.counters(u)[6] == ref.counters(u)[6], variant
 
 
+@pytest.mark.parametrize("name,extra", [("tiny_u0", {}), ("tiny_hmm_u6", {}), ("zam_u0", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0)),
+                                        ("zam_u0", dict(max_active=400, min_active=300, beam=6.0)), ("zam_u1", dict(max_active=40, min_active=0, beam=16.0)),
+                                        ("zam_long30", dict(min_active=350))])
+def test_exact_token_order_is_the_sequential_decoder(case_cache, name, extra, monkeypatch):
+    """rs_decode_opts.exact_token_order: the grammar-graph search creates tokens against the reference's RUNNING cutoff in its
+    HashList order (lattice-faster-decoder.cc:734-787, hash-list-inl.h:125-165).  Checked against oracle/decoder.c -- the
+    sequential restatement that follows that order, pinned to the reference's costs by tests/test_oracle_golden.py -- on the SAME
+    log-likelihoods (the GPU's own): the decisions are then the same float comparisons, so the best path's costs must agree to
+    the last bits of their float sums, the token counts of every frame add up to the same total, and min-active / max-active
+    bound on the same number of frames.  With pruning options that bind on most frames; batch, stream and time-slab paths."""
+    from oracle import kaldi_formats as kf
+    from oracle import pipeline
+    from rhasspy_speech_amd import _lib, synth
+    model_dir, graph_dir, _, pcm = case_cache(name)
+    o = dict(cases.CASES[name].get("opts", {}))
+    o.update(extra)
+    model, _ = make_model(case_cache, name, exact_token_order=1, **extra)
+    plain, _ = make_model(case_cache, name, **extra)
+    pcms = [pcm] + [synth.synth_utterance(700 + i, n) for i, n in enumerate([48000, 17000])]
+    res = model.decode_batch(pcms)
+    assert "token_order: exact" in model.describe(), model.describe()
+    base = plain.decode_batch(pcms)
+    orc = pipeline.Oracle(model_dir, graph_dir, **o)
+    for u in range(len(pcms)):
+        lattice, ctr = pipeline.decode(orc.fst, orc.id2pdf, res.matrix(u, 2), **orc.opts)
+        best = pipeline.lat.nbest(lattice, 1, orc.opts["lattice_beam"], 1.0)[0]
+        assert res.words(u) == best.words
+        np.testing.assert_allclose(res.costs(u), (best.graph_cost, best.acoustic_cost), rtol=2e-6, atol=1e-4)
+        assert res.counters(u)[5] == ctr[5] and res.counters(u)[6] == ctr[6], (res.counters(u), ctr)
+        assert res.counters(u)[3] == ctr[3] + ctr[7], (res.counters(u), ctr)  # tokens on the lists of all frames: the extras too
+        assert res.words(u) == base.words(u)
+    # the stream path parks and resumes the list order with the costs
+    st = _lib.Stream(model)
+    st.accept(pcm[: len(pcm) // 2]); st.advance(); st.accept(pcm[len(pcm) // 2:])
+    got = st.finish()
+    lattice, ctr = pipeline.decode(orc.fst, orc.id2pdf, got.matrix(0, 2), **orc.opts)
+    best = pipeline.lat.nbest(lattice, 1, orc.opts["lattice_beam"], 1.0)[0]
+    assert got.words(0) == best.words and got.counters(0)[3] == ctr[3] + ctr[7]
+    np.testing.assert_allclose(got.costs(0), (best.graph_cost, best.acoustic_cost), rtol=2e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("name,extra", [("tiny_arpa_u7", {}), ("tiny_arpa_prune_u8", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0))])
 def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra, monkeypatch):
     """n-best lists (LatticeKernel on the token lists the search leaves behind) from the live-state-table search, from the dense-table
