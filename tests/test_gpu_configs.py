@@ -37,13 +37,11 @@ def zam_grammar(tmp_path_factory):
 
 
 def _check_against_reference(name, words_of, costs_of, n):
-    """Every utterance: transcript equal to the reference's.  Costs within tolerance -- except, at most, 1 % of the
-    utterances: the reference creates tokens while its running `next_cutoff` tightens (lattice-faster-decoder.cc:774-787),
-    so which tokens beyond best + adaptive-beam exist depends on its HashList iteration order; the kernels prune with the
-    final cutoff.  When max-active / min-active binds, such an order-dependent token occasionally
-    carries a (slightly) cheaper alignment of the SAME words: observed on 2 of the 1600 utterances of configs 1-4 (c2_arpa
-    162, c3_mixed_fr), never a different transcript.  tests/test_oracle_golden.py pins the CPU oracle, which follows the hash
-    order, to the reference's costs on exactly those utterances."""
+    """Every utterance: transcript equal to the reference's; 1-best costs within tolerance -- except on the utterances listed in
+    ORDER_DEPENDENT_COSTS (below), and on those by a few units of cost at most: the reference creates tokens while its running
+    `next_cutoff` tightens (lattice-faster-decoder.cc:774-787), so which tokens beyond best + adaptive-beam exist depends on its
+    HashList iteration order; the kernels prune with the final cutoff unless rs_decode_opts.exact_token_order is set (DESIGN.md
+    section 2).  tests/test_oracle_golden.py pins the CPU oracle, which follows the hash order, to the reference's costs."""
     ref_words, ref_g, ref_a = configs.load_golden(name)
     assert len(ref_words) == n
     bad = [u for u in range(n) if words_of(u) != ref_words[u]]
@@ -52,8 +50,9 @@ def _check_against_reference(name, words_of, costs_of, n):
     ref_tot, tot = ref_g.astype(np.float64) + ref_a, got[:, 0] + got[:, 1]
     off = [u for u in range(n) if not (np.isclose(got[u, 0], ref_g[u], rtol=COST_RTOL, atol=COST_ATOL) and
                                        np.isclose(got[u, 1], ref_a[u], rtol=COST_RTOL, atol=COST_ATOL))]
-    assert len(off) <= max(1, n // 100), f"{name}: costs of {len(off)} of {n} utterances differ from the reference: {off[:10]}"
-    for u in off:       # same words through an alignment the order-dependent pruning lost: close, and a few units of cost at most
+    known = ORDER_DEPENDENT_COSTS.get(name, {})
+    assert set(off) <= set(known), f"{name}: costs of utterances {sorted(set(off) - set(known))} differ from the reference's"
+    for u in off:       # same words through an alignment the order-dependent pruning lost: a few units of cost at most
         assert abs(tot[u] - ref_tot[u]) < 4.0, (name, u, got[u], ref_g[u], ref_a[u])
     return off
 
