@@ -87,7 +87,9 @@ def test_config1_headline_batch_vs_reference(zam_grammar):
 # COST: same 5-best word sequences in the same order, the total of some hypothesis off by the amount noted (ours minus the
 # reference's; the negative one is the reference pruning, with its larger token count, a token the kernels keep).  3 of 1600.
 # (c2 162 and c3_fr 110: the CPU oracle, which follows the reference's hash order, lands on the reference's cost -- test_oracle_golden.py;
-# c3_de 238: the oracle gets the kernels' cost, a pruning decision at the resolution of the log-likelihoods.)
+# c3_de 238: not a decoder effect -- on frame 55 the fifth and sixth best UBM Gaussians are 2.4e-6 apart in score, the reference's BLAS
+# sums select the other one, the iVector moves by 2.6e-3; the oracle decoder on the reference's own log-likelihoods gives the
+# reference's cost: profiles/r04/c3_de_238.txt.)
 ORDER_DEPENDENT_COSTS = {"c2_arpa": {162: 2.05}, "c3_mixed_de": {238: 0.21}, "c3_mixed_fr": {110: -0.93}}
 
 
