@@ -501,6 +501,39 @@ def test_concurrent_calls_on_one_model(zam_grammar):
                 _same_result(res, u, ref[b], u)
 
 
+def test_two_utterance_groups_per_call(zam_grammar, monkeypatch):
+    """RS_SUBBATCHES=2 (read at model load): a call of 32 or more utterances runs as two groups on two streams and two host
+    threads.  The second group's stream must start behind the upload of the samples, which is queued on the first one's
+    (round 3's advisor finding: nothing ordered them); results equal the one-group model's, call after call, from host memory
+    (fresh upload every call) and with other calls in flight."""
+    from rhasspy_speech_amd import _lib, synth
+    monkeypatch.setenv("RS_SUBBATCHES", "2")
+    two = _lib.Model(*zam_grammar, _lib.default_opts())
+    monkeypatch.delenv("RS_SUBBATCHES")
+    one = _lib.Model(*zam_grammar, _lib.default_opts())
+    batches = [[synth.synth_utterance(23000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(96 + 32 * b)] for b in range(3)]
+    ref = [one.decode_batch(pcms) for pcms in batches]
+    for rep in range(6):
+        for b, pcms in enumerate(batches):
+            got = two.decode_batch(pcms)
+            for u in range(len(pcms)):
+                _same_result(got, u, ref[b], u)
+    out = [[] for _ in batches]
+
+    def run(b):
+        for _ in range(3):
+            out[b].append(two.decode_batch(batches[b]))
+    ts = [threading.Thread(target=run, args=(b,)) for b in range(len(batches))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for b, pcms in enumerate(batches):
+        for res in out[b]:
+            for u in range(len(pcms)):
+                _same_result(res, u, ref[b], u)
+
+
 def test_overlapped_contexts_use_the_cu_exclusive_gemm(zam_grammar, monkeypatch):
     """RS_GEMM_B3_EXCLUSIVE=1: the wide layers run as CU-exclusive 512-thread workgroups (nnet_gemm_b3.hip, WM = 2) when a model
     has several decode contexts.  Same results as the default model, sequentially and from four threads at once."""
