@@ -514,6 +514,10 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
   }
   __syncthreads();
   int n_emit = 1;                                 // tokens the emitting arcs put on the list (the start token for the first closure)
+#ifdef RS_DECODE_PROFILE
+  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = clock64();
+#endif
 
   for (int f = f_begin; f < f_stop && !error; f++) {
     if (f >= 0) {
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
         hist_hi = wv::OrderedToFloat(bx);
       }
       if (N == 0) { error = 1; break; }
+      RS_T(0);
       // ---- GetCutoff over every token of the list (:644-711)
       const float beam_cutoff = best_cost + o.beam;
       int c_le = 0, c_lt = 0;
@@ -606,6 +611,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       }
       const float cost_offset = -best_cost;
       if (tid == 0) n_expanded += (unsigned)n_exp;
+      RS_T(1);
       // ---- arc pass A: every expanded token's arcs -- tot + adaptive_beam per arc and (minimum) per list position, the seed
       float tot_a[KE];
       bool exp_a[KE];
@@ -634,10 +640,12 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
         for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
       }
       LdsBarrier();
+      RS_T(2);
       // ---- the cutoff in front of every list position; the frame's final one
       const unsigned tot_min_u = BlockScanExcl<NT, true>(ordm, N, xr, rb);
       const unsigned seed_now = seed_u;
       const float next_cutoff = wv::OrderedToFloat(min(seed_now, tot_min_u));
+      RS_T(3);
       // ---- arc pass B: the reference's test, arc by arc
 #pragma unroll
       for (int a = 0; a < KE; a++) {
@@ -658,6 +666,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       if (tid == 0) *reinterpret_cast<float4 *>(finfo + (size_t)f * 4) = make_float4(cost_offset, cur_cutoff, next_cutoff, adaptive_beam);
       closure_cutoff = next_cutoff;
       LdsBarrier();          // every emitting insertion has landed
+      RS_T(4);
       // ---- list positions of the states the emitting arcs inserted
       for (int s = tid; s < S; s += NT) { const unsigned k = fkey[s]; if (k != 0xFFFFFFFFu) atomicOr(&maskE[k >> 8], 1u << (k & 255u)); }
       for (int i = tid; i < (E > S ? E : S); i += NT) maskX[i] = 0u;      // (arcv is done)
@@ -671,6 +680,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       }
       LdsBarrier();
     }
+    RS_T(5);
     // ---- ProcessNonemitting: source tokens in reverse list order, one round (no epsilon chains)
     int n_eps = 0;
     if (KX > 0 && rg.eps_depth != 0) {
@@ -704,6 +714,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       LdsBarrier();
     }
     (void)n_eps;
+    RS_T(6);
     // ---- commit frame f+1: every token of the list (the ones at or beyond the cutoff too), statistics for the next frame
     int *bp_row = bp + (size_t)(f + 1) * S;
     st_min = INF; st_max = -INF; st_arg = 0x7fffffff; st_cnt = 0;
@@ -723,6 +734,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
     }
     if (tid == 0) seed_u = 0xFFFFFFFFu;
     n_alive += (unsigned)st_cnt;
+    RS_T(7);
   }
   __syncthreads();
   if (!finishing) {
@@ -745,6 +757,11 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
   }
   FinishUtterance<NT>(red, h, g, loglikes, ld, w, cost_cur, bp, finfo, smem, smem_bytes, u, T, S, ll_base, error, n_expanded, n_arcs,
                       n_insert, n_alive, max_active_frames, min_active_frames, slot);
+#ifdef RS_DECODE_PROFILE
+  if (u == 0 && tid == 0)
+    printf("reg decode (exact order) cycles/frame: stats %lld cutoff %lld arcs-A %lld scan %lld arcs-B %lld emit-ranks %lld closure+ranks %lld commit %lld (T=%d)\n",
+           prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[5] / T, prof[6] / T, prof[7] / T, T);
+#endif
 }
 
 template <int NT, int KE, int KX>
