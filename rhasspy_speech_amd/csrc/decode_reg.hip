@@ -399,8 +399,9 @@ __device__ __forceinline__ unsigned WaveScanInclMinU(unsigned v) {
   return v;
 }
 // exclusive scan (minimum of ordered keys, or sum) of arr[0 .. n) in place, n <= 4 NT; returns the total; one barrier inside, one after
+// (popc_of: scan the populations of these masks instead of arr's contents; arr receives the result)
 template <int NT, bool IS_MIN>
-__device__ __forceinline__ unsigned BlockScanExcl(unsigned *arr, int n, int4 (*xr)[NT / 64], int &rb) {
+__device__ __forceinline__ unsigned BlockScanExcl(unsigned *arr, int n, int4 (*xr)[NT / 64], int &rb, const unsigned *popc_of = nullptr) {
   constexpr int NW = NT / 64, PER = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned I = IS_MIN ? 0xFFFFFFFFu : 0u;
@@ -408,7 +409,7 @@ __device__ __forceinline__ unsigned BlockScanExcl(unsigned *arr, int n, int4 (*x
 #pragma unroll
   for (int j = 0; j < PER; j++) {
     const int idx = tid * PER + j;
-    v[j] = idx < n ? arr[idx] : I;
+    v[j] = idx < n ? (popc_of ? (unsigned)__popc(popc_of[idx]) : arr[idx]) : I;
     run = IS_MIN ? min(run, v[j]) : run + v[j];
   }
   const unsigned incl = IS_MIN ? WaveScanInclMinU(run) : (unsigned)WaveScanIncl((int)run);
@@ -669,11 +670,9 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       RS_T(4);
       // ---- list positions of the states the emitting arcs inserted
       for (int s = tid; s < S; s += NT) { const unsigned k = fkey[s]; if (k != 0xFFFFFFFFu) atomicOr(&maskE[k >> 8], 1u << (k & 255u)); }
-      for (int i = tid; i < (E > S ? E : S); i += NT) maskX[i] = 0u;      // (arcv is done)
+      for (int i = tid; i < S; i += NT) maskX[i] = 0u;      // (arcv is done; positions < n_emit <= S are used)
       LdsBarrier();
-      for (int r = tid; r < N; r += NT) ordm[r] = (unsigned)__popc(maskE[r]);
-      LdsBarrier();
-      n_emit = (int)BlockScanExcl<NT, false>(ordm, N, xr, rb);
+      n_emit = (int)BlockScanExcl<NT, false>(ordm, N, xr, rb, maskE);
       for (int s = tid; s < S; s += NT) {
         const unsigned k = fkey[s];
         if (k != 0xFFFFFFFFu) rank16[s] = (unsigned short)(ordm[k >> 8] + (unsigned)__popc(maskE[k >> 8] & ((1u << (k & 255u)) - 1u)));
@@ -701,9 +700,7 @@ __global__ __launch_bounds__(NT) void RegDecodeExactKernel(HclgDev h, RegGraphDe
       LdsBarrier();
       for (int s = tid; s < S; s += NT) { const unsigned k = fkey[s]; if (k != 0xFFFFFFFFu && (k & 0x80000000u)) atomicOr(&maskX[(k & 0x7FFFFFFFu) >> 8], 1u << (k & 255u)); }
       LdsBarrier();
-      for (int r = tid; r < n_emit; r += NT) ordm[r] = (unsigned)__popc(maskX[r]);
-      LdsBarrier();
-      n_eps = (int)BlockScanExcl<NT, false>(ordm, n_emit, xr, rb);
+      n_eps = (int)BlockScanExcl<NT, false>(ordm, n_emit, xr, rb, maskX);
       for (int s = tid; s < S; s += NT) {
         const unsigned k = fkey[s];
         if (k != 0xFFFFFFFFu && (k & 0x80000000u)) {
