@@ -39,13 +39,20 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the search is a chain of short dependent steps: when it shares a CU with GEMM waves (pipelined output layer), its
   // instructions should win the issue arbitration
-  __builtin_amdgcn_s_setprio(3);
+#ifndef RS_REG_PRIO
+#define RS_REG_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(RS_REG_PRIO);
   constexpr int NW = NT / 64;
   __shared__ Red<NW> red;
   __shared__ int4 xr[2][NW];       // cross-wave exchange, ping-pong so that a reduction needs one barrier
   int rb = 0;
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RS_DEBUG_SEARCH_FRAMES      // timing experiments only: the search stops after that many frames of every utterance
+  const int T = min(g.d_num_frames[u], RS_DEBUG_SEARCH_FRAMES), S = h.num_states;
+#else
   const int T = g.d_num_frames[u], S = h.num_states;
+#endif
   // time slab [f_begin, f_end): an utterance is started by the slab with f_begin == -1, resumed from w.state_cost by later
   // ones, and finished (traceback, results) by the slab that holds its last frame.  Streams bring their own window per
   // utterance and say explicitly when the stream ends (T is then the number of frames that exist so far).
