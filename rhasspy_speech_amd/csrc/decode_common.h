@@ -250,34 +250,56 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
   __syncthreads();
   const bool reached = b1 < INF;
   const bool ok = !error && T > 0 && b2 < INF;
-  // ---- traceback (GetBestPath).  The back-pointer rows are staged through LDS a block of frames at a time so
-  // that the inherently sequential walk runs at LDS latency; arc sources come from LDS too when they fit.
-  int *stage = reinterpret_cast<int *>(smem);
-  const int stage_ints = smem_bytes / 4;
-  const bool src_in_lds = (h.num_arcs + S) <= stage_ints / 2 && h.num_arcs > 0;
-  int *lds_src = stage;                                   // [num_arcs]
-  int *rows = src_in_lds ? stage + h.num_arcs : stage;    // staged back-pointer rows
-  const int rows_cap = (stage_ints - (src_in_lds ? h.num_arcs : 0)) / S;
+  // ---- traceback (GetBestPath).  The back-pointer rows are staged through LDS a block of frames at a time so that the
+  // inherently sequential walk runs at LDS latency: a block is a contiguous run of the buffer, fetched 16 bytes per thread and
+  // load, and the NEXT block (the walk always continues with the frames right below this one) is in flight, in registers, while
+  // thread 0 walks the current one.  Arc sources come from LDS too (16 bits per arc) when the table fits beside two rows.
+  constexpr int kPF = 8;                                  // 16-byte loads per thread and block
+  const bool src_in_lds = S <= 0x7fff && h.num_arcs > 0 && (size_t)2 * h.num_arcs + (size_t)8 * S + 64 <= (size_t)smem_bytes;
+  unsigned short *lds_src = reinterpret_cast<unsigned short *>(smem);       // [num_arcs]: source state | epsilon flag << 15
+  const int src_bytes = src_in_lds ? (2 * h.num_arcs + 15) & ~15 : 0;
+  int *rows = reinterpret_cast<int *>(smem + src_bytes);  // the staged run (from a 16-byte boundary of the buffer)
+  const int cap_ints = min((smem_bytes - src_bytes) / 4, 4 * kPF * NT) - 4;
+  const int rows_cap = cap_ints / S;                      // >= 1: the launchers reserve a row
   int *path = w.path + (size_t)u * w.path_cap * 2;        // (arc, source frame) pairs, last arc first
   int path_len = 0;
   __syncthreads();
   if (ok) {
-    if (src_in_lds) for (int i = tid; i < h.num_arcs; i += NT) lds_src[i] = h.arc_srcx[i];
+    if (src_in_lds)
+      for (int i = tid; i < h.num_arcs; i += NT) { const int sx = h.arc_srcx[i]; lds_src[i] = (unsigned short)((sx & 0x7fff) | (sx < 0 ? 0x8000 : 0)); }
     int F = T, st = reached ? i1 : i2;
     bool done = false;
+    const long long idx0 = (long long)(bp - w.bp);        // my first row in the buffer, in ints (the buffer itself is 16-byte aligned)
+    int4 pf[kPF];
+    int pf_tail = 0;
+    int lo = F - rows_cap + 1 > 0 ? F - rows_cap + 1 : 0; // rows lo..F
+    auto fetch = [&](int lo_, int F_) {
+      const long long first = idx0 + (long long)lo_ * S, last = idx0 + (long long)(F_ + 1) * S, start = first & ~3ll;
+      const int nfull = (int)((last - start) >> 2), ntail = (int)((last - start) & 3);
+      const int4 *src4 = reinterpret_cast<const int4 *>(w.bp + start);
+#pragma unroll
+      for (int q = 0; q < kPF; q++) if (q * NT + tid < nfull) pf[q] = src4[q * NT + tid];
+      if (tid < ntail) pf_tail = w.bp[start + 4ll * nfull + tid];
+    };
+    fetch(lo, F);
     while (!done) {
-      const int lo = F - rows_cap + 1 > 0 ? F - rows_cap + 1 : 0;     // stage rows lo..F
-      const int nrow = F - lo + 1;
+      const long long first = idx0 + (long long)lo * S, last = idx0 + (long long)(F + 1) * S, start = first & ~3ll;
+      const int skip = (int)(first - start), nfull = (int)((last - start) >> 2), ntail = (int)((last - start) & 3);
+      __syncthreads();                                    // (everybody is done with the previous block)
+#pragma unroll
+      for (int q = 0; q < kPF; q++) if (q * NT + tid < nfull) reinterpret_cast<int4 *>(rows)[q * NT + tid] = pf[q];
+      if (tid < ntail) rows[4 * nfull + tid] = pf_tail;
       __syncthreads();
-      for (int i = tid; i < nrow * S; i += NT) rows[i] = bp[(size_t)lo * S + i];
-      __syncthreads();
+      const int next_F = lo - 1, next_lo = next_F - rows_cap + 1 > 0 ? next_F - rows_cap + 1 : 0;
+      if (next_F >= 0) fetch(next_lo, next_F);
       if (tid == 0) {
         while (true) {
-          const int arc = rows[(F - lo) * S + st];
+          const int arc = rows[skip + (F - lo) * S + st];
           if (arc < 0) { done = true; break; }
-          const int sx = src_in_lds ? lds_src[arc] : h.arc_srcx[arc];      // source state | (epsilon arc ? 1 << 31 : 0)
-          const int src = sx & 0x7fffffff;
-          const bool emitting = sx >= 0;
+          int src;
+          bool emitting;
+          if (src_in_lds) { const unsigned sx = lds_src[arc]; src = (int)(sx & 0x7fffu); emitting = (sx & 0x8000u) == 0u; }
+          else { const int sx = h.arc_srcx[arc]; src = sx & 0x7fffffff; emitting = sx >= 0; }      // source state | (epsilon arc ? 1 << 31 : 0)
           const int Fs = emitting ? F - 1 : F;
           if (path_len < w.path_cap) { path[2 * path_len] = arc; path[2 * path_len + 1] = Fs; }
           path_len++;
@@ -289,6 +311,8 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       }
       __syncthreads();
       done = red.bi[0] != 0; F = red.bi[1]; st = red.bi[2]; path_len = red.bi[3];
+      lo = next_lo;
+      if (!done && F != next_F) { done = true; path_len = w.path_cap + 1; }      // (cannot happen: a walk leaves its block one frame below it)
     }
   }
   __syncthreads();

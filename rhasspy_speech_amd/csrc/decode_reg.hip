@@ -27,8 +27,10 @@ using namespace dd;
 
 #ifdef RS_DECODE_PROFILE
 #define RS_T(i) do { long long _n = clock64(); if (tid == 0) prof[i] += _n - t_last; t_last = _n; } while (0)
+#define RS_T2(i) do { long long _n = clock64(); prof2[i] += _n - t2_last; t2_last = _n; } while (0)
 #else
 #define RS_T(i) do { } while (0)
+#define RS_T2(i) do { } while (0)
 #endif
 
 
@@ -46,6 +48,9 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   constexpr int NW = NT / 64;
   __shared__ Red<NW> red;
   __shared__ int4 xr[2][NW];       // cross-wave exchange, ping-pong so that a reduction needs one barrier
+  // 256-bin histograms of the committed frame's costs, filled by the commit pass for the NEXT frame's GetCutoff (two, alternating:
+  // the one the current frame has read is cleared by the pass that fills the other)
+  __shared__ __attribute__((aligned(16))) unsigned hist2[2][256];
   int rb = 0;
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef RS_DEBUG_SEARCH_FRAMES      // timing experiments only: the search stops after that many frames of every utterance
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
 #pragma unroll
   for (int a = 0; a < KX; a++) xa[a] = rg.x_tab[(size_t)a * NT + tid];
   for (int s = tid; s <= S; s += NT) { cost_cur[s] = (f_begin >= 0 && s < S) ? state[s] : INF; key_next[s] = RS_EMPTY; }
-  for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // KthFromHist's invariant
+  for (int i = tid; i < 256; i += NT) { red.hist[i] = 0; hist2[0][i] = 0; hist2[1][i] = 0; }      // (red.hist: KthFromHist's invariant)
   if (tid == 0) red.ncand = 0;
   // log-likelihoods of my emitting arcs, fetched one frame ahead (padding arcs read pdf 0 and never pass the cutoff)
   const int f_first = f_begin < 0 ? 0 : f_begin;
@@ -97,6 +102,15 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   if (f_begin < 0 && tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
   float closure_cutoff = f_begin < 0 ? o.beam : state[S];
   int error = f_begin < 0 ? 0 : (int)state[S + 1];
+  // the committed frame's histogram: hist2[hpar], bins = HistBin(cost) over [hist_lo, the cutoff it was committed against)
+  // (hist_ok: there is one -- a resumed slab starts without)
+  int hpar = 0;
+  bool hist_ok = false, hist_open = false;
+  float hist_lo = 0.f, hist_scale = 0.f, hist_reach = 1.f;
+  auto HistBin = [&](float c) -> int {
+    const int b = (int)((c - hist_lo) * hist_scale);
+    return b < 0 ? 0 : (b > 255 ? 255 : b);
+  };
   // statistics of the committed frame, collected by the commit pass (recomputed when resuming)
   float st_min = INF;
   int st_arg = 0x7fffffff, st_cnt = 0;
@@ -113,7 +127,8 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   __syncthreads();
 #ifdef RS_DECODE_PROFILE
   long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_last = clock64();
+  long long prof2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_last = clock64(), t2_last = t_last;
 #endif
 
   for (int f = f_begin; f < f_stop && !error; f++) {
@@ -146,24 +161,72 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       }
       if (N == 0) { error = 1; break; }
       RS_T(0);
-      // ---- GetCutoff (lattice-faster-decoder.cc:644-711).  One pass over the tokens counts those inside the beam and
-      // fills the 256-bin histogram the exact k-th-smallest selection starts from (decode_common.h); both are only needed
-      // when a max-active / min-active limit can bind.  Every live cost is < the previous frame's cutoff, which bounds
-      // the bins (when that cutoff is infinite the true maximum is reduced first).
+      // ---- GetCutoff (lattice-faster-decoder.cc:644-711), order statistic FIRST: "more than max_active tokens are below the beam
+      // cutoff" is "the max_active-th smallest cost is below it", and "at most min_active tokens are at or below it" is "the
+      // min_active-th smallest cost is above it" -- so no pass counts tokens.  The statistic comes out of the histogram the commit
+      // pass left: every wave scans it for itself, the handful of costs in the bin that holds the rank are collected (one barrier)
+      // and every wave ranks them for itself.  Without a usable histogram (infinite cutoff last frame, a crowded bin, a second
+      // statistic in one frame): the exact selection of rounds 2-3 (KthFromHist, decode_common.h).
       const float beam_cutoff = best_cost + o.beam;
-      int c_le = 0, c_lt = 0;
-      const bool need_counts = N > o.max_active || N > o.min_active;      // wave-uniform
-      float hist_hi = closure_cutoff;
+      const bool over_max = N > o.max_active, over_min = N > o.min_active;      // wave-uniform
       // Every live token passed `cost < closure_cutoff` when the previous frame was committed.  When that cutoff is not
       // above this frame's beam cutoff (the usual case: best + beam on both sides), all N tokens are inside the beam and
-      // the counting pass, its barrier and the histogram are skipped; they are still needed when max-active can bind.
-      const bool need_pass = need_counts && (!(closure_cutoff <= beam_cutoff) || N > o.max_active);
-      if (need_counts && !need_pass) { c_le = N; c_lt = N; }
+      // min-active cannot bind.
+      const bool all_inside = closure_cutoff <= beam_cutoff;
+      bool fast_used = false;
+      auto Kth = [&](int k, int *n_le) -> float {
 #ifdef RS_DECODE_PROFILE
-      prof[7] += need_pass ? 1 : 0;
+        prof[7] += 1;
 #endif
-      if (need_pass) {
-        if (!(hist_hi < INF)) {
+        if (hist_ok && !fast_used) {
+          RS_T2(0);
+          const uint4 hv = *reinterpret_cast<const uint4 *>(&hist2[hpar][4 * lane]);
+          const int h0 = (int)hv.x, h1 = (int)hv.y, h2 = (int)hv.z, h3 = (int)hv.w;
+          const int tot = h0 + h1 + h2 + h3;
+          const int inc = WaveScanIncl(tot), exc = inc - tot;
+          const bool hit = (exc <= k) & (k < inc);
+          int bb = 4 * lane, acc = exc, m = h0;
+          if (acc + h0 <= k) { acc += h0; bb++; m = h1; if (acc + h1 <= k) { acc += h1; bb++; m = h2; if (acc + h2 <= k) { acc += h2; bb++; m = h3; } } }
+          const unsigned long long hm = __ballot(hit);
+          const int hl = hm ? __ffsll((long long)hm) - 1 : 0;
+          const int bin = __builtin_amdgcn_readlane(bb, hl), before = __builtin_amdgcn_readlane(acc, hl), cnt = __builtin_amdgcn_readlane(m, hl);
+          if (hist_open && hm != 0ull) {       // keep the rank in the middle of the bins
+            if (bin >= 192 && hist_reach < 1024.f) hist_reach *= 2.f;
+            else if (bin < 64 && hist_reach > 0.03125f) hist_reach *= 0.5f;
+          }
+          if (hm != 0ull && cnt <= 64) {
+            fast_used = true;
+            RS_T2(1);
+            for (int s = tid; s < S; s += NT) {
+              const float c = cost_cur[s];
+              if (c < INF && HistBin(c) == bin) red.cand[atomicAdd(&red.ncand, 1)] = c;
+            }
+            LdsBarrier();           // (red.ncand goes back to zero behind the arc pass's barrier)
+            RS_T2(2);
+            const int kk = k - before;
+            const float v = lane < cnt ? red.cand[lane] : INF;
+            int lt = 0, le = 0;
+            for (int j = 0; j < cnt; j++) {
+              const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+              lt += (int)(x < v);
+              le += (int)(x <= v);
+            }
+            const unsigned long long sel = __ballot((lane < cnt) & (lt <= kk) & (kk < le));
+            const int sl = sel ? __ffsll((long long)sel) - 1 : 0;
+            *n_le = before + __builtin_amdgcn_readlane(le, sl);
+            RS_T2(3);
+#ifdef RS_DECODE_PROFILE
+            prof2[4] += cnt; prof2[5] += 1;
+#endif
+            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), sl));
+          }
+        }
+#ifdef RS_DECODE_PROFILE
+        if (!hist_ok) prof2[6] += 1; else prof2[7] += 1;
+#endif
+        if (fast_used) { LdsBarrier(); if (tid == 0) red.ncand = 0; }
+        float hi = closure_cutoff;
+        if (!(hi < INF)) {
           float mx = -INF;
           for (int s = tid; s < S; s += NT) { const float c = cost_cur[s]; mx = c < INF ? fmaxf(mx, c) : mx; }
           const unsigned wx = wv::MaxU(wv::FloatToOrdered(mx));
@@ -171,46 +234,42 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           LdsBarrier();
           unsigned bx = 0u;
 #pragma unroll
-          for (int k = 0; k < NW; k++) bx = max(bx, (unsigned)xr[rb][k].x);
+          for (int q = 0; q < NW; q++) bx = max(bx, (unsigned)xr[rb][q].x);
           rb ^= 1;
-          hist_hi = wv::OrderedToFloat(bx);
+          hi = wv::OrderedToFloat(bx);
         }
-        const float hscale = hist_hi > best_cost ? 255.0f / (hist_hi - best_cost) : 0.f;
+        const float hscale = hi > best_cost ? 255.0f / (hi - best_cost) : 0.f;
         for (int s = tid; s < S; s += NT) {
           const float c = cost_cur[s];
-          c_le += (int)(c <= beam_cutoff) & (int)(c < INF);
-          c_lt += (int)(c < beam_cutoff);
           if (c < INF) atomicAdd(&red.hist[KthBin(c, best_cost, hscale)], 1u);
         }
-        const int wa = wv::Sum(c_le), wb = wv::Sum(c_lt);
-        if (lane == 0) xr[rb][wave] = make_int4(wa, wb, 0, 0);
-        LdsBarrier();           // counts exchanged, histogram complete
-        c_le = 0; c_lt = 0;
-#pragma unroll
-        for (int k = 0; k < NW; k++) { const int4 e = xr[rb][k]; c_le += e.x; c_lt += e.y; }
-        rb ^= 1;
-      }
-      int kth = -1;                // which order statistic GetCutoff needs, if any
-      if (N > o.max_active && c_lt > o.max_active) kth = o.max_active;
-      else if (N > o.min_active && !(o.min_active == 0 || c_le > o.min_active)) kth = o.min_active;
-      float kth_cost = 0.f;
-      int kth_le = 0;              // tokens at or below it
-      if (need_pass) {
-        if (kth >= 0) kth_cost = KthFromHist<NT>(red, cost_cur, S, kth, best_cost, hist_hi, &kth_le);
-        else for (int i = tid; i < 256; i += NT) red.hist[i] = 0;       // next use is at least one barrier away
-      }
+        LdsBarrier();
+        return KthFromHist<NT>(red, cost_cur, S, k, best_cost, hi, n_le);
+      };
       float cur_cutoff, adaptive_beam;
       int n_exp;
-      if (N > o.max_active && c_lt > o.max_active) {
-        adaptive_beam = kth_cost - best_cost + o.beam_delta;
-        cur_cutoff = kth_cost;
-        n_exp = kth_le;
-        max_active_frames++;
-      } else {
+      bool decided = false;
+      if (over_max) {
+        int le;
+        const float v = Kth(o.max_active, &le);
+        if (v < beam_cutoff) {       // more than max_active tokens below the beam cutoff
+          adaptive_beam = v - best_cost + o.beam_delta;
+          cur_cutoff = v;
+          n_exp = le;
+          max_active_frames++;
+          decided = true;
+        }
+      }
+      if (!decided) {
         float min_active_cutoff = INF;
         bool loosened;
-        if (N > o.min_active) {
-          min_active_cutoff = kth >= 0 ? kth_cost : best_cost;           // best_cost stands for "tmp[min_active] <= beam_cutoff"
+        int kth_le = 0;
+        if (over_min) {
+          min_active_cutoff = best_cost;           // best_cost stands for "tmp[min_active] <= beam_cutoff"
+          if (o.min_active != 0 && !all_inside) {
+            const float v = Kth(o.min_active, &kth_le);
+            if (v > beam_cutoff) min_active_cutoff = v;      // fewer than min_active + 1 tokens at or below the beam cutoff
+          }
           loosened = min_active_cutoff > beam_cutoff;
         } else {
           loosened = true;      // fewer than min_active tokens: the cutoff stays +inf (:691-705)
@@ -218,12 +277,23 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         if (loosened) {
           adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;
           cur_cutoff = min_active_cutoff;
-          n_exp = N > o.min_active ? kth_le : N;
-          if (N > o.min_active) min_active_frames++;
+          n_exp = over_min ? kth_le : N;
+          if (over_min) min_active_frames++;
         } else {
           adaptive_beam = o.beam;
           cur_cutoff = beam_cutoff;
-          n_exp = need_counts ? c_le : N;      // without a binding limit every token is inside the beam... counted lazily
+          n_exp = N;
+          if ((over_max || over_min) && !all_inside) {      // (a statistic only: the tokens at or below the beam cutoff)
+            int c_le = 0;
+            for (int s = tid; s < S; s += NT) c_le += (int)(cost_cur[s] <= beam_cutoff);
+            const int wa = wv::Sum(c_le);
+            if (lane == 0) xr[rb][wave] = make_int4(wa, 0, 0, 0);
+            LdsBarrier();
+            n_exp = 0;
+#pragma unroll
+            for (int q = 0; q < NW; q++) n_exp += xr[rb][q].x;
+            rb ^= 1;
+          }
         }
       }
       const float cost_offset = -best_cost;
@@ -243,7 +313,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         const float gc = __int_as_float(ea[a].z);
         const float tot = (c + (cost_offset - lk)) + gc;
         const float alt = ((gc + cost_offset) - lk) + c;                           // :752-757, arcs of the best token
-        const float m = ((ea[a].x & 0xFFFF) == best_addr) ? fminf(tot, alt) : tot;
+        const float m = ((ea[a].x & 0xFFFF) == best_addr) ? fminf(tot, alt) : tot;   // (under a wave-uniform branch instead: the arc pass 1560 -> 2290 clocks)
         local_min = fminf(local_min, pass ? m : INF);
         n_arcs += (unsigned)pass;
         if (pass)
@@ -271,6 +341,8 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
         for (int k = 0; k < NW; k++) bm = min(bm, (unsigned)xr[rb][k].x);
         rb ^= 1;
         next_cutoff = wv::OrderedToFloat(bm) + adaptive_beam;
+        if (tid == 0) red.ncand = 0;           // (every wave is past its ranking; the next collection is a barrier away)
+        hist_lo = wv::OrderedToFloat(bm);      // no emitted cost is below the smallest one
       }
       if (tid == 0) *reinterpret_cast<float4 *>(finfo + (size_t)f * 4) = make_float4(cost_offset, cur_cutoff, next_cutoff, adaptive_beam);
       closure_cutoff = next_cutoff;      // tokens at or above it are neither expanded below nor committed
@@ -321,6 +393,20 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     // ---- commit frame f+1: keys -> costs and back-pointers; statistics for the next frame
     int *bp_row = bp + (size_t)(f + 1) * S;
     st_min = INF; st_arg = 0x7fffffff; st_cnt = 0;
+    // ... and the histogram of the new frame's costs over [smallest emitted cost, cutoff) (any monotone binning will do: what falls
+    // outside -- an epsilon arc of negative weight -- lands in the first bin)
+    // With an infinite cutoff (fewer than min_active tokens were expanded: every other frame of a small grammar graph) the bins cover
+    // hist_reach beams above the smallest cost and the last one takes the rest; hist_reach follows the rank (GetCutoff keeps it in the
+    // middle half of the bins).
+    if (f < 0) hist_lo = 0.f;
+    hist_open = !(closure_cutoff < INF);
+    hist_ok = hist_lo < INF;
+    {
+      const float width = hist_open ? hist_reach * o.beam : closure_cutoff - hist_lo;
+      hist_scale = (hist_ok && width > 0.f) ? 255.0f / width : 0.f;
+    }
+    hpar ^= 1;
+    for (int i = tid; i < 256; i += NT) hist2[hpar ^ 1][i] = 0;        // the one this frame's GetCutoff has read
     for (int s = tid; s < S; s += NT) {
       const unsigned long long k = key_next[s];
       const float c = wv::OrderedToFloat((unsigned)(k >> 32));
@@ -328,6 +414,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       bp_row[s] = alive ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
       cost_cur[s] = alive ? c : INF;
       key_next[s] = RS_EMPTY;
+      if (alive & hist_ok) atomicAdd(&hist2[hpar][HistBin(c)], 1u);      // (unconditional, into a spare word for the dead: 1.10 -> 1.19 ms)
       st_cnt += (int)alive;
       const bool better = alive & (c < st_min);
       st_min = better ? c : st_min;
@@ -362,6 +449,11 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
                       n_insert, n_alive, max_active_frames, min_active_frames, slot);
 #ifdef RS_DECODE_PROFILE
   RS_T(6);
+  if (u == 0 && tid == 0)
+    printf("reg decode Kth fallback: %lld without a histogram, %lld with a crowded bin\n", prof2[6], prof2[7]);
+  if (u == 0 && tid == 0)
+    printf("reg decode Kth fast path: %lld uses, mean bin population %.1f; clocks per use: scan %lld collect %lld rank %lld\n", prof2[5],
+           prof2[5] ? (double)prof2[4] / prof2[5] : 0.0, prof2[5] ? prof2[1] / prof2[5] : 0, prof2[5] ? prof2[2] / prof2[5] : 0, prof2[5] ? prof2[3] / prof2[5] : 0);
   if (u == 0 && tid == 0)
     printf("reg decode cycles/frame: stats %lld cutoff %lld emit %lld closure %lld commit %lld | finish total %lld (T=%d) | counting passes %lld, max-active frames %d, min-active frames %d\n",
            prof[0] / T, prof[1] / T, prof[2] / T, prof[3] / T, prof[4] / T, prof[6], T, prof[7], max_active_frames, min_active_frames);
@@ -812,8 +904,10 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
   // the GEMM workgroups (33 KB each) of the next decode call on its CU, and the overlap of calls in flight was limited to
   // the feature / iVector stages (3.7 ms per headline batch against 3.35 with 48 KB; the search itself takes the same
   // time).  A slab that finishes no utterance does not trace back and keeps its LDS footprint minimal.
-  // (12 KB since the calls' stages are chained, engine.cc: 2.51 -> 2.47-2.49 ms per headline step; 4-16 KB are within 1 % of each other)
-  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 12; }();
+  // (12 KB since the calls' stages are chained, engine.cc: 2.51 -> 2.47-2.49 ms per headline step; 4-16 KB are within 1 % of each other.
+  // Round 4: 32 KB -- the 16-bit arc -> source table now sits in front of the rows, and the layer GEMM's 72 KB leave one of its
+  // workgroups room beside a search whatever this is; 12 / 20 / 32 / 44 KB: search 1.26 / 1.23 / 1.20 / 1.20 ms, profiles/micro/stage_kb.sh)
+  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 32; }();
   const size_t stage = (w.win_begin ? !any_final : f_end <= g.max_frames) ? 0 : stage_kb * 1024;
   if (smem < stage) smem = stage;
   // A batch that puts a search workgroup on (nearly) every CU shares those CUs with the GEMM workgroups of the next call: with
