@@ -6,12 +6,18 @@ dispatch start / end timestamps), per decode call (= number of MfccKernel dispat
   search = RegDecodeKernel (one workgroup per utterance, latency-bound)      small = everything else (iVector chain, copies, ...)
 """
 import csv
+import os
 import sys
 from collections import defaultdict
 from pathlib import Path
 
 
+STREAMS = os.environ.get("TIMELINE_STREAMS") == "1"
+
+
 def klass(name):
+    if "Ivec" in name:            # (only apart from "small" where it matters: the streams workload)
+        return "ivec" if STREAMS else "small"
     if "Gemm" in name:
         return "gemm"
     if "MfccKernel" in name:

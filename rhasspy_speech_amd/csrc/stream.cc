@@ -31,22 +31,29 @@
 #include <map>
 
 #include "engine.h"
+#include <cstdio>
 
 namespace rs {
 
 struct StreamPool {
-  // Two queues, so that consecutive advances overlap on the device: `qa` runs an advance's feature and iVector stages, `q` its
-  // acoustic model and search (behind an event of `qa`).  Stage A of advance n + 1 touches rows and slots stage B of advance n
+  // Queues, so that consecutive advances overlap on the device: `qa` runs an advance's features and UBM posteriors, `qi` (below)
+  // its iVector steps, `q` its acoustic model (behind events of both), `qc` its search.  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
   hipStream_t q = nullptr, qa = nullptr, qc = nullptr;      // qc: the search of an advance (behind q's event), under the next advance's acoustic model
   static constexpr int kDepth = 3;                                             // advances in flight at most = arena / staging sets
   hipEvent_t ev_a[kDepth] = {}, ev_b[kDepth] = {}, ev_done[kDepth] = {};       // per set: stage A issued / log-likelihoods issued / the advance finished
+  // qi: the iVector steps of an advance (estimator state in, one accumulate / products / solve per new chunk, state out), behind
+  // qa's event at the UBM posteriors.  The chain is the longest sequential piece of an advance (~300 us of dependent small kernels);
+  // on its own queue the next advance's features and posteriors run beside it instead of behind it.
+  hipStream_t qi = nullptr;
+  hipEvent_t ev_f[kDepth] = {}, ev_i[kDepth] = {};                             // per set: posteriors issued (qa) / iVectors issued (qi)
+  std::unique_ptr<Timer> tm_i[kDepth];
   bool pending[kDepth] = {};                                                   // an advance that used this set may still run
   std::vector<rs_stream *> open_streams;                                       // every stream that holds a slot (a device failure nobody can attribute poisons them all)
   std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth], tm_c[kDepth];
   // device time of set `par`'s advance into the pool's totals (its done event has been waited for)
   void Account(int par, float *extra) {
-    const float ms[4] = {tm_a[par]->Ms(0, 1), tm_a[par]->Ms(1, 2), tm_b[par]->Ms(0, 1), tm_c[par]->Ms(0, 1)};
+    const float ms[4] = {tm_a[par]->Ms(0, 1), tm_a[par]->Ms(1, 2) + tm_i[par]->Ms(0, 1), tm_b[par]->Ms(0, 1), tm_c[par]->Ms(0, 1)};
     for (int j = 0; j < 4; j++) { stage_ms[j + 1] += ms[j]; if (extra) extra[j] += ms[j]; }
   }
   long n_adv = 0;
@@ -63,6 +70,7 @@ struct StreamPool {
   std::vector<int> free_slots;
   std::map<int, int> free_rows;  // start -> length
   std::vector<void *> owned;
+  float host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // host time of the sections of an advance (RS_STREAMS_TRACE)
   float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // device time of the stages, summed over the advances since the last finish
 
   int AllocRows(int n) {
@@ -90,16 +98,18 @@ struct StreamPool {
 void StreamPoolDeleter::operator()(StreamPool *p) const {
   if (!p) return;
   if (p->qa) (void)hipStreamSynchronize(p->qa);
+  if (p->qi) (void)hipStreamSynchronize(p->qi);
   if (p->q) (void)hipStreamSynchronize(p->q);
   if (p->qc) (void)hipStreamSynchronize(p->qc);
   for (int k = 0; k < StreamPool::kDepth; k++) {
-    p->tm_a[k].reset(); p->tm_b[k].reset(); p->tm_c[k].reset();
-    for (hipEvent_t e : {p->ev_a[k], p->ev_b[k], p->ev_done[k]}) if (e) (void)hipEventDestroy(e);
+    p->tm_a[k].reset(); p->tm_b[k].reset(); p->tm_c[k].reset(); p->tm_i[k].reset();
+    for (hipEvent_t e : {p->ev_a[k], p->ev_b[k], p->ev_done[k], p->ev_f[k], p->ev_i[k]}) if (e) (void)hipEventDestroy(e);
   }
   for (void *d : p->owned) (void)hipFree(d);
   if (p->q) (void)hipStreamDestroy(p->q);
   if (p->qa) (void)hipStreamDestroy(p->qa);
   if (p->qc) (void)hipStreamDestroy(p->qc);
+  if (p->qi) (void)hipStreamDestroy(p->qi);
   delete p;
 }
 
@@ -143,7 +153,11 @@ StreamPool *Model::Pool() {
   RS_HIP(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking));
   RS_HIP(hipStreamCreateWithFlags(&p->qa, hipStreamNonBlocking));
   RS_HIP(hipStreamCreateWithFlags(&p->qc, hipStreamNonBlocking));
+  RS_HIP(hipStreamCreateWithFlags(&p->qi, hipStreamNonBlocking));
   for (int k = 0; k < StreamPool::kDepth; k++) {
+    RS_HIP(hipEventCreateWithFlags(&p->ev_f[k], hipEventDisableTiming));
+    RS_HIP(hipEventCreateWithFlags(&p->ev_i[k], hipEventDisableTiming));
+    p->tm_i[k].reset(new Timer(p->qi));
     RS_HIP(hipEventCreateWithFlags(&p->ev_a[k], hipEventDisableTiming));
     RS_HIP(hipEventCreateWithFlags(&p->ev_b[k], hipEventDisableTiming));
     RS_HIP(hipEventCreateWithFlags(&p->ev_done[k], hipEventDisableTiming));
@@ -192,6 +206,7 @@ StreamPool *Model::Pool() {
   p->cx = stream_ctx_.get();
   RS_HIP(hipStreamSynchronize(p->q));
   RS_HIP(hipStreamSynchronize(p->qa));
+  RS_HIP(hipStreamSynchronize(p->qi));
   pool_ = std::move(p);
   return pool_.get();
 }
@@ -237,7 +252,7 @@ void Model::StreamOpen(rs_stream *st) {
   // fresh estimator / search state in the slot
   if (fc_.ie.present) {
     const int Di = fc_.ie.ivector_dim(), usz = Di * (Di + 1) / 2;
-    LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->qa);      // (stage A's queue: the estimator state is its)
+    LaunchIvecInit(ivec_dev_, 1, p->lin + (size_t)st->slot * Di, p->quad + (size_t)st->slot * usz, p->x + (size_t)st->slot * Di, p->numf + st->slot, p->qi);      // (the iVector steps' queue: the estimator state is its)
   }
   RS_HIP(hipMemsetAsync(p->dec_ctr + (size_t)st->slot * 8, 0, 64, p->qc));      // (the search's queue)
   st->open = true;
@@ -250,7 +265,7 @@ void Model::StreamClose(rs_stream *st) {
   if (!pool_) return;
   // an advance that still uses the stream's rows / slot finishes first (a device error of it is the other streams' to report:
   // this one is going away either way)
-  try { StreamsDrain(pool_.get(), nullptr); } catch (...) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
+  try { StreamsDrain(pool_.get(), nullptr); } catch (...) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
   pool_->FreeRows(st->row0, st->cap);
   pool_->free_slots.push_back(st->slot);
   st->open = false;
@@ -264,7 +279,7 @@ void Model::StreamClose(rs_stream *st) {
 void Model::StreamsPoisonAll() {
   StreamPool *p = pool_.get();
   if (!p) return;
-  (void)hipStreamSynchronize(p->qa); (void)hipStreamSynchronize(p->q); (void)hipStreamSynchronize(p->qc);
+  (void)hipStreamSynchronize(p->qa); (void)hipStreamSynchronize(p->qi); (void)hipStreamSynchronize(p->q); (void)hipStreamSynchronize(p->qc);
   (void)hipGetLastError();
   for (int k = 0; k < StreamPool::kDepth; k++) p->pending[k] = false;
   for (rs_stream *st : p->open_streams) st->failed = true;
@@ -305,7 +320,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   } catch (...) {
     // The advance may have queued part of its work on a set it never marked pending: whatever is queued finishes before the set
     // can be handed out again (the call's own streams are poisoned by the caller, api.cc).
-    if (pool_) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
+    if (pool_) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
     throw;
   }
 }
@@ -315,13 +330,15 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   RS_HIP(hipSetDevice(opts_.device_id));
   // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive
   // advances rotate over kDepth arena / staging sets, so the host plans and issues the next advances while earlier ones still run
-  hipStream_t qa = p->qa, q = p->q, qc = p->qc;
+  hipStream_t qa = p->qa, q = p->q, qc = p->qc, qi = p->qi;
   DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
   const int par = (int)(p->n_adv % StreamPool::kDepth);
   DeviceArena &arena = cx.arena[par];
   HostArena &harena = cx.host_arena[par];
   if (p->pending[par]) {       // the advance kDepth calls ago used this set: it has to be over (it normally is)
+    const auto w0 = std::chrono::steady_clock::now();
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
+    p->stage_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
     p->pending[par] = false;
     p->Account(par, nullptr);
     const hipError_t le = hipGetLastError();
@@ -337,6 +354,9 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
   const int ld_c = p->ld_c, ld_l = RoundUp(std::max(Dl, 1), 4), ld_i = p->ld_i, usz = Di * (Di + 1) / 2, nsel = has_iv ? fc_.ie.num_gselect : 0;
   auto wall0 = std::chrono::steady_clock::now();
+  // (RS_STREAMS_TRACE: the host's time per section -- plan | arena + uploads | issue of stage A | B | C)
+  auto host_last = wall0;
+#define HOST_MARK(i) do { const auto n_ = std::chrono::steady_clock::now(); p->host_ms[i] += std::chrono::duration<float, std::milli>(n_ - host_last).count(); host_last = n_; } while (0)
 
   // ---------------------------------------------------------------- plan (host)
   struct Plan {
@@ -432,6 +452,11 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   for (int i = 0; i < n; i++) if (pl[i].t1 > pl[i].t0) N_idx.push_back(i);
   const int nN = (int)N_idx.size();
   std::vector<int> n_T(nN + 1, 0), n_rb(nN + 1, 0), n_fb(nN + 1, 0), n_src, n_riv, n_lldst;
+  {
+    size_t rows_est = 0;
+    for (int u = 0; u < nN; u++) rows_est += (size_t)(pl[N_idx[u]].t1 - pl[N_idx[u]].t0) + L_ + R_;
+    n_src.reserve(rows_est); n_riv.reserve(rows_est); n_lldst.reserve(rows_est);
+  }
   int maxTn = 0;
   for (int u = 0; u < nN; u++) {
     const Plan &a = pl[N_idx[u]];
@@ -445,8 +470,10 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
       n_src.push_back(st.row0 + std::min(std::max(t, 0), std::max(a.avail - 1, 0)));
       // the chunk whose iVector this row's Round(ivector, chunk) slot was supplied by (DecodeGroup: row_ivec)
       const int slot_t = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
-      int k = 0;
-      while (k < st.chunks_sched - 1 && slot_t >= (k + 1) * chunk + Rm) k++;
+      // = the number of chunks j >= 1 with j * chunk + Rm <= slot_t, at most the last scheduled one (in closed form: counting
+      // them chunk by chunk was the largest item of an advance's host time late in a 30 s stream)
+      const int d = slot_t - Rm;
+      const int k = std::min(std::max(d >= 0 ? d / chunk : 0, 0), std::max(st.chunks_sched - 1, 0));
       n_riv.push_back(st.row0 / chunk + k);
     }
     for (int t = a.t0; t < a.t1; t++) n_lldst.push_back(st.row0 + t);
@@ -473,6 +500,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   const size_t o_nrb = is.Add(n_rb), o_nfb = is.Add(n_fb), o_nsrc = is.Add(n_src), o_nriv = is.Add(n_riv), o_nll = is.Add(n_lldst);
   const size_t o_dT = is.Add(d_T), o_drb = is.Add(d_rb), o_wb = is.Add(w_b), o_we = is.Add(w_e), o_wf = is.Add(w_f), o_slots = is.Add(slots), o_row0 = is.Add(row0s);
   // ---------------------------------------------------------------- arena
+  HOST_MARK(0);
   const int guard = L_ + R_ + 8;
   auto fbytes = [&](int rows, int ld) { return ((size_t)rows + 2 * guard) * ld * sizeof(float) + 512; };
   std::vector<int> buf_ld(nn.bufs.size());
@@ -509,10 +537,11 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     }
     RS_HIP(hipMemcpyAsync(d_pcm, hp, sizeof(int16_t) * pcm_total, hipMemcpyHostToDevice, qa));
   }
-  Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par], &tmc = *p->tm_c[par];
-  tma.Reset(); tmb.Reset(); tmc.Reset();
+  Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par], &tmc = *p->tm_c[par], &tmi = *p->tm_i[par];
+  tma.Reset(); tmb.Reset(); tmc.Reset(); tmi.Reset();
   tma.Mark();
   // ---------------------------------------------------------------- 1. MFCC
+  HOST_MARK(1);
   if (nM > 0) {
     BatchGeom g;
     g.n_utts = nM; g.total_rows = rowsM; g.total_frames = rowsM;
@@ -546,30 +575,41 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     int *post_idx = arena.AllocT<int>((size_t)rowsI * nsel + 64);
     float *post_w = arena.AllocT<float>((size_t)rowsI * nsel + 64);
     LaunchUbmPosteriors(ivec_dev_, g, lda_norm, ld_l, post_idx, post_w, qa);
+    // the estimator's steps on their own queue, behind the posteriors
+    RS_HIP(hipEventRecord(p->ev_f[par], qa));
+    RS_HIP(hipStreamWaitEvent(qi, p->ev_f[par], 0));
+    tmi.Mark();
     double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
     double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
     double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
     double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, nI));
     // estimator state: slots -> dense, the steps, dense -> slots (one launch each way for the four arrays)
     CopyRowsSet in_set{{{p->lin, linear, 2L * Di, 2 * Di}, {p->quad, quad, 2L * usz, 2 * usz}, {p->numf, numf, 2, 2}, {p->x, x, 2L * Di, 2 * Di}}, 4};
-    LaunchCopyRowsMulti(in_set, D(o_islot), nullptr, nI, qa);
+    LaunchCopyRowsMulti(in_set, D(o_islot), nullptr, nI, qi);
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
     for (int k = 0; k < max_new_chunks; k++) {
       const size_t o = (size_t)k * nI;
-      // (the first step starts the sums itself -- no clear of the 21 MB in front of it -- and nothing reads them after the last)
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, k == 0, qa);
-      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, qa);
-      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, qa);
-      if (k + 1 < max_new_chunks) LaunchIvecClear(ivec_dev_, nI, gamma, wfeats, qa);
+      // (every step starts the sums itself -- a step's statistics are its own frames' -- so nothing clears the 21 MB between steps:
+      // zero + the step's terms in the same order, bit for bit what the cleared buffers gave)
+      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, true, qi);
+      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, qi);
+      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, qi);
     }
     CopyRowsSet out_set{{{linear, p->lin, 2L * Di, 2 * Di}, {quad, p->quad, 2L * usz, 2 * usz}, {numf, p->numf, 2, 2}, {x, p->x, 2L * Di, 2 * Di}}, 4};
-    LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qa);
+    LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qi);
+    tmi.Mark();
   }
   tma.Mark();
+  // the acoustic model waits for both: the features (qa) and, where there is an extractor, the iVectors (qi, itself behind qa)
   RS_HIP(hipEventRecord(p->ev_a[par], qa));
   RS_HIP(hipStreamWaitEvent(q, p->ev_a[par], 0));
+  if (nI > 0) {
+    RS_HIP(hipEventRecord(p->ev_i[par], qi));
+    RS_HIP(hipStreamWaitEvent(q, p->ev_i[par], 0));
+  }
   tmb.Mark();
   // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context)
+  HOST_MARK(2);
   if (nN > 0) {
     std::vector<float *> bufp(nn.bufs.size(), nullptr);
     for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(rowsN, buf_ld[b]);
@@ -584,6 +624,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   }
   tmb.Mark();
   // ---------------------------------------------------------------- 5. search (its own queue: the next advance's acoustic model does not wait for it)
+  HOST_MARK(3);
   RS_HIP(hipEventRecord(p->ev_b[par], q));
   RS_HIP(hipStreamWaitEvent(qc, p->ev_b[par], 0));
   tmc.Mark();
@@ -607,6 +648,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   }
   tmc.Mark();
   // ---------------------------------------------------------------- host bookkeeping
+  HOST_MARK(4);
   for (int i = 0; i < n; i++) {
     rs_stream &st = *streams[i];
     const Plan &a = pl[i];
@@ -679,6 +721,14 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   for (int k = 0; k < 4; k++) res->timings[k + 1] = p->stage_ms[k + 1];
   res->timings[5] = tmr.Ms(0, 1);
   res->timings[6] = p->stage_ms[6] + res->timings[7];
+  // RS_STREAMS_TRACE=1: where the host's time went since the last finish -- inside the advance calls, and of that waiting for the
+  // advance three calls back to leave its arena set (the device is the bottleneck when that is most of it)
+  static const bool trace = [] { const char *e = std::getenv("RS_STREAMS_TRACE"); return e && std::atoi(e) != 0; }();
+  if (trace) {
+    std::fprintf(stderr, "streams: %.2f ms in advance calls, %.2f ms of it waiting for the device; plan %.2f, arena + uploads %.2f, issue of stage A %.2f, B %.2f, C %.2f\n",
+                 p->stage_ms[6], p->stage_ms[7], p->host_ms[0], p->host_ms[1], p->host_ms[2], p->host_ms[3], p->host_ms[4]);
+    for (float &v : p->host_ms) v = 0.f;
+  }
   for (float &v : p->stage_ms) v = 0.f;
 }
 
