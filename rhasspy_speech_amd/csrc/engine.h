@@ -189,9 +189,10 @@ class Model {
     hipEvent_t stage_ev[3] = {};           // end of this call's feature + iVector stage / of its acoustic-model stage / of its sample upload (StageChain)
     int *gemm_ovf = nullptr, *gemm_ovf_dev = nullptr;      // pinned + mapped word and the device's address of it (see exact_gemm_)
     hipEvent_t split_ev = nullptr;         // what `stream` held when a call split into two utterance groups (the second group's stream waits for it)
-    DeviceArena arena[3];                  // one per concurrent utterance group (batch calls use two; stream advances rotate over three)
-    HostArena host_arena[3];
-    LatArcBuffer lat_arcs[3];              // lattice arc output of LatticeKernel, grow-only, one per utterance group
+    static constexpr int kSets = 4;
+    DeviceArena arena[kSets];              // one per concurrent utterance group (batch calls use two; stream advances rotate over all)
+    HostArena host_arena[kSets];
+    LatArcBuffer lat_arcs[kSets];          // lattice arc output of LatticeKernel, grow-only, one per utterance group
     int16_t *h_pcm_pinned = nullptr;       // pinned staging for host-buffer batches
     size_t h_pcm_cap = 0;
     int16_t *d_pcm = nullptr;

@@ -40,7 +40,10 @@ struct StreamPool {
   // its iVector steps, `q` its acoustic model (behind events of both), `qc` its search.  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
   hipStream_t q = nullptr, qa = nullptr, qc = nullptr;      // qc: the search of an advance (behind q's event), under the next advance's acoustic model
-  static constexpr int kDepth = 3;                                             // advances in flight at most = arena / staging sets
+#ifndef RS_STREAM_DEPTH
+#define RS_STREAM_DEPTH 4      // (2 / 3 / 4: 35.2 / 27.3 / 24.5 ms per 64 x 30 s step, profiles/micro/stream_depth.sh; at 4 the host no longer waits for the device)
+#endif
+  static constexpr int kDepth = RS_STREAM_DEPTH;                               // advances in flight at most <= arena / staging sets (DecodeContext::kSets)
   hipEvent_t ev_a[kDepth] = {}, ev_b[kDepth] = {}, ev_done[kDepth] = {};       // per set: stage A issued / log-likelihoods issued / the advance finished
   // qi: the iVector steps of an advance (estimator state in, one accumulate / products / solve per new chunk, state out), behind
   // qa's event at the UBM posteriors.  The chain is the longest sequential piece of an advance (~300 us of dependent small kernels);
