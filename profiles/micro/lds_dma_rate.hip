@@ -60,6 +60,78 @@ __global__ __launch_bounds__(64 * WAVES) void k(const unsigned char *shared_src,
   if (s == 12345.f) out[0] = s;
 }
 
+// The same skeleton with the WEIGHTS going straight to registers (global_load_dwordx4, one step ahead, two register sets) and
+// only the activations through LDS (2 DMAs per wave and step, two steps ahead): is an ordinary load cheaper to issue than a DMA?
+#define GLOAD16(dst, gptr) __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(gptr) : "memory")
+template <int MFMAS, int READS>
+__global__ __launch_bounds__(256, 2) void kw(const unsigned char *shared_src, const unsigned char *priv_src, int steps, float *out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WAVES = 4, PA = 2, PW = 4, STAGE = WAVES * PA * 1024;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const size_t shared_step = (size_t)WAVES * PW * 1024, priv_step = (size_t)WAVES * PA * 1024;
+  const unsigned char *ss = shared_src + (size_t)wave * PW * 1024 + lane * 16;
+  const unsigned char *ps = priv_src + (size_t)blockIdx.x * priv_step * steps + (size_t)wave * PA * 1024 + lane * 16;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  f16x8 a;
+  for (int e = 0; e < 8; e++) a[e] = (_Float16)(0.5f + lane * 0.001f);
+  f16x8 w0[PW], w1[PW];
+  auto issueA = [&](int t) __attribute__((always_inline)) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t % 3) * STAGE + wave * PA * 1024));
+#pragma unroll
+    for (int p = 0; p < PA; p++) DMA16(dst + p * 1024, ps + (size_t)(t / 3) * priv_step + (size_t)(t % 3) * 48 + p * 1024);
+  };
+#define ISSUE_W(SET, T) _Pragma("unroll") for (int p = 0; p < PW; p++) GLOAD16(SET[p], ss + (size_t)(T) * shared_step + p * 1024)
+#define STEP(SET, NEXT, T)                                                                               \
+  {                                                                                                      \
+    if ((T) + 1 < steps) { __asm__ volatile("s_waitcnt vmcnt(2)" : "+v"(SET[0]), "+v"(SET[1]), "+v"(SET[2]), "+v"(SET[3]) : : "memory"); }      \
+    else { __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(SET[0]), "+v"(SET[1]), "+v"(SET[2]), "+v"(SET[3]) : : "memory"); }                      \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    if ((T) + 1 < steps) { ISSUE_W(NEXT, (T) + 1); }                                                     \
+    if ((T) + 2 < steps) issueA((T) + 2);                                                                \
+    if constexpr (READS > 0) {                                                                           \
+      const unsigned src = lds0 + (unsigned)(((T) % 3) * STAGE) + lane * 16;                             \
+      f16x8 f[READS > 0 ? READS : 1];                                                                    \
+      _Pragma("unroll") for (int i = 0; i < READS; i++) __asm__ volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i]) : "v"(src), "n"((i % (WAVES * PA)) * 1024)); \
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+      _Pragma("unroll") for (int i = 0; i < READS; i++) a[0] += f[i][0];                                 \
+    }                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < MFMAS; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(SET[i & 3], a, acc[i & 3], 0, 0, 0); \
+  }
+  ISSUE_W(w0, 0);
+  issueA(0);
+  if (steps > 1) issueA(1);
+  int t = 0;
+#pragma nounroll
+  for (; t + 2 <= steps; t += 2) {
+    STEP(w0, w1, t)
+    STEP(w1, w0, t + 1)
+  }
+  if (t < steps) STEP(w0, w1, t)
+#undef STEP
+#undef ISSUE_W
+  float s = 0; for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
+  if (s == 12345.f) out[0] = s;
+}
+template <int MFMAS, int READS>
+void runw(const char *name, const unsigned char *shared_src, const unsigned char *priv_src, float *out, int steps) {
+  const int blocks = 512;
+  const size_t smem = 3 * 4 * 2 * 1024;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kw<MFMAS, READS>), dim3(blocks), dim3(256), smem, 0, shared_src, priv_src, steps, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double bytes_cu = 2.0 * 4 * 6 * 1024.0 * steps;
+  printf("%-46s waves 4 x 2 wg/CU, 2 DMAs + 4 register loads per wave, mfma %2d: %7.1f us  %6.1f GB/s per CU  %5.2f us per step\n", name, MFMAS, best * 1e3,
+         bytes_cu / (best * 1e-3) / 1e9, best * 1e3 / steps);
+}
+
 template <int WAVES, int DEPTH, int PER, int MFMAS, int REUSE = 3, int READS = 0>
 void run(const char *name, int per_cu, int shared_per, const unsigned char *shared_src, const unsigned char *priv_src, float *out, int steps) {
   const int blocks = 256 * per_cu;
@@ -96,6 +168,10 @@ int main() {
   run<4, 3, 6, 0, 3, 12>("B3J WM=1 shape, 12 fragment reads per step", 2, 4, shared_src, priv_src, out, steps);
   run<4, 3, 6, 24, 3, 12>("B3J WM=1 shape, 12 reads + 24 MFMAs", 2, 4, shared_src, priv_src, out, steps);
   run<4, 3, 6, 24>("B3J WM=1 shape, 24 MFMAs per step", 2, 4, shared_src, priv_src, out, steps);
+  runw<0, 0>("weights to registers, no compute", shared_src, priv_src, out, steps);
+  runw<0, 8>("weights to registers, 8 fragment reads", shared_src, priv_src, out, steps);
+  runw<24, 8>("weights to registers, 8 reads + 24 MFMAs", shared_src, priv_src, out, steps);
+  runw<24, 0>("weights to registers, 24 MFMAs", shared_src, priv_src, out, steps);
   run<4, 3, 6, 0>("  one workgroup per CU", 1, 4, shared_src, priv_src, out, steps);
   run<4, 3, 6, 0>("  all shared (L2 hits only)", 2, 6, shared_src, priv_src, out, steps);
   run<4, 3, 6, 0>("  all private (HBM stream)", 2, 0, shared_src, priv_src, out, steps);

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     // middle half of the bins).
     if (f < 0) hist_lo = 0.f;
     hist_open = !(closure_cutoff < INF);
-    hist_ok = hist_lo < INF;
+    hist_ok = hist_lo < INF && !o.no_commit_hist;
     {
       const float width = hist_open ? hist_reach * o.beam : closure_cutoff - hist_lo;
       hist_scale = (hist_ok && width > 0.f) ? 255.0f / width : 0.f;
@@ -896,9 +896,11 @@ bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int
   return false;
 }
 
-bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
+bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o_in, const BatchGeom &g,
                      const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s, bool any_final) {
   if (g.n_utts == 0) return true;
+  DecodeOptsDev o = o_in;
+  { const char *e = std::getenv("RS_REG_NO_HIST"); o.no_commit_hist = e && std::atoi(e) != 0 ? 1 : 0; }      // (read per launch: a test flips it)
   size_t smem = (size_t)r.key_base + (size_t)(h.num_states + 1) * 8;
   // room to stage back-pointer rows for the traceback.  48 KB, not more: with 128 KB a search workgroup left no room for
   // the GEMM workgroups (33 KB each) of the next decode call on its CU, and the overlap of calls in flight was limited to

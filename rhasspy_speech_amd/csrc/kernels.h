@@ -225,6 +225,7 @@ struct DecodeOptsDev {
   float beam, lattice_beam, beam_delta;
   int max_active, min_active;
   int exact_order;            // rs_decode_opts.exact_token_order: the reference's order-dependent token creation (decode_reg.hip), where the graph allows it
+  int no_commit_hist = 0;     // RS_REG_NO_HIST=1 (tests): RegDecodeKernel's GetCutoff always selects the slow way (KthFromHist)
 };
 struct DecodeWork {
   // per utterance

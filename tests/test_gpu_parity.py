@@ -197,6 +197,37 @@ def test_exact_token_order_is_the_sequential_decoder(case_cache, name, extra, mo
     np.testing.assert_allclose(got.costs(0), (best.graph_cost, best.acoustic_cost), rtol=2e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize("name,extra", VARIANT_CASES)
+def test_cutoff_from_the_commit_histogram_is_the_exact_selection(case_cache, name, extra, monkeypatch):
+    """RegDecodeKernel's GetCutoff takes the max-active / min-active order statistic from the histogram the commit pass leaves
+    (decode_reg.hip); RS_REG_NO_HIST=1 makes every frame select it the way rounds 2-3 did (a histogram pass over the tokens, then
+    KthFromHist): the same cutoffs, so the same tokens, pruning branches and costs, bit for bit."""
+    from rhasspy_speech_amd import _lib, synth
+    monkeypatch.setenv("RS_DECODER", "reg")
+    model, pcm = make_model(case_cache, name, **extra)
+    pcms = [pcm] + [synth.synth_utterance(900 + i, n) for i, n in enumerate([48000, 17000, 33000, 2500])]
+    got = model.decode_batch(pcms)
+    monkeypatch.setenv("RS_REG_NO_HIST", "1")
+    ref = model.decode_batch(pcms)
+    for u in range(len(pcms)):
+        assert got.words(u) == ref.words(u)
+        np.testing.assert_array_equal(got.costs(u), ref.costs(u))
+        assert got.counters(u)[:4] == ref.counters(u)[:4] and got.counters(u)[5:7] == ref.counters(u)[5:7]
+    # streams re-enter the kernel every advance (no histogram on a window's first frame)
+    res = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("RS_REG_NO_HIST", env)
+        st = _lib.Stream(model)
+        raw = pcms[1].tobytes()
+        for k in range(0, len(raw), 8192):
+            st.accept(raw[k:k + 8192])
+            st.advance()
+        res[env] = st.finish()
+    assert res["0"].words(0) == res["1"].words(0)
+    np.testing.assert_array_equal(res["0"].costs(0), res["1"].costs(0))
+    assert res["0"].counters(0)[:4] == res["1"].counters(0)[:4] and res["0"].counters(0)[5:7] == res["1"].counters(0)[5:7]
+
+
 @pytest.mark.parametrize("name,extra", [("tiny_arpa_u7", {}), ("tiny_arpa_prune_u8", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0))])
 def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra, monkeypatch):
     """n-best lists (LatticeKernel on the token lists the search leaves behind) from the live-state-table search, from the dense-table
