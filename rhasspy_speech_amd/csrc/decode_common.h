@@ -254,13 +254,13 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
   // inherently sequential walk runs at LDS latency: a block is a contiguous run of the buffer, fetched 16 bytes per thread and
   // load, and the NEXT block (the walk always continues with the frames right below this one) is in flight, in registers, while
   // thread 0 walks the current one.  Arc sources come from LDS too (16 bits per arc) when the table fits beside two rows.
-  constexpr int kPF = 8;                                  // 16-byte loads per thread and block
+  constexpr int kPF = 8;                                  // 16-byte loads per thread and block that travel ahead (what a block holds beyond them is copied when it is staged)
   const bool src_in_lds = S <= 0x7fff && h.num_arcs > 0 && (size_t)2 * h.num_arcs + (size_t)8 * S + 64 <= (size_t)smem_bytes;
   unsigned short *lds_src = reinterpret_cast<unsigned short *>(smem);       // [num_arcs]: source state | epsilon flag << 15
   const int src_bytes = src_in_lds ? (2 * h.num_arcs + 15) & ~15 : 0;
   int *rows = reinterpret_cast<int *>(smem + src_bytes);  // the staged run (from a 16-byte boundary of the buffer)
-  const int cap_ints = min((smem_bytes - src_bytes) / 4, 4 * kPF * NT) - 4;
-  const int rows_cap = cap_ints / S;                      // >= 1: the launchers reserve a row
+  const int cap_ints = (smem_bytes - src_bytes) / 4 - 4;
+  const int rows_cap = cap_ints / S;                      // >= 1: the launchers' LDS holds the search's own 12 bytes per state
   int *path = w.path + (size_t)u * w.path_cap * 2;        // (arc, source frame) pairs, last arc first
   int path_len = 0;
   __syncthreads();
@@ -288,6 +288,7 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       __syncthreads();                                    // (everybody is done with the previous block)
 #pragma unroll
       for (int q = 0; q < kPF; q++) if (q * NT + tid < nfull) reinterpret_cast<int4 *>(rows)[q * NT + tid] = pf[q];
+      for (int i = kPF * NT + tid; i < nfull; i += NT) reinterpret_cast<int4 *>(rows)[i] = reinterpret_cast<const int4 *>(w.bp + start)[i];      // (rows of more than 32 NT states)
       if (tid < ntail) rows[4 * nfull + tid] = pf_tail;
       __syncthreads();
       const int next_F = lo - 1, next_lo = next_F - rows_cap + 1 > 0 ? next_F - rows_cap + 1 : 0;

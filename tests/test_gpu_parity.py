@@ -197,6 +197,32 @@ def test_exact_token_order_is_the_sequential_decoder(case_cache, name, extra, mo
     np.testing.assert_allclose(got.costs(0), (best.graph_cost, best.acoustic_cost), rtol=2e-6, atol=1e-4)
 
 
+def test_decoder_variants_agree_on_a_graph_of_a_few_thousand_states(tmp_path, monkeypatch):
+    """A grammar graph of 2000-5000 states (a hundred-odd sentences): a back-pointer row no longer fits the 16-byte loads the
+    traceback keeps in flight per thread, the register-resident search runs its wider shapes, the dense search one wave or four."""
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.ModelSpec(name="few-thousand-states", num_phones=120, hidden_dim=64, num_gauss=64, ivector_dim=30)
+    rng = np.random.default_rng(5)
+    vocab = sorted({w for s in synth.DEFAULT_SENTENCES for w in s.split()})
+    sents = [" ".join(vocab[int(i)] for i in rng.integers(0, len(vocab), int(rng.integers(5, 9)))) for _ in range(140)]
+    synth.write_model_dir(tmp_path / "m", spec)
+    fst, _lex = synth.make_grammar_graph(tmp_path / "g", spec, sentences=sents)
+    assert 2100 < fst.num_states <= 5000, fst.num_states
+    pcms = [synth.synth_utterance(40 + i, n) for i, n in enumerate([48000, 9000, 30000])]
+    res = {}
+    for variant in ("sparse", "reg", "dense"):
+        monkeypatch.setenv("RS_DECODER", variant)
+        model = _lib.Model(tmp_path / "m", tmp_path / "g", _lib.default_opts(max_active=300, min_active=100))
+        res[variant] = model.decode_batch(pcms)
+        model.close()
+    for variant in ("reg", "dense"):
+        for u in range(len(pcms)):
+            assert res[variant].words(u) == res["sparse"].words(u), (variant, u)
+            np.testing.assert_allclose(res[variant].costs(u), res["sparse"].costs(u), rtol=1e-6)
+            assert res[variant].counters(u)[3] == res["sparse"].counters(u)[3], (variant, u)
+            assert res[variant].counters(u)[5:7] == res["sparse"].counters(u)[5:7], (variant, u)
+
+
 @pytest.mark.parametrize("name,extra", VARIANT_CASES)
 def test_cutoff_from_the_commit_histogram_is_the_exact_selection(case_cache, name, extra, monkeypatch):
     """RegDecodeKernel's GetCutoff takes the max-active / min-active order statistic from the histogram the commit pass leaves
