@@ -39,6 +39,11 @@ with tempfile.TemporaryDirectory() as td:
                         rows = np.nonzero(d.reshape(len(d), -1).max(axis=1) > 0)[0]
                         msg += f" {nm}: max {d.max():.3g} rows {rows[:4].tolist()}..{rows[-2:].tolist()} ({len(rows)} of {len(d)});"
                     if bad <= 8: print(f"iteration {it} batch {b} utt {u}:{msg}", flush=True)
+                    if bad <= 3 and os.environ.get('STRESS_SHOW_ROWS') and os.environ.get('STRESS_KEEP', '1') != '0':
+                        # the first differing feature rows, both versions (which cepstra move, and how)
+                        f1, f0 = out[b].matrix(u, 0), ref[b].matrix(u, 0)
+                        for r in np.nonzero(np.abs(f1 - f0).max(axis=1) > 0)[0][:2]:
+                            print(f"   row {r} got  {np.array2string(f1[r][:12], precision=3)}\n   row {r} want {np.array2string(f0[r][:12], precision=3)}", flush=True)
         per_it.append(bad - before)
     print("per iteration:", per_it, "per batch:", per_batch)
     print("mismatching results:", bad)
