@@ -514,6 +514,53 @@ int run_beside7(const char *name, unsigned *d_err, float *d_out, hipStream_t sv,
   return 0;
 }
 
+// ... f16 MFMAs again (GemmKernelB3 without its MFMAs leaves the victim alone: pk_perturber2.sh), with the operand VALUES the split
+// produces: KIND 0 normal numbers, 1 fp16 SUBNORMALS in one operand (the low parts), 2 subnormals in both, 3 zeros, 4 operands and
+// accumulators that change every instruction (fresh registers, as fragments read from LDS are)
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void burner8(float *out, int iters) {
+  f32x16 acc[8];
+  for (int i = 0; i < 8; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  u32x4 ua, ub;
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+  for (int k = 0; k < 4; k++) {
+    h = h * 1664525u + 1013904223u;
+    const unsigned sub = (h & 0x03ff03ffu) | 0x00010001u, nor = (h & 0x03ff03ffu) | 0x3c003c00u;
+    ua[k] = KIND == 3 ? 0u : (KIND == 1 || KIND == 2) ? sub : nor;
+    h = h * 1664525u + 1013904223u;
+    ub[k] = KIND == 3 ? 0u : KIND == 2 ? ((h & 0x03ff03ffu) | 0x00010001u) : ((h & 0x03ff03ffu) | 0x3c003c00u);
+  }
+  for (int it = 0; it < iters; it++) {
+    f16x8 a = __builtin_bit_cast(f16x8, ua), b = __builtin_bit_cast(f16x8, ub);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+      if (KIND == 5) { h = h * 1664525u + 1013904223u; h = (h & 0x03ff03ffu) | 0x3c003c00u; }      // the same VALU work, feeding nothing
+      if (KIND == 6) { a = __builtin_bit_cast(f16x8, (i & 1) ? ub : ua); }                            // two operand sets alternating, no VALU write
+      if (KIND == 4) { ua[i & 3] = ua[i & 3] * 1664525u + 1013904223u; ua[i & 3] = (ua[i & 3] & 0x03ff03ffu) | ((i & 1) ? 0x00010001u : 0x3c003c00u); a = __builtin_bit_cast(f16x8, ua); }
+    }
+  }
+  float s = (float)(h & 0xff);
+  for (int i = 0; i < 8; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int KIND>
+int run_beside8(const char *name, unsigned *d_err, float *d_out, hipStream_t sv, hipStream_t sb) {
+  unsigned total = 0;
+  for (int rep = 0; rep < 4; rep++) {
+    CHECK(hipMemsetAsync(d_err, 0, 256, sv));
+    CHECK(hipStreamSynchronize(sv));
+    for (int l = 0; l < 4; l++) hipLaunchKernelGGL(burner8<KIND>, dim3(512), dim3(256), 0, sb, d_out, 50000);
+    hipLaunchKernelGGL(victim<9>, dim3(512), dim3(256), 0, sv, d_err, 100000);
+    unsigned e[2] = {0, 0};
+    CHECK(hipMemcpyAsync(e, d_err, 8, hipMemcpyDeviceToHost, sv));
+    CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sb));
+    total += e[0];
+  }
+  printf("v_pk_mul with source 1 half-swapped beside f16 MFMAs on %-44s %u wrong of 104.9 G values\n", name, total);
+  return 0;
+}
+
 template <int KIND>
 int run_beside4(const char *name, unsigned *d_err, float *d_out, hipStream_t sv, hipStream_t sb) {
   unsigned total = 0;
@@ -631,6 +678,13 @@ int main() {
   run_beside_launches<4>("3000 launches of 2048 short workgroups (few registers):", d_err, d_out, sv, sb, 2048, 20);
   run_beside_launches<64>("3000 launches of 2048 short workgroups (64+ registers):", d_err, d_out, sv, sb, 2048, 4);
   run_beside_launches<4>("3000 launches of 256 workgroups:", d_err, d_out, sv, sb, 256, 200);
+  run_beside8<0>("normal numbers:", d_err, d_out, sv, sb);
+  run_beside8<1>("fp16 subnormals in one operand:", d_err, d_out, sv, sb);
+  run_beside8<2>("fp16 subnormals in both operands:", d_err, d_out, sv, sb);
+  run_beside8<3>("zeros:", d_err, d_out, sv, sb);
+  run_beside8<4>("operands that change every instruction:", d_err, d_out, sv, sb);
+  run_beside8<5>("constant operands, the same VALU work feeding nothing:", d_err, d_out, sv, sb);
+  run_beside8<6>("two constant operand sets alternating:", d_err, d_out, sv, sb);
   run_beside7<0>("v_lshl_add_u64:", d_err, d_out, sv, sb);
   run_beside7<1>("v_mov_b64:", d_err, d_out, sv, sb);
   run_beside7<2>("v_lshlrev_b64:", d_err, d_out, sv, sb);

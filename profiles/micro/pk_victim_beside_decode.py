@@ -14,11 +14,16 @@ with tempfile.TemporaryDirectory() as td:
     synth.write_model_dir(root / "m", spec); synth.make_grammar_graph(root / "g", spec)
     m = _lib.Model(root / "m", root / "g", _lib.default_opts())
     batches = [[synth.synth_utterance(21000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(40 + 16 * b)] for b in range(3)]
-    for b in batches: m.decode_batch(b)
+    def decode(b):
+        try:
+            m.decode_batch(batches[b])
+        except _lib.RsError:          # (pk_perturber2.sh runs this on builds whose GEMM is wrong by design)
+            pass
+    for b in range(3): decode(b)
     stop = False
     def run(b):
         while not stop:
-            m.decode_batch(batches[b])
+            decode(b)
     for beside in (False, True):
         stop = False
         ts = [threading.Thread(target=run, args=(b,)) for b in range(3)] if beside else []

@@ -42,6 +42,11 @@ using namespace b3;
 // WM = 1: 256 threads, two workgroups per CU.  WM = 2: 512 threads = two such wave rows stacked (64 MR rows), launched with
 // (almost) all of the CU's LDS so that no other workgroup shares the CU -- used when several decode pipelines are in flight
 // (see engine.cc: ProcessTurn for why this kernel must then keep other kernels' workgroups off its CU).
+// Measurement only (profiles/micro/pk_perturber2.sh; results WRONG with a bit set): 1 = no MFMAs, 2 = no split / LDS stores of the
+// activations, 4 = no epilogue, 8 = no fragment reads + MFMAs (the whole step), 16 = the split without its |x| maximum
+#ifndef RS_B3_ABLATE
+#define RS_B3_ABLATE 0
+#endif
 template <int MR, bool MIXED, int WM>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDev d, int rows, int nbig, const int *__restrict__ row_ivec, int epi_mode) {
   static_assert(!(MIXED && WM > 1), "two tile heights only with one wave row");
@@ -142,13 +147,14 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   float amax = 0.f;                            // largest |activation| this thread has split
   auto store_a = [&](int stage, const f32x4 (&av)[NA], int staged_lim) __attribute__((always_inline)) {
     unsigned char *As = smem + stage * STAGE;
+    if (RS_B3_ABLATE & 2) return;
 #pragma unroll
     for (int h = 0; h < NA; h++) {
       if (!a_on[h]) continue;
       const f32x4 x0 = av[h];
       const f32x4 x = f32x4{staged_lim > 0 ? x0[0] : 0.f, staged_lim > 1 ? x0[1] : 0.f, staged_lim > 2 ? x0[2] : 0.f, staged_lim > 3 ? x0[3] : 0.f};
       f16x4 p1, p2;
-      amax = fmaxf(amax, Split2(x, &p1, &p2));
+      if (RS_B3_ABLATE & 16) (void)Split2(x, &p1, &p2); else amax = fmaxf(amax, Split2(x, &p1, &p2));
       *reinterpret_cast<f16x4 *>(As + a_lds[h]) = p1;
       *reinterpret_cast<f16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
     }
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   // part, the high part meets both -- smallest terms first for every accumulator.
   auto step = [&](int t, const f16x8 (&bf)[2][P]) __attribute__((always_inline)) {
     const unsigned char *As = smem + (t & 1) * STAGE + lane * 16;
+    if (RS_B3_ABLATE & 8) return;
     // fragment reads run one fragment ahead of the MFMAs that use them
     f16x8 cur = *reinterpret_cast<const f16x8 *>(As + ((P - 1) * RT + wm * MR) * kB3FragBytes), nxt = cur;
 #pragma unroll
@@ -182,7 +189,10 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
         for (int pb = P - 1; pb >= 0; pb--) {
           if (pb > P - 1 - pa) continue;
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) {
+            if (RS_B3_ABLATE & 1) acc[i][j][0] += (float)cur[0] * (float)bf[j][pb][0];
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j][pb], cur, acc[i][j], 0, 0, 0);
+          }
         }
       }
       cur = nxt;
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
   if (amax >= kB3Overflow) *d.ovf = 1;
+  if (RS_B3_ABLATE & 4) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
 #include "nnet_b3_epilogue.inc"
 }
 
