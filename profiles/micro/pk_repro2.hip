@@ -561,6 +561,71 @@ int run_beside8(const char *name, unsigned *d_err, float *d_out, hipStream_t sv,
   return 0;
 }
 
+// ... and the other way round: which OTHER instructions with sub-register operand selection does the perturber of burner8<4> (VALU results
+// on their way into MFMA sources) disturb?  The product's kernels use the sub-dword convert (the fp16 split) and DPP rotations (every
+// wave reduction); the packed forms are the compiler's.
+template <int FORM>
+__global__ __launch_bounds__(256, 2) void victim_forms2(unsigned *errors, int rounds) {
+  const int lane = threadIdx.x & 63;
+  unsigned bad = 0;
+  for (int it = 0; it < rounds; it++) {
+    const float a0 = (float)((it * 7 + lane) & 255), a1 = (float)((it * 13 + 3 * lane) & 255) + 300.f;
+    const float b0 = (float)((it * 5 + 2 * lane) & 255) + 1000.f, b1 = (float)((it * 11 + lane) & 127) + 2000.f;
+    float r0 = 0.f, r1 = 0.f, e0 = 0.f, e1 = 0.f;
+    if (FORM == 0) {            // v_cvt_f32_f16_sdwa src0_sel:WORD_1 (GemmKernelB3's split)
+      const unsigned packed = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)a1) << 16) | (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a0);
+      __asm__ volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r0) : "v"(packed));
+      __asm__ volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(r1) : "v"(packed));
+      e0 = a1; e1 = a0;
+    } else if (FORM == 1) {     // DPP row rotation as a source (the wave reductions of the search, the CG solve, ...)
+      __asm__ volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r0) : "v"(a0), "v"(b0));
+      const float nb = (float)((it * 7 + ((lane & 48) | ((lane - 1) & 15))) & 255);      // a0 of the lane one to the right inside the row of 16
+      e0 = nb + b0; r1 = e1 = 0.f;
+    } else if (FORM == 2) {     // v_pk_add_f32, source 1 half-swapped
+      __asm__ volatile(
+          "v_mov_b32 v112, %2\n\tv_mov_b32 v113, %3\n\tv_mov_b32 v114, %4\n\tv_mov_b32 v115, %5\n\ts_nop 4\n\t"
+          "v_pk_add_f32 v[116:117], v[112:113], v[114:115] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+          "s_nop 4\n\tv_mov_b32 %0, v116\n\tv_mov_b32 %1, v117"
+          : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "v112", "v113", "v114", "v115", "v116", "v117");
+      e0 = a0 + b1; e1 = a1 + b0;
+    } else if (FORM == 3) {     // v_pk_fma_f32, source 2 half-swapped
+      __asm__ volatile(
+          "v_mov_b32 v112, %2\n\tv_mov_b32 v113, %3\n\tv_mov_b32 v114, %4\n\tv_mov_b32 v115, %5\n\tv_mov_b32 v118, 1.0\n\tv_mov_b32 v119, 1.0\n\ts_nop 4\n\t"
+          "v_pk_fma_f32 v[116:117], v[112:113], v[118:119], v[114:115] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n\t"
+          "s_nop 4\n\tv_mov_b32 %0, v116\n\tv_mov_b32 %1, v117"
+          : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
+      e0 = a0 + b1; e1 = a1 + b0;
+    } else {                    // v_pk_mul_f32, source 1 NOT swapped but broadcast from its high word (op_sel:[0,1] op_sel_hi:[1,1])
+      __asm__ volatile(
+          "v_mov_b32 v112, %2\n\tv_mov_b32 v113, %3\n\tv_mov_b32 v114, %4\n\tv_mov_b32 v115, %5\n\ts_nop 4\n\t"
+          "v_pk_mul_f32 v[116:117], v[112:113], v[114:115] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+          "s_nop 4\n\tv_mov_b32 %0, v116\n\tv_mov_b32 %1, v117"
+          : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "v112", "v113", "v114", "v115", "v116", "v117");
+      e0 = a0 * b1; e1 = a1 * b1;
+    }
+    bad += (unsigned)(r0 != e0) + (unsigned)(r1 != e1);
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+template <int FORM>
+int run_forms2(const char *name, unsigned *d_err, float *d_out, hipStream_t sv, hipStream_t sb) {
+  for (int with_burner = 0; with_burner < 2; with_burner++) {
+    unsigned total = 0;
+    for (int rep = 0; rep < 4; rep++) {
+      CHECK(hipMemsetAsync(d_err, 0, 256, sv));
+      CHECK(hipStreamSynchronize(sv));
+      if (with_burner) for (int l = 0; l < 4; l++) hipLaunchKernelGGL(burner8<4>, dim3(512), dim3(256), 0, sb, d_out, 50000);
+      hipLaunchKernelGGL(victim_forms2<FORM>, dim3(512), dim3(256), 0, sv, d_err, 100000);
+      unsigned e = 0;
+      CHECK(hipMemcpyAsync(&e, d_err, 4, hipMemcpyDeviceToHost, sv));
+      CHECK(hipStreamSynchronize(sv)); CHECK(hipStreamSynchronize(sb));
+      total += e;
+    }
+    printf("%-72s %-44s %u wrong\n", name, with_burner ? "beside MFMAs with VALU-written sources:" : "alone:", total);
+  }
+  return 0;
+}
+
 template <int KIND>
 int run_beside4(const char *name, unsigned *d_err, float *d_out, hipStream_t sv, hipStream_t sb) {
   unsigned total = 0;
@@ -685,6 +750,11 @@ int main() {
   run_beside8<4>("operands that change every instruction:", d_err, d_out, sv, sb);
   run_beside8<5>("constant operands, the same VALU work feeding nothing:", d_err, d_out, sv, sb);
   run_beside8<6>("two constant operand sets alternating:", d_err, d_out, sv, sb);
+  run_forms2<0>("v_cvt_f32_f16_sdwa src0_sel:WORD_1 (the split's sub-dword convert)", d_err, d_out, sv, sb);
+  run_forms2<1>("v_add_f32_dpp row_ror:1 (the wave reductions)", d_err, d_out, sv, sb);
+  run_forms2<2>("v_pk_add_f32, source 1 half-swapped", d_err, d_out, sv, sb);
+  run_forms2<3>("v_pk_fma_f32, source 2 half-swapped", d_err, d_out, sv, sb);
+  run_forms2<4>("v_pk_mul_f32, source 1 broadcast from its high word", d_err, d_out, sv, sb);
   run_beside7<0>("v_lshl_add_u64:", d_err, d_out, sv, sb);
   run_beside7<1>("v_mov_b64:", d_err, d_out, sv, sb);
   run_beside7<2>("v_lshlrev_b64:", d_err, d_out, sv, sb);
