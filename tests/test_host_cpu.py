@@ -341,9 +341,12 @@ def test_fuzzy_control_flow_of_the_transcriber(tmp_path):
                                            ("decode_kernels.hip", ["-ffp-contract=off"]), ("decode_dense.hip", ["-ffp-contract=off"])])
 def test_no_packed_fp32_math_beside_the_gemm(source, extra, tmp_path):
     """Kernels that can share a CU with the MFMA GEMM of another decode call must not contain packed FP32 VALU math
-    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): those instructions gave wrong results in 16-lane groups next to
-    GemmKernelB3.  The compiler forms them on its own when it vectorises scalar float code, so the
-    Makefile builds these files with NOPACK; this test compiles them the same way and looks at the ISA.
+    (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): a packed add / multiply whose LOW result takes the HIGH word of source 1
+    (op_sel[1] = 1) returns 0.0 in 16-lane groups while another wave on the CU feeds VALU results into MFMA sources, as
+    GemmKernelB3 does (profiles/r04/pk_interference.txt: bisected to the instruction, reproduced with two standalone kernels).
+    Which operand selection the compiler picks is not ours to choose, so none of the packed forms is allowed: the compiler
+    forms them on its own when it vectorises scalar float code, the Makefile builds these files with NOPACK, and this test
+    compiles them the same way and looks at the ISA.
     (The UBM scoring, once the one deliberate v_pk_fma_f32 user, runs on the matrix cores now -- UbmPostMfmaKernel -- and its
     vector fallback uses scalar FMAs.)"""
     import re
