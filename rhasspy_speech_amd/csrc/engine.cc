@@ -1226,8 +1226,14 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
     // device-wide synchronisation that would stall the other calls in flight) in the steady state
     lw.extra_cost = arena_.AllocT<float>((size_t)n_utts * tok_cap + 64);
     int *d_count = arena_.AllocT<int>(4);
-    std::vector<LatArc> h_arcs;
+    const LatArc *h_arcs = nullptr;          // pinned staging (the call's host arena): a pageable destination copied at 5 GB/s
+    size_t n_arcs = 0;
     LatArcBuffer &ab = cx.lat_arcs[gi];
+    // RS_LATTICE_TRACE=1: where the tail's time goes (kernel + count, copy of the arcs to the host, grouping, the per-utterance jobs)
+    static const bool lat_trace = [] { const char *e = std::getenv("RS_LATTICE_TRACE"); return e && std::atoi(e) != 0; }();
+    auto lt0 = std::chrono::steady_clock::now();
+    float lt_ms[4] = {0, 0, 0, 0};
+    auto lt_mark = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lt_ms[i] += std::chrono::duration<float, std::milli>(n_ - lt0).count(); lt0 = n_; };
     for (int attempt = 0; attempt < 8; attempt++) {
       if (ab.cap == 0) {
         ab.cap = 1u << 20;
@@ -1240,10 +1246,13 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       RS_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
       RS_HIP(hipStreamSynchronize(s));
       const int count = *h_count;
+      lt_mark(0);
       if (count <= (int)ab.cap) {
-        h_arcs.resize(count);
-        if (count) RS_HIP(hipMemcpyAsync(h_arcs.data(), ab.d, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost, s));
+        LatArc *dst = harena.AllocT<LatArc>((size_t)count + 1);
+        if (count) RS_HIP(hipMemcpyAsync(dst, ab.d, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost, s));
         RS_HIP(hipStreamSynchronize(s));
+        h_arcs = dst; n_arcs = (size_t)count;
+        lt_mark(1);
         break;
       }
       if (attempt == 7) Fail("lattice extraction: arc buffer overflow");
@@ -1252,9 +1261,15 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       ab.cap = (size_t)count + (size_t)count / 4 + 1024;
       RS_HIP(hipMalloc((void **)&ab.d, sizeof(LatArc) * ab.cap));
     }
-    // group by utterance
-    std::vector<std::vector<const LatArc *>> per(n_utts);
-    for (auto &a : h_arcs) if (a.utt >= 0 && a.utt < n_utts) per[a.utt].push_back(&a);
+    // group by utterance: a stable counting sort of the arc indices (the kernel appends arcs in whatever order its workgroups finish)
+    std::vector<int> ubegin(n_utts + 1, 0), order(n_arcs);
+    for (size_t i = 0; i < n_arcs; i++) if (h_arcs[i].utt >= 0 && h_arcs[i].utt < n_utts) ubegin[h_arcs[i].utt + 1]++;
+    for (int u = 0; u < n_utts; u++) ubegin[u + 1] += ubegin[u];
+    {
+      std::vector<int> cur(ubegin.begin(), ubegin.end() - 1);
+      for (size_t i = 0; i < n_arcs; i++) if (h_arcs[i].utt >= 0 && h_arcs[i].utt < n_utts) order[cur[h_arcs[i].utt]++] = (int)i;
+    }
+    lt_mark(2);
     auto one = [&](int u) {
       UttResult &ur = out_utts[u];
       if (ur.status != RS_OK) return;
@@ -1268,10 +1283,11 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
         return k;
       };
       lat.start = sid(0);   // the start token is the first token of frame 0
-      for (const LatArc *a : per[u]) { sid(a->src); if (a->arc >= 0) sid(a->dst); }
+      for (int k = ubegin[u]; k < ubegin[u + 1]; k++) { const LatArc *a = h_arcs + order[k]; sid(a->src); if (a->arc >= 0) sid(a->dst); }
       lat.num_states = (int)id.size();
       lat.final_cost.assign(lat.num_states, std::numeric_limits<double>::infinity());
-      for (const LatArc *a : per[u]) {
+      for (int k = ubegin[u]; k < ubegin[u + 1]; k++) {
+        const LatArc *a = h_arcs + order[k];
         if (a->arc < 0) { lat.final_cost[id[a->src]] = a->graph; continue; }
         lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic, hclg_.arcs[a->arc].ilabel});
       }
@@ -1320,6 +1336,10 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       for (auto &t : th) t.join();
       for (auto &e : errs) if (e) std::rethrow_exception(e);
     }
+    lt_mark(3);
+    if (lat_trace)
+      std::fprintf(stderr, "lattice tail: kernel + count %.2f ms, %zu arcs (%.1f MB) to the host %.2f ms, grouping %.2f ms, %d utterances on %d threads %.2f ms\n",
+                   lt_ms[0], n_arcs, n_arcs * sizeof(LatArc) / 1e6, lt_ms[1], lt_ms[2], n_utts, nthr, lt_ms[3]);
     timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_l0).count();
   }}
 
