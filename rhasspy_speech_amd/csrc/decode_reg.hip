@@ -392,6 +392,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     RS_T(3);
     // ---- commit frame f+1: keys -> costs and back-pointers; statistics for the next frame
     int *bp_row = bp + (size_t)(f + 1) * S;
+    float *cost_row = w.cost_rows ? w.cost_rows + (frame_row0 + (size_t)(f + 1)) * S : nullptr;      // (n-best / lattice calls)
     st_min = INF; st_arg = 0x7fffffff; st_cnt = 0;
     // ... and the histogram of the new frame's costs over [smallest emitted cost, cutoff) (any monotone binning will do: what falls
     // outside -- an epsilon arc of negative weight -- lands in the first bin)
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       const bool alive = c < closure_cutoff;                     // empty -> NaN -> false
       bp_row[s] = alive ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
       cost_cur[s] = alive ? c : INF;
+      if (cost_row) cost_row[s] = alive ? c : INF;
       key_next[s] = RS_EMPTY;
       if (alive & hist_ok) atomicAdd(&hist2[hpar][HistBin(c)], 1u);      // (unconditional, into a spare word for the dead: 1.10 -> 1.19 ms)
       st_cnt += (int)alive;
@@ -879,6 +881,54 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
     return;
   }
   hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem, f_begin, f_end);
+}
+
+// Dense rows -> token lists, one workgroup per utterance: its four waves take the frames in turn, count the tokens of each (pass 1),
+// one wave prefix-sums the counts into frame_tok_off, the waves write their frames' tokens in state order (pass 2; frame 0 starts with
+// the start state's token: the lattice's start is token 0).
+__global__ __launch_bounds__(256) void DenseToTokensKernel(HclgDev h, BatchGeom g, DenseWork dw, DecodeWork w) {
+  extern __shared__ int dtt_cnt[];          // [T + 2]
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = g.d_num_frames[u], S = h.num_states;
+  int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  if (T <= 0 || w.out_nwords[u] < 0) { for (int f = tid; f <= g.max_frames + 1; f += 256) frame_off[f] = 0; return; }
+  const size_t row0 = (size_t)u * (g.max_frames + 1);
+  const float *cost = dw.cost_rows + row0 * S;
+  const int *bp = dw.bp + row0 * S;
+  int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
+  for (int f = wave; f <= T; f += 4) {
+    int n = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) { const int s = s0 + lane; n += __popcll(__ballot(s < S && cost[(size_t)f * S + s] < INFINITY)); }
+    if (lane == 0) dtt_cnt[f] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int f = 0; f <= T; f++) { const int n = dtt_cnt[f]; dtt_cnt[f] = run; frame_off[f] = run; run += n; }
+    dtt_cnt[T + 1] = run;
+    frame_off[T + 1] = run;
+  }
+  __syncthreads();
+  for (int f = wave; f <= T; f += 4) {
+    int run = dtt_cnt[f];
+    if (f == 0) {      // the start token first
+      if (lane == 0) tokens[run] = make_int4(h.start, __float_as_int(cost[h.start]), -1, bp[h.start]);
+      run++;
+    }
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const float c = s < S ? cost[(size_t)f * S + s] : INFINITY;
+      const bool on = c < INFINITY && !(f == 0 && s == h.start);
+      const unsigned long long m = __ballot(on);
+      if (on) tokens[run + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(s, __float_as_int(c), -1, bp[(size_t)f * S + s]);
+      run += __popcll(m);
+    }
+  }
+}
+
+void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s) {
+  if (g.n_utts == 0) return;
+  hipLaunchKernelGGL(DenseToTokensKernel, dim3(g.n_utts), dim3(256), sizeof(int) * (size_t)(g.max_frames + 4), s, h, g, dw, w);
 }
 
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state

@@ -1075,6 +1075,15 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   sp->want_lattice = (nbest > 1 || lat_scale != 1.0f || opts_.emit_lattice != 0 || sp->unscale);
   sp->use_reg = reg_dev_.nt != 0 && !sp->want_lattice && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1);
   sp->use_dense = dense_ok_ && !sp->want_lattice && !force_sparse_ && decoder_choice_ != 3;
+  // A lattice needs every token of every frame, which the token-list searches keep and the register-resident one does not (5.8 ms
+  // against 1.1 for the headline batch): it leaves the costs of all (frame, state) pairs beside its back-pointer rows instead and a
+  // compaction kernel writes the token lists LatticeKernel reads (RS_LATTICE_SEARCH=tokens: the token-list search, as before round 4)
+  {
+    const char *e = std::getenv("RS_LATTICE_SEARCH");          // (read per call: a test compares the two)
+    sp->reg_lattice = sp->want_lattice && reg_dev_.nt != 0 && !force_sparse_ && (decoder_choice_ == 0 || decoder_choice_ == 1) &&
+                      !(ExactOrder() && reg_dev_.exact_ok) && !(e && std::string(e) == "tokens");
+    if (sp->reg_lattice) { sp->use_reg = true; sp->use_dense = true; }
+  }
   int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
   cap_pf = std::min(cap_pf, S);
   const long tok_cap_l = (long)(maxT + 2) * cap_pf;
@@ -1086,7 +1095,9 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   size_t need = (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)sp->max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
   if (sp->use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
     need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
-  else {                  // token-list search: per-state tables, queues, the token arrays of every frame
+  if (sp->reg_lattice)    // ... the cost rows, the token lists made of them, LatticeKernel's two maps
+    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4 + (size_t)S * 8) + 8192;
+  if (!sp->use_dense) {                  // token-list search: per-state tables, queues, the token arrays of every frame
     need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
     sp->use_hash = decoder_choice_ != 3 && DecodeHashUsable(hclg_dev_);
     if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeHashTableSize() * (8 + 4 + 4) + (size_t)DecodeHashSlotCap() * (16 + 16) + (size_t)kHashCandCap * 12 + 4) + 8192;
@@ -1117,6 +1128,16 @@ void Model::AllocSearch(SearchPlan *sp, DeviceArena &arena_, hipStream_t s, bool
       dw.state_cost = arena_.AllocT<float>((size_t)n_utts * (2 * (size_t)S + 4));
       RS_HIP(hipMemsetAsync(w.counters, 0, sizeof(long long) * 8 * (size_t)n_utts, s));
     }
+    if (sp->reg_lattice && !pooled_frames) {
+      dw.cost_rows = arena_.AllocT<float>((size_t)n_utts * (maxT + 1) * S);
+      w.tok_cap = sp->tok_cap;
+      w.tokens = arena_.AllocT<int4>((size_t)n_utts * sp->tok_cap);
+      w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
+      w.map_a = arena_.AllocT<int>((size_t)n_utts * S);
+      w.map_b = arena_.AllocT<int>((size_t)n_utts * S);
+      RS_HIP(hipMemsetAsync(w.map_a, 0xFF, sizeof(int) * (size_t)n_utts * S, s));      // LatticeKernel expects both state -> token maps empty
+      RS_HIP(hipMemsetAsync(w.map_b, 0xFF, sizeof(int) * (size_t)n_utts * S, s));
+    }
   }
 }
 
@@ -1125,6 +1146,7 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   if (sp->use_dense) {
     if (sp->use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, sp->dopts, g, ll, ll_ld, sp->dw, -1, maxT + 1, s);
     else LaunchDecodeDense(hclg_dev_, rev_dev_, sp->dopts, g, ll, ll_ld, am_.nnet.output_dim, sp->dw, s);
+    if (sp->reg_lattice) LaunchDenseToTokens(hclg_dev_, g, sp->dw, sp->w, s);
     return;
   }
   DecodeWork &w = sp->w;
@@ -1490,7 +1512,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   const int overlap_env = [] { const char *e = std::getenv("RS_OVERLAP_SLABS"); return e ? std::atoi(e) : 1; }();
   const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
                             nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
-  const bool pipelined = use_reg && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
+  const bool pipelined = use_reg && !sp.reg_lattice && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
                          s == cx.stream;
   const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
   std::vector<int> slab_off(n_slabs + 1, 0);

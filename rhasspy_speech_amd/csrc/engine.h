@@ -114,6 +114,7 @@ struct RowMaps {
 // Which search kernel a call runs and its work buffers (engine.cc: PlanSearch / AllocSearch / LaunchSearch / CollectResults).
 struct SearchPlan {
   bool unscale = false, want_lattice = false, use_reg = false, use_dense = false, use_hash = false;
+  bool reg_lattice = false;      // n-best / lattice call on a grammar graph: register-resident search + its rows turned into token lists
   int S = 0, tok_cap = 0, max_words = 1024, maxT = 0, n_utts = 0;
   DecodeOptsDev dopts{};
   DecodeWork w{};

@@ -288,6 +288,9 @@ struct DenseWork {
   int max_words;
   int *path;                  // n_utts x path_cap x 2 scratch: best path as (arc, frame) pairs
   int path_cap;
+  // n-best / lattice calls on grammar graphs (RegDecodeKernel + LaunchDenseToTokens): the costs of every (frame, state) beside the
+  // back-pointer rows, +inf = no token; null = not kept
+  float *cost_rows = nullptr; // n_utts x (max_frames + 1) x S
   // resumable decoding (decode_reg.hip): token costs and scalars carried between the time slabs of one utterance
   float *state_cost;          // n_utts x (2 S + 4): S costs, then {closure cutoff, error flag, -, -}, then S list positions (exact token order)
   // Streams (decode_reg.hip, win_begin != null): utterance u decodes frames [win_begin[u], win_end[u]) (win_begin -1 starts the
@@ -320,6 +323,9 @@ bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int
 // (LDS for the traceback staging is only requested then).
 bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
                      const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s, bool any_final = true);
+// Token lists (DecodeWork: tokens {state, cost bits, -, back-pointer arc}, frame_tok_off) out of the dense cost / back-pointer rows a
+// register-resident search with DenseWork::cost_rows left behind: what LatticeKernel reads.  Frame 0's first token is the start state's.
+void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,

@@ -223,6 +223,36 @@ def test_decoder_variants_agree_on_a_graph_of_a_few_thousand_states(tmp_path, mo
             assert res[variant].counters(u)[5:7] == res["sparse"].counters(u)[5:7], (variant, u)
 
 
+@pytest.mark.parametrize("name,extra", [("tiny_u0", {}), ("zam_u0", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0)),
+                                        ("zam_u1", dict(max_active=40, min_active=0, beam=16.0))])
+def test_lattice_from_the_register_resident_search_is_the_token_list_searchs(case_cache, name, extra, monkeypatch):
+    """n-best / lattice calls on grammar graphs run the register-resident search, which leaves the costs of every (frame, state) pair
+    beside its back-pointer rows, and turn those rows into the token lists LatticeKernel reads (LaunchDenseToTokens);
+    RS_LATTICE_SEARCH=tokens runs the token-list search instead, as every round before: the same lattice (arc count), the same
+    n-best lists and costs, batch and stream."""
+    from rhasspy_speech_amd import _lib, synth
+    model, pcm = make_model(case_cache, name, **extra)
+    pcms = [pcm] + [synth.synth_utterance(1300 + i, n) for i, n in enumerate([48000, 9000, 33000, 1700])]
+    def run():
+        b = model.decode_batch(pcms, nbest=5)
+        st = _lib.Stream(model)
+        raw = pcms[1].tobytes()
+        for k in range(0, len(raw), 8192):
+            st.accept(raw[k:k + 8192])
+            st.advance()
+        return b, st.finish(5, 1.0)
+    got_b, got_s = run()
+    monkeypatch.setenv("RS_LATTICE_SEARCH", "tokens")
+    ref_b, ref_s = run()
+    for got, ref, n in ((got_b, ref_b, len(pcms)), (got_s, ref_s, 1)):
+        for u in range(n):
+            assert got.num_hyps(u) == ref.num_hyps(u), u
+            assert got.counters(u)[4] == ref.counters(u)[4], u          # arcs of the raw lattice
+            for k in range(ref.num_hyps(u)):
+                assert got.words(u, k) == ref.words(u, k), (u, k)
+                np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
+
+
 @pytest.mark.parametrize("name,extra", VARIANT_CASES)
 def test_cutoff_from_the_commit_histogram_is_the_exact_selection(case_cache, name, extra, monkeypatch):
     """RegDecodeKernel's GetCutoff takes the max-active / min-active order statistic from the histogram the commit pass leaves
