@@ -36,15 +36,24 @@ typedef struct rs_stream rs_stream;
 /* Options = the command-line flags the reference passes (transcribe_wav.py:46-55,
  * transcribe_stream.py:55-60) plus the Kaldi defaults it relies on
  * (decoder/lattice-faster-decoder.h:38-92, nnet3/decodable-simple-looped.h:50-60). */
+/* rs_decode_opts is the command line of the reference's binaries.  The reference registers the decoder's and the decodable's
+ * options on the parser that reads --config=online.conf (online2-wav-nnet3-latgen-faster.cc:131-137,
+ * online2-cli-nnet3-decode-faster.cc:73-78) and ParseOptions reads the config file FIRST, the command line overriding it
+ * (util/parse-options.cc:328-345).  Same here: a field left at RS_OPT_UNSET takes online.conf's value if the file sets the option
+ * and the reference's default otherwise; any other value wins over online.conf.  rs_default_opts() sets what rhasspy passes on
+ * the command line (transcribe_wav.py:46-55: --max-active --lattice-beam --acoustic-scale --beam) and leaves the rest unset.
+ * Options of online.conf the kernels cannot honour (--frame-subsampling-factor != 1, --extra-left-context-initial != 0,
+ * --prune-interval != 25, --determinize-lattice=false, --online=true, --do-endpointing=true) fail the model load. */
+#define RS_OPT_UNSET (-1)
 typedef struct rs_decode_opts {
-  float beam;                  /* --beam            (24.0 as rhasspy runs it) */
-  int32_t max_active;          /* --max-active      (7000) */
-  int32_t min_active;          /* --min-active      (200, Kaldi default) */
-  float lattice_beam;          /* --lattice-beam    (8.0) */
-  float beam_delta;            /* --beam-delta      (0.5) */
-  float acoustic_scale;        /* --acoustic-scale of the decodable (1.0 as rhasspy runs it) */
-  int32_t frames_per_chunk;    /* --frames-per-chunk (24; only changes streaming iVector timing) */
-  int32_t frame_subsampling_factor; /* must be 1: the reference never passes it */
+  float beam;                  /* --beam            (24.0 as rhasspy runs it; reference default 16.0) */
+  int32_t max_active;          /* --max-active      (7000 as rhasspy runs it; reference default INT32_MAX) */
+  int32_t min_active;          /* --min-active      (unset; reference default 200) */
+  float lattice_beam;          /* --lattice-beam    (8.0 as rhasspy runs it; reference default 10.0) */
+  float beam_delta;            /* --beam-delta      (unset; reference default 0.5) */
+  float acoustic_scale;        /* --acoustic-scale of the decodable (1.0 as rhasspy runs it; reference default 0.1) */
+  int32_t frames_per_chunk;    /* --frames-per-chunk (unset; reference default 24; only changes streaming iVector timing) */
+  int32_t frame_subsampling_factor; /* --frame-subsampling-factor (unset; must resolve to 1, the reference's default) */
   int32_t device_id;           /* HIP device ordinal */
   int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
   int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */

@@ -759,13 +759,23 @@ class Transcript:
 class Oracle:
     """CPU restatement of one reference pipeline invocation (model + graph loaded once)."""
 
-    def __init__(self, model_dir, graph_dir, beam=24.0, max_active=7000, min_active=200, lattice_beam=8.0, acoustic_scale=1.0,
-                 frames_per_chunk=24):
+    def __init__(self, model_dir, graph_dir, beam=24.0, max_active=7000, min_active=None, lattice_beam=8.0, acoustic_scale=1.0,
+                 frames_per_chunk=None, beam_delta=None):
         model_dir, graph_dir = Path(model_dir), Path(graph_dir)
-        self.opts = dict(beam=beam, max_active=max_active, min_active=min_active, lattice_beam=lattice_beam)
+        conf = dict(kf.read_config(model_dir / "model" / "online" / "conf" / "online.conf"))
+        # The binaries register decoder / decodable options on the parser that reads --config (online2-wav-nnet3-latgen-faster.cc:
+        # 131-137): the config file is read first, the command line overrides it (util/parse-options.cc:328-345).  The keyword
+        # arguments are the command line; beam / max_active / lattice_beam / acoustic_scale are always on rhasspy's
+        # (transcribe_wav.py:46-55), the others only when given.
+        if min_active is None:
+            min_active = int(conf.get("min-active", 200))                  # lattice-faster-decoder.h:61
+        if frames_per_chunk is None:
+            frames_per_chunk = int(conf.get("frames-per-chunk", 24))      # decodable-simple-looped.h:57
+        if beam_delta is None:
+            beam_delta = float(conf.get("beam-delta", 0.5))                # lattice-faster-decoder.h:66
+        self.opts = dict(beam=beam, max_active=max_active, min_active=min_active, lattice_beam=lattice_beam, beam_delta=beam_delta)
         self.acoustic_scale = acoustic_scale
         self.chunk = frames_per_chunk
-        conf = dict(kf.read_config(model_dir / "model" / "online" / "conf" / "online.conf"))
         assert conf.get("feature-type", "mfcc") == "mfcc"
         self.id2pdf, nf = kf.read_final_mdl(model_dir / "model" / "model" / "final.mdl")
         # the dither of frame t is seeded by rand() value number (calls of the model set-up + t): oracle/nnet3_rand.py

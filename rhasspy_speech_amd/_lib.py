@@ -16,6 +16,7 @@ import numpy as np
 _LIB_PATH = Path(__file__).resolve().parent / "librhasspy_speech_hip.so"
 
 RS_OK, RS_ERR_ARG, RS_ERR_MODEL, RS_ERR_DEVICE, RS_ERR_DECODE = 0, -1, -2, -3, -4
+RS_OPT_UNSET = -1      # rs_decode_opts field not given on the "command line": online.conf's value, else the reference's default
 
 
 class DecodeOpts(C.Structure):

@@ -72,12 +72,12 @@ int rs_default_opts(rs_decode_opts *o) {
   std::memset(o, 0, sizeof(*o));
   o->beam = 24.0f;           // transcribe_wav.py:24
   o->max_active = 7000;      // transcribe_wav.py:21
-  o->min_active = 200;       // lattice-faster-decoder.h:61
+  o->min_active = RS_OPT_UNSET;       // not on rhasspy's command line: online.conf's value, else 200 (lattice-faster-decoder.h:61)
   o->lattice_beam = 8.0f;    // transcribe_wav.py:22
-  o->beam_delta = 0.5f;      // lattice-faster-decoder.h:66
+  o->beam_delta = (float)RS_OPT_UNSET;         // ... else 0.5 (lattice-faster-decoder.h:66)
   o->acoustic_scale = 1.0f;  // transcribe_wav.py:53 ("--acoustic-scale=1.0")
-  o->frames_per_chunk = 24;  // decodable-simple-looped.h:57 rounded by GetChunkSize
-  o->frame_subsampling_factor = 1;
+  o->frames_per_chunk = RS_OPT_UNSET;          // ... else 24 (decodable-simple-looped.h:57)
+  o->frame_subsampling_factor = RS_OPT_UNSET;  // ... else 1  (decodable-simple-looped.h:56)
   o->device_id = 0;
   // The search reads log-likelihoods only for the pdfs that occur on HCLG arcs (decodable-online-looped.cc:213-224): the output
   // layer is cut down to those rows when that saves at least 30 % of it -- same words, same costs (engine.cc: PruneOutputLayer).

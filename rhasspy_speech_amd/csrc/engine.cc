@@ -72,6 +72,96 @@ static int RoundUp(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ model
 
+// The reference registers the decodable's and the decoder's options on the parser that reads --config=online.conf
+// (online2-wav-nnet3-latgen-faster.cc:131-137, online2-cli-nnet3-decode-faster.cc:73-78; nnet3/decodable-simple-looped.h:68-81,
+// decoder/lattice-faster-decoder.h:67-85): ParseOptions reads the config file first and the command line overrides it
+// (util/parse-options.cc:328-345).  Here rs_decode_opts is the command line: a field left at RS_OPT_UNSET takes online.conf's
+// value, else the reference's default; a field that is set wins.  What the kernels cannot honour is refused, never dropped.
+static int ConfInt(const std::string &v) {
+  size_t n = 0;
+  int x = 0;
+  try { x = std::stoi(v, &n); } catch (...) { n = 0; }
+  if (n == 0 || n != v.size()) Fail("Invalid integer option \"" + v + "\"");       // parse-options.cc:591
+  return x;
+}
+static float ConfFloat(const std::string &v) {
+  size_t n = 0;
+  float x = 0;
+  try { x = std::stof(v, &n); } catch (...) { n = 0; }
+  if (n == 0 || n != v.size()) Fail("Invalid floating-point option \"" + v + "\"");
+  return x;
+}
+static bool ConfBool(const std::string &v) {
+  if (v == "true" || v == "t" || v == "1" || v == "True" || v == "T" || v.empty()) return true;
+  if (v == "false" || v == "f" || v == "0" || v == "False" || v == "F") return false;
+  Fail("Invalid format for boolean argument [expected true or false]: " + v);       // parse-options.cc:582
+}
+
+void Model::ResolveDecoderOptions() {
+  const std::string where = " (online.conf: " + fc_.conf_path + ")";
+  // values of online.conf, in file order (a repeated option: the last one wins, as in ParseOptions)
+  bool has_beam = false, has_max = false, has_min = false, has_lb = false, has_bd = false, has_as = false, has_fpc = false, has_fsf = false;
+  float c_beam = 0, c_lb = 0, c_bd = 0, c_as = 0;
+  int c_max = 0, c_min = 0, c_fpc = 0, c_fsf = 0;
+  for (auto &kv : fc_.decoder_conf) {
+    const std::string &k = kv.first, &v = kv.second;
+    if (k == "beam") { c_beam = ConfFloat(v); has_beam = true; }
+    else if (k == "max-active") { c_max = ConfInt(v); has_max = true; }
+    else if (k == "min-active") { c_min = ConfInt(v); has_min = true; }
+    else if (k == "lattice-beam") { c_lb = ConfFloat(v); has_lb = true; }
+    else if (k == "beam-delta") { c_bd = ConfFloat(v); has_bd = true; }
+    else if (k == "acoustic-scale") { c_as = ConfFloat(v); has_as = true; }
+    else if (k == "frames-per-chunk") { c_fpc = ConfInt(v); has_fpc = true; }
+    else if (k == "frame-subsampling-factor") { c_fsf = ConfInt(v); has_fsf = true; }
+    else if (k == "extra-left-context-initial") {
+      const int x = ConfInt(v);
+      if (x < 0) Fail("KALDI_ASSERT: at Check:decodable-simple-looped.h:62, failed: extra_left_context_initial >= 0 && frame_subsampling_factor > 0 && frames_per_chunk > 0 && acoustic_scale > 0.0" + where);
+      if (x != 0) Fail("--extra-left-context-initial=" + v + " is not supported by the HIP path (only 0, the reference's default)" + where);
+    } else if (k == "prune-interval") {
+      const int x = ConfInt(v);
+      if (x != 25) Fail("--prune-interval=" + v + " is not supported by the HIP path (only 25, the reference's default: lattices are pruned once, exactly, at the end)" + where);
+    } else if (k == "determinize-lattice") {
+      if (!ConfBool(v)) Fail("--determinize-lattice=false is not supported by the HIP path (lattices are always determinised)" + where);
+    } else if (k == "hash-ratio") {
+      if (!(ConfFloat(v) >= 1.0f)) Fail("KALDI_ASSERT: at Check:lattice-faster-decoder.h:87, failed: hash_ratio >= 1.0" + where);
+    } else if (k == "online") {
+      if (ConfBool(v)) Fail("--online=true is not supported by the HIP path (the reference passes --online=false)" + where);
+    } else if (k == "do-endpointing") {
+      if (ConfBool(v)) Fail("--do-endpointing=true is not supported by the HIP path (the reference passes --do-endpointing=false)" + where);
+    } else if (k == "minimize" || k == "phone-determinize" || k == "word-determinize" || k == "debug-computation") {
+      (void)ConfBool(v);      // same n-best lists either way (the emitted lattice is equivalent, not minimised)
+    } else if (k == "max-mem" || k == "num-threads-startup") {
+      (void)ConfInt(v);
+    } else if (k == "chunk-length" || k == "delta") {
+      (void)ConfFloat(v);     // chunk-length only paces the wav binary's simulated online loop with --online=true
+    }
+  }
+  auto unset_f = [](float x) { return x == (float)RS_OPT_UNSET; };
+  auto unset_i = [](int x) { return x == RS_OPT_UNSET; };
+  if (unset_f(opts_.beam)) opts_.beam = has_beam ? c_beam : 16.0f;                                   // lattice-faster-decoder.h:56-63
+  if (unset_i(opts_.max_active)) opts_.max_active = has_max ? c_max : 0x7fffffff;
+  if (unset_i(opts_.min_active)) opts_.min_active = has_min ? c_min : 200;
+  if (unset_f(opts_.lattice_beam)) opts_.lattice_beam = has_lb ? c_lb : 10.0f;
+  if (unset_f(opts_.beam_delta)) opts_.beam_delta = has_bd ? c_bd : 0.5f;
+  if (unset_f(opts_.acoustic_scale)) opts_.acoustic_scale = has_as ? c_as : 0.1f;                    // decodable-simple-looped.h:55-59
+  if (unset_i(opts_.frames_per_chunk)) opts_.frames_per_chunk = has_fpc ? c_fpc : 24;
+  if (unset_i(opts_.frame_subsampling_factor)) opts_.frame_subsampling_factor = has_fsf ? c_fsf : 1;
+  // NnetSimpleLoopedComputationOptions::Check (decodable-simple-looped.h:61-65) / LatticeFasterDecoderConfig::Check
+  // (lattice-faster-decoder.h:86-91): the reference's binaries abort on these
+  if (!(opts_.frame_subsampling_factor > 0 && opts_.frames_per_chunk > 0 && opts_.acoustic_scale > 0.0f))
+    Fail("KALDI_ASSERT: at Check:decodable-simple-looped.h:62, failed: extra_left_context_initial >= 0 && frame_subsampling_factor > 0 && frames_per_chunk > 0 && acoustic_scale > 0.0"
+         " (frame-subsampling-factor " + std::to_string(opts_.frame_subsampling_factor) + ", frames-per-chunk " + std::to_string(opts_.frames_per_chunk) +
+         ", acoustic-scale " + std::to_string(opts_.acoustic_scale) + ")");
+  if (!(opts_.beam > 0.0f && opts_.max_active > 1 && opts_.lattice_beam > 0.0f && opts_.min_active <= opts_.max_active && opts_.beam_delta > 0.0f))
+    Fail("KALDI_ASSERT: at Check:lattice-faster-decoder.h:87, failed: beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && min_active <= max_active"
+         " && prune_interval > 0 && beam_delta > 0.0 && hash_ratio >= 1.0 && prune_scale > 0.0 && prune_scale < 1.0"
+         " (beam " + std::to_string(opts_.beam) + ", max-active " + std::to_string(opts_.max_active) + ", min-active " + std::to_string(opts_.min_active) +
+         ", lattice-beam " + std::to_string(opts_.lattice_beam) + ", beam-delta " + std::to_string(opts_.beam_delta) + ")");
+  if (opts_.frame_subsampling_factor != 1)
+    Fail("--frame-subsampling-factor=" + std::to_string(opts_.frame_subsampling_factor) + " is not supported by the HIP path (only 1: every output row is evaluated and searched)" +
+         (has_fsf ? where : std::string()));
+}
+
 Model::Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf,
              const rs_decode_opts &opts)
     : opts_(opts) {
@@ -81,18 +171,11 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
     const std::string v(e);
     // reg / dense: the LDS-resident searches of small graphs; sparse: DecodeKernel alone (dense per-state tables in HBM); hash: the
     // token-list search with the live-state table, which is what "auto" runs on graphs the first two cannot hold
-    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : v == "hash" ? 4 : 0;
-    if (decoder_choice_ == 3 || decoder_choice_ == 4) force_sparse_ = true;
+    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : v == "hash" ? 4 : v == "hash_r4" ? 5 : 0;
+    if (decoder_choice_ >= 3) force_sparse_ = true;
   }
-  if (opts_.frame_subsampling_factor != 1)
-    Fail("frame-subsampling-factor != 1 is not supported (the reference never passes it, SURVEY.md section 5)");
-  if (opts_.frames_per_chunk <= 0) Fail("frames-per-chunk must be positive");
-  // LatticeFasterDecoderConfig::Check (lattice-faster-decoder.h:86-91): the reference's decoders abort on these
-  if (!(opts_.beam > 0.0f && opts_.max_active > 1 && opts_.lattice_beam > 0.0f && opts_.min_active <= opts_.max_active))
-    Fail("KALDI_ASSERT: at Check:lattice-faster-decoder.h:87, failed: beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && min_active <= max_active"
-         " (beam " + std::to_string(opts_.beam) + ", max-active " + std::to_string(opts_.max_active) + ", min-active " + std::to_string(opts_.min_active) +
-         ", lattice-beam " + std::to_string(opts_.lattice_beam) + ")");
   ReadFeatureConfig(online_conf, &fc_);
+  ResolveDecoderOptions();
   am_.Read(final_mdl, opts_.frames_per_chunk, 0);
   hclg_.Read(hclg);
   dither_rand_calls_ = am_.nnet.setup_rand_calls;
@@ -587,6 +670,11 @@ void Model::ToDevice() {
       hclg_dev_.state_rec = static_cast<uint4 *>(UploadBytes(rec.data(), (size_t)S * sizeof(uint4)));
     }
     hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
+    {
+      std::vector<int4> af(arcs);
+      for (size_t a = 0; a < A; a++) if (hclg_.num_ieps[af[a].w] != 0) af[a].x |= (int)0x80000000;
+      hclg_dev_.arcs_f = static_cast<int4 *>(UploadBytes(af.data(), A * sizeof(int4)));
+    }
     hclg_dev_.arc_src = Upload(src);
     {
       std::vector<int> srcx(A);
@@ -700,6 +788,9 @@ std::string Model::Describe() const {
   if (pruned_from_) os << "output layer: pruned to the " << am_.nnet.output_dim << " of " << pruned_from_ << " pdfs that occur on HCLG arcs\n";
   os << "hclg: states=" << hclg_.num_states() << " arcs=" << hclg_.arcs.size() << " start=" << hclg_.start << "\n";
   os << "halo: L=" << L_ << " R=" << R_ << "\n";
+  os << "decoder_opts: beam=" << opts_.beam << " max_active=" << opts_.max_active << " min_active=" << opts_.min_active << " lattice_beam=" << opts_.lattice_beam
+     << " beam_delta=" << opts_.beam_delta << " acoustic_scale=" << opts_.acoustic_scale << " frames_per_chunk=" << opts_.frames_per_chunk
+     << " frame_subsampling_factor=" << opts_.frame_subsampling_factor << "\n";
   // (state, not structure: calls repeated on the exact-FP32 layer GEMMs because an activation left the fp16 split's range, and
   // whether the model has changed to those kernels for good)
   os << "token_order: " << (ExactOrder() && reg_dev_.exact_ok ? "exact (the reference's running cutoff in its hash order)" : "final cutoff")
@@ -1084,7 +1175,7 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
                       !(ExactOrder() && reg_dev_.exact_ok) && !(e && std::string(e) == "tokens");
     if (sp->reg_lattice) { sp->use_reg = true; sp->use_dense = true; }
   }
-  int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : std::max(4 * opts_.max_active, 8192);
+  int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : (int)std::min<long long>(std::max(4ll * opts_.max_active, 8192ll), 0x7fffffffll);
   cap_pf = std::min(cap_pf, S);
   const long tok_cap_l = (long)(maxT + 2) * cap_pf;
   if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
@@ -1100,7 +1191,8 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   if (!sp->use_dense) {                  // token-list search: per-state tables, queues, the token arrays of every frame
     need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
     sp->use_hash = decoder_choice_ != 3 && DecodeHashUsable(hclg_dev_);
-    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeHashTableSize() * (8 + 4 + 4) + (size_t)DecodeHashSlotCap() * (16 + 16) + (size_t)kHashCandCap * 12 + 4) + 8192;
+    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeLiveTableSize() * (8 + 4 + 4) + (size_t)DecodeLiveGlobalTable() * 4 + (size_t)DecodeHashSlotCap() * (16 + 16) +
+                                                (size_t)kHashCandCap * 16 + (size_t)kLiveQueueCap * 2 * 20 + 4) + 16384;
   }
   if (sp->want_lattice) need += sizeof(float) * (size_t)n_utts * sp->tok_cap + 4096;                                // LatticeKernel's extra_cost
   return need;
@@ -1162,17 +1254,24 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   if (sp->use_hash) {
     // live states of a frame in an LDS table, their per-state records in slot-indexed arrays (decode_kernels.hip); the dense tables
     // above are only touched for utterances that outgrow the table (w.redo)
-    const size_t cap = (size_t)DecodeHashSlotCap(), tab = (size_t)DecodeHashTableSize();
+    const size_t cap = (size_t)DecodeHashSlotCap(), tab = (size_t)DecodeLiveTableSize();
+    w.h_tab = (int)tab;
     w.h_keys = arena_.AllocT<unsigned long long>((size_t)n_utts * tab);
     w.h_slot_tok = arena_.AllocT<int>((size_t)n_utts * tab);
     w.h_stamp = arena_.AllocT<int>((size_t)n_utts * tab);
     w.h_cand_cap = kHashCandCap;
     { const char *e = std::getenv("RS_HASH_SLOT_LIMIT"); w.h_slot_limit = e ? std::atoi(e) : DecodeHashSlotCap(); }
-    w.h_cand = arena_.AllocT<int>((size_t)n_utts * 3 * kHashCandCap);
+    w.h_cand = arena_.AllocT<int>((size_t)n_utts * 4 * kHashCandCap);
+    w.h_gtags = arena_.AllocT<unsigned>((size_t)n_utts * DecodeLiveGlobalTable());
+    w.h_qcap = kLiveQueueCap;
+    w.h_q4 = arena_.AllocT<int4>((size_t)n_utts * 2 * kLiveQueueCap);
+    w.h_qne = arena_.AllocT<int>((size_t)n_utts * 2 * kLiveQueueCap);
+    { const char *e = std::getenv("RS_HASH_LDS_LOG"); w.h_lds_log = e ? std::atoi(e) : 0; }
     w.h_queue = arena_.AllocT<int2>((size_t)n_utts * 2 * cap);
     w.h_comp = arena_.AllocT<int4>((size_t)n_utts * cap);
     w.redo = arena_.AllocT<int>(n_utts);
-    LaunchDecodeHash(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
+    if (decoder_choice_ == 5) LaunchDecodeHash(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);      // RS_DECODER=hash_r4: round 3/4's kernel (A/B)
+    else LaunchDecodeLive(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
     if (sp->want_lattice) {      // LatticeKernel expects both state -> token maps empty (DecodeKernel leaves them so for the utterances it decodes)
       RS_HIP(hipMemsetAsync(w.map_a, 0xFF, sizeof(int) * (size_t)n_utts * S, s));
       RS_HIP(hipMemsetAsync(w.map_b, 0xFF, sizeof(int) * (size_t)n_utts * S, s));

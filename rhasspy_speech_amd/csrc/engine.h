@@ -126,6 +126,7 @@ class Model {
   Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf, const rs_decode_opts &opts);
   ~Model();
   void ToDevice();
+  void ResolveDecoderOptions();      // opts_ := command line (rs_decode_opts) over online.conf over the reference's defaults
   std::string Describe() const;
   // streaming = true reproduces online2-cli-nnet3-decode-faster: 1024-sample ticks, one iVector per nnet chunk
   // estimated from the frames available at the tick the chunk is computed on (warm-started CG).

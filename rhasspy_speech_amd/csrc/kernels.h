@@ -219,6 +219,7 @@ struct HclgDev {
   const int4 *arcs;            // {pdf+1 (0 = epsilon), olabel, weight bits, nextstate}
   const int *arc_src;          // source state of each arc
   const int *arc_srcx;         // source state | (1 << 31 if the arc is an epsilon arc): one load per traceback hop
+  const int4 *arcs_f;          // arcs with bit 31 of .x set when the destination state has epsilon arcs (decode_live.hip)
   const float *final_cost;     // S
 };
 struct DecodeOptsDev {
@@ -246,6 +247,13 @@ struct DecodeWork {
   int2 *h_queue;              // n_utts x 2 x slot cap : closure work lists (state, slot)
   int4 *h_comp;               // n_utts x slot cap : the tokens a frame expands, compacted {first emitting arc, cost, token index, out-degree}
   int *redo;                  // n_utts : 1 = the utterance outgrew the live-state table, DecodeKernel decodes it (null: DecodeKernel decodes all)
+  // LiveDecodeKernel (decode_live.hip) on top of the above: h_keys / h_slot_tok are n_utts x h_tab, h_cand holds 16-byte records
+  int h_tab;                  // DecodeLiveTableSize()
+  unsigned *h_gtags;          // n_utts x DecodeLiveGlobalTable() : second level of the state -> slot table
+  int4 *h_q4;                 // n_utts x 2 x h_qcap : closure work lists {slot | writer token << 16, first epsilon arc, key low, key high}
+  int *h_qne;                 // n_utts x 2 x h_qcap : ... and the number of epsilon arcs of the entry's state
+  int h_qcap;
+  int h_lds_log;              // > 0: use only 2^h_lds_log entries of the LDS table (tests: forces states into the second level)
   // results
   int *out_words;             // n_utts x max_words
   int *out_nwords;            // n_utts
@@ -263,6 +271,14 @@ bool DecodeHashUsable(const HclgDev &h);
 int DecodeHashSlotCap();      // live states per frame
 int DecodeHashTableSize();    // entries of the LDS table = length of the slot-indexed arrays
 void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
+                      const DecodeWork &w, hipStream_t s);
+// Round 5's form of the same search (decode_live.hip): two-level table (LDS + global), token-parallel expansion, two workgroups per CU.
+constexpr int kLiveQueueCap = 65536;     // closure work-list entries per round
+bool DecodeLiveUsable(const HclgDev &h);
+int DecodeLiveSlotCap();
+int DecodeLiveTableSize();
+int DecodeLiveGlobalTable();
+void LaunchDecodeLive(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DecodeWork &w, hipStream_t s);
 
 // Dense ("pull") variant for graphs whose per-state tables fit in LDS: one thread per destination state walks

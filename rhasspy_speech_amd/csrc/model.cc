@@ -318,6 +318,7 @@ static void ReadIvectorConfig(const std::string &path, IvectorExtractor *ie, int
 
 void ReadFeatureConfig(const std::string &online_conf, FeatureConfig *fc) {
   std::string mfcc_conf, ivec_conf, cmvn_conf, gstats;
+  fc->conf_path = online_conf;
   for (auto &kv : ReadConfigFile(online_conf)) {
     const std::string &k = kv.first, &v = kv.second;
     if (k == "feature-type") fc->feature_type = v;
@@ -328,12 +329,16 @@ void ReadFeatureConfig(const std::string &online_conf, FeatureConfig *fc) {
     else if (k == "add-pitch") { if (ParseBool(v, k)) Fail("--add-pitch=true is not supported"); }
     else if (k == "plp-config" || k == "fbank-config" || k == "online-pitch-config") {}
     else if (k.compare(0, 9, "endpoint.") == 0 || k.compare(0, 26, "ivector-silence-weighting.") == 0) {}
-    // decodable / decoder options may legally appear in online.conf as well; they are applied by the caller
+    // decodable / decoder options registered on the same parser (NnetSimpleLoopedComputationOptions, decodable-simple-looped.h:68-81;
+    // LatticeFasterDecoderConfig + its det_opts, lattice-faster-decoder.h:67-85; the binaries' own --online, --do-endpointing,
+    // --chunk-length ...): kept, and applied or refused by Model::Model -- never dropped
     else if (k == "frame-subsampling-factor" || k == "frames-per-chunk" || k == "acoustic-scale" ||
              k == "extra-left-context-initial" || k == "beam" || k == "max-active" || k == "min-active" ||
              k == "lattice-beam" || k == "beam-delta" || k == "prune-interval" || k == "hash-ratio" ||
              k == "determinize-lattice" || k == "minimize" || k == "phone-determinize" || k == "word-determinize" ||
-             k == "max-mem" || k == "debug-computation" || k == "online" || k == "do-endpointing" || k == "chunk-length") {}
+             k == "max-mem" || k == "debug-computation" || k == "online" || k == "do-endpointing" || k == "chunk-length" ||
+             k == "delta" || k == "num-threads-startup")
+      fc->decoder_conf.emplace_back(k, v);
     else Fail("Invalid option --" + k + "=" + v + " in config file " + online_conf);
   }
   if (fc->feature_type != "mfcc") {

@@ -86,6 +86,11 @@ struct FeatureConfig {
   CmvnOptions cmvn;
   MatD global_cmvn;
   IvectorExtractor ie;
+  // Decoder / decodable options found in online.conf.  The reference registers them on the parser that reads --config
+  // (online2-wav-nnet3-latgen-faster.cc:131-137, online2-cli-nnet3-decode-faster.cc:73-78), so they take effect there unless the
+  // command line repeats them (util/parse-options.cc:328-345: the config file is read first).  Model::Model applies them.
+  std::vector<std::pair<std::string, std::string>> decoder_conf;
+  std::string conf_path;
 };
 void ReadFeatureConfig(const std::string &online_conf, FeatureConfig *fc);
 

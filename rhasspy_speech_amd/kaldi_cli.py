@@ -22,11 +22,18 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-# option -> (rs_decode_opts field, type); the others the reference passes are accepted and have no effect here
+# option -> (rs_decode_opts field, type).  A field the command line does not set stays RS_OPT_UNSET: online.conf's value, else the
+# reference's default -- ParseOptions reads --config first and the command line overrides it (util/parse-options.cc:328-345).
 _DECODE_OPTS = {"max-active": ("max_active", int), "min-active": ("min_active", int), "beam": ("beam", float),
-                "lattice-beam": ("lattice_beam", float), "acoustic-scale": ("acoustic_scale", float)}
-_IGNORED = {"online", "do-endpointing", "word-symbol-table", "frames-per-chunk", "extra-left-context-initial", "frame-subsampling-factor",
-            "chunk-length", "num-threads-startup", "verbose"}
+                "lattice-beam": ("lattice_beam", float), "acoustic-scale": ("acoustic_scale", float), "beam-delta": ("beam_delta", float),
+                "frames-per-chunk": ("frames_per_chunk", int), "frame-subsampling-factor": ("frame_subsampling_factor", int)}
+_UNSET_FIELDS = [f for f, _ in _DECODE_OPTS.values()]
+# accepted on the command line when they ask for what the library does anyway (the reference's defaults / rhasspy's flags); any other
+# value is an error, as it is in online.conf (csrc/engine.cc: ResolveDecoderOptions)
+_FIXED = {"online": ("false", "f", "0"), "do-endpointing": ("false", "f", "0"), "extra-left-context-initial": ("0",), "prune-interval": ("25",),
+          "determinize-lattice": ("true", "t", "1", "")}
+_IGNORED = {"word-symbol-table", "chunk-length", "num-threads-startup", "verbose", "hash-ratio", "minimize", "phone-determinize",
+            "word-determinize", "max-mem", "debug-computation"}
 
 
 def parse_command_line(argv: List[str]) -> Tuple[Dict[str, object], str, List[str]]:
@@ -41,9 +48,11 @@ def parse_command_line(argv: List[str]) -> Tuple[Dict[str, object], str, List[st
             elif name in _DECODE_OPTS:
                 field, conv = _DECODE_OPTS[name]
                 opts[field] = conv(value)
+            elif name in _FIXED:
+                if value.lower() not in _FIXED[name]:
+                    raise ValueError(f"--{name}={value} is not supported by the HIP path")
             elif name in _IGNORED:
-                if name == "online" and value.lower() not in ("false", "f", "0"):
-                    raise ValueError("--online=true is not supported (the reference passes --online=false)")
+                pass
             else:
                 raise ValueError(f"invalid option --{name}")
         else:
@@ -92,7 +101,8 @@ def open_wspecifier(wspecifier: str):
 
 def _load(opts, config, final_mdl, hclg):
     from . import _lib
-    return _lib, _lib.Model(final_mdl=final_mdl, hclg=hclg, online_conf=config, opts=_lib.default_opts(emit_lattice=1, **opts))
+    unset = {f: _lib.RS_OPT_UNSET for f in _UNSET_FIELDS}
+    return _lib, _lib.Model(final_mdl=final_mdl, hclg=hclg, online_conf=config, opts=_lib.default_opts(emit_lattice=1, **{**unset, **opts}))
 
 
 def wav_main(argv: List[str]) -> int:

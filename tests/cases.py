@@ -44,6 +44,11 @@ CASES = {
     "tiny_nodither_u11": dict(spec=dict(dither=0.0), graph="grammar", audio="synth:11:36000"),
     "tiny_dither05_u12": dict(spec=dict(dither=0.5, ivector_dim=0), graph="grammar", audio="synth:12:36000:0.01"),
     "zam_quiet_u13": dict(big=True, spec=dict(), graph="grammar", audio="synth:13:48000:0.003"),
+    # decoder / decodable options that arrive through online.conf ONLY (the reference registers them on the parser that reads --config,
+    # online2-wav-nnet3-latgen-faster.cc:131-137): --min-active binds on most frames of this graph, --frames-per-chunk moves the
+    # streaming iVector schedule, --beam-delta the adaptive beam; max-active / beam are on the command line as rhasspy passes them
+    "tiny_confopts_u14": dict(spec=dict(num_phones=40), graph="arpa:300:1500", audio="synth:14:44000",
+                              opts=dict(max_active=80, beam=11.0), conf_opts={"min-active": 30, "frames-per-chunk": 30, "beam-delta": 0.25}),
 }
 NBEST = 5
 
@@ -80,6 +85,9 @@ def build_case_files(case: dict, root: Path, golden_dir: Path = GOLDEN):
         synth.write_graph_dir(graph_dir, fst, lex, const=(len(g) < 2 or g[1] != "vector"))
     else:
         synth.make_arpa_graph(graph_dir, spec, extra_words=int(g[1]), num_random_sentences=int(g[2]))
+    if case.get("conf_opts"):
+        conf = model_dir / "model" / "online" / "conf" / "online.conf"
+        conf.write_text(conf.read_text() + "".join(f"--{k}={v}\n" for k, v in case["conf_opts"].items()))
     pcm = case_audio(case, golden_dir)
     wav = root / "utt.wav"
     synth.write_wav(wav, pcm)

@@ -29,9 +29,83 @@ def test_library_exports_every_declared_symbol():
 def test_default_opts_are_the_reference_flags():
     from rhasspy_speech_amd import _lib
     o = _lib.default_opts()
-    assert (o.beam, o.max_active, o.min_active, o.lattice_beam, o.beam_delta, o.acoustic_scale) == (24.0, 7000, 200, 8.0, 0.5, 1.0)
+    # what rhasspy passes on the command line (transcribe_wav.py:46-55) is set; the rest is left to online.conf / the reference's defaults
+    assert (o.beam, o.max_active, o.lattice_beam, o.acoustic_scale) == (24.0, 7000, 8.0, 1.0)
+    assert (o.min_active, o.beam_delta, o.frames_per_chunk, o.frame_subsampling_factor) == (_lib.RS_OPT_UNSET,) * 4
     assert (o.emit_lattice, o.prune_output_pdfs, o.keep_intermediates) == (0, 1, 0)      # (pruned output layer: same words and costs)
-    assert (o.frames_per_chunk, o.frame_subsampling_factor) == (24, 1)
+
+
+def _with_online_conf(case_cache, tmp_path, extra_lines):
+    """A copy of the tiny case's model directory whose online.conf has `extra_lines` appended."""
+    import shutil
+    model_dir, graph_dir, _, _ = case_cache("tiny_u0")
+    dst = tmp_path / "model_dir"
+    shutil.copytree(model_dir, dst)
+    conf = dst / "model" / "online" / "conf" / "online.conf"
+    text = conf.read_text().replace(str(model_dir), str(dst))
+    conf.write_text(text + "".join(l + "\n" for l in extra_lines))
+    for sub in conf.parent.glob("*.conf"):       # (the other config files name files of the directory by absolute path too)
+        sub.write_text(sub.read_text().replace(str(model_dir), str(dst)))
+    return dst, graph_dir
+
+
+def _decoder_opts(describe: str) -> dict:
+    line = [l for l in describe.splitlines() if l.startswith("decoder_opts:")][0]
+    return dict(kv.split("=") for kv in line.split()[1:])
+
+
+def test_decoder_options_of_online_conf_take_effect(case_cache, tmp_path):
+    """The reference registers decoder / decodable options on the parser that reads --config (online2-wav-nnet3-latgen-faster.cc:131-137),
+    config file first, command line overriding (util/parse-options.cc:328-345): a model directory whose online.conf sets them decodes
+    with them unless rs_decode_opts (= the command line) sets the field."""
+    from rhasspy_speech_amd import _lib
+    plain = _decoder_opts(_lib.Model(*case_cache("tiny_u0")[:2]).describe())
+    assert plain == dict(beam="24", max_active="7000", min_active="200", lattice_beam="8", beam_delta="0.5", acoustic_scale="1",
+                         frames_per_chunk="24", frame_subsampling_factor="1")
+    md, gd = _with_online_conf(case_cache, tmp_path, ["--min-active=17", "--beam-delta=0.25", "--frames-per-chunk=30", "--beam=13.0",
+                                                      "--max-active=99", "--lattice-beam=5.5", "--acoustic-scale=0.7",
+                                                      "--frame-subsampling-factor=1", "--extra-left-context-initial=0", "--prune-interval=25",
+                                                      "--determinize-lattice=true", "--hash-ratio=3.0", "--minimize=false", "--max-mem=50000000"])
+    got = _decoder_opts(_lib.Model(md, gd).describe())
+    # not on rhasspy's command line: the file's values; on it (beam, max-active, lattice-beam, acoustic-scale): the command line's
+    assert got == dict(plain, min_active="17", beam_delta="0.25", frames_per_chunk="30")
+    # nothing on the command line: everything from the file
+    unset = _lib.default_opts(beam=_lib.RS_OPT_UNSET, max_active=_lib.RS_OPT_UNSET, lattice_beam=_lib.RS_OPT_UNSET, acoustic_scale=_lib.RS_OPT_UNSET)
+    got = _decoder_opts(_lib.Model(md, gd, unset).describe())
+    assert got == dict(beam="13", max_active="99", min_active="17", lattice_beam="5.5", beam_delta="0.25", acoustic_scale="0.7",
+                       frames_per_chunk="30", frame_subsampling_factor="1")
+    # ... and the command line over the file
+    got = _decoder_opts(_lib.Model(md, gd, _lib.default_opts(min_active=3, beam_delta=0.125, frames_per_chunk=18)).describe())
+    assert (got["min_active"], got["beam_delta"], got["frames_per_chunk"]) == ("3", "0.125", "18")
+    # no file value, nothing on the command line: the reference's defaults (lattice-faster-decoder.h:56-63, decodable-simple-looped.h:55-59)
+    got = _decoder_opts(_lib.Model(*case_cache("tiny_u0")[:2], unset).describe())
+    assert got == dict(beam="16", max_active=str(2**31 - 1), min_active="200", lattice_beam="10", beam_delta="0.5", acoustic_scale="0.1",
+                       frames_per_chunk="24", frame_subsampling_factor="1")
+
+
+@pytest.mark.parametrize("line,needle", [
+    ("--frame-subsampling-factor=3", "--frame-subsampling-factor=3 is not supported"),
+    ("--extra-left-context-initial=4", "--extra-left-context-initial=4 is not supported"),
+    ("--prune-interval=10", "--prune-interval=10 is not supported"),
+    ("--determinize-lattice=false", "--determinize-lattice=false is not supported"),
+    ("--online=true", "--online=true is not supported"),
+    ("--do-endpointing=true", "--do-endpointing=true is not supported"),
+    ("--min-active=abc", 'Invalid integer option "abc"'),
+    ("--beam-delta=x1", 'Invalid floating-point option "x1"'),
+    ("--determinize-lattice=maybe", "Invalid format for boolean argument [expected true or false]: maybe"),
+    ("--min-active=8000", "KALDI_ASSERT: at Check:lattice-faster-decoder.h:87"),       # min_active <= max_active (7000)
+    ("--beam-delta=0", "KALDI_ASSERT: at Check:lattice-faster-decoder.h:87"),
+    ("--frames-per-chunk=0", "KALDI_ASSERT: at Check:decodable-simple-looped.h:62"),
+    ("--hash-ratio=0.5", "hash_ratio >= 1.0"),
+    ("--no-such-option=1", "Invalid option --no-such-option=1"),
+])
+def test_online_conf_options_the_kernels_cannot_honour_fail_the_load(case_cache, tmp_path, line, needle):
+    """... and what cannot be honoured is refused with a message, never dropped (round 4 accepted and ignored these)."""
+    from rhasspy_speech_amd import _lib
+    md, gd = _with_online_conf(case_cache, tmp_path, [line])
+    with pytest.raises(_lib.RsError) as ei:
+        _lib.Model(md, gd)
+    assert needle in str(ei.value), str(ei.value)
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "tiny_text_u1", "tinyf_u5", "tiny_noiv_u2", "tiny_hmm_u6", "tiny_vecfst_u9", "tiny_arpa_u7"])

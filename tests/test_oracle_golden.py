@@ -7,7 +7,7 @@ from tests import cases
 
 FAST = ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tiny_real_time", "tiny_text_u1", "tiny_noiv_u2", "tiny_cmvn_u4", "tinyf_u5",
         "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold", "zam_long30", "zam_s12005",
-        "tiny_silence", "tiny_quiet_u10", "tiny_nodither_u11", "tiny_dither05_u12", "zam_quiet_u13"]
+        "tiny_silence", "tiny_quiet_u10", "tiny_nodither_u11", "tiny_dither05_u12", "zam_quiet_u13", "tiny_confopts_u14"]
 
 
 def parse_nbest(text: bytes):
@@ -194,11 +194,12 @@ def test_setup_rand_calls_match_reference(name):
         synth.write_model_dir(Path(td) / "m", cases.case_spec(cases.CASES[name]))
         mdl = Path(td) / "m" / "model" / "model" / "final.mdl"
         _, nf = kf.read_final_mdl(mdl)
-        assert nnet3_rand.setup_rand_calls(nf) == want
+        chunk = int(cases.CASES[name].get("conf_opts", {}).get("frames-per-chunk", 24))      # (the looped computation is compiled for the chunk size)
+        assert nnet3_rand.setup_rand_calls(nf, chunk) == want
         lib = load_library()
         lib.rs_nnet3_setup.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
         n, cert, buf = C.c_int64(), C.c_int32(), C.create_string_buffer(1 << 16)
-        assert lib.rs_nnet3_setup(str(mdl).encode(), 24, C.byref(n), C.byref(cert), buf, len(buf)) == 0
+        assert lib.rs_nnet3_setup(str(mdl).encode(), chunk, C.byref(n), C.byref(cert), buf, len(buf)) == 0
         assert (n.value, cert.value) == (want, 1)
         cfg = buf.value.decode()
         assert "component-node name=lda " not in cfg and "component=lda.tdnn1.affine" in cfg
