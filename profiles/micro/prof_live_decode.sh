@@ -2,7 +2,7 @@
 # -DRS_DECODE_PROFILE in a scratch copy.  usage (GPU box): bash profiles/micro/prof_live_decode.sh <out dir under gpurun_out> [shape ...]
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-live_prof}; shift
-SHAPES=${@:-512}
+SHAPES=${@:-1024}
 mkdir -p $OUT
 rm -rf /tmp/rsprof && mkdir -p /tmp/rsprof && cp -r rhasspy_speech_amd include /tmp/rsprof/
 rm -f /tmp/rsprof/rhasspy_speech_amd/csrc/decode_live.o /tmp/rsprof/rhasspy_speech_amd/csrc/decode_kernels.o

@@ -23,10 +23,6 @@ except Exception as e:
 PY
 }
 run r4_if3 RS_DECODER=hash_r4
-run live512_if3 RS_LIVE_SHAPE=512
-run live1024_if3 RS_LIVE_SHAPE=1024
-run live256_if3 RS_LIVE_SHAPE=256
+for sh in ${SHAPES:-1024 512 5122 2564}; do run live${sh}_if3 RS_LIVE_SHAPE=$sh; done
 B="$B --inflight 4"
-run live512_if4 RS_LIVE_SHAPE=512
-run live256_if4 RS_LIVE_SHAPE=256
-run live1024_if4 RS_LIVE_SHAPE=1024
+for sh in ${SHAPES:-1024 512 5122 2564}; do run live${sh}_if4 RS_LIVE_SHAPE=$sh; done

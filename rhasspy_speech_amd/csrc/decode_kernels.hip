@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
                                                    const float *__restrict__ loglikes, int ld, DecodeWork w) {
   __shared__ BlockCtx<NT> c;
   const int u = blockIdx.x, tid = threadIdx.x;
-  if (w.redo && !w.redo[u]) return;          // decoded by HashDecodeKernel already
+  if (w.redo && !w.redo[u]) return;          // decoded by LiveDecodeKernel (decode_live.hip) already
   const int T = g.d_num_frames[u];
   const int S = h.num_states;
   unsigned long long *best = w.best + (size_t)u * S;
@@ -523,620 +523,6 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
   }
 }
 
-// ===================================================================================== live-state table in LDS
-// The same search with the per-utterance state tables taken out of HBM.  DecodeKernel indexes best[] / map[] / stamp[] by HCLG
-// state: 28 B x S per utterance (360 MB for 256 utterances on the 50 k-state ARPA graph), touched at random -- a frame with a few
-// thousand live states visits nearly every 64-byte line of its tables, so every pass streams them from HBM again (measured:
-// 2.8 x the algorithmic bytes, profiles/r02/arpa_pmc.json).  Here the states that are live in the frame under construction get
-// consecutive SLOT numbers; the state -> slot map is an open-addressing hash in LDS (one 32-bit word per entry: state << 15 |
-// slot, linear probing, claimed with one LDS compare-and-swap), and everything the passes keep per live state -- the packed
-// (cost, arc) key the arcs race on, the token index, the closure stamp -- is a slot-indexed array of a few tens of KB that stays
-// in L2.  Like the reference's HashList (util/hash-list-inl.h:37-165: buckets sized by the number of live tokens, not by the
-// graph) the table's size follows the beam, not the graph.  Candidate records, token lists, cut-offs, tie rule and every float
-// expression are DecodeKernel's: the two kernels produce the same token lists up to order within a frame.
-//
-// An utterance whose frame outgrows the table (more than kSlotCap live states, a probe sequence that finds no free entry, more
-// candidate records than the list holds) raises redo[u]; DecodeKernel, launched behind this kernel on the same stream, decodes
-// exactly those utterances with the dense tables.
-constexpr int kHashLog = 15;                  // 32768 entries x 4 B = 128 KB of LDS
-constexpr int kHashSize = 1 << kHashLog;
-constexpr int kSlotBits = 15;
-constexpr int kSlotCap = (1 << kSlotBits) * 3 / 4;      // live states per frame (75 % load at most)
-constexpr unsigned kHashFree = 0xFFFFFFFFu;
-constexpr int kHashPrefixCap = 7168;            // expanded tokens per frame whose degree prefix fits LDS (max-active 7000 + 1 + ties)
-
-__device__ __forceinline__ unsigned HashOf(unsigned s) { return (s * 2654435761u) >> (32 - kHashLog); }
-__device__ __forceinline__ unsigned TagLoad(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// slot of `state`, claiming a fresh one if the state is not in the table yet; -1: the table is full.
-// WIDE = false: entry = state << 15 | slot, slots are handed out consecutively (compact slot arrays; graphs below 131 071 states).
-// WIDE = true (any graph): entry = the state id, the slot IS the entry's position -- the slot-indexed arrays are then as long as the
-// table (32 768) and touched sparsely, still a footprint that follows the beam and not the millions of states of a large LM graph.
-template <bool WIDE>
-__device__ __forceinline__ int SlotFindOrInsert(unsigned *tags, int *n_slots, unsigned state, int slot_limit) {
-  unsigned hp = HashOf(state);
-  int mine = -1;
-  for (int probe = 0; probe < 512; probe++) {
-    unsigned e = TagLoad(&tags[hp]);
-    if (e == kHashFree) {
-      if (mine < 0) {
-        mine = atomicAdd(n_slots, 1);
-        if (mine >= slot_limit) return -1;
-      }
-      e = atomicCAS(&tags[hp], kHashFree, WIDE ? state : ((state << kSlotBits) | (unsigned)mine));
-      if (e == kHashFree) return WIDE ? (int)hp : mine;
-      // another lane claimed this entry first (possibly for the same state: then `mine` stays unused, its key stays empty)
-    }
-    if (WIDE) { if (e == state) return (int)hp; }
-    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
-    hp = (hp + 1) & (kHashSize - 1);
-  }
-  return -1;
-}
-template <bool WIDE>
-__device__ __forceinline__ int SlotFind(const unsigned *tags, unsigned state) {
-  unsigned hp = HashOf(state);
-  for (int probe = 0; probe < 512; probe++) {
-    const unsigned e = TagLoad(&tags[hp]);
-    if (e == kHashFree) return -1;
-    if (WIDE) { if (e == state) return (int)hp; }
-    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
-    hp = (hp + 1) & (kHashSize - 1);
-  }
-  return -1;
-}
-
-template <int NT, bool WIDE>
-__global__ __launch_bounds__(NT) void HashDecodeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
-                                                       const float *__restrict__ loglikes, int ld, DecodeWork w) {
-  using Ctx = BlockCtx<NT, 1>;
-  __shared__ Ctx c;
-  __shared__ __attribute__((aligned(16))) unsigned tags[kHashSize];
-  __shared__ int pre[kHashPrefixCap + 1];              // exclusive prefix of the expanded tokens' emitting out-degrees
-  __shared__ int n_slots, s_redo;
-  __shared__ unsigned s_min_bits;                      // ordered bits of the cheapest candidate of the frame (next_cutoff - adaptive beam)
-  __shared__ float kth_cand[256];                      // GetCutoff's selection: the values of the histogram bin that holds the rank
-  __shared__ int kth_n;
-  __shared__ unsigned long long s_best_key;            // (ordered cost bits << 32 | index) of the cheapest token of the frame just completed
-  constexpr int NW = NT / 64;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int u = blockIdx.x, tid = threadIdx.x;
-  const int T = g.d_num_frames[u];
-  unsigned long long *keys = w.h_keys + (size_t)u * kHashSize;
-  int *slot_tok = w.h_slot_tok + (size_t)u * kHashSize;      // slot -> index of its token in the frame under construction
-  int *stamp = w.h_stamp + (size_t)u * kHashSize;            // closure round in which the slot was last pushed
-  int *cand_a = w.h_cand + (size_t)u * 3 * w.h_cand_cap, *cand_s = cand_a + w.h_cand_cap, *cand_x = cand_s + w.h_cand_cap;
-  int2 *queue[2] = {w.h_queue + (size_t)u * 2 * kSlotCap, w.h_queue + (size_t)u * 2 * kSlotCap + kSlotCap};
-  int4 *comp = w.h_comp + (size_t)u * kSlotCap;             // the frame's expanded tokens, compacted: {first emitting arc, cost, token index, out-degree}
-  int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
-  int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
-  float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
-  int round_id = 0;
-  const float INF = INFINITY;
-  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
-  const int cand_cap = w.h_cand_cap;
-  const int slot_limit = w.h_slot_limit < kSlotCap ? w.h_slot_limit : kSlotCap;      // (tests lower it to send utterances to DecodeKernel)
-
-  for (int i = tid; i < (WIDE ? kHashSize : kSlotCap); i += NT) { StoreKey(&keys[i], RS_EMPTY); stamp[i] = 0; }
-  for (int i = tid; i < kHashSize; i += NT) tags[i] = kHashFree;
-  if (tid == 0) {
-    c.n_next = 0; c.overflow = 0; c.error = 0; c.q_n[0] = c.q_n[1] = 0;
-    for (int i = 0; i < 8; i++) c.counters[i] = 0;
-    n_slots = 0; s_redo = 0;
-    w.out_nwords[u] = 0;
-    w.redo[u] = 0;
-  }
-  unsigned long long cnt_expanded = 0, cnt_arcs = 0, cnt_insert = 0;
-  __syncthreads();
-
-  int off_cur = 0, n_cur = 0;       // frame f's token list
-  int off_next = 0;                 // frame under construction
-  if (tid == 0) {                   // InitDecoding: the start state's token
-    const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)h.start, slot_limit);
-    StoreKey(&keys[sl], PackKey(0.0f, RS_NOARC));
-    tokens[0] = make_int4(h.start, sl, -1, -2);
-    slot_tok[sl] = 0;
-    c.n_next = 1;
-    frame_off[0] = 0;
-    if (h.state_rec[h.start].y != 0) { queue[0][0] = make_int2(h.start, sl); c.q_n[0] = 1; }
-  }
-  __syncthreads();
-  float closure_cutoff = o.beam;    // InitDecoding: ProcessNonemitting(config_.beam)
-  float best_cost = INF;            // cheapest token of frame f and its index: found while the frame's tokens were completed
-  int best_idx = 0;
-#ifdef RS_DECODE_PROFILE
-  long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long t_last = clock64();
-#endif
-
-  for (int f = -1; f < T; f++) {
-    int4 *next_toks = tokens + off_next;
-    // a frame holds at most kSlotCap tokens (one per slot), and the candidate records name their source token in 16 bits
-    const int next_cap = w.tok_cap - off_next < slot_limit ? w.tok_cap - off_next : slot_limit;
-    if (f >= 0) {
-      // ================================================================ ProcessEmitting(frame f)
-      const int4 *cur = tokens + off_cur;
-      // ---- GetCutoff.  The reference selects the (max_active+1)-th / (min_active+1)-th cheapest cost (nth_element) and then only
-      // asks on which side of best + beam it lies: one counting sweep answers that, and the exact selection (a radix select: five
-      // more sweeps over the frame's tokens) runs only in the frames where the limit binds.
-      const float beam_cutoff = best_cost + o.beam;
-      // wave w sweeps the tokens [w wseg, (w + 1) wseg) of the frame, 64 at a time
-      const int wseg = ((n_cur + NW - 1) / NW + 63) & ~63;
-      const int wb0 = wave * wseg < n_cur ? wave * wseg : n_cur, wb1 = wb0 + wseg < n_cur ? wb0 + wseg : n_cur;
-      int n_lt = 0, n_le = 0;              // (wave-uniform)
-      for (int ib = wb0; ib < wb1; ib += 64) {
-        const int i = ib + lane;
-        const float cst = i < wb1 ? __int_as_float(cur[i].y) : INF;
-        n_lt += __popcll(__ballot(cst < beam_cutoff));
-        n_le += __popcll(__ballot(cst <= beam_cutoff));
-      }
-      int m_wave = n_le;                   // tokens of this wave's range that the frame expands, if the beam decides the cutoff
-      if (tid == 0) { c.bcast_i[2] = 0; c.bcast_i[3] = 0; c.run_min = OrderedBits(INF); c.n_cand = 0; s_min_bits = OrderedBits(INF); }
-      // A first bound for the arc loop's early-out (an arc at or above "cheapest candidate so far + adaptive beam" cannot end up
-      // below the frame's next_cutoff): the best token's own arcs, looked at by one wave while the others count.  Any candidate's
-      // cost is an upper bound of the minimum, so this only removes candidates that would lose anyway.
-      float first_bound = INF;
-      if (wave == NW - 1 && n_cur > 0) {
-        const int4 bt = cur[best_idx];
-        const uint4 bsr = h.state_rec[bt.x];
-        const float *llr = loglikes + (ll_base + f) * ld;
-        for (unsigned k = lane; k < bsr.z; k += 64) {
-          const int4 arc = h.arcs[bsr.x + bsr.y + k];
-          first_bound = fminf(first_bound, (__int_as_float(bt.y) + ((-best_cost) - llr[arc.x - 1])) + __int_as_float(arc.z));
-        }
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) first_bound = fminf(first_bound, __shfl_xor(first_bound, o2, 64));
-      }
-      __syncthreads();
-      if (lane == 0) { atomicAdd(&c.bcast_i[2], n_lt); atomicAdd(&c.bcast_i[3], n_le); }
-      if (wave == NW - 1 && lane == 0 && first_bound < INF) atomicMin(&c.run_min, OrderedBits(first_bound));
-      __syncthreads();
-      n_lt = c.bcast_i[2]; n_le = c.bcast_i[3];
-      float max_active_cutoff = INF, min_active_cutoff = INF, cur_cutoff, adaptive_beam;
-      bool decided = false;
-      // sorted[max_active] < beam_cutoff  <=>  more than max_active costs lie below beam_cutoff
-      if (n_cur > o.max_active && n_lt > o.max_active) max_active_cutoff = BlockKthSmallestHist<NT>(c, cur, n_cur, o.max_active, best_cost, beam_cutoff, kth_cand, &kth_n);
-      if (max_active_cutoff < beam_cutoff) {
-        adaptive_beam = max_active_cutoff - best_cost + o.beam_delta;
-        cur_cutoff = max_active_cutoff;
-        decided = true;
-        if (tid == 0) c.counters[5]++;
-      }
-      if (!decided) {
-        if (n_cur > o.min_active) {
-          if (o.min_active == 0) min_active_cutoff = best_cost;
-          // sorted[min_active] > beam_cutoff  <=>  at most min_active costs lie at or below beam_cutoff
-          else if (n_le <= o.min_active) min_active_cutoff = BlockKthSmallest<NT>(c, cur, n_cur, o.min_active, best_cost);
-          else min_active_cutoff = beam_cutoff;      // (any value <= beam_cutoff takes the branch below)
-        }
-        if (min_active_cutoff > beam_cutoff) {
-          adaptive_beam = min_active_cutoff - best_cost + o.beam_delta;
-          cur_cutoff = min_active_cutoff;
-          if (tid == 0 && n_cur > o.min_active) c.counters[6]++;
-        } else {
-          adaptive_beam = o.beam;
-          cur_cutoff = beam_cutoff;
-        }
-      }
-      if (cur_cutoff != beam_cutoff) {     // workgroup-uniform: a limit decided the cutoff, count again
-        m_wave = 0;
-        for (int ib = wb0; ib < wb1; ib += 64) {
-          const int i = ib + lane;
-          m_wave += __popcll(__ballot(i < wb1 && __int_as_float(cur[i].y) <= cur_cutoff));
-        }
-      }
-      if (lane == 0) c.red_i[wave] = m_wave;
-      __syncthreads();
-      int comp_base = 0, M = 0;            // this wave's first compact entry; expanded tokens of the frame
-      for (int wv = 0; wv < NW; wv++) { if (wv < wave) comp_base += c.red_i[wv]; M += c.red_i[wv]; }
-      RS_TP(0);
-      const float cost_offset = (n_cur > 0) ? -best_cost : 0.f;
-      const float *ll_row = loglikes + (ll_base + f) * ld;
-      float local_min = INF;
-      // ---- the expanded tokens, compacted in token order: {first emitting arc, cost, token index, out-degree} to HBM (L2), the
-      // out-degree to LDS.  No more than max_active + 1 tokens (plus ties) are ever expanded, so the degree prefix of a whole frame
-      // fits LDS whatever the frame's size (DecodeKernel prefix-sums ALL tokens, a chunk of LDS at a time, five barriers a chunk).
-      {
-        int run = comp_base;
-        for (int ib = wb0; ib < wb1; ib += 128) {        // two blocks of 64 per trip: both state records in flight together
-          int4 tk[2];
-          uint4 sr[2];
-          bool act[2];
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const int i = ib + q * 64 + lane;
-            tk[q] = cur[i < wb1 ? i : wb1 - 1];
-            act[q] = i < wb1 && __int_as_float(tk[q].y) <= cur_cutoff;
-          }
-#pragma unroll
-          for (int q = 0; q < 2; q++) sr[q] = h.state_rec[tk[q].x];
-#pragma unroll
-          for (int q = 0; q < 2; q++) {
-            const unsigned long long m = __ballot(act[q]);
-            if (act[q]) {
-              const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
-              comp[pos] = make_int4((int)(sr[q].x + sr[q].y), tk[q].y, ib + q * 64 + lane, (int)sr[q].z);
-              if (pos < kHashPrefixCap) pre[pos] = (int)sr[q].z;
-              cnt_expanded++;
-            }
-            run += __popcll(m);
-          }
-        }
-      }
-      __syncthreads();
-      auto relax_arc = [&](unsigned a, const int4 arc, float lk, float cur_cost, bool is_best, int src_tok) __attribute__((always_inline)) {
-        const float graph_cost = __int_as_float(arc.z);
-        const float ac_cost = cost_offset - lk;
-        const float tot = (cur_cost + ac_cost) + graph_cost;
-        if (is_best) {
-          const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;      // :752-757, the reference's first bound
-          local_min = fminf(local_min, nw);
-        }
-        local_min = fminf(local_min, tot);
-        cnt_arcs++;
-        const float bound = FromOrdered(c.run_min) + adaptive_beam;
-        if (!(tot < bound)) return;
-        cnt_insert++;
-        const unsigned ot = OrderedBits(tot);
-        if (ot < c.run_min) atomicMin(&c.run_min, ot);
-        const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)arc.w, slot_limit);
-        if (sl < 0) { s_redo = 1; return; }
-        atomicMin(&keys[sl], PackKey(tot, a));                 // result unused: non-returning
-        const int ci = atomicAdd(&c.n_cand, 1);
-        if (ci < cand_cap) { cand_a[ci] = (int)a; cand_s[ci] = arc.w; cand_x[ci] = (sl << 16) | src_tok; }
-        else s_redo = 1;
-      };
-      for (int c0 = 0; c0 < M; c0 += kHashPrefixCap) {       // (one trip; more only with thousands of exact cost ties at the cutoff)
-        const int nc = M - c0 < kHashPrefixCap ? M - c0 : kHashPrefixCap;
-        if (c0 > 0) {
-          __syncthreads();
-          for (int i = tid; i < nc; i += NT) pre[i] = comp[c0 + i].w;
-          __syncthreads();
-        }
-        // exclusive prefix of the degrees in place: a run of consecutive entries per thread
-        const int per = (nc + NT - 1) / NT;
-        const int i0 = tid * per < nc ? tid * per : nc, i1 = i0 + per < nc ? i0 + per : nc;
-        int lsum = 0;
-        for (int i = i0; i < i1; i++) lsum += pre[i];
-        int inc = lsum;
-#pragma unroll
-        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
-        if (lane == 63) c.red_i[wave] = inc;        // (c.red_i's readers above are behind the barrier that follows the compaction)
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int wv = 0; wv < NW; wv++) { if (wv < wave) wbase += c.red_i[wv]; total += c.red_i[wv]; }
-        int run = wbase + inc - lsum;
-        for (int i = i0; i < i1; i++) { const int dgr = pre[i]; pre[i] = run; run += dgr; }
-        if (tid == 0) pre[nc] = total;
-        __syncthreads();
-        RS_TP(5);
-        const int4 *cchunk = comp + c0;
-        for (int jb = tid; jb < total; jb += 4 * NT) {
-          unsigned a[4];
-          float cc[4];
-          bool bst[4], on[4];
-          int tki[4], rel[4];
-          int4 ce[4], arc[4];
-          float lk[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int j = jb + q * NT;
-            on[q] = j < total;
-            const int jj = on[q] ? j : total - 1;
-            int lo = 0, hi = nc;            // last entry with pre[t] <= j
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= jj) lo = mid; else hi = mid; }
-            rel[q] = jj - pre[lo];
-            tki[q] = lo;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) ce[q] = cchunk[tki[q]];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            a[q] = (unsigned)ce[q].x + (unsigned)rel[q];
-            cc[q] = __int_as_float(ce[q].y);
-            tki[q] = ce[q].z;
-            bst[q] = tki[q] == best_idx;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) arc[q] = h.arcs[a[q]];
-#pragma unroll
-          for (int q = 0; q < 4; q++) lk[q] = ll_row[arc[q].x - 1];
-#pragma unroll
-          for (int q = 0; q < 4; q++) if (on[q]) relax_arc(a[q], arc[q], lk[q], cc[q], bst[q], tki[q]);
-        }
-        RS_TP(6);
-      }
-      // next_cutoff = min over the candidates of (tot_cost + adaptive_beam): one LDS atomic per wave instead of a block reduction
-#pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) local_min = fminf(local_min, __shfl_xor(local_min, o2, 64));
-      if (lane == 0) atomicMin(&s_min_bits, OrderedBits(local_min));
-      __syncthreads();
-      RS_TP(1);
-      const float next_cutoff = FromOrdered(s_min_bits) + adaptive_beam;
-      if (tid == 0) {
-        finfo[f * 4 + 0] = cost_offset;
-        finfo[f * 4 + 1] = cur_cutoff;
-        finfo[f * 4 + 2] = next_cutoff;
-        finfo[f * 4 + 3] = adaptive_beam;
-      }
-      if (s_redo) break;                 // workgroup-uniform: read after the barriers of the reduction
-      {
-        // the winner of a slot (= the candidate whose arc id is left in the key) appends the token, complete with back pointer
-        // and arc, or -- at or above the final cutoff -- empties the key again
-        constexpr int WB = 4;
-        const int nc2 = c.n_cand;
-        for (int ib = tid; ib < nc2; ib += WB * NT) {       // WB candidates per thread with every load stage of all of them in flight together
-          int s2[WB], ca[WB], cx[WB];
-          unsigned long long key[WB];
-          bool on[WB];
-#pragma unroll
-          for (int q = 0; q < WB; q++) {
-            const int i = ib + q * NT;
-            on[q] = i < nc2;
-            const int ii = on[q] ? i : nc2 - 1;
-            s2[q] = cand_s[ii];
-            ca[q] = cand_a[ii];
-            cx[q] = cand_x[ii];
-          }
-#pragma unroll
-          for (int q = 0; q < WB; q++) key[q] = LoadKey(&keys[cx[q] >> 16]);
-          unsigned ne[WB];
-#pragma unroll
-          for (int q = 0; q < WB; q++) ne[q] = h.state_rec[s2[q]].y;       // (epsilon arcs of the state: the closure's first work list is filled here)
-#pragma unroll
-          for (int q = 0; q < WB; q++) {
-            if (!on[q] || (unsigned)(key[q] & 0xFFFFFFFFull) != (unsigned)ca[q]) continue;
-            const int sl = cx[q] >> 16;
-            if (KeyCost(key[q]) < next_cutoff) {
-              const int idx = atomicAdd(&c.n_next, 1);
-              if (idx < next_cap) {
-                next_toks[idx] = make_int4(s2[q], sl, cx[q] & 0xFFFF, ca[q]);
-                slot_tok[sl] = idx;
-                if (ne[q] != 0) queue[0][atomicAdd(&c.q_n[0], 1)] = make_int2(s2[q], sl);
-              } else {
-                c.overflow = 1;
-              }
-            } else {
-              StoreKey(&keys[sl], RS_EMPTY);
-            }
-          }
-        }
-      }
-      closure_cutoff = next_cutoff;
-      __syncthreads();
-      RS_TP(2);
-    }
-    // ================================================================ ProcessNonemitting(closure_cutoff)
-    {
-      int qi = 0;      // (queue[0] was filled by the winners' pass / InitDecoding; c.q_n[1] is 0)
-      int guard_rounds = 0;
-      while (c.q_n[qi] > 0) {
-        const int qn = c.q_n[qi];
-        __syncthreads();
-        if (tid == 0) c.q_n[qi ^ 1] = 0;
-        round_id++;
-        __syncthreads();
-        for (int ib = 0; ib < qn; ib += NT) {
-          const int i = ib + tid;
-          const bool have = i < qn;
-          const int2 qe = have ? queue[qi][i] : make_int2(0, 0);
-          const int s = qe.x;
-          const float cur_cost = have ? KeyCost(LoadKey(&keys[qe.y])) : INF;
-          const bool live = have && cur_cost < closure_cutoff;
-          if (live) cnt_expanded++;
-          const uint4 sr = live ? h.state_rec[s] : make_uint4(0u, 0u, 0u, 0u);
-          const unsigned a0 = sr.x, ne = sr.y;
-          unsigned ne_max = ne;
-#pragma unroll
-          for (int o2 = 32; o2 > 0; o2 >>= 1) ne_max = max(ne_max, (unsigned)__shfl_xor((int)ne_max, o2, 64));
-          for (unsigned k = 0; k < ne_max; k++) {
-            const bool has_arc = k < ne;
-            const unsigned a = a0 + (has_arc ? k : 0u);
-            const int4 arc = has_arc ? h.arcs[a] : make_int4(0, 0, 0, 0);
-            const float tot = cur_cost + __int_as_float(arc.z);
-            if (has_arc) cnt_arcs++;
-            const bool act = has_arc && tot < closure_cutoff;
-            if (act) cnt_insert++;
-            const unsigned long long m = __ballot(act);
-            if (m == 0ull) continue;
-            // (thousands of history states back off into ONE unigram state: a wave whose relaxing lanes all target the same
-            // state reduces its keys first and issues a single atomic)
-            const int first = __ffsll((long long)m) - 1;
-            const int d0 = __shfl(arc.w, first, 64);
-            const bool uniform = __ballot(act && arc.w != d0) == 0ull;
-            unsigned long long key = act ? PackKey(tot, a) : RS_EMPTY;
-            bool mine = act;
-            if (uniform && __popcll(m) > 1) {
-              unsigned long long kmin = key;
-#pragma unroll
-              for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)(kmin & 0xFFFFFFFFull), o2, 64);
-                const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(kmin >> 32), o2, 64);
-                const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-                kmin = other < kmin ? other : kmin;
-              }
-              mine = act && key == kmin;          // keys are unique (arc ids): exactly one lane
-              key = kmin;
-            }
-            if (mine) {
-              const int sl = SlotFindOrInsert<WIDE>(tags, &n_slots, (unsigned)arc.w, slot_limit);
-              if (sl < 0) { s_redo = 1; continue; }
-              const unsigned long long old = atomicMin(&keys[sl], key);
-              if (old == RS_EMPTY) {              // FindOrAddToken made a token
-                const int idx = atomicAdd(&c.n_next, 1);
-                if (idx < next_cap) { next_toks[idx] = make_int4(arc.w, sl, -1, -2); slot_tok[sl] = idx; }
-                else c.overflow = 1;
-              }
-              if ((old == RS_EMPTY || key < old) && h.state_rec[arc.w].y != 0) {
-                if (atomicExch(&stamp[sl], round_id) != round_id) queue[qi ^ 1][atomicAdd(&c.q_n[qi ^ 1], 1)] = make_int2(arc.w, sl);
-              }
-            }
-          }
-        }
-        __syncthreads();
-        qi ^= 1;
-        if (s_redo) break;
-        if (++guard_rounds > 100000) { if (tid == 0) c.error = 2; break; }   // epsilon cycle in the graph
-      }
-      __syncthreads();
-      if (tid == 0) { c.q_n[0] = 0; c.q_n[1] = 0; s_best_key = RS_EMPTY; }
-      if (s_redo) break;
-    }
-    RS_TP(3);
-    // ================================================================ materialise frame f+1
-    {
-      const int nn = c.n_next < next_cap ? c.n_next : next_cap;
-      float lv = INF;                                     // cheapest token of the new frame (lowest index on ties)
-      int li = 0x7fffffff;
-      constexpr int MB = 4;                               // tokens per thread and trip, every load stage of all of them in flight together
-      for (int ib = tid; ib < nn; ib += MB * NT) {
-        int4 tk[MB];
-        int sx[MB], bp[MB];
-        unsigned long long key[MB];
-        bool on[MB], eps[MB];
-#pragma unroll
-        for (int q = 0; q < MB; q++) {
-          const int i = ib + q * NT;
-          on[q] = i < nn;
-          tk[q] = next_toks[on[q] ? i : nn - 1];
-          if (!on[q]) tk[q].y = 0;       // (the stand-in token may have been rewritten by its owner already: its .y is then a cost, not a slot)
-        }
-#pragma unroll
-        for (int q = 0; q < MB; q++) key[q] = LoadKey(&keys[tk[q].y]);
-#pragma unroll
-        for (int q = 0; q < MB; q++) {
-          const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
-          eps[q] = arc != RS_NOARC && (int)arc != tk[q].w;     // an epsilon arc made or improved it: its source owns a token of this frame
-          sx[q] = eps[q] ? h.arc_srcx[arc] & 0x7fffffff : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < MB; q++) {
-          const unsigned arc = (unsigned)(key[q] & 0xFFFFFFFFull);
-          int b = arc == RS_NOARC ? -1 : tk[q].z;
-          if (eps[q]) { const int ss = SlotFind<WIDE>(tags, (unsigned)sx[q]); b = ss >= 0 ? slot_tok[ss] : -1; }
-          bp[q] = b;
-        }
-#pragma unroll
-        for (int q = 0; q < MB; q++)
-          if (on[q]) {
-            const float cst = KeyCost(key[q]);
-            const int i = ib + q * NT;
-            next_toks[i] = make_int4(tk[q].x, __float_as_int(cst), bp[q], (int)(unsigned)(key[q] & 0xFFFFFFFFull));
-            StoreKey(&keys[tk[q].y], RS_EMPTY);
-            if (cst < lv || (cst == lv && i < li)) { lv = cst; li = i; }
-          }
-      }
-      {
-        unsigned long long bk = li == 0x7fffffff ? RS_EMPTY : PackKey(lv, (unsigned)li);
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) {
-          const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)(bk & 0xFFFFFFFFull), o2, 64);
-          const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), o2, 64);
-          const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-          bk = other < bk ? other : bk;
-        }
-        __syncthreads();                    // (s_best_key was reset after the closure; every thread is past that point)
-        if (lane == 0 && bk != RS_EMPTY) atomicMin(&s_best_key, bk);
-      }
-      __syncthreads();
-      best_cost = s_best_key == RS_EMPTY ? INF : KeyCost(s_best_key);
-      best_idx = (int)(unsigned)(s_best_key & 0xFFFFFFFFull);
-      // the table starts the next frame empty (every key a slot held was emptied by its owner above or in the winners' pass)
-      for (int i = tid; i < kHashSize / 4; i += NT) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(kHashFree, kHashFree, kHashFree, kHashFree);
-      off_cur = off_next;
-      n_cur = nn;
-      off_next = off_cur + n_cur;
-      if (tid == 0) {
-        frame_off[f + 2] = off_next;
-        c.counters[3] += (unsigned long long)nn;
-        {
-          const unsigned long long mt = c.counters[4] & 0xFFFFFFFFull, mc = c.counters[4] >> 32;
-          const unsigned long long nc_ = f >= 0 ? (unsigned long long)c.n_cand : 0ull;
-          c.counters[4] = ((nc_ > mc ? nc_ : mc) << 32) | ((unsigned long long)nn > mt ? (unsigned long long)nn : mt);
-        }
-        c.n_next = 0;
-        n_slots = 0;
-        if (c.overflow) s_redo = 1;                    // a frame of more than kSlotCap tokens: the dense-table kernel has room
-        if (nn == 0 && c.error == 0) c.error = 1;      // "no surviving tokens"
-      }
-      __syncthreads();
-      RS_TP(4);
-      if (c.error || s_redo) break;
-    }
-  }
-  __syncthreads();
-#ifdef RS_DECODE_PROFILE
-  if (tid == 0 && T > 0)
-    printf("live-table block %d: %lld cycles, %d tokens, T=%d phases cutoff %lld expand: degrees+scan %lld arcs %lld rest %lld winners %lld closure %lld materialise %lld\n", u,
-           prof[0] + prof[1] + prof[2] + prof[3] + prof[4] + prof[5] + prof[6], off_next, T, prof[0], prof[5], prof[6], prof[1], prof[2], prof[3], prof[4]);
-#endif
-  if (s_redo) {                       // workgroup-uniform
-    if (tid == 0) { w.redo[u] = 1; w.out_nwords[u] = -1; }
-    return;
-  }
-  // ================================================================ final costs + best-path traceback (DecodeKernel's)
-  {
-    const int4 *cur = tokens + off_cur;
-    float lv1 = INF, lv2 = INF;
-    int li1 = 0x7fffffff, li2 = 0x7fffffff;
-    for (int i = tid; i < n_cur; i += NT) {
-      const float cst = __int_as_float(cur[i].y);
-      const float wf = cst + h.final_cost[cur[i].x];
-      if (wf < lv1 || (wf == lv1 && i < li1)) { lv1 = wf; li1 = i; }
-      if (cst < lv2 || (cst == lv2 && i < li2)) { lv2 = cst; li2 = i; }
-    }
-    float b1, b2;
-    int i1, i2;
-    BlockMinArg<NT>(c, lv1, li1, &b1, &i1);
-    BlockMinArg<NT>(c, lv2, li2, &b2, &i2);
-    atomicAdd(&c.counters[0], cnt_expanded);
-    atomicAdd(&c.counters[1], cnt_arcs);
-    atomicAdd(&c.counters[2], cnt_insert);
-    __syncthreads();
-    if (tid == 0) {
-      const bool reached = b1 < INF;
-      int idx = reached ? i1 : i2;
-      int F = c.error ? -1 : T;
-      double graph = 0.0, ac = 0.0;
-      int nw = 0;
-      int *words = w.out_words + (size_t)u * w.max_words;
-      bool truncated = false;
-      if (F >= 0 && n_cur > 0) {
-        if (reached) graph += (double)h.final_cost[cur[idx].x];
-        while (true) {
-          const int4 tk = tokens[frame_off[F] + idx];
-          if (tk.w < 0) break;
-          const int4 arc = h.arcs[tk.w];
-          graph += (double)__int_as_float(arc.z);
-          if (arc.x != 0) {
-            F -= 1;
-            const float off = finfo[F * 4 + 0];
-            const float lk = loglikes[(ll_base + F) * ld + (arc.x - 1)];
-            const float link_ac = off - lk;                   // ForwardLink::acoustic_cost
-            ac += (double)(link_ac - off);                    // GetRawLattice :166-172
-          }
-          if (arc.y != 0) {
-            if (nw < w.max_words) words[nw++] = arc.y;
-            else truncated = true;
-          }
-          idx = tk.z;
-        }
-        for (int a = 0, b = nw - 1; a < b; a++, b--) { int t2 = words[a]; words[a] = words[b]; words[b] = t2; }
-      }
-      w.out_nwords[u] = (c.error || truncated) ? -1 : nw;
-      float *oc = w.out_costs + (size_t)u * 4;
-      oc[0] = (float)graph;
-      oc[1] = (float)ac;
-      oc[2] = reached ? b1 : b2;
-      oc[3] = reached ? 1.f : 0.f;
-      c.counters[7] = 2ull * (unsigned long long)c.error;
-      long long *ctr = w.counters + (size_t)u * 8;
-      for (int i = 0; i < 8; i++) ctr[i] = (long long)c.counters[i];
-      frame_off[T + 1] = off_next;
-    }
-  }
-}
-
 // ===================================================================================== lattice extraction
 // Backward pass = FinalizeDecoding: PruneForwardLinksFinal on the last frame, PruneForwardLinks(delta = 0) on
 // every earlier frame (lattice-faster-decoder.cc:376-458,299-370,625-640).  Forward links are not stored by
@@ -1312,20 +698,6 @@ void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeo
                         const DecodeWork &w, const LatticeWork &lw, hipStream_t s) {
   if (g.n_utts == 0) return;
   hipLaunchKernelGGL(LatticeKernel<256>, dim3(g.n_utts), dim3(256), 0, s, h, o, g, loglikes, ld, w, lw);
-}
-
-bool DecodeHashUsable(const HclgDev &h) { return h.num_states > 0; }
-int DecodeHashSlotCap() { return kSlotCap; }
-int DecodeHashTableSize() { return kHashSize; }
-void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
-                      const DecodeWork &w, hipStream_t s) {
-  if (g.n_utts == 0) return;
-  // graphs whose state ids do not fit beside a slot number in one table word use the position-addressed form (RS_HASH_WIDE=1 forces it)
-  const char *we = std::getenv("RS_HASH_WIDE");          // (read per launch: a test flips it)
-  const bool force_wide = we && std::atoi(we) != 0;
-  const bool wide = force_wide || (unsigned)h.num_states >= (1u << (32 - kSlotBits)) - 1u;
-  if (wide) hipLaunchKernelGGL((HashDecodeKernel<1024, true>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
-  else hipLaunchKernelGGL((HashDecodeKernel<1024, false>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
 }
 
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,

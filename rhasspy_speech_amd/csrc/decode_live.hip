@@ -24,11 +24,19 @@
 //        no longer the one it carries -- and the popped entry writes the back pointer into its token, so
 //      - completing the frame's tokens is token -> key -> store (round 3: + source state of the winning epsilon arc -> table
 //        lookup -> slot's token);
-//  * the state -> slot table has two levels: 2^HLOG entries in LDS (eight probes) and, behind it, a 32 K-entry table in global
-//    memory (L2) for the states that find their eight LDS entries taken.  The LDS part no longer has to hold the largest frame
-//    of the batch, so it is 64 KB (or 32) instead of 128 and TWO (four) workgroups share a CU: while one waits at a barrier or
-//    for a round trip the other runs.  Nothing is restarted when a frame outgrows the LDS part; only > 24 576 live states (the
-//    slot arrays' length) hands the utterance to DecodeKernel as before.
+//  * first measurement of the above (profiles/r05/live_notes.txt): the round trips were not the bound.  A workgroup ALONE on
+//    its CU ran the heaviest utterance as fast with 512 threads as with 1024, and two workgroups on a CU ran half as fast each:
+//    a CU's path to L2 was saturated by scattered 16-byte accesses, each pulling a whole cache line -- ~77 k lines per 9 k-token
+//    frame (state record, arcs, key atomicMin, key read by the winners, slot's token, key read + clear by the completion pass).
+//    So the recombination keys moved into LDS: the table is tags[HS] + keys[HS] (12 bytes per live state), claimed by one LDS
+//    compare-and-swap, raced on by ds_min_u64, read by the winners' and the completion pass from LDS and emptied wholesale at
+//    the end of the frame.  Behind it a second level in global memory (32 K entries: tag + key) takes the states whose probe
+//    window in LDS is taken, so nothing is restarted when a frame outgrows LDS; only > 24 576 live states hands the utterance
+//    to DecodeKernel as before.  The slot IS the entry's position (one form for graphs of any size);
+//  * a state's record and its first two emitting arcs are ONE 64-byte record (HclgDev::nodes): one line per expanded token instead
+//    of two; candidate records are 8 bytes (arc | flags, slot | source token: the destination state is the slot's tag);
+//  * slot -> token index is only kept for the states the closure can touch (destinations of epsilon arcs, states with epsilon
+//    arcs, tokens the closure creates): a flag on the arc says so.
 // Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <cfloat>
@@ -43,19 +51,23 @@ namespace rs {
 using namespace tok;
 namespace {
 
-constexpr int kGlobalLog = 15;                      // second-level table: 32768 entries per utterance in global memory
+constexpr int kGlobalLog = 15;                      // second-level table: 32768 entries (tag + key) per utterance in global memory
 constexpr int kGlobalSize = 1 << kGlobalLog;
-constexpr int kSlotBits = 15;
-constexpr int kSlotCap = (1 << kSlotBits) * 3 / 4;  // live states per frame (compact form): 24576
+constexpr int kSlotCap = 24576;                     // live states / tokens per frame (records name a token of a frame in 16 bits)
 constexpr unsigned kFree = 0xFFFFFFFFu;
-constexpr int kLdsProbes = 8;
-constexpr int kBigCap = 512;                        // high-degree tokens whose arcs are dealt out per chunk
-constexpr int kInline = 2;                          // emitting arcs a thread relaxes itself
-#ifndef RS_LIVE_Q
-#define RS_LIVE_Q 4
+#ifndef RS_LIVE_BUCKETS
+#define RS_LIVE_BUCKETS 2
 #endif
+constexpr int kLdsBuckets = RS_LIVE_BUCKETS;      // buckets of four LDS entries looked at before a state goes to the global part
+constexpr int kBigCap = 256;                        // high-degree tokens whose arcs are dealt out per chunk
+constexpr int kStageCap = 128;                      // candidate arcs a wave parks in LDS until 64 of them can be inserted with every lane busy
+constexpr int kInline = 2;                          // emitting arcs a thread relaxes itself (they sit in the state's node record)
 constexpr int kNoBp = 0xFFFF;                       // work-list entry that must not write a back pointer (made by an emitting arc)
+constexpr int kDstHasEps = (int)0x80000000;         // arcs_f.x flags: the destination state has epsilon arcs / is the destination of one
+constexpr int kDstEpsDst = 0x40000000;
+constexpr int kPdfMask = 0x3fffffff;
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned LdsTag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ unsigned GlbTag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -81,55 +93,84 @@ struct LiveCtx {
   unsigned long long counters[8];
   unsigned chist[256];               // costs of the frame just completed, binned over [hist_lo, hist_hi)
   float kth_cand[256];
-  int big_pre[kBigCap + 1];
-  int4 big_ent[kBigCap];
+  int big_pre[kBigCap + 1];          // exclusive prefix of the arcs left of a chunk of high-degree tokens
 };
 
-// slot of `state`, claiming a fresh one if the state is not in the table yet; -1: no slot / no entry left.
-// WIDE = false: entry = state << 15 | slot, slots handed out consecutively (graphs below 131 071 states); WIDE = true: entry = state
-// id, the slot is the entry's position (LDS part: [0, 2^HLOG), global part behind it).
-template <int HLOG, bool WIDE>
-__device__ __forceinline__ int SlotFindOrInsert(unsigned *tags, unsigned *gtags, int *n_slots, int *g_used, unsigned lds_mask,
-                                                unsigned state, int slot_limit) {
-  unsigned hp = ((state * 2654435761u) >> (32 - HLOG)) & lds_mask;
-  int mine = -1;
+// The live-state table of one utterance: HS entries (tag + key) in LDS, kGlobalSize behind them in global memory.
+template <int HS>
+struct LiveTable {
+  unsigned *tags;                    // LDS
+  unsigned long long *keys;          // LDS
+  unsigned *gtags;                   // global
+  unsigned long long *gkeys;         // global
+  int *n_slots, *g_used;             // LDS counters
+  unsigned lds_size;                 // entries of the LDS part in use (HS; tests shrink it)
+  int slot_limit;
+
+  // slot of `state`, claiming a fresh entry if the state is not in the table yet (*claimed says so: the caller counts the frame's live
+  // states); -1: no entry left
+  __device__ __forceinline__ int FindOrInsert(unsigned state, bool *claimed) const {
+    // LDS part: buckets of four tags, read with one 16-byte load; a state lives in the first bucket from its home bucket that had a
+    // free entry when it arrived (entries are never released within a frame, so a bucket with a free entry and without the state
+    // ends the search).  Linear probing one tag at a time cost 8 dependent LDS round trips per insertion at the load a heavy
+    // frame puts on the table (9 k states in 9.7 k entries).
+    const unsigned nb = lds_size >> 2;
+    unsigned b = (unsigned)(((unsigned long long)(state * 2654435761u) * nb) >> 32);
+    *claimed = false;
 #pragma unroll 1
-  for (int probe = 0; probe < kLdsProbes; probe++) {
-    unsigned e = LdsTag(&tags[hp]);
-    if (e == kFree) {
-      if (mine < 0) {
-        mine = atomicAdd(n_slots, 1);
-        if (mine >= slot_limit) return -1;
+    for (int tries = 0, moved = 0; moved < kLdsBuckets && tries < 4 * kLdsBuckets + 8; tries++) {
+      const v4u e = *reinterpret_cast<const volatile v4u *>(&tags[4 * b]);
+      if (e.x == state) return (int)(4 * b);
+      if (e.y == state) return (int)(4 * b + 1);
+      if (e.z == state) return (int)(4 * b + 2);
+      if (e.w == state) return (int)(4 * b + 3);
+      const int j = e.x == kFree ? 0 : e.y == kFree ? 1 : e.z == kFree ? 2 : e.w == kFree ? 3 : -1;
+      if (j >= 0) {
+        const unsigned old = atomicCAS(&tags[4 * b + j], kFree, state);
+        if (old == kFree) { *claimed = true; return (int)(4 * b + j); }
+        if (old == state) return (int)(4 * b + j);
+        continue;      // another state took the entry first: look at this bucket again
       }
-      e = atomicCAS(&tags[hp], kFree, WIDE ? state : ((state << kSlotBits) | (unsigned)mine));
-      if (e == kFree) return WIDE ? (int)hp : mine;
-      // another lane claimed this entry first (possibly for the same state: then `mine` stays unused, its key stays empty)
+      b = b + 1 == nb ? 0u : b + 1;
+      moved++;
     }
-    if (WIDE) { if (e == state) return (int)hp; }
-    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
-    hp = (hp + 1) & lds_mask;
-  }
-  // All eight LDS entries belong to other states.  Entries are never released within a frame, so every lane looking for this state
-  // finds them taken too and continues here.
-  *g_used = 1;
-  unsigned gp = (state * 2246822519u) >> (32 - kGlobalLog);
+    // All probed LDS entries belong to other states.  Entries are never released within a frame, so every lane looking for this
+    // state finds them taken too and continues here.
+    *g_used = 1;
+    unsigned gp = (state * 2246822519u) >> (32 - kGlobalLog);
 #pragma unroll 1
-  for (int probe = 0; probe < 1024; probe++) {
-    unsigned e = GlbTag(&gtags[gp]);
-    if (e == kFree) {
-      if (mine < 0) {
-        mine = atomicAdd(n_slots, 1);
-        if (mine >= slot_limit) return -1;
+    for (int probe = 0; probe < 1024; probe++) {
+      unsigned e = GlbTag(&gtags[gp]);
+      if (e == kFree) {
+        e = atomicCAS(&gtags[gp], kFree, state);
+        if (e == kFree) { *claimed = true; return HS + (int)gp; }
       }
-      e = atomicCAS(&gtags[gp], kFree, WIDE ? state : ((state << kSlotBits) | (unsigned)mine));
-      if (e == kFree) return WIDE ? (1 << HLOG) + (int)gp : mine;
+      if (e == state) return HS + (int)gp;
+      gp = (gp + 1) & (kGlobalSize - 1);
     }
-    if (WIDE) { if (e == state) return (1 << HLOG) + (int)gp; }
-    else if ((e >> kSlotBits) == state) return (int)(e & ((1u << kSlotBits) - 1u));
-    gp = (gp + 1) & (kGlobalSize - 1);
+    return -1;
   }
-  return -1;
-}
+  // one lane's claim (InitDecoding, the closure): counted at once
+  __device__ __forceinline__ int FindOrInsertCounted(unsigned state) const {
+    bool claimed;
+    const int sl = FindOrInsert(state, &claimed);
+    if (claimed && atomicAdd(n_slots, 1) >= slot_limit) return -1;
+    return sl;
+  }
+  __device__ __forceinline__ unsigned State(int slot) const { return slot < HS ? LdsTag(&tags[slot]) : GlbTag(&gtags[slot - HS]); }
+  __device__ __forceinline__ void KeyMin(int slot, unsigned long long k) const {      // result unused: non-returning atomics
+    if (slot < HS) atomicMin(&keys[slot], k); else atomicMin(&gkeys[slot - HS], k);
+  }
+  __device__ __forceinline__ unsigned long long KeyMinRet(int slot, unsigned long long k) const {
+    return slot < HS ? atomicMin(&keys[slot], k) : atomicMin(&gkeys[slot - HS], k);
+  }
+  __device__ __forceinline__ unsigned long long KeyLoad(int slot) const {
+    return slot < HS ? __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : LoadKey(&gkeys[slot - HS]);
+  }
+  __device__ __forceinline__ void KeyStore(int slot, unsigned long long k) const {
+    if (slot < HS) __hip_atomic_store(&keys[slot], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else StoreKey(&gkeys[slot - HS], k);
+  }
+};
 
 // k-th smallest (0-based) of the n token costs whose histogram (CostBin over lo / scale) is chist: the bin that holds the rank
 // from the histogram, one sweep that collects that bin's values, direct ranking.  Radix select when the bin is crowded.
@@ -183,39 +224,52 @@ __device__ float KthFromCommitHist(Ctx &c, const int4 *toks, int n, int k, float
 #define RS_LP(i) do { } while (0)
 #endif
 
-template <int NT, int HLOG, bool WIDE>
+#ifndef RS_LIVE_Q
+#define RS_LIVE_Q 2
+#endif
+#ifndef RS_LIVE_HS
+#define RS_LIVE_HS 9728
+#endif
+
+template <int NT, int HS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void LiveDecodeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
                                                        const float *__restrict__ loglikes, int ld, DecodeWork w) {
   using Ctx = LiveCtx<NT>;
-  constexpr int HS = 1 << HLOG;
   constexpr int NW = NT / 64;
+  static_assert(HS % 4 == 0 && HS + kGlobalSize <= 65536, "slots are named in 16 bits");
   __shared__ Ctx c;
   __shared__ __attribute__((aligned(16))) unsigned tags[HS];
+  __shared__ __attribute__((aligned(16))) unsigned long long lkeys[HS];
+  __shared__ int4 stage_all[NT / 64][kStageCap];             // per wave: candidate arcs waiting for insertion {arc | flags, destination, cost bits, source token}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = blockIdx.x, tid = threadIdx.x;
   const int T = g.d_num_frames[u];
   const size_t tab = (size_t)w.h_tab;
-  unsigned long long *keys = w.h_keys + (size_t)u * tab;
-  int *slot_tok = w.h_slot_tok + (size_t)u * tab;            // slot -> index of its token in the frame under construction
-  unsigned *gtags = w.h_gtags + (size_t)u * kGlobalSize;
-  int4 *cand = reinterpret_cast<int4 *>(w.h_cand) + (size_t)u * w.h_cand_cap;      // {arc, destination | has-epsilon-arcs << 31, slot << 16 | source token, cost bits}
+  int *slot_tok = w.h_slot_tok + (size_t)u * tab;            // slot -> index of its token in the frame under construction (closure-reachable states only)
+  int2 *cand = reinterpret_cast<int2 *>(w.h_cand) + (size_t)u * w.h_cand_cap;      // {arc | flags of arcs_f.x, slot << 16 | source token}
   const int qcap = w.h_qcap;
-  int4 *queue[2] = {w.h_q4 + (size_t)u * 2 * qcap, w.h_q4 + (size_t)u * 2 * qcap + qcap};          // {slot | writer token << 16, first epsilon arc, key low, key high}
-  int *queue_ne[2] = {w.h_qne + (size_t)u * 2 * qcap, w.h_qne + (size_t)u * 2 * qcap + qcap};      // epsilon arcs of the entry's state
+  int4 *const queue0 = w.h_q4 + (size_t)u * 2 * qcap;        // work lists {slot | writer token << 16, first epsilon arc, key low, key high} ...
+  int *const queue_ne0 = w.h_qne + (size_t)u * 2 * qcap;     // ... and the number of epsilon arcs of the entry's state
   int4 *big = w.h_comp + (size_t)u * kSlotCap;               // tokens with more than kInline emitting arcs: {first arc left, cost bits, token index, arcs left}
+  int4 *const my_stage = stage_all[threadIdx.x >> 6];
   int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
   int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
   float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
-  const int4 *arcsf = h.arcs_f;                              // arcs with bit 31 of .x = "the destination state has epsilon arcs"
+  const int4 *arcsf = h.arcs_f;
+  const uint4 *nodes = h.nodes;                              // 4 x 16 bytes per state: {first arc, epsilon arcs, emitting arcs, 0}, emitting arc 0, emitting arc 1, -
   const float INF = INFINITY;
   const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
   const int cand_cap = w.h_cand_cap;
-  const int slot_limit = w.h_slot_limit < kSlotCap ? w.h_slot_limit : kSlotCap;      // (tests lower it to send utterances to DecodeKernel)
-  const unsigned lds_mask = (1u << (w.h_lds_log > 0 && w.h_lds_log < HLOG ? w.h_lds_log : HLOG)) - 1u;      // (tests shrink the LDS part)
+  LiveTable<HS> tb;
+  tb.tags = tags; tb.keys = lkeys;
+  tb.gtags = w.h_gtags + (size_t)u * kGlobalSize;
+  tb.gkeys = w.h_keys + (size_t)u * tab;
+  tb.n_slots = &c.n_slots; tb.g_used = &c.g_used;
+  tb.lds_size = w.h_lds_log > 1 && (1 << w.h_lds_log) < HS ? 1u << w.h_lds_log : (unsigned)HS;      // (tests shrink the LDS part; a multiple of four)
+  tb.slot_limit = w.h_slot_limit < kSlotCap ? w.h_slot_limit : kSlotCap;                            // (tests lower it to send utterances to DecodeKernel)
 
-  for (int i = tid; i < (WIDE ? HS + kGlobalSize : kSlotCap); i += NT) StoreKey(&keys[i], RS_EMPTY);
-  for (int i = tid; i < kGlobalSize; i += NT) __hip_atomic_store(&gtags[i], kFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = tid; i < HS; i += NT) tags[i] = kFree;
+  for (int i = tid; i < kGlobalSize; i += NT) { StoreKey(&tb.gkeys[i], RS_EMPTY); __hip_atomic_store(&tb.gtags[i], kFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  for (int i = tid; i < HS; i += NT) { tags[i] = kFree; lkeys[i] = RS_EMPTY; }
   for (int i = tid; i < 256; i += NT) c.chist[i] = 0;
   if (tid == 0) {
     c.n_next = 0; c.overflow = 0; c.error = 0; c.q_n[0] = c.q_n[1] = 0;
@@ -227,24 +281,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   unsigned cnt_expanded = 0, cnt_arcs = 0, cnt_insert = 0;      // (per thread: 32 bits hold an utterance's share)
   __syncthreads();
-  auto find_or_insert = [&](unsigned state) __attribute__((always_inline)) {
-    return SlotFindOrInsert<HLOG, WIDE>(tags, gtags, &c.n_slots, &c.g_used, lds_mask, state, slot_limit);
-  };
 
   int off_cur = 0, n_cur = 0;       // frame f's token list
   int off_next = 0;                 // frame under construction
   if (tid == 0) {                   // InitDecoding: the start state's token
-    const int sl = find_or_insert((unsigned)h.start);
+    const int sl = tb.FindOrInsertCounted((unsigned)h.start);
     const unsigned long long k0 = PackKey(0.0f, RS_NOARC);
-    StoreKey(&keys[sl], k0);
+    tb.KeyStore(sl, k0);
     tokens[0] = make_int4(h.start, sl, -1, -2);
     slot_tok[sl] = 0;
     c.n_next = 1;
     frame_off[0] = 0;
-    const uint4 sr = h.state_rec[h.start];
+    const uint4 sr = nodes[(size_t)h.start * 4];
     if (sr.y != 0) {
-      queue[0][0] = make_int4(sl | (kNoBp << 16), (int)sr.x, (int)(unsigned)(k0 & 0xFFFFFFFFull), (int)(unsigned)(k0 >> 32));
-      queue_ne[0][0] = (int)sr.y;
+      queue0[0] = make_int4(sl | (kNoBp << 16), (int)sr.x, (int)(unsigned)(k0 & 0xFFFFFFFFull), (int)(unsigned)(k0 >> 32));
+      queue_ne0[0] = (int)sr.y;
       c.q_n[0] = 1;
     }
   }
@@ -260,8 +311,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
   for (int f = -1; f < T; f++) {
     int4 *next_toks = tokens + off_next;
-    // a frame holds at most kSlotCap tokens (one per slot); records name tokens of a frame in 15 / 16 bits
-    const int next_cap = w.tok_cap - off_next < slot_limit ? w.tok_cap - off_next : slot_limit;
+    // a frame holds at most kSlotCap tokens (one per slot); records name tokens of a frame in 16 bits
+    const int next_cap = w.tok_cap - off_next < tb.slot_limit ? w.tok_cap - off_next : tb.slot_limit;
     if (f >= 0) {
       // ================================================================ ProcessEmitting(frame f)
       const int4 *cur = tokens + off_cur;
@@ -322,41 +373,75 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       // dependent loads for one wave: worth it in the frames that make many candidates.
       if (wave == NW - 1 && n_cur > 2048) {
         const int4 bt = cur[best_idx];
-        const uint4 bsr = h.state_rec[bt.x];
+        const uint4 bsr = nodes[(size_t)bt.x * 4];
         float first_bound = INF;
         for (unsigned k = lane; k < bsr.z; k += 64) {
           const int4 arc = arcsf[bsr.x + bsr.y + k];
-          first_bound = fminf(first_bound, (__int_as_float(bt.y) + (cost_offset - ll_row[(arc.x & 0x7fffffff) - 1])) + __int_as_float(arc.z));
+          first_bound = fminf(first_bound, (__int_as_float(bt.y) + (cost_offset - ll_row[(arc.x & kPdfMask) - 1])) + __int_as_float(arc.z));
         }
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) first_bound = fminf(first_bound, __shfl_xor(first_bound, o2, 64));
         if (lane == 0 && first_bound < INF) atomicMin(&c.run_min, OrderedBits(first_bound));
       }
-      auto relax_arc = [&](unsigned a, const int4 arc, float lk, float cur_cost, bool is_best, int src_tok) __attribute__((always_inline)) {
+      // Expansion in two steps, so that the expensive one runs with every lane busy:
+      //   eval:  a lane looks at an arc -- cost, bounds, counters -- and parks the survivors (tot below "cheapest candidate seen so
+      //          far + adaptive beam": anything else cannot end up below the frame's next_cutoff) in the wave's LDS stage;
+      //   flush: as soon as 64 are parked, every lane takes one: table entry of the destination, ds_min on its key, candidate record
+      //          (one counter update per 64 records).
+      // Relaxing arcs where they were evaluated left the table code running for the lanes whose arc survived only, eight times per
+      // trip (profiles/r05/live_notes.txt: 7 G wave instructions per launch, 0.77 of the SIMDs' issue slots).
+      float lane_min = INF;             // the cheapest candidate this lane has seen; the wave's minimum goes to c.run_min once per trip
+      int st_n = 0;                     // parked arcs (wave-uniform)
+      const unsigned long long lanes_below = (1ull << lane) - 1ull;
+      auto publish_min = [&]() __attribute__((always_inline)) {
+        float m = lane_min;
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) m = fminf(m, __shfl_xor(m, o2, 64));
+        if (lane == 0 && OrderedBits(m) < c.run_min) __hip_atomic_fetch_min(&c.run_min, OrderedBits(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      auto flush = [&](int first, int cnt) __attribute__((always_inline)) {      // parked arcs [first, first + cnt), cnt <= 64 (wave-uniform)
+        const bool on = lane < cnt;
+        const int4 it = my_stage[first + (on ? lane : 0)];
+        bool claimed = false;
+        int sl = 0;
+        if (on) {
+          sl = tb.FindOrInsert((unsigned)it.y, &claimed);
+          if (sl >= 0) tb.KeyMin(sl, ((unsigned long long)OrderedBits(__int_as_float(it.z)) << 32) | (unsigned)(it.x & kPdfMask));
+        }
+        const int n_claimed = __popcll(__ballot(on && claimed));
+        const bool failed = __ballot(on && sl < 0) != 0ull;
+        int base = 0;
+        if (lane == 0) {
+          base = atomicAdd(&c.n_cand, cnt);
+          if (n_claimed && atomicAdd(&c.n_slots, n_claimed) + n_claimed > tb.slot_limit) c.redo = 1;
+          if (failed || base + cnt > cand_cap) c.redo = 1;
+        }
+        base = __shfl(base, 0, 64);
+        if (on && base + lane < cand_cap) cand[base + lane] = make_int2(it.x, (sl << 16) | it.w);
+      };
+      auto eval_arc = [&](bool valid, unsigned a, const int4 arc, float lk, float cur_cost, bool is_best, int src_tok) __attribute__((always_inline)) {
         const float graph_cost = __int_as_float(arc.z);
         const float ac_cost = cost_offset - lk;
         const float tot = (cur_cost + ac_cost) + graph_cost;
-        if (is_best) {
-          const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;      // :752-757, the reference's first bound
-          local_min = fminf(local_min, nw);
+        if (valid) {
+          if (is_best) {
+            const float nw = ((graph_cost + cost_offset) - lk) + cur_cost;      // :752-757, the reference's first bound
+            local_min = fminf(local_min, nw);
+          }
+          local_min = fminf(local_min, tot);
+          cnt_arcs++;
         }
-        local_min = fminf(local_min, tot);
-        cnt_arcs++;
-        const float bound = FromOrdered(c.run_min) + adaptive_beam;
-        if (!(tot < bound)) return;
-        cnt_insert++;
-        const unsigned ot = OrderedBits(tot);
-        if (ot < c.run_min) atomicMin(&c.run_min, ot);
-        const int sl = find_or_insert((unsigned)arc.w);
-        if (sl < 0) { c.redo = 1; return; }
-        atomicMin(&keys[sl], PackKey(tot, a));                 // result unused: non-returning
-        const int ci = atomicAdd(&c.n_cand, 1);
-        if (ci < cand_cap) cand[ci] = make_int4((int)a, arc.w | (arc.x & (int)0x80000000), (sl << 16) | src_tok, __float_as_int(tot));
-        else c.redo = 1;
+        const float bound = fminf(FromOrdered(c.run_min), lane_min) + adaptive_beam;
+        const bool keep = valid && tot < bound;
+        if (keep) { cnt_insert++; lane_min = fminf(lane_min, tot); }
+        const unsigned long long m = __ballot(keep);
+        if (keep) my_stage[st_n + __popcll(m & lanes_below)] = make_int4((int)a | (arc.x & (kDstHasEps | kDstEpsDst)), arc.w, __float_as_int(tot), src_tok);
+        st_n += __popcll(m);
+        if (st_n >= 64) { st_n -= 64; flush(st_n, 64); }
       };
       {
         constexpr int Q = RS_LIVE_Q;
-        for (int ib = tid; ib < n_cur; ib += Q * NT) {
+        for (int base = wave * 64; base < n_cur; base += Q * NT) {      // (wave-uniform trip count: the flush needs every lane)
           int2 tk[Q];
           bool act[Q];
           uint4 sr[Q];
@@ -364,62 +449,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           float lk[Q][kInline];
 #pragma unroll
           for (int q = 0; q < Q; q++) {
-            const int i = ib + q * NT;
+            const int i = base + q * NT + lane;
             tk[q] = i < n_cur ? *reinterpret_cast<const int2 *>(&cur[i]) : make_int2(0, __float_as_int(INF));
           }
 #pragma unroll
           for (int q = 0; q < Q; q++) {
-            act[q] = ib + q * NT < n_cur && __int_as_float(tk[q].y) <= cur_cutoff;
-            sr[q] = act[q] ? h.state_rec[tk[q].x] : make_uint4(0u, 0u, 0u, 0u);
+            act[q] = base + q * NT + lane < n_cur && __int_as_float(tk[q].y) <= cur_cutoff;
+            const uint4 *nd = nodes + (size_t)tk[q].x * 4;      // one 64-byte record: the state's arc ranges and its first two emitting arcs
+            sr[q] = act[q] ? nd[0] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < kInline; k++) {
+              const uint4 ar = act[q] ? nd[1 + k] : make_uint4(1u, 0u, 0u, 0u);
+              arc[q][k] = make_int4((int)ar.x, (int)ar.y, (int)ar.z, (int)ar.w);
+            }
           }
 #pragma unroll
           for (int q = 0; q < Q; q++)
 #pragma unroll
-            for (int k = 0; k < kInline; k++)
-              arc[q][k] = (unsigned)k < sr[q].z ? arcsf[sr[q].x + sr[q].y + k] : make_int4(1, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < Q; q++)
-#pragma unroll
-            for (int k = 0; k < kInline; k++) lk[q][k] = ll_row[(arc[q][k].x & 0x7fffffff) - 1];
+            for (int k = 0; k < kInline; k++) lk[q][k] = ll_row[(unsigned)k < sr[q].z ? (arc[q][k].x & kPdfMask) - 1 : 0];
 #pragma unroll
           for (int q = 0; q < Q; q++) {
-            if (!act[q]) continue;
-            const int i = ib + q * NT;
-            cnt_expanded++;
+            const int i = base + q * NT + lane;
+            if (act[q]) cnt_expanded++;
 #pragma unroll
             for (int k = 0; k < kInline; k++)
-              if ((unsigned)k < sr[q].z) relax_arc(sr[q].x + sr[q].y + k, arc[q][k], lk[q][k], __int_as_float(tk[q].y), i == best_idx, i);
-            if (sr[q].z > (unsigned)kInline) big[atomicAdd(&c.n_big, 1)] = make_int4((int)(sr[q].x + sr[q].y + kInline), tk[q].y, i, (int)sr[q].z - kInline);
+              eval_arc(act[q] && (unsigned)k < sr[q].z, sr[q].x + sr[q].y + k, arc[q][k], lk[q][k], __int_as_float(tk[q].y), i == best_idx, i);
+            if (act[q] && sr[q].z > (unsigned)kInline) big[atomicAdd(&c.n_big, 1)] = make_int4((int)(sr[q].x + sr[q].y + kInline), tk[q].y, i, (int)sr[q].z - kInline);
           }
+          publish_min();
         }
       }
       __syncthreads();
       RS_LP(1);
-      // ---- the arcs beyond the first two of the (few) tokens that have them, dealt out over the threads
+      // ---- the arcs beyond the first two of the (few) tokens that have them, dealt out over the threads: degree prefix of a chunk of
+      // such tokens in LDS, a search per arc (a wave per token was tried: its three dependent loads per token ran one token behind
+      // the other -- 6.6 -> 11.6 G cycles per launch for this phase)
       {
         const int nb = c.n_big;
+        int *big_pre = c.big_pre;
         for (int c0 = 0; c0 < nb; c0 += kBigCap) {
           const int nc = nb - c0 < kBigCap ? nb - c0 : kBigCap;
-          if (c0 > 0) __syncthreads();
-          for (int i = tid; i < nc; i += NT) { const int4 e = big[c0 + i]; c.big_ent[i] = e; c.big_pre[i] = e.w; }
+          const int4 *ent = big + c0;
           __syncthreads();
-          // exclusive prefix of the degrees in place: a run of consecutive entries per thread
-          const int per = (nc + NT - 1) / NT;
-          const int i0 = tid * per < nc ? tid * per : nc, i1 = i0 + per < nc ? i0 + per : nc;
-          int lsum = 0;
-          for (int i = i0; i < i1; i++) lsum += c.big_pre[i];
-          int inc = lsum;
+          // inclusive scan of the chunk's degrees by wave 0 (nc <= 256: four per lane)
+          if (wave == 0) {
+            int d[4], sum = 0;
 #pragma unroll
-          for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
-          if (lane == 63) c.red_i[wave] = inc;
+            for (int q = 0; q < 4; q++) { const int i = 4 * lane + q; d[q] = i < nc ? ent[i].w : 0; sum += d[q]; }
+            int inc = sum;
+#pragma unroll
+            for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+            int run = inc - sum;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int i = 4 * lane + q; if (i < nc) big_pre[i] = run; run += d[q]; }
+            if (lane == 63) big_pre[nc] = inc;
+          }
           __syncthreads();
-          int wbase = 0, total = 0;
-          for (int wv = 0; wv < NW; wv++) { if (wv < wave) wbase += c.red_i[wv]; total += c.red_i[wv]; }
-          int run = wbase + inc - lsum;
-          for (int i = i0; i < i1; i++) { const int dgr = c.big_pre[i]; c.big_pre[i] = run; run += dgr; }
-          if (tid == 0) c.big_pre[nc] = total;
-          __syncthreads();
-          for (int jb = tid; jb < total; jb += 4 * NT) {
+          const int total = big_pre[nc];
+          for (int jb = wave * 64; jb < total; jb += 4 * NT) {      // (wave-uniform trip count: the flush needs every lane)
             unsigned a[4];
             float cc[4];
             bool on[4];
@@ -428,24 +515,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             float lk[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const int j = jb + q * NT;
+              const int j = jb + q * NT + lane;
               on[q] = j < total;
               const int jj = on[q] ? j : total - 1;
               int lo = 0, hi = nc;            // last entry with pre[t] <= j
-              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c.big_pre[mid] <= jj) lo = mid; else hi = mid; }
-              const int4 e = c.big_ent[lo];
-              a[q] = (unsigned)e.x + (unsigned)(jj - c.big_pre[lo]);
+              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_pre[mid] <= jj) lo = mid; else hi = mid; }
+              const int4 e = ent[lo];
+              a[q] = (unsigned)e.x + (unsigned)(jj - big_pre[lo]);
               cc[q] = __int_as_float(e.y);
               tki[q] = e.z;
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) arc[q] = arcsf[a[q]];
 #pragma unroll
-            for (int q = 0; q < 4; q++) lk[q] = ll_row[(arc[q].x & 0x7fffffff) - 1];
+            for (int q = 0; q < 4; q++) lk[q] = ll_row[(arc[q].x & kPdfMask) - 1];
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (on[q]) relax_arc(a[q], arc[q], lk[q], cc[q], tki[q] == best_idx, tki[q]);
+            for (int q = 0; q < 4; q++) eval_arc(on[q], a[q], arc[q], lk[q], cc[q], tki[q] == best_idx, tki[q]);
+            publish_min();
           }
         }
+        if (st_n > 0) flush(0, st_n);
+        st_n = 0;
       }
       // next_cutoff = min over the candidates of (tot_cost + adaptive_beam): one LDS atomic per wave instead of a block reduction
 #pragma unroll
@@ -463,42 +553,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       if (c.redo) break;                 // workgroup-uniform: read after the barrier of the reduction
       hist_lo = FromOrdered(c.min_bits);
       {
-        // the winner of a slot (= the candidate whose key is the slot's) appends the token, complete with back pointer and arc,
-        // or -- at or above the final cutoff -- empties the key again; a token whose state has epsilon arcs goes onto the
+        // the winner of a slot (= the candidate whose arc is left in the slot's key) appends the token, complete with back pointer
+        // and arc, or -- at or above the final cutoff -- empties the key again; a token whose state has epsilon arcs goes onto the
         // closure's first work list
         constexpr int WB = 4;
         const int nc2 = c.n_cand;
         for (int ib = tid; ib < nc2; ib += WB * NT) {
-          int4 cr[WB];
+          int2 cr[WB];
           unsigned long long key[WB];
+          unsigned st[WB];
+          bool win[WB];
           uint4 sr[WB];
 #pragma unroll
           for (int q = 0; q < WB; q++) { const int i = ib + q * NT; cr[q] = cand[i < nc2 ? i : nc2 - 1]; }
 #pragma unroll
-          for (int q = 0; q < WB; q++) key[q] = LoadKey(&keys[(unsigned)cr[q].z >> 16]);
+          for (int q = 0; q < WB; q++) {
+            const int sl = (int)((unsigned)cr[q].y >> 16);
+            key[q] = tb.KeyLoad(sl);
+            win[q] = ib + q * NT < nc2 && (unsigned)(key[q] & 0xFFFFFFFFull) == (unsigned)(cr[q].x & kPdfMask);
+            st[q] = win[q] ? tb.State(sl) : 0u;
+          }
 #pragma unroll
-          for (int q = 0; q < WB; q++) sr[q] = cr[q].y < 0 ? h.state_rec[cr[q].y & 0x7fffffff] : make_uint4(0u, 0u, 0u, 0u);
+          for (int q = 0; q < WB; q++) sr[q] = win[q] && cr[q].x < 0 && KeyCost(key[q]) < next_cutoff ? nodes[(size_t)st[q] * 4] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
           for (int q = 0; q < WB; q++) {
-            if (ib + q * NT >= nc2 || (unsigned)(key[q] & 0xFFFFFFFFull) != (unsigned)cr[q].x) continue;
-            const int sl = (int)((unsigned)cr[q].z >> 16);
+            if (!win[q]) continue;
+            const int sl = (int)((unsigned)cr[q].y >> 16);
             if (KeyCost(key[q]) < next_cutoff) {
               const int idx = atomicAdd(&c.n_next, 1);
               if (idx < next_cap) {
-                next_toks[idx] = make_int4(cr[q].y & 0x7fffffff, sl, cr[q].z & 0xFFFF, cr[q].x);
-                slot_tok[sl] = idx;
+                next_toks[idx] = make_int4((int)st[q], sl, cr[q].y & 0xFFFF, cr[q].x & kPdfMask);
+                if (cr[q].x & (kDstHasEps | kDstEpsDst)) slot_tok[sl] = idx;      // (only the states the closure can reach need it)
                 if (sr[q].y != 0) {
                   const int qp = atomicAdd(&c.q_n[0], 1);
                   if (qp < qcap) {
-                    queue[0][qp] = make_int4(sl | (kNoBp << 16), (int)sr[q].x, (int)(unsigned)(key[q] & 0xFFFFFFFFull), (int)(unsigned)(key[q] >> 32));
-                    queue_ne[0][qp] = (int)sr[q].y;
+                    queue0[qp] = make_int4(sl | (kNoBp << 16), (int)sr[q].x, (int)(unsigned)(key[q] & 0xFFFFFFFFull), (int)(unsigned)(key[q] >> 32));
+                    queue_ne0[qp] = (int)sr[q].y;
                   } else c.redo = 1;
                 }
               } else {
                 c.overflow = 1;
               }
             } else {
-              StoreKey(&keys[sl], RS_EMPTY);
+              tb.KeyStore(sl, RS_EMPTY);
             }
           }
         }
@@ -509,21 +606,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     // ================================================================ ProcessNonemitting(closure_cutoff)
     {
-      int qi = 0;      // (queue[0] was filled by the winners' pass / InitDecoding; c.q_n[1] is 0)
+      int qi = 0;      // (list 0 was filled by the winners' pass / InitDecoding; c.q_n[1] is 0)
       int guard_rounds = 0;
       while (c.q_n[qi] > 0) {
         const int qn = c.q_n[qi] < qcap ? c.q_n[qi] : qcap;
+        const int4 *qin = queue0 + (size_t)qi * qcap;
+        const int *qin_ne = queue_ne0 + (size_t)qi * qcap;
+        int4 *qout = queue0 + (size_t)(qi ^ 1) * qcap;
+        int *qout_ne = queue_ne0 + (size_t)(qi ^ 1) * qcap;
         __syncthreads();
         if (tid == 0) c.q_n[qi ^ 1] = 0;
         __syncthreads();
         for (int ib = 0; ib < qn; ib += NT) {
           const int i = ib + tid;
           const bool have = i < qn;
-          const int4 qe = have ? queue[qi][i] : make_int4(0, 0, 0, 0);
-          const int ne_in = have ? queue_ne[qi][i] : 0;
+          const int4 qe = have ? qin[i] : make_int4(0, 0, 0, 0);
+          const int ne_in = have ? qin_ne[i] : 0;
           const int sl = qe.x & 0xFFFF, wtok = (int)((unsigned)qe.x >> 16);
           const unsigned long long ekey = ((unsigned long long)(unsigned)qe.w << 32) | (unsigned)qe.z;
-          const unsigned long long key = have ? LoadKey(&keys[sl]) : RS_EMPTY;
+          const unsigned long long key = have ? tb.KeyLoad(sl) : RS_EMPTY;
           const int my_tok = have ? slot_tok[sl] : 0;
           const bool fresh = have && key == ekey;      // else: the slot was improved again, the entry of that improvement is on a list too
           if (fresh && wtok != kNoBp) next_toks[my_tok].z = wtok;      // the token's back pointer: the token that relaxed the winning epsilon arc
@@ -563,11 +664,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
               mine = act && nkey == kmin;          // keys are unique (arc ids): exactly one lane
             }
             if (mine) {
-              const int sl2 = find_or_insert((unsigned)arc.w);
+              const int sl2 = tb.FindOrInsertCounted((unsigned)arc.w);
               if (sl2 < 0) { c.redo = 1; continue; }
               const bool dst_eps = arc.x < 0;
-              const unsigned long long old = atomicMin(&keys[sl2], nkey);
-              const uint4 dsr = dst_eps ? h.state_rec[arc.w] : make_uint4(0u, 0u, 0u, 0u);
+              const unsigned long long old = tb.KeyMinRet(sl2, nkey);
+              const uint4 dsr = dst_eps ? nodes[(size_t)arc.w * 4] : make_uint4(0u, 0u, 0u, 0u);
               if (old == RS_EMPTY) {              // FindOrAddToken made a token: its back pointer is this lane's token
                 const int idx = atomicAdd(&c.n_next, 1);
                 if (idx < next_cap) { next_toks[idx] = make_int4(arc.w, sl2, my_tok, -2); slot_tok[sl2] = idx; }
@@ -578,8 +679,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
               if ((old == RS_EMPTY && dst_eps) || (old != RS_EMPTY && nkey < old)) {
                 const int qp = atomicAdd(&c.q_n[qi ^ 1], 1);
                 if (qp < qcap) {
-                  queue[qi ^ 1][qp] = make_int4(sl2 | ((old == RS_EMPTY ? kNoBp : my_tok) << 16), (int)dsr.x, (int)(unsigned)(nkey & 0xFFFFFFFFull), (int)(unsigned)(nkey >> 32));
-                  queue_ne[qi ^ 1][qp] = (int)dsr.y;
+                  qout[qp] = make_int4(sl2 | ((old == RS_EMPTY ? kNoBp : my_tok) << 16), (int)dsr.x, (int)(unsigned)(nkey & 0xFFFFFFFFull), (int)(unsigned)(nkey >> 32));
+                  qout_ne[qp] = (int)dsr.y;
                 } else c.redo = 1;
               }
             }
@@ -601,22 +702,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const float hscale = 256.0f / (closure_cutoff - hist_lo);
       float lv = INF;                                     // cheapest token of the new frame (lowest index on ties)
       int li = 0x7fffffff;
-      constexpr int MB = 4;                               // tokens per thread and trip, both load stages of all of them in flight together
+      constexpr int MB = 4;                               // tokens per thread and trip
       for (int ib = tid; ib < nn; ib += MB * NT) {
-        int slot[MB];
-        unsigned long long key[MB];
+        int4 tk[MB];
 #pragma unroll
-        for (int q = 0; q < MB; q++) { const int i = ib + q * NT; slot[q] = i < nn ? next_toks[i].y : 0; }
-#pragma unroll
-        for (int q = 0; q < MB; q++) key[q] = LoadKey(&keys[slot[q]]);
+        for (int q = 0; q < MB; q++) { const int i = ib + q * NT; tk[q] = next_toks[i < nn ? i : nn - 1]; }
 #pragma unroll
         for (int q = 0; q < MB; q++) {
           const int i = ib + q * NT;
           if (i >= nn) continue;
-          const float cst = KeyCost(key[q]);
-          next_toks[i].y = __float_as_int(cst);
-          next_toks[i].w = (int)(unsigned)(key[q] & 0xFFFFFFFFull);
-          StoreKey(&keys[slot[q]], RS_EMPTY);
+          const unsigned long long key = tb.KeyLoad(tk[q].y);
+          const float cst = KeyCost(key);
+          next_toks[i] = make_int4(tk[q].x, __float_as_int(cst), tk[q].z, (int)(unsigned)(key & 0xFFFFFFFFull));
+          if (tk[q].y >= HS) tb.KeyStore(tk[q].y, RS_EMPTY);      // (the LDS part is emptied wholesale below)
           atomicAdd(&c.chist[CostBin(cst, hist_lo, hscale)], 1u);
           if (cst < lv || (cst == lv && i < li)) { lv = cst; li = i; }
         }
@@ -632,10 +730,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if (lane == 0 && bk != RS_EMPTY) atomicMin(&c.best_key, bk);      // (reset in the prologue of ProcessEmitting, behind barriers)
       }
-      // the table starts the next frame empty (every key a slot held was emptied by its owner above or in the winners' pass)
-      for (int i = tid; i < HS / 4; i += NT) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(kFree, kFree, kFree, kFree);
-      if (c.g_used) for (int i = tid; i < kGlobalSize; i += NT) __hip_atomic_store(&gtags[i], kFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
+      // the table starts the next frame empty (global keys were emptied by their owners above or in the winners' pass)
+      for (int i = tid; i < HS / 4; i += NT) reinterpret_cast<uint4 *>(tags)[i] = make_uint4(kFree, kFree, kFree, kFree);
+      for (int i = tid; i < HS / 2; i += NT) reinterpret_cast<uint4 *>(lkeys)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (c.g_used) for (int i = tid; i < kGlobalSize; i += NT) __hip_atomic_store(&tb.gtags[i], kFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       best_cost = c.best_key == RS_EMPTY ? INF : KeyCost(c.best_key);
       best_idx = (int)(unsigned)(c.best_key & 0xFFFFFFFFull);
       off_cur = off_next;
@@ -694,8 +793,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const bool reached = b1 < INF;
     // The walk itself (one dependent load per hop) is thread 0's; what every hop adds -- the arc's weight, its frame's
     // log-likelihood, its word -- is looked up by all threads a block of hops at a time.
-    constexpr int kHops = kBigCap;                 // (arc, frame of the acoustic score) pairs per block, in c.big_ent's LDS
-    int2 *hops = reinterpret_cast<int2 *>(c.big_ent);
+    constexpr int kHops = (NT / 64) * kStageCap * 2;      // (arc, frame of the acoustic score) pairs per block, in the waves' staging LDS
+    int2 *hops = reinterpret_cast<int2 *>(&stage_all[0][0]);
     int *words = w.out_words + (size_t)u * w.max_words;
     double graph = 0.0, ac = 0.0;                  // (thread-local partial sums, reduced at the end)
     int nw = 0;                                    // (wave 0's lanes all hold it)
@@ -785,33 +884,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 }  // namespace
 
-bool DecodeLiveUsable(const HclgDev &h) { return h.num_states > 0 && h.arcs_f != nullptr; }
+bool DecodeLiveUsable(const HclgDev &h) { return h.num_states > 0 && h.arcs_f != nullptr && h.nodes != nullptr && h.num_arcs < (1 << 30); }
 int DecodeLiveSlotCap() { return kSlotCap; }
 int DecodeLiveGlobalTable() { return kGlobalSize; }
-// length of the slot-indexed arrays: the compact form numbers slots consecutively (< kSlotCap); the position-addressed form uses
-// LDS positions [0, 2^HLOG) and global positions behind them
-int DecodeLiveTableSize() { return (1 << 15) + kGlobalSize; }
-
-namespace {
-template <int NT, int HLOG>
-void LaunchLive(bool wide, const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DecodeWork &w, hipStream_t s) {
-  if (wide) hipLaunchKernelGGL((LiveDecodeKernel<NT, HLOG, true>), dim3(g.n_utts), dim3(NT), 0, s, h, o, g, loglikes, ld, w);
-  else hipLaunchKernelGGL((LiveDecodeKernel<NT, HLOG, false>), dim3(g.n_utts), dim3(NT), 0, s, h, o, g, loglikes, ld, w);
-}
-}  // namespace
+// length of the slot-indexed arrays (a slot is the position of the state's table entry: LDS part, then the global part)
+int DecodeLiveTableSize() { return 65536; }
 
 void LaunchDecodeLive(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DecodeWork &w, hipStream_t s) {
   if (g.n_utts == 0) return;
-  // graphs whose state ids do not fit beside a slot number in one table word use the position-addressed form (RS_HASH_WIDE=1 forces it)
-  const char *we = std::getenv("RS_HASH_WIDE");          // (read per launch: a test flips it)
-  const bool force_wide = we && std::atoi(we) != 0;
-  const bool wide = force_wide || (unsigned)h.num_states >= (1u << (32 - kSlotBits)) - 1u;
-  // shape: threads per utterance / LDS entries.  512 / 16 K (two workgroups per CU) unless RS_LIVE_SHAPE says otherwise
-  static const int shape = [] { const char *e = std::getenv("RS_LIVE_SHAPE"); return e ? std::atoi(e) : 512; }();
-  if (shape == 1024) LaunchLive<1024, 15>(wide, h, o, g, loglikes, ld, w, s);
-  else if (shape == 256) LaunchLive<256, 13>(wide, h, o, g, loglikes, ld, w, s);
-  else LaunchLive<512, 14>(wide, h, o, g, loglikes, ld, w, s);
+  // one workgroup of 1024 threads per utterance and CU: 9728 table entries (tags + keys: 114 KB) + 32 KB of staging in LDS.  Shapes
+  // with two or four smaller workgroups per CU were measured and lost (profiles/r05/live_notes.txt).
+  hipLaunchKernelGGL((LiveDecodeKernel<1024, RS_LIVE_HS>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
 }
 
 }  // namespace rs

@@ -883,11 +883,12 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
   hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem, f_begin, f_end);
 }
 
-// Dense rows -> token lists, one workgroup per utterance: its four waves take the frames in turn, count the tokens of each (pass 1),
-// one wave prefix-sums the counts into frame_tok_off, the waves write their frames' tokens in state order (pass 2; frame 0 starts with
-// the start state's token: the lattice's start is token 0).
+// Dense rows -> token lists, one workgroup per utterance: its four waves take the frames in turn, count the tokens of each (pass 1,
+// into frame_tok_off itself: a stream's finishing call hands over every frame of the stream, which no LDS array holds), wave 0
+// prefix-sums the counts in place, the waves write their frames' tokens in state order (pass 2; frame 0 starts with the start state's
+// token: the lattice's start is token 0).  More tokens than the utterance's slice of the token array holds: capacity flag, no lists.
 __global__ __launch_bounds__(256) void DenseToTokensKernel(HclgDev h, BatchGeom g, DenseWork dw, DecodeWork w) {
-  extern __shared__ int dtt_cnt[];          // [T + 2]
+  __shared__ int s_total;
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = g.d_num_frames[u], S = h.num_states;
   int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
@@ -899,18 +900,30 @@ __global__ __launch_bounds__(256) void DenseToTokensKernel(HclgDev h, BatchGeom 
   for (int f = wave; f <= T; f += 4) {
     int n = 0;
     for (int s0 = 0; s0 < S; s0 += 64) { const int s = s0 + lane; n += __popcll(__ballot(s < S && cost[(size_t)f * S + s] < INFINITY)); }
-    if (lane == 0) dtt_cnt[f] = n;
+    if (lane == 0) frame_off[f] = n;
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int f = 0; f <= T; f++) { const int n = dtt_cnt[f]; dtt_cnt[f] = run; frame_off[f] = run; run += n; }
-    dtt_cnt[T + 1] = run;
-    frame_off[T + 1] = run;
+  if (wave == 0) {      // exclusive prefix over the frames, 64 at a time
+    int carry = 0;
+    for (int f0 = 0; f0 <= T; f0 += 64) {
+      const int f = f0 + lane;
+      const int n = f <= T ? frame_off[f] : 0;
+      int inc = n;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+      if (f <= T) frame_off[f] = carry + inc - n;
+      carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) { frame_off[T + 1] = carry; s_total = carry; }
   }
   __syncthreads();
+  if (s_total > w.tok_cap) {      // (workgroup-uniform; PlanSearch sizes the slice for every state of every frame, so this is a caller error)
+    for (int f = tid; f <= g.max_frames + 1; f += 256) frame_off[f] = 0;
+    if (tid == 0) { w.out_nwords[u] = -1; dw.counters[(size_t)u * 8 + 7] |= 1; }      // "decoder token capacity exceeded"
+    return;
+  }
   for (int f = wave; f <= T; f += 4) {
-    int run = dtt_cnt[f];
+    int run = frame_off[f];
     if (f == 0) {      // the start token first
       if (lane == 0) tokens[run] = make_int4(h.start, __float_as_int(cost[h.start]), -1, bp[h.start]);
       run++;
@@ -928,7 +941,7 @@ __global__ __launch_bounds__(256) void DenseToTokensKernel(HclgDev h, BatchGeom 
 
 void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s) {
   if (g.n_utts == 0) return;
-  hipLaunchKernelGGL(DenseToTokensKernel, dim3(g.n_utts), dim3(256), sizeof(int) * (size_t)(g.max_frames + 4), s, h, g, dw, w);
+  hipLaunchKernelGGL(DenseToTokensKernel, dim3(g.n_utts), dim3(256), 0, s, h, g, dw, w);
 }
 
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state

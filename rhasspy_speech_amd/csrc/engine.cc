@@ -171,7 +171,7 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
     const std::string v(e);
     // reg / dense: the LDS-resident searches of small graphs; sparse: DecodeKernel alone (dense per-state tables in HBM); hash: the
     // token-list search with the live-state table, which is what "auto" runs on graphs the first two cannot hold
-    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : v == "hash" ? 4 : v == "hash_r4" ? 5 : 0;
+    decoder_choice_ = v == "reg" ? 1 : v == "dense" ? 2 : v == "sparse" ? 3 : v == "hash" ? 4 : 0;
     if (decoder_choice_ >= 3) force_sparse_ = true;
   }
   ReadFeatureConfig(online_conf, &fc_);
@@ -670,10 +670,26 @@ void Model::ToDevice() {
       hclg_dev_.state_rec = static_cast<uint4 *>(UploadBytes(rec.data(), (size_t)S * sizeof(uint4)));
     }
     hclg_dev_.arcs = static_cast<int4 *>(UploadBytes(arcs.data(), A * sizeof(int4)));
-    {
+    if (A < ((size_t)1 << 30)) {      // the live-state-table search's copies (decode_live.hip)
+      const int S = hclg_.num_states();
+      std::vector<char> eps_dst(S, 0);
+      for (size_t a = 0; a < A; a++) if (arcs[a].x == 0) eps_dst[arcs[a].w] = 1;
       std::vector<int4> af(arcs);
-      for (size_t a = 0; a < A; a++) if (hclg_.num_ieps[af[a].w] != 0) af[a].x |= (int)0x80000000;
+      for (size_t a = 0; a < A; a++) {
+        if (hclg_.num_ieps[af[a].w] != 0) af[a].x |= (int)0x80000000;
+        if (eps_dst[af[a].w]) af[a].x |= 0x40000000;
+      }
       hclg_dev_.arcs_f = static_cast<int4 *>(UploadBytes(af.data(), A * sizeof(int4)));
+      std::vector<uint4> nodes((size_t)S * 4, make_uint4(0u, 0u, 0u, 0u));
+      for (int s = 0; s < S; s++) {
+        const uint32_t b = hclg_.arc_begin[s], e = hclg_.arc_begin[s + 1], ne = hclg_.num_ieps[s];
+        nodes[(size_t)s * 4] = make_uint4(b, ne, e - b - ne, 0u);
+        for (uint32_t k = 0; k < 2 && b + ne + k < e; k++) {
+          const int4 &x = af[b + ne + k];
+          nodes[(size_t)s * 4 + 1 + k] = make_uint4((unsigned)x.x, (unsigned)x.y, (unsigned)x.z, (unsigned)x.w);
+        }
+      }
+      hclg_dev_.nodes = static_cast<uint4 *>(UploadBytes(nodes.data(), nodes.size() * sizeof(uint4)));
     }
     hclg_dev_.arc_src = Upload(src);
     {
@@ -795,7 +811,8 @@ std::string Model::Describe() const {
   // whether the model has changed to those kernels for good)
   os << "token_order: " << (ExactOrder() && reg_dev_.exact_ok ? "exact (the reference's running cutoff in its hash order)" : "final cutoff")
      << (ExactOrder() && !reg_dev_.exact_ok ? " (exact_token_order asked for: not applicable to this graph)" : "") << "\n";
-  os << "layer_gemm: range_retries=" << range_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0) << "\n";
+  os << "layer_gemm: range_retries=" << range_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0)
+     << " (split-fp16: |x| >= 65520, infinity and NaN are flagged and the call repeated on the exact kernels; absolute error floor 2^-25 per operand below |x| = 2^-3)\n";
   return os.str();
 }
 
@@ -1177,6 +1194,10 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   }
   int cap_pf = opts_.max_tokens_per_frame > 0 ? opts_.max_tokens_per_frame : (int)std::min<long long>(std::max(4ll * opts_.max_active, 8192ll), 0x7fffffffll);
   cap_pf = std::min(cap_pf, S);
+  // (the register-resident search behind an n-best / lattice call keeps every live state of every frame -- it has no per-frame token
+  // limit -- and DenseToTokensKernel writes them all: the utterance's slice of the token array holds S per frame whatever
+  // max_tokens_per_frame says)
+  if (sp->reg_lattice) cap_pf = S;
   const long tok_cap_l = (long)(maxT + 2) * cap_pf;
   if (tok_cap_l > 0x7fffffffL) Fail("decoder token capacity overflows; lower max_tokens_per_frame");
   sp->tok_cap = (int)tok_cap_l;
@@ -1185,14 +1206,14 @@ size_t Model::PlanSearch(int n_utts, int maxT, int nbest, float lat_scale, Searc
   sp->dopts.exact_order = ExactOrder() ? 1 : 0;
   size_t need = (size_t)n_utts * ((size_t)(maxT + 1) * 16 + (size_t)sp->max_words * 4 + 4 + 16 + 64) + 65536;      // results, counters, frame info
   if (sp->use_dense)      // dense / register-resident search: back-pointer rows, path scratch, parked token costs
-    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (size_t)(S + 4) * 4) + 4096;
+    need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)(maxT + 2) * 32 + (2 * (size_t)S + 4) * 4) + 4096;
   if (sp->reg_lattice)    // ... the cost rows, the token lists made of them, LatticeKernel's two maps
     need += (size_t)n_utts * ((size_t)(maxT + 1) * S * 4 + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4 + (size_t)S * 8) + 8192;
   if (!sp->use_dense) {                  // token-list search: per-state tables, queues, the token arrays of every frame
     need += (size_t)n_utts * ((size_t)S * (8 + 4 * 5) + (size_t)sp->tok_cap * 16 + (size_t)(maxT + 2) * 4) + 8192;
-    sp->use_hash = decoder_choice_ != 3 && DecodeHashUsable(hclg_dev_);
-    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeLiveTableSize() * (8 + 4 + 4) + (size_t)DecodeLiveGlobalTable() * 4 + (size_t)DecodeHashSlotCap() * (16 + 16) +
-                                                (size_t)kHashCandCap * 16 + (size_t)kLiveQueueCap * 2 * 20 + 4) + 16384;
+    sp->use_hash = decoder_choice_ != 3 && DecodeLiveUsable(hclg_dev_);
+    if (sp->use_hash) need += (size_t)n_utts * ((size_t)DecodeLiveTableSize() * (8 + 4) + (size_t)DecodeLiveGlobalTable() * 4 + (size_t)DecodeLiveSlotCap() * 16 +
+                                                (size_t)kHashCandCap * 8 + (size_t)kLiveQueueCap * 2 * 20 + 4) + 16384;
   }
   if (sp->want_lattice) need += sizeof(float) * (size_t)n_utts * sp->tok_cap + 4096;                                // LatticeKernel's extra_cost
   return need;
@@ -1252,26 +1273,23 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   w.tokens = arena_.AllocT<int4>((size_t)n_utts * sp->tok_cap);
   w.frame_tok_off = arena_.AllocT<int>((size_t)n_utts * (maxT + 2));
   if (sp->use_hash) {
-    // live states of a frame in an LDS table, their per-state records in slot-indexed arrays (decode_kernels.hip); the dense tables
-    // above are only touched for utterances that outgrow the table (w.redo)
-    const size_t cap = (size_t)DecodeHashSlotCap(), tab = (size_t)DecodeLiveTableSize();
+    // live states of a frame in a two-level table (LDS, then global memory: decode_live.hip); the dense tables above are only touched
+    // for utterances that outgrow it (w.redo)
+    const size_t cap = (size_t)DecodeLiveSlotCap(), tab = (size_t)DecodeLiveTableSize();
     w.h_tab = (int)tab;
     w.h_keys = arena_.AllocT<unsigned long long>((size_t)n_utts * tab);
     w.h_slot_tok = arena_.AllocT<int>((size_t)n_utts * tab);
-    w.h_stamp = arena_.AllocT<int>((size_t)n_utts * tab);
     w.h_cand_cap = kHashCandCap;
-    { const char *e = std::getenv("RS_HASH_SLOT_LIMIT"); w.h_slot_limit = e ? std::atoi(e) : DecodeHashSlotCap(); }
-    w.h_cand = arena_.AllocT<int>((size_t)n_utts * 4 * kHashCandCap);
+    { const char *e = std::getenv("RS_HASH_SLOT_LIMIT"); w.h_slot_limit = e ? std::atoi(e) : DecodeLiveSlotCap(); }      // (tests)
+    w.h_cand = arena_.AllocT<int>((size_t)n_utts * 2 * kHashCandCap);
     w.h_gtags = arena_.AllocT<unsigned>((size_t)n_utts * DecodeLiveGlobalTable());
     w.h_qcap = kLiveQueueCap;
     w.h_q4 = arena_.AllocT<int4>((size_t)n_utts * 2 * kLiveQueueCap);
     w.h_qne = arena_.AllocT<int>((size_t)n_utts * 2 * kLiveQueueCap);
-    { const char *e = std::getenv("RS_HASH_LDS_LOG"); w.h_lds_log = e ? std::atoi(e) : 0; }
-    w.h_queue = arena_.AllocT<int2>((size_t)n_utts * 2 * cap);
+    { const char *e = std::getenv("RS_HASH_LDS_LOG"); w.h_lds_log = e ? std::atoi(e) : 0; }                                 // (tests)
     w.h_comp = arena_.AllocT<int4>((size_t)n_utts * cap);
     w.redo = arena_.AllocT<int>(n_utts);
-    if (decoder_choice_ == 5) LaunchDecodeHash(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);      // RS_DECODER=hash_r4: round 3/4's kernel (A/B)
-    else LaunchDecodeLive(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
+    LaunchDecodeLive(hclg_dev_, sp->dopts, g, ll, ll_ld, w, s);
     if (sp->want_lattice) {      // LatticeKernel expects both state -> token maps empty (DecodeKernel leaves them so for the utterances it decodes)
       RS_HIP(hipMemsetAsync(w.map_a, 0xFF, sizeof(int) * (size_t)n_utts * S, s));
       RS_HIP(hipMemsetAsync(w.map_b, 0xFF, sizeof(int) * (size_t)n_utts * S, s));

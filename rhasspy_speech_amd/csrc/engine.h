@@ -277,7 +277,7 @@ struct rs_result { std::unique_ptr<rs::Result> r; };
 struct rs_stream {
   rs_model *model = nullptr;
   bool finished = false, open = false;
-  bool failed = false;             // an rs_streams_advance over this stream threw: schedule and device rows disagree, only close is allowed
+  std::atomic<bool> failed{false}; // an rs_streams_advance over this stream threw: schedule and device rows disagree, only close is allowed
   bool keep_pcm = false;           // RS_STREAM_BATCH=1: keep every sample and replay the stream as one batch at finish (cross-check path)
   std::vector<int16_t> pcm;        // samples from absolute index pcm_start on (the ones no complete frame has consumed yet)
   long pcm_start = 0, n_samples = 0;

@@ -219,7 +219,10 @@ struct HclgDev {
   const int4 *arcs;            // {pdf+1 (0 = epsilon), olabel, weight bits, nextstate}
   const int *arc_src;          // source state of each arc
   const int *arc_srcx;         // source state | (1 << 31 if the arc is an epsilon arc): one load per traceback hop
-  const int4 *arcs_f;          // arcs with bit 31 of .x set when the destination state has epsilon arcs (decode_live.hip)
+  // decode_live.hip: the arcs with two flags in .x (bit 31: the destination state has epsilon arcs; bit 30: it is the destination of
+  // an epsilon arc), and one 64-byte record per state {first arc, epsilon arcs, emitting arcs, 0}, emitting arc 0, emitting arc 1, -
+  const int4 *arcs_f;
+  const uint4 *nodes;
   const float *final_cost;     // S
 };
 struct DecodeOptsDev {
@@ -238,22 +241,21 @@ struct DecodeWork {
   float *frame_info;          // n_utts x (max_frames + 1) x 4 : {cost_offset, cur_cutoff, next_cutoff, adaptive_beam}
   int *queue_a, *queue_b;     // n_utts x S work lists for the epsilon closure
   int *in_queue;              // n_utts x S : round stamp of the state's last push onto a closure queue (token-list search)
-  // live-state-table search (HashDecodeKernel): slot-indexed arrays instead of the state-indexed ones above; null = not in use
-  unsigned long long *h_keys; // n_utts x DecodeHashTableSize() : packed (cost, arc) of the slot's state in the frame under construction
-  int *h_slot_tok, *h_stamp;  // n_utts x table size : token index of the slot / closure round of its last push
-  int *h_cand;                // n_utts x 3 x h_cand_cap : candidate records of the arc loop (arc, destination state, slot << 16 | source token)
+  // live-state-table search (LiveDecodeKernel, decode_live.hip): a slot is the position of a state's entry in the utterance's table
+  // (LDS part, then the global part); null = not in use
+  int h_tab;                  // DecodeLiveTableSize(): length of the slot-indexed arrays
+  unsigned long long *h_keys; // n_utts x h_tab : packed (cost, arc) of the states in the global part of the table (its first entries)
+  int *h_slot_tok;            // n_utts x h_tab : slot -> token index in the frame under construction, for the states the closure can reach
+  unsigned *h_gtags;          // n_utts x DecodeLiveGlobalTable() : state ids of the global part of the table
+  int *h_cand;                // n_utts x 2 x h_cand_cap : candidate records of a frame {arc | flags, slot << 16 | source token}
   int h_cand_cap;
-  int h_slot_limit;           // live states a frame may hold before the utterance is handed to DecodeKernel (<= DecodeHashSlotCap())
-  int2 *h_queue;              // n_utts x 2 x slot cap : closure work lists (state, slot)
-  int4 *h_comp;               // n_utts x slot cap : the tokens a frame expands, compacted {first emitting arc, cost, token index, out-degree}
-  int *redo;                  // n_utts : 1 = the utterance outgrew the live-state table, DecodeKernel decodes it (null: DecodeKernel decodes all)
-  // LiveDecodeKernel (decode_live.hip) on top of the above: h_keys / h_slot_tok are n_utts x h_tab, h_cand holds 16-byte records
-  int h_tab;                  // DecodeLiveTableSize()
-  unsigned *h_gtags;          // n_utts x DecodeLiveGlobalTable() : second level of the state -> slot table
+  int h_slot_limit;           // live states a frame may hold before the utterance is handed to DecodeKernel (<= DecodeLiveSlotCap())
   int4 *h_q4;                 // n_utts x 2 x h_qcap : closure work lists {slot | writer token << 16, first epsilon arc, key low, key high}
   int *h_qne;                 // n_utts x 2 x h_qcap : ... and the number of epsilon arcs of the entry's state
   int h_qcap;
-  int h_lds_log;              // > 0: use only 2^h_lds_log entries of the LDS table (tests: forces states into the second level)
+  int4 *h_comp;               // n_utts x slot cap : the frame's tokens with more than two emitting arcs {first arc left, cost bits, token index, arcs left}
+  int h_lds_log;              // > 1: use only 2^h_lds_log entries of the LDS part (tests: forces states into the global part)
+  int *redo;                  // n_utts : 1 = the utterance outgrew the live-state table, DecodeKernel decodes it (null: DecodeKernel decodes all)
   // results
   int *out_words;             // n_utts x max_words
   int *out_nwords;            // n_utts
@@ -263,16 +265,11 @@ struct DecodeWork {
 };
 void LaunchDecode(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                   const DecodeWork &w, hipStream_t s);
-// The same search with the live states of a frame in an LDS hash (see decode_kernels.hip); usable when the graph's state ids fit
-// the table's tag field.  Utterances that outgrow the table are flagged in w.redo and decoded by LaunchDecode, which the caller
-// issues behind it on the same stream.
+// The same search with the live states of a frame in a table that follows the beam, not the graph (decode_live.hip): tags and
+// recombination keys in LDS, a second level in global memory behind them.  Utterances that outgrow it (more than
+// DecodeLiveSlotCap() live states in a frame, more records than the lists hold) are flagged in w.redo and decoded by LaunchDecode,
+// which the caller issues behind it on the same stream.
 constexpr int kHashCandCap = 65536;      // candidate records per utterance and frame (the ARPA workload's largest frame: 24 k)
-bool DecodeHashUsable(const HclgDev &h);
-int DecodeHashSlotCap();      // live states per frame
-int DecodeHashTableSize();    // entries of the LDS table = length of the slot-indexed arrays
-void LaunchDecodeHash(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
-                      const DecodeWork &w, hipStream_t s);
-// Round 5's form of the same search (decode_live.hip): two-level table (LDS + global), token-parallel expansion, two workgroups per CU.
 constexpr int kLiveQueueCap = 65536;     // closure work-list entries per round
 bool DecodeLiveUsable(const HclgDev &h);
 int DecodeLiveSlotCap();

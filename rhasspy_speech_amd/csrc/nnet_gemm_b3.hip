@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
       }
     }
   };
-  float amax = 0.f;                            // largest |activation| this thread has split
+  bool over = false;                           // an activation this thread split is beyond the fp16 split's range (or not a number)
   auto store_a = [&](int stage, const f32x4 (&av)[NA], int staged_lim) __attribute__((always_inline)) {
     unsigned char *As = smem + stage * STAGE;
     if (RS_B3_ABLATE & 2) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
       const f32x4 x0 = av[h];
       const f32x4 x = f32x4{staged_lim > 0 ? x0[0] : 0.f, staged_lim > 1 ? x0[1] : 0.f, staged_lim > 2 ? x0[2] : 0.f, staged_lim > 3 ? x0[3] : 0.f};
       f16x4 p1, p2;
-      if (RS_B3_ABLATE & 16) (void)Split2(x, &p1, &p2); else amax = fmaxf(amax, Split2(x, &p1, &p2));
+      if (RS_B3_ABLATE & 16) (void)Split2(x, &p1, &p2); else over |= B3Over(Split2(x, &p1, &p2));
       *reinterpret_cast<f16x4 *>(As + a_lds[h]) = p1;
       *reinterpret_cast<f16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
     }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
-  if (amax >= kB3Overflow) *d.ovf = 1;
+  if (over) *d.ovf = 1;
   if (RS_B3_ABLATE & 4) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
 #include "nnet_b3_epilogue.inc"
 }

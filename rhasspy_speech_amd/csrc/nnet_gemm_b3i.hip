@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ s
     hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
   }
   f16x8 p1, p2;
-  if (Split2(lo, hi, &p1, &p2) >= kB3Overflow) *ovf = 1;
+  if (B3Over(Split2(lo, hi, &p1, &p2))) *ovf = 1;
   unsigned char *dst = img.base + (size_t)blk * kB3FragBytes + lane * 16;
   *reinterpret_cast<f16x8 *>(dst) = p1;
   *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;

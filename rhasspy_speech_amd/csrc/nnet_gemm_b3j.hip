@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       eb[2 * BN + c] = (epi_mode == 2 && cok) ? d.stages[1].offset[col] : 0.f;
       eb[3 * BN + c] = cok ? d.w3_inv_scale[col] : 0.f;
     }
-    float xmax = 0.f;                              // largest |value| this thread split into fp16 parts
+    bool over = false;                             // a value this thread split into fp16 parts is beyond their range (or not a number)
     dd::LdsBarrier();
     // the fused stages on four consecutive columns (tile-local column CL0 .. CL0 + 3) of one row
 #define RS_EPI4(V, CL0)                                                                                        \
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
             f32x4 lo = q[2 * ksi], hi = q[2 * ksi + 1];                                                          \
             _Pragma("unroll") for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             f16x8 p1, p2;                                                                                        \
-            xmax = fmaxf(xmax, Split2(lo, hi, &p1, &p2));                                                        \
+            over |= B3Over(Split2(lo, hi, &p1, &p2));                                                            \
             unsigned char *dst = d.out_img.base + ((size_t)(phys[I] >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (phys[I] & 31) * 16; \
             RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst), p1);                                                    \
             RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst + d.out_img.part_bytes), p2);                             \
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
       RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
 #undef RS_DIRECT
-      if (xmax >= kB3Overflow) *d.ovf = 1;
+      if (over) *d.ovf = 1;
 #ifdef RS_B3J_TRACE
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -468,7 +468,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
             for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             f16x8 p1, p2; \
-            xmax = fmaxf(xmax, Split2(lo, hi, &p1, &p2)); \
+            over |= B3Over(Split2(lo, hi, &p1, &p2)); \
             const int phys = img_phys[(SL)]; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
             if ((RS_B3J_ABLATE & 128) && p1[0] != (_Float16)12345.f) dst = nullptr; \
@@ -486,7 +486,7 @@ _Pragma("unroll") \
 #undef RS_SLAB
 #undef RS_PUT_SLAB
 #undef RS_EPI4
-    if (xmax >= kB3Overflow) *d.ovf = 1;
+    if (over) *d.ovf = 1;
   }
 }
 

@@ -233,7 +233,11 @@ void Model::StreamsDrain(StreamPool *p, float *extra) {
 // the fp16 split cannot carry, the model changes to the exact-FP32 kernels for everything that follows and this call fails.
 void Model::StreamsCheckRange() {
   DecodeContext *cx = stream_ctx_.get();
-  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0 && !exact_gemm_.exchange(true)) {
+  // (only the split-fp16 kernels raise the word, so a raised word means an advance issued on them overflowed -- whether or not a
+  // batch call has moved the model to the exact kernels in the meantime)
+  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0) {
+    *static_cast<volatile int *>(cx->gemm_ovf) = 0;
+    exact_gemm_.store(true);
     StreamsPoisonAll();        // (any of the advances in flight may be the one: their log-likelihood rows are not numbers)
     Fail("an activation exceeded the range of the split-fp16 layer GEMMs (|x| >= 65520) during a stream advance; the model now uses the "
          "exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");

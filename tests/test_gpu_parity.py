@@ -294,20 +294,13 @@ def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra
     pcms = [pcm] + [synth.synth_utterance(500 + i, n) for i, n in enumerate([48000, 9000, 33000])]
     ref = ref_model.decode_batch(pcms, nbest=5)
     monkeypatch.setenv("RS_DECODER", "hash")
-    # (limit "wide": the table form large graphs get -- state id per entry, the slot is the entry's position -- forced on this graph)
-    # ("lds4" / "wide-lds4": only 16 entries of the LDS part of the table are used, so nearly every state lives in the second level
-    # in global memory; "r4": round 3/4's kernel, kept for A/B timing)
-    for limit in (None, "40", "6", "wide", "lds4", "wide-lds4", "r4"):
+    # (limit "lds4": only 16 entries of the LDS part of the table are used, so nearly every state lives in its second level in global
+    # memory; "40" / "6": frames of more live states than that hand the utterance to the dense-table kernel on the device)
+    for limit in (None, "40", "6", "lds4"):
         monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
-        monkeypatch.delenv("RS_HASH_WIDE", raising=False)
         monkeypatch.delenv("RS_HASH_LDS_LOG", raising=False)
-        monkeypatch.setenv("RS_DECODER", "hash_r4" if limit == "r4" else "hash")
-        if limit in ("wide", "wide-lds4"):
-            monkeypatch.setenv("RS_HASH_WIDE", "1")
-        if limit in ("lds4", "wide-lds4"):
+        if limit == "lds4":
             monkeypatch.setenv("RS_HASH_LDS_LOG", "4")
-        elif limit in ("wide", "r4"):
-            pass
         elif limit is not None:
             monkeypatch.setenv("RS_HASH_SLOT_LIMIT", limit)
         got = make_model(case_cache, name, **extra)[0].decode_batch(pcms, nbest=5)
@@ -318,7 +311,6 @@ def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra
                 np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
             assert got.counters(u)[3] == ref.counters(u)[3], (limit, u)
     monkeypatch.delenv("RS_HASH_SLOT_LIMIT", raising=False)
-    monkeypatch.delenv("RS_HASH_WIDE", raising=False)
     monkeypatch.delenv("RS_HASH_LDS_LOG", raising=False)
 
 

@@ -449,7 +449,7 @@ def test_decoder_options_the_reference_asserts_on(tmp_path):
     spec = synth.tiny_spec()
     synth.write_model_dir(tmp_path / "model", spec)
     synth.make_grammar_graph(tmp_path / "graph", spec)
-    for bad in (dict(max_active=100, min_active=200), dict(beam=0.0), dict(lattice_beam=-1.0), dict(max_active=1, min_active=0)):
+    for bad in (dict(max_active=100, min_active=200), dict(beam=0.0), dict(lattice_beam=-2.0), dict(max_active=1, min_active=0)):      # (exactly -1 is RS_OPT_UNSET)
         with pytest.raises(_lib.RsError, match="min_active <= max_active"):
             _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(**bad))
     _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(max_active=200, min_active=200)).close()
