@@ -1134,6 +1134,7 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       const BufferInfo &ob = nn.bufs[op.out_buf];
       if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext)) {     // only the rows somebody reads
         gd.row_map = rm->rows;
+        gd.row_map_span128 = rm->span128;
         LaunchGemm(gd, rm->count, d_row_ivec, s);
       } else {
         LaunchGemm(gd, rows, d_row_ivec, s);
@@ -1658,14 +1659,21 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
       if ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || ob.lext > L_ || ob.rext > R_ || row_maps.Find(ob.lext, ob.rext)) continue;
       int *h2 = harena.AllocT<int>(n_utts + 1);
-      int acc = 0;
-      for (int u = 0; u < n_utts; u++) { h2[u] = acc; acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0; }
+      int acc = 0, min_len = 1 << 30;
+      for (int u = 0; u < n_utts; u++) {
+        h2[u] = acc;
+        acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0;
+        if (T[u] > 0) min_len = std::min(min_len, T[u] + ob.lext + ob.rext);
+      }
       h2[n_utts] = acc;
+      // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
+      // nobody reads: the physical rows a GEMM tile reaches over
+      const int span128 = 128 + (126 / std::max(min_len, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext));
       if (acc == 0) continue;
       int *d2 = arena_.AllocT<int>(n_utts + 1), *d_rows = arena_.AllocT<int>(acc);
       RS_HIP(hipMemcpyAsync(d2, h2, sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
       LaunchFrameRows(n_utts, n_utts, acc, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), d2, g.d_row_base, d_rows, s);
-      row_maps.maps.push_back({ob.lext, ob.rext, d_rows, acc});
+      row_maps.maps.push_back({ob.lext, ob.rext, d_rows, acc, span128});
     }
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };

@@ -103,7 +103,8 @@ struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
 // Row lists of a batch for the layers that need fewer rows than the full halo: entry (lext, rext) lists, utterance after
 // utterance, the physical rows of t in [-lext, T + rext) (kernels.h row layout).  (0, 0) = the real frames only.
 struct RowMaps {
-  struct Entry { int lext, rext; const int *rows; int count; };
+  // span128: the physical rows any 128 consecutive rows of the list reach over (GemmDev::row_map_span128), 0 = not known
+  struct Entry { int lext, rext; const int *rows; int count; int span128 = 0; };
   std::vector<Entry> maps;
   const Entry *Find(int lext, int rext) const {
     for (auto &e : maps) if (e.lext == lext && e.rext == rext) return &e;

@@ -141,6 +141,8 @@ struct GemmDev {
   ActImage out_img;    // base non-null: the result is (also) written as an operand image for the layers that consume it
   int write_f32;       // 0: nobody reads `out` as floats (every consumer takes the image): skip that store
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
+  int row_map_span128; // with a row map: an upper bound of row_map[i + 127] - row_map[i] + 1 over the list when the list is ascending (128 rows of
+                       // a tile reach over that many physical rows: GemmKernelB3J stages them as one strip), 0 = not known
 };
 // f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue
 void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s);

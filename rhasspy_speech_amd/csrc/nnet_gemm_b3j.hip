@@ -21,6 +21,12 @@
 //     Measured slower (232 vs 179 us per hidden layer): with one workgroup per CU nothing hides a tile's epilogue -- all CUs
 //     write their 129 MB of output at the same moment -- nor its pipeline fill (profiles/r02/b3j_wm2_ablate.txt).
 // Rows that do not fill whole rounds of full-height tiles run as half-height tiles of the same launch.
+// STRIP (round 5): a TDNN layer's three spliced k-steps read the SAME 16 input columns at three row offsets (nnet-tdnn-component.cc:
+// 181-213, sum over offsets of in[t + o] W_o^T).  Instead of one set of activation fragments per offset (3 x 8 DMA instructions per
+// workgroup) ONE strip of 192 rows x 16 columns (both parts; the tile's 128 rows + the offsets' span) is staged per 16-column
+// group -- 12 instructions, three per wave -- in [part][k-group][row][16 B] order, and the fragment of offset o is the same
+// ds_read_b128 pattern started o rows further down: fewer DMA INSTRUCTIONS per MFMA, which is what the loop is bound by (a wave held
+// at a global_load_lds issues no MFMA, profiles/r04/b3j_notes.txt).  Same fragments, same products in the same order: bit-identical.
 // What the ablations of the default shape say is left (profiles/r02/b3j_wm1_ablate.txt): data movement alone 118 us, matrix
 // cores alone 122 us, together 179 us.  Two workgroups per CU move 72 KiB per k-step = 56 B/clk/CU of the 64 the L2 -> CU path
 // delivers, so the loads are throughput-bound for as long as the MFMAs run; only a tile that re-uses the weights across more
@@ -94,12 +100,17 @@ __device__ unsigned long long g_b3j_trace[8192 * 6];
 #define RS_TRACE_ID() do { } while (0)
 #endif
 
-template <int WM, bool MIXED>
+template <int WM, bool MIXED, bool STRIP>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   RS_TRACE(0);
   RS_TRACE_ID();
   typedef JShape<WM> SH;
-  constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJStage = SH::kStage, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
+  static_assert(!STRIP || (WM == 1 && SH::kStages == 3), "the strip form: four waves, ring of three weight stages");
+  constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
+  // STRIP: a stage of the ring holds a k-step's weights only; behind the ring two strips (the 16-column group in use, the next one)
+  constexpr int kJStage = STRIP ? kJBBytes : SH::kStage, kBOff = STRIP ? 0 : kJABytes;
+  constexpr int kStripRows = 192, kStripBytes = kJP * 2 * kStripRows * 16;
+  constexpr unsigned kStripBase = (unsigned)SH::kStages * kJBBytes;
   constexpr int MR = kJMR, BM = 32 * kJRowBlocks, BN = kB3BN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,14 +184,47 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   // pending" around the loop's back edge and drains vmcnt at the first use in EVERY iteration (seen in the ISA).
   __asm__ volatile("" : "+v"(grow), "+v"(seg_rowoff_v), "+v"(seg_ks0_v), "+v"(seg_nks_v), "+v"(seg_base_lo), "+v"(seg_base_hi), "+v"(seg_part_lo),
                    "+v"(seg_part_hi), "+v"(seg_inks_v), "+v"(seg_guard_v));
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  // STRIP: this wave's share of a strip is (part wave >> 1, k-group wave & 1): three instructions of 64 rows.  Per-lane source
+  // addresses for the segment's first k-step; strip row r = image row of (tile row 0 + smallest offset) + r, clamped to the image.
+  unsigned long long sp0 = 0, sp1 = 0, sp2 = 0;
+  int a_row[kJMR] = {0, 0, 0, 0};
+  int sh1 = 0, sh2 = 0;                                  // byte shift of the second / third offset's fragments inside the strip
+  if constexpr (STRIP) {
+    const ActImage im = d.segs[0].img;
+    const int r0 = d.segs[0].row_off, max_phys = (int)(im.part_bytes / ((size_t)im.nks * kB3FragBytes)) * 32 - 1;
+    const unsigned char *b0 = im.base + (size_t)(wave >> 1) * im.part_bytes + (size_t)(d.segs[0].col0 / kB3KS) * kB3FragBytes + (wave & 1) * 512;
+    const int p0 = d.row_map ? d.row_map[row0] : row0;       // physical row of the tile's first row: strip row r = physical row p0 + r0 + r
+    auto at = [&](int j) {
+      int phys = p0 + r0 + j * 64 + lane + im.guard;
+      phys = phys < 0 ? 0 : (phys > max_phys ? max_phys : phys);
+      return (unsigned long long)(uintptr_t)(b0 + (size_t)(phys >> 5) * im.nks * kB3FragBytes + (phys & 31) * 16);
+    };
+    sp0 = at(0); sp1 = at(1); sp2 = at(2);
+#pragma unroll
+    for (int i = 0; i < MR; i++) {      // strip row (x 16 bytes) of this lane's row of row block i: rows of a tile are not consecutive under a row map
+      const int gr = row0 + (wm * mr_eff + i) * 32 + (lane & 31);
+      const bool ok = gr < rows && i < mr_eff;
+      a_row[i] = ok ? ((d.row_map ? d.row_map[gr] : gr) - p0) * 16 : 0;
+    }
+    sh1 = __builtin_amdgcn_readfirstlane((d.segs[1].row_off - r0) * 16);
+    sh2 = __builtin_amdgcn_readfirstlane((d.segs[2].row_off - r0) * 16);
+    __asm__ volatile("" : "+v"(sp0), "+v"(sp1), "+v"(sp2), "+s"(sh1), "+s"(sh2), "+v"(a_row[0]), "+v"(a_row[1]), "+v"(a_row[2]), "+v"(a_row[3]));
+  }
+  auto stage_strip = [&](int ks16, unsigned buf) __attribute__((always_inline)) {      // the strip of 16-column group ks16 into strip buffer buf
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + kStripBase + buf * kStripBytes + (unsigned)wave * (kStripRows * 16));
+    const unsigned long long ko = (unsigned long long)ks16 * kB3FragBytes;
+    RS_DMA16_STREAM(dst, reinterpret_cast<const unsigned char *>((uintptr_t)(sp0 + ko)));
+    RS_DMA16_STREAM(dst + 1024u, reinterpret_cast<const unsigned char *>((uintptr_t)(sp1 + ko)));
+    RS_DMA16_STREAM(dst + 2048u, reinterpret_cast<const unsigned char *>((uintptr_t)(sp2 + ko)));
+  };
   constexpr int CTW = SH::kColTilesPerWave;
   const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wave * CTW) * kJP * kB3FragBytes + lane * 16;
   const size_t wstep = (size_t)(d.n3 / 32) * kJP * kB3FragBytes;
   const bool wtile_ok = n0 / 32 + wave * CTW + CTW <= d.n3 / 32;     // (tiles past the padded width: their columns are dropped in the epilogue)
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto stage_kstep = [&](unsigned soff) __attribute__((always_inline)) {     // soff: byte offset of this k-step's stage in LDS
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + soff);
-    if (stager && !(RS_B3J_ABLATE & 2048)) {
+    if (!STRIP && stager && !(RS_B3J_ABLATE & 2048)) {
       const unsigned char *img_base = reinterpret_cast<const unsigned char *>(
           (uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_base_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_base_lo, seg)));
       const size_t part_bytes = (size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(seg_part_hi, seg) << 32) | (unsigned)__builtin_amdgcn_readlane(seg_part_lo, seg));
@@ -203,11 +247,12 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
 #pragma unroll
       for (int p = 0; p < kJP * CTW; p++) {
         const unsigned char *g = ws + p * kB3FragBytes;
-        RS_DMA16(dst + (unsigned)(kJABytes + (wave * kJP * CTW + p) * kB3FragBytes), g);
+        RS_DMA16(dst + (unsigned)(kBOff + (wave * kJP * CTW + p) * kB3FragBytes), g);
       }
       wsrc += wstep;
     }
-    if (inter) {
+    if (STRIP) {
+    } else if (inter) {
       if (++seg == nsegs) { seg = 0; ks++; }
     } else if (++ks >= __builtin_amdgcn_readlane(seg_nks_v, seg)) {
       ks = 0;
@@ -215,15 +260,18 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     }
   };
   // ---- one k-step of MFMAs from stage `sbase` (LDS byte address of the stage)
-  const unsigned a_lane = lds0 + (unsigned)(wm * mr_eff) * kB3FragBytes + lane * 16;          // + stage; + (part * row blocks + i) KiB
-  const unsigned b_lane = lds0 + kJABytes + (unsigned)(wn * 2) * kJP * kB3FragBytes + lane * 16;    // + stage; + (j * parts + part) KiB
-  auto step = [&](unsigned soff) __attribute__((always_inline)) {
-    const unsigned aa = a_lane + soff, ba = b_lane + soff;
+  // (STRIP: a fragment row is a strip row: lane l reads strip row a_row[i] / 16 + the offset's shift, of k-group l >> 5; + part * 2 * 192 rows)
+  const unsigned a_lane = STRIP ? lds0 + kStripBase + (unsigned)((lane >> 5) * kStripRows * 16)
+                                : lds0 + (unsigned)(wm * mr_eff) * kB3FragBytes + lane * 16;          // + stage; + (part * row blocks + i) KiB
+  const unsigned b_lane = lds0 + kBOff + (unsigned)(wn * 2) * kJP * kB3FragBytes + lane * 16;    // + stage; + (j * parts + part) KiB
+  auto step = [&](unsigned soff, unsigned a_off) __attribute__((always_inline)) {      // a_off (STRIP): strip buffer + the k-step's offset shift
+    const unsigned aa = a_lane + (STRIP ? a_off : soff), ba = b_lane + soff;
+    const unsigned aa_i[kJMR] = {aa + (unsigned)a_row[0], aa + (unsigned)a_row[1], aa + (unsigned)a_row[2], aa + (unsigned)a_row[3]};      // (STRIP)
     f16x8 bf[2][kJP];
     RS_DS_READ(bf[0][0], ba, 0 * 1024); RS_DS_READ(bf[1][0], ba, 2 * 1024);
     f16x8 af[kJP][MR];
     // activation fragments in the order they are used: low part first (pa = 1, 0), row blocks inside
-#define RS_A_READ(PA, I) RS_DS_READ(af[PA][I], aa, ((PA) * kJRowBlocks + (I)) * 1024)
+#define RS_A_READ(PA, I) RS_DS_READ(af[PA][I], (STRIP ? aa_i[I] : aa), (STRIP ? (PA) * 2 * kStripRows * 16 : ((PA) * kJRowBlocks + (I)) * 1024))
     RS_A_READ(1, 0);
     RS_A_READ(1, 1);
     RS_DS_READ(bf[0][1], ba, 1 * 1024); RS_DS_READ(bf[1][1], ba, 3 * 1024);
@@ -260,22 +308,32 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   // ---- pipeline: DMA of k-step t + 2 is issued in k-step t (after the barrier that says everybody is done with k-step t - 1,
   // whose stage it overwrites); before it, this wave waits for its own DMAs of k-step t, leaving those of k-step t + 1 in flight
   // (-DRS_B3J_STAGES=2: the DMA runs one k-step ahead and the wait is for everything this wave has in flight)
+  unsigned strip_cur = 0;                               // (STRIP) strip buffer of the 16-column group the loop is in
+  if (STRIP) stage_strip(0, 0u);
   stage_kstep(0u);
   if (kJAhead > 1 && nt > 1) stage_kstep((unsigned)kJStage);
   if (kJAhead > 2 && nt > 2) stage_kstep(2u * (unsigned)kJStage);
   int t = 0;
   constexpr int kOwn = SH::kDmaPerKstep, kOther = kJP * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
 #define RS_VMWAIT(N) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
-#define RS_WAIT_OWN()                                                                                          \
-  if (kJAhead > 2 && t + 2 < nt) { if (stager) RS_VMWAIT(kOwn * 2); else RS_VMWAIT(kOther * 2); }               \
+// STRIP (three stages, DMA two k-steps ahead, the loop below unrolled by three so that stage S = position of the k-step in its
+// 16-column group): what a wave issues in k-step t is the weights of k-step t + 2 (kOther instructions) and, at position 1, the strip
+// of the next group (three more).  The wait of k-step t leaves what was issued in k-step t - 1 in flight: 4 + 3 at position 2.
+#define RS_WAIT_OWN(S)                                                                                         \
+  if (STRIP) { if (t + 1 < nt) { if ((S) == 2) RS_VMWAIT(kOther + 3); else RS_VMWAIT(kOther); } else RS_VMWAIT(0); }   \
+  else if (kJAhead > 2 && t + 2 < nt) { if (stager) RS_VMWAIT(kOwn * 2); else RS_VMWAIT(kOther * 2); }          \
   else if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn); else RS_VMWAIT(kOther); }                   \
   else RS_VMWAIT(0);
 #define RS_B3J_KSTEP(S, S2)                                                                                    \
   {                                                                                                            \
-    RS_WAIT_OWN()                                                                                              \
+    RS_WAIT_OWN(S)                                                                                             \
     if (!(RS_B3J_ABLATE & 16)) __builtin_amdgcn_s_barrier();                                                   \
-    if (t + kJAhead < nt) stage_kstep((unsigned)(S2) * kJStage);                                               \
-    step((unsigned)(S) * kJStage);                                                                             \
+    if (t + kJAhead < nt) {                                                                                    \
+      stage_kstep((unsigned)(S2) * kJStage);                                                                   \
+      if (STRIP && (S) == 1) stage_strip((t + 2) / 3, strip_cur ^ 1u);                                         \
+    }                                                                                                          \
+    step((unsigned)(S) * kJStage, strip_cur * kStripBytes + (unsigned)((S) == 0 ? 0 : (S) == 1 ? sh1 : sh2));   \
+    if (STRIP && (S) == 2) strip_cur ^= 1u;                                                                    \
     t++;                                                                                                       \
   }
   static_assert(SH::kStages >= 2 && SH::kStages <= 4, "ring of two to four stages");
@@ -490,7 +548,7 @@ _Pragma("unroll") \
   }
 }
 
-template <int WM, bool MIXED>
+template <int WM, bool MIXED, bool STRIP>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
@@ -501,7 +559,7 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
@@ -511,7 +569,7 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   nfirst = MIXED ? std::min(std::abs(nfirst) / 8 * 8, nsmall / 8 * 8) : 0;
   if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 #ifdef RS_B3J_TRACE
   static int traced = 0;
   const char *tf = std::getenv("RS_B3J_TRACE_FILE");
@@ -528,6 +586,26 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
     }
   }
 #endif
+}
+
+// The strip form applies to a layer whose three segments are the same 16-column groups of ONE image at three ascending row offsets
+// no more than 64 rows apart (a TDNN layer's splice); with a row map (layers evaluated on the rows somebody reads) only when the tile's
+// rows, skipped halo rows included, still fit the strip.  RS_GEMM_B3J_STRIP=0 (tests, profiles: read per call)
+// keeps the one-fragment-set-per-offset form.
+bool JStripOk(const GemmDev &d) {
+  const char *e = std::getenv("RS_GEMM_B3J_STRIP");
+  if (e && std::atoi(e) == 0) return false;
+  if (!d.interleave || d.nsegs != 3) return false;
+  if (d.row_map && (d.row_map_span128 <= 0 || d.row_map_span128 + (d.segs[2].row_off - d.segs[0].row_off) > 192)) return false;
+  const GemmSegDev &a = d.segs[0];
+  if (!a.img.base || a.per_utt) return false;
+  for (int i = 1; i < 3; i++) {
+    const GemmSegDev &b = d.segs[i];
+    if (b.img.base != a.img.base || b.img.part_bytes != a.img.part_bytes || b.img.nks != a.img.nks || b.img.guard != a.img.guard || b.per_utt ||
+        b.col0 != a.col0 || b.ncols != a.ncols || b.row_off <= d.segs[i - 1].row_off)
+      return false;
+  }
+  return a.col0 % kB3KS == 0 && d.segs[2].row_off - a.row_off <= 64;
 }
 
 int JWaveRows() {          // RS_GEMM_B3J_WM = 1 | 2 (read per call)
@@ -572,8 +650,9 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   static const int stagger = [] { const char *e = std::getenv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
   int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
   if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
-  if (wm == 2) { if (all_big) LaunchB3J<2, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true>(d, rows, nbig, nfirst, s); }
-  else { if (all_big) LaunchB3J<1, false>(d, rows, nbig, 0, s); else LaunchB3J<1, true>(d, rows, nbig, nfirst, s); }
+  if (wm == 2) { if (all_big) LaunchB3J<2, false, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true, false>(d, rows, nbig, nfirst, s); }
+  else if (JStripOk(d)) { if (all_big) LaunchB3J<1, false, true>(d, rows, nbig, 0, s); else LaunchB3J<1, true, true>(d, rows, nbig, nfirst, s); }
+  else { if (all_big) LaunchB3J<1, false, false>(d, rows, nbig, 0, s); else LaunchB3J<1, true, false>(d, rows, nbig, nfirst, s); }
 }
 
 }  // namespace rs
