@@ -5,6 +5,10 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-strip_ab}
 mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "gemm or offline_case or streaming_case" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+# (RS_GEMM_B3J_STRIP is a measurement switch: a -DRS_TUNING build of the library in a scratch copy, csrc/env.h)
+rm -rf /tmp/rstune && mkdir -p /tmp/rstune/profiles && cp -r rhasspy_speech_amd include /tmp/rstune/ && cp -r profiles/micro /tmp/rstune/profiles/ && rm -f /tmp/rstune/rhasspy_speech_amd/csrc/*.o
+make -C /tmp/rstune/rhasspy_speech_amd/csrc -j16 EXTRA=-DRS_TUNING > $OUT/make.log 2>&1 || { tail $OUT/make.log; exit 1; }
+cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so; cp /tmp/rstune/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/librhasspy_speech_hip.so
 B="python bench.py --no-cpu-baseline --no-side-figures"
 for strip in 1 0; do
   RS_GEMM_B3J_STRIP=$strip $B --steps 300 --warmup 20 > $OUT/line_strip$strip.json 2> $OUT/line_strip$strip.err
@@ -22,3 +26,4 @@ for r in csv.DictReader(open("$f")):
         print("    %-70s calls %4s avg_us %8.1f" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1000))
 PY
 done
+cp /tmp/librs_orig.so rhasspy_speech_amd/librhasspy_speech_hip.so

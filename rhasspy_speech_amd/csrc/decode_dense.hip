@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include "env.h"
 
 #include "decode_common.h"
 
@@ -262,7 +263,7 @@ void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsD
   if (graph_in_lds) smem = with_graph;
   // RS_DENSE_NT selects the workgroup size per utterance (64 / 256 / 1024); measured on MI355X (625-state grammar graph,
   // 298 frames): 64 -> 18 us/frame, 256 -> 10 us/frame: the frame is a chain of dependent LDS reads, more lanes hide more.
-  static int nt_env = [] { const char *e = std::getenv("RS_DENSE_NT"); return e ? std::atoi(e) : 256; }();
+  static int nt_env = [] { const char *e = TuneEnv("RS_DENSE_NT"); return e ? std::atoi(e) : 256; }();
   const bool one_wave = nt_env == 64 && h.num_states <= 4096 && num_pdfs <= 2048;
   const bool big = nt_env == 1024;
   const size_t stage_min = one_wave ? 40 * 1024 : 64 * 1024;     // room to stage back-pointer rows for the traceback

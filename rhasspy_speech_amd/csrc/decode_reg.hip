@@ -19,6 +19,7 @@
 // Compiled with -ffp-contract=off.
 #include "decode_common.h"
 #include "wave_ops.h"
+#include "env.h"
 
 #include <cstdlib>
 
@@ -951,7 +952,7 @@ static const int kRegConfigs[][3] = {{512, 4, 2}, {256, 8, 4}, {512, 8, 4}, {256
 
 bool RegDecodeConfig(int num_states, int num_emitting, int num_eps, int *nt, int *ke, int *kx) {
   if (num_states > kRegMaxStates) return false;
-  static int force_nt = [] { const char *e = std::getenv("RS_REG_NT"); return e ? std::atoi(e) : 0; }();
+  static int force_nt = [] { const char *e = TuneEnv("RS_REG_NT"); return e ? std::atoi(e) : 0; }();
   for (const auto &c : kRegConfigs) {
     if (force_nt && c[0] != force_nt) continue;
     if ((long long)c[0] * c[1] >= num_emitting && (long long)c[0] * c[2] >= num_eps) { *nt = c[0]; *ke = c[1]; *kx = c[2]; return true; }
@@ -972,14 +973,14 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
   // (12 KB since the calls' stages are chained, engine.cc: 2.51 -> 2.47-2.49 ms per headline step; 4-16 KB are within 1 % of each other.
   // Round 4: 32 KB -- the 16-bit arc -> source table now sits in front of the rows, and the layer GEMM's 72 KB leave one of its
   // workgroups room beside a search whatever this is; 12 / 20 / 32 / 44 KB: search 1.26 / 1.23 / 1.20 / 1.20 ms, profiles/micro/stage_kb.sh)
-  static const size_t stage_kb = [] { const char *e = std::getenv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 32; }();
+  static const size_t stage_kb = [] { const char *e = TuneEnv("RS_DECODE_STAGE_KB"); return e ? (size_t)std::atoi(e) : 32; }();
   const size_t stage = (w.win_begin ? !any_final : f_end <= g.max_frames) ? 0 : stage_kb * 1024;
   if (smem < stage) smem = stage;
   // A batch that puts a search workgroup on (nearly) every CU shares those CUs with the GEMM workgroups of the next call: with
   // half the waves and twice the arcs per thread the search alone is 8 % slower (1.12 -> 1.21 ms for 256 x 3 s) and the step with
   // calls in flight 2.5 % faster (2.51 -> 2.45 ms together with the smaller traceback staging below).  The tables are the same --
   // arc i sits in slot i of e_tab / x_tab whatever the shape.  RS_REG_NT pins the shape chosen at load.
-  static const bool pinned = std::getenv("RS_REG_NT") != nullptr;
+  static const bool pinned = TuneEnv("RS_REG_NT") != nullptr;
   static const int num_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

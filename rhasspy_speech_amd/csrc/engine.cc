@@ -2,6 +2,7 @@
 #include "nnet3_setup.h"
 #include "srfft_plan.h"
 #include "lattice.h"
+#include "env.h"
 
 #include <algorithm>
 #include <atomic>
@@ -165,7 +166,7 @@ void Model::ResolveDecoderOptions() {
 Model::Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf,
              const rs_decode_opts &opts)
     : opts_(opts) {
-  if (const char *e = std::getenv("RS_FORCE_SPARSE_DECODER")) force_sparse_ = e[0] == '1';
+  if (const char *e = TuneEnv("RS_FORCE_SPARSE_DECODER")) force_sparse_ = e[0] == '1';
   if (const char *e = std::getenv("RS_SUBBATCHES")) max_groups_ = std::atoi(e);
   if (const char *e = std::getenv("RS_DECODER")) {
     const std::string v(e);
@@ -558,6 +559,19 @@ void Model::ToDevice() {
     mfcc_dev_.fft_num_tw = (int)(pl.tw.size() / 6);
     for (size_t i = 0; i < pl.level_begin.size(); i++) mfcc_dev_.fft_level_begin[i] = pl.level_begin[i];
     mfcc_dev_.fft_tw = Upload(pl.tw.empty() ? std::vector<float>(6, 0.f) : pl.tw);
+    {
+      bool narrow = true;
+      for (size_t l = 0; l + 1 < pl.level_begin.size(); l++) narrow = narrow && pl.level_begin[l + 1] - pl.level_begin[l] <= 64;
+      mfcc_dev_.fft_recs = nullptr;
+      if (narrow) {
+        std::vector<float> recs(pl.tasks.size() * 12, 0.f);
+        for (size_t i = 0; i < pl.tasks.size(); i++) {
+          std::memcpy(&recs[i * 12], &pl.tasks[i], 16);
+          if (pl.tasks[i].tw >= 0) std::memcpy(&recs[i * 12 + 4], &pl.tw[(size_t)pl.tasks[i].tw * 6], 24);
+        }
+        mfcc_dev_.fft_recs = static_cast<const float4 *>(UploadBytes(recs.data(), recs.size() * sizeof(float)));
+      }
+    }
     mfcc_dev_.fft_perm = Upload(pl.perm);
     mfcc_dev_.fft_kn = Upload(pl.kn);
   }
@@ -609,7 +623,7 @@ void Model::ToDevice() {
     ivec_dev_.sigma_inv_M = Upload(ie.sigma_inv_M);
     ivec_dev_.U = Upload(ie.U);
     BuildGemmPlan(lda_op_, &lda_plan_);
-    if (std::getenv("RS_LDA_ONE_RUN") == nullptr || std::atoi(std::getenv("RS_LDA_ONE_RUN")) != 0) BuildGemmPlan(lda_op1_, &lda_plan1_);
+    if (TuneEnv("RS_LDA_ONE_RUN") == nullptr || std::atoi(TuneEnv("RS_LDA_ONE_RUN")) != 0) BuildGemmPlan(lda_op1_, &lda_plan1_);
   }
   // ---- nnet
   gemm_plans_.assign(am_.nnet.ops.size(), GemmPlan());
@@ -889,12 +903,12 @@ std::unique_ptr<Result> Model::DecodeBatchHost(const int16_t *const *pcm, const 
     auto t0 = std::chrono::steady_clock::now();
     // Pageable caller buffers -> pinned staging -> HBM in spans of about 16 MB: the DMA of one span runs under the host copy of
     // the next, and nothing waits here -- the feature kernel is ordered behind the last span on the context's stream.
-    static const int64_t span = [] { const char *e = std::getenv("RS_UPLOAD_SPAN_KB"); return (int64_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) * 512; }();      // samples per span (16 MB: 2 MB spans cost the mixed workload 5 % in copy calls, one span for everything 6 % in lost overlap)
+    static const int64_t span = [] { const char *e = TuneEnv("RS_UPLOAD_SPAN_KB"); return (int64_t)(e && std::atol(e) > 0 ? std::atol(e) : 16384) * 512; }();      // samples per span (16 MB: 2 MB spans cost the mixed workload 5 % in copy calls, one span for everything 6 % in lost overlap)
     // The copies of consecutive calls are chained like the stages (engine.h: stage 2): a call's hipMemcpyAsync waits, on the
     // device, for the previous call's.  Calls that start at the same moment otherwise submit their copies at the same moment, and
     // one of them was then seen to spend 6.6-9 ms INSIDE hipMemcpyAsync (profiles/r03/soak.txt); with the copies ordered that does
     // not happen: 20 steps from a standing start 2.70 -> 2.55 ms per step on average, steady state unchanged.
-    static const bool up_chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return !e || std::atoi(e) != 0; }();
+    static const bool up_chain = [] { const char *e = TuneEnv("RS_STAGE_CHAIN"); return !e || std::atoi(e) != 0; }();
     std::unique_lock<std::mutex> up_lock;
     if (up_chain) {
       up_lock = std::unique_lock<std::mutex>(stage_mu_[2]);
@@ -966,7 +980,7 @@ Model::DecodeContext *Model::AcquireContext() {
 // GEMM workgroups off its CUs (a call that starts alone cannot meet another call's nnet stage during its own, first,
 // 0.3 ms feature stage, because that call would have to be in flight already).
 bool Model::OthersInFlight() {
-  static const bool on = [] { const char *e = std::getenv("RS_MFCC_EXCLUSIVE"); return e && std::atoi(e) != 0; }();
+  static const bool on = [] { const char *e = TuneEnv("RS_MFCC_EXCLUSIVE"); return e && std::atoi(e) != 0; }();
   return on && g_calls_in_flight.load() > 1;
 }
 void Model::ReleaseContext(DecodeContext *cx) {
@@ -1370,7 +1384,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
     size_t n_arcs = 0;
     LatArcBuffer &ab = cx.lat_arcs[gi];
     // RS_LATTICE_TRACE=1: where the tail's time goes (kernel + count, copy of the arcs to the host, grouping, the per-utterance jobs)
-    static const bool lat_trace = [] { const char *e = std::getenv("RS_LATTICE_TRACE"); return e && std::atoi(e) != 0; }();
+    static const bool lat_trace = [] { const char *e = TuneEnv("RS_LATTICE_TRACE"); return e && std::atoi(e) != 0; }();
     auto lt0 = std::chrono::steady_clock::now();
     float lt_ms[4] = {0, 0, 0, 0};
     auto lt_mark = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lt_ms[i] += std::chrono::duration<float, std::milli>(n_ - lt0).count(); lt0 = n_; };
@@ -1617,12 +1631,16 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
   // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
   const int total_frames = frame_base[n_utts];
-  static const int lds_poison = [] { const char *e = std::getenv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
+#ifdef RS_TUNING
+  static const int lds_poison = [] { const char *e = TuneEnv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
   auto poison = [&]() {
     if (!lds_poison) return;
     static unsigned *sink = [] { unsigned *p = nullptr; (void)hipMalloc((void **)&p, 64); return p; }();
-    LaunchLdsPoison(sink, s);
+    LaunchLdsPoison(sink, s);      // (profiles/micro/poison_kernels.hip)
   };
+#else
+  auto poison = []() {};
+#endif
   // The last layer and the search can be pipelined over time slabs when the search is the register-resident kernel: the
   // output GEMM of slab k+1 (MFMA-bound) runs while slab k is searched (latency-bound) on a second, high-priority stream.
   // Measured on the bench batch: 5.07 -> 4.97 ms with 3 slabs -- the search runs at half speed while it shares the CUs
@@ -1653,7 +1671,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     row_maps.maps.push_back({0, 0, d_frame_rows, total_frames});
     // the hidden layers: only as much halo as the layers after them reach (15 rows a side for the first, none for the last
     // of the zamia-like net: 5 % fewer rows over the stack than evaluating the full halo everywhere)
-    static const int trim = [] { const char *e = std::getenv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
+    static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
     for (size_t i = 0; trim && i < nn.ops.size(); i++) {
       if (nn.ops[i].kind != LayerOp::kGemm) continue;
       const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
@@ -1677,7 +1695,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     }
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
-  static const int chain = [] { const char *e = std::getenv("RS_STAGE_CHAIN"); return e ? std::atoi(e) : 1; }();
+  static const int chain = [] { const char *e = TuneEnv("RS_STAGE_CHAIN"); return e ? std::atoi(e) : 1; }();
   // (one chain per model: a single chain for all models of the process was no better on the two-model batch -- 10.75-10.96 ms
   // against 10.56-10.70 -- and its tail event would have to outlive the model that recorded it)
   std::mutex *const smu = stage_mu_;

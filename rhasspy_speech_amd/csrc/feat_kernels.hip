@@ -37,7 +37,8 @@ __device__ __forceinline__ float WaveMax(float v) {
 // tasks (srfft_plan.h) executed lane-parallel with the same float operations on the same operands, so the power
 // spectrum matches the reference to the bit instead of to its own ~1e-3 rounding noise.  This file is compiled with
 // -ffp-contract=off for that reason.
-__device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restrict__ tw, float *xr, float *xi) {
+// (tw_inline: the task's own six factors, loaded with the task -- MfccDev::fft_recs -- else they are read from tw[6 tk.w ..])
+__device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restrict__ tw, float *xr, float *xi, const float *tw_inline = nullptr) {
   const int kind = tk.x & 0xff, lg = tk.x >> 8, off = tk.y;
   if (kind == 0) {
     // srfft.cc:278-333 for one n: the four points it touches are private to this task
@@ -60,7 +61,7 @@ __device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restr
       i2 = -sqhalf * (r2 + i2);
       r2 = t2;
     } else if (tk.w >= 0) {
-      const float *w = tw + (size_t)tk.w * 6;
+      const float *w = tw_inline ? tw_inline : tw + (size_t)tk.w * 6;
       const float cn = w[0], spcn = w[1], smcn = w[2], c3n = w[3], spc3n = w[4], smc3n = w[5];
       float t2 = cn * (r1 + i1);
       float t1 = spcn * r1 + t2;
@@ -197,10 +198,33 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   }
   WaveLdsSync();
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
-  for (int L = 0; L < m.fft_num_levels; L++) {
-    if (active)
-      for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], fft_tw, xr, xi);
-    WaveLdsSync();
+  if (NFFT == 512 && m.fft_recs) {
+    // at most one task per lane and level: the record of the NEXT level (task + its twiddle factors, three 16-byte loads of one
+    // 48-byte record) is requested before the current level runs, so no level waits for a global round trip -- the task-then-twiddles
+    // pair of dependent loads per level was 14 of the frame's ~45 (profiles/r04/mfcc_notes.txt)
+    const int nl = m.fft_num_levels;
+    auto fetch = [&](int L, float4 *r) __attribute__((always_inline)) {
+      const int ti = m.fft_level_begin[L] + lane;
+      const float4 *src = m.fft_recs + (size_t)(ti < m.fft_level_begin[L + 1] ? ti : m.fft_level_begin[L]) * 3;
+      r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
+    };
+    float4 nxt[3];
+    fetch(0, nxt);
+    for (int L = 0; L < nl; L++) {
+      const float4 r0 = nxt[0], r1 = nxt[1], r2 = nxt[2];
+      if (L + 1 < nl) fetch(L + 1, nxt);
+      if (active && m.fft_level_begin[L] + lane < m.fft_level_begin[L + 1]) {
+        const float w6[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+        SrfftRunTask(make_int4(__float_as_int(r0.x), __float_as_int(r0.y), __float_as_int(r0.z), __float_as_int(r0.w)), fft_tw, xr, xi, w6);
+      }
+      WaveLdsSync();
+    }
+  } else {
+    for (int L = 0; L < m.fft_num_levels; L++) {
+      if (active)
+        for (int ti = m.fft_level_begin[L] + lane; ti < m.fft_level_begin[L + 1]; ti += RS_WAVE) SrfftRunTask(tasks[ti], fft_tw, xr, xi);
+      WaveLdsSync();
+    }
   }
   // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
   // spectrum element k of the bit-reversal pass is element perm[k] of the in-place result
@@ -453,33 +477,6 @@ void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const i
                        hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(RowGeometryKernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_utts, rows, L, row_base, ivrow_base, row_utt, row_t, row_ivec);
-}
-
-// Debug aid (RS_LDS_POISON=1): fills the LDS of every CU with a NaN pattern.  LDS is not cleared between workgroups, so a
-// kernel that reads LDS it never wrote shows up as a changed result when this runs in front of it.
-__global__ __launch_bounds__(1024) void LdsPoisonKernel(unsigned pattern, unsigned *sink) {
-  extern __shared__ unsigned poison[];
-  const int n = 160 * 1024 / 4;
-  for (int i = threadIdx.x; i < n; i += 1024) poison[i] = pattern + i;
-  __syncthreads();
-  if (poison[(threadIdx.x * 37) % n] == 1u) sink[0] = 1;      // keeps the stores alive
-}
-// Same idea for the register files (not cleared between waves either): a kernel that reads a register it never wrote
-// sees whatever the previous wave left there; this leaves NaN patterns in v4..v255 and s16..s99 of every SIMD.
-__global__ __launch_bounds__(64) void RegPoisonKernel(unsigned pattern, unsigned *sink) {
-  const unsigned p = pattern + threadIdx.x;
-  const unsigned q = __builtin_amdgcn_readfirstlane(pattern);
-  __asm__ volatile("v_mov_b32 v4, %0\n\tv_mov_b32 v5, %0\n\tv_mov_b32 v6, %0\n\tv_mov_b32 v7, %0\n\tv_mov_b32 v8, %0\n\tv_mov_b32 v9, %0\n\tv_mov_b32 v10, %0\n\tv_mov_b32 v11, %0\n\tv_mov_b32 v12, %0\n\tv_mov_b32 v13, %0\n\tv_mov_b32 v14, %0\n\tv_mov_b32 v15, %0\n\tv_mov_b32 v16, %0\n\tv_mov_b32 v17, %0\n\tv_mov_b32 v18, %0\n\tv_mov_b32 v19, %0\n\tv_mov_b32 v20, %0\n\tv_mov_b32 v21, %0\n\tv_mov_b32 v22, %0\n\tv_mov_b32 v23, %0\n\tv_mov_b32 v24, %0\n\tv_mov_b32 v25, %0\n\tv_mov_b32 v26, %0\n\tv_mov_b32 v27, %0\n\tv_mov_b32 v28, %0\n\tv_mov_b32 v29, %0\n\tv_mov_b32 v30, %0\n\tv_mov_b32 v31, %0\n\tv_mov_b32 v32, %0\n\tv_mov_b32 v33, %0\n\tv_mov_b32 v34, %0\n\tv_mov_b32 v35, %0\n\tv_mov_b32 v36, %0\n\tv_mov_b32 v37, %0\n\tv_mov_b32 v38, %0\n\tv_mov_b32 v39, %0\n\tv_mov_b32 v40, %0\n\tv_mov_b32 v41, %0\n\tv_mov_b32 v42, %0\n\tv_mov_b32 v43, %0\n\tv_mov_b32 v44, %0\n\tv_mov_b32 v45, %0\n\tv_mov_b32 v46, %0\n\tv_mov_b32 v47, %0\n\tv_mov_b32 v48, %0\n\tv_mov_b32 v49, %0\n\tv_mov_b32 v50, %0\n\tv_mov_b32 v51, %0\n\tv_mov_b32 v52, %0\n\tv_mov_b32 v53, %0\n\tv_mov_b32 v54, %0\n\tv_mov_b32 v55, %0\n\tv_mov_b32 v56, %0\n\tv_mov_b32 v57, %0\n\tv_mov_b32 v58, %0\n\tv_mov_b32 v59, %0\n\tv_mov_b32 v60, %0\n\tv_mov_b32 v61, %0\n\tv_mov_b32 v62, %0\n\tv_mov_b32 v63, %0\n\tv_mov_b32 v64, %0\n\tv_mov_b32 v65, %0\n\tv_mov_b32 v66, %0\n\tv_mov_b32 v67, %0\n\tv_mov_b32 v68, %0\n\tv_mov_b32 v69, %0\n\tv_mov_b32 v70, %0\n\tv_mov_b32 v71, %0\n\tv_mov_b32 v72, %0\n\tv_mov_b32 v73, %0\n\tv_mov_b32 v74, %0\n\tv_mov_b32 v75, %0\n\tv_mov_b32 v76, %0\n\tv_mov_b32 v77, %0\n\tv_mov_b32 v78, %0\n\tv_mov_b32 v79, %0\n\tv_mov_b32 v80, %0\n\tv_mov_b32 v81, %0\n\tv_mov_b32 v82, %0\n\tv_mov_b32 v83, %0\n\tv_mov_b32 v84, %0\n\tv_mov_b32 v85, %0\n\tv_mov_b32 v86, %0\n\tv_mov_b32 v87, %0\n\tv_mov_b32 v88, %0\n\tv_mov_b32 v89, %0\n\tv_mov_b32 v90, %0\n\tv_mov_b32 v91, %0\n\tv_mov_b32 v92, %0\n\tv_mov_b32 v93, %0\n\tv_mov_b32 v94, %0\n\tv_mov_b32 v95, %0\n\tv_mov_b32 v96, %0\n\tv_mov_b32 v97, %0\n\tv_mov_b32 v98, %0\n\tv_mov_b32 v99, %0\n\tv_mov_b32 v100, %0\n\tv_mov_b32 v101, %0\n\tv_mov_b32 v102, %0\n\tv_mov_b32 v103, %0\n\tv_mov_b32 v104, %0\n\tv_mov_b32 v105, %0\n\tv_mov_b32 v106, %0\n\tv_mov_b32 v107, %0\n\tv_mov_b32 v108, %0\n\tv_mov_b32 v109, %0\n\tv_mov_b32 v110, %0\n\tv_mov_b32 v111, %0\n\tv_mov_b32 v112, %0\n\tv_mov_b32 v113, %0\n\tv_mov_b32 v114, %0\n\tv_mov_b32 v115, %0\n\tv_mov_b32 v116, %0\n\tv_mov_b32 v117, %0\n\tv_mov_b32 v118, %0\n\tv_mov_b32 v119, %0\n\tv_mov_b32 v120, %0\n\tv_mov_b32 v121, %0\n\tv_mov_b32 v122, %0\n\tv_mov_b32 v123, %0\n\tv_mov_b32 v124, %0\n\tv_mov_b32 v125, %0\n\tv_mov_b32 v126, %0\n\tv_mov_b32 v127, %0\n\tv_mov_b32 v128, %0\n\tv_mov_b32 v129, %0\n\tv_mov_b32 v130, %0\n\tv_mov_b32 v131, %0\n\tv_mov_b32 v132, %0\n\tv_mov_b32 v133, %0\n\tv_mov_b32 v134, %0\n\tv_mov_b32 v135, %0\n\tv_mov_b32 v136, %0\n\tv_mov_b32 v137, %0\n\tv_mov_b32 v138, %0\n\tv_mov_b32 v139, %0\n\tv_mov_b32 v140, %0\n\tv_mov_b32 v141, %0\n\tv_mov_b32 v142, %0\n\tv_mov_b32 v143, %0\n\tv_mov_b32 v144, %0\n\tv_mov_b32 v145, %0\n\tv_mov_b32 v146, %0\n\tv_mov_b32 v147, %0\n\tv_mov_b32 v148, %0\n\tv_mov_b32 v149, %0\n\tv_mov_b32 v150, %0\n\tv_mov_b32 v151, %0\n\tv_mov_b32 v152, %0\n\tv_mov_b32 v153, %0\n\tv_mov_b32 v154, %0\n\tv_mov_b32 v155, %0\n\tv_mov_b32 v156, %0\n\tv_mov_b32 v157, %0\n\tv_mov_b32 v158, %0\n\tv_mov_b32 v159, %0\n\tv_mov_b32 v160, %0\n\tv_mov_b32 v161, %0\n\tv_mov_b32 v162, %0\n\tv_mov_b32 v163, %0\n\tv_mov_b32 v164, %0\n\tv_mov_b32 v165, %0\n\tv_mov_b32 v166, %0\n\tv_mov_b32 v167, %0\n\tv_mov_b32 v168, %0\n\tv_mov_b32 v169, %0\n\tv_mov_b32 v170, %0\n\tv_mov_b32 v171, %0\n\tv_mov_b32 v172, %0\n\tv_mov_b32 v173, %0\n\tv_mov_b32 v174, %0\n\tv_mov_b32 v175, %0\n\tv_mov_b32 v176, %0\n\tv_mov_b32 v177, %0\n\tv_mov_b32 v178, %0\n\tv_mov_b32 v179, %0\n\tv_mov_b32 v180, %0\n\tv_mov_b32 v181, %0\n\tv_mov_b32 v182, %0\n\tv_mov_b32 v183, %0\n\tv_mov_b32 v184, %0\n\tv_mov_b32 v185, %0\n\tv_mov_b32 v186, %0\n\tv_mov_b32 v187, %0\n\tv_mov_b32 v188, %0\n\tv_mov_b32 v189, %0\n\tv_mov_b32 v190, %0\n\tv_mov_b32 v191, %0\n\tv_mov_b32 v192, %0\n\tv_mov_b32 v193, %0\n\tv_mov_b32 v194, %0\n\tv_mov_b32 v195, %0\n\tv_mov_b32 v196, %0\n\tv_mov_b32 v197, %0\n\tv_mov_b32 v198, %0\n\tv_mov_b32 v199, %0\n\tv_mov_b32 v200, %0\n\tv_mov_b32 v201, %0\n\tv_mov_b32 v202, %0\n\tv_mov_b32 v203, %0\n\tv_mov_b32 v204, %0\n\tv_mov_b32 v205, %0\n\tv_mov_b32 v206, %0\n\tv_mov_b32 v207, %0\n\tv_mov_b32 v208, %0\n\tv_mov_b32 v209, %0\n\tv_mov_b32 v210, %0\n\tv_mov_b32 v211, %0\n\tv_mov_b32 v212, %0\n\tv_mov_b32 v213, %0\n\tv_mov_b32 v214, %0\n\tv_mov_b32 v215, %0\n\tv_mov_b32 v216, %0\n\tv_mov_b32 v217, %0\n\tv_mov_b32 v218, %0\n\tv_mov_b32 v219, %0\n\tv_mov_b32 v220, %0\n\tv_mov_b32 v221, %0\n\tv_mov_b32 v222, %0\n\tv_mov_b32 v223, %0\n\tv_mov_b32 v224, %0\n\tv_mov_b32 v225, %0\n\tv_mov_b32 v226, %0\n\tv_mov_b32 v227, %0\n\tv_mov_b32 v228, %0\n\tv_mov_b32 v229, %0\n\tv_mov_b32 v230, %0\n\tv_mov_b32 v231, %0\n\tv_mov_b32 v232, %0\n\tv_mov_b32 v233, %0\n\tv_mov_b32 v234, %0\n\tv_mov_b32 v235, %0\n\tv_mov_b32 v236, %0\n\tv_mov_b32 v237, %0\n\tv_mov_b32 v238, %0\n\tv_mov_b32 v239, %0\n\tv_mov_b32 v240, %0\n\tv_mov_b32 v241, %0\n\tv_mov_b32 v242, %0\n\tv_mov_b32 v243, %0\n\tv_mov_b32 v244, %0\n\tv_mov_b32 v245, %0\n\tv_mov_b32 v246, %0\n\tv_mov_b32 v247, %0\n\tv_mov_b32 v248, %0\n\tv_mov_b32 v249, %0\n\tv_mov_b32 v250, %0\n\tv_mov_b32 v251, %0\n\tv_mov_b32 v252, %0\n\tv_mov_b32 v253, %0\n\tv_mov_b32 v254, %0\n\tv_mov_b32 v255, %0\n\ts_mov_b32 s16, %1\n\ts_mov_b32 s17, %1\n\ts_mov_b32 s18, %1\n\ts_mov_b32 s19, %1\n\ts_mov_b32 s20, %1\n\ts_mov_b32 s21, %1\n\ts_mov_b32 s22, %1\n\ts_mov_b32 s23, %1\n\ts_mov_b32 s24, %1\n\ts_mov_b32 s25, %1\n\ts_mov_b32 s26, %1\n\ts_mov_b32 s27, %1\n\ts_mov_b32 s28, %1\n\ts_mov_b32 s29, %1\n\ts_mov_b32 s30, %1\n\ts_mov_b32 s31, %1\n\ts_mov_b32 s32, %1\n\ts_mov_b32 s33, %1\n\ts_mov_b32 s34, %1\n\ts_mov_b32 s35, %1\n\ts_mov_b32 s36, %1\n\ts_mov_b32 s37, %1\n\ts_mov_b32 s38, %1\n\ts_mov_b32 s39, %1\n\ts_mov_b32 s40, %1\n\ts_mov_b32 s41, %1\n\ts_mov_b32 s42, %1\n\ts_mov_b32 s43, %1\n\ts_mov_b32 s44, %1\n\ts_mov_b32 s45, %1\n\ts_mov_b32 s46, %1\n\ts_mov_b32 s47, %1\n\ts_mov_b32 s48, %1\n\ts_mov_b32 s49, %1\n\ts_mov_b32 s50, %1\n\ts_mov_b32 s51, %1\n\ts_mov_b32 s52, %1\n\ts_mov_b32 s53, %1\n\ts_mov_b32 s54, %1\n\ts_mov_b32 s55, %1\n\ts_mov_b32 s56, %1\n\ts_mov_b32 s57, %1\n\ts_mov_b32 s58, %1\n\ts_mov_b32 s59, %1\n\ts_mov_b32 s60, %1\n\ts_mov_b32 s61, %1\n\ts_mov_b32 s62, %1\n\ts_mov_b32 s63, %1\n\ts_mov_b32 s64, %1\n\ts_mov_b32 s65, %1\n\ts_mov_b32 s66, %1\n\ts_mov_b32 s67, %1\n\ts_mov_b32 s68, %1\n\ts_mov_b32 s69, %1\n\ts_mov_b32 s70, %1\n\ts_mov_b32 s71, %1\n\ts_mov_b32 s72, %1\n\ts_mov_b32 s73, %1\n\ts_mov_b32 s74, %1\n\ts_mov_b32 s75, %1\n\ts_mov_b32 s76, %1\n\ts_mov_b32 s77, %1\n\ts_mov_b32 s78, %1\n\ts_mov_b32 s79, %1\n\ts_mov_b32 s80, %1\n\ts_mov_b32 s81, %1\n\ts_mov_b32 s82, %1\n\ts_mov_b32 s83, %1\n\ts_mov_b32 s84, %1\n\ts_mov_b32 s85, %1\n\ts_mov_b32 s86, %1\n\ts_mov_b32 s87, %1\n\ts_mov_b32 s88, %1\n\ts_mov_b32 s89, %1\n\ts_mov_b32 s90, %1\n\ts_mov_b32 s91, %1\n\ts_mov_b32 s92, %1\n\ts_mov_b32 s93, %1\n\ts_mov_b32 s94, %1\n\ts_mov_b32 s95, %1\n\ts_mov_b32 s96, %1\n\ts_mov_b32 s97, %1\n\ts_mov_b32 s98, %1\n\ts_mov_b32 s99, %1\n\ts_nop 0" :: "v"(p), "s"(q) : "v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167","v168","v169","v170","v171","v172","v173","v174","v175","v176","v177","v178","v179","v180","v181","v182","v183","v184","v185","v186","v187","v188","v189","v190","v191","v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255", "s16","s17","s18","s19","s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","s30","s31","s32","s33","s34","s35","s36","s37","s38","s39","s40","s41","s42","s43","s44","s45","s46","s47","s48","s49","s50","s51","s52","s53","s54","s55","s56","s57","s58","s59","s60","s61","s62","s63","s64","s65","s66","s67","s68","s69","s70","s71","s72","s73","s74","s75","s76","s77","s78","s79","s80","s81","s82","s83","s84","s85","s86","s87","s88","s89","s90","s91","s92","s93","s94","s95","s96","s97","s98","s99");
-  if (p == 1u) sink[1] = 1;
-}
-void LaunchLdsPoison(unsigned *sink, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&LdsPoisonKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(LdsPoisonKernel, dim3(512), dim3(1024), 160 * 1024, s, 0x7fc00000u, sink);
-  hipLaunchKernelGGL(RegPoisonKernel, dim3(16384), dim3(64), 0, s, 0x7fc00000u, sink);
 }
 
 }  // namespace rs

@@ -21,6 +21,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include "env.h"
 
 #include "kernels.h"
 #include "wave_ops.h"
@@ -426,7 +427,7 @@ void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda
   if (use_mfma && iv.ubm_bm && iv.num_gauss <= 512 && iv.feat_dim <= 48 && iv.num_gselect <= 8) {
     const int nt = (iv.num_gauss + 15) / 16, kg = iv.ubm_kg;
     const dim3 grid((g.total_rows + 4 * kUbmRows - 1) / (4 * kUbmRows));
-    static const int ablate = [] { const char *e = std::getenv("RS_UBM_ABLATE"); return e ? std::atoi(e) : 0; }();
+    static const int ablate = [] { const char *e = TuneEnv("RS_UBM_ABLATE"); return e ? std::atoi(e) : 0; }();
 #define RS_UBM_M(N, K) hipLaunchKernelGGL((UbmPostMfmaKernel<N, K>), grid, dim3(256), 0, s, iv, g, lda_norm, ld, iv.ubm_bm, iv.ubm_bv, post_idx, post_w, ablate)
     if (kg == 1) { if (nt <= 2) RS_UBM_M(2, 1); else if (nt <= 8) RS_UBM_M(8, 1); else RS_UBM_M(32, 1); }
     else if (nt > 8 && iv.feat_dim <= 40)

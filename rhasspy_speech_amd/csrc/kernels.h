@@ -44,6 +44,10 @@ struct MfccDev {
   int fft_num_levels, fft_num_tasks, fft_num_tw;
   int fft_level_begin[16];   // task range of each level
   const float *fft_tw;       // 6 floats per twiddled butterfly
+  // the same plan as one 48-byte record per task {kind | logm << 8, off, n, tw; the task's six twiddle factors; -, -} when no level has
+  // more than 64 tasks (a 512-point window): a lane's task of the NEXT level is requested while the current one runs, and the
+  // factors come with it instead of by a second, dependent load (null: plans with wider levels)
+  const float4 *fft_recs;
   const int *fft_perm;       // padded/2: bit-reversal pass as a gather
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
   // Dither (feature-window.cc:90-98): sample i of frame t += dither[t * win + i] * dither_value, before DC removal.  The
@@ -359,6 +363,6 @@ struct LatticeWork {
 void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                         const DecodeWork &w, const LatticeWork &lw, hipStream_t s);
 
-void LaunchLdsPoison(unsigned *sink, hipStream_t s);   // debug aid, see feat_kernels.hip
+void LaunchLdsPoison(unsigned *sink, hipStream_t s);   // -DRS_TUNING builds only: profiles/micro/poison_kernels.hip
 
 }  // namespace rs

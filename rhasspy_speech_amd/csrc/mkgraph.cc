@@ -7,6 +7,7 @@
 //   Mkgraph             egs/wsj/s5/utils/mkgraph.sh:72-170
 #include <sys/stat.h>
 #include <unistd.h>
+#include "env.h"
 
 #include <algorithm>
 #include <chrono>
@@ -301,7 +302,7 @@ void Mkgraph(const std::string &lang, const std::string &model_dir, const std::s
     tm.Read(r);
   }
   MakeDirs(dir);
-  const bool timing = std::getenv("RS_MKGRAPH_TIMING") != nullptr;
+  const bool timing = TuneEnv("RS_MKGRAPH_TIMING") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what, const Fst &f) {
     if (!timing) return;

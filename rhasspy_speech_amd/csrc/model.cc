@@ -1,5 +1,6 @@
 #include "model.h"
 #include "nnet3_setup.h"
+#include "env.h"
 
 #include <algorithm>
 #include <cmath>
@@ -753,7 +754,7 @@ void Nnet::Read(KaldiReader &r, int frames_per_chunk, int extra_left_context_ini
     // written (A/B of the rounding difference; the rand() count is that of the reference either way)
     std::vector<std::string> names = component_names;
     std::vector<Component> comps = components;
-    const char *e = std::getenv("RS_NO_COLLAPSE");
+    const char *e = TuneEnv("RS_NO_COLLAPSE");
     const bool keep_layers = e && e[0] == '1';
     Nnet3SetupResult su = Nnet3Setup(cfg, keep_layers ? &names : &component_names, keep_layers ? &comps : &components, frames_per_chunk,
                                      extra_left_context_initial);

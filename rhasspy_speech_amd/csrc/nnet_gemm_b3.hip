@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include "env.h"
 
 #include "nnet_b3_common.h"
 
@@ -259,7 +260,7 @@ void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStre
 // the exact-FP32 kernel with its 128-column tiles (hidden layer 105 us for 33 GFLOP against 163 us for the 15 GFLOP of the pruned
 // output layer, profiles/r04), so e.g. the headline's 362 output columns (29 % padding in two tiles) belong here: 163 -> 85 us.
 bool GemmB3PaddingOk(int n, int n3) {
-  static const int pct = [] { const char *e = std::getenv("RS_GEMM_B3_PAD"); return e ? std::atoi(e) : 45; }();
+  static const int pct = [] { const char *e = TuneEnv("RS_GEMM_B3_PAD"); return e ? std::atoi(e) : 45; }();
   return (long)(n3 - n) * 100 <= (long)n3 * pct;
 }
 
@@ -278,8 +279,8 @@ void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
-  static int mixed = [] { const char *e = std::getenv("RS_GEMM_B3_MIXED"); return e ? std::atoi(e) : 1; }();
+  static int force_mr = [] { const char *e = TuneEnv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
+  static int mixed = [] { const char *e = TuneEnv("RS_GEMM_B3_MIXED"); return e ? std::atoi(e) : 1; }();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   if (d.exclusive) {
     // one 512-thread workgroup per CU; tile height 128 or 192 rows, whichever leaves the fuller last round

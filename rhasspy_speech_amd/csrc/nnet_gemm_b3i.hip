@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include "env.h"
 
 #include "nnet_b3_common.h"
 
@@ -268,13 +269,13 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  static int force_mr = [] { const char *e = std::getenv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
+  static int force_mr = [] { const char *e = TuneEnv("RS_GEMM_B3_MR"); return e ? std::atoi(e) : 0; }();
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
   const long slots = std::max(2L * num_cu / std::max(d.share, 1), 8L);      // two workgroups per CU; the device may be shared
   // Tile height: rounds of `slots` tiles, each as long as the tile is tall, weighted by the per-row cost of the height
   // (a 64-row tile streams the weights for half as many rows as a 128-row one)
   auto rounds = [&](long row_tiles) { return (double)((row_tiles * ncol + slots - 1) / slots); };
-  static const double eff64 = [] { const char *e = std::getenv("RS_GEMM_B3I_EFF64"); return e ? std::atof(e) : 1.3; }();
+  static const double eff64 = [] { const char *e = TuneEnv("RS_GEMM_B3I_EFF64"); return e ? std::atof(e) : 1.3; }();
   // whole rounds of 128-row tiles, the remaining rows as 64-row tiles of the same launch
   const long full = (long)(rows / 128) * ncol / slots * slots / ncol;
   const long rest = rows - full * 128;
@@ -282,7 +283,7 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   const double c_128 = rounds((rows + 127) / 128) * 128, c_64 = rounds((rows + 63) / 64) * 64 * eff64;
   // a launch of less than one round (a stream advance: a few thousand rows) is as long as ONE tile is: the 32-row tile spreads it
   // over four times as many CUs as the 128-row one, each streaming the same weights for a quarter of the rows
-  static const double eff32 = [] { const char *e = std::getenv("RS_GEMM_B3I_EFF32"); return e ? std::atof(e) : 1.7; }();
+  static const double eff32 = [] { const char *e = TuneEnv("RS_GEMM_B3I_EFF32"); return e ? std::atof(e) : 1.7; }();
   const double c_32 = rounds((rows + 31) / 32) * 32 * eff32;
   int mr = 4, nbig = (rows + 127) / 128;
   bool mixed = false;
@@ -292,7 +293,7 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   if (force_mr == 1) { mr = 1; nbig = (rows + 31) / 32; mixed = false; }
   if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
   if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
-  static const int kps1 = [] { const char *e = std::getenv("RS_GEMM_B3I_KPS"); return e ? std::atoi(e) : 8; }();
+  static const int kps1 = [] { const char *e = TuneEnv("RS_GEMM_B3I_KPS"); return e ? std::atoi(e) : 8; }();
   if (mr == 1 && kps1 == 8) LaunchB3I<1, false, 8>(d, rows, nbig, s);
   else if (mr == 1 && kps1 == 4) LaunchB3I<1, false, 4>(d, rows, nbig, s);
   else if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);

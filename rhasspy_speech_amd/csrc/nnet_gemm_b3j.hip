@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
+#include "env.h"
 
 #include "nnet_b3_common.h"
 
@@ -555,7 +556,7 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
   constexpr size_t smem0 = ring > ctile ? ring : ctile;
   // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
-  static const bool one_per_cu = [] { const char *e = std::getenv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
+  static const bool one_per_cu = [] { const char *e = TuneEnv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
   const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
@@ -572,8 +573,8 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 #ifdef RS_B3J_TRACE
   static int traced = 0;
-  const char *tf = std::getenv("RS_B3J_TRACE_FILE");
-  static const int trace_at = [] { const char *e = std::getenv("RS_B3J_TRACE_AT"); return e ? std::atoi(e) : 40; }();
+  const char *tf = TuneEnv("RS_B3J_TRACE_FILE");
+  static const int trace_at = [] { const char *e = TuneEnv("RS_B3J_TRACE_AT"); return e ? std::atoi(e) : 40; }();
   if (tf && d.out_img.base && !d.write_f32 && ++traced == trace_at) {       // one hidden-layer launch well after warm-up
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(8192 * 6);
@@ -593,7 +594,7 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
 // rows, skipped halo rows included, still fit the strip.  RS_GEMM_B3J_STRIP=0 (tests, profiles: read per call)
 // keeps the one-fragment-set-per-offset form.
 bool JStripOk(const GemmDev &d) {
-  const char *e = std::getenv("RS_GEMM_B3J_STRIP");
+  const char *e = TuneEnv("RS_GEMM_B3J_STRIP");
   if (e && std::atoi(e) == 0) return false;
   if (!d.interleave || d.nsegs != 3) return false;
   if (d.row_map && (d.row_map_span128 <= 0 || d.row_map_span128 + (d.segs[2].row_off - d.segs[0].row_off) > 192)) return false;
@@ -647,7 +648,7 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   const long full = tiles * ncol / slots * slots / ncol;
   const bool all_big = full * bm >= rows;
   const int nbig = all_big ? (rows + bm - 1) / bm : (int)full;
-  static const int stagger = [] { const char *e = std::getenv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
+  static const int stagger = [] { const char *e = TuneEnv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
   int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
   if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
   if (wm == 2) { if (all_big) LaunchB3J<2, false, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true, false>(d, rows, nbig, nfirst, s); }

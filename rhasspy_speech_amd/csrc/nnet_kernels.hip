@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include "env.h"
 
 #include "kernels.h"
 #include "nnet_common.h"
@@ -362,7 +363,7 @@ static void LaunchGemmT(const GemmDev &d, int rows, const int *row_ivec, hipStre
   bool vec = true;
   for (int i = 0; i < d.nsegs; i++)
     vec = vec && (d.segs[i].ld & 3) == 0 && (d.segs[i].col0 & 3) == 0 && (reinterpret_cast<uintptr_t>(d.segs[i].src) & 15) == 0;
-  static int use_dma = [] { const char *e = std::getenv("RS_GEMM_DMA"); return e ? std::atoi(e) : 1; }();
+  static int use_dma = [] { const char *e = TuneEnv("RS_GEMM_DMA"); return e ? std::atoi(e) : 1; }();
   if (vec && use_dma) LaunchGemmDma<MT, WM, WN>(d, rows, row_ivec, s);
   else if (vec) LaunchGemmV<MT, WM, WN, true>(d, rows, row_ivec, s);
   else LaunchGemmV<MT, WM, WN, false>(d, rows, row_ivec, s);
@@ -394,7 +395,7 @@ void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) 
     return;
   }
   double c128 = cost(128, 128), c96 = cost(96, 128), c64 = cost(64, 128);
-  static int force_bm = [] { const char *e = std::getenv("RS_GEMM_BM"); return e ? std::atoi(e) : 0; }();
+  static int force_bm = [] { const char *e = TuneEnv("RS_GEMM_BM"); return e ? std::atoi(e) : 0; }();
   if (force_bm == 128) c128 = 0; else if (force_bm == 96) c96 = 0; else if (force_bm == 64) c64 = 0;
   if (c128 <= c96 && c128 <= c64) LaunchGemmT<4, 2, 2>(d, rows, row_ivec, s);
   else if (c96 <= c64) LaunchGemmT<3, 2, 2>(d, rows, row_ivec, s);

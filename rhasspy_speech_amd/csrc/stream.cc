@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include "env.h"
 
 #include "engine.h"
 #include <cstdio>
@@ -168,7 +169,7 @@ StreamPool *Model::Pool() {
     p->tm_b[k].reset(new Timer(p->q));
     p->tm_c[k].reset(new Timer(p->qc));
   }
-  p->sync_each = EnvInt("RS_STREAM_SYNC", 0) != 0;
+  { const char *e = TuneEnv("RS_STREAM_SYNC"); p->sync_each = e && std::atoi(e) != 0; }
   auto dalloc = [&](size_t bytes) {
     void *d = nullptr;
     RS_HIP(hipMalloc(&d, std::max<size_t>(bytes, 256)));
@@ -730,7 +731,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   res->timings[6] = p->stage_ms[6] + res->timings[7];
   // RS_STREAMS_TRACE=1: where the host's time went since the last finish -- inside the advance calls, and of that waiting for the
   // advance three calls back to leave its arena set (the device is the bottleneck when that is most of it)
-  static const bool trace = [] { const char *e = std::getenv("RS_STREAMS_TRACE"); return e && std::atoi(e) != 0; }();
+  static const bool trace = [] { const char *e = TuneEnv("RS_STREAMS_TRACE"); return e && std::atoi(e) != 0; }();
   if (trace) {
     std::fprintf(stderr, "streams: %.2f ms in advance calls, %.2f ms of it waiting for the device; plan %.2f, arena + uploads %.2f, issue of stage A %.2f, B %.2f, C %.2f\n",
                  p->stage_ms[6], p->stage_ms[7], p->host_ms[0], p->host_ms[1], p->host_ms[2], p->host_ms[3], p->host_ms[4]);
