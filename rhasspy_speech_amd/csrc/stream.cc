@@ -56,9 +56,14 @@ struct StreamPool {
   std::vector<rs_stream *> open_streams;                                       // every stream that holds a slot (a device failure nobody can attribute poisons them all)
   std::unique_ptr<Timer> tm_a[kDepth], tm_b[kDepth], tm_c[kDepth];
   // device time of set `par`'s advance into the pool's totals (its done event has been waited for)
+  // (device time is SAMPLED: ten event records per advance were a fifth of an advance's issue time on the host, so only every
+  // kTimedEvery-th advance -- and every finishing one -- carries them and counts kTimedEvery-fold)
+  static constexpr int kTimedEvery = 4;
+  float time_weight[kDepth] = {};
   void Account(int par, float *extra) {
+    if (time_weight[par] == 0.f) return;
     const float ms[4] = {tm_a[par]->Ms(0, 1), tm_a[par]->Ms(1, 2) + tm_i[par]->Ms(0, 1), tm_b[par]->Ms(0, 1), tm_c[par]->Ms(0, 1)};
-    for (int j = 0; j < 4; j++) { stage_ms[j + 1] += ms[j]; if (extra) extra[j] += ms[j]; }
+    for (int j = 0; j < 4; j++) { stage_ms[j + 1] += ms[j] * time_weight[par]; if (extra) extra[j] += ms[j]; }
   }
   long n_adv = 0;
   bool sync_each = false;        // RS_STREAM_SYNC=1: wait for every advance before returning (the behaviour before the two queues)
@@ -419,7 +424,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     m_f0.push_back(pl[i].mf0);
     m_rb.push_back(m_rb.back() + tn);
     m_so.push_back(m_so.back() + cnt);
-    for (int t = 0; t < tn; t++) m_out.push_back(st.row0 + pl[i].mf0 + t);
+    { const size_t b0 = m_out.size(); m_out.resize(b0 + tn); int *po = m_out.data() + b0; const int r0 = st.row0 + pl[i].mf0; for (int t = 0; t < tn; t++) po[t] = r0 + t; }
     pcm_total += (size_t)cnt;
   }
   const int nM = (int)m_T.size(), rowsM = m_rb.back();
@@ -441,7 +446,13 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     i_T[u] = a.sb - a.sa;
     i_rb[u + 1] = i_rb[u] + i_T[u] + sl + sr;
     i_slot[u] = st.slot;
-    for (int r = 0; r < i_T[u] + sl + sr; r++) i_src.push_back(st.row0 + std::min(std::max(a.sa - sl + r, 0), std::max(a.avail - 1, 0)));
+    {
+      const int nr = i_T[u] + sl + sr, hi = std::max(a.avail - 1, 0), t_first = a.sa - sl;
+      const size_t b0 = i_src.size();
+      i_src.resize(b0 + nr);
+      int *ps = i_src.data() + b0;
+      for (int r = 0; r < nr; r++) { const int t = t_first + r; ps[r] = st.row0 + (t < 0 ? 0 : (t > hi ? hi : t)); }
+    }
   }
   const int rowsI = i_rb[nI];
   std::vector<int> s_fb((size_t)max_new_chunks * std::max(nI, 1), 0), s_fe(s_fb.size(), 0), s_or(s_fb.size(), -1), s_ac(s_fb.size(), 0);
@@ -473,18 +484,30 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     maxTn = std::max(maxTn, n_T[u]);
     n_rb[u + 1] = n_rb[u] + n_T[u] + L_ + R_;
     n_fb[u + 1] = n_fb[u] + n_T[u];
-    for (int r = 0; r < n_T[u] + L_ + R_; r++) {
-      const int t = a.t0 - L_ + r;
-      n_src.push_back(st.row0 + std::min(std::max(t, 0), std::max(a.avail - 1, 0)));
-      // the chunk whose iVector this row's Round(ivector, chunk) slot was supplied by (DecodeGroup: row_ivec)
-      const int slot_t = (t >= 0 ? t / chunk : -((-t + chunk - 1) / chunk)) * chunk;
-      // = the number of chunks j >= 1 with j * chunk + Rm <= slot_t, at most the last scheduled one (in closed form: counting
-      // them chunk by chunk was the largest item of an advance's host time late in a 30 s stream)
-      const int d = slot_t - Rm;
-      const int k = std::min(std::max(d >= 0 ? d / chunk : 0, 0), std::max(st.chunks_sched - 1, 0));
-      n_riv.push_back(st.row0 / chunk + k);
+    {
+      // per row: the pool row it is gathered from (context rows clamped to the stream's frames) and the chunk whose iVector its
+      // Round(ivector, chunk) slot was supplied by (DecodeGroup: row_ivec) = the number of chunks j >= 1 with j * chunk + Rm <= slot_t,
+      // at most the last scheduled one.  slot_t / chunk is carried along instead of divided out per row (the plan was 3.7 ms of a
+      // 24 ms step on the host).
+      const int nr = n_T[u] + L_ + R_, hi = std::max(a.avail - 1, 0), t_first = a.t0 - L_, kmax = std::max(st.chunks_sched - 1, 0), ivrow0 = st.row0 / chunk;
+      const size_t b0 = n_src.size();
+      n_src.resize(b0 + nr);
+      n_riv.resize(b0 + nr);
+      int *ps = n_src.data() + b0, *pr = n_riv.data() + b0;
+      int q = t_first >= 0 ? t_first / chunk : -((-t_first + chunk - 1) / chunk), rem = t_first - q * chunk;      // t = q * chunk + rem, 0 <= rem < chunk
+      auto k_of = [&](int qq) { const int d = qq * chunk - Rm; const int k = d >= 0 ? d / chunk : 0; return ivrow0 + (k > kmax ? kmax : k); };
+      int kv = k_of(q);
+      for (int r = 0; r < nr; r++) {
+        const int t = t_first + r;
+        ps[r] = st.row0 + (t < 0 ? 0 : (t > hi ? hi : t));
+        pr[r] = kv;
+        if (++rem == chunk) { rem = 0; kv = k_of(++q); }
+      }
+      const size_t l0 = n_lldst.size();
+      n_lldst.resize(l0 + n_T[u]);
+      int *pd = n_lldst.data() + l0;
+      for (int t = 0; t < n_T[u]; t++) pd[t] = st.row0 + a.t0 + t;
     }
-    for (int t = a.t0; t < a.t1; t++) n_lldst.push_back(st.row0 + t);
   }
   const int rowsN = n_rb[nN], framesN = n_fb[nN];
   // stage 5: search windows (every stream of the call: a stream that ends without new rows still needs its traceback)
@@ -547,7 +570,10 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   }
   Timer &tma = *p->tm_a[par], &tmb = *p->tm_b[par], &tmc = *p->tm_c[par], &tmi = *p->tm_i[par];
   tma.Reset(); tmb.Reset(); tmc.Reset(); tmi.Reset();
-  tma.Mark();
+  const bool timed = final || p->n_adv % StreamPool::kTimedEvery == 0;
+  p->time_weight[par] = final ? 1.f : (timed ? (float)StreamPool::kTimedEvery : 0.f);
+#define TM_MARK(t) do { if (timed) (t).Mark(); } while (0)
+  TM_MARK(tma);
   // ---------------------------------------------------------------- 1. MFCC
   HOST_MARK(1);
   if (nM > 0) {
@@ -565,7 +591,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     if (has_iv) LaunchOnlineCmvn(cmvn_iv_dev_, gc, p->raw, p->cm, ld_c, qa, D(o_ctb), p->cmvn_iv, D(o_cslot));
     if (fc_.use_cmvn) LaunchOnlineCmvn(cmvn_nnet_dev_, gc, p->raw, p->nn_in, ld_c, qa, D(o_ctb), p->cmvn_nn, D(o_cslot));
   }
-  tma.Mark();
+  TM_MARK(tma);
   // ---------------------------------------------------------------- 3. iVectors of the new chunks
   auto falloc = [&](int rows, int ld) { return arena.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   if (nI > 0) {
@@ -586,7 +612,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     // the estimator's steps on their own queue, behind the posteriors
     RS_HIP(hipEventRecord(p->ev_f[par], qa));
     RS_HIP(hipStreamWaitEvent(qi, p->ev_f[par], 0));
-    tmi.Mark();
+    TM_MARK(tmi);
     double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
     double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
     double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
@@ -605,9 +631,9 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     }
     CopyRowsSet out_set{{{linear, p->lin, 2L * Di, 2 * Di}, {quad, p->quad, 2L * usz, 2 * usz}, {numf, p->numf, 2, 2}, {x, p->x, 2L * Di, 2 * Di}}, 4};
     LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qi);
-    tmi.Mark();
+    TM_MARK(tmi);
   }
-  tma.Mark();
+  TM_MARK(tma);
   // the acoustic model waits for both: the features (qa) and, where there is an extractor, the iVectors (qi, itself behind qa)
   RS_HIP(hipEventRecord(p->ev_a[par], qa));
   RS_HIP(hipStreamWaitEvent(q, p->ev_a[par], 0));
@@ -615,7 +641,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     RS_HIP(hipEventRecord(p->ev_i[par], qi));
     RS_HIP(hipStreamWaitEvent(q, p->ev_i[par], 0));
   }
-  tmb.Mark();
+  TM_MARK(tmb);
   // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context)
   HOST_MARK(2);
   if (nN > 0) {
@@ -630,12 +656,12 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, row_maps, 1, 0, nn.ops.size(), q, &imgs);
     LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
   }
-  tmb.Mark();
+  TM_MARK(tmb);
   // ---------------------------------------------------------------- 5. search (its own queue: the next advance's acoustic model does not wait for it)
   HOST_MARK(3);
   RS_HIP(hipEventRecord(p->ev_b[par], q));
   RS_HIP(hipStreamWaitEvent(qc, p->ev_b[par], 0));
-  tmc.Mark();
+  TM_MARK(tmc);
   BatchGeom gd;
   gd.n_utts = n; gd.max_frames = maxT; gd.d_num_frames = D(o_dT); gd.d_row_base = D(o_drb);
   if (final) AllocSearch(&sp, arena, qc, /*pooled_frames=*/reg_windows);
@@ -654,7 +680,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   } else if (final) {
     LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, qc);
   }
-  tmc.Mark();
+  TM_MARK(tmc);
   // ---------------------------------------------------------------- host bookkeeping
   HOST_MARK(4);
   for (int i = 0; i < n; i++) {
