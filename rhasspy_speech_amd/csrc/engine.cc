@@ -1668,7 +1668,13 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     d_frame_rows = arena_.AllocT<int>(total_frames);
     RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
     LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
-    row_maps.maps.push_back({0, 0, d_frame_rows, total_frames});
+    {
+      // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
+      int min_len = 1 << 30;
+      for (int u = 0; u < n_utts; u++) if (T[u] > 0) min_len = std::min(min_len, T[u]);
+      const int span128 = n_slabs == 1 ? 128 + (126 / std::max(min_len, 1) + 1) * (L_ + R_) : 0;
+      row_maps.maps.push_back({0, 0, d_frame_rows, total_frames, span128});
+    }
     // the hidden layers: only as much halo as the layers after them reach (15 rows a side for the first, none for the last
     // of the zamia-like net: 5 % fewer rows over the stack than evaluating the full halo everywhere)
     static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
