@@ -1601,35 +1601,12 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   need += 64 * 256;   // alignment slack
   arena_.Reserve(need + (1u << 20), s);
   arena_.Reset();
-  // ---- upload geometry
+  // ---- geometry: ONE page-locked staging block -> one async copy, ONE launch that derives every per-row array on the device (the
+  // rows' utterance / frame / iVector row and the row lists of the layers that are evaluated on fewer rows than the full halo).
+  // Round 4 issued a copy + a launch per list: 8 + 8 of the ~25 launch boundaries in front of a call's first real kernel.
   int *d_row_ivec = nullptr;
   BatchGeom g;
   g.n_utts = n_utts; g.L = L_; g.R = R_; g.total_rows = rows; g.total_frames = frame_base[n_utts]; g.max_frames = maxT; g.guard = guard;
-  {
-    // one page-locked staging block -> one async copy; the per-row arrays are derived on the device
-    const size_t n1 = (size_t)n_utts + 1;
-    const size_t bytes = n1 * sizeof(int64_t) + 4 * n1 * sizeof(int);
-    char *hp = static_cast<char *>(harena.Alloc(bytes));
-    char *dp = static_cast<char *>(arena_.Alloc(bytes));
-    int64_t *h_so = reinterpret_cast<int64_t *>(hp);
-    int *h_T = reinterpret_cast<int *>(hp + n1 * sizeof(int64_t)), *h_rb = h_T + n1, *h_fb = h_rb + n1, *h_ib = h_fb + n1;
-    std::memcpy(h_so, sample_offsets, n1 * sizeof(int64_t));
-    std::memcpy(h_T, T.data(), sizeof(int) * n_utts);
-    h_T[n_utts] = 0;
-    std::memcpy(h_rb, row_base.data(), sizeof(int) * n1);
-    std::memcpy(h_fb, frame_base.data(), sizeof(int) * n1);
-    std::memcpy(h_ib, ivrow_base.data(), sizeof(int) * n1);
-    RS_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s));
-    int64_t *d_so = reinterpret_cast<int64_t *>(dp);
-    int *d_T = reinterpret_cast<int *>(dp + n1 * sizeof(int64_t)), *d_rb = d_T + n1, *d_fb = d_rb + n1, *d_ib = d_fb + n1;
-    int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
-    d_row_ivec = arena_.AllocT<int>(rows);
-    if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
-    LaunchRowGeometry(n_utts, rows, L_, d_rb, d_ib, d_ru, d_rt, host_row_ivec ? nullptr : d_row_ivec, s);
-    g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
-  }
-  // physical rows of the real frames (no halo), in slab-major order (slab k = frames [k * slab_len, (k+1) * slab_len) of every
-  // utterance): layers nothing downstream reads with a time offset are evaluated on these rows only
   const int total_frames = frame_base[n_utts];
 #ifdef RS_TUNING
   static const int lds_poison = [] { const char *e = TuneEnv("RS_LDS_POISON"); return e ? std::atoi(e) : 0; }();
@@ -1654,51 +1631,80 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   std::vector<int> slab_off(n_slabs + 1, 0);
   int *d_frame_rows = nullptr;
   RowMaps row_maps;
-  if (total_frames > 0) {
-    const int n_segs = n_slabs * n_utts;
-    int *h_seg = harena.AllocT<int>(n_segs + 1);
-    int acc_rows = 0;
-    for (int k = 0; k < n_slabs; k++) {
-      slab_off[k] = acc_rows;
-      for (int u = 0; u < n_utts; u++) { h_seg[k * n_utts + u] = acc_rows; acc_rows += std::min(std::max(T[u] - k * slab_len, 0), slab_len); }
-    }
-    h_seg[n_segs] = acc_rows;
-    slab_off[n_slabs] = acc_rows;
-    int *d_seg = arena_.AllocT<int>(n_segs + 1);
-    d_frame_rows = arena_.AllocT<int>(total_frames);
-    RS_HIP(hipMemcpyAsync(d_seg, h_seg, sizeof(int) * (n_segs + 1), hipMemcpyHostToDevice, s));
-    LaunchFrameRows(n_utts, n_segs, total_frames, L_, slab_len, d_seg, g.d_row_base, d_frame_rows, s);
-    {
-      // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
-      int min_len = 1 << 30;
-      for (int u = 0; u < n_utts; u++) if (T[u] > 0) min_len = std::min(min_len, T[u]);
-      const int span128 = n_slabs == 1 ? 128 + (126 / std::max(min_len, 1) + 1) * (L_ + R_) : 0;
-      row_maps.maps.push_back({0, 0, d_frame_rows, total_frames, span128});
-    }
-    // the hidden layers: only as much halo as the layers after them reach (15 rows a side for the first, none for the last
-    // of the zamia-like net: 5 % fewer rows over the stack than evaluating the full halo everywhere)
-    static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
-    for (size_t i = 0; trim && i < nn.ops.size(); i++) {
-      if (nn.ops[i].kind != LayerOp::kGemm) continue;
-      const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
-      if ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || ob.lext > L_ || ob.rext > R_ || row_maps.Find(ob.lext, ob.rext)) continue;
-      int *h2 = harena.AllocT<int>(n_utts + 1);
-      int acc = 0, min_len = 1 << 30;
-      for (int u = 0; u < n_utts; u++) {
-        h2[u] = acc;
-        acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0;
-        if (T[u] > 0) min_len = std::min(min_len, T[u] + ob.lext + ob.rext);
+  {
+    // which row lists this batch needs: the real frames in slab-major order (slab k = frames [k * slab_len, (k + 1) * slab_len) of
+    // every utterance: layers nothing downstream reads with a time offset are evaluated on these rows only), and per hidden layer
+    // only as much halo as the layers after it reach (15 rows a side for the first, none for the last of the zamia-like net:
+    // 5 % fewer rows over the stack than evaluating the full halo everywhere)
+    struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; };
+    std::vector<ListPlan> lists;
+    std::vector<int> segs;      // the lists' segment offsets, back to back
+    int min_T = 1 << 30;
+    for (int u = 0; u < n_utts; u++) if (T[u] > 0) min_T = std::min(min_T, T[u]);
+    if (total_frames > 0) {
+      ListPlan lp{0, 0, n_slabs * n_utts, total_frames, L_, slab_len, 0, segs.size()};
+      int acc_rows = 0;
+      for (int k = 0; k < n_slabs; k++) {
+        slab_off[k] = acc_rows;
+        for (int u = 0; u < n_utts; u++) { segs.push_back(acc_rows); acc_rows += std::min(std::max(T[u] - k * slab_len, 0), slab_len); }
       }
-      h2[n_utts] = acc;
-      // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
-      // nobody reads: the physical rows a GEMM tile reaches over
-      const int span128 = 128 + (126 / std::max(min_len, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext));
-      if (acc == 0) continue;
-      int *d2 = arena_.AllocT<int>(n_utts + 1), *d_rows = arena_.AllocT<int>(acc);
-      RS_HIP(hipMemcpyAsync(d2, h2, sizeof(int) * (n_utts + 1), hipMemcpyHostToDevice, s));
-      LaunchFrameRows(n_utts, n_utts, acc, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), d2, g.d_row_base, d_rows, s);
-      row_maps.maps.push_back({ob.lext, ob.rext, d_rows, acc, span128});
+      segs.push_back(acc_rows);
+      slab_off[n_slabs] = acc_rows;
+      // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
+      lp.span128 = n_slabs == 1 ? 128 + (126 / std::max(min_T, 1) + 1) * (L_ + R_) : 0;
+      lists.push_back(lp);
+      static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
+      for (size_t i = 0; trim && i < nn.ops.size(); i++) {
+        if (nn.ops[i].kind != LayerOp::kGemm) continue;
+        const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
+        if ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || ob.lext > L_ || ob.rext > R_) continue;
+        bool have = false;
+        for (auto &l : lists) have = have || (l.lext == ob.lext && l.rext == ob.rext);
+        if (have || (int)lists.size() >= BatchSetup::kMaxLists) continue;
+        ListPlan l2{ob.lext, ob.rext, n_utts, 0, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), 0, segs.size()};
+        int acc = 0;
+        for (int u = 0; u < n_utts; u++) { segs.push_back(acc); acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0; }
+        segs.push_back(acc);
+        if (acc == 0) { segs.resize(l2.seg_at); continue; }
+        l2.total = acc;
+        // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
+        // nobody reads: the physical rows a GEMM tile reaches over
+        l2.span128 = 128 + (126 / std::max(min_T + ob.lext + ob.rext, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext));
+        lists.push_back(l2);
+      }
     }
+    const size_t n1 = (size_t)n_utts + 1;
+    const size_t geo_bytes = n1 * sizeof(int64_t) + 4 * n1 * sizeof(int), bytes = geo_bytes + segs.size() * sizeof(int);
+    char *hp = static_cast<char *>(harena.Alloc(bytes));
+    char *dp = static_cast<char *>(arena_.Alloc(bytes));
+    int64_t *h_so = reinterpret_cast<int64_t *>(hp);
+    int *h_T = reinterpret_cast<int *>(hp + n1 * sizeof(int64_t)), *h_rb = h_T + n1, *h_fb = h_rb + n1, *h_ib = h_fb + n1;
+    std::memcpy(h_so, sample_offsets, n1 * sizeof(int64_t));
+    std::memcpy(h_T, T.data(), sizeof(int) * n_utts);
+    h_T[n_utts] = 0;
+    std::memcpy(h_rb, row_base.data(), sizeof(int) * n1);
+    std::memcpy(h_fb, frame_base.data(), sizeof(int) * n1);
+    std::memcpy(h_ib, ivrow_base.data(), sizeof(int) * n1);
+    if (!segs.empty()) std::memcpy(hp + geo_bytes, segs.data(), segs.size() * sizeof(int));
+    RS_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, s));
+    int64_t *d_so = reinterpret_cast<int64_t *>(dp);
+    int *d_T = reinterpret_cast<int *>(dp + n1 * sizeof(int64_t)), *d_rb = d_T + n1, *d_fb = d_rb + n1, *d_ib = d_fb + n1;
+    const int *d_segs = reinterpret_cast<const int *>(dp + geo_bytes);
+    int *d_ru = arena_.AllocT<int>(rows), *d_rt = arena_.AllocT<int>(rows);
+    d_row_ivec = arena_.AllocT<int>(rows);
+    if (host_row_ivec) RS_HIP(hipMemcpyAsync(d_row_ivec, row_ivec, sizeof(int) * rows, hipMemcpyHostToDevice, s));
+    BatchSetup bs;
+    std::memset(&bs, 0, sizeof(bs));
+    bs.n_utts = n_utts; bs.rows = rows; bs.L = L_; bs.row_base = d_rb; bs.ivrow_base = d_ib; bs.row_utt = d_ru; bs.row_t = d_rt;
+    bs.row_ivec = host_row_ivec ? nullptr : d_row_ivec;
+    for (auto &l : lists) {
+      int *out = arena_.AllocT<int>(l.total);
+      bs.lists[bs.n_lists++] = {l.n_segs, l.total, l.L_eff, l.slab_len, d_segs + l.seg_at, out};
+      row_maps.maps.push_back({l.lext, l.rext, out, l.total, l.span128});
+      if (l.lext == 0 && l.rext == 0) d_frame_rows = out;
+    }
+    LaunchBatchSetup(bs, s);
+    g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
   }
   auto falloc = [&](int ld) { return arena_.AllocT<float>(((size_t)rows + 2 * guard) * ld) + (size_t)guard * ld; };
   static const int chain = [] { const char *e = TuneEnv("RS_STAGE_CHAIN"); return e ? std::atoi(e) : 1; }();

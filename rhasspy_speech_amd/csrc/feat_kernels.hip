@@ -468,6 +468,42 @@ __global__ void FrameRowsKernel(int n_utts, int n_segs, int total, int L, int sl
   const int k = lo / n_utts, u = lo % n_utts;
   frame_rows[i] = row_base[u] + L + k * slab_len + (i - seg_off[lo]);
 }
+// RowGeometryKernel + one FrameRowsKernel per list, as block ranges of one launch
+__global__ __launch_bounds__(256) void BatchSetupKernel(BatchSetup b) {
+  int blk = blockIdx.x;
+  const int geo_blocks = (b.rows + 255) / 256;
+  if (blk < geo_blocks) {
+    const int r = blk * 256 + threadIdx.x;
+    if (r >= b.rows) return;
+    int lo = 0, hi = b.n_utts;          // largest u with row_base[u] <= r
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b.row_base[mid] <= r) lo = mid; else hi = mid; }
+    b.row_utt[r] = lo;
+    b.row_t[r] = r - b.row_base[lo] - b.L;
+    if (b.row_ivec) b.row_ivec[r] = b.ivrow_base[lo];
+    return;
+  }
+  blk -= geo_blocks;
+  for (int l = 0; l < b.n_lists; l++) {      // (block-uniform)
+    const int nb = (b.lists[l].total + 255) / 256;
+    if (blk < nb) {
+      const BatchSetup::List &ls = b.lists[l];
+      const int i = blk * 256 + threadIdx.x;
+      if (i >= ls.total) return;
+      int lo = 0, hi = ls.n_segs;          // largest segment with seg_off[seg] <= i
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls.seg_off[mid] <= i) lo = mid; else hi = mid; }
+      const int k = lo / b.n_utts, u = lo % b.n_utts;
+      ls.out[i] = b.row_base[u] + ls.L + k * ls.slab_len + (i - ls.seg_off[lo]);
+      return;
+    }
+    blk -= nb;
+  }
+}
+void LaunchBatchSetup(const BatchSetup &b, hipStream_t s) {
+  int blocks = (b.rows + 255) / 256;
+  for (int l = 0; l < b.n_lists; l++) blocks += (b.lists[l].total + 255) / 256;
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(BatchSetupKernel, dim3(blocks), dim3(256), 0, s, b);
+}
 void LaunchFrameRows(int n_utts, int n_segs, int total, int L, int slab_len, const int *seg_off, const int *row_base, int *frame_rows,
                      hipStream_t s) {
   if (total <= 0) return;

@@ -71,7 +71,7 @@ void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void
 
 // zero fill of a list of 16-byte aligned regions in one launch
 struct ZeroRegions {
-  static constexpr int kMax = 48;
+  static constexpr int kMax = 96;
   struct One { void *p; size_t bytes; } r[kMax];
   int count;
 };
@@ -83,6 +83,17 @@ void LaunchFrameRows(int n_utts, int n_segs, int total, int L, int slab_len, con
                      hipStream_t s);
 void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const int *ivrow_base, int *row_utt, int *row_t, int *row_ivec,
                        hipStream_t s);
+// The two above for a whole batch in ONE launch: the per-row geometry and up to kMaxLists row lists (a copy and a launch per list was
+// 16 of the launch boundaries in front of a decode call's first real kernel).
+struct BatchSetup {
+  static constexpr int kMaxLists = 10;
+  int n_utts, rows, L;
+  const int *row_base, *ivrow_base;
+  int *row_utt, *row_t, *row_ivec;      // row_ivec null: not written
+  struct List { int n_segs, total, L, slab_len; const int *seg_off; int *out; } lists[kMaxLists];
+  int n_lists;
+};
+void LaunchBatchSetup(const BatchSetup &b, hipStream_t s);
 
 // ---------------------------------------------------------------- online CMVN (sliding window, causal)
 struct CmvnDev {
