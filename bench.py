@@ -65,10 +65,10 @@ def nnet_flops_per_row(desc: str) -> float:
 
 def pmc_traffic(workload: str, kernel_substr: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS round
-    (profiles/collect.sh -> profiles/r04/<workload>_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KB, the doubling per
+    (profiles/collect.sh -> profiles/r05/<workload>_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KB, the doubling per
     MI355X_MICROARCH.md (128-B requests of streaming reads tallied at 64 B on gfx950).  None when no summary of this round
     is committed for the workload -- the line never carries a stale figure."""
-    path = ROOT / "profiles" / "r04" / f"{workload}_pmc.json"
+    path = ROOT / "profiles" / "r05" / f"{workload}_pmc.json"
     if not path.exists():
         return None, None
     ks = json.loads(path.read_text())["kernels"]
@@ -589,11 +589,11 @@ def main() -> None:
                          "mfma_issue_frac": 3.0 * achieved / 2500.0 if split_bf16 else achieved / 157.3,
                          "peak_note": "2.5 PFLOP/s dense fp16 / 3 MFMAs per FP32 product (MI355X_MICROARCH.md); rounds 1-3 priced 6 bf16 MFMAs per product against 417"}
             # (the search kernel the workload runs: the register-resident one on the grammar graph, the live-state-table one on the ARPA graph)
-            dtraffic, dtraffic_from = pmc_traffic(wl, "HashDecodeKernel" if wl == "arpa" else "RegDecodeKernel")
+            dtraffic, dtraffic_from = pmc_traffic(wl, "LiveDecodeKernel" if wl == "arpa" else "RegDecodeKernel")
             roof_dec = {"bound": "hbm", "achieved": dec_bytes / (stage[4] * 1e-3) / 1e9 if stage[4] > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                         "frac": dec_bytes / (stage[4] * 1e-3) / 1e9 / 8000.0 if stage[4] > 0 else 0.0, "traffic": dtraffic, "traffic_from": dtraffic_from,
                         "algorithmic_bytes": dec_bytes,
-                        "kernel": ("HashDecodeKernel" if wl == "arpa" else "RegDecodeKernel") + ": beam search (one workgroup per utterance, T sequential steps: latency-bound)", "stage_ms": float(stage[4])}
+                        "kernel": ("LiveDecodeKernel" if wl == "arpa" else "RegDecodeKernel") + ": beam search (one workgroup per utterance, T sequential steps: bound by dependent instruction chains, not by bytes)", "stage_ms": float(stage[4])}
             # The line's roofline is that of the stage that bounds the overlapped step.  On the grammar graph that is the acoustic
             # model: with calls in flight the step is the sum of the device-filling kernels (features, iVector, layer GEMMs) and the
             # search -- one persistent workgroup per utterance, T dependent frames, its graph in registers -- runs under the next

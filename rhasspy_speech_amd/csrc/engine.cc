@@ -1186,6 +1186,39 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
     LaunchPriorScale(bufp[nn.output_buf], buf_ld[nn.output_buf], rows, nn.output_dim, d_log_priors_, opts_.acoustic_scale, s);
 }
 
+// ------------------------------------------------------------------------------------------------ online iVector estimator, chunk chain
+static int IvecChainGroup(int n, int K) { return std::max(1, std::min(K, 512 / std::max(n, 1))); }      // chunks whose statistics are computed side by side
+size_t Model::IvecChunkChainBytes(const IvecDev &iv, int n, int K) {
+  const size_t P = (size_t)IvecChainGroup(n, K) * n, Di = iv.ivec_dim, usz = Di * (Di + 1) / 2;
+  return P * ((size_t)iv.num_gauss * 8 + (size_t)iv.num_gauss * iv.feat_dim * 8 + (Di + usz + 1) * 8) + IvecStatsScratchDoubles(iv, (int)P) * 8 + 4096;
+}
+void Model::IvecChunkChain(DeviceArena &arena, const BatchGeom &g, int n, int K, const float *stats_feats, int ld_l, const int *post_idx, const float *post_w,
+                           const int *d_fb, const int *d_fe, const int *d_or, const int *d_ac, double *lin, double *quad, double *numf, double *x,
+                           const int *slot, float *ivec_out, int ld_i, hipStream_t s) const {
+  if (n <= 0 || K <= 0) return;
+  const IvecDev &iv = ivec_dev_;
+  const int KB = IvecChainGroup(n, K), Di = iv.ivec_dim, usz = Di * (Di + 1) / 2;
+  const size_t Pmax = (size_t)KB * n;
+  double *gamma = arena.AllocT<double>(Pmax * iv.num_gauss), *wfeats = arena.AllocT<double>(Pmax * iv.num_gauss * iv.feat_dim);
+  double *dblock = arena.AllocT<double>(Pmax * (size_t)(Di + usz + 1));
+  double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(iv, (int)Pmax));
+  IvecDev iv0 = iv;
+  iv0.max_count = 0.f;            // the increments carry no prior rescaling: the chain kernel applies it to the running state
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    const int kb = std::min(KB, K - k0), P = kb * n;
+    const size_t o = (size_t)k0 * n;
+    BatchGeom g2 = g;
+    g2.n_utts = P;
+    // (every pseudo-utterance starts its sums itself -- a chunk's statistics are its own frames' -- so nothing clears gamma / wfeats)
+    LaunchIvecAccumulate(iv, g2, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, true, s, n);
+    double *dlin = dblock, *dquad = dlin + (size_t)P * Di, *dtot = dquad + (size_t)P * usz;
+    RS_HIP(hipMemsetAsync(dblock, 0, sizeof(double) * (size_t)P * (Di + usz + 1), s));
+    LaunchIvecStats(iv0, P, gamma, wfeats, dlin, dquad, dtot, scratch, s);
+    if (!LaunchIvecChain(iv, n, kb, dlin, dquad, dtot, lin, quad, numf, x, slot, ivec_out, ld_i, d_or + o, d_ac + o, s))
+      Fail("internal error: iVector dimension beyond the chain kernel (callers check)");
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ search
 // Which search kernel a call runs and the work buffers it needs (all from the call's arena).  Shared by the batch path
 // (DecodeGroup) and the end of a stream (stream.cc), whose log-likelihoods live in the stream pool.
@@ -1594,6 +1627,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     need += (size_t)n_utts * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 8 * 2 + (size_t)usz * 8 + 8) + (size_t)n_ivrows * ld_i * 4 + 8192 + 1024;
     need += (size_t)max_chunks * n_utts * 16 + 4096;
     need += IvecStatsScratchDoubles(ivec_dev_, n_utts) * 8 + 1024;
+    if (streaming) need += IvecChunkChainBytes(ivec_dev_, n_utts, max_chunks);
   }
   SearchPlan sp;
   need += PlanSearch(n_utts, maxT, nbest, lat_scale, &sp);
@@ -1797,12 +1831,16 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       RS_HIP(hipMemcpyAsync(d_or, orow.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
       RS_HIP(hipMemcpyAsync(d_ac, act.data(), sizeof(int) * fb.size(), hipMemcpyHostToDevice, s));
       RS_HIP(hipStreamSynchronize(s));
-      for (int k = 0; k < max_chunks; k++) {
-        const size_t o = (size_t)k * n_utts;
-        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, false, s);
-        LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
-        LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
-        LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
+      if (Di <= 128) {
+        IvecChunkChain(arena_, g, n_utts, max_chunks, stats_feats, ld_l, post_idx, post_w, d_fb, d_fe, d_or, d_ac, linear, quad, numf, x, nullptr, d_ivec, ld_i, s);
+      } else {
+        for (int k = 0; k < max_chunks; k++) {
+          const size_t o = (size_t)k * n_utts;
+          LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, d_fb + o, d_fe + o, gamma, wfeats, false, s);
+          LaunchIvecStats(ivec_dev_, n_utts, gamma, wfeats, linear, quad, numf, iv_scratch, s);
+          LaunchIvecSolve(ivec_dev_, n_utts, linear, quad, numf, x, d_ivec, ld_i, d_or + o, d_ac + o, s);
+          LaunchIvecClear(ivec_dev_, n_utts, gamma, wfeats, s);
+        }
       }
     }
   }

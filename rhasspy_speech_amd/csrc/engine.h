@@ -127,6 +127,12 @@ class Model {
   Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf, const rs_decode_opts &opts);
   ~Model();
   void ToDevice();
+  // The online iVector estimator over K chunks of n streams / utterances in four launches (ivector_kernels.hip: IvecChainKernel);
+  // d_fb / d_fe / d_or / d_ac: [K][n] frame ranges, iVector rows, "has new frames"; state rows slot[u] (null: u) of lin / quad / numf / x
+  static size_t IvecChunkChainBytes(const IvecDev &iv, int n, int K);
+  void IvecChunkChain(DeviceArena &arena, const BatchGeom &g, int n, int K, const float *stats_feats, int ld_l, const int *post_idx, const float *post_w,
+                      const int *d_fb, const int *d_fe, const int *d_or, const int *d_ac, double *lin, double *quad, double *numf, double *x, const int *slot,
+                      float *ivec_out, int ld_i, hipStream_t s) const;
   void ResolveDecoderOptions();      // opts_ := command line (rs_decode_opts) over online.conf over the reference's defaults
   std::string Describe() const;
   // streaming = true reproduces online2-cli-nnet3-decode-faster: 1024-sample ticks, one iVector per nnet chunk

@@ -487,14 +487,15 @@ constexpr int kAccNSeg = 16;         // frame segments sorted in parallel (<= wa
 __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g, const float *__restrict__ lda, int ld,
                                                          const int *__restrict__ post_idx, const float *__restrict__ post_w,
                                                          const int *frame_begin, const int *frame_end,
-                                                         float *__restrict__ gamma, double *__restrict__ wfeats, int nseg, int fresh) {
+                                                         float *__restrict__ gamma, double *__restrict__ wfeats, int nseg, int fresh, int geo_mod) {
   extern __shared__ __attribute__((aligned(16))) char acc_smem[];
   const int u = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int T = g.d_num_frames[u];
+  const int ug = geo_mod > 0 ? u % geo_mod : u;      // (several pseudo-utterances -- the chunks of a stream -- over one utterance's rows)
+  const int T = g.d_num_frames[ug];
   int t_begin = frame_begin ? frame_begin[u] : 0, t_end = frame_end ? frame_end[u] : T;
   if (t_end > T) t_end = T;
   const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
-  const size_t base = (size_t)g.d_row_base[u] + g.L;
+  const size_t base = (size_t)g.d_row_base[ug] + g.L;
   float *gm = gamma + (size_t)u * G;
   double *wf = wfeats + (size_t)u * G * D;
   // LDS carve-up
@@ -612,7 +613,7 @@ static size_t IvecAccumSmemBytes(const IvecDev &iv, int nseg) {
 
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
                           const float *post_w, const int *frame_begin, const int *frame_end, double *gamma,
-                          double *wfeats, bool fresh, hipStream_t s) {
+                          double *wfeats, bool fresh, hipStream_t s, int geo_mod) {
   if (g.n_utts == 0) return;
   // gamma is kept in float (GaussInfo::tot_weight is a BaseFloat); the buffer is sized for doubles, we use
   // its first half as floats.
@@ -625,7 +626,7 @@ void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *ld
     attr_set = true;
   }
   hipLaunchKernelGGL(IvecAccumKernel, dim3(g.n_utts), dim3(1024), smem, s, iv, g, lda, ld, post_idx, post_w, frame_begin,
-                     frame_end, reinterpret_cast<float *>(gamma), wfeats, nseg, fresh ? 1 : 0);
+                     frame_end, reinterpret_cast<float *>(gamma), wfeats, nseg, fresh ? 1 : 0, geo_mod);
 }
 
 constexpr int kIvecUB = 8;        // utterances per workgroup in the two batch products
@@ -1272,6 +1273,69 @@ __device__ __forceinline__ void BlockSumK(const double (&v)[K], double (&out)[K]
 #ifndef RS_SOLVE_ABLATE               // measurement only (profiles/micro/kernel_ablate.sh): 1 = no CG iterations, 2 = no expansion either,
 #define RS_SOLVE_ABLATE 0            // 4 = one iteration
 #endif
+// LinearCgd (matrix/optimization.cc:453-566) on the expanded matrix A (n x n in LDS), right-hand side b and start x held one
+// element per thread (tid < n); the code of IvecSolveFullKernel, shared with IvecChainKernel so that both run the same arithmetic.
+template <int NW>
+__device__ __forceinline__ double IvecCgSolve(const IvecDev &iv, const double *A, double *xs, double *ps, double (*xch)[NW][4], int &rb,
+                                              bool mine, int tid, int n, double b, double x) {
+  if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
+  if (mine) xs[tid] = x;
+  __syncthreads();
+  auto matvec = [&](const double *vec) __attribute__((always_inline)) {
+    // four accumulators over the columns c = 4 q + j, summed pairwise at the end: a single one (round 3) made a row product a
+    // chain of n dependent fp64 FMAs -- 45 us for 15 iterations of n = 100; the order of an fp64 sum is free at the 1e-4 the
+    // iVector is held to (batch and stream paths run this same kernel and stay bit-equal to each other)
+    constexpr int MB = 20;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (mine) {
+      int c = 0;
+      for (; c + MB <= n; c += MB) {
+        double a[MB], w[MB];
+#pragma unroll
+        for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + tid]; w[i] = vec[c + i]; }
+#pragma unroll
+        for (int i = 0; i < MB; i += 4) { a0 += a[i] * w[i]; a1 += a[i + 1] * w[i + 1]; a2 += a[i + 2] * w[i + 2]; a3 += a[i + 3] * w[i + 3]; }
+      }
+      for (; c < n; c++) a0 += A[(size_t)c * n + tid] * vec[c];
+    }
+    return (a0 + a1) + (a2 + a3);
+  };
+  // p0 = b - A x0 ; r0 = -p0
+  double p = b - matvec(xs), r = -p;
+  if (!mine) { p = 0.0; r = 0.0; }
+  double in1[1] = {r * r}, out1[1];
+  BlockSumK<1, NW>(in1, out1, xch, rb);
+  double r_cur = out1[0], r_recompute = r_cur;
+  const double max_error_sq = DBL_MIN, residual_factor = (double)(0.01f * 0.01f), inv_residual_factor = 1.0 / residual_factor;
+  for (int k = 0; k < n + 5 && k != ((RS_SOLVE_ABLATE & 3) ? 0 : (RS_SOLVE_ABLATE & 4) ? 1 : iv.num_cg_iters); k++) {
+    if (mine) ps[tid] = p;
+    __syncthreads();
+    const double ap = matvec(ps);
+    double in2[2] = {p * r, p * ap}, out2[2];
+    BlockSumK<2, NW>(in2, out2, xch, rb);
+    const double alpha = -out2[0] / out2[1];
+    x += alpha * p;
+    r += alpha * ap;
+    in1[0] = r * r;
+    BlockSumK<1, NW>(in1, out1, xch, rb);
+    double r_next = out1[0];
+    if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
+      if (mine) xs[tid] = x;
+      __syncthreads();
+      r = mine ? matvec(xs) - b : 0.0;
+      in1[0] = r * r;
+      BlockSumK<1, NW>(in1, out1, xch, rb);
+      r_next = out1[0];
+      r_recompute = r_next;
+    }
+    if (r_next <= max_error_sq) break;
+    const double beta = r_next / r_cur;
+    p = p * beta - r;
+    r_cur = r_next;
+  }
+  return x;
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const double *__restrict__ linear,
                                                                const double *__restrict__ quadratic, const double *__restrict__ num_frames,
@@ -1312,61 +1376,7 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
       }
     }
     const double b = mine ? linear[(size_t)u * n + tid] : 0.0;
-    if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
-    if (mine) xs[tid] = x;
-    __syncthreads();
-    auto matvec = [&](const double *vec) __attribute__((always_inline)) {
-      // four accumulators over the columns c = 4 q + j, summed pairwise at the end: a single one (round 3) made a row product a
-      // chain of n dependent fp64 FMAs -- 45 us for 15 iterations of n = 100; the order of an fp64 sum is free at the 1e-4 the
-      // iVector is held to (batch and stream paths run this same kernel and stay bit-equal to each other)
-      constexpr int MB = 20;
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      if (mine) {
-        int c = 0;
-        for (; c + MB <= n; c += MB) {
-          double a[MB], w[MB];
-#pragma unroll
-          for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + tid]; w[i] = vec[c + i]; }
-#pragma unroll
-          for (int i = 0; i < MB; i += 4) { a0 += a[i] * w[i]; a1 += a[i + 1] * w[i + 1]; a2 += a[i + 2] * w[i + 2]; a3 += a[i + 3] * w[i + 3]; }
-        }
-        for (; c < n; c++) a0 += A[(size_t)c * n + tid] * vec[c];
-      }
-      return (a0 + a1) + (a2 + a3);
-    };
-    // p0 = b - A x0 ; r0 = -p0
-    double p = b - matvec(xs), r = -p;
-    if (!mine) { p = 0.0; r = 0.0; }
-    double in1[1] = {r * r}, out1[1];
-    BlockSumK<1, NW>(in1, out1, xch, rb);
-    double r_cur = out1[0], r_recompute = r_cur;
-    const double max_error_sq = DBL_MIN, residual_factor = (double)(0.01f * 0.01f), inv_residual_factor = 1.0 / residual_factor;
-    for (int k = 0; k < n + 5 && k != ((RS_SOLVE_ABLATE & 3) ? 0 : (RS_SOLVE_ABLATE & 4) ? 1 : iv.num_cg_iters); k++) {
-      if (mine) ps[tid] = p;
-      __syncthreads();
-      const double ap = matvec(ps);
-      double in2[2] = {p * r, p * ap}, out2[2];
-      BlockSumK<2, NW>(in2, out2, xch, rb);
-      const double alpha = -out2[0] / out2[1];
-      x += alpha * p;
-      r += alpha * ap;
-      in1[0] = r * r;
-      BlockSumK<1, NW>(in1, out1, xch, rb);
-      double r_next = out1[0];
-      if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
-        if (mine) xs[tid] = x;
-        __syncthreads();
-        r = mine ? matvec(xs) - b : 0.0;
-        in1[0] = r * r;
-        BlockSumK<1, NW>(in1, out1, xch, rb);
-        r_next = out1[0];
-        r_recompute = r_next;
-      }
-      if (r_next <= max_error_sq) break;
-      const double beta = r_next / r_cur;
-      p = p * beta - r;
-      r_cur = r_next;
-    }
+    x = IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);
   } else if (solve) {
     x = (tid == 0) ? iv.prior_offset : 0.0;
   }
@@ -1376,6 +1386,108 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
     if (tid == 0) v = (float)((double)v - iv.prior_offset);   // (*feat)(0) -= PriorOffset() on the float copy
     ivec_out[(size_t)orow * ldo + tid] = v;
   }
+}
+
+// A stream's new chunks in ONE launch (round 5).  The per-chunk chain of an advance -- accumulate, two batch products, CG solve, each a
+// latency-bound launch of ~50 us on a few dozen streams, times two or three chunks -- was the busiest queue of the streams workload.
+// The statistics of every (chunk, stream) pair are now computed side by side as INCREMENTS (LaunchIvecAccumulate / LaunchIvecStats on
+// K x n pseudo-utterances that start from zero), and this kernel, a workgroup per stream, walks the stream's chunks in order:
+// AccStats' bookkeeping (ivector-extractor.cc:611-668: num_frames, the max_count prior rescaling, linear and quadratic terms += the
+// chunk's increment) on the estimator state in place, then GetIvector's warm-started CG (IvecCgSolve), then the chunk's iVector row.
+//   dlin / dquad / dtot: [K][n][.] increments (dtot = the chunk's sum of posteriors); out_row / active: [K][n] (row -1: no such chunk;
+//   active 0: no new frames since the last estimate, re-emit it); slot (null = u): the stream's row of lin / quad / numf / x.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void IvecChainKernel(IvecDev iv, int n_utts, int K, const double *__restrict__ dlin, const double *__restrict__ dquad,
+                                                           const double *__restrict__ dtot, double *__restrict__ lin, double *__restrict__ quad,
+                                                           double *__restrict__ numf, double *__restrict__ xst, const int *__restrict__ slot,
+                                                           float *__restrict__ ivec_out, int ldo, const int *__restrict__ out_row,
+                                                           const int *__restrict__ active) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ double xch[2][NW][4];
+  int rb = 0;
+  const int u = blockIdx.x, tid = threadIdx.x, n = iv.ivec_dim, usz = n * (n + 1) / 2;
+  const size_t sl = slot ? (size_t)slot[u] : (size_t)u;
+  double *A = reinterpret_cast<double *>(smem_raw);        // n x n, symmetric
+  double *xs = A + (size_t)n * n, *ps = xs + n;
+  const bool mine = tid < n;
+  double *qu = quad + sl * usz, *li = lin + sl * n;
+  double nf = numf[sl];                                    // (every thread carries the same value)
+  double x = mine ? xst[sl * n + tid] : 0.0;
+  bool touched = false;
+  for (int k = 0; k < K; k++) {
+    const size_t p = (size_t)k * n_utts + u;
+    const int orow = out_row[p];
+    if (orow < 0) continue;                                // (workgroup-uniform) this stream has no chunk at this step
+    const bool act = active[p] != 0;
+    if (act) {
+      // AccStats: num_frames, the prior rescaling step, the terms
+      const double tot = dtot[p], newn = nf + tot;
+      double ch = 0.0;
+      if (iv.max_count > 0.0f) {
+        const double mc = (double)iv.max_count;
+        ch = (newn > mc ? newn : mc) / mc - (nf > mc ? nf : mc) / mc;
+      }
+      nf = newn;
+      __syncthreads();                                     // (the previous chunk's solve is done with A)
+      constexpr int EB = 10;
+      const double *dq = dquad + p * usz;
+      for (int k0 = tid; k0 < usz; k0 += 64 * NW * EB) {
+        double v[EB], d[EB];
+#pragma unroll
+        for (int j = 0; j < EB; j++) { const int e = k0 + j * 64 * NW; v[j] = e < usz ? qu[e] : 0.0; d[j] = e < usz ? dq[e] : 0.0; }
+#pragma unroll
+        for (int j = 0; j < EB; j++) {
+          const int e = k0 + j * 64 * NW;
+          if (e >= usz) continue;
+          int r = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+          while ((r + 1) * (r + 2) / 2 <= e) r++;
+          while (r * (r + 1) / 2 > e) r--;
+          const int cc = e - r * (r + 1) / 2;
+          double val = v[j] + d[j];
+          if (cc == r && ch != 0.0) val += ch;             // quadratic_term_.AddToDiag(prior_scale_change)
+          qu[e] = val;
+          A[(size_t)r * n + cc] = val;
+          A[(size_t)cc * n + r] = val;
+        }
+      }
+      double b = 0.0;
+      if (mine) {
+        b = li[tid] + dlin[p * n + tid];
+        if (tid == 0 && ch != 0.0) b += iv.prior_offset * ch;      // linear_term_(0) += prior_offset_ * prior_scale_change
+        li[tid] = b;
+      }
+      touched = true;
+      if (nf > 0.0) x = IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);      // (its first barrier orders the expansion)
+      else x = (tid == 0) ? iv.prior_offset : 0.0;
+    }
+    if (mine) {
+      float v = (float)x;
+      if (tid == 0) v = (float)((double)v - iv.prior_offset);   // (*feat)(0) -= PriorOffset() on the float copy
+      ivec_out[(size_t)orow * ldo + tid] = v;
+    }
+  }
+  if (touched) {
+    if (mine) xst[sl * n + tid] = x;
+    if (tid == 0) numf[sl] = nf;
+  }
+}
+
+// -> false: the extractor is wider than the kernel's LDS matrix holds (the caller runs the chunks one LaunchIvecStats / LaunchIvecSolve at a time)
+bool LaunchIvecChain(const IvecDev &iv, int n_utts, int K, const double *dlin, const double *dquad, const double *dtot, double *lin, double *quad,
+                     double *numf, double *x, const int *slot, float *ivec_out, int ldo, const int *out_row, const int *active, hipStream_t s) {
+  const int n = iv.ivec_dim;
+  if (n > 128) return false;
+  if (n_utts == 0 || K == 0) return true;
+  const size_t smem = sizeof(double) * ((size_t)n * n + 2 * (size_t)n);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecChainKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecChainKernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  if (n <= 64) hipLaunchKernelGGL(IvecChainKernel<1>, dim3(n_utts), dim3(64), smem, s, iv, n_utts, K, dlin, dquad, dtot, lin, quad, numf, x, slot, ivec_out, ldo, out_row, active);
+  else hipLaunchKernelGGL(IvecChainKernel<4>, dim3(n_utts), dim3(256), smem, s, iv, n_utts, K, dlin, dquad, dtot, lin, quad, numf, x, slot, ivec_out, ldo, out_row, active);
+  return true;
 }
 
 void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const double *quadratic,

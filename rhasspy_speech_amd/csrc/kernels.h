@@ -206,10 +206,11 @@ struct IvecDev {
 void LaunchUbmPosteriors(const IvecDev &iv, const BatchGeom &g, const float *lda_norm, int ld,
                          int *post_idx, float *post_w, hipStream_t s);
 // Accumulates, per (utterance, Gaussian): gamma (n_utts x G) and weighted feature sums (n_utts x G x D),
-// in frame order (double), for frames [frame_begin[u], frame_end[u]) of each utterance (null = all).
+// in frame order (double), for frames [frame_begin[u], frame_end[u]) of each utterance (null = all).  geo_mod > 0: g.n_utts pseudo-
+// utterances, number u over the rows of utterance u % geo_mod (the chunks of a round of streams side by side).
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
                           const float *post_w, const int *frame_begin, const int *frame_end,
-                          double *gamma, double *wfeats, bool fresh, hipStream_t s);
+                          double *gamma, double *wfeats, bool fresh, hipStream_t s, int geo_mod = 0);
 // linear (n_utts x I) += sum_g Sigma_inv_M_g^T wfeats_g ; quadratic (n_utts x I(I+1)/2) += sum_g gamma_g U_g,
 // plus the max_count prior rescaling of OnlineIvectorEstimationStats::AccStats; num_frames (n_utts, double).
 // scratch: IvecStatsScratchDoubles() doubles of workspace.
@@ -226,6 +227,12 @@ void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const 
                      const double *num_frames, double *x, float *ivec_out, int ldo, const int *out_row, const int *active,
                      hipStream_t s);
 void LaunchIvecClear(const IvecDev &iv, int n_utts, double *gamma, double *wfeats, hipStream_t s);
+// The chunks of a round of streams in one launch: dlin / dquad / dtot = the increments LaunchIvecStats leaves for K x n_utts
+// pseudo-utterances started from zero ([k * n_utts + u]); the kernel applies them in chunk order to stream u's estimator state
+// (row slot[u], or u, of lin / quad / numf / x), solves, writes iVector row out_row[k * n_utts + u] (-1: no such chunk; active 0: re-emit).
+// false: ivec_dim beyond the kernel's LDS matrix -- the caller falls back to one LaunchIvecStats + LaunchIvecSolve per chunk.
+bool LaunchIvecChain(const IvecDev &iv, int n_utts, int K, const double *dlin, const double *dquad, const double *dtot, double *lin, double *quad,
+                     double *numf, double *x, const int *slot, float *ivec_out, int ldo, const int *out_row, const int *active, hipStream_t s);
 
 // ---------------------------------------------------------------- decoder
 struct HclgDev {

@@ -542,6 +542,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     need += 2 * fbytes(rowsI, ld_c) + 2 * fbytes(rowsI, ld_l) + (size_t)rowsI * nsel * 8 + 4096;
     need += (size_t)std::max(nI, 1) * ((size_t)G * 8 + (size_t)G * Dl * 8 + (size_t)Di * 16 + (size_t)usz * 8 + 64) + 8192;
     need += IvecStatsScratchDoubles(ivec_dev_, std::max(nI, 1)) * 8 + 1024;
+    need += IvecChunkChainBytes(ivec_dev_, std::max(nI, 1), std::max(max_new_chunks, 1));
   }
   need += search_bytes + (size_t)n * 64 * 8 + 64 * 256 + (1u << 20);
   arena.Reserve(need, qa);
@@ -613,24 +614,29 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     RS_HIP(hipEventRecord(p->ev_f[par], qa));
     RS_HIP(hipStreamWaitEvent(qi, p->ev_f[par], 0));
     TM_MARK(tmi);
-    double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
-    double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
-    double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
-    double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, nI));
-    // estimator state: slots -> dense, the steps, dense -> slots (one launch each way for the four arrays)
-    CopyRowsSet in_set{{{p->lin, linear, 2L * Di, 2 * Di}, {p->quad, quad, 2L * usz, 2 * usz}, {p->numf, numf, 2, 2}, {p->x, x, 2L * Di, 2 * Di}}, 4};
-    LaunchCopyRowsMulti(in_set, D(o_islot), nullptr, nI, qi);
     const float *stats_feats = fc_.ie.online_cmvn_iextractor ? lda_norm : lda_raw;
-    for (int k = 0; k < max_new_chunks; k++) {
-      const size_t o = (size_t)k * nI;
-      // (every step starts the sums itself -- a step's statistics are its own frames' -- so nothing clears the 21 MB between steps:
-      // zero + the step's terms in the same order, bit for bit what the cleared buffers gave)
-      LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, true, qi);
-      LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, qi);
-      LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, qi);
+    if (Di <= 128) {
+      // the new chunks of all streams: statistics side by side, then one launch that walks every stream's chunks in order on its
+      // estimator state in place (round 4: state rows gathered, a five-launch chain per chunk, state rows scattered)
+      IvecChunkChain(arena, g, nI, max_new_chunks, stats_feats, ld_l, post_idx, post_w, D(o_sfb), D(o_sfe), D(o_sor), D(o_sac), p->lin, p->quad, p->numf,
+                     p->x, D(o_islot), p->ivec, ld_i, qi);
+    } else {
+      double *gamma = arena.AllocT<double>((size_t)nI * G), *wfeats = arena.AllocT<double>((size_t)nI * G * Dl);
+      double *linear = arena.AllocT<double>((size_t)nI * Di), *quad = arena.AllocT<double>((size_t)nI * usz);
+      double *numf = arena.AllocT<double>(nI), *x = arena.AllocT<double>((size_t)nI * Di);
+      double *scratch = arena.AllocT<double>(IvecStatsScratchDoubles(ivec_dev_, nI));
+      // estimator state: slots -> dense, the steps, dense -> slots (one launch each way for the four arrays)
+      CopyRowsSet in_set{{{p->lin, linear, 2L * Di, 2 * Di}, {p->quad, quad, 2L * usz, 2 * usz}, {p->numf, numf, 2, 2}, {p->x, x, 2L * Di, 2 * Di}}, 4};
+      LaunchCopyRowsMulti(in_set, D(o_islot), nullptr, nI, qi);
+      for (int k = 0; k < max_new_chunks; k++) {
+        const size_t o = (size_t)k * nI;
+        LaunchIvecAccumulate(ivec_dev_, g, stats_feats, ld_l, post_idx, post_w, D(o_sfb) + o, D(o_sfe) + o, gamma, wfeats, true, qi);
+        LaunchIvecStats(ivec_dev_, nI, gamma, wfeats, linear, quad, numf, scratch, qi);
+        LaunchIvecSolve(ivec_dev_, nI, linear, quad, numf, x, p->ivec, ld_i, D(o_sor) + o, D(o_sac) + o, qi);
+      }
+      CopyRowsSet out_set{{{linear, p->lin, 2L * Di, 2 * Di}, {quad, p->quad, 2L * usz, 2 * usz}, {numf, p->numf, 2, 2}, {x, p->x, 2L * Di, 2 * Di}}, 4};
+      LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qi);
     }
-    CopyRowsSet out_set{{{linear, p->lin, 2L * Di, 2 * Di}, {quad, p->quad, 2L * usz, 2 * usz}, {numf, p->numf, 2, 2}, {x, p->x, 2L * Di, 2 * Di}}, 4};
-    LaunchCopyRowsMulti(out_set, nullptr, D(o_islot), nI, qi);
     TM_MARK(tmi);
   }
   TM_MARK(tma);
