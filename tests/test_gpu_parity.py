@@ -314,6 +314,22 @@ def test_live_state_table_search_leaves_the_same_lattice(case_cache, name, extra
     monkeypatch.delenv("RS_HASH_LDS_LOG", raising=False)
 
 
+def test_nbest_on_a_grammar_graph_ignores_the_per_frame_token_limit(case_cache):
+    """An n-best / lattice call on a grammar graph runs the register-resident search, which keeps every live state of a frame, and
+    DenseToTokensKernel writes them all: the utterance's slice of the token array holds S per frame whatever
+    rs_decode_opts.max_tokens_per_frame says (round 4 sized the slice by the option and wrote past it)."""
+    from rhasspy_speech_amd import synth
+    ref_model, pcm = make_model(case_cache, "zam_u0")
+    pcms = [pcm] + [synth.synth_utterance(900 + i, n) for i, n in enumerate([48000, 21000])]
+    ref = ref_model.decode_batch(pcms, nbest=5)
+    got = make_model(case_cache, "zam_u0", max_tokens_per_frame=8)[0].decode_batch(pcms, nbest=5)
+    for u in range(len(pcms)):
+        assert got.num_hyps(u) == ref.num_hyps(u)
+        for k in range(ref.num_hyps(u)):
+            assert got.words(u, k) == ref.words(u, k)
+            np.testing.assert_array_equal(got.costs(u, k), ref.costs(u, k))
+
+
 def test_time_slab_pipeline_is_the_same_search(case_cache, monkeypatch):
     """RS_OVERLAP_SLABS=n: the output layer and the (resumable) register-resident search are pipelined over n time slabs."""
     from rhasspy_speech_amd import synth
