@@ -18,6 +18,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,6 +29,8 @@ typedef struct {
   int next;         /* next token on the same frame (-1 end) */
   int backpointer;
   int alive;
+  int frame;            /* trace only: the frame (plus one) the token lives on */
+  float born_margin;    /* trace only: tot_cost - the frame's FINAL next_cutoff after ProcessEmitting (>= 0: an order-dependent extra); NAN: made by the closure */
 } Tok;
 
 typedef struct {
@@ -76,6 +79,9 @@ typedef struct {
   int finalized; float final_relative_cost, final_best_cost;
   float *final_costs;   /* per token id, NAN = absent */ int have_final_costs;
   int64_t counters[8];
+  /* diagnostics (profiles/micro/c2_arpa_162.py), off unless the environment asks: */
+  int final_cutoff_mode;    /* RS_ORACLE_FINAL_CUTOFF=1: ProcessEmitting prunes with the frame's final next_cutoff (what the kernels do) */
+  FILE *trace;              /* RS_ORACLE_TRACE=<file>: one line per frame + the best path's order-dependent tokens */
 } Dec;
 
 static const float INF = INFINITY;
@@ -85,6 +91,7 @@ static int new_tok(Dec *d, float tot, float extra, int links, int next, int bp, 
   if (d->ntok == d->captok) { d->captok = d->captok ? d->captok * 2 : 4096; d->tok = (Tok *)realloc(d->tok, sizeof(Tok) * d->captok); }
   Tok *t = &d->tok[d->ntok];
   t->state = state; t->tot_cost = tot; t->extra_cost = extra; t->links = links; t->next = next; t->backpointer = bp; t->alive = 1;
+  t->frame = d->nframes - 1; t->born_margin = NAN;
   d->num_toks++;
   return d->ntok++;
 }
@@ -252,6 +259,18 @@ static float process_emitting(Dec *d) {
     }
   }
   d->cost_offsets[frame] = cost_offset;
+  if (d->final_cutoff_mode) {     /* diagnostic variant: the cutoff every token of the frame is pruned with is the one the loop below ends with */
+    for (int e = final_toks; e != -1; e = d->elem[e].tail) {
+      int state = d->elem[e].key, tki = d->elem[e].val;
+      if (d->tok[tki].tot_cost > cur_cutoff) continue;
+      for (int64_t a = d->arc_begin[state]; a < d->arc_begin[state + 1]; a++)
+        if (d->ilabel[a] != 0) {
+          float tot_cost = d->tok[tki].tot_cost + (cost_offset - loglike(d, frame, d->ilabel[a])) + d->weight[a];
+          if (tot_cost + adaptive_beam < next_cutoff) next_cutoff = tot_cost + adaptive_beam;
+        }
+    }
+  }
+  float best_in = best_elem != -1 ? d->tok[d->elem[best_elem].val].tot_cost : 0.0f;
   for (int e = final_toks, e_tail; e != -1; e = e_tail) {
     int state = d->elem[e].key, tki = d->elem[e].val;
     if (d->tok[tki].tot_cost <= cur_cutoff) {
@@ -270,6 +289,18 @@ static float process_emitting(Dec *d) {
     }
     e_tail = d->elem[e].tail;
     hl_delete(d, e);
+  }
+  if (d->trace) {
+    int made = 0, extras = 0;
+    float worst = 0.0f;
+    for (int t = d->frames[frame + 1].toks; t != -1; t = d->tok[t].next) {
+      float m = d->tok[t].tot_cost - next_cutoff;
+      d->tok[t].born_margin = m;
+      made++;
+      if (m >= 0.0f) { extras++; if (m > worst) worst = m; }
+    }
+    fprintf(d->trace, "frame %d tokens_in %zu cutoff-best %.4f adaptive_beam %.4f made %d extras %d worst_margin %.4f\n", frame, tok_cnt,
+            cur_cutoff - best_in, adaptive_beam, made, extras, worst);
   }
   return next_cutoff;
 }
@@ -447,6 +478,8 @@ Dec *rs_oracle_decode(int num_states, int start, const float *final, const int64
   d->beam = beam; d->max_active = max_active; d->min_active = min_active; d->lattice_beam = lattice_beam; d->beam_delta = beam_delta;
   d->prune_scale = 0.1f; d->hash_ratio = 2.0f; d->prune_interval = 25;
   d->free_lnk = -1; d->free_elem = -1; d->list_head = -1; d->bucket_list_tail = -1;
+  { const char *e = getenv("RS_ORACLE_FINAL_CUTOFF"); d->final_cutoff_mode = e && e[0] == '1';
+    e = getenv("RS_ORACLE_TRACE"); d->trace = e && e[0] ? fopen(e, "w") : NULL; }
   hl_set_size(d, 1000);      /* LatticeFasterDecoderTpl constructor: toks_.SetSize(1000) */
   /* InitDecoding */
   push_frame(d);
@@ -465,6 +498,18 @@ Dec *rs_oracle_decode(int num_states, int start, const float *final, const int64
   /* FinalizeDecoding */
   int final_frame_plus_one = d->nframes - 1;
   prune_forward_links_final(d);
+  if (d->trace) {       /* the best path, by back-pointers from the best token of the last frame: which of its tokens were order-dependent extras */
+    int best = -1; float bc = INF;
+    for (int t = d->frames[final_frame_plus_one].toks; t != -1; t = d->tok[t].next) {
+      float fc = !d->have_final_costs ? 0.0f : (d->final_costs[t] == d->final_costs[t] ? d->final_costs[t] : INF);
+      if (d->tok[t].tot_cost + fc < bc) { bc = d->tok[t].tot_cost + fc; best = t; }
+    }
+    for (int t = best; t != -1; t = d->tok[t].backpointer)
+      if (d->tok[t].born_margin >= 0.0f)
+        fprintf(d->trace, "best_path frame %d state %d born %.4f ABOVE the frame's final cutoff\n", d->tok[t].frame, d->tok[t].state, d->tok[t].born_margin);
+    fprintf(d->trace, "best_path end\n");
+    fclose(d->trace); d->trace = NULL;
+  }
   for (int f = final_frame_plus_one - 1; f >= 0; f--) {
     int b1, b2;
     prune_forward_links(d, f, &b1, &b2, 0.0f);
