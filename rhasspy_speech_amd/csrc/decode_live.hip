@@ -56,7 +56,7 @@ constexpr int kGlobalSize = 1 << kGlobalLog;
 constexpr int kSlotCap = 24576;                     // live states / tokens per frame (records name a token of a frame in 16 bits)
 constexpr unsigned kFree = 0xFFFFFFFFu;
 #ifndef RS_LIVE_BUCKETS
-#define RS_LIVE_BUCKETS 2
+#define RS_LIVE_BUCKETS 3
 #endif
 constexpr int kLdsBuckets = RS_LIVE_BUCKETS;      // buckets of four LDS entries looked at before a state goes to the global part
 constexpr int kBigCap = 256;                        // high-degree tokens whose arcs are dealt out per chunk
@@ -68,7 +68,19 @@ constexpr int kDstEpsDst = 0x40000000;
 constexpr int kPdfMask = 0x3fffffff;
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned LdsTag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// The LDS part of the table is addressed through LDS-typed pointers: a `volatile` access or a pointer selected between the LDS and the
+// global part through a GENERIC pointer compiles to flat_load / flat_atomic (address check, vmcnt(0) + lgkmcnt(0) behind every one of
+// them: the sweep's outstanding global loads and stores were waited for at every table probe).
+#ifdef RS_LIVE_GENERIC      // (A/B: profiles/micro/live_variants.sh)
+typedef unsigned LdsU32;
+typedef unsigned long long LdsU64;
+typedef v4u LdsV4;
+#else
+typedef __attribute__((address_space(3))) unsigned LdsU32;
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+typedef __attribute__((address_space(3))) v4u LdsV4;
+#endif
+__device__ __forceinline__ unsigned LdsTag(const LdsU32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ unsigned GlbTag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Monotone binning of a token cost over [lo, lo + 256 / scale): both the pass that fills the histogram and the pass that collects
@@ -99,8 +111,8 @@ struct LiveCtx {
 // The live-state table of one utterance: HS entries (tag + key) in LDS, kGlobalSize behind them in global memory.
 template <int HS>
 struct LiveTable {
-  unsigned *tags;                    // LDS
-  unsigned long long *keys;          // LDS
+  LdsU32 *tags;                      // LDS
+  LdsU64 *keys;                      // LDS
   unsigned *gtags;                   // global
   unsigned long long *gkeys;         // global
   int *n_slots, *g_used;             // LDS counters
@@ -119,14 +131,13 @@ struct LiveTable {
     *claimed = false;
 #pragma unroll 1
     for (int tries = 0, moved = 0; moved < kLdsBuckets && tries < 4 * kLdsBuckets + 8; tries++) {
-      const v4u e = *reinterpret_cast<const volatile v4u *>(&tags[4 * b]);
-      if (e.x == state) return (int)(4 * b);
-      if (e.y == state) return (int)(4 * b + 1);
-      if (e.z == state) return (int)(4 * b + 2);
-      if (e.w == state) return (int)(4 * b + 3);
+      const v4u e = *(const volatile LdsV4 *)(tags + 4 * b);
+      const int hit = e.x == state ? 0 : e.y == state ? 1 : e.z == state ? 2 : e.w == state ? 3 : -1;
+      if (hit >= 0) return (int)(4 * b) + hit;
       const int j = e.x == kFree ? 0 : e.y == kFree ? 1 : e.z == kFree ? 2 : e.w == kFree ? 3 : -1;
       if (j >= 0) {
-        const unsigned old = atomicCAS(&tags[4 * b + j], kFree, state);
+        unsigned old = kFree;
+        __hip_atomic_compare_exchange_strong(tags + 4 * b + j, &old, state, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (old == kFree) { *claimed = true; return (int)(4 * b + j); }
         if (old == state) return (int)(4 * b + j);
         continue;      // another state took the entry first: look at this bucket again
@@ -157,18 +168,21 @@ struct LiveTable {
     if (claimed && atomicAdd(n_slots, 1) >= slot_limit) return -1;
     return sl;
   }
-  __device__ __forceinline__ unsigned State(int slot) const { return slot < HS ? LdsTag(&tags[slot]) : GlbTag(&gtags[slot - HS]); }
+  __device__ __forceinline__ unsigned State(int slot) const { return slot < HS ? LdsTag(tags + slot) : GlbTag(&gtags[slot - HS]); }
   __device__ __forceinline__ void KeyMin(int slot, unsigned long long k) const {      // result unused: non-returning atomics
-    if (slot < HS) atomicMin(&keys[slot], k); else atomicMin(&gkeys[slot - HS], k);
+    if (slot < HS) __hip_atomic_fetch_min(keys + slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicMin(&gkeys[slot - HS], k);
   }
   __device__ __forceinline__ unsigned long long KeyMinRet(int slot, unsigned long long k) const {
-    return slot < HS ? atomicMin(&keys[slot], k) : atomicMin(&gkeys[slot - HS], k);
+    if (slot < HS) return __hip_atomic_fetch_min(keys + slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return atomicMin(&gkeys[slot - HS], k);
   }
   __device__ __forceinline__ unsigned long long KeyLoad(int slot) const {
-    return slot < HS ? __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : LoadKey(&gkeys[slot - HS]);
+    if (slot < HS) return __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return LoadKey(&gkeys[slot - HS]);
   }
   __device__ __forceinline__ void KeyStore(int slot, unsigned long long k) const {
-    if (slot < HS) __hip_atomic_store(&keys[slot], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else StoreKey(&gkeys[slot - HS], k);
+    if (slot < HS) __hip_atomic_store(keys + slot, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else StoreKey(&gkeys[slot - HS], k);
   }
 };
 
@@ -228,7 +242,7 @@ __device__ float KthFromCommitHist(Ctx &c, const int4 *toks, int n, int k, float
 #define RS_LIVE_Q 2
 #endif
 #ifndef RS_LIVE_HS
-#define RS_LIVE_HS 9728
+#define RS_LIVE_HS 10496
 #endif
 
 template <int NT, int HS>
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
   const int cand_cap = w.h_cand_cap;
   LiveTable<HS> tb;
-  tb.tags = tags; tb.keys = lkeys;
+  tb.tags = (LdsU32 *)tags; tb.keys = (LdsU64 *)lkeys;
   tb.gtags = w.h_gtags + (size_t)u * kGlobalSize;
   tb.gkeys = w.h_keys + (size_t)u * tab;
   tb.n_slots = &c.n_slots; tb.g_used = &c.g_used;
@@ -893,7 +907,7 @@ int DecodeLiveTableSize() { return 65536; }
 void LaunchDecodeLive(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                       const DecodeWork &w, hipStream_t s) {
   if (g.n_utts == 0) return;
-  // one workgroup of 1024 threads per utterance and CU: 9728 table entries (tags + keys: 114 KB) + 32 KB of staging in LDS.  Shapes
+  // one workgroup of 1024 threads per utterance and CU: 10496 table entries (tags + keys: 123 KB) + 32 KB of staging in LDS (all but 0.7 KB of the CU's 160).  Shapes
   // with two or four smaller workgroups per CU were measured and lost (profiles/r05/live_notes.txt).
   hipLaunchKernelGGL((LiveDecodeKernel<1024, RS_LIVE_HS>), dim3(g.n_utts), dim3(1024), 0, s, h, o, g, loglikes, ld, w);
 }
