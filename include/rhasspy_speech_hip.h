@@ -252,6 +252,10 @@ int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *
  *     that called rand() `rand_calls` times before its first frame. */
 int rs_nnet3_setup(const char *final_mdl, int32_t frames_per_chunk, int64_t *rand_calls, int32_t *certain, char *collapsed_config,
                    size_t buf_len);
+/*   rs_nnet3_setup_subsampled: the same under --frame-subsampling-factor (the looped computation is compiled for the output frames
+ *     t = 0, f, 2 f, ... and a chunk rounded up to a multiple of f: nnet-compile-looped.cc:81-94,111-128). */
+int rs_nnet3_setup_subsampled(const char *final_mdl, int32_t frames_per_chunk, int32_t frame_subsampling_factor, int64_t *rand_calls,
+                              int32_t *certain, char *collapsed_config, size_t buf_len);
 int rs_dither_noise(int64_t rand_calls, int32_t t0, int32_t t1, int32_t window, float *out);
 
 /* ---- rescoring against a NEW language directory (host side; the lattices come from decodes with rs_decode_opts.emit_lattice = 1).

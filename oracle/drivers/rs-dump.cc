@@ -146,7 +146,7 @@ int main(int argc, char *argv[]) {
         Vector<BaseFloat> row(P);
         for (int32 p = 0; p < P; p++) row(p) = decodable.LogLikelihood(done, p + 1);
         loglike_rows.push_back(row);
-        if (done % chunk == 0 && pipeline.IvectorFeature() != NULL) {
+        if (done % (chunk / decodable_opts.frame_subsampling_factor) == 0 && pipeline.IvectorFeature() != NULL) {
           // the chunk holding frame 'done' has just been computed on this tick; re-query the
           // iVector the decodable used (decodable-online-looped.cc:186-194; idempotent).
           OnlineIvectorFeature *iv = pipeline.IvectorFeature();

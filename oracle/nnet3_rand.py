@@ -999,9 +999,10 @@ def modify_ivector_period(net: Net, period: int) -> None:
                 n.desc = Descriptor(text, names)
 
 
-def looped_requests(net: Net, chunk: int, left: int, right: int, num_requests: int):
+def looped_requests(net: Net, chunk: int, left: int, right: int, num_requests: int, fsf: int = 1):
     """CreateLoopedComputationRequest + the extrapolated requests of CompileLoopedInternal (nnet-compile-looped.cc:131-300);
-    one sequence, frame-subsampling-factor 1, ivector period = chunk (decodable-simple-looped.cc:68-70)."""
+    one sequence, outputs at the multiples of the frame-subsampling-factor (CreateComputationRequestInternal :111-128), ivector
+    period = chunk (decodable-simple-looped.cc:68-70)."""
     has_ivector = net.index("ivector") != -1
     reqs = []
     seen: set = set()
@@ -1021,11 +1022,11 @@ def looped_requests(net: Net, chunk: int, left: int, right: int, num_requests: i
             prev_times = times
             if times:
                 inputs.append(("ivector", [(0, t, 0) for t in times]))
-        reqs.append((inputs, [("output", [(0, t, 0) for t in range(k * chunk, (k + 1) * chunk)])]))
+        reqs.append((inputs, [("output", [(0, t, 0) for t in range(k * chunk, (k + 1) * chunk, fsf)])]))
     return reqs
 
 
-def setup_rand_calls(nf: kf.NnetFile, frames_per_chunk: int = 24, extra_left_context_initial: int = 0) -> int:
+def setup_rand_calls(nf: kf.NnetFile, frames_per_chunk: int = 24, extra_left_context_initial: int = 0, frame_subsampling_factor: int = 1) -> int:
     """Number of rand() calls both decoder binaries make before the first feature frame
     (online2-wav-nnet3-latgen-faster.cc:160-176, online2-cli-nnet3-decode-faster.cc:97-111)."""
     rng = GlibcRand()
@@ -1036,13 +1037,13 @@ def setup_rand_calls(nf: kf.NnetFile, frames_per_chunk: int = 24, extra_left_con
     left += extra_left_context_initial
     modulus = net.modulus()
     chunk = frames_per_chunk
-    while chunk % modulus != 0:                                    # GetChunkSize (nnet-compile-looped.cc:82-96)
+    while chunk % modulus != 0 or chunk % frame_subsampling_factor != 0:      # GetChunkSize (nnet-compile-looped.cc:82-96)
         chunk += 1
     if net.index("ivector") != -1:
         modify_ivector_period(net, chunk)
     num_requests = 5                                               # CompileLooped (:326-345): 5, then 10, 20, ... on failure
     b = GraphBuilder(net, rng)
-    for inputs, outputs in looped_requests(net, chunk, left, right, num_requests):   # Compiler::CreateComputation (nnet-compile.cc:50-62)
+    for inputs, outputs in looped_requests(net, chunk, left, right, num_requests, frame_subsampling_factor):   # Compiler::CreateComputation (nnet-compile.cc:50-62)
         b.compute(inputs, outputs)
         b.prune()
     # Compiler::SetUpPrecomputedIndexes (nnet-compile.cc:1239-1291): one step per (node, segment) in a feed-forward network;

@@ -760,7 +760,7 @@ class Oracle:
     """CPU restatement of one reference pipeline invocation (model + graph loaded once)."""
 
     def __init__(self, model_dir, graph_dir, beam=24.0, max_active=7000, min_active=None, lattice_beam=8.0, acoustic_scale=1.0,
-                 frames_per_chunk=None, beam_delta=None):
+                 frames_per_chunk=None, beam_delta=None, frame_subsampling_factor=None):
         model_dir, graph_dir = Path(model_dir), Path(graph_dir)
         conf = dict(kf.read_config(model_dir / "model" / "online" / "conf" / "online.conf"))
         # The binaries register decoder / decodable options on the parser that reads --config (online2-wav-nnet3-latgen-faster.cc:
@@ -773,6 +773,14 @@ class Oracle:
             frames_per_chunk = int(conf.get("frames-per-chunk", 24))      # decodable-simple-looped.h:57
         if beam_delta is None:
             beam_delta = float(conf.get("beam-delta", 0.5))                # lattice-faster-decoder.h:66
+        if frame_subsampling_factor is None:
+            frame_subsampling_factor = int(conf.get("frame-subsampling-factor", 1))      # decodable-simple-looped.h:56
+        # the network is evaluated for the output frames t = 0, fsf, 2 fsf, ... and the decoder sees those as its frames
+        # (decodable-online-looped.cc:56-84; nnet-compile-looped.cc:111-128); the chunk is the advised size rounded up to a
+        # multiple of the factor (GetChunkSize, nnet-compile-looped.cc:81-94; every network here has modulus 1)
+        self.fsf = frame_subsampling_factor
+        while frames_per_chunk % self.fsf != 0:
+            frames_per_chunk += 1
         self.opts = dict(beam=beam, max_active=max_active, min_active=min_active, lattice_beam=lattice_beam, beam_delta=beam_delta)
         self.acoustic_scale = acoustic_scale
         self.chunk = frames_per_chunk
@@ -781,7 +789,7 @@ class Oracle:
         # the dither of frame t is seeded by rand() value number (calls of the model set-up + t): oracle/nnet3_rand.py
         from . import nnet3_rand
         mo = MfccOpts.from_conf(conf["mfcc-config"]) if "mfcc-config" in conf else MfccOpts()
-        self.rand_calls = nnet3_rand.setup_rand_calls(nf, frames_per_chunk) if mo.dither != 0.0 else 0
+        self.rand_calls = nnet3_rand.setup_rand_calls(nf, frames_per_chunk, 0, self.fsf) if mo.dither != 0.0 else 0
         self.mfcc = Mfcc(mo, self.rand_calls)
         self.nnet = Nnet3(nf)
         self.fst = kf.read_fst(graph_dir / "HCLG.fst")
@@ -901,9 +909,10 @@ class Oracle:
         if T == 0:
             raise RuntimeError("You cannot get a lattice if you decoded no frames.")
         nn_in, ivs, ll = self.loglikes_stream(feats, len(pcm))
+        ll = np.ascontiguousarray(ll[::self.fsf])
         lattice, ctr = decode(self.fst, self.id2pdf, ll, **self.opts)
         paths = lat.nbest(lattice, nbest, self.opts["lattice_beam"], lattice_acoustic_scale)
-        return Transcript(T, nn_in, ivs, ll, paths, lattice, ctr)
+        return Transcript(ll.shape[0], nn_in, ivs, ll, paths, lattice, ctr)
 
     def transcribe(self, pcm: np.ndarray, nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Transcript:
         feats = self.features(np.asarray(pcm))
@@ -911,6 +920,7 @@ class Oracle:
         if T == 0:
             raise RuntimeError("You cannot get a lattice if you decoded no frames.")
         nn_in, iv, ll = self.loglikes_offline(feats)
+        ll = np.ascontiguousarray(ll[::self.fsf])
         lattice, ctr = decode(self.fst, self.id2pdf, ll, **self.opts)
         paths = lat.nbest(lattice, nbest, self.opts["lattice_beam"], lattice_acoustic_scale)
-        return Transcript(T, nn_in, iv, ll, paths, lattice, ctr)
+        return Transcript(ll.shape[0], nn_in, iv, ll, paths, lattice, ctr)

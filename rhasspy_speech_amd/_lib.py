@@ -36,7 +36,7 @@ EXPORTS = [
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
     "rs_mkgraph", "rs_fst_tool", "rs_fuzzy_open", "rs_fuzzy_match", "rs_result_fuzzy", "rs_fuzzy_free", "rs_lattice_entry_from_raw",
     "rs_rescorer_open", "rs_rescore_result", "rs_rescore_lattice", "rs_rescorer_free",
-    "rs_nnet3_setup", "rs_dither_noise", "rs_bind_host_thread",
+    "rs_nnet3_setup", "rs_nnet3_setup_subsampled", "rs_dither_noise", "rs_bind_host_thread",
 ]
 
 

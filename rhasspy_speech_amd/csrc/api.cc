@@ -581,6 +581,11 @@ int rs_fst_tool(const char *tool, const char *in1, const char *in2, const char *
 
 int rs_nnet3_setup(const char *final_mdl, int32_t frames_per_chunk, int64_t *rand_calls, int32_t *certain, char *collapsed_config,
                    size_t buf_len) {
+  return rs_nnet3_setup_subsampled(final_mdl, frames_per_chunk, 1, rand_calls, certain, collapsed_config, buf_len);
+}
+
+int rs_nnet3_setup_subsampled(const char *final_mdl, int32_t frames_per_chunk, int32_t frame_subsampling_factor, int64_t *rand_calls,
+                              int32_t *certain, char *collapsed_config, size_t buf_len) {
   if (!final_mdl || !rand_calls) return ArgError("rs_nnet3_setup: null argument");
   return Guard([&]() {
     // the network section of final.mdl, read the way Model does, without compiling a layer plan
@@ -599,7 +604,7 @@ int rs_nnet3_setup(const char *final_mdl, int32_t frames_per_chunk, int64_t *ran
     std::vector<std::string> names;
     std::vector<rs::Component> comps;
     rs::ReadNnetComponents(r, &names, &comps);
-    const rs::Nnet3SetupResult su = rs::Nnet3Setup(cfg, &names, &comps, frames_per_chunk > 0 ? frames_per_chunk : 24, 0);
+    const rs::Nnet3SetupResult su = rs::Nnet3Setup(cfg, &names, &comps, frames_per_chunk > 0 ? frames_per_chunk : 24, 0, frame_subsampling_factor > 0 ? frame_subsampling_factor : 1);
     *rand_calls = su.rand_calls;
     if (certain) *certain = su.rand_calls_certain ? 1 : 0;
     if (collapsed_config && buf_len) {

@@ -158,9 +158,9 @@ void Model::ResolveDecoderOptions() {
          " && prune_interval > 0 && beam_delta > 0.0 && hash_ratio >= 1.0 && prune_scale > 0.0 && prune_scale < 1.0"
          " (beam " + std::to_string(opts_.beam) + ", max-active " + std::to_string(opts_.max_active) + ", min-active " + std::to_string(opts_.min_active) +
          ", lattice-beam " + std::to_string(opts_.lattice_beam) + ", beam-delta " + std::to_string(opts_.beam_delta) + ")");
-  if (opts_.frame_subsampling_factor != 1)
-    Fail("--frame-subsampling-factor=" + std::to_string(opts_.frame_subsampling_factor) + " is not supported by the HIP path (only 1: every output row is evaluated and searched)" +
-         (has_fsf ? where : std::string()));
+  // GetChunkSize (nnet-compile-looped.cc:81-94): the advised chunk rounded up to a multiple of the subsampling factor (and of the
+  // network's modulus, which is 1 for every network the layer plan accepts)
+  while (opts_.frames_per_chunk % opts_.frame_subsampling_factor != 0) opts_.frames_per_chunk++;
 }
 
 Model::Model(const std::string &final_mdl, const std::string &hclg, const std::string &online_conf,
@@ -177,7 +177,7 @@ Model::Model(const std::string &final_mdl, const std::string &hclg, const std::s
   }
   ReadFeatureConfig(online_conf, &fc_);
   ResolveDecoderOptions();
-  am_.Read(final_mdl, opts_.frames_per_chunk, 0);
+  am_.Read(final_mdl, opts_.frames_per_chunk, 0, opts_.frame_subsampling_factor);
   hclg_.Read(hclg);
   dither_rand_calls_ = am_.nnet.setup_rand_calls;
   if (const char *e = std::getenv("RS_DITHER_RAND_CALLS")) dither_rand_calls_ = std::atol(e);
@@ -812,7 +812,9 @@ std::string Model::Describe() const {
     } else {
       os << " terms=" << op.terms.size();
     }
-    os << " stages=" << op.stages.size() << "\n";
+    os << " stages=" << op.stages.size();
+    if (n.bufs[op.out_buf].stride > 1) os << " rows=every-" << n.bufs[op.out_buf].stride;      // (--frame-subsampling-factor: nothing reads the rows between)
+    os << "\n";
   }
   os << "transition_model: tids=" << am_.trans.id2pdf.size() - 1 << " pdfs=" << am_.trans.num_pdfs << "\n";
   if (pruned_from_) os << "output layer: pruned to the " << am_.nnet.output_dim << " of " << pruned_from_ << " pdfs that occur on HCLG arcs\n";
@@ -1137,6 +1139,16 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
   const Nnet &nn = am_.nnet;
   const bool images_on = imgs != nullptr && GemmImagesEnabled() && !tls_exact_gemm && tls_gemm_ovf_dev != nullptr;
   if (op_begin == 0 && !tls_exact_gemm) ZeroGuards(bufp, buf_ld, rows, images_on ? imgs : nullptr, s);
+  if (op_begin == 0) {
+    // buffers evaluated on every stride-th row: the rows in between are read by nobody whose result is used, but kernels that run
+    // over all rows (image conversion, range check, prior scaling) must find numbers there, not what the arena held before
+    const int guard = L_ + R_ + 8;
+    for (size_t b = 0; b < nn.bufs.size(); b++) {
+      if (nn.bufs[b].stride <= 1) continue;
+      RS_HIP(hipMemsetAsync(bufp[b] - (size_t)guard * buf_ld[b], 0, ((size_t)rows + 2 * guard) * buf_ld[b] * sizeof(float), s));
+      if (images_on && (*imgs)[b].base) RS_HIP(hipMemsetAsync((*imgs)[b].base, 0, (size_t)kActImageParts * (*imgs)[b].part_bytes, s));
+    }
+  }
   for (size_t i = op_begin; i < op_end; i++) {
     const LayerOp &op = nn.ops[i];
     const bool img_out = images_on && (*imgs)[op.out_buf].base != nullptr;
@@ -1146,7 +1158,7 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       if (img_out && !GemmWritesImage(gd)) gd.write_f32 = 1;      // a kernel without the image epilogue: converted below
       else img_done = img_out;
       const BufferInfo &ob = nn.bufs[op.out_buf];
-      if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext)) {     // only the rows somebody reads
+      if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext, ob.stride)) {     // only the rows somebody reads
         gd.row_map = rm->rows;
         gd.row_map_span128 = rm->span128;
         LaunchGemm(gd, rm->count, d_row_ivec, s);
@@ -1553,7 +1565,17 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     maxT = std::max(maxT, T[u]);
     row_base[u + 1] = row_base[u] + T[u] + L_ + R_;
     frame_base[u + 1] = frame_base[u] + T[u];
-    out_utts[u].num_frames = T[u];
+  }
+  // --frame-subsampling-factor f: the decoder's frames are the output rows t = 0, f, 2 f, ... (decodable-online-looped.cc:56-84:
+  // (T + f - 1) / f of them once the input is finished); num_frames is what the reference's binaries log as decoded frames
+  const int fsf = opts_.frame_subsampling_factor;
+  std::vector<int> T_dec(n_utts), dec_base(n_utts + 1, 0);
+  int maxT_dec = 0;
+  for (int u = 0; u < n_utts; u++) {
+    T_dec[u] = (T[u] + fsf - 1) / fsf;
+    maxT_dec = std::max(maxT_dec, T_dec[u]);
+    dec_base[u + 1] = dec_base[u] + T_dec[u];
+    out_utts[u].num_frames = T_dec[u];
   }
   const int rows = row_base[n_utts];
   const int guard = L_ + R_ + 8;
@@ -1630,7 +1652,8 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     if (streaming) need += IvecChunkChainBytes(ivec_dev_, n_utts, max_chunks);
   }
   SearchPlan sp;
-  need += PlanSearch(n_utts, maxT, nbest, lat_scale, &sp);
+  need += PlanSearch(n_utts, maxT_dec, nbest, lat_scale, &sp);
+  if (fsf > 1) need += ((size_t)dec_base[n_utts] + 8) * RoundUp(P, 4) * sizeof(float) + (size_t)(dec_base[n_utts] + 3 * n_utts + 16) * sizeof(int) + 4096;
   const bool use_reg = sp.use_reg;
   need += 64 * 256;   // alignment slack
   arena_.Reserve(need + (1u << 20), s);
@@ -1660,7 +1683,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   const bool last_is_gemm = !nn.ops.empty() && nn.ops.back().kind == LayerOp::kGemm && nn.ops.back().out_buf == nn.output_buf &&
                             nn.bufs[nn.output_buf].lext == 0 && nn.bufs[nn.output_buf].rext == 0;
   const bool pipelined = use_reg && !sp.reg_lattice && last_is_gemm && !d_log_priors_ && opts_.acoustic_scale == 1.0f && overlap_env > 1 && maxT >= 64 &&
-                         s == cx.stream;
+                         s == cx.stream && fsf == 1;
   const int n_slabs = pipelined ? std::min(overlap_env, 8) : 1, slab_len = std::max(1, (maxT + n_slabs - 1) / n_slabs);
   std::vector<int> slab_off(n_slabs + 1, 0);
   int *d_frame_rows = nullptr;
@@ -1670,7 +1693,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     // every utterance: layers nothing downstream reads with a time offset are evaluated on these rows only), and per hidden layer
     // only as much halo as the layers after it reach (15 rows a side for the first, none for the last of the zamia-like net:
     // 5 % fewer rows over the stack than evaluating the full halo everywhere)
-    struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; };
+    struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; int stride = 1, first = 0; };
     std::vector<ListPlan> lists;
     std::vector<int> segs;      // the lists' segment offsets, back to back
     int min_T = 1 << 30;
@@ -1691,19 +1714,25 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       for (size_t i = 0; trim && i < nn.ops.size(); i++) {
         if (nn.ops[i].kind != LayerOp::kGemm) continue;
         const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
-        if ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || ob.lext > L_ || ob.rext > R_) continue;
+        const int st = ob.stride;
+        if (ob.lext > L_ || ob.rext > R_) continue;
+        if (st == 1 && ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_))) continue;
+        if (st > 1 && n_slabs != 1) continue;
         bool have = false;
-        for (auto &l : lists) have = have || (l.lext == ob.lext && l.rext == ob.rext);
+        for (auto &l : lists) have = have || (l.lext == ob.lext && l.rext == ob.rext && l.stride == st);
         if (have || (int)lists.size() >= BatchSetup::kMaxLists) continue;
         ListPlan l2{ob.lext, ob.rext, n_utts, 0, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), 0, segs.size()};
+        l2.stride = st;
+        l2.first = ob.lext % st;             // t = -lext + first is the first row with t = 0 mod stride
         int acc = 0;
-        for (int u = 0; u < n_utts; u++) { segs.push_back(acc); acc += T[u] > 0 ? T[u] + ob.lext + ob.rext : 0; }
+        // (rows t = 0 mod stride of [-lext, T + rext): (T + rext - 1) / stride + lext / stride + 1 of them)
+        for (int u = 0; u < n_utts; u++) { segs.push_back(acc); acc += T[u] > 0 ? (st == 1 ? T[u] + ob.lext + ob.rext : (T[u] + ob.rext - 1) / st + ob.lext / st + 1) : 0; }
         segs.push_back(acc);
         if (acc == 0) { segs.resize(l2.seg_at); continue; }
         l2.total = acc;
         // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
-        // nobody reads: the physical rows a GEMM tile reaches over
-        l2.span128 = 128 + (126 / std::max(min_T + ob.lext + ob.rext, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext));
+        // nobody reads: the physical rows a GEMM tile reaches over (a strided list: not bounded here, the strip form is not used)
+        l2.span128 = st == 1 ? 128 + (126 / std::max(min_T + ob.lext + ob.rext, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext)) : 0;
         lists.push_back(l2);
       }
     }
@@ -1733,9 +1762,9 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     bs.row_ivec = host_row_ivec ? nullptr : d_row_ivec;
     for (auto &l : lists) {
       int *out = arena_.AllocT<int>(l.total);
-      bs.lists[bs.n_lists++] = {l.n_segs, l.total, l.L_eff, l.slab_len, d_segs + l.seg_at, out};
-      row_maps.maps.push_back({l.lext, l.rext, out, l.total, l.span128});
-      if (l.lext == 0 && l.rext == 0) d_frame_rows = out;
+      bs.lists[bs.n_lists++] = {l.n_segs, l.total, l.L_eff, l.slab_len, d_segs + l.seg_at, out, l.stride, l.first};
+      row_maps.maps.push_back({l.lext, l.rext, out, l.total, l.span128, l.stride});
+      if (l.lext == 0 && l.rext == 0 && l.stride == 1) d_frame_rows = out;
     }
     LaunchBatchSetup(bs, s);
     g.d_sample_off = d_so; g.d_num_frames = d_T; g.d_row_base = d_rb; g.d_frame_base = d_fb; g.d_row_utt = d_ru; g.d_row_t = d_rt;
@@ -1873,13 +1902,35 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
   }
   stage_end(1);
   float *ll = bufp[nn.output_buf];
-  const int ll_ld = buf_ld[nn.output_buf];
+  int ll_ld = buf_ld[nn.output_buf];
+  BatchGeom gdec = g;                     // what the search sees: the utterances' decoder frames
+  if (fsf > 1) {
+    // the rows the decoder reads, gathered into a dense [decoder frame][pdf] array with its own geometry (no halo)
+    const int nd = dec_base[n_utts];
+    int *h_idx = harena.AllocT<int>((size_t)nd + 2 * (size_t)n_utts + 2);
+    int *h_T = h_idx + nd, *h_base = h_T + n_utts;
+    for (int u = 0; u < n_utts; u++) {
+      for (int f = 0; f < T_dec[u]; f++) h_idx[dec_base[u] + f] = row_base[u] + L_ + f * fsf;
+      h_T[u] = T_dec[u];
+      h_base[u] = dec_base[u];
+    }
+    h_base[n_utts] = nd;
+    int *d_idx = arena_.AllocT<int>((size_t)nd + 2 * (size_t)n_utts + 2);
+    RS_HIP(hipMemcpyAsync(d_idx, h_idx, sizeof(int) * ((size_t)nd + 2 * (size_t)n_utts + 2), hipMemcpyHostToDevice, s));
+    const int ld_dec = RoundUp(P, 4);
+    float *ll_dec = arena_.AllocT<float>(((size_t)nd + 8) * ld_dec);
+    if (nd > 0) LaunchCopyRows(ll, ll_ld, d_idx, ll_dec, ld_dec, nullptr, nd, P, s);
+    ll = ll_dec; ll_ld = ld_dec;
+    gdec.L = 0; gdec.R = 0; gdec.total_rows = nd; gdec.total_frames = nd; gdec.max_frames = maxT_dec;
+    gdec.d_num_frames = d_idx + nd; gdec.d_row_base = d_idx + nd + n_utts; gdec.d_frame_base = d_idx + nd + n_utts;
+    gdec.d_row_utt = nullptr; gdec.d_row_t = nullptr; gdec.d_sample_off = nullptr;
+  }
   tm.Mark();
   // ---- decode
   if (pipelined) RS_HIP(hipStreamWaitEvent(s, cx.slab_ev[8], 0));       // the search of the last slab
-  else { poison(); LaunchSearch(&sp, arena_, g, ll, ll_ld, s); }
+  else { poison(); LaunchSearch(&sp, arena_, gdec, ll, ll_ld, s); }
   tm.Mark();
-  CollectResults(sp, cx, gi, g, T.data(), ll, ll_ld, nbest, lat_scale, s, out_utts, timings);
+  CollectResults(sp, cx, gi, gdec, T_dec.data(), ll, ll_ld, nbest, lat_scale, s, out_utts, timings);
   tm.Mark();
   if (opts_.keep_intermediates) {
     for (int u = 0; u < n_utts; u++) {
@@ -1887,11 +1938,11 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? ivrow_base[u + 1] - ivrow_base[u] : 0;
       if (T[u] == 0) continue;
       ur.feats.resize((size_t)T[u] * C);
-      ur.loglikes.resize((size_t)T[u] * P);
+      ur.loglikes.resize((size_t)T_dec[u] * P);
       const float *fin = bufp[nn.input_buf] + ((size_t)row_base[u] + L_) * buf_ld[nn.input_buf];
       RS_HIP(hipMemcpy2D(ur.feats.data(), sizeof(float) * C, fin, sizeof(float) * buf_ld[nn.input_buf], sizeof(float) * C, T[u], hipMemcpyDeviceToHost));
-      const float *lin = ll + ((size_t)row_base[u] + L_) * ll_ld;
-      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, lin, sizeof(float) * ll_ld, sizeof(float) * P, T[u], hipMemcpyDeviceToHost));
+      const float *lin = ll + (fsf > 1 ? (size_t)dec_base[u] : (size_t)row_base[u] + L_) * ll_ld;
+      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, lin, sizeof(float) * ll_ld, sizeof(float) * P, T_dec[u], hipMemcpyDeviceToHost));
       if (has_iv) {
         ur.ivector.resize((size_t)ur.ivec_rows * Di);
         RS_HIP(hipMemcpy2D(ur.ivector.data(), sizeof(float) * Di, d_ivec + (size_t)ivrow_base[u] * ld_i, sizeof(float) * ld_i,

@@ -104,10 +104,11 @@ struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
 // utterance, the physical rows of t in [-lext, T + rext) (kernels.h row layout).  (0, 0) = the real frames only.
 struct RowMaps {
   // span128: the physical rows any 128 consecutive rows of the list reach over (GemmDev::row_map_span128), 0 = not known
-  struct Entry { int lext, rext; const int *rows; int count; int span128 = 0; };
+  // stride: the list holds the rows t = 0 mod stride of [-lext, T + rext) (BufferInfo::stride)
+  struct Entry { int lext, rext; const int *rows; int count; int span128 = 0; int stride = 1; };
   std::vector<Entry> maps;
-  const Entry *Find(int lext, int rext) const {
-    for (auto &e : maps) if (e.lext == lext && e.rext == rext) return &e;
+  const Entry *Find(int lext, int rext, int stride = 1) const {
+    for (auto &e : maps) if (e.lext == lext && e.rext == rext && e.stride == stride) return &e;
     return nullptr;
   }
 };

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void BatchSetupKernel(BatchSetup b) {
       int lo = 0, hi = ls.n_segs;          // largest segment with seg_off[seg] <= i
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ls.seg_off[mid] <= i) lo = mid; else hi = mid; }
       const int k = lo / b.n_utts, u = lo % b.n_utts;
-      ls.out[i] = b.row_base[u] + ls.L + k * ls.slab_len + (i - ls.seg_off[lo]);
+      ls.out[i] = b.row_base[u] + ls.L + k * ls.slab_len + ls.first + ls.stride * (i - ls.seg_off[lo]);
       return;
     }
     blk -= nb;

@@ -90,7 +90,8 @@ struct BatchSetup {
   int n_utts, rows, L;
   const int *row_base, *ivrow_base;
   int *row_utt, *row_t, *row_ivec;      // row_ivec null: not written
-  struct List { int n_segs, total, L, slab_len; const int *seg_off; int *out; } lists[kMaxLists];
+  // element i of segment (k, u): row_base[u] + L + k * slab_len + first + stride * (i - seg_off)
+  struct List { int n_segs, total, L, slab_len; const int *seg_off; int *out; int stride, first; } lists[kMaxLists];
   int n_lists;
 };
 void LaunchBatchSetup(const BatchSetup &b, hipStream_t s);

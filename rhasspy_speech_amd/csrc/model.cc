@@ -737,7 +737,7 @@ void ReadNnetComponents(KaldiReader &r, std::vector<std::string> *names, std::ve
   r.ExpectToken("</Nnet3>");
 }
 
-void Nnet::Read(KaldiReader &r, int frames_per_chunk, int extra_left_context_initial) {
+void Nnet::Read(KaldiReader &r, int frames_per_chunk, int extra_left_context_initial, int frame_subsampling_factor) {
   r.ExpectToken("<Nnet3>");
   std::string line = r.ReadLine();
   if (!line.empty() && line.find_first_not_of(" \t") != std::string::npos) Fail("Expected newline in config file, got " + line);
@@ -757,7 +757,7 @@ void Nnet::Read(KaldiReader &r, int frames_per_chunk, int extra_left_context_ini
     const char *e = TuneEnv("RS_NO_COLLAPSE");
     const bool keep_layers = e && e[0] == '1';
     Nnet3SetupResult su = Nnet3Setup(cfg, keep_layers ? &names : &component_names, keep_layers ? &comps : &components, frames_per_chunk,
-                                     extra_left_context_initial);
+                                     extra_left_context_initial, frame_subsampling_factor);
     setup_rand_calls = su.rand_calls;
     setup_rand_certain = su.rand_calls_certain;
     setup_rand_uncertain_why = su.uncertain_why;
@@ -1104,10 +1104,35 @@ void Nnet::Compile() {
   }
 }
 
-void AcousticModel::Read(const std::string &final_mdl, int frames_per_chunk, int extra_left_context_initial) {
+// --frame-subsampling-factor f: the output is wanted at t = 0, f, 2 f, ... only (CreateComputationRequestInternal, nnet-compile-looped.cc:
+// 111-128) and the reference's compiler computes of every layer just the rows something reads.  Same here, in the one form a TDNN
+// stack needs: walking the ops backwards, the residues (t mod f) of every buffer that are read; a buffer read at residue 0 only is
+// evaluated on every f-th row (chain models: everything above the last layer with offsets that are not multiples of f).
+void Nnet::SetSubsampling(int factor) {
+  for (auto &b : bufs) b.stride = 1;
+  if (factor <= 1 || factor > 30 || output_buf < 0) return;
+  std::vector<unsigned> need(bufs.size(), 0u);
+  need[output_buf] = 1u;
+  auto mod = [&](int a) { int r = a % factor; return r < 0 ? r + factor : r; };
+  for (auto it = ops.rbegin(); it != ops.rend(); ++it) {
+    const unsigned out = need[it->out_buf];
+    auto reads = [&](int src, int off) {
+      if (src < 0) return;
+      for (int r = 0; r < factor; r++) if (out >> r & 1u) need[src] |= 1u << mod(r + off);
+    };
+    for (auto &sg : it->segs) reads(sg.src_buf, sg.offset);
+    for (auto &t : it->terms) reads(t.src_buf, t.offset);
+  }
+  for (size_t b = 0; b < bufs.size(); b++) if (!bufs[b].is_input && need[b] == 1u) bufs[b].stride = factor;
+  // an elementwise op runs over all rows of its buffers: keep its operands dense
+  for (auto &op : ops)
+    if (op.kind == LayerOp::kEltwise) { bufs[op.out_buf].stride = 1; for (auto &t : op.terms) if (t.src_buf >= 0) bufs[t.src_buf].stride = 1; }
+}
+
+void AcousticModel::Read(const std::string &final_mdl, int frames_per_chunk, int extra_left_context_initial, int frame_subsampling_factor) {
   KaldiReader r(final_mdl);
   trans.Read(r);
-  nnet.Read(r, frames_per_chunk, extra_left_context_initial);
+  nnet.Read(r, frames_per_chunk, extra_left_context_initial, frame_subsampling_factor);
   r.ExpectToken("<LeftContext>");
   r.ReadInt32();
   r.ExpectToken("<RightContext>");
@@ -1118,6 +1143,7 @@ void AcousticModel::Read(const std::string &final_mdl, int frames_per_chunk, int
   if (trans.num_pdfs != nnet.output_dim)
     Fail(final_mdl + ": transition model has " + std::to_string(trans.num_pdfs) + " pdfs but the nnet output dim is " + std::to_string(nnet.output_dim));
   nnet.Compile();
+  nnet.SetSubsampling(frame_subsampling_factor);
 }
 
 // =============================================================================== HCLG

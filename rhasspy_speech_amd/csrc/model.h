@@ -190,6 +190,7 @@ struct LayerOp {
 struct BufferInfo {
   int dim = 0, lext = 0, rext = 0;   // rows cover t in [-lext, T + rext)
   bool is_input = false;             // the MFCC ("input") buffer
+  int stride = 1;                    // > 1 (--frame-subsampling-factor): only the rows t = 0 mod stride are read by anybody
 };
 
 struct Nnet {
@@ -208,8 +209,9 @@ struct Nnet {
   long setup_rand_calls = 0;
   bool setup_rand_certain = true;
   std::string setup_rand_uncertain_why;
-  void Read(KaldiReader &r, int frames_per_chunk = 24, int extra_left_context_initial = 0);
+  void Read(KaldiReader &r, int frames_per_chunk = 24, int extra_left_context_initial = 0, int frame_subsampling_factor = 1);
   void Compile();   // builds ops/bufs for the "output" node
+  void SetSubsampling(int factor);   // fills BufferInfo::stride for outputs wanted at t = 0, factor, 2 factor, ...
   int FindNode(const std::string &name) const;
 };
 
@@ -219,7 +221,7 @@ void ReadNnetComponents(KaldiReader &r, std::vector<std::string> *names, std::ve
 struct AcousticModel {
   TransitionModel trans;
   Nnet nnet;
-  void Read(const std::string &final_mdl, int frames_per_chunk = 24, int extra_left_context_initial = 0);
+  void Read(const std::string &final_mdl, int frames_per_chunk = 24, int extra_left_context_initial = 0, int frame_subsampling_factor = 1);
 };
 
 // ---------------------------------------------------------------- HCLG

@@ -1046,7 +1046,8 @@ void ModifyIvectorPeriod(Net &net, int period) {
 }  // namespace
 
 Nnet3SetupResult Nnet3Setup(const std::vector<std::string> &config_lines, std::vector<std::string> *component_names,
-                            std::vector<Component> *components, int frames_per_chunk, int extra_left_context_initial) {
+                            std::vector<Component> *components, int frames_per_chunk, int extra_left_context_initial,
+                            int frame_subsampling_factor) {
   Nnet3SetupResult res;
   Rng rng;
   Net net = BuildNet(config_lines, component_names, components);
@@ -1074,7 +1075,8 @@ Nnet3SetupResult Nnet3Setup(const std::vector<std::string> &config_lines, std::v
   const int left = l + extra_left_context_initial, right = r;
   int chunk = frames_per_chunk;
   const int modulus = net.Modulus();
-  while (chunk % modulus != 0) chunk++;                              // GetChunkSize (nnet-compile-looped.cc:82-96)
+  const int fsf = std::max(frame_subsampling_factor, 1);
+  while (chunk % modulus != 0 || chunk % fsf != 0) chunk++;          // GetChunkSize (nnet-compile-looped.cc:82-96)
   const bool has_ivector = net.Find("ivector") != -1;
   if (has_ivector) ModifyIvectorPeriod(net, chunk);
   // CompileLooped (:326-345) -> CompileLoopedInternal with 5 requests (:131-300) -> Compiler::CreateComputation (nnet-compile.cc:50-62)
@@ -1084,7 +1086,7 @@ Nnet3SetupResult Nnet3Setup(const std::vector<std::string> &config_lines, std::v
     const int in0 = k == 0 ? -left : chunk + right + (k - 1) * chunk, in1 = k == 0 ? chunk + right : in0 + chunk;
     std::vector<Index> in, out, iv;
     for (int t = in0; t < in1; t++) in.push_back(Index{0, t, 0});
-    for (int t = k * chunk; t < (k + 1) * chunk; t++) out.push_back(Index{0, t, 0});
+    for (int t = k * chunk; t < (k + 1) * chunk; t += fsf) out.push_back(Index{0, t, 0});      // (CreateComputationRequestInternal, :111-128)
     GraphBuilder::Io ins{{"input", in}}, outs{{"output", out}};
     if (has_ivector) {
       std::vector<int> times;

@@ -37,7 +37,8 @@ struct Nnet3SetupResult {
 
 // `components` / `component_names` gain the combined components CollapseModel creates.
 Nnet3SetupResult Nnet3Setup(const std::vector<std::string> &config_lines, std::vector<std::string> *component_names,
-                            std::vector<Component> *components, int frames_per_chunk, int extra_left_context_initial);
+                            std::vector<Component> *components, int frames_per_chunk, int extra_left_context_initial,
+                            int frame_subsampling_factor = 1);
 
 // glibc rand() of a fresh process (stdlib/random_r.c, TYPE_3 additive feedback generator, seed 1) and rand_r()
 // (stdlib/rand_r.c), restated so that the host process's own rand() state is never touched.

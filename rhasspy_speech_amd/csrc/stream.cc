@@ -361,7 +361,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   SampleGemmMode(exact_gemm_.load(), cx.gemm_ovf_dev);
   const Nnet &nn = am_.nnet;
   const bool has_iv = fc_.ie.present;
-  const int C = fc_.mfcc.nceps, P = nn.output_dim, chunk = p->chunk, Rm = nn.right_context;
+  const int C = fc_.mfcc.nceps, P = nn.output_dim, chunk = p->chunk, Rm = nn.right_context, fsf = opts_.frame_subsampling_factor;
   const int shift = fc_.mfcc.shift;
   const int sl = has_iv ? fc_.ie.splice_left : 0, sr = has_iv ? fc_.ie.splice_right : 0;
   const int Dl = has_iv ? fc_.ie.feat_dim() : 0, Di = has_iv ? fc_.ie.ivector_dim() : 0, G = has_iv ? fc_.ie.num_gauss() : 0;
@@ -410,7 +410,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   // ---------------------------------------------------------------- transient geometry of the stages, index arrays
   IntStage is;
   std::vector<int> slots(n), row0s(n), avails(n);
-  for (int i = 0; i < n; i++) { slots[i] = streams[i]->slot; row0s[i] = streams[i]->row0; avails[i] = pl[i].avail; }
+  for (int i = 0; i < n; i++) { slots[i] = streams[i]->slot; row0s[i] = streams[i]->row0; avails[i] = (pl[i].avail + fsf - 1) / fsf; }
   // stage 1: MFCC over the new frames (dense rows, no halo), rows -> pool
   std::vector<int> m_T, m_rb{0}, m_out, m_f0;
   std::vector<int64_t> m_so{0};
@@ -470,7 +470,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   std::vector<int> N_idx;
   for (int i = 0; i < n; i++) if (pl[i].t1 > pl[i].t0) N_idx.push_back(i);
   const int nN = (int)N_idx.size();
-  std::vector<int> n_T(nN + 1, 0), n_rb(nN + 1, 0), n_fb(nN + 1, 0), n_src, n_riv, n_lldst;
+  std::vector<int> n_T(nN + 1, 0), n_rb(nN + 1, 0), n_fb(nN + 1, 0), n_src, n_riv, n_lldst, n_llsrc;
   {
     size_t rows_est = 0;
     for (int u = 0; u < nN; u++) rows_est += (size_t)(pl[N_idx[u]].t1 - pl[N_idx[u]].t0) + L_ + R_;
@@ -503,32 +503,38 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
         pr[r] = kv;
         if (++rem == chunk) { rem = 0; kv = k_of(++q); }
       }
-      const size_t l0 = n_lldst.size();
-      n_lldst.resize(l0 + n_T[u]);
-      int *pd = n_lldst.data() + l0;
-      for (int t = 0; t < n_T[u]; t++) pd[t] = st.row0 + a.t0 + t;
+      if (fsf == 1) {
+        const size_t l0 = n_lldst.size();
+        n_lldst.resize(l0 + n_T[u]);
+        int *pd = n_lldst.data() + l0;
+        for (int t = 0; t < n_T[u]; t++) pd[t] = st.row0 + a.t0 + t;
+      } else {
+        // --frame-subsampling-factor: the decoder's frame t / fsf is the output row of t = 0, fsf, 2 fsf, ...; only those go to the pool
+        for (int t = (a.t0 + fsf - 1) / fsf * fsf; t < a.t1; t += fsf) { n_llsrc.push_back(n_rb[u] + L_ + (t - a.t0)); n_lldst.push_back(st.row0 + t / fsf); }
+      }
     }
   }
   const int rowsN = n_rb[nN], framesN = n_fb[nN];
   // stage 5: search windows (every stream of the call: a stream that ends without new rows still needs its traceback)
   SearchPlan sp;
   int maxT = 0;
-  for (int i = 0; i < n; i++) maxT = std::max(maxT, pl[i].avail);
+  auto dec_frames = [&](int t) { return (t + fsf - 1) / fsf; };       // decoder frames of the first t feature frames (decodable-online-looped.cc:56-84)
+  for (int i = 0; i < n; i++) maxT = std::max(maxT, dec_frames(pl[i].avail));
   size_t search_bytes = 0;
   if (final) search_bytes = PlanSearch(n, maxT, nbest, lat_scale, &sp);
   const bool reg_windows = p->reg && !(final && sp.want_lattice);
   std::vector<int> d_T(n + 1, 0), d_rb(n + 1, 0), w_b(n), w_e(n), w_f(n, final ? 1 : 0);
   for (int i = 0; i < n; i++) {
-    d_T[i] = pl[i].t1; d_rb[i] = streams[i]->row0;
+    d_T[i] = dec_frames(pl[i].t1); d_rb[i] = streams[i]->row0;
     w_b[i] = streams[i]->dec_started ? streams[i]->frames_decoded : -1;
-    w_e[i] = pl[i].t1;
+    w_e[i] = dec_frames(pl[i].t1);
   }
   const size_t o_mT = is.Add(m_T), o_mrb = is.Add(m_rb), o_mout = is.Add(m_out), o_mf0 = is.Add(m_f0), o_mso = is.Add64(m_so);
   const size_t o_cT = is.Add(c_T), o_crb = is.Add(c_rb), o_ctb = is.Add(c_tb), o_cslot = is.Add(c_slot);
   const size_t o_iT = is.Add(i_T), o_irb = is.Add(i_rb), o_isrc = is.Add(i_src), o_islot = is.Add(i_slot);
   const size_t o_sfb = is.Add(s_fb), o_sfe = is.Add(s_fe), o_sor = is.Add(s_or), o_sac = is.Add(s_ac);
   is.Add(n_T);
-  const size_t o_nrb = is.Add(n_rb), o_nfb = is.Add(n_fb), o_nsrc = is.Add(n_src), o_nriv = is.Add(n_riv), o_nll = is.Add(n_lldst);
+  const size_t o_nrb = is.Add(n_rb), o_nfb = is.Add(n_fb), o_nsrc = is.Add(n_src), o_nriv = is.Add(n_riv), o_nll = is.Add(n_lldst), o_nlls = is.Add(n_llsrc);
   const size_t o_dT = is.Add(d_T), o_drb = is.Add(d_rb), o_wb = is.Add(w_b), o_we = is.Add(w_e), o_wf = is.Add(w_f), o_slots = is.Add(slots), o_row0 = is.Add(row0s);
   // ---------------------------------------------------------------- arena
   HOST_MARK(0);
@@ -659,8 +665,10 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     LaunchFrameRows(nN, nN, framesN, L_, std::max(maxTn, 1), D(o_nfb), D(o_nrb), frame_rows, q);
     RowMaps row_maps;
     row_maps.maps.push_back({0, 0, frame_rows, framesN});
+    if (fsf > 1 && !n_llsrc.empty()) row_maps.maps.push_back({0, 0, D(o_nlls), (int)n_llsrc.size(), 0, fsf});      // the layers only the decoder's frames read
     RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, row_maps, 1, 0, nn.ops.size(), q, &imgs);
-    LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
+    if (fsf == 1) LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
+    else if (!n_lldst.empty()) LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], D(o_nlls), p->ll, p->ld_ll, D(o_nll), (int)n_lldst.size(), P, q);
   }
   TM_MARK(tmb);
   // ---------------------------------------------------------------- 5. search (its own queue: the next advance's acoustic model does not wait for it)
@@ -695,7 +703,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     st.frames_mfcc = a.avail;
     st.stats_done = a.sb;
     st.ll_done = a.t1;
-    if (reg_windows) { st.frames_decoded = a.t1; st.dec_started = true; }
+    if (reg_windows) { st.frames_decoded = dec_frames(a.t1); st.dec_started = true; }
     // samples before the first frame that is not complete yet are not needed again (online-feature.cc:186-203)
     const long keep_from = (long)a.avail * shift;
     if (!st.keep_pcm && keep_from > st.pcm_start) {
@@ -730,7 +738,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   }
   // ---------------------------------------------------------------- results
   res->utts.resize(n);
-  for (int i = 0; i < n; i++) res->utts[i].num_frames = pl[i].avail;
+  for (int i = 0; i < n; i++) res->utts[i].num_frames = dec_frames(pl[i].avail);
   Timer tmr(qc);
   tmr.Mark();
   CollectResults(sp, cx, par, gd, avails.data(), p->ll, p->ld_ll, nbest, lat_scale, qc, res->utts.data(), res->timings);
@@ -744,9 +752,9 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
       ur.feat_dim = C; ur.num_pdfs = P; ur.ivec_dim = Di; ur.ivec_rows = has_iv ? nch : 0;
       if (T == 0) continue;
       ur.feats.resize((size_t)T * C);
-      ur.loglikes.resize((size_t)T * P);
+      ur.loglikes.resize((size_t)dec_frames(T) * P);
       RS_HIP(hipMemcpy2D(ur.feats.data(), sizeof(float) * C, fin + (size_t)st.row0 * ld_c, sizeof(float) * ld_c, sizeof(float) * C, T, hipMemcpyDeviceToHost));
-      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, p->ll + (size_t)st.row0 * p->ld_ll, sizeof(float) * p->ld_ll, sizeof(float) * P, T,
+      RS_HIP(hipMemcpy2D(ur.loglikes.data(), sizeof(float) * P, p->ll + (size_t)st.row0 * p->ld_ll, sizeof(float) * p->ld_ll, sizeof(float) * P, dec_frames(T),
                          hipMemcpyDeviceToHost));
       if (has_iv) {
         ur.ivector.resize((size_t)nch * Di);

@@ -51,6 +51,15 @@ CASES = {
     # (offline and streaming: checked with the pinned oracle when the case was chosen)
     "tiny_confopts_u15": dict(spec=dict(num_phones=40), graph="arpa:300:1500", audio="synth:15:44000",
                               opts=dict(max_active=60, beam=12.0), conf_opts={"min-active": 20, "frames-per-chunk": 30, "beam-delta": 0.25}),
+    # --frame-subsampling-factor (decodable-simple-looped.h:56; every chain recipe's value is 3; rhasspy leaves it at 1): the network is
+    # evaluated for t = 0, 3, 6, ... only, the decoder's frames are those, the chunk is rounded up to a multiple of the factor (20 -> 21)
+    "tiny_fsf3_u16": dict(spec=dict(layer_offsets=((0,), (-1, 0, 1), (-1, 0, 1), (-3, 0, 3))), graph="grammar", audio="synth:16:48000",
+                          conf_opts={"frame-subsampling-factor": 3}),
+    "tiny_fsf3_chunk20_u17": dict(spec=dict(num_phones=40), graph="arpa:300:1500", audio="synth:17:44000",
+                                  opts=dict(max_active=200, beam=14.0), conf_opts={"frame-subsampling-factor": 3, "frames-per-chunk": 20}),
+    "tiny_fsf2_noiv_u18": dict(spec=dict(ivector_dim=0, seed=9), graph="grammar", audio="synth:18:40001",
+                               conf_opts={"frame-subsampling-factor": 2}),
+    "zam_fsf3_u19": dict(big=True, spec=dict(), graph="grammar", audio="synth:19:48000", conf_opts={"frame-subsampling-factor": 3}),
 }
 NBEST = 5
 

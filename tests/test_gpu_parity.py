@@ -67,10 +67,12 @@ def test_offline_case(case_cache, name):
     assert res.text(0).split(b"\n")[0].split() == bytes(g["offline_nbest_text"]).split(b"\n")[0].split()
 
 
-def test_batch_matches_single(case_cache):
-    """Ragged batch: every utterance decodes exactly as it does alone (no cross-utterance leakage)."""
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_fsf3_u16", "tiny_fsf2_noiv_u18", "zam_fsf3_u19"])
+def test_batch_matches_single(case_cache, name):
+    """Ragged batch: every utterance decodes exactly as it does alone (no cross-utterance leakage) -- also with the upper layers
+    evaluated on every second / third row (--frame-subsampling-factor: the row lists then skip rows inside every utterance)."""
     from rhasspy_speech_amd import synth
-    model, _ = make_model(case_cache, "tiny_u0")
+    model, _ = make_model(case_cache, name)
     pcms = [synth.synth_utterance(20 + i, n) for i, n in enumerate([48000, 16000, 30000, 8000, 48000, 400, 24001])]
     batch = model.decode_batch(pcms)
     for i, p in enumerate(pcms):
@@ -78,6 +80,22 @@ def test_batch_matches_single(case_cache):
         assert batch.words(i) == single.words(0)
         assert np.array_equal(batch.matrix(i, 2), single.matrix(0, 2))
         assert batch.costs(i) == single.costs(0)
+
+
+@pytest.mark.parametrize("fsf", [2, 3, 5])
+def test_subsampled_log_likelihoods_are_every_nth_row_of_the_dense_ones(case_cache, fsf):
+    """--frame-subsampling-factor n: the decoder's frame f is output row n f, bit for bit the row the dense evaluation gives it (the
+    layers that are evaluated on every n-th row only run the same kernels through a row list); a model without dither, whose noise
+    would otherwise follow the factor through the reference's rand() count."""
+    from rhasspy_speech_amd import synth
+    pcms = [synth.synth_utterance(70 + i, n) for i, n in enumerate([36000, 16001, 5000, 700])]
+    dense = make_model(case_cache, "tiny_nodither_u11", frame_subsampling_factor=1)[0].decode_batch(pcms)
+    sub = make_model(case_cache, "tiny_nodither_u11", frame_subsampling_factor=fsf)[0].decode_batch(pcms)
+    for u in range(len(pcms)):
+        np.testing.assert_array_equal(sub.matrix(u, 0), dense.matrix(u, 0))
+        np.testing.assert_array_equal(sub.matrix(u, 1), dense.matrix(u, 1))
+        np.testing.assert_array_equal(sub.matrix(u, 2), dense.matrix(u, 2)[::fsf])
+        assert sub.num_frames(u) == (dense.num_frames(u) + fsf - 1) // fsf
 
 
 def test_too_short_utterance_fails_like_reference(case_cache):
@@ -383,7 +401,8 @@ def test_streaming_case(case_cache, name, mode):
     assert res.text(0).split() == bytes(g["stream_nbest_text"]).split()
 
 
-@pytest.mark.parametrize("name", ["tiny_u0", "tiny_noiv_u2", "tiny_cmvn_u4", "zam_u1", "zam_s12005", "tiny_arpa_u7"])
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_noiv_u2", "tiny_cmvn_u4", "zam_u1", "zam_s12005", "tiny_arpa_u7", "tiny_fsf3_chunk20_u17", "tiny_fsf2_noiv_u18",
+                                  "zam_fsf3_u19"])
 def test_incremental_stream_equals_batch_replay(case_cache, name, monkeypatch):
     """The incremental engine (stream.cc) against the batch replay of the same stream (DecodeGroup(streaming = true),
     RS_STREAM_BATCH=1): features, per-chunk iVectors and log-likelihoods bit for bit, same 1-best and n-best."""
@@ -472,9 +491,10 @@ def test_failed_advance_poisons_its_streams(case_cache, monkeypatch):
     assert c.finish().words(0) == ref
 
 
-def test_many_streams_one_batch(case_cache):
+@pytest.mark.parametrize("name", ["tiny_u0", "tiny_fsf3_u16"])
+def test_many_streams_one_batch(case_cache, name):
     from rhasspy_speech_amd import _lib, synth
-    model, _ = make_model(case_cache, "tiny_u0")
+    model, _ = make_model(case_cache, name)
     pcms = [synth.synth_utterance(500 + i, n) for i, n in enumerate([48000, 20000, 70000, 5000])]
     streams = [_lib.Stream(model) for _ in pcms]
     for s, p in zip(streams, pcms):

@@ -84,7 +84,7 @@ def test_decoder_options_of_online_conf_take_effect(case_cache, tmp_path):
 
 
 @pytest.mark.parametrize("line,needle", [
-    ("--frame-subsampling-factor=3", "--frame-subsampling-factor=3 is not supported"),
+    ("--frame-subsampling-factor=0", "KALDI_ASSERT: at Check:decodable-simple-looped.h:62"),
     ("--extra-left-context-initial=4", "--extra-left-context-initial=4 is not supported"),
     ("--prune-interval=10", "--prune-interval=10 is not supported"),
     ("--determinize-lattice=false", "--determinize-lattice=false is not supported"),
@@ -106,6 +106,33 @@ def test_online_conf_options_the_kernels_cannot_honour_fail_the_load(case_cache,
     with pytest.raises(_lib.RsError) as ei:
         _lib.Model(md, gd)
     assert needle in str(ei.value), str(ei.value)
+
+
+def test_frame_subsampling_factor_rounds_the_chunk_like_the_reference(case_cache, tmp_path):
+    """--frame-subsampling-factor from online.conf is taken (round 5: refused) and the chunk becomes the advised size rounded up to a
+    multiple of it (GetChunkSize, nnet-compile-looped.cc:81-94); an opts value overrides the file's."""
+    from rhasspy_speech_amd import _lib
+    md, gd = _with_online_conf(case_cache, tmp_path, ["--frame-subsampling-factor=3", "--frames-per-chunk=20"])
+    got = _decoder_opts(_lib.Model(md, gd).describe())
+    assert (got["frame_subsampling_factor"], got["frames_per_chunk"]) == ("3", "21")
+    got = _decoder_opts(_lib.Model(md, gd, _lib.default_opts(frame_subsampling_factor=2)).describe())
+    assert (got["frame_subsampling_factor"], got["frames_per_chunk"]) == ("2", "20")
+
+
+def test_frame_subsampling_evaluates_the_upper_layers_on_every_third_row(case_cache):
+    """Like the reference's compiler (the looped request asks for t = 0, 3, 6, ...: nnet-compile-looped.cc:111-128), the layer plan
+    evaluates a layer only where something reads it: with offsets (0) (-1,0,1) (-1,0,1) (-3,0,3) x 4 everything from the third
+    layer up is read at multiples of three only; with factor 1 every layer is dense, with factor 2 all but the last three."""
+    from rhasspy_speech_amd import _lib
+    md, gd = case_cache("zam_fsf3_u19")[:2]
+    ops = [l for l in _lib.Model(md, gd).describe().splitlines() if l.startswith("op: gemm")]
+    strided = ["rows=every-3" in l for l in ops]
+    assert strided == [False, False] + [True] * (len(ops) - 2), ops
+    ops1 = [l for l in _lib.Model(md, gd, _lib.default_opts(frame_subsampling_factor=1)).describe().splitlines() if l.startswith("op: gemm")]
+    assert not any("rows=every" in l for l in ops1)
+    ops2 = [l for l in _lib.Model(md, gd, _lib.default_opts(frame_subsampling_factor=2)).describe().splitlines() if l.startswith("op: gemm")]
+    # (the last (-3,0,3) layer reads its input at odd and even rows; its own output, the pre-final and the output layer are read at even rows)
+    assert [("rows=every-2" in l) for l in ops2] == [False] * (len(ops2) - 3) + [True, True, True], ops2
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "tiny_text_u1", "tinyf_u5", "tiny_noiv_u2", "tiny_hmm_u6", "tiny_vecfst_u9", "tiny_arpa_u7"])

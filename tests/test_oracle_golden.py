@@ -194,12 +194,14 @@ def test_setup_rand_calls_match_reference(name):
         synth.write_model_dir(Path(td) / "m", cases.case_spec(cases.CASES[name]))
         mdl = Path(td) / "m" / "model" / "model" / "final.mdl"
         _, nf = kf.read_final_mdl(mdl)
-        chunk = int(cases.CASES[name].get("conf_opts", {}).get("frames-per-chunk", 24))      # (the looped computation is compiled for the chunk size)
-        assert nnet3_rand.setup_rand_calls(nf, chunk) == want
+        co = cases.CASES[name].get("conf_opts", {})
+        chunk = int(co.get("frames-per-chunk", 24))      # (the looped computation is compiled for the chunk size ...
+        fsf = int(co.get("frame-subsampling-factor", 1))      # ... and the output frames t = 0, fsf, 2 fsf, ...)
+        assert nnet3_rand.setup_rand_calls(nf, chunk, 0, fsf) == want
         lib = load_library()
-        lib.rs_nnet3_setup.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
+        lib.rs_nnet3_setup_subsampled.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]
         n, cert, buf = C.c_int64(), C.c_int32(), C.create_string_buffer(1 << 16)
-        assert lib.rs_nnet3_setup(str(mdl).encode(), chunk, C.byref(n), C.byref(cert), buf, len(buf)) == 0
+        assert lib.rs_nnet3_setup_subsampled(str(mdl).encode(), chunk, fsf, C.byref(n), C.byref(cert), buf, len(buf)) == 0
         assert (n.value, cert.value) == (want, 1)
         cfg = buf.value.decode()
         assert "component-node name=lda " not in cfg and "component=lda.tdnn1.affine" in cfg
