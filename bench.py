@@ -525,6 +525,21 @@ def main() -> None:
         run_steps(n_tail, with_lattice)
         side["emit_lattice"] = figure(n_tail, time.perf_counter() - tl, "rs_decode_opts.emit_lattice = 1: every utterance's determinised CompactLattice kept with the result")
         del lat_model
+        # --frame-subsampling-factor=3 (how a chain model is meant to be decoded; rhasspy leaves the factor at 1): the decoder sees every
+        # third frame and the layers only those frames read run on a third of the rows.  Another search on other frames: no golden to
+        # check against here (the parity cases of tests/cases.py hold the reference's results for it)
+        fsf_model = _lib.Model(model_dir, graph_dir, _lib.default_opts(device_id=local_rank, prune_output_pdfs=0 if args.all_pdfs else 1, frame_subsampling_factor=3))
+        fsf_model.to_device()
+
+        def fsf3():
+            return fsf_model.decode_batch(pcms)
+        n_fsf = max(steps, 60)
+        run_steps(max(2, 2 * inflight), fsf3)
+        tf = time.perf_counter()
+        run_steps(n_fsf, fsf3)
+        side["frame_subsampling_factor_3"] = figure(n_fsf, time.perf_counter() - tf, "rs_decode_opts.frame_subsampling_factor = 3 on the same model and batch: "
+                                                    "100 decoder frames per utterance instead of 298 (not the reference's configuration for this metric; rhasspy runs factor 1)")
+        del fsf_model
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
     stage, counters, n_iso = np.zeros(8), np.zeros(8), 0

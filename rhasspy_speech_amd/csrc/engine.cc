@@ -1139,16 +1139,6 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
   const Nnet &nn = am_.nnet;
   const bool images_on = imgs != nullptr && GemmImagesEnabled() && !tls_exact_gemm && tls_gemm_ovf_dev != nullptr;
   if (op_begin == 0 && !tls_exact_gemm) ZeroGuards(bufp, buf_ld, rows, images_on ? imgs : nullptr, s);
-  if (op_begin == 0) {
-    // buffers evaluated on every stride-th row: the rows in between are read by nobody whose result is used, but kernels that run
-    // over all rows (image conversion, range check, prior scaling) must find numbers there, not what the arena held before
-    const int guard = L_ + R_ + 8;
-    for (size_t b = 0; b < nn.bufs.size(); b++) {
-      if (nn.bufs[b].stride <= 1) continue;
-      RS_HIP(hipMemsetAsync(bufp[b] - (size_t)guard * buf_ld[b], 0, ((size_t)rows + 2 * guard) * buf_ld[b] * sizeof(float), s));
-      if (images_on && (*imgs)[b].base) RS_HIP(hipMemsetAsync((*imgs)[b].base, 0, (size_t)kActImageParts * (*imgs)[b].part_bytes, s));
-    }
-  }
   for (size_t i = op_begin; i < op_end; i++) {
     const LayerOp &op = nn.ops[i];
     const bool img_out = images_on && (*imgs)[op.out_buf].base != nullptr;
@@ -1158,6 +1148,12 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       if (img_out && !GemmWritesImage(gd)) gd.write_f32 = 1;      // a kernel without the image epilogue: converted below
       else img_done = img_out;
       const BufferInfo &ob = nn.bufs[op.out_buf];
+      if (ob.stride > 1 && img_out && !img_done) {
+        // evaluated on every stride-th row, converted (and range-checked) over all rows: the rows in between must hold numbers,
+        // not what the arena held before (everything else that touches a strided buffer goes through the row list)
+        const int guard = L_ + R_ + 8;
+        RS_HIP(hipMemsetAsync(bufp[op.out_buf] - (size_t)guard * buf_ld[op.out_buf], 0, ((size_t)rows + 2 * guard) * buf_ld[op.out_buf] * sizeof(float), s));
+      }
       if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext, ob.stride)) {     // only the rows somebody reads
         gd.row_map = rm->rows;
         gd.row_map_span128 = rm->span128;
