@@ -42,7 +42,7 @@ typedef struct rs_stream rs_stream;
  * (util/parse-options.cc:328-345).  Same here: a field left at RS_OPT_UNSET takes online.conf's value if the file sets the option
  * and the reference's default otherwise; any other value wins over online.conf.  rs_default_opts() sets what rhasspy passes on
  * the command line (transcribe_wav.py:46-55: --max-active --lattice-beam --acoustic-scale --beam) and leaves the rest unset.
- * Options of online.conf the kernels cannot honour (--frame-subsampling-factor != 1, --extra-left-context-initial != 0,
+ * Options of online.conf the kernels cannot honour (--extra-left-context-initial != 0,
  * --prune-interval != 25, --determinize-lattice=false, --online=true, --do-endpointing=true) fail the model load. */
 #define RS_OPT_UNSET (-1)
 typedef struct rs_decode_opts {
@@ -53,7 +53,8 @@ typedef struct rs_decode_opts {
   float beam_delta;            /* --beam-delta      (unset; reference default 0.5) */
   float acoustic_scale;        /* --acoustic-scale of the decodable (1.0 as rhasspy runs it; reference default 0.1) */
   int32_t frames_per_chunk;    /* --frames-per-chunk (unset; reference default 24; only changes streaming iVector timing) */
-  int32_t frame_subsampling_factor; /* --frame-subsampling-factor (unset; must resolve to 1, the reference's default) */
+  int32_t frame_subsampling_factor; /* --frame-subsampling-factor (unset; reference default 1.  f > 1: the decoder's frames are the output
+                                     * rows t = 0, f, 2f, ...; frames_per_chunk is rounded up to a multiple of f: nnet-compile-looped.cc:81-94) */
   int32_t device_id;           /* HIP device ordinal */
   int32_t keep_intermediates;  /* 1: results keep features / iVectors / log-likelihoods for parity tests */
   int32_t max_tokens_per_frame;/* capacity of the per-frame token arrays on the device (0 = automatic) */
