@@ -531,9 +531,13 @@ __global__ __launch_bounds__(NT) void DecodeKernel(HclgDev h, DecodeOptsDev o, B
 // cost < closure cutoff and tot < closure cutoff), so link costs are bit-identical to the search's.
 // extra_cost is the exact fixpoint the reference's "while (changed)" loops converge to.
 template <int NT>
+struct LatticeCtx { float red_f[NT / 64]; int red_i[NT / 64]; float bcast_f[2]; int bcast_i[4]; };
+template <int NT>
 __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g,
                                                     const float *__restrict__ loglikes, int ld, DecodeWork w, LatticeWork lw) {
-  __shared__ BlockCtx<NT> c;
+  // (only what BlockMinArg needs: the search's BlockCtx is 97 KB of LDS, which kept every other kernel that needs LDS -- the next
+  // call's layer GEMMs -- off the CUs of a lattice pass for its 2.3 ms)
+  __shared__ LatticeCtx<NT> c;
   __shared__ int s_changed;
   const int u = blockIdx.x, tid = threadIdx.x;
   const int T = g.d_num_frames[u];

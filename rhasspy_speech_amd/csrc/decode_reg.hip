@@ -884,65 +884,76 @@ static void LaunchOne(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDe
   hipLaunchKernelGGL((RegDecodeKernel<NT, KE, KX>), dim3(g.n_utts), dim3(NT), smem, s, h, r, o, g, loglikes, ld, w, (int)smem, f_begin, f_end);
 }
 
-// Dense rows -> token lists, one workgroup per utterance: its four waves take the frames in turn, count the tokens of each (pass 1,
-// into frame_tok_off itself: a stream's finishing call hands over every frame of the stream, which no LDS array holds), wave 0
-// prefix-sums the counts in place, the waves write their frames' tokens in state order (pass 2; frame 0 starts with the start state's
-// token: the lattice's start is token 0).  More tokens than the utterance's slice of the token array holds: capacity flag, no lists.
-__global__ __launch_bounds__(256) void DenseToTokensKernel(HclgDev h, BatchGeom g, DenseWork dw, DecodeWork w) {
-  __shared__ int s_total;
-  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Dense rows -> token lists.  Three launches, the two that read the rows parallel over (utterance, frame): a wave per frame counts its
+// tokens (into frame_tok_off itself: a stream's finishing call hands over every frame of the stream), one wave per utterance
+// prefix-sums the counts in place and checks the capacity, a wave per frame writes its tokens in state order (frame 0 starts with the
+// start state's token: the lattice's start is token 0).  More tokens than the utterance's slice of the token array holds: capacity
+// flag, no lists.  (Round 4/5: one workgroup per utterance walked its frames in turn -- 150 dependent global reads per wave and pass,
+// 1.0 ms per 256 x 298 frames; this takes the time of reading the rows twice.)
+constexpr int kD2TFrames = 4;      // frames (waves) per workgroup
+__global__ __launch_bounds__(64 * kD2TFrames) void DenseCountKernel(HclgDev h, BatchGeom g, DenseWork dw, DecodeWork w) {
+  const int u = blockIdx.y, lane = threadIdx.x & 63, f = blockIdx.x * kD2TFrames + (threadIdx.x >> 6);
   const int T = g.d_num_frames[u], S = h.num_states;
   int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
-  if (T <= 0 || w.out_nwords[u] < 0) { for (int f = tid; f <= g.max_frames + 1; f += 256) frame_off[f] = 0; return; }
-  const size_t row0 = (size_t)u * (g.max_frames + 1);
-  const float *cost = dw.cost_rows + row0 * S;
-  const int *bp = dw.bp + row0 * S;
-  int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
-  for (int f = wave; f <= T; f += 4) {
-    int n = 0;
-    for (int s0 = 0; s0 < S; s0 += 64) { const int s = s0 + lane; n += __popcll(__ballot(s < S && cost[(size_t)f * S + s] < INFINITY)); }
-    if (lane == 0) frame_off[f] = n;
-  }
-  __syncthreads();
-  if (wave == 0) {      // exclusive prefix over the frames, 64 at a time
-    int carry = 0;
-    for (int f0 = 0; f0 <= T; f0 += 64) {
-      const int f = f0 + lane;
-      const int n = f <= T ? frame_off[f] : 0;
-      int inc = n;
+  if (f > g.max_frames + 1) return;
+  if (T <= 0 || w.out_nwords[u] < 0 || f > T) { if (lane == 0) frame_off[f] = 0; return; }
+  const float *cost = dw.cost_rows + ((size_t)u * (g.max_frames + 1) + f) * S;
+  int n = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) { const int s = s0 + lane; n += __popcll(__ballot(s < S && cost[s] < INFINITY)); }
+  if (lane == 0) frame_off[f] = n;
+}
+__global__ __launch_bounds__(64) void DenseScanKernel(BatchGeom g, DenseWork dw, DecodeWork w) {
+  const int u = blockIdx.x, lane = threadIdx.x;
+  const int T = g.d_num_frames[u];
+  int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  if (T <= 0 || w.out_nwords[u] < 0) return;      // (all zero already)
+  int carry = 0;
+  for (int f0 = 0; f0 <= T; f0 += 64) {            // exclusive prefix over the frames, 64 at a time
+    const int f = f0 + lane;
+    const int n = f <= T ? frame_off[f] : 0;
+    int inc = n;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-      if (f <= T) frame_off[f] = carry + inc - n;
-      carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) { frame_off[T + 1] = carry; s_total = carry; }
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    if (f <= T) frame_off[f] = carry + inc - n;
+    carry += __shfl(inc, 63, 64);
   }
-  __syncthreads();
-  if (s_total > w.tok_cap) {      // (workgroup-uniform; PlanSearch sizes the slice for every state of every frame, so this is a caller error)
-    for (int f = tid; f <= g.max_frames + 1; f += 256) frame_off[f] = 0;
-    if (tid == 0) { w.out_nwords[u] = -1; dw.counters[(size_t)u * 8 + 7] |= 1; }      // "decoder token capacity exceeded"
+  if (carry > w.tok_cap) {      // (PlanSearch sizes the slice for every state of every frame, so this is a caller error)
+    for (int f = lane; f <= g.max_frames + 1; f += 64) frame_off[f] = 0;
+    if (lane == 0) { w.out_nwords[u] = -1; dw.counters[(size_t)u * 8 + 7] |= 1; }      // "decoder token capacity exceeded"
     return;
   }
-  for (int f = wave; f <= T; f += 4) {
-    int run = frame_off[f];
-    if (f == 0) {      // the start token first
-      if (lane == 0) tokens[run] = make_int4(h.start, __float_as_int(cost[h.start]), -1, bp[h.start]);
-      run++;
-    }
-    for (int s0 = 0; s0 < S; s0 += 64) {
-      const int s = s0 + lane;
-      const float c = s < S ? cost[(size_t)f * S + s] : INFINITY;
-      const bool on = c < INFINITY && !(f == 0 && s == h.start);
-      const unsigned long long m = __ballot(on);
-      if (on) tokens[run + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(s, __float_as_int(c), -1, bp[(size_t)f * S + s]);
-      run += __popcll(m);
-    }
+  if (lane == 0) frame_off[T + 1] = carry;
+}
+__global__ __launch_bounds__(64 * kD2TFrames) void DenseWriteKernel(HclgDev h, BatchGeom g, DenseWork dw, DecodeWork w) {
+  const int u = blockIdx.y, lane = threadIdx.x & 63, f = blockIdx.x * kD2TFrames + (threadIdx.x >> 6);
+  const int T = g.d_num_frames[u], S = h.num_states;
+  if (T <= 0 || w.out_nwords[u] < 0 || f > T) return;
+  const int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  const size_t row = ((size_t)u * (g.max_frames + 1) + f) * S;
+  const float *cost = dw.cost_rows + row;
+  const int *bp = dw.bp + row;
+  int4 *tokens = w.tokens + (size_t)u * w.tok_cap;
+  int run = frame_off[f];
+  if (f == 0) {      // the start token first
+    if (lane == 0) tokens[run] = make_int4(h.start, __float_as_int(cost[h.start]), -1, bp[h.start]);
+    run++;
+  }
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const float c = s < S ? cost[s] : INFINITY;
+    const bool on = c < INFINITY && !(f == 0 && s == h.start);
+    const unsigned long long m = __ballot(on);
+    if (on) tokens[run + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(s, __float_as_int(c), -1, bp[s]);
+    run += __popcll(m);
   }
 }
 
 void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s) {
   if (g.n_utts == 0) return;
-  hipLaunchKernelGGL(DenseToTokensKernel, dim3(g.n_utts), dim3(256), 0, s, h, g, dw, w);
+  const dim3 grid((g.max_frames + 2 + kD2TFrames - 1) / kD2TFrames, g.n_utts);
+  hipLaunchKernelGGL(DenseCountKernel, grid, dim3(64 * kD2TFrames), 0, s, h, g, dw, w);
+  hipLaunchKernelGGL(DenseScanKernel, dim3(g.n_utts), dim3(64), 0, s, g, dw, w);
+  hipLaunchKernelGGL(DenseWriteKernel, grid, dim3(64 * kD2TFrames), 0, s, h, g, dw, w);
 }
 
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state

@@ -1371,11 +1371,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
   int *h_nw = harena.AllocT<int>(n_utts), *h_words = harena.AllocT<int>((size_t)n_utts * kWordsInline);
   float *h_costs = harena.AllocT<float>((size_t)n_utts * 4);
   long long *h_ctr = harena.AllocT<long long>((size_t)n_utts * 8);
-  RS_HIP(hipMemcpyAsync(h_nw, w.out_nwords, sizeof(int) * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpyAsync(h_costs, w.out_costs, sizeof(float) * 4 * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpyAsync(h_ctr, w.counters, sizeof(long long) * 8 * n_utts, hipMemcpyDeviceToHost, s));
-  RS_HIP(hipMemcpy2DAsync(h_words, sizeof(int) * kWordsInline, w.out_words, sizeof(int) * max_words, sizeof(int) * kWordsInline, n_utts,
-                          hipMemcpyDeviceToHost, s));
+  LaunchResultsToHost(w.out_nwords, w.out_costs, w.counters, w.out_words, max_words, std::min(kWordsInline, max_words), n_utts, h_nw, h_costs, h_ctr, h_words, s);
   RS_HIP(hipStreamSynchronize(s));
   RS_HIP(hipGetLastError());
   if (CheckGemmRange(cx)) throw RangeRetry{};      // an activation beyond the fp16 split's range: the call is repeated on the exact-FP32 GEMMs
@@ -1438,13 +1434,21 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       lw.arcs = static_cast<LatArc *>(ab.d); lw.arcs_cap = (int)ab.cap; lw.arcs_count = d_count;
       LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
       int *h_count = harena.AllocT<int>(1);
-      RS_HIP(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      LaunchCopyRows(d_count, 1, nullptr, h_count, 1, nullptr, 1, 1, s);
       RS_HIP(hipStreamSynchronize(s));
       const int count = *h_count;
       lt_mark(0);
       if (count <= (int)ab.cap) {
         LatArc *dst = harena.AllocT<LatArc>((size_t)count + 1);
-        if (count) RS_HIP(hipMemcpyAsync(dst, ab.d, sizeof(LatArc) * (size_t)count, hipMemcpyDeviceToHost, s));
+        // The arcs travel by a kernel that stores into the pinned block, not by the copy engine: with other calls in flight their
+        // 25 MB sample uploads are queued on that engine and this 5 MB copy waited behind them (0.15 ms alone, 5.4 ms with four
+        // calls in flight: profiles/micro/nbest_trace.sh)
+        if (count) {
+          static_assert(sizeof(LatArc) % 4 == 0, "copied as 32-bit words");
+          const size_t words = sizeof(LatArc) / 4 * (size_t)count, full = words / 1024, rem = words % 1024;
+          LaunchCopyRows(ab.d, 1024, nullptr, dst, 1024, nullptr, (int)full, 1024, s);
+          if (rem) LaunchCopyRows(static_cast<const unsigned *>(ab.d) + full * 1024, 1024, nullptr, reinterpret_cast<unsigned *>(dst) + full * 1024, 1024, nullptr, 1, (int)rem, s);
+        }
         RS_HIP(hipStreamSynchronize(s));
         h_arcs = dst; n_arcs = (size_t)count;
         lt_mark(1);
