@@ -548,6 +548,7 @@ __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, 
   const int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
   const float *finfo = w.frame_info + (size_t)u * (g.max_frames + 1) * 4;
   float *extra = lw.extra_cost + (size_t)u * w.tok_cap;
+  LatArc *my_arcs = lw.arcs + (size_t)u * lw.utt_cap;
   const float INF = INFINITY, beam = o.lattice_beam;
   const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
 
@@ -647,8 +648,8 @@ __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, 
       if (f == T) {
         const float fc = have_final ? h.final_cost[tk.x] : 0.f;
         if (fc < INF) {
-          const int k = atomicAdd(lw.arcs_count, 1);
-          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, -1, -1, fc, 0.f};
+          const int k = atomicAdd(&lw.arcs_count[u], 1);
+          if (k < lw.utt_cap) my_arcs[k] = LatArc{u, off + i, -1, -1, fc, 0.f};
         }
       } else if (cost <= cur_cutoff) {
         const unsigned a0 = h.arc_begin[tk.x] + h.num_ieps[tk.x], a1 = h.arc_begin[tk.x + 1];
@@ -662,8 +663,8 @@ __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, 
           if (j < 0) continue;
           const float le = extra[off_n + j] + (tot - __int_as_float(nxt[j].y));
           if (le > beam) continue;
-          const int k = atomicAdd(lw.arcs_count, 1);
-          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, off_n + j, (int)a, gc, ac - cost_offset};
+          const int k = atomicAdd(&lw.arcs_count[u], 1);
+          if (k < lw.utt_cap) my_arcs[k] = LatArc{u, off + i, off_n + j, (int)a, gc, ac - cost_offset};
         }
       }
       if (h.num_ieps[tk.x] != 0 && cost < closure_cutoff) {
@@ -677,8 +678,8 @@ __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, 
           if (j < 0) continue;
           const float le = extra[off + j] + (tot - __int_as_float(cur[j].y));
           if (le > beam) continue;
-          const int k = atomicAdd(lw.arcs_count, 1);
-          if (k < lw.arcs_cap) lw.arcs[k] = LatArc{u, off + i, off + j, (int)a, gc, 0.f};
+          const int k = atomicAdd(&lw.arcs_count[u], 1);
+          if (k < lw.utt_cap) my_arcs[k] = LatArc{u, off + i, off + j, (int)a, gc, 0.f};
         }
       }
     }
@@ -696,6 +697,27 @@ __global__ __launch_bounds__(NT) void LatticeKernel(HclgDev h, DecodeOptsDev o, 
     const int n = frame_off[1] - frame_off[0];
     for (int i = tid; i < n; i += NT) map_nxt[tokens[frame_off[0] + i].x] = -1;
   }
+}
+
+__global__ __launch_bounds__(256) void CompactArcsKernel(const LatArc *__restrict__ arcs, int utt_cap, const int *__restrict__ counts, int n_utts, LatArc *__restrict__ dst) {
+  __shared__ int s_part[4];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  int before = 0;
+  for (int v = tid; v < u; v += 256) before += min(counts[v], utt_cap);
+#pragma unroll
+  for (int o2 = 32; o2 > 0; o2 >>= 1) before += __shfl_xor(before, o2, 64);
+  if ((tid & 63) == 0) s_part[tid >> 6] = before;
+  __syncthreads();
+  const size_t base = (size_t)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  const int n = min(counts[u], utt_cap);
+  static_assert(sizeof(LatArc) == 24, "copied as 8-byte words");
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(arcs + (size_t)u * utt_cap);
+  unsigned long long *out = reinterpret_cast<unsigned long long *>(dst + base);
+  for (int i = tid; i < 3 * n; i += 256) out[i] = src[i];
+}
+void LaunchCompactArcs(const LatArc *arcs, int utt_cap, const int *counts, int n_utts, LatArc *dst, hipStream_t s) {
+  if (n_utts <= 0) return;
+  hipLaunchKernelGGL(CompactArcsKernel, dim3(n_utts), dim3(256), 0, s, arcs, utt_cap, counts, n_utts, dst);
 }
 
 void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,

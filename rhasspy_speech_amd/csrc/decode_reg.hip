@@ -18,8 +18,11 @@
 // conditions into exec-mask branches with a wait in front of each, which is what made the first version slow.
 // Compiled with -ffp-contract=off.
 #include "decode_common.h"
+#include "decode_tok.h"
 #include "wave_ops.h"
 #include "env.h"
+
+#include <string>
 
 #include <cstdlib>
 
@@ -948,12 +951,269 @@ __global__ __launch_bounds__(64 * kD2TFrames) void DenseWriteKernel(HclgDev h, B
   }
 }
 
-void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s) {
+void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s, bool write_tokens) {
   if (g.n_utts == 0) return;
   const dim3 grid((g.max_frames + 2 + kD2TFrames - 1) / kD2TFrames, g.n_utts);
   hipLaunchKernelGGL(DenseCountKernel, grid, dim3(64 * kD2TFrames), 0, s, h, g, dw, w);
   hipLaunchKernelGGL(DenseScanKernel, dim3(g.n_utts), dim3(64), 0, s, g, dw, w);
-  hipLaunchKernelGGL(DenseWriteKernel, grid, dim3(64 * kD2TFrames), 0, s, h, g, dw, w);
+  // (DenseLatticeKernel works on the rows themselves: it needs the frames' token offsets only)
+  if (write_tokens) hipLaunchKernelGGL(DenseWriteKernel, grid, dim3(64 * kD2TFrames), 0, s, h, g, dw, w);
+}
+
+// ===================================================================================== lattice extraction from the dense rows
+// LatticeKernel's backward pass (decode_kernels.hip: FinalizeDecoding = PruneForwardLinksFinal on the last frame, PruneForwardLinks
+// with delta 0 on every earlier one, lattice-faster-decoder.cc:299-458,625-640) for the graphs the register-resident search holds:
+// the same links, float expressions and existence rules, on the cost rows that search leaves behind instead of token lists.
+// Arcs live in registers for the whole utterance (arc i -> thread i % 256, slot i / 256) and are looked at arc-parallel; per-state
+// arrays (cost of this and the next frame, extra_cost of both as ordered bits -- non-negative floats order like their bit
+// patterns, so the min over a token's links is one LDS atomic --, token numbers of both) are in LDS; the next frame's cost row and
+// log-likelihoods are requested a frame ahead.  Token numbers are DenseWriteKernel's: the live states of a frame in state order
+// behind frame_tok_off (frame 0: the start state first).  A frame is ~6 barriers of LDS work; the token-list kernel's frame was
+// ~11 barriers with two to four dependent global round trips in each phase (2.3 ms per 256 x 298 frames).
+constexpr int kDLStatesPerThread = 8;       // S <= 2048
+constexpr unsigned kInfBits = 0x7f800000u;
+struct DenseLatticeCtx { float red_f[4]; int red_i[4]; float bcast_f[2]; int bcast_i[4]; };
+template <int KA>
+__global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g, const float *__restrict__ loglikes, int ld,
+                                                          DenseWork dw, DecodeWork w, LatticeWork lw, int has_eps) {
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
+  __shared__ DenseLatticeCtx c;
+  __shared__ int s_narcs;
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = g.d_num_frames[u];
+  if (T <= 0 || w.out_nwords[u] < 0) return;
+  if (tid == 0) s_narcs = 0;              // (barriers follow before its first use)
+  LatArc *my_arcs = lw.arcs + (size_t)u * lw.utt_cap;
+  const int S = h.num_states, A = h.num_arcs;
+  float *cost_a = reinterpret_cast<float *>(dl_smem), *cost_b = cost_a + S;
+  unsigned *ex_a = reinterpret_cast<unsigned *>(cost_b + S), *ex_b = ex_a + S;
+  unsigned short *rk_a = reinterpret_cast<unsigned short *>(ex_b + S), *rk_b = rk_a + S;
+  const int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
+  const float *finfo = dw.frame_info + (size_t)u * (g.max_frames + 1) * 4;
+  const float *rows = dw.cost_rows + (size_t)u * (g.max_frames + 1) * S;
+  const float INF = INFINITY, beam = o.lattice_beam;
+  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
+  // ---- this thread's arcs
+  int ax[KA];            // pdf + 1, 0 = epsilon arc, -1 = no arc
+  float aw[KA];
+  unsigned asd[KA];      // source | destination << 16
+#pragma unroll
+  for (int k = 0; k < KA; k++) {
+    const int a = tid + k * NT;
+    if (a < A) { const int4 arc = h.arcs[a]; ax[k] = arc.x; aw[k] = __int_as_float(arc.z); asd[k] = (unsigned)h.arc_src[a] | ((unsigned)arc.w << 16); }
+    else { ax[k] = -1; aw[k] = 0.f; asd[k] = 0u; }
+  }
+  // ---- the last frame's costs, final costs (ComputeFinalCosts)
+  float *cost_cur = cost_a, *cost_nxt = cost_b;
+  unsigned *ex_cur = ex_a, *ex_nxt = ex_b;
+  unsigned short *rk_cur = rk_a, *rk_nxt = rk_b;
+  float final_best;
+  bool have_final;
+  {
+    float lv1 = INF, lv2 = INF;
+    for (int s0 = 0; s0 < S; s0 += NT) {
+      const int st = s0 + tid;
+      if (st < S) {
+        const float cst = rows[(size_t)T * S + st];
+        cost_cur[st] = cst;
+        cost_nxt[st] = INF;
+        ex_nxt[st] = kInfBits;
+        lv1 = fminf(lv1, cst + h.final_cost[st]);
+        lv2 = fminf(lv2, cst);
+      }
+    }
+    float b1, b2;
+    int d1, d2;
+    tok::BlockMinArg<NT>(c, lv1, tid, &b1, &d1);
+    tok::BlockMinArg<NT>(c, lv2, tid, &b2, &d2);
+    have_final = b1 < INF;
+    final_best = have_final ? b1 : b2;
+  }
+  float llv[KA], pre_cost[kDLStatesPerThread];
+#pragma unroll
+  for (int k = 0; k < KA; k++) llv[k] = 0.f;
+  for (int f = T; f >= 0; f--) {
+    const int off = frame_off[f], off_n = frame_off[f + 1];
+    const float cost_offset = f < T ? finfo[f * 4 + 0] : 0.f, cur_cutoff = f < T ? finfo[f * 4 + 1] : 0.f, next_cutoff = f < T ? finfo[f * 4 + 2] : 0.f;
+    const float closure_cutoff = f > 0 ? finfo[(f - 1) * 4 + 2] : o.beam;
+    // requests for the frame below: its cost row, the log-likelihoods of this thread's emitting arcs
+    float ll_next[KA];
+    if (f > 0) {
+      const float *ll_row = loglikes + (ll_base + (size_t)(f - 1)) * ld;
+#pragma unroll
+      for (int k = 0; k < KA; k++) ll_next[k] = ax[k] > 0 ? ll_row[ax[k] - 1] : 0.f;
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) { const int st = q * NT + tid; pre_cost[q] = st < S ? rows[(size_t)(f - 1) * S + st] : INF; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KA; k++) ll_next[k] = 0.f;
+    }
+    __syncthreads();                     // cost_cur holds row f
+    // ---- token numbers of this frame (every wave counts all 64-state chunks for itself: no exchange), extra_cost's start values
+    {
+      int before = 0;                    // live states in the chunks before the one at hand
+      for (int c0 = 0; c0 < S; c0 += 64) {
+        const int st = c0 + lane;
+        const float cst = st < S ? cost_cur[st] : INF;
+        const bool live = cst < INF && !(f == 0 && st == h.start);      // (frame 0: the start state's token is number 0, the others follow)
+        const unsigned long long m = __ballot(live);
+        if ((c0 >> 6 & 3) == wave && st < S) {
+          rk_cur[st] = (unsigned short)((f == 0 ? 1 : 0) + before + __popcll(m & ((1ull << lane) - 1ull)));
+          if (f == 0 && st == h.start) rk_cur[st] = 0;
+          float e = INF;
+          if (f == T && cst < INF) e = cst + (have_final ? h.final_cost[st] : 0.f) - final_best;
+          ex_cur[st] = e < INF ? (__float_as_uint(e) & 0x7fffffffu) : kInfBits;
+        }
+        before += __popcll(m);
+      }
+    }
+    __syncthreads();
+    // ---- pass 1: emitting links into the next frame
+    if (f < T) {
+#pragma unroll
+      for (int k = 0; k < KA; k++) {
+        if (ax[k] <= 0) continue;
+        const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+        const float cs = cost_cur[src];
+        if (!(cs <= cur_cutoff)) continue;
+        const float ac = cost_offset - llv[k];
+        const float tot = (cs + ac) + aw[k];
+        if (!(tot < next_cutoff)) continue;
+        const float cn = cost_nxt[dst];
+        if (!(cn < INF)) continue;
+        float le = __uint_as_float(ex_nxt[dst]) + (tot - cn);
+        if (le > beam) continue;
+        if (le < 0.f) le = 0.f;
+        atomicMin(&ex_cur[src], __float_as_uint(le) & 0x7fffffffu);
+      }
+      __syncthreads();
+    }
+    // ---- pass 2: epsilon links inside the frame, to the fixpoint
+    if (has_eps) {
+      for (int round = 0; round < 1000; round++) {
+        int changed = 0;
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+          if (ax[k] != 0) continue;
+          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+          const float cs = cost_cur[src];
+          if (!(cs < closure_cutoff)) continue;
+          const float tot = cs + aw[k];
+          if (!(tot < closure_cutoff)) continue;
+          const float cd = cost_cur[dst];
+          if (!(cd < INF)) continue;
+          float le = __uint_as_float(__hip_atomic_load(&ex_cur[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + (tot - cd);
+          if (le > beam) continue;
+          if (le < 0.f) le = 0.f;
+          const unsigned nb = __float_as_uint(le) & 0x7fffffffu;
+          if (nb < atomicMin(&ex_cur[src], nb)) changed = 1;
+        }
+        if (!__syncthreads_or(changed)) break;
+      }
+    }
+    if (f == T) {
+      for (int st = tid; st < S; st += NT) if (__uint_as_float(ex_cur[st]) > beam) ex_cur[st] = kInfBits;
+      __syncthreads();
+    }
+    // ---- pass 3: the surviving links (and the final-cost records of the last frame); one counter update per wave
+    {
+      unsigned emit = 0u;                 // bit k: arc k is a link of the lattice
+      float e_ac[KA];
+      if (true) {
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+          e_ac[k] = 0.f;
+          if (ax[k] < 0) continue;
+          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+          if (!(__uint_as_float(ex_cur[src]) < INF)) continue;
+          const float cs = cost_cur[src];
+          if (ax[k] > 0) {
+            if (f == T || !(cs <= cur_cutoff)) continue;
+            const float ac = cost_offset - llv[k];
+            const float tot = (cs + ac) + aw[k];
+            if (!(tot < next_cutoff)) continue;
+            const float cn = cost_nxt[dst];
+            if (!(cn < INF)) continue;
+            const float le = __uint_as_float(ex_nxt[dst]) + (tot - cn);
+            if (le > beam) continue;
+            e_ac[k] = ac - cost_offset;
+            emit |= 1u << k;
+          } else {
+            if (!(cs < closure_cutoff)) continue;
+            const float tot = cs + aw[k];
+            if (!(tot < closure_cutoff)) continue;
+            const float cd = cost_cur[dst];
+            if (!(cd < INF)) continue;
+            const float le = __uint_as_float(ex_cur[dst]) + (tot - cd);
+            if (le > beam) continue;
+            emit |= 1u << k;
+          }
+        }
+      }
+      int n_mine = __popc(emit);
+      int fin_st = -1;                    // last frame: this thread's states with a final-cost record (at most kDLStatesPerThread; one at a time below)
+      int inc = n_mine;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+      const int wave_total = __shfl(inc, 63, 64);
+      int base = 0;
+      if (wave_total > 0) {
+        if (lane == 0) base = atomicAdd(&s_narcs, wave_total);      // (the utterance's own region: an LDS counter)
+        base = __shfl(base, 0, 64) + inc - n_mine;
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+          if (!(emit >> k & 1u)) continue;
+          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+          if (base < lw.utt_cap)
+            my_arcs[base] = ax[k] > 0 ? LatArc{u, off + (int)rk_cur[src], off_n + (int)rk_nxt[dst], tid + k * NT, aw[k], e_ac[k]}
+                                      : LatArc{u, off + (int)rk_cur[src], off + (int)rk_cur[dst], tid + k * NT, aw[k], 0.f};
+          base++;
+        }
+      }
+      if (f == T) {
+        for (int st = tid; st < S; st += NT) {
+          if (!(__uint_as_float(ex_cur[st]) < INF)) continue;
+          const float fc = have_final ? h.final_cost[st] : 0.f;
+          if (fc < INF) {
+            const int k2 = atomicAdd(&s_narcs, 1);
+            if (k2 < lw.utt_cap) my_arcs[k2] = LatArc{u, off + (int)rk_cur[st], -1, -1, fc, 0.f};
+          }
+        }
+      }
+      (void)fin_st;
+    }
+    __syncthreads();
+    // ---- frame f becomes "next"; the row requested at the top becomes "current"
+    { float *t1 = cost_cur; cost_cur = cost_nxt; cost_nxt = t1; }
+    { unsigned *t2 = ex_cur; ex_cur = ex_nxt; ex_nxt = t2; }
+    { unsigned short *t3 = rk_cur; rk_cur = rk_nxt; rk_nxt = t3; }
+    if (f > 0) {
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) { const int st = q * NT + tid; if (st < S) cost_cur[st] = pre_cost[q]; }
+#pragma unroll
+      for (int k = 0; k < KA; k++) llv[k] = ll_next[k];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) lw.arcs_count[u] = s_narcs;
+}
+
+bool DenseLatticeUsable(const HclgDev &h) {
+  const char *e = std::getenv("RS_LATTICE_KERNEL");      // "tokens": the token-list kernel (read per call: a test compares the two)
+  if (e && std::string(e) == "tokens") return false;
+  return h.num_states <= kDLStatesPerThread * 256 && h.num_arcs <= 32 * 256;
+}
+
+void LaunchDenseLattice(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DenseWork &dw,
+                        const DecodeWork &w, const LatticeWork &lw, bool has_eps, hipStream_t s) {
+  if (g.n_utts == 0) return;
+  const size_t smem = (size_t)h.num_states * (2 * 4 + 2 * 4 + 2 * 2) + 16;
+  const int ka = (h.num_arcs + 255) / 256;
+  const dim3 grid(g.n_utts), block(256);
+#define RS_DL(KA) hipLaunchKernelGGL((DenseLatticeKernel<KA>), grid, block, smem, s, h, o, g, loglikes, ld, dw, w, lw, has_eps ? 1 : 0)
+  if (ka <= 4) RS_DL(4); else if (ka <= 8) RS_DL(8); else if (ka <= 12) RS_DL(12); else if (ka <= 16) RS_DL(16); else if (ka <= 24) RS_DL(24); else RS_DL(32);
+#undef RS_DL
 }
 
 // the instantiations; RegDecodeConfig picks the first one the graph fits.  Workgroup size measured on MI355X (625-state

@@ -674,6 +674,8 @@ void Model::ToDevice() {
     hclg_dev_.start = hclg_.start;
     hclg_dev_.arc_begin = Upload(hclg_.arc_begin);
     hclg_dev_.num_ieps = Upload(hclg_.num_ieps);
+    hclg_has_eps_ = false;
+    for (auto n : hclg_.num_ieps) hclg_has_eps_ = hclg_has_eps_ || n != 0;
     {
       const int S = hclg_.num_states();
       std::vector<uint4> rec(S);
@@ -1315,7 +1317,7 @@ void Model::LaunchSearch(SearchPlan *sp, DeviceArena &arena_, const BatchGeom &g
   if (sp->use_dense) {
     if (sp->use_reg) LaunchDecodeReg(hclg_dev_, reg_dev_, sp->dopts, g, ll, ll_ld, sp->dw, -1, maxT + 1, s);
     else LaunchDecodeDense(hclg_dev_, rev_dev_, sp->dopts, g, ll, ll_ld, am_.nnet.output_dim, sp->dw, s);
-    if (sp->reg_lattice) LaunchDenseToTokens(hclg_dev_, g, sp->dw, sp->w, s);
+    if (sp->reg_lattice) LaunchDenseToTokens(hclg_dev_, g, sp->dw, sp->w, s, /*write_tokens=*/!DenseLatticeUsable(hclg_dev_));
     return;
   }
   DecodeWork &w = sp->w;
@@ -1416,57 +1418,50 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
     // extra_cost comes from the call's arena; the arc buffer is the context's own, grow-only: no hipMalloc / hipFree (a
     // device-wide synchronisation that would stall the other calls in flight) in the steady state
     lw.extra_cost = arena_.AllocT<float>((size_t)n_utts * tok_cap + 64);
-    int *d_count = arena_.AllocT<int>(4);
+    int *d_count = arena_.AllocT<int>((size_t)n_utts + 4);
     const LatArc *h_arcs = nullptr;          // pinned staging (the call's host arena): a pageable destination copied at 5 GB/s
     size_t n_arcs = 0;
     LatArcBuffer &ab = cx.lat_arcs[gi];
-    // RS_LATTICE_TRACE=1: where the tail's time goes (kernel + count, copy of the arcs to the host, grouping, the per-utterance jobs)
+    std::vector<int> ubegin(n_utts + 1, 0);  // the utterances' arcs in h_arcs: every utterance appends to its own region of the buffer
+    // RS_LATTICE_TRACE=1: where the tail's time goes (kernel + counts, arcs to the host, -, the per-utterance jobs)
     static const bool lat_trace = [] { const char *e = TuneEnv("RS_LATTICE_TRACE"); return e && std::atoi(e) != 0; }();
     auto lt0 = std::chrono::steady_clock::now();
     float lt_ms[4] = {0, 0, 0, 0};
     auto lt_mark = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lt_ms[i] += std::chrono::duration<float, std::milli>(n_ - lt0).count(); lt0 = n_; };
     for (int attempt = 0; attempt < 8; attempt++) {
-      if (ab.cap == 0) {
-        ab.cap = 1u << 20;
+      if (ab.cap < (size_t)n_utts * 256) {
+        if (ab.d) RS_HIP(hipFree(ab.d));
+        ab.cap = std::max<size_t>(1u << 20, (size_t)n_utts * 1024);
         RS_HIP(hipMalloc((void **)&ab.d, sizeof(LatArc) * ab.cap));
       }
-      RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int), s));
-      lw.arcs = static_cast<LatArc *>(ab.d); lw.arcs_cap = (int)ab.cap; lw.arcs_count = d_count;
-      LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
-      int *h_count = harena.AllocT<int>(1);
-      LaunchCopyRows(d_count, 1, nullptr, h_count, 1, nullptr, 1, 1, s);
+      RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int) * n_utts, s));
+      lw.arcs = static_cast<LatArc *>(ab.d); lw.utt_cap = (int)std::min<size_t>(ab.cap / n_utts, 0x7fffffff); lw.arcs_count = d_count;
+      if (sp.reg_lattice && DenseLatticeUsable(hclg_dev_)) LaunchDenseLattice(hclg_dev_, dopts, g, ll, ll_ld, sp.dw, w, lw, hclg_has_eps_, s);
+      else LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
+      // (counts and arcs travel by kernels that store into the pinned block, not by the copy engine: with other calls in flight their
+      // 25 MB sample uploads are queued on that engine and these copies waited behind them -- 0.15 ms alone, 5.4 ms with four calls
+      // in flight: profiles/micro/nbest_trace.sh)
+      int *h_count = harena.AllocT<int>(n_utts);
+      LaunchCopyRows(d_count, n_utts, nullptr, h_count, n_utts, nullptr, 1, n_utts, s);
       RS_HIP(hipStreamSynchronize(s));
-      const int count = *h_count;
+      int most = 0;
+      for (int u = 0; u < n_utts; u++) most = std::max(most, h_count[u]);
       lt_mark(0);
-      if (count <= (int)ab.cap) {
-        LatArc *dst = harena.AllocT<LatArc>((size_t)count + 1);
-        // The arcs travel by a kernel that stores into the pinned block, not by the copy engine: with other calls in flight their
-        // 25 MB sample uploads are queued on that engine and this 5 MB copy waited behind them (0.15 ms alone, 5.4 ms with four
-        // calls in flight: profiles/micro/nbest_trace.sh)
-        if (count) {
-          static_assert(sizeof(LatArc) % 4 == 0, "copied as 32-bit words");
-          const size_t words = sizeof(LatArc) / 4 * (size_t)count, full = words / 1024, rem = words % 1024;
-          LaunchCopyRows(ab.d, 1024, nullptr, dst, 1024, nullptr, (int)full, 1024, s);
-          if (rem) LaunchCopyRows(static_cast<const unsigned *>(ab.d) + full * 1024, 1024, nullptr, reinterpret_cast<unsigned *>(dst) + full * 1024, 1024, nullptr, 1, (int)rem, s);
-        }
+      if (most <= lw.utt_cap) {
+        for (int u = 0; u < n_utts; u++) ubegin[u + 1] = ubegin[u] + h_count[u];
+        n_arcs = (size_t)ubegin[n_utts];
+        LatArc *dst = harena.AllocT<LatArc>(n_arcs + 1);
+        if (n_arcs) LaunchCompactArcs(lw.arcs, lw.utt_cap, d_count, n_utts, dst, s);
         RS_HIP(hipStreamSynchronize(s));
-        h_arcs = dst; n_arcs = (size_t)count;
+        h_arcs = dst;
         lt_mark(1);
         break;
       }
       if (attempt == 7) Fail("lattice extraction: arc buffer overflow");
-      RS_HIP(hipFree(ab.d));                     // rare: the lattice outgrew the buffer
+      RS_HIP(hipFree(ab.d));                     // rare: an utterance's lattice outgrew its region
       ab.d = nullptr;
-      ab.cap = (size_t)count + (size_t)count / 4 + 1024;
+      ab.cap = ((size_t)most + (size_t)most / 4 + 256) * (size_t)n_utts;
       RS_HIP(hipMalloc((void **)&ab.d, sizeof(LatArc) * ab.cap));
-    }
-    // group by utterance: a stable counting sort of the arc indices (the kernel appends arcs in whatever order its workgroups finish)
-    std::vector<int> ubegin(n_utts + 1, 0), order(n_arcs);
-    for (size_t i = 0; i < n_arcs; i++) if (h_arcs[i].utt >= 0 && h_arcs[i].utt < n_utts) ubegin[h_arcs[i].utt + 1]++;
-    for (int u = 0; u < n_utts; u++) ubegin[u + 1] += ubegin[u];
-    {
-      std::vector<int> cur(ubegin.begin(), ubegin.end() - 1);
-      for (size_t i = 0; i < n_arcs; i++) if (h_arcs[i].utt >= 0 && h_arcs[i].utt < n_utts) order[cur[h_arcs[i].utt]++] = (int)i;
     }
     lt_mark(2);
     auto one = [&](int u) {
@@ -1482,11 +1477,11 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
         return k;
       };
       lat.start = sid(0);   // the start token is the first token of frame 0
-      for (int k = ubegin[u]; k < ubegin[u + 1]; k++) { const LatArc *a = h_arcs + order[k]; sid(a->src); if (a->arc >= 0) sid(a->dst); }
+      for (int k = ubegin[u]; k < ubegin[u + 1]; k++) { const LatArc *a = h_arcs + k; sid(a->src); if (a->arc >= 0) sid(a->dst); }
       lat.num_states = (int)id.size();
       lat.final_cost.assign(lat.num_states, std::numeric_limits<double>::infinity());
       for (int k = ubegin[u]; k < ubegin[u + 1]; k++) {
-        const LatArc *a = h_arcs + order[k];
+        const LatArc *a = h_arcs + k;
         if (a->arc < 0) { lat.final_cost[id[a->src]] = a->graph; continue; }
         lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic, hclg_.arcs[a->arc].ilabel});
       }

@@ -270,6 +270,7 @@ class Model {
   std::vector<GemmPlan> gemm_plans_;  // indexed like am_.nnet.ops (unused entries for eltwise ops)
   float *d_log_priors_ = nullptr;
   HclgDev hclg_dev_{};
+  bool hclg_has_eps_ = false;      // the graph has input-epsilon arcs (DenseLatticeKernel skips its closure pass otherwise)
   RevGraphDev rev_dev_{};
   RegGraphDev reg_dev_{};
   int decoder_choice_ = 0;      // RS_DECODER=reg|dense|sparse forces a kernel variant (tests); 0 = automatic

@@ -366,7 +366,12 @@ bool LaunchDecodeReg(const HclgDev &h, const RegGraphDev &r, const DecodeOptsDev
                      const float *loglikes, int ld, const DenseWork &w, int f_begin, int f_end, hipStream_t s, bool any_final = true);
 // Token lists (DecodeWork: tokens {state, cost bits, -, back-pointer arc}, frame_tok_off) out of the dense cost / back-pointer rows a
 // register-resident search with DenseWork::cost_rows left behind: what LatticeKernel reads.  Frame 0's first token is the start state's.
-void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s);
+void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &dw, const DecodeWork &w, hipStream_t s, bool write_tokens = true);
+// the lattice's links straight from the dense rows (graphs of at most 2048 states / 8192 arcs; RS_LATTICE_KERNEL=tokens: never)
+struct LatticeWork;
+bool DenseLatticeUsable(const HclgDev &h);
+void LaunchDenseLattice(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DenseWork &dw,
+                        const DecodeWork &w, const LatticeWork &lw, bool has_eps, hipStream_t s);
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
@@ -378,10 +383,15 @@ void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsD
 struct LatArc { int utt, src, dst, arc; float graph, acoustic; };   // arc = -1: final-cost record of token `src`
 struct LatticeWork {
   float *extra_cost;          // n_utts x tok_cap
-  LatArc *arcs;               // shared output buffer
-  int arcs_cap;
-  int *arcs_count;            // one global counter (may exceed arcs_cap: then the caller retries with a larger buffer)
+  // Every utterance appends to its own region [u * utt_cap, (u + 1) * utt_cap) of the buffer and counts in arcs_count[u] (which may
+  // exceed utt_cap: then the caller retries with a larger buffer).  One counter for the whole call was 220 000 - 300 000 returning
+  // atomics on one address per call -- most of the time of a lattice pass.
+  LatArc *arcs;
+  int utt_cap;
+  int *arcs_count;            // n_utts
 };
+// region u's first min(count[u], utt_cap) records -> dst, regions back to back (dst: page-locked host memory or device memory)
+void LaunchCompactArcs(const LatArc *arcs, int utt_cap, const int *counts, int n_utts, LatArc *dst, hipStream_t s);
 void LaunchLatticePrune(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld,
                         const DecodeWork &w, const LatticeWork &lw, hipStream_t s);
 
