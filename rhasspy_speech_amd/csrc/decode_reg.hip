@@ -970,24 +970,32 @@ void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &
 // log-likelihoods are requested a frame ahead.  Token numbers are DenseWriteKernel's: the live states of a frame in state order
 // behind frame_tok_off (frame 0: the start state first).  A frame is ~6 barriers of LDS work; the token-list kernel's frame was
 // ~11 barriers with two to four dependent global round trips in each phase (2.3 ms per 256 x 298 frames).
-constexpr int kDLStatesPerThread = 8;       // S <= 2048
+constexpr int kDLMaxStates = 2048, kDLMaxArcs = 8192;
+#ifdef RS_DL_PROFILE
+#define RS_DLP(i) do { const long long _n = clock64(); if (tid == 0) dlp[i] += _n - dl_last; dl_last = _n; } while (0)
+#else
+#define RS_DLP(i) do { } while (0)
+#endif
 constexpr unsigned kInfBits = 0x7f800000u;
-struct DenseLatticeCtx { float red_f[4]; int red_i[4]; float bcast_f[2]; int bcast_i[4]; };
-template <int KA>
-__global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g, const float *__restrict__ loglikes, int ld,
-                                                          DenseWork dw, DecodeWork w, LatticeWork lw, int has_eps) {
-  constexpr int NT = 256;
+template <int NT>
+struct DenseLatticeCtx { float red_f[NT / 64]; int red_i[NT / 64]; float bcast_f[2]; int bcast_i[4]; };
+template <int NT, int KA>
+__global__ __launch_bounds__(NT) void DenseLatticeKernel(HclgDev h, DecodeOptsDev o, BatchGeom g, const float *__restrict__ loglikes, int ld,
+                                                          DenseWork dw, DecodeWork w, LatticeWork lw, int eps_rounds) {
+  constexpr int kDLStatesPerThread = kDLMaxStates / NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
-  __shared__ DenseLatticeCtx c;
+  __shared__ DenseLatticeCtx<NT> c;
   __shared__ int s_narcs;
+  __shared__ int s_flag[3];
+  __shared__ int s_wtot[NT / 64];
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = g.d_num_frames[u];
   if (T <= 0 || w.out_nwords[u] < 0) return;
   if (tid == 0) s_narcs = 0;              // (barriers follow before its first use)
   LatArc *my_arcs = lw.arcs + (size_t)u * lw.utt_cap;
   const int S = h.num_states, A = h.num_arcs;
-  float *cost_a = reinterpret_cast<float *>(dl_smem), *cost_b = cost_a + S;
-  unsigned *ex_a = reinterpret_cast<unsigned *>(cost_b + S), *ex_b = ex_a + S;
+  float *cost_a = reinterpret_cast<float *>(dl_smem), *cost_b = cost_a + S, *cost_c = cost_b + S;
+  unsigned *ex_a = reinterpret_cast<unsigned *>(cost_c + S), *ex_b = ex_a + S;
   unsigned short *rk_a = reinterpret_cast<unsigned short *>(ex_b + S), *rk_b = rk_a + S;
   const int *frame_off = w.frame_tok_off + (size_t)u * (g.max_frames + 2);
   const float *finfo = dw.frame_info + (size_t)u * (g.max_frames + 1) * 4;
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsD
     else { ax[k] = -1; aw[k] = 0.f; asd[k] = 0u; }
   }
   // ---- the last frame's costs, final costs (ComputeFinalCosts)
-  float *cost_cur = cost_a, *cost_nxt = cost_b;
+  float *cost_cur = cost_a, *cost_nxt = cost_b, *cost_pre = cost_c;
   unsigned *ex_cur = ex_a, *ex_nxt = ex_b;
   unsigned short *rk_cur = rk_a, *rk_nxt = rk_b;
   float final_best;
@@ -1033,11 +1041,24 @@ __global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsD
   float llv[KA], pre_cost[kDLStatesPerThread];
 #pragma unroll
   for (int k = 0; k < KA; k++) llv[k] = 0.f;
+#ifdef RS_DL_PROFILE
+  long long dlp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl_last = clock64();
+#endif
+  int flag_round = 0;                    // (vote mode of the closure pass: three flags in rotation, one barrier per round)
+  if (tid < 3) s_flag[tid] = 0;
+  // The frame loop communicates through LDS only: its barriers order LDS traffic (dd::LdsBarrier) and leave the vector-memory counter
+  // alone, so the rows requested at the top of a frame and the arc records stored at its end are in flight across them.
+  // a frame's scalars (its token offset, cost offset and cutoffs) are requested two frames ahead as ordinary loads and ride along in
+  // registers: as scalar loads at the top of the frame they were a cache miss in front of the frame's first barrier
+  const float4 *finfo4 = reinterpret_cast<const float4 *>(finfo);
+  float4 fi_cur = make_float4(0.f, 0.f, 0.f, 0.f), fi_below = T > 0 ? finfo4[T - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+  int off = frame_off[T], off_n = frame_off[T + 1], off_below = T > 0 ? frame_off[T - 1] : 0;
   for (int f = T; f >= 0; f--) {
-    const int off = frame_off[f], off_n = frame_off[f + 1];
-    const float cost_offset = f < T ? finfo[f * 4 + 0] : 0.f, cur_cutoff = f < T ? finfo[f * 4 + 1] : 0.f, next_cutoff = f < T ? finfo[f * 4 + 2] : 0.f;
-    const float closure_cutoff = f > 0 ? finfo[(f - 1) * 4 + 2] : o.beam;
-    // requests for the frame below: its cost row, the log-likelihoods of this thread's emitting arcs
+    const float cost_offset = fi_cur.x, cur_cutoff = fi_cur.y, next_cutoff = fi_cur.z;      // (f == T: unused)
+    const float closure_cutoff = f > 0 ? fi_below.z : o.beam;
+    const float4 fi_pre = f > 1 ? finfo4[f - 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int off_pre = f > 1 ? frame_off[f - 2] : 0;
+    // requests for the frame below: its cost row, the log-likelihoods of this thread's emitting arcs (taken in before pass 3)
     float ll_next[KA];
     if (f > 0) {
       const float *ll_row = loglikes + (ll_base + (size_t)(f - 1)) * ld;
@@ -1048,125 +1069,147 @@ __global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsD
     } else {
 #pragma unroll
       for (int k = 0; k < KA; k++) ll_next[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) pre_cost[q] = INF;
     }
-    __syncthreads();                     // cost_cur holds row f
-    // ---- token numbers of this frame (every wave counts all 64-state chunks for itself: no exchange), extra_cost's start values
+    RS_DLP(0);
+    dd::LdsBarrier();                    // cost_cur holds row f
+    RS_DLP(1);
+    // ---- token numbers of this frame: a thread takes kDLStatesPerThread consecutive states, the block prefix of the live counts is a
+    // wave scan + four partial sums through LDS (a loop over 64-state chunks cost 3 300 cycles of a 12 000-cycle frame); extra_cost's
+    // start values
     {
-      int before = 0;                    // live states in the chunks before the one at hand
-      for (int c0 = 0; c0 < S; c0 += 64) {
-        const int st = c0 + lane;
-        const float cst = st < S ? cost_cur[st] : INF;
-        const bool live = cst < INF && !(f == 0 && st == h.start);      // (frame 0: the start state's token is number 0, the others follow)
-        const unsigned long long m = __ballot(live);
-        if ((c0 >> 6 & 3) == wave && st < S) {
-          rk_cur[st] = (unsigned short)((f == 0 ? 1 : 0) + before + __popcll(m & ((1ull << lane) - 1ull)));
-          if (f == 0 && st == h.start) rk_cur[st] = 0;
+      const int st0 = tid * kDLStatesPerThread;
+      float cst[kDLStatesPerThread];
+      unsigned live = 0u;
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) {
+        const int st = st0 + q;
+        cst[q] = st < S ? cost_cur[st] : INF;
+        live |= ((cst[q] < INF && !(f == 0 && st == h.start)) ? 1u : 0u) << q;      // (frame 0: the start state's token is number 0, the others follow)
+      }
+      const int n_live = __popc(live);
+      int inc = n_live;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+      if (lane == 63) s_wtot[wave] = inc;
+      dd::LdsBarrier();
+      int run = (f == 0 ? 1 : 0) + inc - n_live;
+#pragma unroll
+      for (int w2 = 0; w2 < NT / 64 - 1; w2++) run += w2 < wave ? s_wtot[w2] : 0;
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) {
+        const int st = st0 + q;
+        if (st < S) {
+          rk_cur[st] = (unsigned short)((f == 0 && st == h.start) ? 0 : run);
           float e = INF;
-          if (f == T && cst < INF) e = cst + (have_final ? h.final_cost[st] : 0.f) - final_best;
+          if (f == T && cst[q] < INF) e = cst[q] + (have_final ? h.final_cost[st] : 0.f) - final_best;
           ex_cur[st] = e < INF ? (__float_as_uint(e) & 0x7fffffffu) : kInfBits;
         }
-        before += __popcll(m);
+        run += (int)(live >> q & 1u);
       }
     }
-    __syncthreads();
-    // ---- pass 1: emitting links into the next frame
-    if (f < T) {
+    RS_DLP(2);
+    dd::LdsBarrier();
+    // ---- the per-arc operands of the frame, requested together (with `if ... continue` chains a thread went through four
+    // dependent LDS round trips per arc, twelve arcs, three passes: 5 us of a frame's 6)
+    float cs[KA], cdn[KA], tot[KA];
+    unsigned edn[KA];
 #pragma unroll
-      for (int k = 0; k < KA; k++) {
-        if (ax[k] <= 0) continue;
-        const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
-        const float cs = cost_cur[src];
-        if (!(cs <= cur_cutoff)) continue;
-        const float ac = cost_offset - llv[k];
-        const float tot = (cs + ac) + aw[k];
-        if (!(tot < next_cutoff)) continue;
-        const float cn = cost_nxt[dst];
-        if (!(cn < INF)) continue;
-        float le = __uint_as_float(ex_nxt[dst]) + (tot - cn);
-        if (le > beam) continue;
-        if (le < 0.f) le = 0.f;
-        atomicMin(&ex_cur[src], __float_as_uint(le) & 0x7fffffffu);
-      }
-      __syncthreads();
+    for (int k = 0; k < KA; k++) {
+      const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+      cs[k] = cost_cur[src];
+      cdn[k] = (ax[k] > 0 ? cost_nxt : cost_cur)[dst];      // the destination token's cost: next frame (emitting arc) or this one (epsilon arc)
+      edn[k] = ex_nxt[dst];
     }
-    // ---- pass 2: epsilon links inside the frame, to the fixpoint
-    if (has_eps) {
-      for (int round = 0; round < 1000; round++) {
+    // ---- pass 1: emitting links into the next frame
+    unsigned link_e = 0u, link_x = 0u;      // bit k: arc k meets the conditions that do not depend on this frame's extra costs
+    float acv[KA];
+#pragma unroll
+    for (int k = 0; k < KA; k++) {
+      acv[k] = cost_offset - llv[k];
+      const bool em = ax[k] > 0;
+      tot[k] = em ? (cs[k] + acv[k]) + aw[k] : cs[k] + aw[k];
+      const float le = __uint_as_float(edn[k]) + (tot[k] - cdn[k]);
+      const bool ok_e = em && f < T && cs[k] <= cur_cutoff && tot[k] < next_cutoff && cdn[k] < INF && !(le > beam);
+      const bool ok_x = ax[k] == 0 && cs[k] < closure_cutoff && tot[k] < closure_cutoff && cdn[k] < INF;
+      link_e |= (ok_e ? 1u : 0u) << k;
+      link_x |= (ok_x ? 1u : 0u) << k;
+      if (ok_e) atomicMin(&ex_cur[asd[k] & 0xFFFFu], __float_as_uint(le < 0.f ? 0.f : le) & 0x7fffffffu);
+    }
+    if (f < T) dd::LdsBarrier();
+    RS_DLP(3);
+    // ---- pass 2: epsilon links inside the frame, to the fixpoint: as many rounds as the longest epsilon path has arcs (known on
+    // the host for an acyclic epsilon subgraph), else until a round changes nothing
+    if (eps_rounds != 0) {
+      for (int round = 0; round < (eps_rounds > 0 ? eps_rounds : 1000); round++) {
         int changed = 0;
+        unsigned ed[KA];
+#pragma unroll
+        for (int k = 0; k < KA; k++) ed[k] = __hip_atomic_load(&ex_cur[asd[k] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int k = 0; k < KA; k++) {
-          if (ax[k] != 0) continue;
-          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
-          const float cs = cost_cur[src];
-          if (!(cs < closure_cutoff)) continue;
-          const float tot = cs + aw[k];
-          if (!(tot < closure_cutoff)) continue;
-          const float cd = cost_cur[dst];
-          if (!(cd < INF)) continue;
-          float le = __uint_as_float(__hip_atomic_load(&ex_cur[dst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + (tot - cd);
-          if (le > beam) continue;
-          if (le < 0.f) le = 0.f;
-          const unsigned nb = __float_as_uint(le) & 0x7fffffffu;
-          if (nb < atomicMin(&ex_cur[src], nb)) changed = 1;
+          const float le = __uint_as_float(ed[k]) + (tot[k] - cdn[k]);
+          if ((link_x >> k & 1u) && !(le > beam)) {
+            const unsigned nb = __float_as_uint(le < 0.f ? 0.f : le) & 0x7fffffffu;
+            if (eps_rounds > 0) atomicMin(&ex_cur[asd[k] & 0xFFFFu], nb);
+            else if (nb < atomicMin(&ex_cur[asd[k] & 0xFFFFu], nb)) changed = 1;
+          }
         }
-        if (!__syncthreads_or(changed)) break;
+        if (eps_rounds > 0) { dd::LdsBarrier(); continue; }
+        // flag r % 3 collects this round's votes; thread 0 clears the flag of the round after next in front of this round's barrier:
+        // that flag's last readers passed the barrier before, its next writers come after this one
+        const int fr = flag_round % 3;
+        if (tid == 0) s_flag[(flag_round + 1) % 3] = 0;
+        if (changed) s_flag[fr] = 1;
+        flag_round++;
+        dd::LdsBarrier();
+        if (!s_flag[fr]) break;
       }
     }
     if (f == T) {
       for (int st = tid; st < S; st += NT) if (__uint_as_float(ex_cur[st]) > beam) ex_cur[st] = kInfBits;
-      __syncthreads();
+      dd::LdsBarrier();
     }
-    // ---- pass 3: the surviving links (and the final-cost records of the last frame); one counter update per wave
+    RS_DLP(4);
+    // ---- the rows requested at the top are taken in here, before this frame's arc records are stored behind them
+    if (f > 0) {
+#pragma unroll
+      for (int q = 0; q < kDLStatesPerThread; q++) { const int st = q * NT + tid; if (st < S) cost_pre[st] = pre_cost[q]; }
+    }
+#pragma unroll
+    for (int k = 0; k < KA; k++) llv[k] = ll_next[k];
+    RS_DLP(5);
+    // ---- pass 3: the surviving links (and the final-cost records of the last frame); the utterance's own region of the arc buffer,
+    // an LDS counter, one update per wave
     {
       unsigned emit = 0u;                 // bit k: arc k is a link of the lattice
-      float e_ac[KA];
-      if (true) {
+      {
+        unsigned es[KA], ed[KA];
+#pragma unroll
+        for (int k = 0; k < KA; k++) { es[k] = ex_cur[asd[k] & 0xFFFFu]; ed[k] = ex_cur[asd[k] >> 16]; }
 #pragma unroll
         for (int k = 0; k < KA; k++) {
-          e_ac[k] = 0.f;
-          if (ax[k] < 0) continue;
-          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
-          if (!(__uint_as_float(ex_cur[src]) < INF)) continue;
-          const float cs = cost_cur[src];
-          if (ax[k] > 0) {
-            if (f == T || !(cs <= cur_cutoff)) continue;
-            const float ac = cost_offset - llv[k];
-            const float tot = (cs + ac) + aw[k];
-            if (!(tot < next_cutoff)) continue;
-            const float cn = cost_nxt[dst];
-            if (!(cn < INF)) continue;
-            const float le = __uint_as_float(ex_nxt[dst]) + (tot - cn);
-            if (le > beam) continue;
-            e_ac[k] = ac - cost_offset;
-            emit |= 1u << k;
-          } else {
-            if (!(cs < closure_cutoff)) continue;
-            const float tot = cs + aw[k];
-            if (!(tot < closure_cutoff)) continue;
-            const float cd = cost_cur[dst];
-            if (!(cd < INF)) continue;
-            const float le = __uint_as_float(ex_cur[dst]) + (tot - cd);
-            if (le > beam) continue;
-            emit |= 1u << k;
-          }
+          const bool src_ok = __uint_as_float(es[k]) < INF;
+          const bool x_ok = (link_x >> k & 1u) && !(__uint_as_float(ed[k]) + (tot[k] - cdn[k]) > beam);
+          emit |= ((src_ok && ((link_e >> k & 1u) || x_ok)) ? 1u : 0u) << k;
         }
       }
-      int n_mine = __popc(emit);
-      int fin_st = -1;                    // last frame: this thread's states with a final-cost record (at most kDLStatesPerThread; one at a time below)
+      const int n_mine = __popc(emit);
       int inc = n_mine;
 #pragma unroll
       for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
       const int wave_total = __shfl(inc, 63, 64);
-      int base = 0;
       if (wave_total > 0) {
-        if (lane == 0) base = atomicAdd(&s_narcs, wave_total);      // (the utterance's own region: an LDS counter)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_narcs, wave_total);
         base = __shfl(base, 0, 64) + inc - n_mine;
 #pragma unroll
         for (int k = 0; k < KA; k++) {
           if (!(emit >> k & 1u)) continue;
           const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
           if (base < lw.utt_cap)
-            my_arcs[base] = ax[k] > 0 ? LatArc{u, off + (int)rk_cur[src], off_n + (int)rk_nxt[dst], tid + k * NT, aw[k], e_ac[k]}
+            my_arcs[base] = ax[k] > 0 ? LatArc{u, off + (int)rk_cur[src], off_n + (int)rk_nxt[dst], tid + k * NT, aw[k], acv[k] - cost_offset}
                                       : LatArc{u, off + (int)rk_cur[src], off + (int)rk_cur[dst], tid + k * NT, aw[k], 0.f};
           base++;
         }
@@ -1181,38 +1224,42 @@ __global__ __launch_bounds__(256) void DenseLatticeKernel(HclgDev h, DecodeOptsD
           }
         }
       }
-      (void)fin_st;
     }
-    __syncthreads();
-    // ---- frame f becomes "next"; the row requested at the top becomes "current"
-    { float *t1 = cost_cur; cost_cur = cost_nxt; cost_nxt = t1; }
+    // ---- frame f becomes "next", the row taken in above "current", the old "next" is free (its readers are behind the next barrier:
+    // nobody writes it before the top-of-frame barrier of the frame after)
+    RS_DLP(6);
+    { float *t1 = cost_nxt; cost_nxt = cost_cur; cost_cur = cost_pre; cost_pre = t1; }
+    fi_cur = fi_below; fi_below = fi_pre;
+    off_n = off; off = off_below; off_below = off_pre;
     { unsigned *t2 = ex_cur; ex_cur = ex_nxt; ex_nxt = t2; }
     { unsigned short *t3 = rk_cur; rk_cur = rk_nxt; rk_nxt = t3; }
-    if (f > 0) {
-#pragma unroll
-      for (int q = 0; q < kDLStatesPerThread; q++) { const int st = q * NT + tid; if (st < S) cost_cur[st] = pre_cost[q]; }
-#pragma unroll
-      for (int k = 0; k < KA; k++) llv[k] = ll_next[k];
-    }
   }
   __syncthreads();
   if (tid == 0) lw.arcs_count[u] = s_narcs;
+#ifdef RS_DL_PROFILE
+  if (tid == 0 && (u == 0 || u == 100)) printf("dense lattice block %d T=%d arcs=%d: top %lld barrier0 %lld rank %lld operands+pass1 %lld pass2 %lld take-in %lld pass3 %lld\n", u, T, s_narcs, dlp[0], dlp[1], dlp[2], dlp[3], dlp[4], dlp[5], dlp[6]);
+#endif
 }
 
 bool DenseLatticeUsable(const HclgDev &h) {
   const char *e = std::getenv("RS_LATTICE_KERNEL");      // "tokens": the token-list kernel (read per call: a test compares the two)
   if (e && std::string(e) == "tokens") return false;
-  return h.num_states <= kDLStatesPerThread * 256 && h.num_arcs <= 32 * 256;
+  return h.num_states <= kDLMaxStates && h.num_arcs <= kDLMaxArcs;
 }
 
 void LaunchDenseLattice(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DenseWork &dw,
-                        const DecodeWork &w, const LatticeWork &lw, bool has_eps, hipStream_t s) {
+                        const DecodeWork &w, const LatticeWork &lw, int eps_rounds, hipStream_t s) {
   if (g.n_utts == 0) return;
-  const size_t smem = (size_t)h.num_states * (2 * 4 + 2 * 4 + 2 * 2) + 16;
-  const int ka = (h.num_arcs + 255) / 256;
-  const dim3 grid(g.n_utts), block(256);
-#define RS_DL(KA) hipLaunchKernelGGL((DenseLatticeKernel<KA>), grid, block, smem, s, h, o, g, loglikes, ld, dw, w, lw, has_eps ? 1 : 0)
-  if (ka <= 4) RS_DL(4); else if (ka <= 8) RS_DL(8); else if (ka <= 12) RS_DL(12); else if (ka <= 16) RS_DL(16); else if (ka <= 24) RS_DL(24); else RS_DL(32);
+  const size_t smem = (size_t)h.num_states * (3 * 4 + 2 * 4 + 2 * 2) + 16;
+  // 512 threads: a wave alone on its SIMD issues an instruction every ~10 cycles whatever it is, and a frame is per-arc instructions
+  // (256 / 512 / 1024 threads: 1.9 / 1.3 / 1.3 ms per 256 x 298 frames, profiles/micro/dl_nt.sh; RS_DL_NT in a -DRS_TUNING build)
+  static const int nt = [] { const char *e = TuneEnv("RS_DL_NT"); const int v = e ? std::atoi(e) : 512; return v == 256 || v == 1024 ? v : 512; }();
+  const int ka = (h.num_arcs + nt - 1) / nt;
+  const dim3 grid(g.n_utts);
+#define RS_DL(NT, KA) hipLaunchKernelGGL((DenseLatticeKernel<NT, KA>), grid, dim3(NT), smem, s, h, o, g, loglikes, ld, dw, w, lw, eps_rounds)
+  if (nt == 1024) { if (ka <= 1) RS_DL(1024, 1); else if (ka <= 2) RS_DL(1024, 2); else if (ka <= 3) RS_DL(1024, 3); else if (ka <= 4) RS_DL(1024, 4); else if (ka <= 6) RS_DL(1024, 6); else RS_DL(1024, 8); }
+  else if (nt == 512) { if (ka <= 2) RS_DL(512, 2); else if (ka <= 4) RS_DL(512, 4); else if (ka <= 6) RS_DL(512, 6); else if (ka <= 8) RS_DL(512, 8); else if (ka <= 12) RS_DL(512, 12); else RS_DL(512, 16); }
+  else { if (ka <= 4) RS_DL(256, 4); else if (ka <= 8) RS_DL(256, 8); else if (ka <= 12) RS_DL(256, 12); else if (ka <= 16) RS_DL(256, 16); else if (ka <= 24) RS_DL(256, 24); else RS_DL(256, 32); }
 #undef RS_DL
 }
 

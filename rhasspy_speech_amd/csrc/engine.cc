@@ -1436,7 +1436,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       }
       RS_HIP(hipMemsetAsync(d_count, 0, sizeof(int) * n_utts, s));
       lw.arcs = static_cast<LatArc *>(ab.d); lw.utt_cap = (int)std::min<size_t>(ab.cap / n_utts, 0x7fffffff); lw.arcs_count = d_count;
-      if (sp.reg_lattice && DenseLatticeUsable(hclg_dev_)) LaunchDenseLattice(hclg_dev_, dopts, g, ll, ll_ld, sp.dw, w, lw, hclg_has_eps_, s);
+      if (sp.reg_lattice && DenseLatticeUsable(hclg_dev_)) LaunchDenseLattice(hclg_dev_, dopts, g, ll, ll_ld, sp.dw, w, lw, hclg_has_eps_ ? reg_dev_.eps_depth : 0, s);
       else LaunchLatticePrune(hclg_dev_, dopts, g, ll, ll_ld, w, lw, s);
       // (counts and arcs travel by kernels that store into the pinned block, not by the copy engine: with other calls in flight their
       // 25 MB sample uploads are queued on that engine and these copies waited behind them -- 0.15 ms alone, 5.4 ms with four calls

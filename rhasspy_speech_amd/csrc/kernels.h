@@ -371,7 +371,7 @@ void LaunchDenseToTokens(const HclgDev &h, const BatchGeom &g, const DenseWork &
 struct LatticeWork;
 bool DenseLatticeUsable(const HclgDev &h);
 void LaunchDenseLattice(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DenseWork &dw,
-                        const DecodeWork &w, const LatticeWork &lw, bool has_eps, hipStream_t s);
+                        const DecodeWork &w, const LatticeWork &lw, int eps_rounds, hipStream_t s);   // eps_rounds: RegGraphDev::eps_depth
 size_t DenseDecodeSmemBytes(int num_states, int num_pdfs);
 bool DenseDecodeFits(int num_states, int num_pdfs);
 void LaunchDecodeDense(const HclgDev &h, const RevGraphDev &r, const DecodeOptsDev &o, const BatchGeom &g,
