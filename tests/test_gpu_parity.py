@@ -242,12 +242,13 @@ def test_decoder_variants_agree_on_a_graph_of_a_few_thousand_states(tmp_path, mo
 
 
 @pytest.mark.parametrize("name,extra", [("tiny_u0", {}), ("zam_u0", {}), ("zam_u0", dict(max_active=150, min_active=100, beam=10.0)),
-                                        ("zam_u1", dict(max_active=40, min_active=0, beam=16.0))])
+                                        ("zam_u1", dict(max_active=40, min_active=0, beam=16.0)), ("tiny_hmm_u6", {}), ("tinyf_u5", {}), ("tiny_vecfst_u9", {}),
+                                        ("tiny_fsf3_u16", {})])
 def test_lattice_from_the_register_resident_search_is_the_token_list_searchs(case_cache, name, extra, monkeypatch):
     """n-best / lattice calls on grammar graphs run the register-resident search, which leaves the costs of every (frame, state) pair
-    beside its back-pointer rows, and turn those rows into the token lists LatticeKernel reads (LaunchDenseToTokens);
-    RS_LATTICE_SEARCH=tokens runs the token-list search instead, as every round before: the same lattice (arc count), the same
-    n-best lists and costs, batch and stream."""
+    beside its back-pointer rows, and the lattice pass on those rows (DenseLatticeKernel, round 5).  RS_LATTICE_KERNEL=tokens turns the
+    rows into token lists and runs LatticeKernel on them (round 4's path); RS_LATTICE_SEARCH=tokens runs the token-list search in front
+    of it, as every round before: the same lattice (arc count), the same n-best lists and costs, batch and stream."""
     from rhasspy_speech_amd import _lib, synth
     model, pcm = make_model(case_cache, name, **extra)
     pcms = [pcm] + [synth.synth_utterance(1300 + i, n) for i, n in enumerate([48000, 9000, 33000, 1700])]
@@ -260,15 +261,19 @@ def test_lattice_from_the_register_resident_search_is_the_token_list_searchs(cas
             st.advance()
         return b, st.finish(5, 1.0)
     got_b, got_s = run()
+    monkeypatch.setenv("RS_LATTICE_KERNEL", "tokens")
+    mid_b, mid_s = run()
+    monkeypatch.delenv("RS_LATTICE_KERNEL")
     monkeypatch.setenv("RS_LATTICE_SEARCH", "tokens")
     ref_b, ref_s = run()
-    for got, ref, n in ((got_b, ref_b, len(pcms)), (got_s, ref_s, 1)):
-        for u in range(n):
-            assert got.num_hyps(u) == ref.num_hyps(u), u
-            assert got.counters(u)[4] == ref.counters(u)[4], u          # arcs of the raw lattice
-            for k in range(ref.num_hyps(u)):
-                assert got.words(u, k) == ref.words(u, k), (u, k)
-                np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
+    for got_b, got_s in ((got_b, got_s), (mid_b, mid_s)):
+        for got, ref, n in ((got_b, ref_b, len(pcms)), (got_s, ref_s, 1)):
+            for u in range(n):
+                assert got.num_hyps(u) == ref.num_hyps(u), u
+                assert got.counters(u)[4] == ref.counters(u)[4], u          # arcs of the raw lattice
+                for k in range(ref.num_hyps(u)):
+                    assert got.words(u, k) == ref.words(u, k), (u, k)
+                    np.testing.assert_allclose(got.costs(u, k), ref.costs(u, k), rtol=1e-6)
 
 
 @pytest.mark.parametrize("name,extra", VARIANT_CASES)
