@@ -1250,6 +1250,7 @@ bool DenseLatticeUsable(const HclgDev &h) {
 void LaunchDenseLattice(const HclgDev &h, const DecodeOptsDev &o, const BatchGeom &g, const float *loglikes, int ld, const DenseWork &dw,
                         const DecodeWork &w, const LatticeWork &lw, int eps_rounds, hipStream_t s) {
   if (g.n_utts == 0) return;
+  { const char *e = std::getenv("RS_LATTICE_KERNEL"); if (e && std::string(e) == "vote" && eps_rounds != 0) eps_rounds = -1; }      // (tests: closure rounds until nothing changes)
   const size_t smem = (size_t)h.num_states * (3 * 4 + 2 * 4 + 2 * 2) + 16;
   // 512 threads: a wave alone on its SIMD issues an instruction every ~10 cycles whatever it is, and a frame is per-arc instructions
   // (256 / 512 / 1024 threads: 1.9 / 1.3 / 1.3 ms per 256 x 298 frames, profiles/micro/dl_nt.sh; RS_DL_NT in a -DRS_TUNING build)
