@@ -120,6 +120,9 @@ void rs_stream_free(rs_stream *stream);
  * device work those samples make possible (MFCC of the completed frames, the iVector estimates and nnet chunks of the ticks
  * reached, the search over the new rows -- what online2-cli-nnet3-decode-faster.cc:143-161 does per tick), so that
  * rs_streams_finish (stdin EOF for all listed streams) only has the tail left; result utterance i belongs to streams[i].
+ * A call that finds less than 16 ticks (1 s) of new audio on every listed stream leaves them to the next call: an advance is
+ * chains of small dependent launches whose length hardly depends on the rows, and nothing but the end of a stream reads its
+ * results -- same rows, same results, a third fewer milliseconds per hour of audio (RS_STREAM_MIN_TICKS=1: every call works).
  * An advance that fails leaves the streams it listed unusable (every later call on them except rs_stream_free is refused). */
 int rs_streams_accept(rs_stream *const *streams, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_streams);
     /* rs_stream_accept for many streams in one call: pcm[i] / n_samples[i] go to streams[i] (a host that serves hundreds of streams

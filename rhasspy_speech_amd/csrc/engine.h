@@ -199,7 +199,10 @@ class Model {
     hipEvent_t stage_ev[3] = {};           // end of this call's feature + iVector stage / of its acoustic-model stage / of its sample upload (StageChain)
     int *gemm_ovf = nullptr, *gemm_ovf_dev = nullptr;      // pinned + mapped word and the device's address of it (see exact_gemm_)
     hipEvent_t split_ev = nullptr;         // what `stream` held when a call split into two utterance groups (the second group's stream waits for it)
-    static constexpr int kSets = 4;
+#ifndef RS_CONTEXT_SETS
+#define RS_CONTEXT_SETS 4
+#endif
+    static constexpr int kSets = RS_CONTEXT_SETS;
     DeviceArena arena[kSets];              // one per concurrent utterance group (batch calls use two; stream advances rotate over all)
     HostArena host_arena[kSets];
     LatArcBuffer lat_arcs[kSets];          // lattice arc output of LatticeKernel, grow-only, one per utterance group

@@ -34,6 +34,8 @@ bool GemmB3IUsable(const GemmDev &d);
 void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s);
 // nnet_gemm_b3j.hip: the same GEMM with both operands through LDS-DMA, hand-placed waits and a 256 x 256 tile (large launches)
 bool GemmB3JUsable(const GemmDev &d, int rows);
+bool GemmB3JSmallUsable(const GemmDev &d);                 // launches of 32-row tiles on GemmKernelB3J (nnet_gemm_b3j.hip)
+void LaunchGemmB3JSmall(const GemmDev &d, int rows, hipStream_t s);
 void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s);
 
 }  // namespace rs

@@ -294,6 +294,7 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
   if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
   static const int kps1 = [] { const char *e = TuneEnv("RS_GEMM_B3I_KPS"); return e ? std::atoi(e) : 8; }();
+  if (mr == 1 && GemmB3JSmallUsable(d)) { LaunchGemmB3JSmall(d, rows, s); return; }
   if (mr == 1 && kps1 == 8) LaunchB3I<1, false, 8>(d, rows, nbig, s);
   else if (mr == 1 && kps1 == 4) LaunchB3I<1, false, 4>(d, rows, nbig, s);
   else if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);

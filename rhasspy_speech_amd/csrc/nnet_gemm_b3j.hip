@@ -101,7 +101,9 @@ __device__ unsigned long long g_b3j_trace[8192 * 6];
 #define RS_TRACE_ID() do { } while (0)
 #endif
 
-template <int WM, bool MIXED, bool STRIP>
+// SDIV: the small tiles of a MIXED launch are 1 / SDIV of the full height (2: the tail of a batch launch; 4: a launch of 32-row tiles
+// only -- a stream advance's few thousand rows, one tile's worth of time on four times the CUs)
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   RS_TRACE(0);
   RS_TRACE_ID();
@@ -144,10 +146,10 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       bid = first_blocks + (small ? b2 - big_left : b2);
     }
   }
-  const int mr_eff = small ? MR / 2 : MR;                       // 32-row blocks per wave
+  const int mr_eff = small ? MR / SDIV : MR;                    // 32-row blocks per wave
   const int xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
-  const int row0 = small ? nbig * BM + rt * (BM / 2) : rt * BM, n0 = ct * BN;
+  const int row0 = small ? nbig * BM + rt * (BM / SDIV) : rt * BM, n0 = ct * BN;
   if (small ? row0 >= rows : rt >= nbig) return;
   f32x16 acc[MR][2];
 #pragma unroll
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // ---- staging: wave w copies activation row block w (three parts) and weight column tile w (three parts) of every k-step
-  const int nrb = small ? kJRowBlocks / 2 : kJRowBlocks;
+  const int nrb = small ? kJRowBlocks / SDIV : kJRowBlocks;
   const bool stager = wave < nrb;
   int grow = row0 + wave * 32 + (lane & 31);
   if (grow >= rows) grow = 0;                          // clamped rows are dropped in the epilogue
@@ -496,8 +498,8 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     // (the slab number is a macro argument: acc[] must never be indexed by a loop variable the compiler might not unroll -- that put
     // the accumulators in scratch -- and a lambda capturing `d` makes the compiler copy the 1.2 KB argument block to scratch)
 #define RS_SLAB(SL)                                                                                            \
-    if (!(MIXED && small && (SL) >= WM * MR / 2)) {     /* workgroup-uniform: a half-height tile has half the slabs */ \
-      if (MIXED && small) { if (wm == (SL) / (MR / 2)) { RS_PUT_SLAB(acc[(SL) % (MR / 2)]) } } \
+    if (!(MIXED && small && (SL) >= WM * MR / SDIV)) {     /* workgroup-uniform: a half-height tile has half the slabs */ \
+      if (MIXED && small) { if (wm == (SL) / (MR / SDIV)) { RS_PUT_SLAB(acc[(SL) % (MR / SDIV)]) } } \
       else if (wm == (SL) / MR) { RS_PUT_SLAB(acc[(SL) % MR]) } \
       dd::LdsBarrier(); \
       if (vec_out && d.write_f32) { \
@@ -549,7 +551,7 @@ _Pragma("unroll") \
   }
 }
 
-template <int WM, bool MIXED, bool STRIP>
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
   typedef JShape<WM> SH;
   constexpr int BM = 32 * SH::kRowBlocks;
@@ -560,17 +562,17 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
   const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP, SDIV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
-  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / 2 - 1) / (BM / 2) : 0;
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / SDIV - 1) / (BM / SDIV) : 0;
   // the half-height tiles are numbered through both of their block ranges: the first range holds a multiple of 8 of them
   const bool alt = nfirst < 0;
   nfirst = MIXED ? std::min(std::abs(nfirst) / 8 * 8, nsmall / 8 * 8) : 0;
   if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP, SDIV>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 #ifdef RS_B3J_TRACE
   static int traced = 0;
   const char *tf = TuneEnv("RS_B3J_TRACE_FILE");
@@ -638,6 +640,18 @@ bool GemmB3JUsable(const GemmDev &d, int rows) {
   const int min_rows = e && std::atoi(e) > 1 ? std::atoi(e) : (int)std::min<long>(min_default, 1 << 30);
   return rows >= min_rows;
 }
+
+// A launch of less than one round of tiles (a stream advance: a few thousand rows) as 32-row tiles of this kernel: GemmKernelB3I's
+// ordinary weight loads are waited for with vmcnt(0) in every k-step (the compiler drains the counter in front of the first use of a
+// load result while an LDS-DMA is in flight), 0.59 us per k-step for a workgroup alone on its CU; here nothing in the loop is a load
+// the compiler sees.  RS_GEMM_B3J_SMALL=0 (read per call: a test compares the two kernels bit for bit) keeps GemmKernelB3I.
+bool GemmB3JSmallUsable(const GemmDev &d) {
+  const char *e = std::getenv("RS_GEMM_B3J_SMALL");
+  if (e && std::atoi(e) == 0) return false;
+  const char *e2 = std::getenv("RS_GEMM_B3J");
+  return !(e2 && std::atoi(e2) == 0) && JWaveRows() == 1;
+}
+void LaunchGemmB3JSmall(const GemmDev &d, int rows, hipStream_t s) { LaunchB3J<1, true, false, 4>(d, rows, 0, 0, s); }
 
 void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   const int wm = JWaveRows();

@@ -27,8 +27,12 @@
 // rs_streams_finish = one last advance with end-of-input semantics, then traceback / lattice / result records: its device
 // work is one chunk's worth when the streams were advanced as the audio came in.
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
+#include <thread>
 #include "env.h"
 
 #include "engine.h"
@@ -36,7 +40,74 @@
 
 namespace rs {
 
+// A second host thread for the second half of an advance.  Issuing an advance's ~35 launches is the host's largest share of a
+// streams step (profiles/micro/streams_trace.sh: 7 ms of 21.5 per 64 x 30 s, beside 2.6 ms accepting samples, 1.5 planning, 1.3
+// uploading, 2.7 finishing); the acoustic model's and the search's launches (stage B / C: queues q and qc) need nothing the caller's
+// thread computes afterwards, so they are handed to this thread as a closure and the caller goes on to its bookkeeping and the next
+// advance's plan and stage A (queues qa, qi).  Jobs run in submission order (the order on q / qc is the advances' order); whoever
+// is about to wait for an advance's events, to queue work on q / qc itself, or to tear the pool down drains the thread first; an
+// exception of a job surfaces at that drain.
+struct StreamIssuer {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::deque<std::function<void()>> jobs;
+  long submitted = 0, completed = 0;
+  bool stop = false, started = false;
+  std::exception_ptr err;
+  int device = 0;
+  void Loop() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !jobs.empty(); });
+        if (jobs.empty()) return;
+        job = std::move(jobs.front());
+        jobs.pop_front();
+      }
+      std::exception_ptr e;
+      try { job(); } catch (...) { e = std::current_exception(); }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e && !err) err = e;
+        completed++;
+      }
+      cv_done.notify_all();
+    }
+  }
+  void Submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!started) { started = true; th = std::thread([this] { Loop(); }); }
+      jobs.push_back(std::move(f));
+      submitted++;
+    }
+    cv.notify_one();
+  }
+  // everything submitted has been issued; a job's exception is rethrown here (once)
+  void Drain(bool rethrow = true) {
+    std::exception_ptr e;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return completed == submitted; });
+      e = err;
+      err = nullptr;
+    }
+    if (e && rethrow) std::rethrow_exception(e);
+  }
+  ~StreamIssuer() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct StreamPool {
+  StreamIssuer issuer;
+  bool use_issuer = true;        // RS_STREAM_ISSUER=0: the caller's thread issues everything (A/B: profiles/micro)
+  int min_ticks = 16;            // an advance call with fewer new 1024-sample ticks than this on every stream is coalesced into the next (RS_STREAM_MIN_TICKS)
   // Queues, so that consecutive advances overlap on the device: `qa` runs an advance's features and UBM posteriors, `qi` (below)
   // its iVector steps, `q` its acoustic model (behind events of both), `qc` its search.  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
@@ -106,6 +177,7 @@ struct StreamPool {
 
 void StreamPoolDeleter::operator()(StreamPool *p) const {
   if (!p) return;
+  p->issuer.Drain(false);
   if (p->qa) (void)hipStreamSynchronize(p->qa);
   if (p->qi) (void)hipStreamSynchronize(p->qi);
   if (p->q) (void)hipStreamSynchronize(p->q);
@@ -175,6 +247,9 @@ StreamPool *Model::Pool() {
     p->tm_c[k].reset(new Timer(p->qc));
   }
   { const char *e = TuneEnv("RS_STREAM_SYNC"); p->sync_each = e && std::atoi(e) != 0; }
+  { const char *e = std::getenv("RS_STREAM_ISSUER"); p->use_issuer = !(e && std::atoi(e) == 0); }
+  { const char *e = std::getenv("RS_STREAM_MIN_TICKS"); if (e && std::atoi(e) >= 1) p->min_ticks = std::atoi(e); }
+  p->issuer.device = opts_.device_id;
   auto dalloc = [&](size_t bytes) {
     void *d = nullptr;
     RS_HIP(hipMalloc(&d, std::max<size_t>(bytes, 256)));
@@ -223,6 +298,7 @@ StreamPool *Model::Pool() {
 // Waits for the advances still in flight and adds their stage times to the pool's totals (and to `extra`, if given: the finishing
 // call's own share).  Device errors of those advances surface here.
 void Model::StreamsDrain(StreamPool *p, float *extra) {
+  p->issuer.Drain();
   for (int k = 0; k < StreamPool::kDepth; k++) {
     const int par = (int)((p->n_adv + k) % StreamPool::kDepth);      // the oldest advance first
     if (!p->pending[par]) continue;
@@ -254,6 +330,7 @@ void Model::StreamOpen(rs_stream *st) {
   std::lock_guard<std::mutex> lk(pool_mu_);
   StreamPool *p = Pool();
   RS_HIP(hipSetDevice(opts_.device_id));
+  p->issuer.Drain();             // (this call queues on qi / qc itself)
   if (p->free_slots.empty()) Fail("too many live streams on this model (RS_STREAM_SLOTS=" + std::to_string(p->max_slots) + ")");
   const int want = RoundUp(std::max(EnvInt("RS_STREAM_INIT_FRAMES", 4096), 2 * p->chunk), p->chunk);
   const int row0 = p->AllocRows(want);
@@ -278,7 +355,7 @@ void Model::StreamClose(rs_stream *st) {
   if (!pool_) return;
   // an advance that still uses the stream's rows / slot finishes first (a device error of it is the other streams' to report:
   // this one is going away either way)
-  try { StreamsDrain(pool_.get(), nullptr); } catch (...) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
+  try { StreamsDrain(pool_.get(), nullptr); } catch (...) { pool_->issuer.Drain(false); (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
   pool_->FreeRows(st->row0, st->cap);
   pool_->free_slots.push_back(st->slot);
   st->open = false;
@@ -292,6 +369,7 @@ void Model::StreamClose(rs_stream *st) {
 void Model::StreamsPoisonAll() {
   StreamPool *p = pool_.get();
   if (!p) return;
+  p->issuer.Drain(false);
   (void)hipStreamSynchronize(p->qa); (void)hipStreamSynchronize(p->qi); (void)hipStreamSynchronize(p->q); (void)hipStreamSynchronize(p->qc);
   (void)hipGetLastError();
   for (int k = 0; k < StreamPool::kDepth; k++) p->pending[k] = false;
@@ -333,7 +411,7 @@ void Model::StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbe
   } catch (...) {
     // The advance may have queued part of its work on a set it never marked pending: whatever is queued finishes before the set
     // can be handed out again (the call's own streams are poisoned by the caller, api.cc).
-    if (pool_) { (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
+    if (pool_) { pool_->issuer.Drain(false); (void)hipStreamSynchronize(pool_->qa); (void)hipStreamSynchronize(pool_->qi); (void)hipStreamSynchronize(pool_->q); (void)hipStreamSynchronize(pool_->qc); }
     throw;
   }
 }
@@ -343,13 +421,25 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   RS_HIP(hipSetDevice(opts_.device_id));
   // queues: qa = features + iVectors (stage A), q = acoustic model + search (stage B, behind stage A's event); consecutive
   // advances rotate over kDepth arena / staging sets, so the host plans and issues the next advances while earlier ones still run
+  // Coalescing: nothing but the end of a stream reads what an advance computes, and an advance is chains of small dependent launches
+  // (the iVector estimator's per-chunk chain is the longest queue of a step: ~300 us per advance whatever the number of chunks) -- so
+  // a call that brings less than min_ticks ticks of new audio on every stream leaves it to the next one.  The chunk / iVector
+  // schedule is a function of the sample counts, not of the calls (the tick loop below): same rows, same results as with one
+  // advance per tick or one at the end (the three delivery patterns of the stream tests).  RS_STREAM_MIN_TICKS=1: every call works.
+  if (!final && p->min_ticks > 1) {
+    long most = 0;
+    for (int i = 0; i < n; i++) most = std::max(most, (long)(streams[i]->n_samples / 1024) - streams[i]->ticks_done);
+    if (most < p->min_ticks) return;
+  }
   hipStream_t qa = p->qa, q = p->q, qc = p->qc, qi = p->qi;
   DecodeContext &cx = *static_cast<DecodeContext *>(p->cx);
   const int par = (int)(p->n_adv % StreamPool::kDepth);
   DeviceArena &arena = cx.arena[par];
   HostArena &harena = cx.host_arena[par];
+  if (final) p->issuer.Drain();      // a finishing call issues everything itself, behind what the issuing thread still holds
   if (p->pending[par]) {       // the advance kDepth calls ago used this set: it has to be over (it normally is)
     const auto w0 = std::chrono::steady_clock::now();
+    p->issuer.Drain();         // (its done event has been recorded)
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->stage_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
     p->pending[par] = false;
@@ -405,7 +495,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     a.sa = a.sb = st.stats_done;
     for (auto &c : a.chunks) a.sb = std::max(a.sb, c.second + 1);
     a.t0 = st.ll_done;
-    a.t1 = a.chunks.empty() ? st.ll_done : (final ? a.avail : std::min(chunk * st.chunks_sched, a.avail));
+    a.t1 = final ? a.avail : std::min(chunk * st.chunks_sched, a.avail);
   }
   // ---------------------------------------------------------------- transient geometry of the stages, index arrays
   IntStage is;
@@ -648,53 +738,80 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   TM_MARK(tma);
   // the acoustic model waits for both: the features (qa) and, where there is an extractor, the iVectors (qi, itself behind qa)
   RS_HIP(hipEventRecord(p->ev_a[par], qa));
-  RS_HIP(hipStreamWaitEvent(q, p->ev_a[par], 0));
-  if (nI > 0) {
-    RS_HIP(hipEventRecord(p->ev_i[par], qi));
-    RS_HIP(hipStreamWaitEvent(q, p->ev_i[par], 0));
-  }
-  TM_MARK(tmb);
-  // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context)
+  if (nI > 0) RS_HIP(hipEventRecord(p->ev_i[par], qi));
+  // ---------------------------------------------------------------- 4. acoustic model over the new chunks (+ context), 5. search
+  // Everything below queues on q / qc and needs nothing this thread computes later: a closure over values, run here by a finishing
+  // call and handed to the pool's issuing thread otherwise (StreamIssuer).  Buffers come out of the arena here, in this thread.
   HOST_MARK(2);
+  std::vector<float *> bufp(nn.bufs.size(), nullptr);
+  std::vector<ActImage> imgs;
+  int *frame_rows = nullptr;
   if (nN > 0) {
-    std::vector<float *> bufp(nn.bufs.size(), nullptr);
     for (size_t b = 0; b < nn.bufs.size(); b++) bufp[b] = falloc(rowsN, buf_ld[b]);
-    const std::vector<ActImage> imgs = AllocImages(arena, rowsN);
-    LaunchCopyRows(fc_.use_cmvn ? p->nn_in : p->raw, ld_c, D(o_nsrc), bufp[nn.input_buf], buf_ld[nn.input_buf], nullptr, rowsN, C, q);
-    int *frame_rows = arena.AllocT<int>(framesN + 8);
-    LaunchFrameRows(nN, nN, framesN, L_, std::max(maxTn, 1), D(o_nfb), D(o_nrb), frame_rows, q);
-    RowMaps row_maps;
-    row_maps.maps.push_back({0, 0, frame_rows, framesN});
-    if (fsf > 1 && !n_llsrc.empty()) row_maps.maps.push_back({0, 0, D(o_nlls), (int)n_llsrc.size(), 0, fsf});      // the layers only the decoder's frames read
-    RunNnet(bufp, buf_ld, p->ivec, ld_i, D(o_nriv), rowsN, row_maps, 1, 0, nn.ops.size(), q, &imgs);
-    if (fsf == 1) LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], frame_rows, p->ll, p->ld_ll, D(o_nll), framesN, P, q);
-    else if (!n_lldst.empty()) LaunchCopyRows(bufp[nn.output_buf], buf_ld[nn.output_buf], D(o_nlls), p->ll, p->ld_ll, D(o_nll), (int)n_lldst.size(), P, q);
+    imgs = AllocImages(arena, rowsN);
+    frame_rows = arena.AllocT<int>(framesN + 8);
   }
-  TM_MARK(tmb);
-  // ---------------------------------------------------------------- 5. search (its own queue: the next advance's acoustic model does not wait for it)
-  HOST_MARK(3);
-  RS_HIP(hipEventRecord(p->ev_b[par], q));
-  RS_HIP(hipStreamWaitEvent(qc, p->ev_b[par], 0));
-  TM_MARK(tmc);
   BatchGeom gd;
   gd.n_utts = n; gd.max_frames = maxT; gd.d_num_frames = D(o_dT); gd.d_row_base = D(o_drb);
-  if (final) AllocSearch(&sp, arena, qc, /*pooled_frames=*/reg_windows);
-  if (reg_windows) {
-    DenseWork dw;
-    std::memset(&dw, 0, sizeof(dw));
-    if (final) dw = sp.dw;
-    dw.bp = p->bp; dw.frame_info = p->finfo; dw.state_cost = p->dec_state; dw.counters = p->dec_ctr;
-    dw.win_begin = D(o_wb); dw.win_end = D(o_we); dw.win_final = D(o_wf); dw.pool_row = D(o_row0); dw.slot = D(o_slots);
-    DecodeOptsDev dopts;
-    dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
-    dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
-    dopts.exact_order = ExactOrder() ? 1 : 0;
-    LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw, 0, 0, qc, final);
-    if (final) LaunchCopyRows(p->dec_ctr, 16, D(o_slots), sp.w.counters, 16, nullptr, n, 16, qc);
-  } else if (final) {
-    LaunchSearch(&sp, arena, gd, p->ll, p->ld_ll, qc);
+  DenseWork dw;
+  std::memset(&dw, 0, sizeof(dw));
+  dw.bp = p->bp; dw.frame_info = p->finfo; dw.state_cost = p->dec_state; dw.counters = p->dec_ctr;
+  dw.win_begin = D(o_wb); dw.win_end = D(o_we); dw.win_final = D(o_wf); dw.pool_row = D(o_row0); dw.slot = D(o_slots);
+  DecodeOptsDev dopts;
+  dopts.beam = opts_.beam; dopts.lattice_beam = opts_.lattice_beam; dopts.beam_delta = opts_.beam_delta;
+  dopts.max_active = opts_.max_active; dopts.min_active = opts_.min_active;
+  dopts.exact_order = ExactOrder() ? 1 : 0;
+  {
+    const float *nn_src = fc_.use_cmvn ? p->nn_in : p->raw;
+    const int *d_nsrc = D(o_nsrc), *d_nfb = D(o_nfb), *d_nrb = D(o_nrb), *d_nriv = D(o_nriv), *d_nll = D(o_nll), *d_nlls = D(o_nlls), *d_slots = D(o_slots);
+    const int n_sub = (int)n_lldst.size();
+    const bool have_sub = !n_llsrc.empty(), exact_now = exact_gemm_.load();
+    int *const ovf_dev = cx.gemm_ovf_dev;
+    Timer *const tb = &tmb, *const tc = &tmc;
+    SearchPlan *const spp = &sp;            // (a finishing call only; it runs the closure itself)
+    DeviceArena *const arp = &arena;
+    hipEvent_t ev_a = p->ev_a[par], ev_i = p->ev_i[par], ev_b = p->ev_b[par], ev_done = p->ev_done[par];
+    const int maxTn_c = std::max(maxTn, 1);
+    const Nnet *const nnp = &nn;             // (a pointer: [=] on the reference would copy the network)
+    auto issue_bc = [=]() {
+      SampleGemmMode(exact_now, ovf_dev);      // (thread-local: the issuing thread's launches run in the mode this advance was planned in)
+      RS_HIP(hipStreamWaitEvent(q, ev_a, 0));
+      if (nI > 0) RS_HIP(hipStreamWaitEvent(q, ev_i, 0));
+      if (timed) tb->Mark();
+      if (nN > 0) {
+        LaunchCopyRows(nn_src, ld_c, d_nsrc, bufp[nnp->input_buf], buf_ld[nnp->input_buf], nullptr, rowsN, C, q);
+        LaunchFrameRows(nN, nN, framesN, L_, maxTn_c, d_nfb, d_nrb, frame_rows, q);
+        RowMaps row_maps;
+        row_maps.maps.push_back({0, 0, frame_rows, framesN});
+        if (fsf > 1 && have_sub) row_maps.maps.push_back({0, 0, d_nlls, n_sub, 0, fsf});      // the layers only the decoder's frames read
+        RunNnet(bufp, buf_ld, p->ivec, ld_i, d_nriv, rowsN, row_maps, 1, 0, nnp->ops.size(), q, &imgs);
+        if (fsf == 1) LaunchCopyRows(bufp[nnp->output_buf], buf_ld[nnp->output_buf], frame_rows, p->ll, p->ld_ll, d_nll, framesN, P, q);
+        else if (n_sub > 0) LaunchCopyRows(bufp[nnp->output_buf], buf_ld[nnp->output_buf], d_nlls, p->ll, p->ld_ll, d_nll, n_sub, P, q);
+      }
+      if (timed) tb->Mark();
+      // the search on its own queue: the next advance's acoustic model does not wait for it
+      RS_HIP(hipEventRecord(ev_b, q));
+      RS_HIP(hipStreamWaitEvent(qc, ev_b, 0));
+      if (timed) tc->Mark();
+      if (final) AllocSearch(spp, *arp, qc, /*pooled_frames=*/reg_windows);
+      if (reg_windows && (final || nN > 0)) {      // (an advance without new log-likelihood rows has nothing to search)
+        DenseWork dw2 = dw;
+        if (final) { dw2 = spp->dw; dw2.bp = dw.bp; dw2.frame_info = dw.frame_info; dw2.state_cost = dw.state_cost; dw2.counters = dw.counters;
+                     dw2.win_begin = dw.win_begin; dw2.win_end = dw.win_end; dw2.win_final = dw.win_final; dw2.pool_row = dw.pool_row; dw2.slot = dw.slot; }
+        LaunchDecodeReg(hclg_dev_, reg_dev_, dopts, gd, p->ll, p->ld_ll, dw2, 0, 0, qc, final);
+        if (final) LaunchCopyRows(p->dec_ctr, 16, d_slots, spp->w.counters, 16, nullptr, n, 16, qc);
+      } else if (final) {
+        LaunchSearch(spp, *arp, gd, p->ll, p->ld_ll, qc);
+      }
+      if (timed) tc->Mark();
+      RS_HIP(hipEventRecord(ev_done, qc));
+      const hipError_t le = hipGetLastError();      // (per thread: a failed launch of this closure is seen here)
+      if (le != hipSuccess) Fail(std::string("a kernel launch failed: ") + hipGetErrorString(le));
+    };
+    if (final || !p->use_issuer) issue_bc();
+    else p->issuer.Submit(issue_bc);
   }
-  TM_MARK(tmc);
+  HOST_MARK(3);
   // ---------------------------------------------------------------- host bookkeeping
   HOST_MARK(4);
   for (int i = 0; i < n; i++) {
@@ -703,7 +820,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     st.frames_mfcc = a.avail;
     st.stats_done = a.sb;
     st.ll_done = a.t1;
-    if (reg_windows) { st.frames_decoded = dec_frames(a.t1); st.dec_started = true; }
+    if (reg_windows && (final || nN > 0)) { st.frames_decoded = dec_frames(a.t1); st.dec_started = true; }      // (the search was launched)
     // samples before the first frame that is not complete yet are not needed again (online-feature.cc:186-203)
     const long keep_from = (long)a.avail * shift;
     if (!st.keep_pcm && keep_from > st.pcm_start) {
@@ -711,8 +828,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
       st.pcm_start = keep_from;
     }
   }
-  RS_HIP(hipEventRecord(p->ev_done[par], qc));
-  p->pending[par] = true;
+  p->pending[par] = true;         // (its done event is recorded by the closure above)
   p->n_adv++;
   if (!final) {
     // No wait here: the next advance is planned and issued while this one runs.  What it did on the device is accounted for --

@@ -547,6 +547,31 @@ def test_all_dma_gemm_is_bitwise_the_image_gemm(zam_grammar, monkeypatch):
                 assert got.words(u) == ref.words(u) and got.costs(u) == ref.costs(u)
 
 
+def test_small_launches_on_the_all_dma_gemm_are_bitwise_the_image_gemm(zam_grammar, monkeypatch):
+    """A launch of less than one round of tiles (a few utterances; a stream advance) runs GemmKernelB3J with 32-row tiles (round 5;
+    GemmKernelB3I<1> before, RS_GEMM_B3J_SMALL=0): same MFMAs, same order -> equal bit for bit, batch and incremental stream."""
+    from rhasspy_speech_amd import _lib, synth
+    model = _lib.Model(*zam_grammar, _lib.default_opts(keep_intermediates=1))
+    pcms = [synth.synth_utterance(33000 + u, n) for u, n in enumerate([48000, 30000, 1700, 20011])]
+
+    def run():
+        b = model.decode_batch(pcms)
+        st = _lib.Stream(model)
+        raw = pcms[0].tobytes()
+        for k in range(0, len(raw), 16384):
+            st.accept(raw[k:k + 16384])
+            st.advance()
+        return b, st.finish(1, 1.0)
+    got_b, got_s = run()
+    monkeypatch.setenv("RS_GEMM_B3J_SMALL", "0")
+    ref_b, ref_s = run()
+    for u in range(len(pcms)):
+        np.testing.assert_array_equal(got_b.matrix(u, 2), ref_b.matrix(u, 2))
+        assert got_b.words(u) == ref_b.words(u) and got_b.costs(u) == ref_b.costs(u)
+    np.testing.assert_array_equal(got_s.matrix(0, 2), ref_s.matrix(0, 2))
+    assert got_s.words(0) == ref_s.words(0) and got_s.costs(0) == ref_s.costs(0)
+
+
 def test_pruned_output_layer_on_a_batch(zam_grammar):
     """prune_output_pdfs on the headline model / graph (362 of the 2000 pdfs are on HCLG arcs): a ragged batch decodes to
     the same words and costs as with the full output layer."""
