@@ -612,6 +612,60 @@ def test_concurrent_calls_on_one_model(zam_grammar):
                 _same_result(res, u, ref[b], u)
 
 
+def test_streams_and_batch_calls_at_the_same_time(zam_grammar):
+    """One model: a host thread advancing sixteen streams round by round (its advances' second halves issued by the pool's own
+    thread, calls coalesced two by two) while two other threads decode batches -- every stream and every batch utterance equals its
+    sequential result."""
+    from rhasspy_speech_amd import _lib, synth
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    spcm = [synth.synth_utterance(41000 + i, 16000 * 6 + 977 * i) for i in range(16)]
+    batches = [[synth.synth_utterance(42000 + 100 * b + u, 48000 - 320 * ((u + b) % 11)) for u in range(48 + 16 * b)] for b in range(2)]
+
+    def run_streams():
+        sts = [_lib.Stream(model) for _ in spcm]
+        pos = 0
+        while pos < max(len(p) for p in spcm):
+            for s, p in zip(sts, spcm):
+                if pos < len(p):
+                    s.accept(p[pos:pos + 8192])
+            _lib.advance_streams([s for s, p in zip(sts, spcm) if pos < len(p) + 8192])
+            pos += 8192
+        return _lib.finish_streams(sts, nbest=1)
+
+    ref_s = run_streams()
+    ref_b = [model.decode_batch(pcms) for pcms in batches]
+    out_s, out_b, errs = [], [[] for _ in batches], []
+
+    def guard(fn):
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    def streams_job():
+        for _ in range(3):
+            out_s.append(run_streams())
+
+    def batch_job(b):
+        for _ in range(6):
+            out_b[b].append(model.decode_batch(batches[b]))
+
+    ts = [threading.Thread(target=guard, args=(streams_job,))] + [threading.Thread(target=guard, args=(lambda b=b: batch_job(b),)) for b in range(len(batches))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert len(out_s) == 3
+    for res in out_s:
+        for i in range(len(spcm)):
+            _same_result(res, i, ref_s, i)
+    for b, pcms in enumerate(batches):
+        for res in out_b[b]:
+            for u in range(len(pcms)):
+                _same_result(res, u, ref_b[b], u)
+
+
 def test_two_utterance_groups_per_call(zam_grammar, monkeypatch):
     """RS_SUBBATCHES=2 (read at model load): a call of 32 or more utterances runs as two groups on two streams and two host
     threads.  The second group's stream must start behind the upload of the samples, which is queued on the first one's
