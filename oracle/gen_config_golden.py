@@ -10,7 +10,10 @@ process shared by several utterances would carry from one to the next (feature-w
 Stored per config: the 5-best word ids of every utterance and nbest-to-linear's graph / acoustic costs
 (tests/golden/configs/<name>.npz, a few KB each); `words` / `graph_cost` / `acoustic_cost` are the 1-best of that list.
 
-Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams]
+c1_fsf3 / c4_fsf3: the first 128 utterances of configs[1] / the first 16 streams of configs[4] with --frame-subsampling-factor=3
+in the model's online.conf.
+
+Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c1_fsf3 c4_fsf3]
 """
 from __future__ import annotations
 
@@ -135,6 +138,18 @@ def main():
                 m = configs.MIXED_MODELS[key]
                 md, gd = configs.build_grammar_model(td / key, m["model_seed"], m["graph_seed"])
                 run_offline(tag, md, gd, [p for nm, p in zip(names, pcms) if nm == key], td)
+        if "c1_fsf3" in want:
+            md, gd = configs.build_grammar_model(td / "zam_fsf3", conf_opts=configs.FSF3_CONF)
+            run_offline("c1_fsf3", md, gd, configs.grammar_utterances()[:configs.N_FSF3_UTTS], td)
+        if "c4_fsf3" in want:
+            md, gd = configs.build_grammar_model(td / "zam_fsf3", conf_opts=configs.FSF3_CONF)
+            pcms = configs.stream_utterances()[:configs.N_FSF3_STREAMS]
+            res = {}
+            with concurrent.futures.ThreadPoolExecutor(8) as ex:
+                futs = [ex.submit(stream_one, md, gd, p, i, td / f"sf{i}") for i, p in enumerate(pcms)]
+                for f in futs:
+                    res.update(f.result())
+            save("c4_fsf3", res, len(pcms), "reference: online2-cli-nnet3-decode-faster (stdin s16le), --frame-subsampling-factor=3 in online.conf | lattice-to-nbest --n=5 | nbest-to-linear")
         if "c4_streams" in want:
             md, gd = configs.build_grammar_model(td / "zam")
             pcms = configs.stream_utterances()

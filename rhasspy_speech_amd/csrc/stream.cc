@@ -609,7 +609,8 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   SearchPlan sp;
   int maxT = 0;
   auto dec_frames = [&](int t) { return (t + fsf - 1) / fsf; };       // decoder frames of the first t feature frames (decodable-online-looped.cc:56-84)
-  for (int i = 0; i < n; i++) maxT = std::max(maxT, dec_frames(pl[i].avail));
+  int max_feat_frames = 0;                                               // (the dither table is indexed by FEATURE frames)
+  for (int i = 0; i < n; i++) { maxT = std::max(maxT, dec_frames(pl[i].avail)); max_feat_frames = std::max(max_feat_frames, pl[i].avail); }
   size_t search_bytes = 0;
   if (final) search_bytes = PlanSearch(n, maxT, nbest, lat_scale, &sp);
   const bool reg_windows = p->reg && !(final && sp.want_lattice);
@@ -681,7 +682,7 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
     int *ru = arena.AllocT<int>(rowsM), *rt = arena.AllocT<int>(rowsM);
     LaunchRowGeometry(nM, rowsM, 0, D(o_mrb), nullptr, ru, rt, nullptr, qa);
     g.d_row_utt = ru; g.d_row_t = rt;
-    LaunchMfcc(MfccWithDither(maxT), g, d_pcm, p->raw, ld_c, qa, false, D(o_mout));
+    LaunchMfcc(MfccWithDither(max_feat_frames), g, d_pcm, p->raw, ld_c, qa, false, D(o_mout));
     // ---------------------------------------------------------------- 2. CMVN, resumed
     BatchGeom gc;
     gc.n_utts = nM; gc.d_num_frames = D(o_cT); gc.d_row_base = D(o_crb);

@@ -53,14 +53,22 @@ def mixed_utterances(n_per_model: int = 512) -> Tuple[List[str], List[np.ndarray
     return names, pcm
 
 
-def build_grammar_model(root: Path, model_seed: int = 1, graph_seed: int = 11) -> Tuple[Path, Path]:
+def build_grammar_model(root: Path, model_seed: int = 1, graph_seed: int = 11, conf_opts: dict = None) -> Tuple[Path, Path]:
+    """conf_opts: decoder / decodable options appended to the model's online.conf (the reference reads them through --config)."""
     root = Path(root)
     model_dir, graph_dir = root / "model", root / "graph"
     if not (graph_dir / "HCLG.fst").exists():
         spec = synth.ModelSpec(seed=model_seed)
         synth.write_model_dir(model_dir, spec)
         synth.make_grammar_graph(graph_dir, spec, seed=graph_seed)
+        if conf_opts:
+            conf = model_dir / "model" / "online" / "conf" / "online.conf"
+            conf.write_text(conf.read_text() + "".join(f"--{k}={v}\n" for k, v in conf_opts.items()))
     return model_dir, graph_dir
+
+
+FSF3_CONF = {"frame-subsampling-factor": 3}      # c1_fsf3 / c4_fsf3: the headline model decoded the way a chain model is meant to be
+N_FSF3_UTTS, N_FSF3_STREAMS = 128, 16
 
 
 def build_arpa_model(root: Path) -> Tuple[Path, Path]:

@@ -238,6 +238,27 @@ def test_config4_five_best_of_every_stream(zam_grammar):
     _check_nbest_against_reference("c4_streams", _lib.finish_streams(streams, nbest=5), len(pcms))
 
 
+def test_frame_subsampling_factor_3_at_config_size(tmp_path_factory):
+    """--frame-subsampling-factor=3 in the headline model's online.conf (how a chain model is meant to be decoded; the upper layers then
+    run on every third row): the 5-best lists of the first 128 utterances of configs[1] (one batch) and of the first 16 streams of
+    configs[4] (8-tick rounds) against the reference binaries run with the same online.conf (oracle/gen_config_golden.py c1_fsf3 c4_fsf3)."""
+    from rhasspy_speech_amd import _lib
+    md, gd = configs.build_grammar_model(tmp_path_factory.mktemp("zam_fsf3"), conf_opts=configs.FSF3_CONF)
+    model = _lib.Model(md, gd, _lib.default_opts())
+    assert "frame_subsampling_factor=3" in model.describe() and "rows=every-3" in model.describe()
+    pcms = configs.grammar_utterances()[:configs.N_FSF3_UTTS]
+    res = model.decode_batch(pcms, nbest=5)
+    assert all(res.num_frames(u) == 100 for u in range(len(pcms)))
+    _check_nbest_against_reference("c1_fsf3", res, len(pcms))
+    spcm = configs.stream_utterances()[:configs.N_FSF3_STREAMS]
+    streams = [_lib.Stream(model) for _ in spcm]
+    tick = 8 * 1024
+    for r in range((max(len(p) for p in spcm) + tick - 1) // tick):
+        _lib.accept_streams(streams, [p[r * tick:(r + 1) * tick] for p in spcm])
+        _lib.advance_streams(streams)
+    _check_nbest_against_reference("c4_fsf3", _lib.finish_streams(streams, nbest=5), len(spcm))
+
+
 def test_streams_fed_through_the_array_entry_points(zam_grammar):
     """stream_handles / accept_streams_raw / advance_streams_raw (addresses and lengths as arrays the caller keeps, ragged rounds:
     streams that have run out of audio drop out of the accept call) against the per-object calls on the same audio."""
