@@ -472,6 +472,34 @@ def test_finish_after_incremental_advances_is_cheap(case_cache):
     assert sum(inc.timings()[1:5]) > 0.5 * sum(full.timings()[1:5])
 
 
+@pytest.mark.parametrize("name", ["zam_u1", "zam_fsf3_u19", "tiny_arpa_u7"])
+def test_a_stream_that_outgrows_its_rows_moves_and_goes_on(case_cache, name, monkeypatch):
+    """A stream opened with room for 256 frames and fed 14 s round by round: its rows move to a range twice as long three times
+    (StreamGrow: pool rows of features, log-likelihoods, back pointers, per-chunk iVectors) while advances are in flight on the
+    issuing thread -- same result, bit for bit, as the same stream with room from the start."""
+    from rhasspy_speech_amd import _lib, synth
+    model, _ = make_model(case_cache, name)
+    pcm = synth.synth_utterance(4242, 16000 * 14)
+
+    def run():
+        st = _lib.Stream(model)
+        for k in range(0, len(pcm), 8192):
+            st.accept(pcm[k:k + 8192])
+            st.advance()
+        return st.finish(nbest=cases.NBEST)
+    ref = run()
+    monkeypatch.setenv("RS_STREAM_INIT_FRAMES", "256")
+    got = run()
+    for kind in (0, 1, 2):
+        if kind == 1 and cases.CASES[name]["spec"].get("ivector_dim", 1) == 0:
+            continue
+        np.testing.assert_array_equal(got.matrix(0, kind), ref.matrix(0, kind))
+    assert got.num_hyps(0) == ref.num_hyps(0)
+    for k in range(ref.num_hyps(0)):
+        assert got.words(0, k) == ref.words(0, k)
+        np.testing.assert_array_equal(got.costs(0, k), ref.costs(0, k))
+
+
 def test_failed_advance_poisons_its_streams(case_cache, monkeypatch):
     """An advance that throws after the chunk schedule of some streams has moved on (here: the pool has no room for a stream
     that outgrew its row range) must not leave streams that look usable: every later call on the streams of that advance
