@@ -633,6 +633,21 @@ def test_concurrent_calls_on_one_model(zam_grammar):
                 _same_result(res, u, ref[b], u)
 
 
+def test_lattice_arc_regions_grow_when_an_utterance_outgrows_its_share(zam_grammar):
+    """Every utterance of an n-best call appends its lattice arcs to its own region of the context's arc buffer (1 M records
+    shared out evenly at first): with 1360 utterances a region holds 771 arcs, less than a 3 s lattice of this graph has, so the
+    first attempt reports the largest count, the buffer is re-allocated and the lattice pass repeated -- same 5-best lists as
+    the same utterances in a small call."""
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts())
+    base = configs.grammar_utterances()[:8]
+    ref = model.decode_batch(base, nbest=5)
+    assert max(ref.counters(u)[4] for u in range(8)) > 771          # (arcs of the raw lattice)
+    res = _lib.Model(*zam_grammar, _lib.default_opts()).decode_batch(base * 170, nbest=5)
+    for u in range(8 * 170):
+        _same_result(res, u, ref, u % 8)
+
+
 def test_streams_and_batch_calls_at_the_same_time(zam_grammar):
     """One model: a host thread advancing sixteen streams round by round (its advances' second halves issued by the pool's own
     thread, calls coalesced two by two) while two other threads decode batches -- every stream and every batch utterance equals its
