@@ -445,8 +445,9 @@ def test_incremental_stream_equals_batch_replay(case_cache, name, monkeypatch):
 
 
 def test_finish_after_incremental_advances_is_cheap(case_cache):
-    """A 30 s stream advanced as its audio arrives: what is left for finish is the last chunk -- its wall time must be a small
-    fraction of decoding the whole stream at the end (same stream, no advances)."""
+    """A 30 s stream advanced as its audio arrives: what is left for finish is the tail -- the last chunk, at most a second of audio
+    a coalesced advance left for the next call, and the advances still in flight -- so its wall time must be a fraction of decoding
+    the whole stream at the end (same stream, no advances)."""
     import time
     from rhasspy_speech_amd import _lib
     model, pcm = make_model(case_cache, "zam_long30", keep_intermediates=0)
@@ -465,10 +466,10 @@ def test_finish_after_incremental_advances_is_cheap(case_cache):
     inc, t_inc = run(True)
     full, t_full = run(False)
     assert inc.words(0) == full.words(0) and inc.costs(0) == full.costs(0)
-    assert t_inc < 0.25 * t_full, (t_inc, t_full)
+    assert t_inc < 0.5 * t_full, (t_inc, t_full)
     # ... the library's own clock around the finishing call (timings[7]); timings[1:5] are the stage times of the WHOLE
     # stream (advances included), which add up to about the same device work either way
-    assert inc.timings()[7] < 0.25 * full.timings()[7], (inc.timings(), full.timings())
+    assert inc.timings()[7] < 0.5 * full.timings()[7], (inc.timings(), full.timings())
     assert sum(inc.timings()[1:5]) > 0.5 * sum(full.timings()[1:5])
 
 
