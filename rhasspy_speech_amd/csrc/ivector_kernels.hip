@@ -1281,24 +1281,40 @@ __device__ __forceinline__ double IvecCgSolve(const IvecDev &iv, const double *A
   if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
   if (mine) xs[tid] = x;
   __syncthreads();
+  // Row products with TWO threads per row when the workgroup has them (n <= 32 NW): thread tid < n takes the first half of the
+  // columns, thread tid + 32 NW the second, the halves meet through LDS (hs = ps + n; one more barrier per product).  With one
+  // thread per row 100 of the 256 threads worked and a product was 200 LDS reads + 100 dependent-issue fp64 FMAs per thread, the
+  // longest piece of the per-chunk chain of a stream advance (four accumulators each, summed pairwise at the end: the order of an
+  // fp64 sum is free at the 1e-4 the iVector is held to; batch and stream paths run this same code and stay bit-equal to each other).
+  double *hs = ps + n;
+  const bool two = NW > 1 && n <= 32 * NW;                 // (tid + 32 NW < 64 NW for every row)
+  const bool second = two && tid >= 32 * NW && tid - 32 * NW < n;
+  const int row = second ? tid - 32 * NW : tid;
+  const int c_lo = second ? n / 2 : 0, c_hi = two ? (second ? n : n / 2) : n;
   auto matvec = [&](const double *vec) __attribute__((always_inline)) {
-    // four accumulators over the columns c = 4 q + j, summed pairwise at the end: a single one (round 3) made a row product a
-    // chain of n dependent fp64 FMAs -- 45 us for 15 iterations of n = 100; the order of an fp64 sum is free at the 1e-4 the
-    // iVector is held to (batch and stream paths run this same kernel and stay bit-equal to each other)
-    constexpr int MB = 20;
+    constexpr int MB = 10;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (mine) {
-      int c = 0;
-      for (; c + MB <= n; c += MB) {
+    if (mine || second) {
+      int c = c_lo;
+      for (; c + MB <= c_hi; c += MB) {
         double a[MB], w[MB];
 #pragma unroll
-        for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + tid]; w[i] = vec[c + i]; }
+        for (int i = 0; i < MB; i++) { a[i] = A[(size_t)(c + i) * n + row]; w[i] = vec[c + i]; }
 #pragma unroll
-        for (int i = 0; i < MB; i += 4) { a0 += a[i] * w[i]; a1 += a[i + 1] * w[i + 1]; a2 += a[i + 2] * w[i + 2]; a3 += a[i + 3] * w[i + 3]; }
+        for (int i = 0; i + 4 <= MB; i += 4) { a0 += a[i] * w[i]; a1 += a[i + 1] * w[i + 1]; a2 += a[i + 2] * w[i + 2]; a3 += a[i + 3] * w[i + 3]; }
+#pragma unroll
+        for (int i = MB / 4 * 4; i < MB; i++) a0 += a[i] * w[i];
       }
-      for (; c < n; c++) a0 += A[(size_t)c * n + tid] * vec[c];
+      for (; c < c_hi; c++) a0 += A[(size_t)c * n + row] * vec[c];
     }
-    return (a0 + a1) + (a2 + a3);
+    double sum = (a0 + a1) + (a2 + a3);
+    if (two) {
+      if (second) hs[row] = sum;
+      __syncthreads();
+      if (mine) sum += hs[tid];
+      // (the next product rewrites hs behind the barrier its caller puts in front of it)
+    }
+    return mine ? sum : 0.0;      // (the threads past ivec_dim add exact zeros to the block sums)
   };
   // p0 = b - A x0 ; r0 = -p0
   double p = b - matvec(xs), r = -p;
@@ -1322,7 +1338,8 @@ __device__ __forceinline__ double IvecCgSolve(const IvecDev &iv, const double *A
     if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
       if (mine) xs[tid] = x;
       __syncthreads();
-      r = mine ? matvec(xs) - b : 0.0;
+      const double ax = matvec(xs);          // (every thread: the product has a barrier inside)
+      r = mine ? ax - b : 0.0;
       in1[0] = r * r;
       BlockSumK<1, NW>(in1, out1, xch, rb);
       r_next = out1[0];
@@ -1478,7 +1495,7 @@ bool LaunchIvecChain(const IvecDev &iv, int n_utts, int K, const double *dlin, c
   const int n = iv.ivec_dim;
   if (n > 128) return false;
   if (n_utts == 0 || K == 0) return true;
-  const size_t smem = sizeof(double) * ((size_t)n * n + 2 * (size_t)n);
+  const size_t smem = sizeof(double) * ((size_t)n * n + 3 * (size_t)n);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecChainKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1496,7 +1513,7 @@ void LaunchIvecSolve(const IvecDev &iv, int n_utts, const double *linear, const 
   if (n_utts == 0) return;
   int n = iv.ivec_dim;
   if (n <= 128) {
-    const size_t smem = sizeof(double) * ((size_t)n * n + 2 * (size_t)n);
+    const size_t smem = sizeof(double) * ((size_t)n * n + 3 * (size_t)n);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&IvecSolveFullKernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
