@@ -9,7 +9,7 @@ rm -rf /tmp/rstune && mkdir -p /tmp/rstune/profiles && cp -r rhasspy_speech_amd 
 make -C /tmp/rstune/rhasspy_speech_amd/csrc -j32 EXTRA=-DRS_TUNING > $OUT/make.log 2>&1 || { tail $OUT/make.log; exit 1; }
 cp rhasspy_speech_amd/librhasspy_speech_hip.so /tmp/librs_orig.so; cp /tmp/rstune/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/librhasspy_speech_hip.so
 B="python bench.py --no-cpu-baseline --no-side-figures"
-for st in 1 0 2 1; do
+for st in ${STS:-1 0 2 1}; do
   RS_GEMM_B3J_STAGGER=$st timeout 120 $B --steps 300 --warmup 20 2>/dev/null | tail -1 > $OUT/line_$st.json
   python - <<PY
 import json
