@@ -252,16 +252,29 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
   const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
   unsigned active = 0;          // bit r: row r is a real frame (wave-uniform)
   for (int i = threadIdx.x; i < 16 * NT; i += 256) gcs[i] = iv.gconsts[i < G ? i : G - 1];
-#pragma unroll
-  for (int r = 0; r < kUbmRows; r++) {
-    const int row = row0 + r;
-    bool ok = row < g.total_rows;
-    if (ok) {
-      const int u = g.d_row_utt[row], t = g.d_row_t[row];
-      ok = t >= 0 && t < g.d_num_frames[u];
+  {
+    // which of the wave's rows are frames: lane r looks its row up (row -> utterance, frame index -> frame count: three dependent
+    // loads, once, for all 16 rows side by side), then the 16 feature rows are requested together.  Row after row -- each row's
+    // lookups and its feature load behind the previous row's -- the wave began with 64 dependent global round trips, about as long
+    // as its 640 MFMAs (scoring alone took 115 us for the headline batch against the matrix pipe's 54).
+    bool ok = false;
+    if (lane < kUbmRows) {
+      const int row = row0 + lane;
+      ok = row < g.total_rows;
+      if (ok) {
+        const int u = g.d_row_utt[row], t = g.d_row_t[row];
+        ok = t >= 0 && t < g.d_num_frames[u];
+      }
     }
-    active |= ok ? (1u << r) : 0u;
-    if (lane < 16 * KG) xs[wave][r][lane] = (ok && lane < D) ? feats[(size_t)row * ld + lane] : 0.f;
+    active = (unsigned)(__ballot(ok) & 0xFFFFull);
+    float xv[kUbmRows];
+#pragma unroll
+    for (int r = 0; r < kUbmRows; r++)
+      xv[r] = (((active >> r) & 1u) && lane < D && lane < 16 * KG) ? feats[(size_t)(row0 + r) * ld + lane] : 0.f;
+    if (lane < 16 * KG) {
+#pragma unroll
+      for (int r = 0; r < kUbmRows; r++) xs[wave][r][lane] = xv[r];
+    }
   }
   __syncthreads();
   if (active != 0u) {
