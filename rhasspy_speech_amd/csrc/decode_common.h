@@ -270,15 +270,18 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
     int F = T, st = reached ? i1 : i2;
     bool done = false;
     const long long idx0 = (long long)(bp - w.bp);        // my first row in the buffer, in ints (the buffer itself is 16-byte aligned)
-    int4 pf[kPF];
+    // (eight named registers: as an array the block in flight was kept in scratch memory, with a wait after every load)
+    int4 pf0 = {0, 0, 0, 0}, pf1 = pf0, pf2 = pf0, pf3 = pf0, pf4 = pf0, pf5 = pf0, pf6 = pf0, pf7 = pf0;
+    static_assert(kPF == 8, "the block in flight is eight named registers");
     int pf_tail = 0;
     int lo = F - rows_cap + 1 > 0 ? F - rows_cap + 1 : 0; // rows lo..F
     auto fetch = [&](int lo_, int F_) {
       const long long first = idx0 + (long long)lo_ * S, last = idx0 + (long long)(F_ + 1) * S, start = first & ~3ll;
       const int nfull = (int)((last - start) >> 2), ntail = (int)((last - start) & 3);
       const int4 *src4 = reinterpret_cast<const int4 *>(w.bp + start);
-#pragma unroll
-      for (int q = 0; q < kPF; q++) if (q * NT + tid < nfull) pf[q] = src4[q * NT + tid];
+#define RS_PF_LOAD(q) if ((q) * NT + tid < nfull) pf##q = src4[(q) * NT + tid];
+      RS_PF_LOAD(0) RS_PF_LOAD(1) RS_PF_LOAD(2) RS_PF_LOAD(3) RS_PF_LOAD(4) RS_PF_LOAD(5) RS_PF_LOAD(6) RS_PF_LOAD(7)
+#undef RS_PF_LOAD
       if (tid < ntail) pf_tail = w.bp[start + 4ll * nfull + tid];
     };
     fetch(lo, F);
@@ -286,8 +289,9 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       const long long first = idx0 + (long long)lo * S, last = idx0 + (long long)(F + 1) * S, start = first & ~3ll;
       const int skip = (int)(first - start), nfull = (int)((last - start) >> 2), ntail = (int)((last - start) & 3);
       __syncthreads();                                    // (everybody is done with the previous block)
-#pragma unroll
-      for (int q = 0; q < kPF; q++) if (q * NT + tid < nfull) reinterpret_cast<int4 *>(rows)[q * NT + tid] = pf[q];
+#define RS_PF_STAGE(q) if ((q) * NT + tid < nfull) reinterpret_cast<int4 *>(rows)[(q) * NT + tid] = pf##q;
+      RS_PF_STAGE(0) RS_PF_STAGE(1) RS_PF_STAGE(2) RS_PF_STAGE(3) RS_PF_STAGE(4) RS_PF_STAGE(5) RS_PF_STAGE(6) RS_PF_STAGE(7)
+#undef RS_PF_STAGE
       for (int i = kPF * NT + tid; i < nfull; i += NT) reinterpret_cast<int4 *>(rows)[i] = reinterpret_cast<const int4 *>(w.bp + start)[i];      // (rows of more than 32 NT states)
       if (tid < ntail) rows[4 * nfull + tid] = pf_tail;
       __syncthreads();
