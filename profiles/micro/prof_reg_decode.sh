@@ -11,8 +11,8 @@ cp /tmp/rsprof/rhasspy_speech_amd/librhasspy_speech_hip.so rhasspy_speech_amd/li
 for nt in auto 512; do
   for infl in 1 4; do
     if [ $nt = auto ]; then unset RS_REG_NT; else export RS_REG_NT=$nt; fi
-    python bench.py --no-cpu-baseline --no-side-figures --steps 2 --warmup 1 --inflight $infl 2>&1 | grep "reg decode" | tail -n 6 > $OUT/reg_phases_${nt}_inflight$infl.txt
+    python bench.py --no-cpu-baseline --no-side-figures --steps 2 --warmup 1 --inflight $infl 2>&1 | grep "reg decode" | tail -n 8 > $OUT/reg_phases_${nt}_inflight$infl.txt
   done
 done
 cp /tmp/librs_orig.so rhasspy_speech_amd/librhasspy_speech_hip.so
-tail -n 2 $OUT/reg_phases_*.txt
+tail -n 3 $OUT/reg_phases_*.txt

@@ -250,6 +250,15 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
   __syncthreads();
   const bool reached = b1 < INF;
   const bool ok = !error && T > 0 && b2 < INF;
+#ifdef RS_DECODE_PROFILE
+  long long fin_t[5] = {clock64(), 0, 0, 0, 0};
+  int fin_blocks = 0;
+#define RS_FIN_T(i) fin_t[i] = clock64()
+#define RS_FIN_BLOCK fin_blocks++
+#else
+#define RS_FIN_T(i)
+#define RS_FIN_BLOCK
+#endif
   // ---- traceback (GetBestPath).  The back-pointer rows are staged through LDS a block of frames at a time so that the
   // inherently sequential walk runs at LDS latency: a block is a contiguous run of the buffer, fetched 16 bytes per thread and
   // load, and the NEXT block (the walk always continues with the frames right below this one) is in flight, in registers, while
@@ -285,7 +294,9 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       if (tid < ntail) pf_tail = w.bp[start + 4ll * nfull + tid];
     };
     fetch(lo, F);
+    RS_FIN_T(1);
     while (!done) {
+      RS_FIN_BLOCK;
       const long long first = idx0 + (long long)lo * S, last = idx0 + (long long)(F + 1) * S, start = first & ~3ll;
       const int skip = (int)(first - start), nfull = (int)((last - start) >> 2), ntail = (int)((last - start) & 3);
       __syncthreads();                                    // (everybody is done with the previous block)
@@ -298,20 +309,41 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       const int next_F = lo - 1, next_lo = next_F - rows_cap + 1 > 0 ? next_F - rows_cap + 1 : 0;
       if (next_F >= 0) fetch(next_lo, next_F);
       if (tid == 0) {
-        while (true) {
-          const int arc = rows[skip + (F - lo) * S + st];
-          if (arc < 0) { done = true; break; }
-          int src;
-          bool emitting;
-          if (src_in_lds) { const unsigned sx = lds_src[arc]; src = (int)(sx & 0x7fffu); emitting = (sx & 0x8000u) == 0u; }
-          else { const int sx = h.arc_srcx[arc]; src = sx & 0x7fffffff; emitting = sx >= 0; }      // source state | (epsilon arc ? 1 << 31 : 0)
-          const int Fs = emitting ? F - 1 : F;
-          if (path_len < w.path_cap) { path[2 * path_len] = arc; path[2 * path_len + 1] = Fs; }
-          path_len++;
-          st = src;
-          F = Fs;
-          if (F < lo) break;       // need older rows
+        // (the walk is ~300 dependent hops of one lane, ~470 clocks each: two LDS reads and as few instructions as possible per hop --
+        // the row's address and the path's are carried along, the choice of the source table is made outside the loop.  It is the
+        // walk, not the trips to memory, that the traceback's time is made of: with two blocks in flight instead of one it takes
+        // the same 143 k clocks for 303 hops in 25 blocks, profiles/micro/prof_reg_decode.sh)
+        const int *row = rows + skip + (F - lo) * S;
+        int *out = path + 2 * path_len;
+        int room = w.path_cap - path_len;
+        if (src_in_lds) {
+          while (true) {
+            const int arc = row[st];
+            if (arc < 0) { done = true; break; }
+            const unsigned sx = lds_src[arc];
+            const int eps = (int)(sx >> 15);                // 1: epsilon arc, the source is in the same row
+            F -= 1 - eps;
+            if (room > 0) { out[0] = arc; out[1] = F; out += 2; }
+            room--;
+            st = (int)(sx & 0x7fffu);
+            row -= eps ? 0 : S;
+            if (F < lo) break;       // need older rows
+          }
+        } else {
+          while (true) {
+            const int arc = row[st];
+            if (arc < 0) { done = true; break; }
+            const int sx = h.arc_srcx[arc];                 // source state | (epsilon arc ? 1 << 31 : 0)
+            const int eps = (int)((unsigned)sx >> 31);
+            F -= 1 - eps;
+            if (room > 0) { out[0] = arc; out[1] = F; out += 2; }
+            room--;
+            st = sx & 0x7fffffff;
+            row -= eps ? 0 : S;
+            if (F < lo) break;
+          }
         }
+        path_len = w.path_cap - room;
         red.bi[0] = done ? 1 : 0; red.bi[1] = F; red.bi[2] = st; red.bi[3] = path_len;
       }
       __syncthreads();
@@ -321,6 +353,7 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
     }
   }
   __syncthreads();
+  RS_FIN_T(2);
   // ---- path costs and words, in parallel over the path
   const bool path_ok = ok && path_len <= w.path_cap;
   double pg = 0.0, pa = 0.0;
@@ -345,6 +378,7 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
   if ((tid & 63) == 0) { dsum[(tid >> 6) * 2] = pg; dsum[(tid >> 6) * 2 + 1] = pa; }
   __syncthreads();
   if (tid < 64) {
+    RS_FIN_T(3);
     // wave 0: ordered compaction of the word labels (path is stored last-arc-first)
     int *words = w.out_words + (size_t)u * w.max_words;
     int nw = 0;
@@ -373,8 +407,16 @@ __device__ void FinishUtterance(Red<NT / 64> &red, const HclgDev &h, const Batch
       // += : a resumable decoder has already flushed the counts of earlier time slabs (the buffer starts zeroed)
       for (int i = 0; i < 4; i++) c8[i] += (long long)ctr[i];
       c8[4] = 0; c8[5] += max_active_frames; c8[6] += min_active_frames; c8[7] = error ? 2 : 0;
+#ifdef RS_DECODE_PROFILE
+      RS_FIN_T(4);
+      if (u == 0)
+        printf("reg decode finish cycles: pick + arc sources %lld, traceback %lld (%d blocks of %d rows, path %d), path costs %lld, words + results %lld\n",
+               fin_t[1] - fin_t[0], fin_t[2] - fin_t[1], fin_blocks, rows_cap, path_len, fin_t[3] - fin_t[2], fin_t[4] - fin_t[3]);
+#endif
     }
   }
+#undef RS_FIN_T
+#undef RS_FIN_BLOCK
 }
 
 }  // namespace dd
