@@ -251,10 +251,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   using Ctx = LiveCtx<NT>;
   constexpr int NW = NT / 64;
   static_assert(HS % 4 == 0 && HS + kGlobalSize <= 65536, "slots are named in 16 bits");
-  __shared__ Ctx c;
-  __shared__ __attribute__((aligned(16))) unsigned tags[HS];
-  __shared__ __attribute__((aligned(16))) unsigned long long lkeys[HS];
-  __shared__ int4 stage_all[NT / 64][kStageCap];             // per wave: candidate arcs waiting for insertion {arc | flags, destination, cost bits, source token}
+  // One LDS object with the workgroup's scalars FIRST: an LDS word at a constant address below 64 KB is a zero base register plus
+  // an instruction offset; laid out by the linker the scalars sat behind the table (0x27090...) and every one of them that a loop
+  // touches held a VGPR with its address for the whole kernel -- fifteen of the 128 a wave of this workgroup has, with spills.
+  struct Lds {
+    alignas(16) Ctx c;
+    alignas(16) unsigned long long lkeys[HS];
+    alignas(16) unsigned tags[HS];
+    alignas(16) int4 stage_all[NT / 64][kStageCap];         // per wave: candidate arcs waiting for insertion {arc | flags, destination, cost bits, source token}
+  };
+  __shared__ Lds lds;
+  Ctx &c = lds.c;
+  auto &tags = lds.tags;
+  auto &lkeys = lds.lkeys;
+  auto &stage_all = lds.stage_all;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = blockIdx.x, tid = threadIdx.x;
   const int T = g.d_num_frames[u];
