@@ -400,10 +400,22 @@ def main() -> None:
     def run_steps(n, fn, check_against=None):
         """n steps, at most `inflight` decode calls in flight; results are consumed (and gathered) in step order."""
         t_start = time.perf_counter()
-        futures = [pool.submit(fn) for _ in range(n)] if inflight > 1 else None
+        if os.environ.get("RS_BENCH_TRACE"):
+            inner = fn
+
+            def fn():
+                t_in = time.perf_counter()
+                r = inner()
+                sys.stderr.write(f"  call entered at {(t_in - t_start) * 1e3:.2f} ms, returned at {(time.perf_counter() - t_start) * 1e3:.2f} ms\n")
+                return r
+        # `inflight` calls are outstanding at any time, the next one is submitted when the oldest has been consumed (all n submitted
+        # up front, the worker threads could not start before this thread had finished submitting: ~1 ms of an idle device per run)
+        futures = [pool.submit(fn) for _ in range(min(n, inflight))] if inflight > 1 else None
         last = None
         for k in range(n):
             res = futures[k].result() if futures else fn()
+            if futures and len(futures) < n:
+                futures.append(pool.submit(fn))
             if os.environ.get("RS_BENCH_TRACE"):
                 tm_ = res.timings() if hasattr(res, "timings") else []
                 sys.stderr.write(f"step {k} done at {(time.perf_counter() - t_start) * 1e3:.2f} ms  timings {[round(x, 2) for x in tm_]}\n")
