@@ -201,9 +201,17 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
           if (hm != 0ull && cnt <= 64) {
             fast_used = true;
             RS_T2(1);
-            for (int s = tid; s < S; s += NT) {
-              const float c = cost_cur[s];
-              if (c < INF && HistBin(c) == bin) red.cand[atomicAdd(&red.ncand, 1)] = c;
+            {
+              constexpr int kCS = 3;      // (the costs first, then the appends: as in the commit pass)
+              float cq[kCS];
+#pragma unroll
+              for (int q = 0; q < kCS; q++) { const int s = tid + q * NT; cq[q] = cost_cur[s < S ? s : S]; }      // (cost_cur[S] = +inf)
+#pragma unroll
+              for (int q = 0; q < kCS; q++) if (cq[q] < INF && HistBin(cq[q]) == bin) red.cand[atomicAdd(&red.ncand, 1)] = cq[q];
+              for (int s = tid + kCS * NT; s < S; s += NT) {
+                const float c = cost_cur[s];
+                if (c < INF && HistBin(c) == bin) red.cand[atomicAdd(&red.ncand, 1)] = c;
+              }
             }
             LdsBarrier();           // (red.ncand goes back to zero behind the arc pass's barrier)
             RS_T2(2);
@@ -412,8 +420,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     }
     hpar ^= 1;
     for (int i = tid; i < 256; i += NT) hist2[hpar ^ 1][i] = 0;        // the one this frame's GetCutoff has read
-    for (int s = tid; s < S; s += NT) {
-      const unsigned long long k = key_next[s];
+    auto commit_state = [&](int s, unsigned long long k) {
       const float c = wv::OrderedToFloat((unsigned)(k >> 32));
       const bool alive = c < closure_cutoff;                     // empty -> NaN -> false
       bp_row[s] = alive ? (int)(unsigned)(k & 0xFFFFFFFFull) : -2;
@@ -425,6 +432,17 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       const bool better = alive & (c < st_min);
       st_min = better ? c : st_min;
       st_arg = better ? s : st_arg;
+    };
+    {
+      // a thread's first kCS keys are read together, then committed: written as one loop the LDS atomic of state s (which may alias
+      // anything, as far as the compiler knows) stood between the reads, one LDS round trip per state behind the other
+      constexpr int kCS = 3;
+      unsigned long long kq[kCS];
+#pragma unroll
+      for (int q = 0; q < kCS; q++) { const int s = tid + q * NT; kq[q] = key_next[s < S ? s : S]; }      // (key_next has S + 1 entries)
+#pragma unroll
+      for (int q = 0; q < kCS; q++) { const int s = tid + q * NT; if (s < S) commit_state(s, kq[q]); }
+      for (int s = tid + kCS * NT; s < S; s += NT) commit_state(s, key_next[s]);
     }
     n_alive += (unsigned)st_cnt;
     RS_T(4);
