@@ -78,15 +78,17 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   int *bp = w.bp + frame_row0 * S;
   float *finfo = w.frame_info + frame_row0 * 4;
   const float INF = INFINITY;
-  const size_t ll_base = (size_t)g.d_row_base[u] + g.L;
-  unsigned long long n_expanded = 0, n_arcs = 0, n_insert = 0, n_alive = 0;
+  // (the utterance's first row through readfirstlane: loaded by a vector instruction it stays in a VGPR, and with it the 64-bit row
+  // address of every frame -- eight VALU instructions per frame and a 64-bit add per load instead of base register + 32-bit offset)
+  const size_t ll_base = (size_t)__builtin_amdgcn_readfirstlane(g.d_row_base[u]) + g.L;
+  unsigned n_expanded = 0, n_arcs = 0, n_insert = 0, n_alive = 0;      // (a thread's share of one launch: 32 bits; as 64-bit counters, two instructions per arc and frame)
   int max_active_frames = 0, min_active_frames = 0;
 
   // ---- my arcs, in registers for the whole utterance
-  int4 ea[KE];         // {src cost addr | dst key addr << 16, pdf, weight bits, forward arc index}
+  int4 ea[KE];         // {src cost addr | dst key addr << 16, pdf * 4 (a byte offset into the frame's row), weight bits, forward arc index}
   int4 xa[KX];         // {src key-high-word addr | dst key addr << 16, -, weight bits, forward arc index}
 #pragma unroll
-  for (int a = 0; a < KE; a++) ea[a] = rg.e_tab[(size_t)a * NT + tid];
+  for (int a = 0; a < KE; a++) { ea[a] = rg.e_tab[(size_t)a * NT + tid]; ea[a].y <<= 2; }
 #pragma unroll
   for (int a = 0; a < KX; a++) xa[a] = rg.x_tab[(size_t)a * NT + tid];
   for (int s = tid; s <= S; s += NT) { cost_cur[s] = (f_begin >= 0 && s < S) ? state[s] : INF; key_next[s] = RS_EMPTY; }
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
   if (f_first < T) {
     const float *row = loglikes + (ll_base + f_first) * ld;
 #pragma unroll
-    for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
+    for (int a = 0; a < KE; a++) llv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(row) + (unsigned)ea[a].y);
   }
   __syncthreads();
   if (f_begin < 0 && tid == 0) key_next[h.start] = PackKey(0.0f, RS_NOARC);
@@ -341,7 +343,13 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
       {
         const float *row = loglikes + (ll_base + (f + 1 < T ? f + 1 : f)) * ld;
 #pragma unroll
-        for (int a = 0; a < KE; a++) llv[a] = row[ea[a].y];
+        for (int a = 0; a < KE; a++) {
+          // (the empty asm keeps the 32 -> 64 bit extension of the offset inside the loop, where instruction selection can fold it
+          // into the load: scalar base + 32-bit vector offset.  Hoisted, the offsets are eight 64-bit register pairs and every
+          // load is preceded by a 64-bit vector add)
+          asm volatile("" : "+v"(ea[a].y));
+          llv[a] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(row) + (unsigned)ea[a].y);
+        }
       }
       float next_cutoff;
       {
@@ -456,10 +464,10 @@ __global__ __launch_bounds__(NT) void RegDecodeKernel(HclgDev h, RegGraphDev rg,
     if (tid == 0) { state[S] = closure_cutoff; state[S + 1] = (float)error; }
     for (int i = tid; i < 8; i += NT) red.ctr[i] = 0;
     __syncthreads();
-    atomicAdd(&red.ctr[0], n_expanded);
-    atomicAdd(&red.ctr[1], n_arcs);
-    atomicAdd(&red.ctr[2], n_insert);
-    atomicAdd(&red.ctr[3], n_alive);
+    atomicAdd(&red.ctr[0], (unsigned long long)n_expanded);
+    atomicAdd(&red.ctr[1], (unsigned long long)n_arcs);
+    atomicAdd(&red.ctr[2], (unsigned long long)n_insert);
+    atomicAdd(&red.ctr[3], (unsigned long long)n_alive);
     __syncthreads();
     if (tid == 0) {
       long long *c8 = w.counters + slot * 8;
