@@ -8,7 +8,10 @@ namespace wv {
 
 template <int CTRL>
 __device__ __forceinline__ unsigned Dpp(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  // (old = 0 with bound_ctrl: a row rotation gives every lane a source, so the result is the same -- and the compiler folds the
+  // move into the operation that consumes it, v_min_u32_dpp instead of copy + nop + v_mov_b32_dpp + v_min_u32: two issue slots per
+  // step of a reduction instead of four)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 // butterfly of row rotations inside each row of 16 lanes (row_ror:1,2,4,8), then the four row results via SGPRs
 #define RS_WAVE_REDUCE(OP)                                                                                              \
