@@ -307,21 +307,26 @@ void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float 
 // per frame), (2) one thread per frame does SmoothOnlineCmvnStats' per-frame scalars (the two fp64 divisions), (3) all
 // threads apply the mean-only ApplyCmvn to the chunk in parallel with coalesced stores.  No speaker stats: the
 // reference starts every utterance from a fresh process.
-constexpr int kCmvnTC = 32, kCmvnMaxDim = 128;
+constexpr int kCmvnTC = 32;      // frames per chunk (the feature dimension is at most 128: engine.cc)
 //
 // Streams (t_begin != null): utterance u resumes at frame t_begin[u] with the running sums and the window count parked in
 // state[(D + 1) * state_slot[u]] by the launch that produced frame t_begin[u] - 1, and parks them again at frame T; the frames
 // that leave the window are re-read from `in`, which holds the whole stream.
+template <int kPer>      // elements of a chunk per thread, at most: kCmvnTC * D <= 256 * kPer
 __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, const float *__restrict__ in, float *__restrict__ out, int ld,
                                                         const int *__restrict__ t_begin, double *__restrict__ state, const int *__restrict__ state_slot) {
-  __shared__ float xs[kCmvnTC][kCmvnMaxDim];      // the chunk
-  __shared__ float xp[kCmvnTC][kCmvnMaxDim];      // the frames leaving the window while the chunk enters
-  __shared__ double ss[kCmvnTC][kCmvnMaxDim];     // running sums after each frame
-  __shared__ double nn[kCmvnTC], aa[kCmvnTC];     // frame count in the window; weight of the global stats
-  __shared__ float al[kCmvnTC];                   // -1 / (smoothed count)
-  __shared__ float edge[2][kCmvnMaxDim];          // normalised first / last frame (halo rows replicate them)
-  __shared__ double gs[kCmvnMaxDim];              // global stats (read per element in step 3 while the window is not full)
+  // LDS by the feature dimension (40: 23 KB; as [32][128] arrays the kernel held 68 KB of a CU, i.e. the place of one of the two
+  // layer-GEMM workgroups of the call in flight beside it), and the NEXT chunk's frames are in flight, in registers, while a chunk
+  // is processed (every chunk used to start with a trip to memory: ten of them per 3 s utterance).
+  extern __shared__ __attribute__((aligned(16))) unsigned char cmvn_smem[];
   const int u = blockIdx.x, tid = threadIdx.x, D = c.dim, W = c.cmn_window;
+  double *ss = reinterpret_cast<double *>(cmvn_smem);                 // [TC][D] running sums after each frame
+  double *gs = ss + kCmvnTC * D;                                       // [D] global stats (read per element in step 3 while the window is not full)
+  double *nn = gs + D, *aa = nn + kCmvnTC;                             // [TC] frame count in the window; weight of the global stats
+  float *xs = reinterpret_cast<float *>(aa + kCmvnTC);                // [TC][D] the chunk
+  float *xp = xs + kCmvnTC * D;                                        // [TC][D] the frames leaving the window while the chunk enters
+  float *al = xp + kCmvnTC * D;                                        // [TC] -1 / (smoothed count)
+  float *edge = al + kCmvnTC;                                          // [2][D] normalised first / last frame (halo rows replicate them)
   if (tid < D) gs[tid] = c.global_stats[tid];
   const int T = g.d_num_frames[u];
   const size_t base = (size_t)g.d_row_base[u] + g.L;
@@ -330,21 +335,40 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
   const int t_first = t_begin ? t_begin[u] : 0;
   double *park = t_begin ? state + (size_t)(D + 1) * state_slot[u] : nullptr;
   if (park && t_first > 0 && tid < D) { sum = park[tid]; count = park[D]; }
+  float nx[kPer], np[kPer];
+  const int i_first = tid / D, d_first = tid - i_first * D, i_step = 256 / D, d_step = 256 - i_step * D;      // element tid + 256 q = (frame, dimension), by steps
+  auto fetch = [&](int t0) {                             // element idx = tid + 256 q of the chunk that starts at frame t0
+    const int n = T - t0 < kCmvnTC ? T - t0 : kCmvnTC;
+    int i = i_first, d = d_first;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+      nx[q] = 0.f; np[q] = 0.f;
+      if (i < n) {
+        const float *row = in + (base + t0 + i) * ld + d;
+        nx[q] = row[0];
+        if (t0 + i - W >= 0) np[q] = row[-(ptrdiff_t)W * ld];
+      }
+      i += i_step; d += d_step;
+      if (d >= D) { d -= D; i++; }
+    }
+  };
+  if (t_first < T) fetch(t_first);
   for (int t0 = t_first; t0 < T; t0 += kCmvnTC) {
     const int n = T - t0 < kCmvnTC ? T - t0 : kCmvnTC;
-    for (int idx = tid; idx < n * D; idx += 256) {
-      const int i = idx / D, d = idx % D, tp = t0 + i - W;
-      xs[i][d] = in[(base + t0 + i) * ld + d];
-      xp[i][d] = tp >= 0 ? in[(base + tp) * ld + d] : 0.f;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+      const int idx = tid + 256 * q;
+      if (idx < n * D) { xs[idx] = nx[q]; xp[idx] = np[q]; }
     }
     __syncthreads();
+    if (t0 + kCmvnTC < T) fetch(t0 + kCmvnTC);
     if (tid < D) {
-#pragma unroll 8
+#pragma unroll 4
       for (int i = 0; i < n; i++) {
-        sum += (double)xs[i][tid];
+        sum += (double)xs[i * D + tid];
         count += 1.0;
-        if (t0 + i - W >= 0) { sum -= (double)xp[i][tid]; count -= 1.0; }
-        ss[i][tid] = sum;
+        if (t0 + i - W >= 0) { sum -= (double)xp[i * D + tid]; count -= 1.0; }
+        ss[i * D + tid] = sum;
         if (tid == 0) nn[i] = count;
       }
     }
@@ -361,29 +385,36 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
     }
     __syncthreads();
     for (int idx = tid; idx < n * D; idx += 256) {
-      const int i = idx / D, d = idx % D;
-      double sv = ss[i][d];
+      const int i = idx / D, d = idx - i * D;
+      double sv = ss[idx];
       const double a = aa[i];
       if (a > 0.0) sv += a * gs[d];
       const float offset = (float)((double)al[i] * sv);
-      const float yv = xs[i][d] + offset;
+      const float yv = xs[idx] + offset;
       out[(base + t0 + i) * ld + d] = yv;
-      if (t0 + i == 0) edge[0][d] = yv;
-      if (t0 + i == T - 1) edge[1][d] = yv;
+      if (t0 + i == 0) edge[d] = yv;
+      if (t0 + i == T - 1) edge[D + d] = yv;
     }
     __syncthreads();
   }
   if (park && tid < D) { park[tid] = sum; if (tid == 0) park[D] = count; }
   if (T > 0 && !t_begin) {
-    for (int idx = tid; idx < g.L * D; idx += 256) out[(base - g.L + idx / D) * ld + idx % D] = edge[0][idx % D];
-    for (int idx = tid; idx < g.R * D; idx += 256) out[(base + T + idx / D) * ld + idx % D] = edge[1][idx % D];
+    for (int idx = tid; idx < g.L * D; idx += 256) out[(base - g.L + idx / D) * ld + idx % D] = edge[idx % D];
+    for (int idx = tid; idx < g.R * D; idx += 256) out[(base + T + idx / D) * ld + idx % D] = edge[D + idx % D];
   }
 }
 
 void LaunchOnlineCmvn(const CmvnDev &c, const BatchGeom &g, const float *in, float *out, int ld, hipStream_t s, const int *t_begin,
                       double *state, const int *state_slot) {
   if (g.n_utts == 0) return;
-  hipLaunchKernelGGL(OnlineCmvnKernel, dim3(g.n_utts), dim3(256), 0, s, c, g, in, out, ld, t_begin, state, state_slot);
+  const int D = c.dim;
+  // (D <= 128: engine.cc refuses more cepstral coefficients when the model is loaded; kPer = 16 covers 32 frames x 128)
+  const size_t smem = sizeof(double) * ((size_t)kCmvnTC * D + D + 2 * kCmvnTC) + sizeof(float) * ((size_t)2 * kCmvnTC * D + kCmvnTC + 2 * D);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&OnlineCmvnKernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); attr_set = true; }
+  if (D <= 40) hipLaunchKernelGGL(OnlineCmvnKernel<5>, dim3(g.n_utts), dim3(256), smem, s, c, g, in, out, ld, t_begin, state, state_slot);
+  else if (D <= 64) hipLaunchKernelGGL(OnlineCmvnKernel<8>, dim3(g.n_utts), dim3(256), smem, s, c, g, in, out, ld, t_begin, state, state_slot);
+  else hipLaunchKernelGGL(OnlineCmvnKernel<16>, dim3(g.n_utts), dim3(256), smem, s, c, g, in, out, ld, t_begin, state, state_slot);
 }
 
 // ------------------------------------------------------------------------------------------ row copies
