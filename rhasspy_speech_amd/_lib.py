@@ -227,7 +227,11 @@ class Model:
             lib().rs_model_free(self._h)
             self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except TypeError:      # interpreter shutdown: the module's globals are gone already, and the process's memory goes with it
+            pass
 
     def to_device(self) -> None:
         _check(lib().rs_model_to_device(self._h))
