@@ -1115,9 +1115,7 @@ __global__ __launch_bounds__(NT) void DenseLatticeKernel(HclgDev h, DecodeOptsDe
         live |= ((cst[q] < INF && !(f == 0 && st == h.start)) ? 1u : 0u) << q;      // (frame 0: the start state's token is number 0, the others follow)
       }
       const int n_live = __popc(live);
-      int inc = n_live;
-#pragma unroll
-      for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+      const int inc = dd::WaveScanIncl(n_live);      // (DPP row shifts + broadcasts; as six __shfl_up steps: six dependent ds_bpermute round trips)
       if (lane == 63) s_wtot[wave] = inc;
       dd::LdsBarrier();
       int run = (f == 0 ? 1 : 0) + inc - n_live;
@@ -1222,21 +1220,24 @@ __global__ __launch_bounds__(NT) void DenseLatticeKernel(HclgDev h, DecodeOptsDe
         }
       }
       const int n_mine = __popc(emit);
-      int inc = n_mine;
-#pragma unroll
-      for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
-      const int wave_total = __shfl(inc, 63, 64);
+      const int inc = dd::WaveScanIncl(n_mine);
+      const int wave_total = __builtin_amdgcn_readlane(inc, 63);
       if (wave_total > 0) {
+        // the token numbers of both ends of every arc first (LDS), then the records (global stores)
+        int rs_[KA], rd_[KA];
+#pragma unroll
+        for (int k = 0; k < KA; k++) {
+          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
+          rs_[k] = off + (int)rk_cur[src];
+          rd_[k] = ax[k] > 0 ? off_n + (int)rk_nxt[dst] : off + (int)rk_cur[dst];
+        }
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_narcs, wave_total);
-        base = __shfl(base, 0, 64) + inc - n_mine;
+        base = __builtin_amdgcn_readfirstlane(base) + inc - n_mine;
 #pragma unroll
         for (int k = 0; k < KA; k++) {
           if (!(emit >> k & 1u)) continue;
-          const unsigned src = asd[k] & 0xFFFFu, dst = asd[k] >> 16;
-          if (base < lw.utt_cap)
-            my_arcs[base] = ax[k] > 0 ? LatArc{u, off + (int)rk_cur[src], off_n + (int)rk_nxt[dst], tid + k * NT, aw[k], acv[k] - cost_offset}
-                                      : LatArc{u, off + (int)rk_cur[src], off + (int)rk_cur[dst], tid + k * NT, aw[k], 0.f};
+          if (base < lw.utt_cap) my_arcs[base] = LatArc{u, rs_[k], rd_[k], tid + k * NT, aw[k], ax[k] > 0 ? acv[k] - cost_offset : 0.f};
           base++;
         }
       }
