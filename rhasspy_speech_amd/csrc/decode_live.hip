@@ -46,6 +46,7 @@
 
 #include "kernels.h"
 #include "decode_tok.h"
+#include "wave_ops.h"
 
 namespace rs {
 using namespace tok;
@@ -403,9 +404,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const int4 arc = arcsf[bsr.x + bsr.y + k];
           first_bound = fminf(first_bound, (__int_as_float(bt.y) + (cost_offset - ll_row[(arc.x & kPdfMask) - 1])) + __int_as_float(arc.z));
         }
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) first_bound = fminf(first_bound, __shfl_xor(first_bound, o2, 64));
-        if (lane == 0 && first_bound < INF) atomicMin(&c.run_min, OrderedBits(first_bound));
+        const unsigned fb = wv::MinU(OrderedBits(first_bound));
+        if (lane == 0 && fb < OrderedBits(INF)) atomicMin(&c.run_min, fb);
       }
       // Expansion in two steps, so that the expensive one runs with every lane busy:
       //   eval:  a lane looks at an arc -- cost, bounds, counters -- and parks the survivors (tot below "cheapest candidate seen so
@@ -418,10 +418,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       int st_n = 0;                     // parked arcs (wave-uniform)
       const unsigned long long lanes_below = (1ull << lane) - 1ull;
       auto publish_min = [&]() __attribute__((always_inline)) {
-        float m = lane_min;
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) m = fminf(m, __shfl_xor(m, o2, 64));
-        if (lane == 0 && OrderedBits(m) < c.run_min) __hip_atomic_fetch_min(&c.run_min, OrderedBits(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned mb = wv::MinU(OrderedBits(lane_min));      // (DPP; as __shfl_xor steps: six dependent ds_bpermute round trips per trip)
+        if (lane == 0 && mb < c.run_min) __hip_atomic_fetch_min(&c.run_min, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
       auto flush = [&](int first, int cnt) __attribute__((always_inline)) {      // parked arcs [first, first + cnt), cnt <= 64 (wave-uniform)
         const bool on = lane < cnt;
@@ -440,7 +438,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if (n_claimed && atomicAdd(&c.n_slots, n_claimed) + n_claimed > tb.slot_limit) c.redo = 1;
           if (failed || base + cnt > cand_cap) c.redo = 1;
         }
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);
         if (on && base + lane < cand_cap) cand[base + lane] = make_int2(it.x, (sl << 16) | it.w);
       };
       auto eval_arc = [&](bool valid, unsigned a, const int4 arc, float lk, float cur_cost, bool is_best, int src_tok) __attribute__((always_inline)) {
@@ -562,9 +560,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         st_n = 0;
       }
       // next_cutoff = min over the candidates of (tot_cost + adaptive_beam): one LDS atomic per wave instead of a block reduction
-#pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) local_min = fminf(local_min, __shfl_xor(local_min, o2, 64));
-      if (lane == 0) atomicMin(&c.min_bits, OrderedBits(local_min));
+      { const unsigned lb = wv::MinU(OrderedBits(local_min)); if (lane == 0) atomicMin(&c.min_bits, lb); }
       __syncthreads();
       RS_LP(2);
       const float next_cutoff = FromOrdered(c.min_bits) + adaptive_beam;
@@ -656,9 +652,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const bool live = fresh && ne_in > 0 && cur_cost < closure_cutoff;
           if (live) cnt_expanded++;
           const unsigned a0 = (unsigned)qe.y, ne = live ? (unsigned)ne_in : 0u;
-          unsigned ne_max = ne;
-#pragma unroll
-          for (int o2 = 32; o2 > 0; o2 >>= 1) ne_max = max(ne_max, (unsigned)__shfl_xor((int)ne_max, o2, 64));
+          const unsigned ne_max = wv::MaxU(ne);
           for (unsigned k = 0; k < ne_max; k++) {
             const bool has_arc = k < ne;
             const unsigned a = a0 + (has_arc ? k : 0u);
@@ -672,20 +666,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // (thousands of history states back off into ONE unigram state: a wave whose relaxing lanes all target the same
             // state reduces its keys first and issues a single atomic)
             const int first = __ffsll((long long)m) - 1;
-            const int d0 = __shfl(arc.w, first, 64);
+            const int d0 = __builtin_amdgcn_readlane(arc.w, first);
             const bool uniform = __ballot(act && arc.w != d0) == 0ull;
             unsigned long long nkey = act ? PackKey(tot, a) : RS_EMPTY;
             bool mine = act;
             if (uniform && __popcll(m) > 1) {
-              unsigned long long kmin = nkey;
-#pragma unroll
-              for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)(kmin & 0xFFFFFFFFull), o2, 64);
-                const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(kmin >> 32), o2, 64);
-                const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-                kmin = other < kmin ? other : kmin;
-              }
-              mine = act && nkey == kmin;          // keys are unique (arc ids): exactly one lane
+              // (the smallest 64-bit key = the smallest high word, then the smallest low word among its holders: two DPP reductions)
+              const unsigned khi = (unsigned)(nkey >> 32), klo = (unsigned)(nkey & 0xFFFFFFFFull);
+              const unsigned mhi = wv::MinU(khi);
+              const unsigned mlo = wv::MinU(khi == mhi ? klo : 0xFFFFFFFFu);
+              mine = act && khi == mhi && klo == mlo;          // keys are unique (arc ids): exactly one lane
             }
             if (mine) {
               const int sl2 = tb.FindOrInsertCounted((unsigned)arc.w);
@@ -744,14 +734,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
       }
       {
-        unsigned long long bk = li == 0x7fffffff ? RS_EMPTY : PackKey(lv, (unsigned)li);
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) {
-          const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)(bk & 0xFFFFFFFFull), o2, 64);
-          const unsigned hi32 = (unsigned)__shfl_xor((int)(unsigned)(bk >> 32), o2, 64);
-          const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
-          bk = other < bk ? other : bk;
-        }
+        const unsigned long long bk0 = li == 0x7fffffff ? RS_EMPTY : PackKey(lv, (unsigned)li);
+        const unsigned bhi = (unsigned)(bk0 >> 32), blo = (unsigned)(bk0 & 0xFFFFFFFFull);
+        const unsigned mhi = wv::MinU(bhi);
+        const unsigned mlo = wv::MinU(bhi == mhi ? blo : 0xFFFFFFFFu);
+        const unsigned long long bk = ((unsigned long long)mhi << 32) | mlo;
         if (lane == 0 && bk != RS_EMPTY) atomicMin(&c.best_key, bk);      // (reset in the prologue of ProcessEmitting, behind barriers)
       }
       __syncthreads();

@@ -8,6 +8,8 @@ namespace wv {
 
 template <int CTRL>
 __device__ __forceinline__ unsigned Dpp(unsigned v) {
+  // EVERY LANE OF THE WAVE MUST BE ACTIVE where these reductions are called (wave-uniform control flow): a disabled source lane reads
+  // as 0 under bound_ctrl.
   // (old = 0 with bound_ctrl: a row rotation gives every lane a source, so the result is the same -- and the compiler folds the
   // move into the operation that consumes it, v_min_u32_dpp instead of copy + nop + v_mov_b32_dpp + v_min_u32: two issue slots per
   // step of a reduction instead of four)
