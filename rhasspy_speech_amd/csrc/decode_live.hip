@@ -518,9 +518,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             int d[4], sum = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = 4 * lane + q; d[q] = i < nc ? ent[i].w : 0; sum += d[q]; }
-            int inc = sum;
-#pragma unroll
-            for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc, o2, 64); if (lane >= o2) inc += v; }
+            const int inc = wv::ScanIncl(sum);
             int run = inc - sum;
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int i = 4 * lane + q; if (i < nc) big_pre[i] = run; run += d[q]; }

@@ -34,6 +34,19 @@ __device__ __forceinline__ int Sum(int x) {
 }
 #undef RS_WAVE_REDUCE
 
+// inclusive prefix sum over the 64 lanes (row shifts + row broadcasts; the same sequence as dd::WaveScanIncl, decode_common.h)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int DppM(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND); }
+__device__ __forceinline__ int ScanIncl(int v) {
+  v += DppM<0x111, 0xF, true>(v);      // row_shr:1
+  v += DppM<0x112, 0xF, true>(v);      // row_shr:2
+  v += DppM<0x114, 0xF, true>(v);      // row_shr:4
+  v += DppM<0x118, 0xF, true>(v);      // row_shr:8
+  v += DppM<0x142, 0xA, false>(v);     // row_bcast:15 into rows 1 and 3
+  v += DppM<0x143, 0xC, false>(v);     // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // order-preserving float <-> unsigned maps (branch-free)
 __device__ __forceinline__ float OrderedToFloat(unsigned u) {
   return __uint_as_float(u ^ ((unsigned)((int)~u >> 31) | 0x80000000u));
