@@ -1250,8 +1250,10 @@ __global__ void IvecSolveKernel(IvecDev iv, const double *__restrict__ linear, c
 // Same iteration (LinearCgd, matrix/optimization.cc:453-566) and the same decisions as IvecSolveKernel.
 template <int CTRL>
 __device__ __forceinline__ double DppD(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);
+  // (old = 0 with bound_ctrl: the same value for a row rotation with every lane active -- all call sites are -- and one v_mov_b32_dpp
+  // per half instead of copy + wait state + v_mov_b32_dpp)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double ReadLaneD(double v, int l) {
