@@ -552,6 +552,33 @@ def main() -> None:
         side["frame_subsampling_factor_3"] = figure(n_fsf, time.perf_counter() - tf, "rs_decode_opts.frame_subsampling_factor = 3 on the same model and batch: "
                                                     "100 decoder frames per utterance instead of 298 (not the reference's configuration for this metric; rhasspy runs factor 1)")
         del fsf_model
+        # The second acoustic model of SURVEY.md section 8(d), "tdnn-f-like", at full size (tests/configs.py: TDNNF_SPEC -- TdnnComponent
+        # bottlenecks 1024 / 128 with 0.66-scaled residual sums, 2000 pdfs) on the same batch and graph shape; its first 64 utterances are
+        # checked against the reference's transcripts (tests/golden/configs/c5_tdnnf.npz), all of them in tests/test_gpu_configs.py.
+        f_md, f_gd = configs.build_tdnnf_model(Path(tempfile.gettempdir()) / f"rs_bench_tdnnf_rank{rank}")
+        f_model = _lib.Model(f_md, f_gd, _lib.default_opts(device_id=local_rank, prune_output_pdfs=0 if args.all_pdfs else 1))
+        f_model.to_device()
+
+        def tdnnf():
+            return f_model.decode_batch(pcms)
+        rf = tdnnf()
+        f_gold = configs.load_golden("c5_tdnnf")[0]
+        n_chk = min(len(f_gold), n_utts) if n_utts == 256 and rank == 0 else 0
+        if [rf.words(u) for u in range(n_chk)] != f_gold[:n_chk]:
+            raise SystemExit("bench.py: the factorised-TDNN model's transcripts differ from the reference's")
+        n_f = max(6, min(steps, 40))
+        run_steps(max(2, 2 * inflight), tdnnf)
+        tf = time.perf_counter()
+        run_steps(n_f, tdnnf)
+        side["tdnnf_model"] = figure(n_f, time.perf_counter() - tf, "the same batch on the full-size factorised TDNN (zamia-like-F: 1024 / 128 bottleneck TdnnComponents, "
+                                     f"residual sums, 2000 pdfs); {n_chk} transcripts checked against the reference's")
+        fst = np.zeros(8)
+        for _ in range(3):
+            fst += np.array(tdnnf().timings())
+        side["tdnnf_model"]["nnet_stage_ms"] = float(fst[3] / 3)
+        side["tdnnf_model"]["nnet_tflops"] = nnet_flops_per_row(f_model.describe()) * sum(1 + (len(p) - 400) // 160 for p in pcms) / (fst[3] / 3 * 1e-3) / 1e12
+        side["tdnnf_model"]["layer_gemm"] = [l for l in f_model.describe().splitlines() if l.startswith("layer_gemm")][0][:110]
+        del f_model
     # Stage times and the roofline come from un-overlapped calls made right after the timed region: same process, same
     # buffers, one call at a time.
     stage, counters, n_iso = np.zeros(8), np.zeros(8), 0

@@ -67,8 +67,18 @@ typedef struct rs_decode_opts {
                                 * reference's on the frames where min-active / max-active binds, about 40 % more search time; graphs it
                                 * does not apply to (more than 1000 states, chained epsilon arcs) are searched as with 0.  Default 0;
                                 * RS_EXACT_ORDER=0|1 overrides. */
-  int32_t reserved[4];
+  int32_t command_line_fixed;  /* RS_FIXED_* bits: options whose only supported value was given ON THE COMMAND LINE (--online=false,
+                                * --do-endpointing=false, --extra-left-context-initial=0, --prune-interval=25, --determinize-lattice=true).
+                                * ParseOptions reads --config first and the command line overrides it (util/parse-options.cc:328-345), so
+                                * an unsupported value of such an option in online.conf is then not an error.  rs_default_opts sets
+                                * ONLINE | DO_ENDPOINTING: rhasspy's command line carries both (transcribe_wav.py:48-49). */
+  int32_t reserved[3];
 } rs_decode_opts;
+#define RS_FIXED_ONLINE 1
+#define RS_FIXED_DO_ENDPOINTING 2
+#define RS_FIXED_EXTRA_LEFT_CONTEXT_INITIAL 4
+#define RS_FIXED_PRUNE_INTERVAL 8
+#define RS_FIXED_DETERMINIZE_LATTICE 16
 
 /* Fills `opts` with the values the reference's Python passes / Kaldi defaults. */
 int rs_default_opts(rs_decode_opts *opts);
@@ -91,6 +101,13 @@ void rs_model_free(rs_model *model);
 /* Writes a one-line-per-item description of the parsed model (dims, layer plan, graph size) into buf;
  * returns the number of bytes needed (like snprintf). */
 int rs_model_describe(const rs_model *model, char *buf, size_t len);
+/* The check the reference makes when a waveform arrives (OnlineGenericBaseFeature::MaybeCreateResampler, feat/online-feature.cc:
+ * 86-101; online2-wav-nnet3-latgen-faster.cc:233 hands it WaveData::SampFreq()): RS_OK when `sample_rate` is the model's
+ * --sample-frequency, else an error whose text is Kaldi's "Sampling frequency mismatch, expected 16000, got 8000 ...".  The PCM entry
+ * points below take samples, not files: a caller that read a wav header calls this first (rhasspy_speech_amd.transcribe_wav and the
+ * online2-wav-nnet3-latgen-faster shim do).  --allow-downsample / --allow-upsample in mfcc.conf (the reference then resamples) are
+ * refused with a message: the library does not resample. */
+int rs_model_check_sample_rate(const rs_model *model, float sample_rate);
 
 /* Offline batch decode = N invocations of the reference's 3-process pipeline with --online=false
  * (online2-wav-nnet3-latgen-faster.cc:196-300 + lattice-to-nbest.cc:80-110 + nbest-to-linear.cc:67-87).

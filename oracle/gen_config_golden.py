@@ -13,7 +13,10 @@ Stored per config: the 5-best word ids of every utterance and nbest-to-linear's 
 c1_fsf3 / c4_fsf3: the first 128 utterances of configs[1] / the first 16 streams of configs[4] with --frame-subsampling-factor=3
 in the model's online.conf.
 
-Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c1_fsf3 c4_fsf3]
+c5_tdnnf / c5_tdnnf_fsf3: the first 64 / 32 utterances of configs[1] on the full-size factorised TDNN (tests/configs.py: TDNNF_SPEC),
+the second with --frame-subsampling-factor=3.
+
+Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c1_fsf3 c4_fsf3 c5_tdnnf c5_tdnnf_fsf3]
 """
 from __future__ import annotations
 
@@ -141,6 +144,12 @@ def main():
         if "c1_fsf3" in want:
             md, gd = configs.build_grammar_model(td / "zam_fsf3", conf_opts=configs.FSF3_CONF)
             run_offline("c1_fsf3", md, gd, configs.grammar_utterances()[:configs.N_FSF3_UTTS], td)
+        if "c5_tdnnf" in want:
+            md, gd = configs.build_tdnnf_model(td / "zamf")
+            run_offline("c5_tdnnf", md, gd, configs.grammar_utterances()[:configs.N_TDNNF_UTTS], td)
+        if "c5_tdnnf_fsf3" in want:
+            md, gd = configs.build_tdnnf_model(td / "zamf_fsf3", conf_opts=configs.FSF3_CONF)
+            run_offline("c5_tdnnf_fsf3", md, gd, configs.grammar_utterances()[:configs.N_TDNNF_FSF3_UTTS], td)
         if "c4_fsf3" in want:
             md, gd = configs.build_grammar_model(td / "zam_fsf3", conf_opts=configs.FSF3_CONF)
             pcms = configs.stream_utterances()[:configs.N_FSF3_STREAMS]

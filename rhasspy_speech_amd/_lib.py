@@ -24,13 +24,15 @@ class DecodeOpts(C.Structure):
         ("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("lattice_beam", C.c_float),
         ("beam_delta", C.c_float), ("acoustic_scale", C.c_float), ("frames_per_chunk", C.c_int32),
         ("frame_subsampling_factor", C.c_int32), ("device_id", C.c_int32), ("keep_intermediates", C.c_int32),
-        ("max_tokens_per_frame", C.c_int32), ("emit_lattice", C.c_int32), ("prune_output_pdfs", C.c_int32), ("exact_token_order", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("max_tokens_per_frame", C.c_int32), ("emit_lattice", C.c_int32), ("prune_output_pdfs", C.c_int32), ("exact_token_order", C.c_int32), ("command_line_fixed", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
+FIXED_ONLINE, FIXED_DO_ENDPOINTING, FIXED_EXTRA_LEFT_CONTEXT_INITIAL, FIXED_PRUNE_INTERVAL, FIXED_DETERMINIZE_LATTICE = 1, 2, 4, 8, 16      # RS_FIXED_*
+
 EXPORTS = [
     "rs_default_opts", "rs_last_error", "rs_model_load_files", "rs_model_load", "rs_model_to_device", "rs_model_free",
-    "rs_model_describe", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_shard_gather", "rs_stream_open", "rs_stream_accept",
+    "rs_model_describe", "rs_model_check_sample_rate", "rs_decode_batch", "rs_decode_batch_device", "rs_decode_batch_sharded", "rs_shard_gather", "rs_stream_open", "rs_stream_accept",
     "rs_stream_finish", "rs_stream_free", "rs_streams_accept", "rs_streams_advance", "rs_streams_finish", "rs_result_num_utts", "rs_result_num_hyps",
     "rs_result_num_frames", "rs_result_words", "rs_result_costs", "rs_result_text", "rs_result_lattice", "rs_result_matrix",
     "rs_result_counters", "rs_result_timings", "rs_result_pack", "rs_result_free",
@@ -55,6 +57,7 @@ def load_library() -> C.CDLL:
     lib.rs_model_free.argtypes = [vp]
     lib.rs_model_free.restype = None
     lib.rs_model_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.rs_model_check_sample_rate.argtypes = [vp, f32]
     lib.rs_decode_batch.argtypes = [vp, C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, f32, C.POINTER(vp)]
     lib.rs_decode_batch_device.argtypes = [vp, vp, C.POINTER(C.c_int64), i32, i32, f32, vp, C.POINTER(vp)]
     lib.rs_decode_batch_sharded.argtypes = [C.POINTER(vp), i32, C.POINTER(i32), C.POINTER(C.POINTER(C.c_int16)), C.POINTER(i32), i32, i32, i32, vp,
@@ -241,6 +244,10 @@ class Model:
         buf = C.create_string_buffer(n + 1)
         lib().rs_model_describe(self._h, buf, n + 1)
         return buf.value.decode()
+
+    def check_sample_rate(self, sample_rate: float) -> None:
+        """Raises RsError with Kaldi's "Sampling frequency mismatch ..." unless `sample_rate` is the model's --sample-frequency."""
+        _check(lib().rs_model_check_sample_rate(self._h, float(sample_rate)))
 
     def decode_batch(self, pcm: Sequence[np.ndarray], nbest: int = 1, lattice_acoustic_scale: float = 1.0) -> Result:
         n = len(pcm)

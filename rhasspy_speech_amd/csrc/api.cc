@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,7 @@ int rs_default_opts(rs_decode_opts *o) {
   // layer is cut down to those rows when that saves at least 30 % of it -- same words, same costs (engine.cc: PruneOutputLayer).
   // Off automatically with keep_intermediates and for nets that end in a log-softmax; 0 computes every pdf like the reference.
   o->prune_output_pdfs = 1;
+  o->command_line_fixed = RS_FIXED_ONLINE | RS_FIXED_DO_ENDPOINTING;      // transcribe_wav.py:48-49 ("--online=false", "--do-endpointing=false")
   return RS_OK;
 }
 
@@ -129,6 +131,25 @@ int rs_model_describe(const rs_model *model, char *buf, size_t len) {
     buf[n] = 0;
   }
   return (int)d.size();
+}
+
+// OnlineGenericBaseFeature<C>::MaybeCreateResampler (feat/online-feature.cc:86-101)
+int rs_model_check_sample_rate(const rs_model *model, float sample_rate) {
+  if (!model) return ArgError("rs_model_check_sample_rate: null model");
+  return Guard([&]() {
+    const rs::MfccOptions &o = model->m->features().mfcc.opts;
+    if (sample_rate == o.samp_freq) return RS_OK;
+    std::ostringstream e;
+    if ((sample_rate > o.samp_freq && o.allow_downsample) || (sample_rate < o.samp_freq && o.allow_upsample)) {
+      e << "Sampling frequency mismatch, expected " << o.samp_freq << ", got " << sample_rate << ": the model's mfcc.conf sets --allow-"
+        << (sample_rate > o.samp_freq ? "downsample" : "upsample") << ", with which the reference resamples the waveform (LinearResample); "
+        << "this library does not resample: convert the audio to " << o.samp_freq << " Hz first";
+    } else {
+      e << "Sampling frequency mismatch, expected " << o.samp_freq << ", got " << sample_rate << "\nPerhaps you want to use the options --allow_{upsample,downsample}";
+    }
+    rs::Fail(e.str());
+    return RS_OK;
+  });
 }
 
 int rs_decode_batch(rs_model *model, const int16_t *const *pcm, const int32_t *n_samples, int32_t n_utts, int32_t nbest,

@@ -104,6 +104,8 @@ void Model::ResolveDecoderOptions() {
   bool has_beam = false, has_max = false, has_min = false, has_lb = false, has_bd = false, has_as = false, has_fpc = false, has_fsf = false;
   float c_beam = 0, c_lb = 0, c_bd = 0, c_as = 0;
   int c_max = 0, c_min = 0, c_fpc = 0, c_fsf = 0;
+  // (an option of this kind given on the command line overrides the file's value: what the file says is then parsed, not refused)
+  const int fixed = opts_.command_line_fixed;
   for (auto &kv : fc_.decoder_conf) {
     const std::string &k = kv.first, &v = kv.second;
     if (k == "beam") { c_beam = ConfFloat(v); has_beam = true; }
@@ -117,18 +119,18 @@ void Model::ResolveDecoderOptions() {
     else if (k == "extra-left-context-initial") {
       const int x = ConfInt(v);
       if (x < 0) Fail("KALDI_ASSERT: at Check:decodable-simple-looped.h:62, failed: extra_left_context_initial >= 0 && frame_subsampling_factor > 0 && frames_per_chunk > 0 && acoustic_scale > 0.0" + where);
-      if (x != 0) Fail("--extra-left-context-initial=" + v + " is not supported by the HIP path (only 0, the reference's default)" + where);
+      if (x != 0 && !(fixed & RS_FIXED_EXTRA_LEFT_CONTEXT_INITIAL)) Fail("--extra-left-context-initial=" + v + " is not supported by the HIP path (only 0, the reference's default)" + where);
     } else if (k == "prune-interval") {
       const int x = ConfInt(v);
-      if (x != 25) Fail("--prune-interval=" + v + " is not supported by the HIP path (only 25, the reference's default: lattices are pruned once, exactly, at the end)" + where);
+      if (x != 25 && !(fixed & RS_FIXED_PRUNE_INTERVAL)) Fail("--prune-interval=" + v + " is not supported by the HIP path (only 25, the reference's default: lattices are pruned once, exactly, at the end)" + where);
     } else if (k == "determinize-lattice") {
-      if (!ConfBool(v)) Fail("--determinize-lattice=false is not supported by the HIP path (lattices are always determinised)" + where);
+      if (!ConfBool(v) && !(fixed & RS_FIXED_DETERMINIZE_LATTICE)) Fail("--determinize-lattice=false is not supported by the HIP path (lattices are always determinised)" + where);
     } else if (k == "hash-ratio") {
       if (!(ConfFloat(v) >= 1.0f)) Fail("KALDI_ASSERT: at Check:lattice-faster-decoder.h:87, failed: hash_ratio >= 1.0" + where);
     } else if (k == "online") {
-      if (ConfBool(v)) Fail("--online=true is not supported by the HIP path (the reference passes --online=false)" + where);
+      if (ConfBool(v) && !(fixed & RS_FIXED_ONLINE)) Fail("--online=true is not supported by the HIP path (the reference passes --online=false on its command line)" + where);
     } else if (k == "do-endpointing") {
-      if (ConfBool(v)) Fail("--do-endpointing=true is not supported by the HIP path (the reference passes --do-endpointing=false)" + where);
+      if (ConfBool(v) && !(fixed & RS_FIXED_DO_ENDPOINTING)) Fail("--do-endpointing=true is not supported by the HIP path (the reference passes --do-endpointing=false on its command line)" + where);
     } else if (k == "minimize" || k == "phone-determinize" || k == "word-determinize" || k == "debug-computation") {
       (void)ConfBool(v);      // same n-best lists either way (the emitted lattice is equivalent, not minimised)
     } else if (k == "max-mem" || k == "num-threads-startup") {
@@ -534,7 +536,7 @@ void Model::ToDevice() {
       for (auto &ev : c->stage_ev) RS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       RS_HIP(hipEventCreateWithFlags(&c->split_ev, hipEventDisableTiming));
       RS_HIP(hipHostMalloc((void **)&c->gemm_ovf, 64, hipHostMallocMapped));
-      *c->gemm_ovf = 0;
+      c->gemm_ovf[0] = c->gemm_ovf[1] = 0;
       RS_HIP(hipHostGetDevicePointer((void **)&c->gemm_ovf_dev, c->gemm_ovf, 0));
       ctx_.push_back(std::move(c));
     }
@@ -829,8 +831,11 @@ std::string Model::Describe() const {
   // whether the model has changed to those kernels for good)
   os << "token_order: " << (ExactOrder() && reg_dev_.exact_ok ? "exact (the reference's running cutoff in its hash order)" : "final cutoff")
      << (ExactOrder() && !reg_dev_.exact_ok ? " (exact_token_order asked for: not applicable to this graph)" : "") << "\n";
-  os << "layer_gemm: range_retries=" << range_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0)
-     << " (split-fp16: |x| >= 65520, infinity and NaN are flagged and the call repeated on the exact kernels; absolute error floor 2^-25 per operand below |x| = 2^-3)\n";
+  os << "layer_gemm: range_retries=" << range_retries_.load() << " precision_retries=" << precision_retries_.load() << " exact_fp32=" << (exact_gemm_.load() ? 1 : 0)
+     << " regime=" << (exact_gemm_.load() ? "exact-fp32" : "split-fp16")
+     << " (split-fp16 carries an operand row to 2^-22 of its largest element while that element lies in [2^-3, 65520): a row with |x| >= 65520, infinity"
+        " or NaN, or a non-zero row whose largest |x| is below 2^-3, raises a flag and the call is repeated on the exact-FP32 kernels; the third such call"
+        " makes them permanent)\n";
   return os.str();
 }
 
@@ -968,7 +973,12 @@ thread_local bool tls_exact_gemm = false;
 thread_local int *tls_gemm_ovf_dev = nullptr;
 void SampleGemmMode(bool exact, int *ovf_dev) { tls_exact_gemm = exact; tls_gemm_ovf_dev = ovf_dev; }
 bool Model::CheckGemmRange(DecodeContext &cx) {
-  if (tls_exact_gemm || !cx.gemm_ovf || *static_cast<volatile int *>(cx.gemm_ovf) == 0) return false;
+  if (tls_exact_gemm || !cx.gemm_ovf) return false;
+  // (RS_GEMM_B3_NOUNDER=1, -DRS_TUNING builds: the precision flag is ignored -- what the split kernels do to small rows, measured)
+  static const bool no_under = [] { const char *e = TuneEnv("RS_GEMM_B3_NOUNDER"); return e && std::atoi(e) != 0; }();
+  const int over = static_cast<volatile int *>(cx.gemm_ovf)[0], under = no_under ? 0 : static_cast<volatile int *>(cx.gemm_ovf)[1];
+  if (over == 0 && under == 0) return false;
+  if (under != 0) precision_retries_.fetch_add(1);
   if (range_retries_.fetch_add(1) + 1 >= 3) exact_gemm_.store(true);
   return true;
 }
@@ -1004,7 +1014,7 @@ std::unique_ptr<Result> Model::DecodeInContext(DecodeContext &cx, const int16_t 
   const int ngroups = (user_stream || n_utts < 32 || max_groups_ < 2) ? 1 : 2;
   cx.active_groups = ngroups;
   for (int attempt = 0;; attempt++) {
-  *cx.gemm_ovf = 0;
+  cx.gemm_ovf[0] = cx.gemm_ovf[1] = 0;
   cx.force_exact = attempt > 0;
   try {
   if (ngroups == 1) {
@@ -1188,7 +1198,14 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
         }
       }
       d.nstages = ns;
-      LaunchEltwise(d, rows, s);
+      const BufferInfo &ob = nn.bufs[op.out_buf];
+      if (ob.stride > 1 && img_out) {      // (as for a layer GEMM above: the conversion below runs over all rows)
+        const int guard = L_ + R_ + 8;
+        RS_HIP(hipMemsetAsync(bufp[op.out_buf] - (size_t)guard * buf_ld[op.out_buf], 0, ((size_t)rows + 2 * guard) * buf_ld[op.out_buf] * sizeof(float), s));
+      }
+      const RowMaps::Entry *rm = ob.stride > 1 ? row_maps.Find(ob.lext, ob.rext, ob.stride) : nullptr;
+      if (rm) { d.row_map = rm->rows; LaunchEltwise(d, rm->count, s); }
+      else LaunchEltwise(d, rows, s);
     }
     if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, rows, (*imgs)[op.out_buf], tls_gemm_ovf_dev, s);
   }
@@ -1691,8 +1708,26 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; int stride = 1, first = 0; };
     std::vector<ListPlan> lists;
     std::vector<int> segs;      // the lists' segment offsets, back to back
-    int min_T = 1 << 30;
-    for (int u = 0; u < n_utts; u++) if (T[u] > 0) min_T = std::min(min_T, T[u]);
+    // The physical rows 128 consecutive entries of a stride-1 list reach over, exactly: the list is one run of consecutive rows per
+    // utterance with frames (t in [-lext, T + rext): T + lext + rext entries from row row_base + L - lext on); a window of 128 entries
+    // that holds the last entry of run a and the first of run b crosses every gap between them, and it can do so when the runs in
+    // between hold at most 126 entries.  An utterance without frames has no entries but still owns L + R rows (a too-short clip
+    // inside a batch), so the gap between two runs is not bounded by one halo: GemmKernelB3J's strip form trusts this number.
+    auto span_of_runs = [&](int lext, int rext) {
+      std::vector<std::pair<int, int>> runs;      // (first physical row, entries)
+      for (int u = 0; u < n_utts; u++) if (T[u] > 0) runs.emplace_back(row_base[u] + L_ - lext, T[u] + lext + rext);
+      int worst = 0;
+      size_t b = 0;
+      long inner = 0;                             // entries of the runs strictly between a and b
+      for (size_t a = 0; a + 1 < runs.size(); a++) {
+        if (b <= a) { b = a + 1; inner = 0; }
+        while (b + 1 < runs.size() && inner + runs[b].second <= 126) { inner += runs[b].second; b++; }
+        const long gaps = (long)runs[b].first - (runs[a].first + runs[a].second) - inner;
+        worst = std::max<long>(worst, gaps);
+        if (b > a + 1) inner -= runs[a + 1].second;
+      }
+      return 128 + worst;
+    };
     if (total_frames > 0) {
       ListPlan lp{0, 0, n_slabs * n_utts, total_frames, L_, slab_len, 0, segs.size()};
       int acc_rows = 0;
@@ -1703,19 +1738,27 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       segs.push_back(acc_rows);
       slab_off[n_slabs] = acc_rows;
       // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
-      lp.span128 = n_slabs == 1 ? 128 + (126 / std::max(min_T, 1) + 1) * (L_ + R_) : 0;
+      lp.span128 = n_slabs == 1 ? span_of_runs(0, 0) : 0;
       lists.push_back(lp);
       static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
-      for (size_t i = 0; trim && i < nn.ops.size(); i++) {
-        if (nn.ops[i].kind != LayerOp::kGemm) continue;
+      // (two passes: the lists of the strided buffers first -- a buffer evaluated on every f-th row MUST have its list, its consumers
+      // read nothing else and its own sources may hold nothing else -- then, while there is room, the trimmed halos, which only save work)
+      for (size_t pi = 0; pi < 2 * nn.ops.size(); pi++) {
+        const size_t i = pi % nn.ops.size();
+        const bool strided_pass = pi < nn.ops.size();
         const BufferInfo &ob = nn.bufs[nn.ops[i].out_buf];
         const int st = ob.stride;
+        if ((st > 1) != strided_pass || (st == 1 && !trim)) continue;
         if (ob.lext > L_ || ob.rext > R_) continue;
         if (st == 1 && ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_))) continue;
-        if (st > 1 && n_slabs != 1) continue;
+        if (st > 1 && n_slabs != 1) Fail("internal error: strided layers in a slab-pipelined call");
         bool have = false;
         for (auto &l : lists) have = have || (l.lext == ob.lext && l.rext == ob.rext && l.stride == st);
-        if (have || (int)lists.size() >= BatchSetup::kMaxLists) continue;
+        if (have) continue;
+        if ((int)lists.size() >= BatchSetup::kMaxLists) {
+          if (st > 1) Fail("nnet3: more distinct (context, stride) row lists than a call carries (" + std::to_string(BatchSetup::kMaxLists) + ") with --frame-subsampling-factor");
+          continue;
+        }
         ListPlan l2{ob.lext, ob.rext, n_utts, 0, L_ - ob.lext, std::max(maxT + ob.lext + ob.rext, 1), 0, segs.size()};
         l2.stride = st;
         l2.first = ob.lext % st;             // t = -lext + first is the first row with t = 0 mod stride
@@ -1727,7 +1770,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
         l2.total = acc;
         // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
         // nobody reads: the physical rows a GEMM tile reaches over (a strided list: not bounded here, the strip form is not used)
-        l2.span128 = st == 1 ? 128 + (126 / std::max(min_T + ob.lext + ob.rext, 1) + 1) * ((L_ - ob.lext) + (R_ - ob.rext)) : 0;
+        l2.span128 = st == 1 ? span_of_runs(ob.lext, ob.rext) : 0;
         lists.push_back(l2);
       }
     }

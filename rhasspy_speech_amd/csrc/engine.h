@@ -241,6 +241,7 @@ class Model {
   // to them for good); a stream advance cannot be repeated: its call fails and the model changes kernels at once.
   std::atomic<bool> exact_gemm_{false};
   std::atomic<int> range_retries_{0};     // batch calls repeated so far; the third makes the change permanent
+  std::atomic<int> precision_retries_{0}; // ... of them, those repeated because an operand row was too small for the split (GemmDev::ovf[1])
   struct RangeRetry {};             // thrown by a batch call that has to be repeated on the exact kernels
   void StreamsCheckRange();         // the same for stream advances (stream.cc)
   bool CheckGemmRange(DecodeContext &cx);      // after a wait: true if this call ran on the split-fp16 kernels and one of them overflowed

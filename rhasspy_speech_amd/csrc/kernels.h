@@ -89,7 +89,7 @@ void LaunchRowGeometry(int n_utts, int rows, int L, const int *row_base, const i
 // The two above for a whole batch in ONE launch: the per-row geometry and up to kMaxLists row lists (a copy and a launch per list was
 // 16 of the launch boundaries in front of a decode call's first real kernel).
 struct BatchSetup {
-  static constexpr int kMaxLists = 10;
+  static constexpr int kMaxLists = 24;
   int n_utts, rows, L;
   const int *row_base, *ivrow_base;
   int *row_utt, *row_t, *row_ivec;      // row_ivec null: not written
@@ -147,7 +147,9 @@ struct GemmDev {
   const void *W3;     // the same weights, every output column scaled by a power of two (w3_inv_scale) and split into two fp16 parts in MFMA fragment order (nnet_gemm_b3.hip), or null
   const void *W3I;    // the same for GemmKernelB3I: segments padded to the 16-wide k-step instead of to kGemmBK, or null
   const float *w3_inv_scale;   // n3 floats: what the accumulators of column c are multiplied by (the inverse of W3's column scale)
-  int *ovf;           // set to 1 by a kernel that met an activation the fp16 split cannot carry (|x| >= 65520): the host repeats the call on the exact-FP32 kernels
+  int *ovf;           // two words.  [0]: set to 1 by a kernel that met an activation the fp16 split cannot carry (|x| >= 65520 or not a number);
+                      // [1]: ... that split an operand row whose largest element is below 2^-3 (the split would carry it to 2^-25
+                      // absolute only, nnet_b3_common.h).  Either way the host repeats the call on the exact-FP32 kernels
   int n3;             // columns of W3 (n rounded up to 256)
   int interleave;     // 1: W3's k-steps alternate between the segments (all segments shifted views of one buffer)
   int exclusive;      // 1: GemmKernelB3 keeps every other workgroup off its CU (several decode pipelines in flight)
@@ -185,6 +187,7 @@ struct EltwiseDev {
   int ldo;
   int row_reduce;     // 0 none, 2 log-softmax, 3 normalize (alpha = target rms)
   float alpha;
+  const int *row_map; // null, or `rows` entries: element i works on physical row row_map[i] of every operand and of the result
 };
 void LaunchEltwise(const EltwiseDev &d, int rows, hipStream_t s);
 // out[row][:] = (in[row][:] + neg_log_prior[:]) * scale  (decodable-online-looped.cc:218-223), in place

@@ -42,7 +42,9 @@ void ReadMfccOptions(const std::string &conf_path, MfccOptions *o) {
     else if (k == "blackman-coeff") o->blackman_coeff = std::stof(v);
     else if (k == "round-to-power-of-two") o->round_pow2 = ParseBool(v, k);
     else if (k == "snip-edges") o->snip_edges = ParseBool(v, k);
-    else if (k == "allow-downsample" || k == "allow-upsample" || k == "max-feature-vectors" || k == "debug-mel") {}
+    else if (k == "allow-downsample") o->allow_downsample = ParseBool(v, k);
+    else if (k == "allow-upsample") o->allow_upsample = ParseBool(v, k);
+    else if (k == "max-feature-vectors" || k == "debug-mel") {}
     else if (k == "num-mel-bins") o->num_bins = std::stoi(v);
     else if (k == "low-freq") o->low_freq = std::stof(v);
     else if (k == "high-freq") o->high_freq = std::stof(v);
@@ -1114,6 +1116,10 @@ void Nnet::SetSubsampling(int factor) {
   std::vector<unsigned> need(bufs.size(), 0u);
   need[output_buf] = 1u;
   auto mod = [&](int a) { int r = a % factor; return r < 0 ? r + factor : r; };
+  // (elementwise ops -- a TDNN-F layer's Sum(Scale(0.66, x), y), a row-wise component -- take row lists like the GEMMs (RunNnet), so
+  // they propagate the residues they are read at like any other op.  Round 5 forced their buffers dense AFTER the walk, which left
+  // a layer X that feeds a Sum dense while its own input W stayed strided: X's GEMM ran over all rows and read rows of W nobody
+  // had written in that call.)
   for (auto it = ops.rbegin(); it != ops.rend(); ++it) {
     const unsigned out = need[it->out_buf];
     auto reads = [&](int src, int off) {
@@ -1124,9 +1130,6 @@ void Nnet::SetSubsampling(int factor) {
     for (auto &t : it->terms) reads(t.src_buf, t.offset);
   }
   for (size_t b = 0; b < bufs.size(); b++) if (!bufs[b].is_input && need[b] == 1u) bufs[b].stride = factor;
-  // an elementwise op runs over all rows of its buffers: keep its operands dense
-  for (auto &op : ops)
-    if (op.kind == LayerOp::kEltwise) { bufs[op.out_buf].stride = 1; for (auto &t : op.terms) if (t.src_buf >= 0) bufs[t.src_buf].stride = 1; }
 }
 
 void AcousticModel::Read(const std::string &final_mdl, int frames_per_chunk, int extra_left_context_initial, int frame_subsampling_factor) {

@@ -15,6 +15,7 @@ namespace rs {
 struct MfccOptions {
   float samp_freq = 16000, frame_shift_ms = 10, frame_length_ms = 25, dither = 1.0f, preemph = 0.97f;
   bool remove_dc = true, round_pow2 = true, snip_edges = true;
+  bool allow_downsample = false, allow_upsample = false;   // feature-window.h:95-107: the reference then resamples (LinearResample); the library refuses such input
   std::string window_type = "povey";
   float blackman_coeff = 0.42f;
   int num_bins = 23;

@@ -146,6 +146,9 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
     }
   };
   bool over = false;                           // an activation this thread split is beyond the fp16 split's range (or not a number)
+  float amax[NA];                              // max |x| over what this thread splits of its row(s): every fourth float4 of the layer's K
+#pragma unroll
+  for (int h = 0; h < NA; h++) amax[h] = 0.f;
   auto store_a = [&](int stage, const f32x4 (&av)[NA], int staged_lim) __attribute__((always_inline)) {
     unsigned char *As = smem + stage * STAGE;
     if (RS_B3_ABLATE & 2) return;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
       const f32x4 x0 = av[h];
       const f32x4 x = f32x4{staged_lim > 0 ? x0[0] : 0.f, staged_lim > 1 ? x0[1] : 0.f, staged_lim > 2 ? x0[2] : 0.f, staged_lim > 3 ? x0[3] : 0.f};
       f16x4 p1, p2;
-      if (RS_B3_ABLATE & 16) (void)Split2(x, &p1, &p2); else over |= B3Over(Split2(x, &p1, &p2));
+      if (RS_B3_ABLATE & 16) (void)Split2(x, &p1, &p2); else { over |= B3Over(Split2(x, &p1, &p2)); amax[h] = B3AbsMax(amax[h], x); }
       *reinterpret_cast<f16x4 *>(As + a_lds[h]) = p1;
       *reinterpret_cast<f16x4 *>(As + a_lds[h] + RT * kB3FragBytes) = p2;
     }
@@ -232,7 +235,19 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3(GemmDe
   if (nt - nfull >= 1) RS_B3_SUBSTEP(nfull, b0, b2, av1, lim1, av0, lim0)
   if (nt - nfull == 2) RS_B3_SUBSTEP(nfull + 1, b1, b0, av2, lim2, av1, lim1)
 #undef RS_B3_SUBSTEP
-  if (over) *d.ovf = 1;
+  if (over) d.ovf[0] = 1;
+  {
+    // a row's K is dealt out to four neighbouring lanes (kq = lane & 3): their maxima together are the row's
+    bool under = false;
+#pragma unroll
+    for (int h = 0; h < NA; h++) {
+      float m = amax[h];
+      m = fmaxf(m, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0xB1, 0xF, 0xF, true)));      // quad_perm [1,0,3,2]
+      m = fmaxf(m, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(m), 0x4E, 0xF, 0xF, true)));      // quad_perm [2,3,0,1]
+      under |= a_on[h] && B3Under(m);
+    }
+    if (under) d.ovf[1] = 1;
+  }
   if (RS_B3_ABLATE & 4) { float fs = 0.f; for (int i = 0; i < MR; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) fs += acc[i][j][r]; if (fs == 12345.f) d.out[0] = fs; return; }
 #include "nnet_b3_epilogue.inc"
 }

@@ -215,23 +215,36 @@ void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
 }
 
 // f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, both parts
-__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int nblocks, int *ovf) {
-  const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= nblocks) return;
-  const int rb = blk / img.nks, ks = blk % img.nks;
-  const int row = rb * 32 + (lane & 31) - img.guard, col = ks * 16 + (lane >> 5) * 8;
-  if (row < 0 || row >= rows) return;
-  f32x4 lo, hi;
+// one workgroup per 32-row block of the image, wave w converts the k-steps w, w + 4, ...; the four waves' maxima of |x| over a row
+// together are the row's (B3Under, nnet_b3_common.h)
+__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int *ovf) {
+  __shared__ unsigned rmx[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rb = blockIdx.x;
+  if (threadIdx.x < 32) rmx[threadIdx.x] = 0u;
+  __syncthreads();
+  const int row = rb * 32 + (lane & 31) - img.guard;
+  const bool rok = row >= 0 && row < rows;
+  bool over = false;
+  float rm = 0.f;
+  for (int ks = wave; ks < img.nks && rok; ks += 4) {
+    const int col = ks * 16 + (lane >> 5) * 8;
+    f32x4 lo, hi;
 #pragma unroll
-  for (int e = 0; e < 4; e++) {
-    lo[e] = col + e < dim ? src[(size_t)row * ld + col + e] : 0.f;
-    hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
+    for (int e = 0; e < 4; e++) {
+      lo[e] = col + e < dim ? src[(size_t)row * ld + col + e] : 0.f;
+      hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
+    }
+    f16x8 p1, p2;
+    over |= B3Over(Split2(lo, hi, &p1, &p2));
+    rm = B3AbsMax(B3AbsMax(rm, lo), hi);
+    unsigned char *dst = img.base + ((size_t)rb * img.nks + ks) * kB3FragBytes + lane * 16;
+    *reinterpret_cast<f16x8 *>(dst) = p1;
+    *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
   }
-  f16x8 p1, p2;
-  if (B3Over(Split2(lo, hi, &p1, &p2))) *ovf = 1;
-  unsigned char *dst = img.base + (size_t)blk * kB3FragBytes + lane * 16;
-  *reinterpret_cast<f16x8 *>(dst) = p1;
-  *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
+  if (over) ovf[0] = 1;
+  atomicMax(&rmx[lane & 31], __float_as_uint(rm));
+  __syncthreads();
+  if (threadIdx.x < 32 && B3Under(__uint_as_float(rmx[threadIdx.x]))) ovf[1] = 1;
 }
 
 }  // namespace
@@ -243,9 +256,8 @@ size_t ActImagePartBytes(int rows, int guard, int dim) {
 
 void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s) {
   const int row_blocks = (rows + img.guard + 31) / 32 + 1;
-  const int nblocks = row_blocks * img.nks;
-  if (nblocks <= 0) return;
-  hipLaunchKernelGGL(ToImageKernel, dim3((nblocks + 3) / 4), dim3(256), 0, s, src, ld, dim, rows, img, nblocks, ovf);
+  if (row_blocks <= 0 || img.nks <= 0) return;
+  hipLaunchKernelGGL(ToImageKernel, dim3(row_blocks), dim3(256), 0, s, src, ld, dim, rows, img, ovf);
 }
 
 bool GemmImagesEnabled() {

@@ -387,7 +387,9 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     constexpr int C_LD = BN + 4, NT = kJThreads;
     float *Cs = reinterpret_cast<float *>(smem);
     float *eb = Cs + 32 * C_LD;                   // [4][BN]: bias, scale, offset of the tile's columns; inverse of the weight image's column scale
+    unsigned *rmx = reinterpret_cast<unsigned *>(eb + 4 * BN);      // [BM]: max |x| of the tile's rows over what is split (bits of a non-negative float)
     const int half = lane >> 5;
+    for (int c = tid; c < BM; c += NT) rmx[c] = 0u;
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
       const bool cok = col < d.n;
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         phys[i] = rok[i] ? (d.row_map ? d.row_map[row] : row) + d.out_img.guard : 0;
       }
       // (the block numbers are macro arguments: acc[] must never be indexed by a variable the compiler might not unroll)
+      float rm0 = 0.f, rm1 = 0.f, rm2 = 0.f, rm3 = 0.f;      // max |x| over what this lane splits of its row of row block 0 .. 3
 #define RS_DIRECT(I, J)                                                                                        \
       if (!MIXED || (I) < mr_eff) {                                                                              \
         const int cb = wn * 64 + (J) * 32;                                                                       \
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
             _Pragma("unroll") for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             f16x8 p1, p2;                                                                                        \
             over |= B3Over(Split2(lo, hi, &p1, &p2));                                                            \
+            rm##I = B3AbsMax(B3AbsMax(rm##I, lo), hi);                                                           \
             unsigned char *dst = d.out_img.base + ((size_t)(phys[I] >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (phys[I] & 31) * 16; \
             RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst), p1);                                                    \
             RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst + d.out_img.part_bytes), p2);                             \
@@ -461,7 +465,15 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
       RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
 #undef RS_DIRECT
-      if (over) *d.ovf = 1;
+      if (over) d.ovf[0] = 1;
+      {
+        const int rb = (wm * mr_eff) * 32 + (lane & 31);
+        atomicMax(&rmx[rb], __float_as_uint(rm0));
+        if (mr_eff > 1) atomicMax(&rmx[rb + 32], __float_as_uint(rm1));
+        if (mr_eff > 2) { atomicMax(&rmx[rb + 64], __float_as_uint(rm2)); atomicMax(&rmx[rb + 96], __float_as_uint(rm3)); }
+        dd::LdsBarrier();
+        if (tid < BM && B3Under(__uint_as_float(rmx[tid]))) d.ovf[1] = 1;
+      }
 #ifdef RS_B3J_TRACE
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -519,6 +531,7 @@ _Pragma("unroll") \
         } \
       } \
       if (d.out_img.base) { \
+        float rm = 0.f; \
 _Pragma("unroll") \
         for (int q = 0; q < 1024 / NT; q++) { \
           const int unit = tid + NT * q, rl = unit & 31, kg = (unit >> 5) & 1, ksi = unit >> 6; \
@@ -530,6 +543,7 @@ _Pragma("unroll") \
             for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             f16x8 p1, p2; \
             over |= B3Over(Split2(lo, hi, &p1, &p2)); \
+            rm = B3AbsMax(B3AbsMax(rm, lo), hi); \
             const int phys = img_phys[(SL)]; \
             unsigned char *dst = d.out_img.base + ((size_t)(phys >> 5) * d.out_img.nks + (col >> 4)) * kB3FragBytes + kg * 512 + (phys & 31) * 16; \
             if ((RS_B3J_ABLATE & 128) && p1[0] != (_Float16)12345.f) dst = nullptr; \
@@ -539,6 +553,7 @@ _Pragma("unroll") \
             RS_IMG_STORE(reinterpret_cast<f16x8 *>(dst + d.out_img.part_bytes), p2); } \
           } \
         } \
+        atomicMax(&rmx[(SL) * 32 + (tid & 31)], __float_as_uint(rm)); \
       } \
       dd::LdsBarrier(); \
     }
@@ -547,7 +562,8 @@ _Pragma("unroll") \
 #undef RS_SLAB
 #undef RS_PUT_SLAB
 #undef RS_EPI4
-    if (over) *d.ovf = 1;
+    if (over) d.ovf[0] = 1;
+    if (d.out_img.base && tid < BM && B3Under(__uint_as_float(rmx[tid]))) d.ovf[1] = 1;
   }
 }
 

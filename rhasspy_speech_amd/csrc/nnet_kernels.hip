@@ -414,6 +414,7 @@ __global__ void EltwiseKernel(EltwiseDev d, int rows) {
   size_t total = (size_t)rows * d.dim;
   if (idx >= total) return;
   int row = (int)(idx / d.dim), col = (int)(idx % d.dim);
+  if (d.row_map) row = d.row_map[row];
   float v = 0.f;
   for (int t = 0; t < d.nterms; t++) {
     const SumTermDev &tm = d.terms[t];
@@ -427,8 +428,10 @@ __global__ void EltwiseKernel(EltwiseDev d, int rows) {
 
 // wave per row: log-softmax (cu-math / LogSoftMaxPerRow) or NormalizePerRow (cu-math.cc:280-318)
 __global__ __launch_bounds__(256) void RowReduceKernel(EltwiseDev d, int rows) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  if (d.row_map) row = d.row_map[row];
   const SumTermDev &tm = d.terms[0];
   const float *src = tm.src + ((long)row + tm.row_off) * tm.ld + tm.col0;
   float *dst = d.out + (size_t)row * d.ldo;

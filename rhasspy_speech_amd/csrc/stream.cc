@@ -284,7 +284,7 @@ StreamPool *Model::Pool() {
   std::unique_ptr<DecodeContext> c(new DecodeContext());
   c->stream = p->q;
   RS_HIP(hipHostMalloc((void **)&c->gemm_ovf, 64, hipHostMallocMapped));
-  *c->gemm_ovf = 0;
+  c->gemm_ovf[0] = c->gemm_ovf[1] = 0;
   RS_HIP(hipHostGetDevicePointer((void **)&c->gemm_ovf_dev, c->gemm_ovf, 0));
   stream_ctx_ = std::move(c);
   p->cx = stream_ctx_.get();
@@ -317,12 +317,20 @@ void Model::StreamsCheckRange() {
   DecodeContext *cx = stream_ctx_.get();
   // (only the split-fp16 kernels raise the word, so a raised word means an advance issued on them overflowed -- whether or not a
   // batch call has moved the model to the exact kernels in the meantime)
-  if (cx && cx->gemm_ovf && *static_cast<volatile int *>(cx->gemm_ovf) != 0) {
-    *static_cast<volatile int *>(cx->gemm_ovf) = 0;
+  if (!cx || !cx->gemm_ovf) return;
+  volatile int *w = static_cast<volatile int *>(cx->gemm_ovf);
+  const int over = w[0], under = w[1];
+  if (over != 0 || under != 0) {
+    w[0] = w[1] = 0;
     exact_gemm_.store(true);
-    StreamsPoisonAll();        // (any of the advances in flight may be the one: their log-likelihood rows are not numbers)
-    Fail("an activation exceeded the range of the split-fp16 layer GEMMs (|x| >= 65520) during a stream advance; the model now uses the "
-         "exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");
+    range_retries_.fetch_add(1);
+    if (under != 0) precision_retries_.fetch_add(1);
+    StreamsPoisonAll();        // (any of the advances in flight may be the one: their log-likelihood rows are not numbers / not the FP32 result)
+    if (over != 0)
+      Fail("an activation exceeded the range of the split-fp16 layer GEMMs (|x| >= 65520) during a stream advance; the model now uses the "
+           "exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");
+    Fail("an activation row below the precision range of the split-fp16 layer GEMMs (largest |x| < 2^-3) was met during a stream advance; the model "
+         "now uses the exact-FP32 kernels (RS_GEMM_B3=0 selects them from the start)");
   }
 }
 

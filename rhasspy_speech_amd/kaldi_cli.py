@@ -32,6 +32,7 @@ _UNSET_FIELDS = [f for f, _ in _DECODE_OPTS.values()]
 # value is an error, as it is in online.conf (csrc/engine.cc: ResolveDecoderOptions)
 _FIXED = {"online": ("false", "f", "0"), "do-endpointing": ("false", "f", "0"), "extra-left-context-initial": ("0",), "prune-interval": ("25",),
           "determinize-lattice": ("true", "t", "1", "")}
+_FIXED_BIT = {"online": 1, "do-endpointing": 2, "extra-left-context-initial": 4, "prune-interval": 8, "determinize-lattice": 16}      # RS_FIXED_*
 _IGNORED = {"word-symbol-table", "chunk-length", "num-threads-startup", "verbose", "hash-ratio", "minimize", "phone-determinize",
             "word-determinize", "max-mem", "debug-computation"}
 
@@ -51,6 +52,9 @@ def parse_command_line(argv: List[str]) -> Tuple[Dict[str, object], str, List[st
             elif name in _FIXED:
                 if value.lower() not in _FIXED[name]:
                     raise ValueError(f"--{name}={value} is not supported by the HIP path")
+                # given on the command line: overrides online.conf's value (util/parse-options.cc:328-345), so the library must not
+                # refuse the model for what the file says (rs_decode_opts.command_line_fixed)
+                opts["command_line_fixed"] = int(opts.get("command_line_fixed", 0)) | _FIXED_BIT[name]
             elif name in _IGNORED:
                 pass
             else:
@@ -82,14 +86,18 @@ def read_table(rspecifier: str) -> List[Tuple[str, str]]:
     return rows
 
 
-def read_wav(path: str) -> np.ndarray:
+def read_wav(path: str, model=None) -> np.ndarray:
     """WaveData::Read as the binary uses it (16-bit PCM only, wave-reader.cc:199-200; channel 0 of a multi-channel file,
-    online2-wav-nnet3-latgen-faster.cc:216-218) -- the same reader the transcriber uses."""
-    from .transcribe_wav import read_wav_pcm16
+    online2-wav-nnet3-latgen-faster.cc:216-218) -- the same reader the transcriber uses; with `model`, the header's sampling rate
+    is checked against the model's like the binary's feature pipeline does (feat/online-feature.cc:86-101)."""
+    from .transcribe_wav import read_wav_pcm16_rate
     try:
-        return read_wav_pcm16(path)
+        pcm, rate = read_wav_pcm16_rate(path)
     except RuntimeError as e:
         raise ValueError(str(e)) from e
+    if model is not None:
+        model.check_sample_rate(rate)           # RsError: exit status 1 with Kaldi's message on stderr (main)
+    return pcm
 
 
 def open_wspecifier(wspecifier: str):
@@ -102,7 +110,7 @@ def open_wspecifier(wspecifier: str):
 def _load(opts, config, final_mdl, hclg):
     from . import _lib
     unset = {f: _lib.RS_OPT_UNSET for f in _UNSET_FIELDS}
-    return _lib, _lib.Model(final_mdl=final_mdl, hclg=hclg, online_conf=config, opts=_lib.default_opts(emit_lattice=1, **{**unset, **opts}))
+    return _lib, _lib.Model(final_mdl=final_mdl, hclg=hclg, online_conf=config, opts=_lib.default_opts(emit_lattice=1, **{**unset, "command_line_fixed": 0, **opts}))
 
 
 def wav_main(argv: List[str]) -> int:
@@ -111,12 +119,21 @@ def wav_main(argv: List[str]) -> int:
         raise ValueError("usage: online2-wav-nnet3-latgen-faster [options] <nnet3-in> <fst-in> <spk2utt-rspecifier> <wav-rspecifier> <lattice-wspecifier>")
     final_mdl, hclg, spk2utt, wav_rspec, lat_wspec = pos
     wavs = dict(read_table(wav_rspec))
-    utts = [u for _, us in read_table(spk2utt) for u in us.split()]
+    spk = read_table(spk2utt)
+    # The binary carries the iVector estimator's adaptation state from one utterance of a speaker to the next
+    # (online2-wav-nnet3-latgen-faster.cc:203-205, 287-288: Get / SetAdaptationState around every utterance).  rhasspy never does that
+    # -- one process, one speaker, one utterance (transcribe_wav.py:45-75) -- and the library starts every utterance fresh, so a table
+    # that asks for the carry is refused rather than decoded differently.
+    for s, us in spk:
+        if len(us.split()) > 1:
+            raise ValueError(f"speaker {s} has {len(us.split())} utterances: the reference decodes them with the iVector adaptation state carried "
+                             "from one to the next, which this library does not do (every utterance starts fresh); list one utterance per speaker")
+    utts = [u for _, us in spk for u in us.split()]
     missing = [u for u in utts if u not in wavs]
     if missing:
         raise ValueError(f"no wav for utterance {missing[0]}")
     _lib, model = _load(opts, config, final_mdl, hclg)
-    res = model.decode_batch([read_wav(wavs[u]) for u in utts])
+    res = model.decode_batch([read_wav(wavs[u], model) for u in utts])
     out = open_wspecifier(lat_wspec)
     for i, u in enumerate(utts):
         out.write(res.lattice(i, u))

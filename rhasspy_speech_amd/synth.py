@@ -181,6 +181,11 @@ class ModelSpec:
     # its largest weight)
     weight_dist: str = "normal"
     hidden_gain: float = 1.0         # the second hidden layer's weights times this (activations beyond fp16's range for ~1e5)
+    # hidden_gain with the rest of the network making up for it: the second hidden layer's bias is scaled too, it has no BatchNorm
+    # (its output is relu(gain * (W x + b)): every element of every row is of order gain), and the third layer's weights are
+    # divided by gain -- in exact arithmetic the network of gain 1 without that BatchNorm; in a GEMM that carries small operands
+    # to a fixed ABSOLUTE error only, a different one (tests: small activations and the split-fp16 layer GEMMs)
+    gain_compensated: bool = False
     hmm_states: int = 1              # emitting states per phone (left-to-right; > 1 only with chain_topology = False, graphs by mkgraph)
 
     @property
@@ -492,10 +497,17 @@ def build_nnet(spec: ModelSpec, rng: np.random.Generator):
         W, b = randw(H, prev_dim * len(offs)), randb(H)
         if li == 2 and spec.hidden_gain != 1.0:
             W = (W * np.float32(spec.hidden_gain)).astype(np.float32)
+            if spec.gain_compensated:
+                b = (b * np.float32(spec.hidden_gain)).astype(np.float32)
+        if li == 3 and spec.hidden_gain != 1.0 and spec.gain_compensated:
+            W = (W / np.float32(spec.hidden_gain)).astype(np.float32)
         comps.append((f"tdnn{li}.affine", lambda w, W=W, b=b: _w_affine(w, "NaturalGradientAffineComponent", W, b)))
         cfg.append(f"component-node name=tdnn{li}.affine component=tdnn{li}.affine input={_append_desc(prev, offs)}")
         comps.append((f"tdnn{li}.relu", lambda w, d=H: _w_nonlinear(w, "RectifiedLinearComponent", d)))
         cfg.append(f"component-node name=tdnn{li}.relu component=tdnn{li}.relu input=tdnn{li}.affine")
+        if li == 2 and spec.gain_compensated:
+            prev, prev_dim = f"tdnn{li}.relu", H
+            continue
         mean, var = (0.4 + 0.1 * rng.standard_normal(H)).astype(np.float32), rng.uniform(0.1, 0.5, H).astype(np.float32)
         comps.append((f"tdnn{li}.batchnorm", lambda w, m=mean, v=var: _w_batchnorm(w, m, v)))
         cfg.append(f"component-node name=tdnn{li}.batchnorm component=tdnn{li}.batchnorm input=tdnn{li}.relu")

@@ -24,14 +24,18 @@ from .tools import KaldiTools
 _LOGGER = logging.getLogger(__name__)
 
 
-def read_wav_pcm16(wav_path: Union[str, Path]) -> np.ndarray:
-    """WaveData::Read semantics (feat/wave-reader.cc): RIFF PCM 16-bit only, channel 0 is used."""
+def read_wav_pcm16_rate(wav_path: Union[str, Path]):
+    """WaveData::Read semantics (feat/wave-reader.cc): RIFF PCM 16-bit only, channel 0 is used.  -> (samples, sampling rate)"""
     with wave.open(str(wav_path), "rb") as w:
         if w.getsampwidth() != 2:
             raise RuntimeError(f"WaveData: can read only 16-bit PCM data, got {8 * w.getsampwidth()} bits: {wav_path}")
         data = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
-        ch = w.getnchannels()
-    return np.ascontiguousarray(data.reshape(-1, ch)[:, 0]) if ch > 1 else data.copy()
+        ch, rate = w.getnchannels(), w.getframerate()
+    return (np.ascontiguousarray(data.reshape(-1, ch)[:, 0]) if ch > 1 else data.copy()), rate
+
+
+def read_wav_pcm16(wav_path: Union[str, Path]) -> np.ndarray:
+    return read_wav_pcm16_rate(wav_path)[0]
 
 
 class KaldiNnet3WavTranscriber:
@@ -68,6 +72,17 @@ class KaldiNnet3WavTranscriber:
             self._words = read_words_txt(self.graph_dir / "words.txt")
         return self._model
 
+    def _read_wav(self, wav_path) -> np.ndarray:
+        """The file's samples, after the check the reference's binary makes on its header: a wav whose rate is not the model's
+        --sample-frequency ends `online2-wav-nnet3-latgen-faster` with "Sampling frequency mismatch, expected 16000, got ..."
+        (feat/online-feature.cc:86-101) and the Python with RuntimeError (tools.py:138-145)."""
+        pcm, rate = read_wav_pcm16_rate(wav_path)
+        try:
+            self._ensure_loaded().check_sample_rate(rate)
+        except _lib.RsError as e:
+            raise RuntimeError(f"Unexpected error running command online2-wav-nnet3-latgen-faster (HIP): {e}") from e
+        return pcm
+
     def _nbest_stdout(self, pcm_batch: Sequence[np.ndarray], nbest: int) -> List[bytes]:
         """One `nbest-to-linear ... ark,t:-` byte string per utterance (key "utt" like the reference)."""
         try:
@@ -85,18 +100,18 @@ class KaldiNnet3WavTranscriber:
         max_fuzzy_cost: Optional[float] = None,
         require_fuzzy: bool = False,
     ) -> List[str]:
-        pcm = read_wav_pcm16(wav_path)
+        pcm = self._read_wav(wav_path)
         loop = asyncio.get_running_loop()
         nbest_stdout = (await loop.run_in_executor(None, self._nbest_stdout, [pcm], nbest))[0]
         return self._finish(nbest_stdout, Path(lang_dir), max_fuzzy_cost, require_fuzzy)
 
     def transcribe(self, wav_path, lang_dir, nbest: int = 1, max_fuzzy_cost=None, require_fuzzy: bool = False) -> List[str]:
-        return self._finish(self._nbest_stdout([read_wav_pcm16(wav_path)], nbest)[0], Path(lang_dir), max_fuzzy_cost, require_fuzzy)
+        return self._finish(self._nbest_stdout([self._read_wav(wav_path)], nbest)[0], Path(lang_dir), max_fuzzy_cost, require_fuzzy)
 
     def transcribe_many(self, wav_paths: Sequence[Union[str, Path]], lang_dir, nbest: int = 1, max_fuzzy_cost=None,
                         require_fuzzy: bool = False) -> List[List[str]]:
         """Batched: all files decoded in one device pass."""
-        outs = self._nbest_stdout([read_wav_pcm16(p) for p in wav_paths], nbest)
+        outs = self._nbest_stdout([self._read_wav(p) for p in wav_paths], nbest)
         return [self._finish(o, Path(lang_dir), max_fuzzy_cost, require_fuzzy) for o in outs]
 
     # ---- rescoring path (transcribe_wav.py:107-232): decode with the old graph, re-rank the lattice with a NEW lexicon + LM
@@ -128,7 +143,7 @@ class KaldiNnet3WavTranscriber:
         max_fuzzy_cost: Optional[float] = None,
         require_fuzzy: bool = False,
     ) -> List[str]:
-        pcm = read_wav_pcm16(wav_path)
+        pcm = self._read_wav(wav_path)
         loop = asyncio.get_running_loop()
         nbest_stdout = await loop.run_in_executor(None, self._rescored_stdout, pcm, Path(new_lang_dir), nbest)
         # ids -> words with the NEW table, fuzzy matching against the OLD language directory (transcribe_wav.py:204-218)

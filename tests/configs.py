@@ -71,6 +71,30 @@ FSF3_CONF = {"frame-subsampling-factor": 3}      # c1_fsf3 / c4_fsf3: the headli
 N_FSF3_UTTS, N_FSF3_STREAMS = 128, 16
 
 
+# "zamia-like-F" (the second net, "tdnn-f-like"): a full-size factorised TDNN -- the first hidden layer an
+# ordinary affine + ReLU + BatchNorm, the six after it TdnnComponent bottlenecks 1024 -> 128 (no bias, offsets (-k, 0)) ->
+# TdnnComponent 128 -> 1024 (offsets (0, k)) + ReLU + BatchNorm + dropout (identity at test time) with the residual
+# Sum(Scale(0.66, previous), this) (nnet3/nnet-tdnn-component.cc:181-213; the xconfig tdnnf-layer), 2 000 pdfs, the headline's
+# grammar graph shape.  The linear bottleneck outputs have neither ReLU nor BatchNorm behind them: the shape the split-fp16 layer
+# GEMMs had never been pinned on at size.  c5_tdnnf: the first N_TDNNF_UTTS utterances of configs[1]; c5_tdnnf_fsf3: the first 32
+# with --frame-subsampling-factor=3 (every layer above the (-1, 0, 1) ones on every third row, the residual sums included).
+TDNNF_SPEC = dict(name="zamia-like-F", tdnnf=True, hidden_dim=1024, bottleneck_dim=128, seed=5)
+N_TDNNF_UTTS, N_TDNNF_FSF3_UTTS = 64, 32
+
+
+def build_tdnnf_model(root: Path, conf_opts: dict = None) -> Tuple[Path, Path]:
+    root = Path(root)
+    model_dir, graph_dir = root / "model", root / "graph"
+    if not (graph_dir / "HCLG.fst").exists():
+        spec = synth.ModelSpec(**TDNNF_SPEC)
+        synth.write_model_dir(model_dir, spec)
+        synth.make_grammar_graph(graph_dir, spec, seed=11)
+        if conf_opts:
+            conf = model_dir / "model" / "online" / "conf" / "online.conf"
+            conf.write_text(conf.read_text() + "".join(f"--{k}={v}\n" for k, v in conf_opts.items()))
+    return model_dir, graph_dir
+
+
 def build_arpa_model(root: Path) -> Tuple[Path, Path]:
     root = Path(root)
     model_dir, graph_dir = root / "model", root / "graph"

@@ -763,3 +763,93 @@ def test_overlapped_contexts_use_the_cu_exclusive_gemm(zam_grammar, monkeypatch)
         for res in out[b]:
             for u in range(len(p)):
                 _same_result(res, u, ref[b], u)
+
+
+# ---- the full-size factorised TDNN (round 6; tests/configs.py: TDNNF_SPEC).  Goldens: the reference's binaries, one process per
+# utterance (c5_tdnnf.npz: 5-best lists and costs; c5_tdnnf_inter.npz: rs-dump's iVectors and log-likelihood samples).
+@pytest.fixture(scope="module")
+def zam_tdnnf(tmp_path_factory):
+    return configs.build_tdnnf_model(tmp_path_factory.mktemp("zam_tdnnf"))
+
+
+def test_config5_tdnnf_full_size_vs_reference(zam_tdnnf, monkeypatch):
+    """TdnnComponent + linear bottlenecks 1024 / 128 with Sum(Scale(0.66, .), .) residuals, 2 000 pdfs: every transcript, 5-best list
+    and cost of the reference; iVectors and sampled log-likelihoods within 1e-4 -- on the split-fp16 layer GEMMs (the bottleneck
+    outputs they read carry neither ReLU nor BatchNorm) with no call sent to the exact kernels, and the same on the exact kernels."""
+    from rhasspy_speech_amd import _lib
+    pcms = configs.grammar_utterances()[:configs.N_TDNNF_UTTS]
+    model = _lib.Model(*zam_tdnnf, _lib.default_opts(keep_intermediates=1))
+    res = model.decode_batch(pcms)
+    _check_against_reference("c5_tdnnf", res.words, res.costs, len(pcms))
+    assert _check_intermediates("c5_tdnnf", res, len(pcms)) == []
+    assert "range_retries=0 precision_retries=0 exact_fp32=0 regime=split-fp16" in model.describe(), model.describe()
+    _check_nbest_against_reference("c5_tdnnf", model.decode_batch(pcms, nbest=5), len(pcms))
+    monkeypatch.setenv("RS_GEMM_B3", "0")
+    exact = model.decode_batch(pcms)
+    monkeypatch.delenv("RS_GEMM_B3")
+    _check_against_reference("c5_tdnnf", exact.words, exact.costs, len(pcms))
+    _check_intermediates("c5_tdnnf", exact, len(pcms))
+    worst = max(float(np.abs(res.matrix(u, 2) - exact.matrix(u, 2)).max()) for u in range(len(pcms)))
+    print(f"c5_tdnnf: split-fp16 against exact-FP32 layer GEMMs, all rows and pdfs of {len(pcms)} utterances: max |diff| {worst:.2e}")
+    assert 0 < worst < LOGLIKE_TOL
+
+
+def test_config5_tdnnf_streams_and_subsampling(zam_tdnnf, tmp_path_factory):
+    """The same model fed as streams (the results of its batch decode), and with --frame-subsampling-factor=3 in online.conf against
+    the reference run that way: with the factor every layer above the (-1, 0, 1) ones -- bottlenecks, affines AND the residual sums --
+    is evaluated on every third row (round 5 forced an elementwise op's operands dense without re-deriving what THEIR producers
+    read)."""
+    from rhasspy_speech_amd import _lib
+    pcms = configs.grammar_utterances()[:16]
+    model = _lib.Model(*zam_tdnnf, _lib.default_opts())
+    batch = model.decode_batch(pcms, nbest=5)
+    streams = [_lib.Stream(model) for _ in pcms]
+    for r in range((configs.N_SAMPLES_3S + 8191) // 8192):
+        _lib.accept_streams(streams, [p[r * 8192:(r + 1) * 8192] for p in pcms])
+        _lib.advance_streams(streams)
+    got = _lib.finish_streams(streams, nbest=5)
+    ref = configs.load_golden_nbest("c5_tdnnf")
+    for u in range(len(pcms)):
+        assert [got.words(u, k) for k in range(got.num_hyps(u))] == [r[0] for r in ref[u]], u
+        assert got.num_hyps(u) == batch.num_hyps(u)
+        for k in range(got.num_hyps(u)):
+            np.testing.assert_allclose(got.costs(u, k), batch.costs(u, k), rtol=COST_RTOL, atol=COST_ATOL)
+    md3, gd3 = configs.build_tdnnf_model(tmp_path_factory.mktemp("zam_tdnnf_fsf3"), conf_opts=configs.FSF3_CONF)
+    m3 = _lib.Model(md3, gd3, _lib.default_opts(keep_intermediates=1))
+    assert "frame_subsampling_factor=3" in m3.describe()
+    pcms3 = configs.grammar_utterances()[:configs.N_TDNNF_FSF3_UTTS]
+    res3 = m3.decode_batch(pcms3)
+    _check_against_reference("c5_tdnnf_fsf3", res3.words, res3.costs, len(pcms3))
+    g = np.load(configs.GOLDEN / "c5_tdnnf_fsf3_inter.npz")
+    sr, sc = (int(x) for x in g["ll_stride"])
+    for k, u in enumerate(g["ll_utts"]):
+        ll = res3.matrix(int(u), 2)[::sr, ::sc]
+        np.testing.assert_allclose(ll, g["ll"][k][:ll.shape[0]], rtol=0, atol=LOGLIKE_TOL)
+    assert "range_retries=0 precision_retries=0" in m3.describe(), m3.describe()
+    _check_nbest_against_reference("c5_tdnnf_fsf3", m3.decode_batch(pcms3, nbest=5), len(pcms3))
+
+
+def test_too_short_clips_inside_a_large_batch(zam_grammar):
+    """Utterances without a single frame between the others of a batch large enough for the 128-row layer GEMM tiles (ADVICE r05:
+    an empty utterance owns L + R halo rows but no entry of a row list, so the physical rows 128 list entries reach over were
+    under-estimated and GemmKernelB3J's 192-row strip was read beyond its end): every non-empty utterance decodes as it does in a
+    batch without the empty ones, bit for bit."""
+    from rhasspy_speech_amd import _lib
+    model = _lib.Model(*zam_grammar, _lib.default_opts(keep_intermediates=1))
+    base = configs.grammar_utterances()[:96]
+    rng = np.random.default_rng(6)
+    empty = np.zeros(100, np.int16)
+    pcms, where = [], []
+    for i, p in enumerate(base):
+        n = len(p) - 160 * int(rng.integers(0, 120))          # ragged: 178 .. 298 frames
+        pcms.append(p[:n]); where.append(len(pcms) - 1)
+        for _ in range(int(rng.integers(0, 4)) if i % 3 == 0 else 0):      # runs of up to three empty utterances
+            pcms.append(empty)
+    assert len(pcms) > len(base) + 20
+    a = model.decode_batch(pcms)
+    b = model.decode_batch([pcms[w] for w in where])
+    for j, w in enumerate(where):
+        assert a.num_frames(w) == b.num_frames(j) > 0
+        np.testing.assert_array_equal(a.matrix(w, 2), b.matrix(j, 2))
+        assert a.words(w) == b.words(j)
+    assert all(a.num_frames(i) == 0 and a.words(i) == [] for i in range(len(pcms)) if i not in where)

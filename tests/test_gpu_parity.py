@@ -614,7 +614,7 @@ def test_split_fp16_gemm_is_as_close_to_exact_as_fp32_on_heavy_tailed_weights(tm
     monkeypatch.undo()
     model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
     split = model.decode_batch(pcms)
-    assert "range_retries=0 exact_fp32=0" in model.describe()
+    assert "range_retries=0 precision_retries=0 exact_fp32=0" in model.describe()
     monkeypatch.setenv("RS_GEMM_B3", "0")
     exact = model.decode_batch(pcms)
     monkeypatch.delenv("RS_GEMM_B3")
@@ -650,9 +650,9 @@ def test_activation_beyond_fp16_range_repeats_the_call_on_the_exact_kernels(tmp_
         res = model.decode_batch([pcm])
         assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2))
         assert res.words(0) == ref.words(0)
-        assert f"range_retries={k} exact_fp32={1 if k >= 3 else 0}" in model.describe(), model.describe()
+        assert f"range_retries={k} precision_retries=0 exact_fp32={1 if k >= 3 else 0}" in model.describe(), model.describe()
     res = model.decode_batch([pcm])                                  # no further repetitions: the model is on the exact kernels
-    assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2)) and "range_retries=3 exact_fp32=1" in model.describe()
+    assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2)) and "range_retries=3 precision_retries=0 exact_fp32=1" in model.describe()
     # streams
     model2 = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
     st = _lib.Stream(model2)
@@ -667,6 +667,81 @@ def test_activation_beyond_fp16_range_repeats_the_call_on_the_exact_kernels(tmp_
     got = st.finish()
     assert np.array_equal(got.matrix(0, 2), ref_stream.matrix(0, 2)) and got.words(0) == ref_stream.words(0)
     st.close()
+
+
+@pytest.mark.parametrize("gain", [1e-3, 1e-6])
+def test_activation_below_fp16_subnormal_range_repeats_the_call_on_the_exact_kernels(tmp_path, monkeypatch, gain):
+    """The underflow twin of the test above.  A hidden layer whose outputs are all of order `gain` (no BatchNorm behind it, the next
+    layer's weights divided by `gain`: in exact arithmetic the network of gain 1): the low fp16 part of |x| < 2^-3 is subnormal, so the
+    split carries such a row to 2^-25 absolute instead of 2^-22 relative -- 15 bits at 1e-3, 4 at 1e-6.  The kernels take the largest
+    |x| of every operand row they split and raise the call's precision flag for a non-zero row below 2^-3; the call is repeated on
+    the exact-FP32 kernels (bit for bit THEIR result, within 1e-4 of the float64 oracle), describe() counts it, the third such call
+    moves the model to the exact kernels for good; a stream advance fails with a message and the model changes at once.  With the
+    flag ignored (RS_GEMM_B3_NOUNDER=1, -DRS_TUNING builds only) the split result at gain 1e-6 is off by more than the tolerance:
+    measured in profiles/r06/underflow_notes.txt."""
+    from oracle import pipeline
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.tiny_spec(hidden_dim=256, prefinal_dim=256, hidden_gain=gain, gain_compensated=True, seed=9)
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    pcms = [synth.synth_utterance(41, 32000), synth.synth_utterance(42, 20000)]
+    orc = pipeline.Oracle(tmp_path / "model", tmp_path / "graph")
+    monkeypatch.setattr(pipeline.Nnet3, "matmul", staticmethod(lambda x, wt: (x.astype(np.float64) @ wt.astype(np.float64)).astype(np.float32)))
+    f64 = [orc.transcribe(p) for p in pcms]
+    monkeypatch.undo()
+    monkeypatch.setenv("RS_GEMM_B3", "0")
+    ref_model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    ref = ref_model.decode_batch(pcms)
+    rs = _lib.Stream(ref_model)
+    rs.accept(pcms[0])
+    ref_stream = rs.finish()
+    rs.close()
+    monkeypatch.delenv("RS_GEMM_B3")
+    for i in range(len(pcms)):
+        assert np.abs(ref.matrix(i, 2) - f64[i].loglikes).max() < LOGLIKE_TOL
+    model = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    assert "regime=split-fp16" in model.describe()
+    for k in range(1, 4):
+        res = model.decode_batch(pcms)
+        for i in range(len(pcms)):
+            assert np.array_equal(res.matrix(i, 2), ref.matrix(i, 2))
+            assert np.abs(res.matrix(i, 2) - f64[i].loglikes).max() < LOGLIKE_TOL
+            assert res.words(i) == f64[i].nbest[0].words
+        assert f"range_retries={k} precision_retries={k} exact_fp32={1 if k >= 3 else 0}" in model.describe(), model.describe()
+    res = model.decode_batch(pcms)
+    assert np.array_equal(res.matrix(0, 2), ref.matrix(0, 2))
+    assert "range_retries=3 precision_retries=3 exact_fp32=1 regime=exact-fp32" in model.describe(), model.describe()
+    # streams
+    model2 = _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(keep_intermediates=1))
+    st = _lib.Stream(model2)
+    st.accept(pcms[0])
+    with pytest.raises(_lib.RsError, match="below the precision range of the split-fp16"):
+        st.advance()
+        st.finish()
+    st.close()
+    assert "precision_retries=1 exact_fp32=1" in model2.describe(), model2.describe()
+    st = _lib.Stream(model2)
+    st.accept(pcms[0])
+    got = st.finish()
+    assert np.array_equal(got.matrix(0, 2), ref_stream.matrix(0, 2)) and got.words(0) == ref_stream.words(0)
+    st.close()
+
+
+def test_activations_of_order_one_never_raise_the_precision_flag(case_cache):
+    """The other side of the rule: on the zamia-size model (ReLU + BatchNorm hidden layers, MFCC + iVector input whose iVector part is
+    small beside the cepstra) no row is below the split's precision range -- a batch with a too-short clip, digital silence and a
+    few-LSB signal in it included (rows of halo and guard that hold zeros are not rows `below` anything)."""
+    from rhasspy_speech_amd import synth
+    model, pcm = make_model(case_cache, "zam_u0")
+    quiet = (synth.synth_utterance(77, 24000).astype(np.float32) * 2e-4).astype(np.int16)
+    res = model.decode_batch([pcm, np.zeros(100, np.int16), np.zeros(16000, np.int16), quiet, pcm[:5000]])
+    assert res.num_frames(1) == 0 and res.num_frames(2) > 0
+    assert "range_retries=0 precision_retries=0 exact_fp32=0 regime=split-fp16" in model.describe(), model.describe()
+    st = __import__("rhasspy_speech_amd")._lib.Stream(model)
+    st.accept(quiet)
+    st.finish()
+    st.close()
+    assert "range_retries=0 precision_retries=0" in model.describe()
 
 
 @pytest.mark.parametrize("name", ["tiny_u0", "zam_u0", "zam_long30"])

@@ -104,8 +104,57 @@ def test_online_conf_options_the_kernels_cannot_honour_fail_the_load(case_cache,
     from rhasspy_speech_amd import _lib
     md, gd = _with_online_conf(case_cache, tmp_path, [line])
     with pytest.raises(_lib.RsError) as ei:
-        _lib.Model(md, gd)
+        _lib.Model(md, gd, _lib.default_opts(command_line_fixed=0))       # (a command line that does not repeat the option)
     assert needle in str(ei.value), str(ei.value)
+
+
+def test_command_line_overrides_unsupported_values_in_online_conf(case_cache, tmp_path):
+    """ParseOptions reads --config first and the command line overrides it (util/parse-options.cc:328-345): the reference runs with
+    `--online=false --do-endpointing=false` on its command line (transcribe_wav.py:48-49) whatever online.conf says, so a model
+    directory whose online.conf carries --online=true / --do-endpointing=true loads with rs_default_opts (= rhasspy's command line);
+    an option the command line did not fix is still refused, and the shim passes down exactly what its argv holds."""
+    from rhasspy_speech_amd import _lib, kaldi_cli
+    md, gd = _with_online_conf(case_cache, tmp_path, ["--online=true", "--do-endpointing=true"])
+    assert _lib.default_opts().command_line_fixed == _lib.FIXED_ONLINE | _lib.FIXED_DO_ENDPOINTING
+    _lib.Model(md, gd)
+    with pytest.raises(_lib.RsError, match="--online=true is not supported"):
+        _lib.Model(md, gd, _lib.default_opts(command_line_fixed=_lib.FIXED_DO_ENDPOINTING))
+    md2, gd2 = _with_online_conf(case_cache, tmp_path / "b", ["--prune-interval=10", "--determinize-lattice=false"])
+    with pytest.raises(_lib.RsError, match="--prune-interval=10 is not supported"):
+        _lib.Model(md2, gd2)
+    _lib.Model(md2, gd2, _lib.default_opts(command_line_fixed=_lib.FIXED_PRUNE_INTERVAL | _lib.FIXED_DETERMINIZE_LATTICE))
+    opts, _, _ = kaldi_cli.parse_command_line(["--config=x", "--online=false", "--prune-interval=25", "a"])
+    assert opts["command_line_fixed"] == _lib.FIXED_ONLINE | _lib.FIXED_PRUNE_INTERVAL
+    assert "command_line_fixed" not in kaldi_cli.parse_command_line(["--config=x", "--beam=13", "a"])[0]
+
+
+def test_sampling_rate_is_checked_like_the_reference(case_cache, tmp_path):
+    """feat/online-feature.cc:86-101: a waveform whose rate is not the model's --sample-frequency is an error with Kaldi's text (the
+    reference's binary exits with status 1, its Python raises RuntimeError, tools.py:138-145) -- not a decode of garbage; and
+    --allow-downsample (the reference then resamples) is refused with a message, not dropped."""
+    import wave
+    from rhasspy_speech_amd import _lib, transcribe_wav
+    md, gd, wav, pcm = case_cache("tiny_u0")
+    model = _lib.Model(md, gd)
+    model.check_sample_rate(16000)
+    with pytest.raises(_lib.RsError, match=r"Sampling frequency mismatch, expected 16000, got 8000\nPerhaps you want to use the options --allow_\{upsample,downsample\}"):
+        model.check_sample_rate(8000)
+    w8 = tmp_path / "u8k.wav"
+    with wave.open(str(w8), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+        w.writeframes(pcm[::2].tobytes())
+    assert transcribe_wav.read_wav_pcm16_rate(w8)[1] == 8000
+    tr = transcribe_wav.KaldiNnet3WavTranscriber(md, gd)
+    with pytest.raises(RuntimeError, match="Sampling frequency mismatch, expected 16000, got 8000"):
+        tr.transcribe(w8, gd)
+    md2, gd2 = _with_online_conf(case_cache, tmp_path / "c", [])
+    mfcc = md2 / "model" / "online" / "conf" / "mfcc.conf"
+    mfcc.write_text(mfcc.read_text() + "--allow-downsample=true\n")
+    m2 = _lib.Model(md2, gd2)
+    with pytest.raises(_lib.RsError, match="does not resample"):
+        m2.check_sample_rate(44100)
+    with pytest.raises(_lib.RsError, match="Perhaps you want to use the options"):
+        m2.check_sample_rate(8000)             # (--allow-upsample was not given)
 
 
 def test_frame_subsampling_factor_rounds_the_chunk_like_the_reference(case_cache, tmp_path):
@@ -505,3 +554,23 @@ print(getenv(b"GPU_MAX_HW_QUEUES").decode())
     for preset, want in (("-", "8"), ("5", "5")):
         out = subprocess.run([sys.executable, "-c", code, preset], cwd=root, capture_output=True, text=True, check=True).stdout.strip()
         assert out == want, (preset, out)
+
+
+def test_frame_subsampling_strides_the_residual_sums_of_a_factorised_tdnn(tmp_path):
+    """TDNN-F with --frame-subsampling-factor=3: layer offsets (0) (-1,0,1) (-1,0,1) (-3,0,3) x 4, every layer a bottleneck + affine +
+    Sum(Scale(0.66, previous), this).  Everything from the third layer's affine up is read at multiples of three only -- the
+    elementwise residual sums too: they take row lists like the GEMMs (round 5 forced an elementwise op's buffers dense after the walk,
+    leaving the layer that feeds it dense over an input evaluated on every third row: ADVICE r05)."""
+    from rhasspy_speech_amd import _lib, synth
+    spec = synth.tiny_spec(tdnnf=True, hidden_dim=64, bottleneck_dim=16, layer_offsets=((0,), (-1, 0, 1), (-1, 0, 1), (-3, 0, 3), (-3, 0, 3)))
+    synth.write_model_dir(tmp_path / "model", spec)
+    synth.make_grammar_graph(tmp_path / "graph", spec)
+    ops = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(frame_subsampling_factor=3)).describe().splitlines() if l.startswith("op:")]
+    names = [l.split()[2].split("+")[0] for l in ops]
+    strided = {n: "rows=every-3" in l for n, l in zip(names, ops)}
+    dense = ["tdnn1.affine", "tdnnf2.linear", "tdnnf2.affine", "tdnnf2.noop", "tdnnf3.linear"]
+    assert all(not strided[n] for n in dense), ops
+    assert all(v for n, v in strided.items() if n not in dense), ops
+    assert sum(1 for l in ops if l.startswith("op: eltwise") and "rows=every-3" in l) == 3, ops
+    ops1 = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph").describe().splitlines() if l.startswith("op:")]
+    assert not any("rows=every" in l for l in ops1)

@@ -86,7 +86,7 @@ def test_oracle_streaming_matches_reference(oracles, name):
 
 # ---- full-size configurations (tests/configs.py): the restatement against the reference's per-utterance goldens on samples
 @pytest.mark.parametrize("config,utts", [("c1_grammar", (0, 131, 255)), ("c2_arpa", (3, 162)), ("c3_mixed_de", (7,)), ("c3_mixed_fr", (110, 500)),
-                                         ("c4_streams", (5,))])
+                                         ("c4_streams", (5,)), ("c5_tdnnf", (2, 40)), ("c5_tdnnf_fsf3", (9,))])
 def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
     """c2_arpa utterance 162 and c3_mixed_fr utterance 110 are the cases where the reference's order-dependent pruning (tokens created under a running
     next_cutoff, lattice-faster-decoder.cc:774-787) changes the best path's cost: oracle/decoder.c follows the HashList
@@ -104,6 +104,9 @@ def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
         md, gd = configs.build_grammar_model(root, m["model_seed"], m["graph_seed"])
         names, allp = configs.mixed_utterances()
         pcms = [p for nm, p in zip(names, allp) if nm == key]
+    elif config.startswith("c5_tdnnf"):          # the full-size factorised TDNN (also pins the oracle's log-likelihoods on it, below)
+        md, gd = configs.build_tdnnf_model(root, conf_opts=configs.FSF3_CONF if config.endswith("fsf3") else None)
+        pcms = configs.grammar_utterances()
     else:
         md, gd = configs.build_grammar_model(root)
         pcms = configs.stream_utterances() if config == "c4_streams" else configs.grammar_utterances()
@@ -112,6 +115,14 @@ def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
         tr = orc.transcribe_stream(pcms[u]) if config == "c4_streams" else orc.transcribe(pcms[u])
         assert tr.nbest[0].words == ref_words[u], (config, u)
         np.testing.assert_allclose([tr.nbest[0].graph_cost, tr.nbest[0].acoustic_cost], [ref_g[u], ref_a[u]], rtol=2e-4, atol=2e-3)
+    if config.startswith("c5_tdnnf"):
+        g = np.load(configs.GOLDEN / f"{config}_inter.npz")
+        sr, sc = (int(x) for x in g["ll_stride"])
+        k = 0                                        # (ll_utts[0] is utterance 0)
+        tr = orc.transcribe(pcms[int(g["ll_utts"][k])])
+        ll = tr.loglikes[::sr, ::sc]
+        np.testing.assert_allclose(ll, g["ll"][k][:ll.shape[0]], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(tr.ivector[0] if tr.ivector.ndim == 2 else tr.ivector, g["ivector"][int(g["ll_utts"][k])], rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("i", [0, 5, 11, 17, 23, 31, 37, 41])
