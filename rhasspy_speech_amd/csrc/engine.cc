@@ -5,6 +5,7 @@
 #include "env.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -404,7 +405,7 @@ void Model::BuildGemmPlan(const LayerOp &op, GemmPlan *plan) {
   plan->d_W3 = nullptr;
   plan->d_W3I = nullptr;
   plan->d_w3_inv_scale = nullptr;
-  if (op.out_dim >= 192 && GemmB3PaddingOk(op.out_dim, plan->n3)) {
+  if (op.out_dim >= 96 && GemmB3PaddingOk(op.out_dim, plan->n3)) {
     auto to_f16 = [](float x) -> uint16_t {          // round to nearest even, subnormals kept; |x| < 65520 here
       uint32_t u;
       std::memcpy(&u, &x, 4);
@@ -646,6 +647,7 @@ void Model::ToDevice() {
         for (auto &sg : op.segs) by_image = by_image && sg.src_buf >= 0 && sg.src_buf != nn.input_buf;
         for (auto &sg : op.segs)
           if (sg.src_buf >= 0) (by_image ? buf_image_ : buf_f32_)[sg.src_buf] = 1;
+        if (op.res_buf >= 0) buf_f32_[op.res_buf] = 1;      // (a folded residual is read as plain floats)
       } else {
         for (auto &t : op.terms) buf_f32_[t.src_buf] = 1;
       }
@@ -813,6 +815,7 @@ std::string Model::Describe() const {
     if (op.kind == LayerOp::kGemm) {
       os << " k=" << op.W.cols << " segs=";
       for (auto &s : op.segs) os << "[" << s.src_buf << ":" << s.offset << ":" << s.ncols << "]";
+      if (op.res_buf >= 0) os << " residual=" << op.res_scale << "*[" << op.res_buf << "]";
     } else {
       os << " terms=" << op.terms.size();
     }
@@ -1139,6 +1142,7 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
     d.stages[i].scale = pl.d_stage[i].first; d.stages[i].offset = pl.d_stage[i].second; d.stages[i].alpha = st.alpha;
   }
   d.out = out; d.ldo = ldo;
+  if (op.res_buf >= 0) { d.res = src[op.res_buf]; d.res_ld = src_ld[op.res_buf]; d.res_scale = op.res_scale; }
   return d;
 }
 
@@ -1155,21 +1159,18 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
     const LayerOp &op = nn.ops[i];
     const bool img_out = images_on && (*imgs)[op.out_buf].base != nullptr;
     bool img_done = false;
+    const int *conv_map = nullptr;
+    int conv_rows = rows;
     if (op.kind == LayerOp::kGemm) {
       GemmDev gd = MakeGemm(gemm_plans_[i], bufp, buf_ld, d_ivec, ld_i, bufp[op.out_buf], buf_ld[op.out_buf], share, imgs, (int)op.out_buf);
       if (img_out && !GemmWritesImage(gd)) gd.write_f32 = 1;      // a kernel without the image epilogue: converted below
       else img_done = img_out;
       const BufferInfo &ob = nn.bufs[op.out_buf];
-      if (ob.stride > 1 && img_out && !img_done) {
-        // evaluated on every stride-th row, converted (and range-checked) over all rows: the rows in between must hold numbers,
-        // not what the arena held before (everything else that touches a strided buffer goes through the row list)
-        const int guard = L_ + R_ + 8;
-        RS_HIP(hipMemsetAsync(bufp[op.out_buf] - (size_t)guard * buf_ld[op.out_buf], 0, ((size_t)rows + 2 * guard) * buf_ld[op.out_buf] * sizeof(float), s));
-      }
       if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext, ob.stride)) {     // only the rows somebody reads
         gd.row_map = rm->rows;
         gd.row_map_span128 = rm->span128;
         LaunchGemm(gd, rm->count, d_row_ivec, s);
+        conv_map = rm->rows; conv_rows = rm->count;
       } else {
         LaunchGemm(gd, rows, d_row_ivec, s);
       }
@@ -1198,16 +1199,18 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
         }
       }
       d.nstages = ns;
+      // (the rows somebody reads, like a layer GEMM: its operands hold nothing else when THEY were evaluated through that list)
       const BufferInfo &ob = nn.bufs[op.out_buf];
-      if (ob.stride > 1 && img_out) {      // (as for a layer GEMM above: the conversion below runs over all rows)
-        const int guard = L_ + R_ + 8;
-        RS_HIP(hipMemsetAsync(bufp[op.out_buf] - (size_t)guard * buf_ld[op.out_buf], 0, ((size_t)rows + 2 * guard) * buf_ld[op.out_buf] * sizeof(float), s));
+      if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext, ob.stride)) {
+        d.row_map = rm->rows;
+        LaunchEltwise(d, rm->count, s);
+        conv_map = rm->rows; conv_rows = rm->count;
+      } else {
+        LaunchEltwise(d, rows, s);
       }
-      const RowMaps::Entry *rm = ob.stride > 1 ? row_maps.Find(ob.lext, ob.rext, ob.stride) : nullptr;
-      if (rm) { d.row_map = rm->rows; LaunchEltwise(d, rm->count, s); }
-      else LaunchEltwise(d, rows, s);
     }
-    if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, rows, (*imgs)[op.out_buf], tls_gemm_ovf_dev, s);
+    // a producer without the image epilogue: its rows -- the ones it wrote, no others -- converted (and range-checked) here
+    if (img_out && !img_done) LaunchToImage(bufp[op.out_buf], buf_ld[op.out_buf], nn.bufs[op.out_buf].dim, conv_rows, (*imgs)[op.out_buf], tls_gemm_ovf_dev, s, conv_map);
   }
   if (op_end == nn.ops.size() && (d_log_priors_ || opts_.acoustic_scale != 1.0f))
     LaunchPriorScale(bufp[nn.output_buf], buf_ld[nn.output_buf], rows, nn.output_dim, d_log_priors_, opts_.acoustic_scale, s);
@@ -1740,7 +1743,21 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
       lp.span128 = n_slabs == 1 ? span_of_runs(0, 0) : 0;
       lists.push_back(lp);
-      static const int trim = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
+      static const int trim_env = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
+      // Trimmed halos are all or nothing: an op evaluated through its list leaves the other rows of its buffer as the arena held them, so
+      // everything that reads the buffer must go through a list as narrow or narrower.  Count the distinct lists first; a network with
+      // more of them than a call carries evaluates every layer on all rows (of the full halo: always valid) instead.
+      int trim = trim_env;
+      {
+        std::vector<std::array<int, 3>> distinct;
+        for (auto &op : nn.ops) {
+          const BufferInfo &ob = nn.bufs[op.out_buf];
+          if (ob.stride == 1 && ((ob.lext == 0 && ob.rext == 0) || (ob.lext >= L_ && ob.rext >= R_) || !trim_env)) continue;
+          const std::array<int, 3> key{ob.lext, ob.rext, ob.stride};
+          if (std::find(distinct.begin(), distinct.end(), key) == distinct.end()) distinct.push_back(key);
+        }
+        if ((int)distinct.size() + 1 > BatchSetup::kMaxLists) trim = 0;
+      }
       // (two passes: the lists of the strided buffers first -- a buffer evaluated on every f-th row MUST have its list, its consumers
       // read nothing else and its own sources may hold nothing else -- then, while there is room, the trimmed halos, which only save work)
       for (size_t pi = 0; pi < 2 * nn.ops.size(); pi++) {

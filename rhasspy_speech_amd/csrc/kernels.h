@@ -159,14 +159,21 @@ struct GemmDev {
   EltStageDev stages[kMaxStages];
   float *out;
   int ldo;
+  // null, or the rows of a buffer as wide as the result: out = stages(...) + res_scale * res[same row] (a residual sum folded into the
+  // layer, LayerOp::res_buf), the product and the sum rounded like the elementwise kernel's (__fmul_rn, __fadd_rn)
+  const float *res;
+  int res_ld;
+  float res_scale;
   ActImage out_img;    // base non-null: the result is (also) written as an operand image for the layers that consume it
   int write_f32;       // 0: nobody reads `out` as floats (every consumer takes the image): skip that store
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
   int row_map_span128; // with a row map: an upper bound of row_map[i + 127] - row_map[i] + 1 over the list when the list is ascending (128 rows of
                        // a tile reach over that many physical rows: GemmKernelB3J stages them as one strip), 0 = not known
 };
-// f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue
-void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s);
+// f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue.
+// row_map (null: rows 0 .. rows - 1): the `rows` physical rows to convert -- the rows the producer wrote (a layer evaluated through a
+// row list leaves the others as the arena held them: not numbers, possibly, and they would pass through the range checks)
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s, const int *row_map = nullptr);
 constexpr int kActImageParts = 2;
 size_t ActImagePartBytes(int rows, int guard, int dim);      // bytes of one part for a buffer of `rows` rows
 void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);

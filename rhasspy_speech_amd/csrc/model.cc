@@ -1093,6 +1093,49 @@ void Nnet::Compile() {
   output_buf = node_buf[out_node];
   if (output_buf < 0 || node_col[out_node] != 0 || bufs[output_buf].dim != output_dim)
     Fail("nnet3: could not resolve the output node to a buffer");
+  // ---- a two-term sum whose one term is the (otherwise unread) result of a GEMM becomes that GEMM's epilogue: the residual of a
+  // factorised TDNN layer, NoOp(Sum(Scale(0.66, previous layer), dropout(batchnorm(relu(affine))))) -- as a separate pass over two
+  // 1024-wide buffers it took as long as the layer's two GEMMs together (profiles/r06/tdnnf_notes.txt).  RS_FUSE_RESIDUAL=0 keeps
+  // the elementwise op (tests compare the two bit for bit).
+  {
+    const char *e = std::getenv("RS_FUSE_RESIDUAL");
+    const bool fuse = !(e && std::atoi(e) == 0);
+    auto readers = [&](int buf) {
+      int n = buf == output_buf ? 1 : 0;
+      for (auto &op : ops) {
+        for (auto &sg : op.segs) n += sg.src_buf == buf;
+        for (auto &t : op.terms) n += t.src_buf == buf;
+        n += op.res_buf == buf;
+      }
+      return n;
+    };
+    for (size_t ei = 0; fuse && ei < ops.size(); ei++) {
+      LayerOp &eo = ops[ei];
+      if (eo.kind != LayerOp::kEltwise || eo.terms.size() != 2 || !eo.stages.empty()) continue;
+      for (int k = 0; k < 2; k++) {
+        const SumTerm &t = eo.terms[k], &r = eo.terms[1 - k];
+        if (t.scale != 1.0f || t.offset != 0 || r.offset != 0 || t.src_col != 0 || r.src_col != 0 || t.src_buf == r.src_buf) continue;
+        if (bufs[t.src_buf].dim != eo.out_dim || bufs[r.src_buf].dim != eo.out_dim || readers(t.src_buf) != 1) continue;
+        size_t gi = ops.size(), ri = 0;
+        bool r_made = bufs[r.src_buf].is_input;
+        for (size_t i = 0; i < ei; i++) {
+          if (ops[i].out_buf == t.src_buf) gi = i;
+          if (ops[i].out_buf == r.src_buf) { ri = i; r_made = true; }
+        }
+        if (gi == ops.size() || ops[gi].kind != LayerOp::kGemm || ops[gi].res_buf >= 0 || !r_made || (ri >= gi && !bufs[r.src_buf].is_input)) continue;
+        for (auto &st : ops[gi].stages) if (st.kind == EltStage::kLogSoftmax || st.kind == EltStage::kNormalize) gi = ops.size();
+        if (gi == ops.size()) continue;
+        LayerOp &g = ops[gi];
+        g.res_buf = r.src_buf;
+        g.res_scale = r.scale;
+        g.out_buf = eo.out_buf;
+        g.name += "+" + eo.name;
+        ops.erase(ops.begin() + ei);
+        ei--;
+        break;
+      }
+    }
+  }
   // sanity: every source buffer must cover what its consumers read
   for (auto &op : ops) {
     const BufferInfo &ob = bufs[op.out_buf];
@@ -1103,6 +1146,7 @@ void Nnet::Compile() {
     };
     for (auto &s : op.segs) check(s.src_buf, s.offset);
     for (auto &t : op.terms) check(t.src_buf, t.offset);
+    check(op.res_buf, 0);
   }
 }
 
@@ -1128,6 +1172,7 @@ void Nnet::SetSubsampling(int factor) {
     };
     for (auto &sg : it->segs) reads(sg.src_buf, sg.offset);
     for (auto &t : it->terms) reads(t.src_buf, t.offset);
+    reads(it->res_buf, 0);
   }
   for (size_t b = 0; b < bufs.size(); b++) if (!bufs[b].is_input && need[b] == 1u) bufs[b].stride = factor;
 }

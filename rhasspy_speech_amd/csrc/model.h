@@ -184,6 +184,10 @@ struct LayerOp {
   std::vector<GemmSegment> segs;
   MatF W;                       // out_dim x K (K = sum of segment widths, Kaldi column order)
   std::vector<float> bias;      // may be empty
+  // a two-term Sum() folded into this GEMM (Nnet::Compile: the residual of a factorised TDNN layer, Sum(Scale(0.66, previous), this)):
+  // out = stages(W x + b) + res_scale * res_buf[t], computed with the float operations of the elementwise op it replaces
+  int res_buf = -1;
+  float res_scale = 1.0f;
   // kEltwise: out = stages(sum_i scale_i * src_i[t+o_i])
   std::vector<SumTerm> terms;
   std::vector<EltStage> stages; // applied after the gemm/sum, in order

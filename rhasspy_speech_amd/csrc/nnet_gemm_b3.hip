@@ -276,6 +276,10 @@ void LaunchB3(const GemmDev &d, int rows, int nbig, const int *row_ivec, hipStre
 // output layer, profiles/r04), so e.g. the headline's 362 output columns (29 % padding in two tiles) belong here: 163 -> 85 us.
 bool GemmB3PaddingOk(int n, int n3) {
   static const int pct = [] { const char *e = TuneEnv("RS_GEMM_B3_PAD"); return e ? std::atoi(e) : 45; }();
+  // One tile wide, at least 96 columns (round 6: a factorised TDNN's 128-wide bottlenecks, K = 2048): the exact-FP32 kernel ran such a
+  // layer at 109 TFLOP/s, 0.7 of ITS peak (403 us for 84 k rows), the split kernels take 62.5 % padding and are still 2.4 times as fast
+  // (profiles/r06/tdnnf_notes.txt); RS_GEMM_B3_NARROW=0 (read per model load) keeps the 45 % rule alone.
+  if (n3 == kB3BN && n >= 96) { const char *e = std::getenv("RS_GEMM_B3_NARROW"); if (!(e && std::atoi(e) == 0)) return true; }
   return (long)(n3 - n) * 100 <= (long)n3 * pct;
 }
 

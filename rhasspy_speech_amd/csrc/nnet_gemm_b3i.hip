@@ -215,15 +215,17 @@ void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
 }
 
 // f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, both parts
-// one workgroup per 32-row block of the image, wave w converts the k-steps w, w + 4, ...; the four waves' maxima of |x| over a row
-// together are the row's (B3Under, nnet_b3_common.h)
-__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int *ovf) {
+// one workgroup per 32 rows (of the row list, or of the buffer), wave w converts the k-steps w, w + 4, ...; the four waves' maxima
+// of |x| over a row together are the row's (B3Under, nnet_b3_common.h)
+__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int *ovf,
+                                                     const int *__restrict__ row_map) {
   __shared__ unsigned rmx[32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rb = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 32) rmx[threadIdx.x] = 0u;
   __syncthreads();
-  const int row = rb * 32 + (lane & 31) - img.guard;
-  const bool rok = row >= 0 && row < rows;
+  const int idx = blockIdx.x * 32 + (lane & 31);
+  const bool rok = idx < rows;
+  const int row = rok ? (row_map ? row_map[idx] : idx) : 0, phys = row + img.guard;
   bool over = false;
   float rm = 0.f;
   for (int ks = wave; ks < img.nks && rok; ks += 4) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ s
     f16x8 p1, p2;
     over |= B3Over(Split2(lo, hi, &p1, &p2));
     rm = B3AbsMax(B3AbsMax(rm, lo), hi);
-    unsigned char *dst = img.base + ((size_t)rb * img.nks + ks) * kB3FragBytes + lane * 16;
+    unsigned char *dst = img.base + ((size_t)(phys >> 5) * img.nks + ks) * kB3FragBytes + (lane >> 5) * 512 + (phys & 31) * 16;
     *reinterpret_cast<f16x8 *>(dst) = p1;
     *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
   }
@@ -254,10 +256,9 @@ size_t ActImagePartBytes(int rows, int guard, int dim) {
   return row_blocks * (size_t)((dim + 15) / 16) * b3::kB3FragBytes;
 }
 
-void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s) {
-  const int row_blocks = (rows + img.guard + 31) / 32 + 1;
-  if (row_blocks <= 0 || img.nks <= 0) return;
-  hipLaunchKernelGGL(ToImageKernel, dim3(row_blocks), dim3(256), 0, s, src, ld, dim, rows, img, ovf);
+void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s, const int *row_map) {
+  if (rows <= 0 || img.nks <= 0) return;
+  hipLaunchKernelGGL(ToImageKernel, dim3((rows + 31) / 32), dim3(256), 0, s, src, ld, dim, rows, img, ovf, row_map);
 }
 
 bool GemmImagesEnabled() {

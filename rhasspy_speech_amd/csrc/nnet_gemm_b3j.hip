@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         }                                                                                                        \
       }                                                                                                          \
     }
-    const bool direct = d.out_img.base && !d.write_f32 && !(RS_B3J_ABLATE & (128 | 256));
+    const bool direct = d.out_img.base && !d.write_f32 && !d.res && !(RS_B3J_ABLATE & (128 | 256));
     if (direct) {
       // destination rows first: a row-map load between two stores makes the compiler wait for vmcnt(0), stores included
       int phys[MR];
@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       return;
     }
     const bool vec_out = ((d.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.out) & 15) == 0) && (((d.n + 3) & ~3) <= d.ldo);
+    const bool vec_res = d.res && ((d.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.res) & 15) == 0) && (((d.n + 3) & ~3) <= d.res_ld);
 #define RS_PUT_SLAB(A)                                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                              \
       _Pragma("unroll") for (int g = 0; g < 4; g++) {                                                            \
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
 #pragma unroll
       for (int q = 0; q < 2048 / NT; q++) {
         const int r2 = row0 + sl * 32 + ((tid + NT * q) >> 6);
-        f32_phys[sl][q] = (d.write_f32 && r2 < rows) ? (d.row_map ? d.row_map[r2] : r2) : 0;
+        f32_phys[sl][q] = ((d.write_f32 || d.res) && r2 < rows) ? (d.row_map ? d.row_map[r2] : r2) : 0;
       }
     }
     // (the slab number is a macro argument: acc[] must never be indexed by a loop variable the compiler might not unroll -- that put
@@ -514,7 +515,29 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       if (MIXED && small) { if (wm == (SL) / (MR / SDIV)) { RS_PUT_SLAB(acc[(SL) % (MR / SDIV)]) } } \
       else if (wm == (SL) / MR) { RS_PUT_SLAB(acc[(SL) % MR]) } \
       dd::LdsBarrier(); \
-      if (vec_out && d.write_f32) { \
+      if (d.res) {      /* a folded residual sum (LayerOp::res_buf): see nnet_b3_epilogue.inc */ \
+_Pragma("unroll") \
+        for (int q = 0; q < 2048 / NT; q++) { \
+          const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \
+          const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
+          if (row < rows && col < d.n) { \
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]); \
+            const float *rp = d.res + (size_t)f32_phys[(SL)][q] * d.res_ld + col; \
+            f32x4 r; \
+            if (vec_res) r = *reinterpret_cast<const f32x4 *>(rp); \
+            else { for (int e = 0; e < 4; e++) r[e] = col + e < d.n ? rp[e] : 0.f; } \
+_Pragma("unroll") \
+            for (int e = 0; e < 4; e++) v[e] = __fadd_rn(d.res_scale != 1.0f ? __fmul_rn(r[e], d.res_scale) : r[e], v[e]); \
+            *reinterpret_cast<f32x4 *>(&Cs[rl * C_LD + c4]) = v; \
+            if (d.write_f32) { \
+              float *op = d.out + (size_t)f32_phys[(SL)][q] * d.ldo + col; \
+              if (vec_out) *reinterpret_cast<f32x4 *>(op) = v; \
+              else { for (int e = 0; e < 4; e++) if (col + e < d.n) op[e] = v[e]; } \
+            } \
+          } \
+        } \
+        dd::LdsBarrier(); \
+      } else if (vec_out && d.write_f32) { \
 _Pragma("unroll") \
         for (int q = 0; q < 2048 / NT; q++) { \
           const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \

@@ -80,14 +80,25 @@ __device__ __forceinline__ void GemmEpilogue(const f32x4 (&acc)[MT][4], const Ge
       const int row = row0 + rl, col = n0 + c4;
       if (row < rows && col < d.n) {
         const int prow = d.row_map ? d.row_map[row] : row;
-        *reinterpret_cast<f32x4 *>(d.out + (size_t)prow * d.ldo + col) = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]);
+        if (d.res) {      // a folded residual sum (LayerOp::res_buf): EltwiseKernel's operations
+          const f32x4 r = *reinterpret_cast<const f32x4 *>(d.res + (size_t)prow * d.res_ld + col);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = __fadd_rn(d.res_scale != 1.0f ? __fmul_rn(r[e], d.res_scale) : r[e], v[e]);
+        }
+        *reinterpret_cast<f32x4 *>(d.out + (size_t)prow * d.ldo + col) = v;
       }
     }
   } else {
     for (int idx = tid; idx < BM * BN; idx += 256) {
       const int rl = idx / BN, cl = idx % BN;
       const int row = row0 + rl, col = n0 + cl;
-      if (row < rows && col < d.n) d.out[(size_t)(d.row_map ? d.row_map[row] : row) * d.ldo + col] = Cs[rl * C_LD + cl];
+      if (row < rows && col < d.n) {
+        const size_t prow = d.row_map ? d.row_map[row] : row;
+        float v = Cs[rl * C_LD + cl];
+        if (d.res) { const float r = d.res[prow * d.res_ld + col]; v = __fadd_rn(d.res_scale != 1.0f ? __fmul_rn(r, d.res_scale) : r, v); }
+        d.out[prow * d.ldo + col] = v;
+      }
     }
   }
 }

@@ -79,7 +79,7 @@ N_FSF3_UTTS, N_FSF3_STREAMS = 128, 16
 # GEMMs had never been pinned on at size.  c5_tdnnf: the first N_TDNNF_UTTS utterances of configs[1]; c5_tdnnf_fsf3: the first 32
 # with --frame-subsampling-factor=3 (every layer above the (-1, 0, 1) ones on every third row, the residual sums included).
 TDNNF_SPEC = dict(name="zamia-like-F", tdnnf=True, hidden_dim=1024, bottleneck_dim=128, seed=5)
-N_TDNNF_UTTS, N_TDNNF_FSF3_UTTS = 64, 32
+N_TDNNF_UTTS, N_TDNNF_FSF3_UTTS, N_TDNNF_STREAMS = 64, 32, 16      # (c5_tdnnf_stream: the first 16 fed to the reference's streaming binary)
 
 
 def build_tdnnf_model(root: Path, conf_opts: dict = None) -> Tuple[Path, Path]:

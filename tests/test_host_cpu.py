@@ -556,21 +556,30 @@ print(getenv(b"GPU_MAX_HW_QUEUES").decode())
         assert out == want, (preset, out)
 
 
-def test_frame_subsampling_strides_the_residual_sums_of_a_factorised_tdnn(tmp_path):
-    """TDNN-F with --frame-subsampling-factor=3: layer offsets (0) (-1,0,1) (-1,0,1) (-3,0,3) x 4, every layer a bottleneck + affine +
+def test_frame_subsampling_strides_the_residual_sums_of_a_factorised_tdnn(tmp_path, monkeypatch):
+    """TDNN-F with --frame-subsampling-factor=3: layer offsets (0) (-1,0,1) (-1,0,1) (-3,0,3) x 2, every layer a bottleneck + affine +
     Sum(Scale(0.66, previous), this).  Everything from the third layer's affine up is read at multiples of three only -- the
-    elementwise residual sums too: they take row lists like the GEMMs (round 5 forced an elementwise op's buffers dense after the walk,
-    leaving the layer that feeds it dense over an input evaluated on every third row: ADVICE r05)."""
+    residual sums too, whether they run as elementwise ops (RS_FUSE_RESIDUAL=0: they take row lists like the GEMMs; round 5 forced an
+    elementwise op's buffers dense after the walk, leaving the layer that feeds it dense over an input evaluated on every third
+    row: ADVICE r05) or folded into the affine GEMM's epilogue (the default)."""
     from rhasspy_speech_amd import _lib, synth
     spec = synth.tiny_spec(tdnnf=True, hidden_dim=64, bottleneck_dim=16, layer_offsets=((0,), (-1, 0, 1), (-1, 0, 1), (-3, 0, 3), (-3, 0, 3)))
     synth.write_model_dir(tmp_path / "model", spec)
     synth.make_grammar_graph(tmp_path / "graph", spec)
-    ops = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(frame_subsampling_factor=3)).describe().splitlines() if l.startswith("op:")]
-    names = [l.split()[2].split("+")[0] for l in ops]
-    strided = {n: "rows=every-3" in l for n, l in zip(names, ops)}
     dense = ["tdnn1.affine", "tdnnf2.linear", "tdnnf2.affine", "tdnnf2.noop", "tdnnf3.linear"]
-    assert all(not strided[n] for n in dense), ops
-    assert all(v for n, v in strided.items() if n not in dense), ops
-    assert sum(1 for l in ops if l.startswith("op: eltwise") and "rows=every-3" in l) == 3, ops
-    ops1 = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph").describe().splitlines() if l.startswith("op:")]
-    assert not any("rows=every" in l for l in ops1)
+    for fused in (False, True):
+        if not fused:
+            monkeypatch.setenv("RS_FUSE_RESIDUAL", "0")
+        ops = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph", _lib.default_opts(frame_subsampling_factor=3)).describe().splitlines() if l.startswith("op:")]
+        ops1 = [l for l in _lib.Model(tmp_path / "model", tmp_path / "graph").describe().splitlines() if l.startswith("op:")]
+        monkeypatch.delenv("RS_FUSE_RESIDUAL", raising=False)
+        names = [l.split()[2].split("+")[0] for l in ops]
+        strided = {n: "rows=every-3" in l for n, l in zip(names, ops)}
+        assert all(not strided[n] for n in dense if n in strided), ops
+        assert all(v for n, v in strided.items() if n not in dense), ops
+        if fused:
+            assert not any(l.startswith("op: eltwise") for l in ops) and sum("residual=0.66*" in l for l in ops) == 4, ops
+            assert sum("residual=" in l and "rows=every-3" in l for l in ops) == 3, ops
+        else:
+            assert sum(1 for l in ops if l.startswith("op: eltwise") and "rows=every-3" in l) == 3 and not any("residual=" in l for l in ops), ops
+        assert not any("rows=every" in l for l in ops1)
