@@ -647,7 +647,13 @@ void Model::ToDevice() {
         for (auto &sg : op.segs) by_image = by_image && sg.src_buf >= 0 && sg.src_buf != nn.input_buf;
         for (auto &sg : op.segs)
           if (sg.src_buf >= 0) (by_image ? buf_image_ : buf_f32_)[sg.src_buf] = 1;
-        if (op.res_buf >= 0) buf_f32_[op.res_buf] = 1;      // (a folded residual is read as plain floats)
+        if (op.res_buf >= 0) {
+          // a folded residual: through the source's operand image when the layer is image-fed (RS_RESIDUAL_IMAGE=0, read per model
+          // load: as plain floats, the elementwise op's exact operands), else as plain floats
+          const char *e = std::getenv("RS_RESIDUAL_IMAGE");
+          gemm_plans_[i].res_by_image = by_image && op.res_buf != nn.input_buf && !(e && std::atoi(e) == 0);
+          (gemm_plans_[i].res_by_image ? buf_image_ : buf_f32_)[op.res_buf] = 1;
+        }
       } else {
         for (auto &t : op.terms) buf_f32_[t.src_buf] = 1;
       }
@@ -1142,7 +1148,10 @@ GemmDev Model::MakeGemm(const GemmPlan &pl, const std::vector<float *> &src, con
     d.stages[i].scale = pl.d_stage[i].first; d.stages[i].offset = pl.d_stage[i].second; d.stages[i].alpha = st.alpha;
   }
   d.out = out; d.ldo = ldo;
-  if (op.res_buf >= 0) { d.res = src[op.res_buf]; d.res_ld = src_ld[op.res_buf]; d.res_scale = op.res_scale; }
+  if (op.res_buf >= 0) {
+    d.res = src[op.res_buf]; d.res_ld = src_ld[op.res_buf]; d.res_scale = op.res_scale;
+    if (images_on && pl.res_by_image && d.W3I) d.res_img = (*imgs)[op.res_buf];
+  }
   return d;
 }
 

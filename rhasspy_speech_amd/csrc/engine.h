@@ -76,6 +76,7 @@ struct GemmPlan {        // one LayerOp of kind kGemm, uploaded
   void *d_W3 = nullptr;           // split-fp16 image of W for GemmKernelB3 (layers at least 192 columns wide)
   void *d_W3I = nullptr;          // the same for GemmKernelB3I (every source a frame buffer on a k-step boundary)
   float *d_w3_inv_scale = nullptr;   // inverse of the images' column scales (n3 floats)
+  bool res_by_image = false;      // LayerOp::res_buf is read through its operand image (GemmDev::res_img) when the call runs on the image-fed kernels
   int k_pad = 0, n_pad = 0, n3 = 0;
   bool interleave = false;        // W3 k-steps alternate between the segments (see GemmKernelB3)
   std::vector<int> seg_k0;

@@ -164,6 +164,10 @@ struct GemmDev {
   const float *res;
   int res_ld;
   float res_scale;
+  // base non-null (split-fp16 kernels fed by operand images): the residual's rows are taken from ITS operand image instead -- the sum of
+  // the two fp16 parts, i.e. the value the next layer's GEMM multiplies, within 2^-22 of the FP32 number (nnet_b3_common.h) -- so a
+  // chain of residual layers needs no FP32 copy of its activations at all (half the epilogue's traffic, no pass through LDS)
+  ActImage res_img;
   ActImage out_img;    // base non-null: the result is (also) written as an operand image for the layers that consume it
   int write_f32;       // 0: nobody reads `out` as floats (every consumer takes the image): skip that store
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)

@@ -29,6 +29,9 @@ inline int GemmEpiMode(const GemmDev &d, int rows) {
 // nnet_gemm_b3.hip
 bool GemmB3Usable(const GemmDev &d);
 void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s);
+// nnet_gemm_b3i.hip: a layer with a folded residual (GemmDev::res) on a kernel that does not add it in its own epilogue
+GemmDev GemmWithoutResidual(const GemmDev &d);
+void LaunchResidualAdd(const GemmDev &d, int rows, hipStream_t s);
 // nnet_gemm_b3i.hip (sources stored as operand images)
 bool GemmB3IUsable(const GemmDev &d);
 void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s);

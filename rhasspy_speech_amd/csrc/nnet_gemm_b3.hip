@@ -292,7 +292,13 @@ bool GemmB3Usable(const GemmDev &d) {
   return true;
 }
 
-void LaunchGemmB3(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) {
+void LaunchGemmB3(const GemmDev &d0, int rows, const int *row_ivec, hipStream_t s) {
+  if (d0.res) {      // (a folded residual: this kernel's epilogue does not add it -- nnet_gemm_b3i.hip)
+    LaunchGemmB3(GemmWithoutResidual(d0), rows, row_ivec, s);
+    LaunchResidualAdd(d0, rows, s);
+    return;
+  }
+  const GemmDev &d = d0;
   static int num_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

@@ -216,9 +216,12 @@ void LaunchB3I(const GemmDev &d, int rows, int nbig, hipStream_t s) {
 
 // f32 rows -> operand image: one wave per (row block, k-step) 1 KiB block, both parts
 // one workgroup per 32 rows (of the row list, or of the buffer), wave w converts the k-steps w, w + 4, ...; the four waves' maxima
-// of |x| over a row together are the row's (B3Under, nnet_b3_common.h)
-__global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ src, int ld, int dim, int rows, ActImage img, int *ovf,
-                                                     const int *__restrict__ row_map) {
+// of |x| over a row together are the row's (B3Under, nnet_b3_common.h).
+// With a residual (GemmDev::res / res_img of a layer that did NOT run on GemmKernelB3J, which adds it in registers): the row is
+// src + res_scale * residual first -- the same float operations -- and goes back to `src` when somebody reads it as floats.
+struct ResidualDev { const float *res; int res_ld; float scale; ActImage img; int write_back; };
+__global__ __launch_bounds__(256) void ToImageKernel(float *__restrict__ src, int ld, int dim, int rows, ActImage img, int *ovf,
+                                                     const int *__restrict__ row_map, ResidualDev rd) {
   __shared__ unsigned rmx[32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 32) rmx[threadIdx.x] = 0u;
@@ -226,9 +229,10 @@ __global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ s
   const int idx = blockIdx.x * 32 + (lane & 31);
   const bool rok = idx < rows;
   const int row = rok ? (row_map ? row_map[idx] : idx) : 0, phys = row + img.guard;
+  const int nks = (dim + 15) / 16;
   bool over = false;
   float rm = 0.f;
-  for (int ks = wave; ks < img.nks && rok; ks += 4) {
+  for (int ks = wave; ks < nks && rok; ks += 4) {
     const int col = ks * 16 + (lane >> 5) * 8;
     f32x4 lo, hi;
 #pragma unroll
@@ -236,12 +240,44 @@ __global__ __launch_bounds__(256) void ToImageKernel(const float *__restrict__ s
       lo[e] = col + e < dim ? src[(size_t)row * ld + col + e] : 0.f;
       hi[e] = col + 4 + e < dim ? src[(size_t)row * ld + col + 4 + e] : 0.f;
     }
-    f16x8 p1, p2;
-    over |= B3Over(Split2(lo, hi, &p1, &p2));
-    rm = B3AbsMax(B3AbsMax(rm, lo), hi);
-    unsigned char *dst = img.base + ((size_t)(phys >> 5) * img.nks + ks) * kB3FragBytes + (lane >> 5) * 512 + (phys & 31) * 16;
-    *reinterpret_cast<f16x8 *>(dst) = p1;
-    *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
+    if (rd.res || rd.img.base) {
+      f32x4 rl, rh;
+      if (rd.img.base) {
+        const int rp = row + rd.img.guard;
+        const unsigned char *rs = rd.img.base + ((size_t)(rp >> 5) * rd.img.nks + ks) * kB3FragBytes + (lane >> 5) * 512 + (rp & 31) * 16;
+        const f16x8 r1 = *reinterpret_cast<const f16x8 *>(rs), r2 = *reinterpret_cast<const f16x8 *>(rs + rd.img.part_bytes);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { rl[e] = (float)r1[e] + (float)r2[e]; rh[e] = (float)r1[4 + e] + (float)r2[4 + e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          rl[e] = col + e < dim ? rd.res[(size_t)row * rd.res_ld + col + e] : 0.f;
+          rh[e] = col + 4 + e < dim ? rd.res[(size_t)row * rd.res_ld + col + 4 + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        lo[e] = __fadd_rn(rd.scale != 1.0f || rd.img.base ? __fmul_rn(rl[e], rd.scale) : rl[e], lo[e]);
+        hi[e] = __fadd_rn(rd.scale != 1.0f || rd.img.base ? __fmul_rn(rh[e], rd.scale) : rh[e], hi[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) { if (col + e >= dim) lo[e] = 0.f; if (col + 4 + e >= dim) hi[e] = 0.f; }
+      if (rd.write_back) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (col + e < dim) src[(size_t)row * ld + col + e] = lo[e];
+          if (col + 4 + e < dim) src[(size_t)row * ld + col + 4 + e] = hi[e];
+        }
+      }
+    }
+    if (img.base) {
+      f16x8 p1, p2;
+      over |= B3Over(Split2(lo, hi, &p1, &p2));
+      rm = B3AbsMax(B3AbsMax(rm, lo), hi);
+      unsigned char *dst = img.base + ((size_t)(phys >> 5) * img.nks + ks) * kB3FragBytes + (lane >> 5) * 512 + (phys & 31) * 16;
+      *reinterpret_cast<f16x8 *>(dst) = p1;
+      *reinterpret_cast<f16x8 *>(dst + img.part_bytes) = p2;
+    }
   }
   if (over) ovf[0] = 1;
   atomicMax(&rmx[lane & 31], __float_as_uint(rm));
@@ -258,7 +294,24 @@ size_t ActImagePartBytes(int rows, int guard, int dim) {
 
 void LaunchToImage(const float *src, int ld, int dim, int rows, const ActImage &img, int *ovf, hipStream_t s, const int *row_map) {
   if (rows <= 0 || img.nks <= 0) return;
-  hipLaunchKernelGGL(ToImageKernel, dim3((rows + 31) / 32), dim3(256), 0, s, src, ld, dim, rows, img, ovf, row_map);
+  hipLaunchKernelGGL(ToImageKernel, dim3((rows + 31) / 32), dim3(256), 0, s, const_cast<float *>(src), ld, dim, rows, img, ovf, row_map, ResidualDev{nullptr, 0, 1.0f, ActImage{nullptr, 0, 0, 0}, 0});
+}
+
+// A layer with a folded residual on a kernel that does not add it itself (GemmKernelB3 / GemmKernelB3I: the extra operands pushed their
+// 128-row shapes past 256 registers): the GEMM writes plain floats, then this pass adds the residual and cuts the operand image.  Same
+// float operations as GemmKernelB3J's in-register form, so a layer's result does not depend on which of the kernels ran it.
+GemmDev GemmWithoutResidual(const GemmDev &d) {
+  GemmDev g = d;
+  g.res = nullptr; g.res_ld = 0; g.res_scale = 1.0f;
+  g.res_img = ActImage{nullptr, 0, 0, 0};
+  g.out_img = ActImage{nullptr, 0, 0, 0};
+  g.write_f32 = 1;
+  return g;
+}
+void LaunchResidualAdd(const GemmDev &d, int rows, hipStream_t s) {
+  if (rows <= 0) return;
+  ResidualDev rd{d.res_img.base ? nullptr : d.res, d.res_ld, d.res_scale, d.res_img, d.write_f32 || !d.out_img.base ? 1 : 0};
+  hipLaunchKernelGGL(ToImageKernel, dim3((rows + 31) / 32), dim3(256), 0, s, d.out, d.ldo, d.n, rows, d.out_img, d.ovf, d.row_map, rd);
 }
 
 bool GemmImagesEnabled() {
@@ -276,7 +329,8 @@ bool GemmB3IUsable(const GemmDev &d) {
   return true;
 }
 
-void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
+void LaunchGemmB3I(const GemmDev &d0, int rows, hipStream_t s) {
+  const GemmDev d = d0.res ? GemmWithoutResidual(d0) : d0;
   static int num_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -307,13 +361,14 @@ void LaunchGemmB3I(const GemmDev &d, int rows, hipStream_t s) {
   if (force_mr == 2) { mr = 2; nbig = (rows + 63) / 64; mixed = false; }
   if (force_mr == 4) { mr = 4; nbig = (rows + 127) / 128; mixed = false; }
   static const int kps1 = [] { const char *e = TuneEnv("RS_GEMM_B3I_KPS"); return e ? std::atoi(e) : 8; }();
-  if (mr == 1 && GemmB3JSmallUsable(d)) { LaunchGemmB3JSmall(d, rows, s); return; }
+  if (mr == 1 && GemmB3JSmallUsable(d0)) { LaunchGemmB3JSmall(d0, rows, s); return; }      // (adds a folded residual itself)
   if (mr == 1 && kps1 == 8) LaunchB3I<1, false, 8>(d, rows, nbig, s);
   else if (mr == 1 && kps1 == 4) LaunchB3I<1, false, 4>(d, rows, nbig, s);
   else if (mr == 1) LaunchB3I<1, false>(d, rows, nbig, s);
   else if (mr == 2) LaunchB3I<2, false>(d, rows, nbig, s);
   else if (mixed) LaunchB3I<4, true>(d, rows, nbig, s);
   else LaunchB3I<4, false>(d, rows, nbig, s);
+  if (d0.res) LaunchResidualAdd(d0, rows, s);
 }
 
 }  // namespace rs

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         }                                                                                                        \
       }                                                                                                          \
     }
-    const bool direct = d.out_img.base && !d.write_f32 && !d.res && !(RS_B3J_ABLATE & (128 | 256));
+    const bool direct = d.out_img.base && !d.write_f32 && (!d.res || d.res_img.base) && !(RS_B3J_ABLATE & (128 | 256));
     if (direct) {
       // destination rows first: a row-map load between two stores makes the compiler wait for vmcnt(0), stores included
       int phys[MR];
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         rok[i] = row < rows && i < mr_eff;
         phys[i] = rok[i] ? (d.row_map ? d.row_map[row] : row) + d.out_img.guard : 0;
       }
+      const int rguard = d.res_img.guard - d.out_img.guard;      // (a folded residual read through its image: the same rows of that image)
       // (the block numbers are macro arguments: acc[] must never be indexed by a variable the compiler might not unroll)
       float rm0 = 0.f, rm1 = 0.f, rm2 = 0.f, rm3 = 0.f;      // max |x| over what this lane splits of its row of row block 0 .. 3
 #define RS_DIRECT(I, J)                                                                                        \
@@ -452,6 +453,15 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
           const int col = n0 + cb + 16 * ksi + 8 * half;                                                         \
           if (rok[I] && (col >> 4) < d.out_img.nks) {                                                            \
             f32x4 lo = q[2 * ksi], hi = q[2 * ksi + 1];                                                          \
+            if (d.res_img.base) {                                                                                \
+              const int rp = phys[I] + rguard;                                                                   \
+              const unsigned char *rs = d.res_img.base + ((size_t)(rp >> 5) * d.res_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (rp & 31) * 16; \
+              const f16x8 r1 = *reinterpret_cast<const f16x8 *>(rs), r2 = *reinterpret_cast<const f16x8 *>(rs + d.res_img.part_bytes); \
+              _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                  \
+                lo[e] = __fadd_rn(__fmul_rn((float)r1[e] + (float)r2[e], d.res_scale), lo[e]);                   \
+                hi[e] = __fadd_rn(__fmul_rn((float)r1[4 + e] + (float)r2[4 + e], d.res_scale), hi[e]);           \
+              }                                                                                                  \
+            }                                                                                                    \
             _Pragma("unroll") for (int e = 0; e < 4; e++) { if (col + e >= d.n) lo[e] = 0.f; if (col + 4 + e >= d.n) hi[e] = 0.f; } \
             f16x8 p1, p2;                                                                                        \
             over |= B3Over(Split2(lo, hi, &p1, &p2));                                                            \
@@ -522,10 +532,18 @@ _Pragma("unroll") \
           const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
           if (row < rows && col < d.n) { \
             f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]); \
-            const float *rp = d.res + (size_t)f32_phys[(SL)][q] * d.res_ld + col; \
             f32x4 r; \
-            if (vec_res) r = *reinterpret_cast<const f32x4 *>(rp); \
-            else { for (int e = 0; e < 4; e++) r[e] = col + e < d.n ? rp[e] : 0.f; } \
+            if (d.res_img.base) { \
+              const int ip = f32_phys[(SL)][q] + d.res_img.guard; \
+              const unsigned char *rs = d.res_img.base + ((size_t)(ip >> 5) * d.res_img.nks + (col >> 4)) * kB3FragBytes + ((col >> 3) & 1) * 512 + (ip & 31) * 16 + (col & 7) * 2; \
+              const f16x4 r1 = *reinterpret_cast<const f16x4 *>(rs), r2 = *reinterpret_cast<const f16x4 *>(rs + d.res_img.part_bytes); \
+_Pragma("unroll") \
+              for (int e = 0; e < 4; e++) r[e] = (float)r1[e] + (float)r2[e]; \
+            } else { \
+              const float *rp = d.res + (size_t)f32_phys[(SL)][q] * d.res_ld + col; \
+              if (vec_res) r = *reinterpret_cast<const f32x4 *>(rp); \
+              else { for (int e = 0; e < 4; e++) r[e] = col + e < d.n ? rp[e] : 0.f; } \
+            } \
 _Pragma("unroll") \
             for (int e = 0; e < 4; e++) v[e] = __fadd_rn(d.res_scale != 1.0f ? __fmul_rn(r[e], d.res_scale) : r[e], v[e]); \
             *reinterpret_cast<f32x4 *>(&Cs[rl * C_LD + c4]) = v; \
