@@ -6,7 +6,10 @@ each is pinned to the reference's transcript in tests/test_gpu_configs.py):
   grammar (default, configs[1], the headline): zamia-like-S model, grammar HCLG, 256 x 3 s utterances per GPU;
   arpa    (configs[2]): the same model on the back-off ARPA HCLG, 256 x 3 s;
   mixed   (configs[3]): 1024 utterances naming two zamia-size models, sharded over the ranks, one gather;
-  streams (configs[4]): 64 concurrent 30 s streams fed in 1024-sample ticks round-robin (rs_stream_* entry points).
+  streams (configs[4]): 64 concurrent 30 s streams (rs_streams_* entry points) handed over round-robin in rounds of 8192 samples per stream
+          (8 of the reference binary's 1024-sample reads; the library's default coalescing makes every second rs_streams_advance call do
+          the device work of two) -- with `streams_per_tick` (1024-sample rounds, every call advances: SURVEY 8(d)'s wording) and
+          `finish_latency_ms` (p50 / p99 of last-samples-in -> words-out at real-time arrival) beside it;
 No real zamia model exists offline, so the model is the synthetic "zamia-like-S" of SURVEY.md section 8(d) written in
 genuine Kaldi formats by rhasspy_speech_amd.synth (40-dim hires MFCC, 100-dim iVector with a 512-Gaussian UBM, 7x250
 TDNN + prefinal, 2000 pdfs); audio is synthetic (seeded).
@@ -90,6 +93,8 @@ def other_workloads(timeout_s: float = 240.0):
     out = {}
     for wl, (steps, warm) in OTHER_WORKLOADS.items():
         cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", wl, "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--no-side-figures"]
+        if wl == "streams":
+            cmd.append("--stream-figures")
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, env=dict(os.environ, RS_BENCH_NO_OTHER="1"))
@@ -100,6 +105,9 @@ def other_workloads(timeout_s: float = 240.0):
             out[wl] = {"error": (r.stderr.decode()[-400:] if r is not None else f"no result within {timeout_s:.0f} s")}
             continue
         keep = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "timed_seconds", "results_checked", "stages_ms", "roofline", "roofline_note")}
+        for k in ("streams_per_tick", "finish_latency_ms"):
+            if k in line:
+                keep[k] = line[k]
         keep["workload"] = line["config"]["workload"]
         keep["calls_in_flight"] = line["config"]["calls_in_flight"]
         keep["golden_checked"] = "equal the reference's" in (line.get("results_checked") or "")
@@ -159,15 +167,30 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, second
                 steady = {"value": tab_audio / wall_tab, "unit": "audio-seconds/s", "cores": 1,
                           "sample": f"{n_tab} utterances through ONE pipeline invocation (model + HCLG loaded once)"}
                 # ... and on all host cores, the way a Kaldi deployment scales: one such single-load pipeline per core
-                n_workers = max(1, min(os.cpu_count() or 1, 64))
+                # (every logical CPU of the box, whatever this process's threads are bound to: the children get the full affinity mask.
+                # Until round 5 this was capped at 64 workers on boxes with 128+ CPUs per socket.)
+                n_workers = max(1, os.cpu_count() or 1)
+
+                def all_cpus():
+                    try:
+                        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                    except OSError:
+                        pass
                 t2 = time.perf_counter()
-                procs = [subprocess.Popen(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(n_workers)]
+                procs = [subprocess.Popen(["bash", "-c", cmd], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, preexec_fn=all_cpus) for _ in range(n_workers)]
                 outs = [p.communicate()[0] for p in procs]
                 wall_all = time.perf_counter() - t2
                 if all(p.returncode == 0 for p in procs) and all(len(o.decode().splitlines()) == n_tab for o in outs):
                     all_cores = {"value": n_workers * tab_audio / wall_all, "unit": "audio-seconds/s", "cores": n_workers,
                                  "sample": f"{n_workers} single-load pipelines side by side, {n_tab} utterances each"}
-    return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference",
+    cpu_model = "unknown"
+    try:
+        for line in subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().splitlines():
+            if line.startswith("Model name:"):
+                cpu_model = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model, "host_cpus": os.cpu_count(),
             "sample": f"{n_done} of the {len(pcms)} utterances, one reference pipeline per utterance "
                       f"({'online2-cli-nnet3-decode-faster on stdin' if streaming else 'transcribe_wav.py-style 3-process pipeline'}; model + HCLG "
                       f"re-loaded every call, as the reference does)",
@@ -183,6 +206,7 @@ def main() -> None:
     ap.add_argument("--utts", type=int, default=None, help="utterances (streams) per GPU; default = the configuration's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-figures", action="store_true", help="time the headline only (profiling runs)")
+    ap.add_argument("--stream-figures", action="store_true", help="streams: streams_per_tick and finish_latency_ms even with --no-side-figures")
     ap.add_argument("--inflight", type=int, default=None,
                     help="decode calls in flight per rank (host threads on one model; the library gives each its own decode "
                          "context): the latency-bound search of one batch overlaps the GEMMs of the next.  1 = one call at a time")
@@ -335,8 +359,84 @@ def main() -> None:
                 sys.stderr.write(f"streams step: open {t_open * 1e3:.2f} ms, slicing {t_py * 1e3:.2f}, accept {t_acc * 1e3:.2f}, advance {t_adv * 1e3:.2f}, "
                                  f"finish {(time.perf_counter() - t0) * 1e3:.2f} ({n_rounds} rounds)\n")
             return out
-        workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU fed in {tick}-sample "
-                         f"rounds (online2-cli-nnet3-decode-faster semantics: 1024-sample ticks, one iVector per 24-frame nnet chunk)")
+        workload_name = (f"zamia-like-S synthetic Kaldi model, grammar HCLG, {n_utts} concurrent 30 s streams per GPU, audio handed over round-robin in rounds of "
+                         f"{tick} samples per stream (8 of the reference binary's 1024-sample reads; rs_decode_opts.stream_min_ticks at its default 16: every second "
+                         f"round's rs_streams_advance does the device work of two), online2-cli-nnet3-decode-faster semantics inside: the chunk / iVector schedule "
+                         f"of 1024-sample ticks, one iVector per 24-frame nnet chunk; beside it `streams_per_tick` (1024-sample rounds, every call advances) and "
+                         f"`finish_latency_ms` (real-time pacing)")
+
+        def stream_figures(ref_rec):
+            """What the headline's 8-tick rounds do not show: the same 64 streams fed the way SURVEY.md section 8(d) words it --
+            1024-sample ticks round-robin, every rs_streams_advance call doing its tick's work (stream_min_ticks = 1) -- and the time
+            from handing over a stream's last samples to holding its words when the audio arrives in real time."""
+            tm = _lib.Model(model_dir, graph_dir, _lib.default_opts(**opts, stream_min_ticks=1))
+            tm.to_device()
+
+            def fed_by_tick(m, t_samples):
+                streams = [_lib.Stream(m) for _ in pcms]
+                handles = _lib.stream_handles(streams)
+                for r in range((int(pcm_len.max()) + t_samples - 1) // t_samples):
+                    left = pcm_len - r * t_samples
+                    live = left > 0
+                    _lib.accept_streams_raw(handles[live], (pcm_base + np.uintp(2 * r * t_samples))[live], np.minimum(left[live], t_samples).astype(np.int32))
+                    _lib.advance_streams_raw(handles)
+                return _lib.finish_streams(streams)
+            out = {}
+            r0 = fed_by_tick(tm, 1024)
+            if not np.array_equal(r0.pack(MAX_WORDS), ref_rec):
+                raise SystemExit("bench.py: streams fed tick by tick decode differently from the 8-tick rounds")
+            n_t = 3
+            t0 = time.perf_counter()
+            for _ in range(n_t):
+                fed_by_tick(tm, 1024)
+            secs = time.perf_counter() - t0
+            n_calls = (int(pcm_len.max()) + 1023) // 1024
+            out["streams_per_tick"] = {"value": audio_seconds * n_t / secs, "unit": "audio-seconds/s", "ms_per_step": 1000.0 * secs / n_t, "steps": n_t,
+                                       "advance_calls_per_step": n_calls, "ms_per_advance_call": 1000.0 * secs / n_t / n_calls,
+                                       "note": "1024-sample ticks round-robin over the 64 streams, rs_decode_opts.stream_min_ticks = 1 (every rs_streams_advance call does its "
+                                               "tick's work: the reference binary's cadence), not paced: the rate at which ticks can be absorbed; records equal the headline's (checked)"}
+
+            def paced_tail(m, tail_ticks=24):
+                """all but the last tail_ticks ticks as fast as they go, then one tick per 64 ms of wall clock (real time); a stream whose audio
+                ends with a tick is finished right behind that tick's advance -- streams that end together in one rs_streams_finish call"""
+                streams = [_lib.Stream(m) for _ in pcms]
+                handles = _lib.stream_handles(streams)
+                n_ticks = (pcm_len + 1023) // 1024                      # per stream: the tick that holds its last sample is n_ticks - 1
+                first_paced = max(int(n_ticks.min()) - tail_ticks, 0)
+                for r in range(0, first_paced, 8):
+                    n_s = min(8, first_paced - r) * 1024
+                    _lib.accept_streams_raw(handles, pcm_base + np.uintp(2 * r * 1024), np.full(len(pcms), n_s, np.int32))
+                    _lib.advance_streams_raw(handles)
+                time.sleep(0.25)                                         # (the device catches up: from here on the audio arrives in real time)
+                lat = np.zeros(len(pcms))
+                t_start = time.perf_counter()
+                for k, r in enumerate(range(first_paced, int(n_ticks.max()))):
+                    wait = t_start + k * 0.064 - time.perf_counter()
+                    if wait > 0:
+                        time.sleep(wait)
+                    left = pcm_len - r * 1024
+                    live = left > 0
+                    t_in = time.perf_counter()
+                    _lib.accept_streams_raw(handles[live], (pcm_base + np.uintp(2 * r * 1024))[live], np.minimum(left[live], 1024).astype(np.int32))
+                    _lib.advance_streams_raw(handles[live])
+                    ending = np.nonzero(n_ticks - 1 == r)[0]
+                    if len(ending):
+                        _lib.finish_streams([streams[i] for i in ending])
+                        lat[ending] = (time.perf_counter() - t_in) * 1e3
+                for st in streams:
+                    st.close()
+                return lat
+            lat = {}
+            for name, m in (("stream_min_ticks_1", tm), ("stream_min_ticks_16_default", model)):
+                paced_tail(m)                                            # (warm: arenas of the small advances)
+                v = np.concatenate([paced_tail(m) for _ in range(2)])
+                lat[name] = {"p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": float(v.max()), "samples": int(v.size)}
+            lat["note"] = ("ms from handing a stream's LAST 1024 samples to rs_streams_accept until rs_streams_finish has returned its words, audio arriving at real time "
+                           "(one tick per 64 ms) over the last 1.5 s of 64 concurrent streams whose lengths differ by up to 0.49 s; streams that end with the same tick "
+                           "are finished in one call.  With the default coalescing the finishing call also does the up to 15 ticks of device work left undone.")
+            out["finish_latency_ms"] = lat
+            del tm
+            return out
     else:   # mixed
         n_per = (args.utts or 1024) // 2
         names, pcms = configs.mixed_utterances(n_per)
@@ -511,6 +611,8 @@ def main() -> None:
                 full_stage += np.array(full_dev().timings())
             all_pdfs_stage = (float(full_stage[3] / 5), full.describe())
             del full
+    if wl == "streams" and world == 1 and (args.stream_figures or not args.no_side_figures):
+        side.update(stream_figures(ref_rec))
     # ---- the n-best / lattice tail (what every rescoring or fuzzy-matching call of the Python API asks for: nbest = 5; and the
     # determinised lattice itself): device-side lattice extraction + host determinisation and n-best, utterances of a call on a
     # few host threads.  Short runs: the tail is host work, an order of magnitude slower than the 1-best step.

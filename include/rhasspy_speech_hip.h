@@ -72,7 +72,13 @@ typedef struct rs_decode_opts {
                                 * ParseOptions reads --config first and the command line overrides it (util/parse-options.cc:328-345), so
                                 * an unsupported value of such an option in online.conf is then not an error.  rs_default_opts sets
                                 * ONLINE | DO_ENDPOINTING: rhasspy's command line carries both (transcribe_wav.py:48-49). */
-  int32_t reserved[3];
+  int32_t stream_min_ticks;    /* rs_streams_advance coalescing: a call that brings fewer than this many new 1024-sample ticks (64 ms each) on EVERY
+                                * listed stream does nothing and leaves the audio to the next call (the chunk / iVector schedule is a function
+                                * of the samples accepted, not of the calls: results are the same for any value).  1: every call advances, the
+                                * reference binary's per-tick cadence (online2-cli-nnet3-decode-faster.cc:143-161) -- lowest latency of
+                                * rs_streams_finish, most launches; 0 = the library's default, 16 (about a second of audio per advance: the
+                                * throughput setting).  RS_STREAM_MIN_TICKS=<n> overrides. */
+  int32_t reserved[2];
 } rs_decode_opts;
 #define RS_FIXED_ONLINE 1
 #define RS_FIXED_DO_ENDPOINTING 2

@@ -13,7 +13,8 @@ runs exactly that pipeline with the reference's binaries (oracle/_ref) and store
   * the lattice the reference decoder produced (binary CompactLattice entry) -- input of the host-only parity test,
   * the n-best text and nbest-to-linear's graph / acoustic costs after rescoring.
 
-Usage: python oracle/gen_rescore_golden.py
+Usage: python oracle/gen_rescore_golden.py [lang style ...]      (the wav transcriber's path)
+       python oracle/gen_rescore_golden.py --stream            (adds the streaming transcriber's runs to the committed cases.json)
 """
 from __future__ import annotations
 
@@ -227,7 +228,61 @@ def reference_rescore(model_dir: Path, graph_dir: Path, wav: Path, lang_dir: Pat
     return text, [lm[k] for k in keys], [ac[k] for k in keys], (td / "dec.lat").read_bytes()
 
 
+def reference_rescore_stream(model_dir: Path, graph_dir: Path, pcm, lang_dir: Path, td: Path, case: dict):
+    """The STREAMING transcriber's rescoring path (rhasspy_speech/transcribe_stream.py:131-274): the lattice comes from
+    online2-cli-nnet3-decode-faster fed s16le on stdin (an iVector per chunk: other acoustic costs than the wav binary's), the tail
+    is the same chain."""
+    phi = phi_of(lang_dir)
+    mdl = model_dir / "model" / "model" / "final.mdl"
+    conf = model_dir / "model" / "online" / "conf" / "online.conf"
+    sh = (f"fstprint {lang_dir}/L_disambig.fst | awk '{{if($4 != {phi}){{print;}}}}' | fstcompile | fstdeterminizestar | "
+          f"fstrmsymbols {lang_dir}/phones/disambig.int - {td}/Ldet.fst")
+    subprocess.run(["bash", "-c", sh], env=ENV, check=True, stderr=subprocess.PIPE)
+    o = dict(max_active=7000, lattice_beam=8.0, beam=24.0)
+    o.update({k: v for k, v in case.get("opts", {}).items() if k in o})
+    dec = (f"online2-cli-nnet3-decode-faster --config={conf} --max-active={o['max_active']} --lattice-beam={o['lattice_beam']} --acoustic-scale=1.0 "
+           f"--beam={o['beam']} {mdl} {graph_dir}/HCLG.fst {graph_dir}/words.txt ark:{td}/sdec.lat")
+    subprocess.run(["bash", "-c", dec], env=ENV, check=True, input=np.asarray(pcm).astype("<i2").tobytes(), stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+    tail = (f"lattice-scale --lm-scale=0.0 ark:{td}/sdec.lat ark:- | lattice-to-phone-lattice {mdl} ark:- ark:- | lattice-compose ark:- {td}/Ldet.fst ark:- | "
+            f"lattice-determinize ark:- ark:- | lattice-compose --phi-label={phi} ark:- {lang_dir}/G.fst ark:- | "
+            f"lattice-add-trans-probs --transition-scale=1.0 --self-loop-scale=0.1 {mdl} ark:- ark:- | "
+            f"lattice-to-nbest --n={NBEST} --acoustic-scale=1.0 ark:- ark:- | nbest-to-linear ark:- ark:/dev/null ark,t:- ark,t:{td}/slm.txt ark,t:{td}/sac.txt")
+    r = subprocess.run(["bash", "-c", tail], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    text = r.stdout if r.returncode == 0 else b""
+
+    def vec(p):
+        out = {}
+        if Path(p).exists():
+            for line in Path(p).read_text().splitlines():
+                q = line.split()
+                if q:
+                    out[q[0]] = float(q[1])
+        return out
+    lm, ac = vec(td / "slm.txt"), vec(td / "sac.txt")
+    keys = sorted(lm, key=lambda k: int(k.split("-")[1]))
+    return text, [lm[k] for k in keys], [ac[k] for k in keys]
+
+
+def add_stream_runs():
+    """`gen_rescore_golden.py --stream`: adds stream_nbest_text / stream_graph_cost / stream_acoustic_cost to every entry of the
+    committed cases.json, on the committed language directories (nothing else changes)."""
+    index = json.loads((OUT / "cases.json").read_text())
+    with tempfile.TemporaryDirectory() as tds:
+        for e in index:
+            case = cases.CASES[e["case"]]
+            td = Path(tds) / e["dir"]
+            td.mkdir()
+            model_dir, graph_dir, wav, pcm = cases.build_case_files(case, td)
+            text, lm, ac = reference_rescore_stream(model_dir, graph_dir, pcm, OUT / e["dir"], td, case)
+            e["stream_nbest_text"], e["stream_graph_cost"], e["stream_acoustic_cost"] = text.decode(), lm, ac
+            print(f"{e['case']} x {e['lang']} (stream): {text.decode().strip().replace(chr(10), ' | ') or '(nothing survives)'}")
+    (OUT / "cases.json").write_text(json.dumps(index, indent=1))
+
+
 def main():
+    if sys.argv[1:] == ["--stream"]:
+        add_stream_runs()
+        return
     OUT.mkdir(parents=True, exist_ok=True)
     index = []
     only = set(sys.argv[1:])            # e.g. `gen_rescore_golden.py eps_grammar`: (re)generate that language style only

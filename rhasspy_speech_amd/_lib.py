@@ -24,7 +24,7 @@ class DecodeOpts(C.Structure):
         ("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32), ("lattice_beam", C.c_float),
         ("beam_delta", C.c_float), ("acoustic_scale", C.c_float), ("frames_per_chunk", C.c_int32),
         ("frame_subsampling_factor", C.c_int32), ("device_id", C.c_int32), ("keep_intermediates", C.c_int32),
-        ("max_tokens_per_frame", C.c_int32), ("emit_lattice", C.c_int32), ("prune_output_pdfs", C.c_int32), ("exact_token_order", C.c_int32), ("command_line_fixed", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("max_tokens_per_frame", C.c_int32), ("emit_lattice", C.c_int32), ("prune_output_pdfs", C.c_int32), ("exact_token_order", C.c_int32), ("command_line_fixed", C.c_int32), ("stream_min_ticks", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 

@@ -262,10 +262,15 @@ int rs_stream_open(rs_model *model, rs_stream **out) {
   });
 }
 
+static std::string FailedStream(const char *who, const rs_stream *st) {
+  return std::string(who) + ": stream was part of an advance that failed; its device state is undefined, close it" +
+         (st->fail_why.empty() ? std::string() : " (" + st->fail_why + ")");
+}
+
 int rs_stream_accept(rs_stream *stream, const int16_t *pcm, int32_t n_samples) {
   if (!stream || n_samples < 0 || (n_samples > 0 && !pcm)) return ArgError("rs_stream_accept: bad argument");
   if (stream->finished) return ArgError("rs_stream_accept: stream already finished");
-  if (stream->failed) return ArgError("rs_stream_accept: stream was part of an advance that failed; its device state is undefined, close it");
+  if (stream->failed) return ArgError(FailedStream("rs_stream_accept", stream).c_str());
   return Guard([&]() {
     stream->pcm.insert(stream->pcm.end(), pcm, pcm + n_samples);
     stream->n_samples += n_samples;
@@ -278,7 +283,7 @@ int rs_streams_accept(rs_stream *const *streams, const int16_t *const *pcm, cons
   for (int i = 0; i < n_streams; i++) {
     if (!streams[i] || n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) return ArgError("rs_streams_accept: bad argument");
     if (streams[i]->finished) return ArgError("rs_streams_accept: stream already finished");
-    if (streams[i]->failed) return ArgError("rs_streams_accept: stream was part of an advance that failed; its device state is undefined, close it");
+    if (streams[i]->failed) return ArgError(FailedStream("rs_streams_accept", streams[i]).c_str());
   }
   return Guard([&]() {
     for (int i = 0; i < n_streams; i++) {
@@ -295,7 +300,7 @@ static int CheckStreams(rs_stream *const *streams, int32_t n_streams, const char
     if (!streams[i] || !streams[i]->model) return ArgError((std::string(who) + ": null stream").c_str());
     if (streams[i]->model != streams[0]->model) return ArgError((std::string(who) + ": all streams must belong to one model").c_str());
     if (streams[i]->finished) return ArgError((std::string(who) + ": stream already finished").c_str());
-    if (streams[i]->failed) return ArgError((std::string(who) + ": stream was part of an advance that failed; its device state is undefined, close it").c_str());
+    if (streams[i]->failed) return ArgError(FailedStream(who, streams[i]).c_str());
     if (streams[i]->keep_pcm != streams[0]->keep_pcm) return ArgError((std::string(who) + ": streams opened in different modes").c_str());
     for (int j = 0; j < i; j++) if (streams[j] == streams[i]) return ArgError((std::string(who) + ": a stream is listed twice").c_str());
   }

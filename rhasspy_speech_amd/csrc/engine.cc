@@ -1402,7 +1402,7 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
   int *h_nw = harena.AllocT<int>(n_utts), *h_words = harena.AllocT<int>((size_t)n_utts * kWordsInline);
   float *h_costs = harena.AllocT<float>((size_t)n_utts * 4);
   long long *h_ctr = harena.AllocT<long long>((size_t)n_utts * 8);
-  LaunchResultsToHost(w.out_nwords, w.out_costs, w.counters, w.out_words, max_words, std::min(kWordsInline, max_words), n_utts, h_nw, h_costs, h_ctr, h_words, s);
+  LaunchResultsToHost(w.out_nwords, w.out_costs, w.counters, w.out_words, max_words, std::min(kWordsInline, max_words), kWordsInline, n_utts, h_nw, h_costs, h_ctr, h_words, s);
   RS_HIP(hipStreamSynchronize(s));
   RS_HIP(hipGetLastError());
   if (CheckGemmRange(cx)) throw RangeRetry{};      // an activation beyond the fp16 split's range: the call is repeated on the exact-FP32 GEMMs

@@ -155,7 +155,7 @@ class Model {
   void StreamClose(rs_stream *st);
   void StreamsAdvance(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res);
   void StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, int nbest, float lat_scale, Result *res);      // pool_mu_ held
-  void StreamsPoisonAll();          // pool_mu_ held
+  void StreamsPoisonAll(const std::string &why = std::string());          // pool_mu_ held
 
  private:
   struct DecodeContext;
@@ -235,6 +235,7 @@ class Model {
   std::mutex pool_mu_;             // pool bookkeeping and advances of this model, one at a time
   StreamPool *Pool();
   void StreamsDrain(StreamPool *p, float *extra);
+  void IssuerSync(StreamPool *p);     // everything handed to the pool's issuing thread has been queued; ITS failure poisons the open streams, then rethrows
   void StreamGrow(rs_stream *st, int need_frames);
   // The split-fp16 layer GEMMs carry activations below 65520 in magnitude (nnet_gemm_b3.hip).  A kernel that meets a larger
   // one sets the flag of the decode context it runs for (DecodeContext::gemm_ovf: host memory the device writes to); a batch
@@ -292,6 +293,7 @@ struct rs_stream {
   rs_model *model = nullptr;
   bool finished = false, open = false;
   std::atomic<bool> failed{false}; // an rs_streams_advance over this stream threw: schedule and device rows disagree, only close is allowed
+  std::string fail_why;            // ... and, when the failure surfaced in another call (an advance's deferred work), its message (written before `failed`)
   bool keep_pcm = false;           // RS_STREAM_BATCH=1: keep every sample and replay the stream as one batch at finish (cross-check path)
   std::vector<int16_t> pcm;        // samples from absolute index pcm_start on (the ones no complete frame has consumed yet)
   long pcm_start = 0, n_samples = 0;

@@ -480,18 +480,18 @@ void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void
 // kernel: four small device-to-host copies on the copy engine wait behind whatever the other calls in flight have queued there
 // (their 25 MB sample uploads).
 __global__ __launch_bounds__(64) void ResultsToHostKernel(const int *__restrict__ nw, const float *__restrict__ costs, const long long *__restrict__ ctr,
-                                                          const int *__restrict__ words, int max_words, int inline_words, int *h_nw, float *h_costs,
-                                                          long long *h_ctr, int *h_words) {
+                                                          const int *__restrict__ words, int max_words, int inline_words, int h_stride, int *h_nw,
+                                                          float *h_costs, long long *h_ctr, int *h_words) {
   const int u = blockIdx.x, t = threadIdx.x;
   if (t == 0) h_nw[u] = nw[u];
   if (t < 4) h_costs[(size_t)u * 4 + t] = costs[(size_t)u * 4 + t];
   if (t < 8) h_ctr[(size_t)u * 8 + t] = ctr[(size_t)u * 8 + t];
-  for (int k = t; k < inline_words; k += 64) h_words[(size_t)u * inline_words + k] = words[(size_t)u * max_words + k];
+  for (int k = t; k < inline_words; k += 64) h_words[(size_t)u * h_stride + k] = words[(size_t)u * max_words + k];
 }
-void LaunchResultsToHost(const int *nw, const float *costs, const long long *ctr, const int *words, int max_words, int inline_words, int n, int *h_nw,
-                         float *h_costs, long long *h_ctr, int *h_words, hipStream_t s) {
+void LaunchResultsToHost(const int *nw, const float *costs, const long long *ctr, const int *words, int max_words, int inline_words, int h_stride, int n,
+                         int *h_nw, float *h_costs, long long *h_ctr, int *h_words, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(ResultsToHostKernel, dim3(n), dim3(64), 0, s, nw, costs, ctr, words, max_words, inline_words, h_nw, h_costs, h_ctr, h_words);
+  hipLaunchKernelGGL(ResultsToHostKernel, dim3(n), dim3(64), 0, s, nw, costs, ctr, words, max_words, inline_words, h_stride, h_nw, h_costs, h_ctr, h_words);
 }
 
 // ------------------------------------------------------------------------------------------ row geometry

@@ -66,9 +66,10 @@ struct CopyRowsSet {
   int count;
 };
 void LaunchCopyRowsMulti(const CopyRowsSet &set, const int *src_row, const int *dst_row, int n, hipStream_t s);
-// h_*: page-locked host memory the device can store into (hipHostMalloc)
-void LaunchResultsToHost(const int *nw, const float *costs, const long long *ctr, const int *words, int max_words, int inline_words, int n, int *h_nw,
-                         float *h_costs, long long *h_ctr, int *h_words, hipStream_t s);
+// h_*: page-locked host memory the device can store into (hipHostMalloc); the first inline_words word ids of utterance u go to
+// h_words[u * h_stride ...] (copy count and destination pitch are separate: ADVICE r05)
+void LaunchResultsToHost(const int *nw, const float *costs, const long long *ctr, const int *words, int max_words, int inline_words, int h_stride, int n,
+                         int *h_nw, float *h_costs, long long *h_ctr, int *h_words, hipStream_t s);
 void LaunchCopyRows(const void *src, long src_ld_words, const int *src_row, void *dst, long dst_ld_words, const int *dst_row, int n, int width_words,
                     hipStream_t s);
 

@@ -107,7 +107,7 @@ struct StreamIssuer {
 struct StreamPool {
   StreamIssuer issuer;
   bool use_issuer = true;        // RS_STREAM_ISSUER=0: the caller's thread issues everything (A/B: profiles/micro)
-  int min_ticks = 16;            // an advance call with fewer new 1024-sample ticks than this on every stream is coalesced into the next (RS_STREAM_MIN_TICKS)
+  int min_ticks = 16;            // an advance call with fewer new 1024-sample ticks than this on every stream is coalesced into the next (rs_decode_opts.stream_min_ticks; RS_STREAM_MIN_TICKS overrides)
   // Queues, so that consecutive advances overlap on the device: `qa` runs an advance's features and UBM posteriors, `qi` (below)
   // its iVector steps, `q` its acoustic model (behind events of both), `qc` its search.  Stage A of advance n + 1 touches rows and slots stage B of advance n
   // does not (new frames / new chunks vs. the ones already scheduled), so the only ordering between them is per queue.
@@ -248,6 +248,7 @@ StreamPool *Model::Pool() {
   }
   { const char *e = TuneEnv("RS_STREAM_SYNC"); p->sync_each = e && std::atoi(e) != 0; }
   { const char *e = std::getenv("RS_STREAM_ISSUER"); p->use_issuer = !(e && std::atoi(e) == 0); }
+  if (opts_.stream_min_ticks >= 1) p->min_ticks = opts_.stream_min_ticks;      // rs_decode_opts (0: the default above)
   { const char *e = std::getenv("RS_STREAM_MIN_TICKS"); if (e && std::atoi(e) >= 1) p->min_ticks = std::atoi(e); }
   p->issuer.device = opts_.device_id;
   auto dalloc = [&](size_t bytes) {
@@ -297,8 +298,24 @@ StreamPool *Model::Pool() {
 
 // Waits for the advances still in flight and adds their stage times to the pool's totals (and to `extra`, if given: the finishing
 // call's own share).  Device errors of those advances surface here.
+// A closure the issuing thread ran for an advance (its acoustic-model and search launches) threw: the advance's rows were never
+// computed, its done event never recorded -- and the exception comes out in whichever later call waits for the thread, possibly one
+// that has nothing to do with the streams concerned (rs_stream_open).  So wherever it is collected, every open stream of the pool is
+// poisoned with its message first (the streams used to carry on with missing rows behind a stale event).
+void Model::IssuerSync(StreamPool *p) {
+  try {
+    p->issuer.Drain();
+  } catch (const std::exception &e) {
+    StreamsPoisonAll(e.what());
+    throw;
+  } catch (...) {
+    StreamsPoisonAll("an advance's deferred work failed");
+    throw;
+  }
+}
+
 void Model::StreamsDrain(StreamPool *p, float *extra) {
-  p->issuer.Drain();
+  IssuerSync(p);
   for (int k = 0; k < StreamPool::kDepth; k++) {
     const int par = (int)((p->n_adv + k) % StreamPool::kDepth);      // the oldest advance first
     if (!p->pending[par]) continue;
@@ -338,7 +355,9 @@ void Model::StreamOpen(rs_stream *st) {
   std::lock_guard<std::mutex> lk(pool_mu_);
   StreamPool *p = Pool();
   RS_HIP(hipSetDevice(opts_.device_id));
-  p->issuer.Drain();             // (this call queues on qi / qc itself)
+  // (this call queues on qi / qc itself.  A failure of an earlier advance's deferred work belongs to the streams that are open, not to
+  // the one being opened: they are poisoned with its message and refuse their next call; the open goes ahead on the drained pool)
+  try { IssuerSync(p); } catch (...) {}
   if (p->free_slots.empty()) Fail("too many live streams on this model (RS_STREAM_SLOTS=" + std::to_string(p->max_slots) + ")");
   const int want = RoundUp(std::max(EnvInt("RS_STREAM_INIT_FRAMES", 4096), 2 * p->chunk), p->chunk);
   const int row0 = p->AllocRows(want);
@@ -374,14 +393,17 @@ void Model::StreamClose(rs_stream *st) {
 // A failure that cannot be pinned on one advance's streams -- a device error that surfaced at a wait, up to three advances
 // after the one that caused it; a layer GEMM that left its range in any of the advances in flight: no stream of the pool can
 // trust its rows.  Everything queued is waited for, every set is free again, every open stream refuses further calls.
-void Model::StreamsPoisonAll() {
+void Model::StreamsPoisonAll(const std::string &why) {
   StreamPool *p = pool_.get();
   if (!p) return;
   p->issuer.Drain(false);
   (void)hipStreamSynchronize(p->qa); (void)hipStreamSynchronize(p->qi); (void)hipStreamSynchronize(p->q); (void)hipStreamSynchronize(p->qc);
   (void)hipGetLastError();
   for (int k = 0; k < StreamPool::kDepth; k++) p->pending[k] = false;
-  for (rs_stream *st : p->open_streams) st->failed = true;
+  for (rs_stream *st : p->open_streams) {
+    if (!st->failed && !why.empty()) st->fail_why = why;
+    st->failed = true;
+  }
 }
 
 // A stream outgrew its row range: move it to a range twice as long (device-to-device copies on the pool's stream).
@@ -444,10 +466,10 @@ void Model::StreamsAdvanceLocked(rs_stream *const *streams, int n, bool final, i
   const int par = (int)(p->n_adv % StreamPool::kDepth);
   DeviceArena &arena = cx.arena[par];
   HostArena &harena = cx.host_arena[par];
-  if (final) p->issuer.Drain();      // a finishing call issues everything itself, behind what the issuing thread still holds
+  if (final) IssuerSync(p);      // a finishing call issues everything itself, behind what the issuing thread still holds
   if (p->pending[par]) {       // the advance kDepth calls ago used this set: it has to be over (it normally is)
     const auto w0 = std::chrono::steady_clock::now();
-    p->issuer.Drain();         // (its done event has been recorded)
+    IssuerSync(p);         // (its done event has been recorded)
     RS_HIP(hipEventSynchronize(p->ev_done[par]));
     p->stage_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
     p->pending[par] = false;

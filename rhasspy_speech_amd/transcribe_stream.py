@@ -54,6 +54,11 @@ class KaldiNnet3StreamTranscriber:
             self._words = read_words_txt(self.graph_dir / "words.txt")
         return self._model
 
+    @staticmethod
+    def _accept_and_advance(stream, chunk) -> None:
+        stream.accept(chunk)
+        stream.advance()
+
     async def async_transcribe(
         self,
         audio_stream: AsyncIterable[Optional[bytes]],
@@ -64,15 +69,16 @@ class KaldiNnet3StreamTranscriber:
     ) -> List[str]:
         lang_dir = Path(lang_dir)
         stream = _lib.Stream(self._ensure_loaded())
+        loop = asyncio.get_running_loop()
         try:
             async for chunk in audio_stream:
                 if chunk:
-                    # the reference writes the chunk to the decoder's stdin (transcribe_stream.py:73-76), which decodes as it reads;
-                    # here: hand the samples over and let the device do what they make possible (MFCC, iVector, nnet chunks, search)
-                    stream.accept(chunk)
-                    stream.advance()
+                    # the reference writes the chunk to the decoder's stdin and awaits the drain (transcribe_stream.py:73-76) while the
+                    # decoder decodes as it reads; here: hand the samples over and let the device do what they make possible (MFCC,
+                    # iVector, nnet chunks, search) -- in the executor, so the event loop is not held while the library plans and
+                    # issues the advance (the calls release the GIL)
+                    await loop.run_in_executor(None, self._accept_and_advance, stream, chunk)
             _LOGGER.debug("Stream ended")
-            loop = asyncio.get_running_loop()
             try:
                 res = await loop.run_in_executor(None, stream.finish, nbest, self.acoustic_scale)
                 nbest_stdout = res.text(0, "utt")
@@ -118,12 +124,11 @@ class KaldiNnet3StreamTranscriber:
                     raise ValueError("No value for disambiguation state (#0)") from e       # transcribe_stream.py:150-151
                 raise
         stream = _lib.Stream(self._lat_model)
+        loop = asyncio.get_running_loop()
         try:
             async for chunk in audio_stream:
                 if chunk:
-                    stream.accept(chunk)
-                    stream.advance()
-            loop = asyncio.get_running_loop()
+                    await loop.run_in_executor(None, self._accept_and_advance, stream, chunk)
             try:
                 res = await loop.run_in_executor(None, stream.finish, 1, 1.0)
                 nbest_stdout = self._rescorers[key].rescore(res, 0, nbest=nbest, acoustic_scale=self.acoustic_scale, key="utt")[0]

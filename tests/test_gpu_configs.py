@@ -822,7 +822,7 @@ def test_config5_tdnnf_full_size_vs_reference(zam_tdnnf, monkeypatch):
         np.testing.assert_array_equal(exact.matrix(u, 2), plain_exact.matrix(u, 2))
     moved = max(float(np.abs(res.matrix(u, 2) - plain.matrix(u, 2)).max()) for u in range(len(pcms)))
     print(f"c5_tdnnf: residual through the operand image against the FP32 residual: max |diff| {moved:.2e}")
-    assert 0 < moved < 3e-5
+    assert 0 < moved < 6e-5
     for a_model, b_model in ((model, None), (f32res_model, plain_model)):
         sa = _lib.Stream(a_model)
         sa.accept(pcms[3])
