@@ -26,7 +26,8 @@ def reference_wav_argv(model_dir, graph_dir, wav, max_active=7000, lattice_beam=
 def test_command_line_of_the_reference_parses():
     from rhasspy_speech_amd import kaldi_cli
     opts, config, pos = kaldi_cli.parse_command_line(reference_wav_argv("/m", "/g", "/tmp/a.wav", 2500, 6.0, 13.0)[1:])
-    assert opts == dict(max_active=2500, lattice_beam=6.0, acoustic_scale=1.0, beam=13.0)
+    # (--online=false --do-endpointing=false on the command line override online.conf: rs_decode_opts.command_line_fixed = ONLINE | DO_ENDPOINTING)
+    assert opts == dict(max_active=2500, lattice_beam=6.0, acoustic_scale=1.0, beam=13.0, command_line_fixed=3)
     assert config == "/m/model/online/conf/online.conf"
     assert pos == ["/m/model/model/final.mdl", "/g/HCLG.fst", "ark:echo utt utt|", "scp:echo utt /tmp/a.wav|", "ark:-"]
     assert kaldi_cli.read_table("ark:echo utt utt|") == [("utt", "utt")]
