@@ -1178,6 +1178,7 @@ void Model::RunNnet(const std::vector<float *> &bufp, const std::vector<int> &bu
       if (const RowMaps::Entry *rm = row_maps.Find(ob.lext, ob.rext, ob.stride)) {     // only the rows somebody reads
         gd.row_map = rm->rows;
         gd.row_map_span128 = rm->span128;
+        gd.row_map_span160 = rm->span160;
         LaunchGemm(gd, rm->count, d_row_ivec, s);
         conv_map = rm->rows; conv_rows = rm->count;
       } else {
@@ -1717,7 +1718,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     // every utterance: layers nothing downstream reads with a time offset are evaluated on these rows only), and per hidden layer
     // only as much halo as the layers after it reach (15 rows a side for the first, none for the last of the zamia-like net:
     // 5 % fewer rows over the stack than evaluating the full halo everywhere)
-    struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; int stride = 1, first = 0; };
+    struct ListPlan { int lext, rext, n_segs, total, L_eff, slab_len, span128; size_t seg_at; int stride = 1, first = 0, span160 = 0; };
     std::vector<ListPlan> lists;
     std::vector<int> segs;      // the lists' segment offsets, back to back
     // The physical rows 128 consecutive entries of a stride-1 list reach over, exactly: the list is one run of consecutive rows per
@@ -1725,7 +1726,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     // that holds the last entry of run a and the first of run b crosses every gap between them, and it can do so when the runs in
     // between hold at most 126 entries.  An utterance without frames has no entries but still owns L + R rows (a too-short clip
     // inside a batch), so the gap between two runs is not bounded by one halo: GemmKernelB3J's strip form trusts this number.
-    auto span_of_runs = [&](int lext, int rext) {
+    auto span_of_runs = [&](int lext, int rext, int window = 128) {
       std::vector<std::pair<int, int>> runs;      // (first physical row, entries)
       for (int u = 0; u < n_utts; u++) if (T[u] > 0) runs.emplace_back(row_base[u] + L_ - lext, T[u] + lext + rext);
       int worst = 0;
@@ -1733,12 +1734,12 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       long inner = 0;                             // entries of the runs strictly between a and b
       for (size_t a = 0; a + 1 < runs.size(); a++) {
         if (b <= a) { b = a + 1; inner = 0; }
-        while (b + 1 < runs.size() && inner + runs[b].second <= 126) { inner += runs[b].second; b++; }
+        while (b + 1 < runs.size() && inner + runs[b].second <= window - 2) { inner += runs[b].second; b++; }
         const long gaps = (long)runs[b].first - (runs[a].first + runs[a].second) - inner;
         worst = std::max<long>(worst, gaps);
         if (b > a + 1) inner -= runs[a + 1].second;
       }
-      return 128 + worst;
+      return window + worst;
     };
     if (total_frames > 0) {
       ListPlan lp{0, 0, n_slabs * n_utts, total_frames, L_, slab_len, 0, segs.size()};
@@ -1751,6 +1752,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
       slab_off[n_slabs] = acc_rows;
       // (one slab: the list runs through the utterances in order, so a GEMM tile of 128 rows reaches over its rows + the halos it skips)
       lp.span128 = n_slabs == 1 ? span_of_runs(0, 0) : 0;
+      lp.span160 = n_slabs == 1 ? span_of_runs(0, 0, 160) : 0;
       lists.push_back(lp);
       static const int trim_env = [] { const char *e = TuneEnv("RS_TRIM_HALO"); return e ? std::atoi(e) : 1; }();
       // Trimmed halos are all or nothing: an op evaluated through its list leaves the other rows of its buffer as the arena held them, so
@@ -1797,6 +1799,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
         // 128 consecutive rows of the list cross at most (126 / shortest run) + 1 utterance boundaries, each skipping the halo rows
         // nobody reads: the physical rows a GEMM tile reaches over (a strided list: not bounded here, the strip form is not used)
         l2.span128 = st == 1 ? span_of_runs(ob.lext, ob.rext) : 0;
+        l2.span160 = st == 1 ? span_of_runs(ob.lext, ob.rext, 160) : 0;
         lists.push_back(l2);
       }
     }
@@ -1827,7 +1830,7 @@ void Model::DecodeGroup(DecodeContext &cx, int gi, const int16_t *d_pcm, const i
     for (auto &l : lists) {
       int *out = arena_.AllocT<int>(l.total);
       bs.lists[bs.n_lists++] = {l.n_segs, l.total, l.L_eff, l.slab_len, d_segs + l.seg_at, out, l.stride, l.first};
-      row_maps.maps.push_back({l.lext, l.rext, out, l.total, l.span128, l.stride});
+      row_maps.maps.push_back({l.lext, l.rext, out, l.total, l.span128, l.stride, l.span160});
       if (l.lext == 0 && l.rext == 0 && l.stride == 1) d_frame_rows = out;
     }
     LaunchBatchSetup(bs, s);

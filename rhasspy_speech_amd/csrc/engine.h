@@ -106,7 +106,7 @@ struct StreamPoolDeleter { void operator()(StreamPool *p) const; };
 struct RowMaps {
   // span128: the physical rows any 128 consecutive rows of the list reach over (GemmDev::row_map_span128), 0 = not known
   // stride: the list holds the rows t = 0 mod stride of [-lext, T + rext) (BufferInfo::stride)
-  struct Entry { int lext, rext; const int *rows; int count; int span128 = 0; int stride = 1; };
+  struct Entry { int lext, rext; const int *rows; int count; int span128 = 0; int stride = 1; int span160 = 0; };
   std::vector<Entry> maps;
   const Entry *Find(int lext, int rext, int stride = 1) const {
     for (auto &e : maps) if (e.lext == lext && e.rext == rext && e.stride == stride) return &e;

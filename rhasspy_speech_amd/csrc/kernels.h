@@ -174,6 +174,7 @@ struct GemmDev {
   const int *row_map;  // null, or rows entries: GEMM row i reads / writes physical row row_map[i] (e.g. only the real frames)
   int row_map_span128; // with a row map: an upper bound of row_map[i + 127] - row_map[i] + 1 over the list when the list is ascending (128 rows of
                        // a tile reach over that many physical rows: GemmKernelB3J stages them as one strip), 0 = not known
+  int row_map_span160; // the same for 160 consecutive rows of the list (the 160-row tile)
 };
 // f32 frame buffer (rows x ld, `dim` columns) -> operand image (nnet_gemm_b3i.hip); for producers without a fused image epilogue.
 // row_map (null: rows 0 .. rows - 1): the `rows` physical rows to convert -- the rows the producer wrote (a layer evaluated through a

@@ -46,13 +46,18 @@ namespace rs {
 namespace {
 using namespace b3;
 
-constexpr int kJMR = 4, kJColTiles = 8;                                 // 32-row blocks per wave; 32-column tiles per tile
+constexpr int kJColTiles = 8;                                           // 32-column tiles per tile
 constexpr int kJP = kB3Parts;
 constexpr int kJBBytes = kJColTiles * kJP * kB3FragBytes;               // 16 KiB: [column tile][part] fragments
-// WM wave rows of four waves each: WM = 2 -> 256-row tile, 512 threads, three stages (96 KiB, one workgroup per CU);
-// WM = 1 -> 128-row tile, 256 threads, three stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop)
-template <int WM> struct JShape {
-  static constexpr int kThreads = 256 * WM, kWaves = 4 * WM, kRowBlocks = 4 * WM;
+// WM wave rows of four waves each, MRT 32-row blocks per wave:
+//   WM = 2 -> 256-row tile, 512 threads, three stages (96 KiB, one workgroup per CU);
+//   WM = 1, MRT = 4 -> 128-row tile, 256 threads, three stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop);
+//   WM = 1, MRT = 5 (round 6) -> 160-row tile, 160 accumulator registers per wave.  A tile's k loop is bound by the DMA instructions that
+//     stage its WEIGHTS (16 KiB per k-step whatever the height: profiles/r04/b3j_notes.txt), so a launch costs about as many loop times as
+//     it has rounds of tiles, full-height or not; the headline's hidden layers have 76-84 k rows = 596-653 tiles of 128 rows = two rounds of
+//     the 512 slots, and 477-522 tiles of 160.  The launcher takes this shape where it saves a round (LaunchGemmB3J).
+template <int WM, int MRT = 4> struct JShape {
+  static constexpr int kThreads = 256 * WM, kWaves = 4 * WM, kRowBlocks = MRT * WM;
   static constexpr int kABytes = kRowBlocks * kJP * kB3FragBytes;         // [part][row block] fragments
   static constexpr int kStage = kABytes + kJBBytes;
 #ifndef RS_B3J_STAGES
@@ -63,7 +68,6 @@ template <int WM> struct JShape {
 #endif
   static constexpr int kStages = WM == 2 ? RS_B3J_STAGES_WM2 : RS_B3J_STAGES, kAhead = kStages - 1;
   static constexpr int kColTilesPerWave = kJColTiles / kWaves;             // weight column tiles a wave stages
-  static constexpr int kDmaPerKstep = kJP + kJP * kColTilesPerWave;        // per staging wave and k-step
 };
 
 // Timing ablations (results WRONG with a bit set): 512 = weight DMAs of different workgroups ask for different k-steps, 1024 = no weight DMA, 2048 = no activation DMA, 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
@@ -103,18 +107,22 @@ __device__ unsigned long long g_b3j_trace[8192 * 6];
 
 // SDIV: the small tiles of a MIXED launch are 1 / SDIV of the full height (2: the tail of a batch launch; 4: a launch of 32-row tiles
 // only -- a stream advance's few thousand rows, one tile's worth of time on four times the CUs)
-template <int WM, bool MIXED, bool STRIP, int SDIV = 2>
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4>
 __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   RS_TRACE(0);
   RS_TRACE_ID();
-  typedef JShape<WM> SH;
+  typedef JShape<WM, MRT> SH;
   static_assert(!STRIP || (WM == 1 && SH::kStages == 3), "the strip form: four waves, ring of three weight stages");
-  constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJAhead = SH::kAhead, kJThreads = SH::kThreads;
+  static_assert(MRT == 4 || (MRT == 5 && WM == 1 && SDIV == 2), "five row blocks per wave: the 160-row tile of four waves");
+  constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJAhead = SH::kAhead, kJThreads = SH::kThreads, kJWaves = SH::kWaves;
   // STRIP: a stage of the ring holds a k-step's weights only; behind the ring two strips (the 16-column group in use, the next one)
   constexpr int kJStage = STRIP ? kJBBytes : SH::kStage, kBOff = STRIP ? 0 : kJABytes;
-  constexpr int kStripRows = 192, kStripBytes = kJP * 2 * kStripRows * 16;
+  // the strip: the tile's rows + the 64 rows the offsets may span, staged 64 rows per instruction (the last one half masked when the
+  // count is not a multiple of 64)
+  constexpr int kStripRows = 32 * MRT + 64, kStripBytes = kJP * 2 * kStripRows * 16, kStripInstr = (kStripRows + 63) / 64;
   constexpr unsigned kStripBase = (unsigned)SH::kStages * kJBBytes;
-  constexpr int MR = kJMR, BM = 32 * kJRowBlocks, BN = kB3BN;
+  constexpr int MR = MRT, BM = 32 * kJRowBlocks, BN = kB3BN;
+  constexpr int kSmallBlocks = MR / SDIV, kSmallBM = 32 * WM * kSmallBlocks;      // a MIXED launch's small tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -146,10 +154,10 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       bid = first_blocks + (small ? b2 - big_left : b2);
     }
   }
-  const int mr_eff = small ? MR / SDIV : MR;                    // 32-row blocks per wave
+  const int mr_eff = small ? kSmallBlocks : MR;                  // 32-row blocks per wave
   const int xcd = bid & 7, local = bid >> 3;
   const int rt = (local / ncol) * 8 + xcd, ct = local % ncol;
-  const int row0 = small ? nbig * BM + rt * (BM / SDIV) : rt * BM, n0 = ct * BN;
+  const int row0 = small ? nbig * BM + rt * kSmallBM : rt * BM, n0 = ct * BN;
   if (small ? row0 >= rows : rt >= nbig) return;
   f32x16 acc[MR][2];
 #pragma unroll
@@ -160,11 +168,16 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // ---- staging: wave w copies activation row block w (three parts) and weight column tile w (three parts) of every k-step
-  const int nrb = small ? kJRowBlocks / SDIV : kJRowBlocks;
-  const bool stager = wave < nrb;
+  const int nrb = small ? kSmallBlocks * WM : kJRowBlocks;
+  // (wave w stages row block w and, where the tile has more blocks than the workgroup waves, block w + waves too)
+  const int n_my = __builtin_amdgcn_readfirstlane((wave < nrb ? 1 : 0) + (wave + kJWaves < nrb ? 1 : 0));
+  const bool stager = n_my > 0;
   int grow = row0 + wave * 32 + (lane & 31);
   if (grow >= rows) grow = 0;                          // clamped rows are dropped in the epilogue
   if (d.row_map) grow = d.row_map[grow];
+  int grow2 = row0 + (wave + kJWaves) * 32 + (lane & 31);
+  if (grow2 >= rows || kJRowBlocks <= kJWaves) grow2 = 0;
+  if (d.row_map && kJRowBlocks > kJWaves) grow2 = d.row_map[grow2];
   const int kg_off = (lane >> 5) * 512;
   const int sl_ = lane < d.nsegs ? (lane < kMaxSegs ? lane : 0) : 0;
   int seg_rowoff_v = lane < d.nsegs ? d.segs[sl_].row_off : 0;
@@ -185,13 +198,16 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   int seg_inks_v = lane < d.nsegs ? d.segs[sl_].img.nks : 0, seg_guard_v = lane < d.nsegs ? d.segs[sl_].img.guard : 0;
   // Everything loaded above is consumed here once, unconditionally: otherwise the compiler's wait-count analysis carries "load
   // pending" around the loop's back edge and drains vmcnt at the first use in EVERY iteration (seen in the ISA).
+  __asm__ volatile("" : "+v"(grow2));
   __asm__ volatile("" : "+v"(grow), "+v"(seg_rowoff_v), "+v"(seg_ks0_v), "+v"(seg_nks_v), "+v"(seg_base_lo), "+v"(seg_base_hi), "+v"(seg_part_lo),
                    "+v"(seg_part_hi), "+v"(seg_inks_v), "+v"(seg_guard_v));
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   // STRIP: this wave's share of a strip is (part wave >> 1, k-group wave & 1): three instructions of 64 rows.  Per-lane source
   // addresses for the segment's first k-step; strip row r = image row of (tile row 0 + smallest offset) + r, clamped to the image.
-  unsigned long long sp0 = 0, sp1 = 0, sp2 = 0;
-  int a_row[kJMR] = {0, 0, 0, 0};
+  unsigned long long sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0;
+  int a_row[MR];
+#pragma unroll
+  for (int i = 0; i < MR; i++) a_row[i] = 0;
   int sh1 = 0, sh2 = 0;                                  // byte shift of the second / third offset's fragments inside the strip
   if constexpr (STRIP) {
     const ActImage im = d.segs[0].img;
@@ -204,6 +220,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       return (unsigned long long)(uintptr_t)(b0 + (size_t)(phys >> 5) * im.nks * kB3FragBytes + (phys & 31) * 16);
     };
     sp0 = at(0); sp1 = at(1); sp2 = at(2);
+    if (kStripInstr > 3) sp3 = at(3);
 #pragma unroll
     for (int i = 0; i < MR; i++) {      // strip row (x 16 bytes) of this lane's row of row block i: rows of a tile are not consecutive under a row map
       const int gr = row0 + (wm * mr_eff + i) * 32 + (lane & 31);
@@ -213,6 +230,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     sh1 = __builtin_amdgcn_readfirstlane((d.segs[1].row_off - r0) * 16);
     sh2 = __builtin_amdgcn_readfirstlane((d.segs[2].row_off - r0) * 16);
     __asm__ volatile("" : "+v"(sp0), "+v"(sp1), "+v"(sp2), "+s"(sh1), "+s"(sh2), "+v"(a_row[0]), "+v"(a_row[1]), "+v"(a_row[2]), "+v"(a_row[3]));
+    if constexpr (MR > 4) __asm__ volatile("" : "+v"(sp3), "+v"(a_row[MR - 1]));
   }
   auto stage_strip = [&](int ks16, unsigned buf) __attribute__((always_inline)) {      // the strip of 16-column group ks16 into strip buffer buf
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + kStripBase + buf * kStripBytes + (unsigned)wave * (kStripRows * 16));
@@ -220,6 +238,9 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     RS_DMA16_STREAM(dst, reinterpret_cast<const unsigned char *>((uintptr_t)(sp0 + ko)));
     RS_DMA16_STREAM(dst + 1024u, reinterpret_cast<const unsigned char *>((uintptr_t)(sp1 + ko)));
     RS_DMA16_STREAM(dst + 2048u, reinterpret_cast<const unsigned char *>((uintptr_t)(sp2 + ko)));
+    if constexpr (kStripInstr > 3) {      // rows 192 .. of a taller strip; beyond its last row (a half instruction) the lanes are off
+      if (kStripRows % 64 == 0 || lane < kStripRows % 64) RS_DMA16_STREAM(dst + 3072u, reinterpret_cast<const unsigned char *>((uintptr_t)(sp3 + ko)));
+    }
   };
   constexpr int CTW = SH::kColTilesPerWave;
   const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(d.W3I) + (size_t)(n0 / 32 + wave * CTW) * kJP * kB3FragBytes + lane * 16;
@@ -239,6 +260,16 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       for (int p = 0; p < kJP; p++) {
         const unsigned char *g = src + p * part_bytes;
         RS_DMA16_STREAM(dst + (unsigned)((p * kJRowBlocks + wave) * kB3FragBytes), g);
+      }
+      if (kJRowBlocks > kJWaves && n_my == 2) {
+        const int phys2 = grow2 + __builtin_amdgcn_readlane(seg_rowoff_v, seg) + img_guard;
+        const unsigned char *src2 = img_base + ((size_t)(phys2 >> 5) * img_nks + (__builtin_amdgcn_readlane(seg_ks0_v, seg) + ks)) * kB3FragBytes +
+                                    kg_off + (phys2 & 31) * 16;
+#pragma unroll
+        for (int p = 0; p < kJP; p++) {
+          const unsigned char *g = src2 + p * part_bytes;
+          RS_DMA16_STREAM(dst + (unsigned)((p * kJRowBlocks + wave + kJWaves) * kB3FragBytes), g);
+        }
       }
     }
     if (!(RS_B3J_ABLATE & 1024)) {
@@ -269,7 +300,9 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   const unsigned b_lane = lds0 + kBOff + (unsigned)(wn * 2) * kJP * kB3FragBytes + lane * 16;    // + stage; + (j * parts + part) KiB
   auto step = [&](unsigned soff, unsigned a_off) __attribute__((always_inline)) {      // a_off (STRIP): strip buffer + the k-step's offset shift
     const unsigned aa = a_lane + (STRIP ? a_off : soff), ba = b_lane + soff;
-    const unsigned aa_i[kJMR] = {aa + (unsigned)a_row[0], aa + (unsigned)a_row[1], aa + (unsigned)a_row[2], aa + (unsigned)a_row[3]};      // (STRIP)
+    unsigned aa_i[MR];      // (STRIP)
+#pragma unroll
+    for (int i = 0; i < MR; i++) aa_i[i] = aa + (unsigned)a_row[i];
     f16x8 bf[2][kJP];
     RS_DS_READ(bf[0][0], ba, 0 * 1024); RS_DS_READ(bf[1][0], ba, 2 * 1024);
     f16x8 af[kJP][MR];
@@ -297,13 +330,25 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     RS_STEP(1, 0, 1, 1, 1, 2, 3)          // still in flight behind (1, 1): the weights' two low parts and (1, 2)
     RS_STEP(1, 1, 1, 2, 1, 3, 1)
     __asm__ volatile("" : "+v"(bf[0][1]), "+v"(bf[1][1]));          // (that wait covered them too)
-    RS_STEP(1, 2, 1, 3, 0, 0, 1)
-    RS_STEP(1, 3, 0, 0, 0, 1, 1)
-    RS_STEP(0, 0, 0, 1, 0, 2, 1)
-    RS_STEP(0, 1, 0, 2, 0, 3, 1)
-    RS_MFMAS(0, 2)
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][3]));
-    RS_MFMAS(0, 3)
+    if constexpr (MR == 4) {
+      RS_STEP(1, 2, 1, 3, 0, 0, 1)
+      RS_STEP(1, 3, 0, 0, 0, 1, 1)
+      RS_STEP(0, 0, 0, 1, 0, 2, 1)
+      RS_STEP(0, 1, 0, 2, 0, 3, 1)
+      RS_MFMAS(0, 2)
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][3]));
+      RS_MFMAS(0, 3)
+    } else {
+      RS_STEP(1, 2, 1, 3, 1, MR - 1, 1)
+      RS_STEP(1, 3, 1, MR - 1, 0, 0, 1)
+      RS_STEP(1, MR - 1, 0, 0, 0, 1, 1)
+      RS_STEP(0, 0, 0, 1, 0, 2, 1)
+      RS_STEP(0, 1, 0, 2, 0, 3, 1)
+      RS_STEP(0, 2, 0, 3, 0, MR - 1, 1)
+      RS_MFMAS(0, 3)
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][MR - 1]));
+      RS_MFMAS(0, MR - 1)
+    }
 #undef RS_STEP
 #undef RS_MFMAS
 #undef RS_A_READ
@@ -317,15 +362,15 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   if (kJAhead > 1 && nt > 1) stage_kstep((unsigned)kJStage);
   if (kJAhead > 2 && nt > 2) stage_kstep(2u * (unsigned)kJStage);
   int t = 0;
-  constexpr int kOwn = SH::kDmaPerKstep, kOther = kJP * CTW;           // DMAs per k-step of a wave that stages activations / of one that does not
+  constexpr int kOther = kJP * CTW, kOwn = kJP + kOther, kOwn2 = 2 * kJP + kOther;      // DMAs per k-step of a wave that stages no / one / two activation row blocks
 #define RS_VMWAIT(N) __asm__ volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
 // STRIP (three stages, DMA two k-steps ahead, the loop below unrolled by three so that stage S = position of the k-step in its
 // 16-column group): what a wave issues in k-step t is the weights of k-step t + 2 (kOther instructions) and, at position 1, the strip
 // of the next group (three more).  The wait of k-step t leaves what was issued in k-step t - 1 in flight: 4 + 3 at position 2.
 #define RS_WAIT_OWN(S)                                                                                         \
-  if (STRIP) { if (t + 1 < nt) { if ((S) == 2) RS_VMWAIT(kOther + 3); else RS_VMWAIT(kOther); } else RS_VMWAIT(0); }   \
-  else if (kJAhead > 2 && t + 2 < nt) { if (stager) RS_VMWAIT(kOwn * 2); else RS_VMWAIT(kOther * 2); }          \
-  else if (kJAhead > 1 && t + 1 < nt) { if (stager) RS_VMWAIT(kOwn); else RS_VMWAIT(kOther); }                   \
+  if (STRIP) { if (t + 1 < nt) { if ((S) == 2) RS_VMWAIT(kOther + kStripInstr); else RS_VMWAIT(kOther); } else RS_VMWAIT(0); }   \
+  else if (kJAhead > 2 && t + 2 < nt) { if (n_my == 2) RS_VMWAIT(kOwn2 * 2); else if (n_my == 1) RS_VMWAIT(kOwn * 2); else RS_VMWAIT(kOther * 2); }          \
+  else if (kJAhead > 1 && t + 1 < nt) { if (n_my == 2) RS_VMWAIT(kOwn2); else if (n_my == 1) RS_VMWAIT(kOwn); else RS_VMWAIT(kOther); }                   \
   else RS_VMWAIT(0);
 #define RS_B3J_KSTEP(S, S2)                                                                                    \
   {                                                                                                            \
@@ -433,7 +478,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       }
       const int rguard = d.res_img.guard - d.out_img.guard;      // (a folded residual read through its image: the same rows of that image)
       // (the block numbers are macro arguments: acc[] must never be indexed by a variable the compiler might not unroll)
-      float rm0 = 0.f, rm1 = 0.f, rm2 = 0.f, rm3 = 0.f;      // max |x| over what this lane splits of its row of row block 0 .. 3
+      float rm0 = 0.f, rm1 = 0.f, rm2 = 0.f, rm3 = 0.f, rm4 = 0.f;      // max |x| over what this lane splits of its row of row block 0 .. 4
 #define RS_DIRECT(I, J)                                                                                        \
       if (!MIXED || (I) < mr_eff) {                                                                              \
         const int cb = wn * 64 + (J) * 32;                                                                       \
@@ -474,6 +519,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       }
       RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
       RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
+      if constexpr (MR > 4) { RS_DIRECT(4, 0) RS_DIRECT(4, 1) }
 #undef RS_DIRECT
       if (over) d.ovf[0] = 1;
       {
@@ -481,6 +527,7 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
         atomicMax(&rmx[rb], __float_as_uint(rm0));
         if (mr_eff > 1) atomicMax(&rmx[rb + 32], __float_as_uint(rm1));
         if (mr_eff > 2) { atomicMax(&rmx[rb + 64], __float_as_uint(rm2)); atomicMax(&rmx[rb + 96], __float_as_uint(rm3)); }
+        if (MR > 4 && mr_eff > 4) atomicMax(&rmx[rb + 128], __float_as_uint(rm4));
         dd::LdsBarrier();
         if (tid < BM && B3Under(__uint_as_float(rmx[tid]))) d.ovf[1] = 1;
       }
@@ -521,8 +568,8 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     // (the slab number is a macro argument: acc[] must never be indexed by a loop variable the compiler might not unroll -- that put
     // the accumulators in scratch -- and a lambda capturing `d` makes the compiler copy the 1.2 KB argument block to scratch)
 #define RS_SLAB(SL)                                                                                            \
-    if (!(MIXED && small && (SL) >= WM * MR / SDIV)) {     /* workgroup-uniform: a half-height tile has half the slabs */ \
-      if (MIXED && small) { if (wm == (SL) / (MR / SDIV)) { RS_PUT_SLAB(acc[(SL) % (MR / SDIV)]) } } \
+    if (!(MIXED && small && (SL) >= WM * kSmallBlocks)) {     /* workgroup-uniform: a half-height tile has half the slabs */ \
+      if (MIXED && small) { if (wm == (SL) / kSmallBlocks) { RS_PUT_SLAB(acc[(SL) % kSmallBlocks]) } } \
       else if (wm == (SL) / MR) { RS_PUT_SLAB(acc[(SL) % MR]) } \
       dd::LdsBarrier(); \
       if (d.res) {      /* a folded residual sum (LayerOp::res_buf): see nnet_b3_epilogue.inc */ \
@@ -599,7 +646,8 @@ _Pragma("unroll") \
       dd::LdsBarrier(); \
     }
     RS_SLAB(0) RS_SLAB(1) RS_SLAB(2) RS_SLAB(3)
-    if constexpr (WM == 2) { RS_SLAB(4) RS_SLAB(5) RS_SLAB(6) RS_SLAB(7) }
+    if constexpr (WM * MR > 4) { RS_SLAB(4) }
+    if constexpr (WM == 2) { RS_SLAB(5) RS_SLAB(6) RS_SLAB(7) }
 #undef RS_SLAB
 #undef RS_PUT_SLAB
 #undef RS_EPI4
@@ -608,28 +656,29 @@ _Pragma("unroll") \
   }
 }
 
-template <int WM, bool MIXED, bool STRIP, int SDIV = 2>
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
-  typedef JShape<WM> SH;
-  constexpr int BM = 32 * SH::kRowBlocks;
-  constexpr size_t ring = (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
+  typedef JShape<WM, MRT> SH;
+  constexpr int BM = 32 * SH::kRowBlocks, kSmallBM = 32 * WM * (MRT / SDIV);
+  // (STRIP: the ring holds weights only, two strips of 32 MRT + 64 rows x 16 columns x two parts behind it)
+  constexpr size_t ring = STRIP ? (size_t)SH::kStages * kJBBytes + 2 * (size_t)(kJP * 2 * (32 * MRT + 64) * 16) : (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
   constexpr size_t smem0 = ring > ctile ? ring : ctile;
   // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
   static const bool one_per_cu = [] { const char *e = TuneEnv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
   const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP, SDIV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
     attr_set = true;
   }
   const int ncol = (d.n + kB3BN - 1) / kB3BN;
-  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + BM / SDIV - 1) / (BM / SDIV) : 0;
+  const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + kSmallBM - 1) / kSmallBM : 0;
   // the half-height tiles are numbered through both of their block ranges: the first range holds a multiple of 8 of them
   const bool alt = nfirst < 0;
   nfirst = MIXED ? std::min(std::abs(nfirst) / 8 * 8, nsmall / 8 * 8) : 0;
   if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP, SDIV>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 #ifdef RS_B3J_TRACE
   static int traced = 0;
   const char *tf = TuneEnv("RS_B3J_TRACE_FILE");
@@ -652,11 +701,12 @@ void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) 
 // no more than 64 rows apart (a TDNN layer's splice); with a row map (layers evaluated on the rows somebody reads) only when the tile's
 // rows, skipped halo rows included, still fit the strip.  RS_GEMM_B3J_STRIP=0 (tests, profiles: read per call)
 // keeps the one-fragment-set-per-offset form.
-bool JStripOk(const GemmDev &d) {
+bool JStripOk(const GemmDev &d, int tile_rows = 128) {
   const char *e = TuneEnv("RS_GEMM_B3J_STRIP");
   if (e && std::atoi(e) == 0) return false;
   if (!d.interleave || d.nsegs != 3) return false;
-  if (d.row_map && (d.row_map_span128 <= 0 || d.row_map_span128 + (d.segs[2].row_off - d.segs[0].row_off) > 192)) return false;
+  const int span = tile_rows == 128 ? d.row_map_span128 : d.row_map_span160;      // physical rows the tile's list rows reach over
+  if (d.row_map && (span <= 0 || span + (d.segs[2].row_off - d.segs[0].row_off) > tile_rows + 64)) return false;
   const GemmSegDev &a = d.segs[0];
   if (!a.img.base || a.per_utt) return false;
   for (int i = 1; i < 3; i++) {
@@ -722,6 +772,26 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   static const int stagger = [] { const char *e = TuneEnv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
   int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
   if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
+  // The 160-row tile (five row blocks per wave) where it saves a round of tiles: a tile's k loop is as long as staging its weights
+  // takes, whatever its height, so the launch costs one loop time per round -- the half-height tiles of the last, partly filled round
+  // included -- and a 160-row tile's loop is measured about 1.18 times a 128-row tile's (more activation DMAs and MFMAs beside the
+  // same weight DMAs).  RS_GEMM_B3J_MR=4|5 forces a height (tests: same bits either way).
+  if (wm == 1) {
+    const char *em = std::getenv("RS_GEMM_B3J_MR");
+    const int force = em ? std::atoi(em) : 0;
+    static const double cost5 = [] { const char *e = TuneEnv("RS_GEMM_B3J_MR5_COST"); return e ? std::atof(e) : 1.18; }();
+    const long rounds4 = ((long)((rows + 127) / 128) * ncol + slots - 1) / slots, rounds5 = ((long)((rows + 159) / 160) * ncol + slots - 1) / slots;
+    if (force == 5 || (force != 4 && (double)rounds5 * cost5 < (double)rounds4)) {
+      const long tiles5 = rows / 160;
+      const long full5 = tiles5 * ncol / slots * slots / ncol;
+      const bool all5 = full5 * 160 >= rows || rounds5 == ((long)((rows + 159) / 160) * ncol + slots - 1) / slots;      // (the last round's tiles full-height too: same loop time)
+      const int nbig5 = (rows + 159) / 160;
+      (void)full5; (void)all5;
+      if (JStripOk(d, 160)) LaunchB3J<1, false, true, 2, 5>(d, rows, nbig5, 0, s);
+      else LaunchB3J<1, false, false, 2, 5>(d, rows, nbig5, 0, s);
+      return;
+    }
+  }
   if (wm == 2) { if (all_big) LaunchB3J<2, false, false>(d, rows, nbig, 0, s); else LaunchB3J<2, true, false>(d, rows, nbig, nfirst, s); }
   else if (JStripOk(d)) { if (all_big) LaunchB3J<1, false, true>(d, rows, nbig, 0, s); else LaunchB3J<1, true, true>(d, rows, nbig, nfirst, s); }
   else { if (all_big) LaunchB3J<1, false, false>(d, rows, nbig, 0, s); else LaunchB3J<1, true, false>(d, rows, nbig, nfirst, s); }

@@ -32,6 +32,11 @@ def zam_arpa(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
+def zam_tdnnf(tmp_path_factory):
+    return configs.build_tdnnf_model(tmp_path_factory.mktemp("zam_tdnnf"))
+
+
+@pytest.fixture(scope="module")
 def zam_grammar(tmp_path_factory):
     return configs.build_grammar_model(tmp_path_factory.mktemp("zam_grammar"))
 
@@ -568,6 +573,35 @@ def test_all_dma_gemm_is_bitwise_the_image_gemm(zam_grammar, monkeypatch):
                 assert got.words(u) == ref.words(u) and got.costs(u) == ref.costs(u)
 
 
+def test_160_row_tiles_are_bitwise_the_128_row_ones(zam_grammar, zam_tdnnf, monkeypatch):
+    """GemmKernelB3J with five row blocks per wave (round 6: where a 160-row tile saves a round of tiles) against the 128-row shape:
+    same MFMAs in the same k order per output element -> equal bit for bit.  RS_GEMM_B3J_MR forces either height.  Ragged batch
+    with runs of too-short clips (the strip form's span bound for 160 list rows), the pruned and the full output layer (two / eight
+    column tiles), and the factorised model (residual read through the image in the register epilogue of row block 4; the narrow
+    bottleneck layers)."""
+    from rhasspy_speech_amd import _lib, synth
+    pcms = [synth.synth_utterance(34000 + u, 48000 - 640 * (u % 7)) for u in range(140)]
+    for k in (5, 6, 60, 61, 62):
+        pcms.insert(k, np.zeros(120, np.int16))
+    for dirs, opts in ((zam_grammar, dict(keep_intermediates=1)), (zam_grammar, dict()), (zam_tdnnf, dict(keep_intermediates=1))):
+        model = _lib.Model(*dirs, _lib.default_opts(**opts))
+        some = pcms if dirs is zam_grammar else pcms[:80]
+        out = {}
+        for mr in ("4", "5"):
+            monkeypatch.setenv("RS_GEMM_B3J_MR", mr)
+            out[mr] = model.decode_batch(some)
+        monkeypatch.delenv("RS_GEMM_B3J_MR")
+        auto = model.decode_batch(some)
+        for u in range(len(some)):
+            if out["4"].num_frames(u) == 0:
+                continue
+            if opts:
+                np.testing.assert_array_equal(out["5"].matrix(u, 2), out["4"].matrix(u, 2))
+                np.testing.assert_array_equal(auto.matrix(u, 2), out["4"].matrix(u, 2))
+            assert out["5"].words(u) == out["4"].words(u) == auto.words(u) and out["5"].costs(u) == out["4"].costs(u) == auto.costs(u)
+        assert "range_retries=0 precision_retries=0" in model.describe()
+
+
 def test_small_launches_on_the_all_dma_gemm_are_bitwise_the_image_gemm(zam_grammar, monkeypatch):
     """A launch of less than one round of tiles (a few utterances; a stream advance) runs GemmKernelB3J with 32-row tiles (round 5;
     GemmKernelB3I<1> before, RS_GEMM_B3J_SMALL=0): same MFMAs, same order -> equal bit for bit, batch and incremental stream."""
@@ -767,11 +801,6 @@ def test_overlapped_contexts_use_the_cu_exclusive_gemm(zam_grammar, monkeypatch)
 
 # ---- the full-size factorised TDNN (round 6; tests/configs.py: TDNNF_SPEC).  Goldens: the reference's binaries, one process per
 # utterance (c5_tdnnf.npz: 5-best lists and costs; c5_tdnnf_inter.npz: rs-dump's iVectors and log-likelihood samples).
-@pytest.fixture(scope="module")
-def zam_tdnnf(tmp_path_factory):
-    return configs.build_tdnnf_model(tmp_path_factory.mktemp("zam_tdnnf"))
-
-
 def test_config5_tdnnf_full_size_vs_reference(zam_tdnnf, monkeypatch):
     """TdnnComponent + linear bottlenecks 1024 / 128 with Sum(Scale(0.66, .), .) residuals, 2 000 pdfs: every transcript, 5-best list
     and cost of the reference; iVectors and sampled log-likelihoods within 1e-4 -- on the split-fp16 layer GEMMs (the bottleneck
