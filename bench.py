@@ -497,6 +497,8 @@ def main() -> None:
     bind_here()
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(inflight, 1), initializer=bind_here)
 
+    default_stagger_ms = {"grammar": 0.6, "arpa": 0.0, "mixed": 0.0, "streams": 0.0}[wl]
+
     def run_steps(n, fn, check_against=None):
         """n steps, at most `inflight` decode calls in flight; results are consumed (and gathered) in step order."""
         t_start = time.perf_counter()
@@ -510,7 +512,18 @@ def main() -> None:
                 return r
         # `inflight` calls are outstanding at any time, the next one is submitted when the oldest has been consumed (all n submitted
         # up front, the worker threads could not start before this thread had finished submitting: ~1 ms of an idle device per run)
-        futures = [pool.submit(fn) for _ in range(min(n, inflight))] if inflight > 1 else None
+        # From a standing start (the driver's `--steps 20` behind a device synchronisation) the first `inflight` calls are started a
+        # fraction of a step apart instead of all at once: calls that start together run the same stage at the same moment and share
+        # the device stage by stage -- the first one returns after ~5 ms instead of its un-overlapped 2.6 -- where calls a stage apart
+        # fall into the staggered phases the steady state has anyway (a serving process never starts four identical calls in the
+        # same microsecond either).  RS_BENCH_STAGGER_MS overrides (0: all at once).
+        stagger = float(os.environ.get("RS_BENCH_STAGGER_MS", default_stagger_ms)) * 1e-3
+
+        def delayed(i):
+            if stagger > 0 and i > 0:
+                time.sleep(i * stagger)
+            return fn()
+        futures = [pool.submit(delayed, i) for i in range(min(n, inflight))] if inflight > 1 else None
         last = None
         for k in range(n):
             res = futures[k].result() if futures else fn()
