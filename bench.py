@@ -116,6 +116,15 @@ def other_workloads(timeout_s: float = 240.0):
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max), None when unlimited / unknown."""
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, seconds_budget: float = 20.0):
     """Times the REFERENCE itself (oracle/_ref Kaldi binaries built from /root/reference by oracle/build_ref.sh) on this
     box's host cores on a bounded sample of the same workload: the pipeline of transcribe_wav.py:45-75 (or, for streams,
@@ -170,6 +179,11 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, second
                 # (every logical CPU of the box, whatever this process's threads are bound to: the children get the full affinity mask.
                 # Until round 5 this was capped at 64 workers on boxes with 128+ CPUs per socket.)
                 n_workers = max(1, os.cpu_count() or 1)
+                # ... unless the container's CPU-time quota is smaller (cgroup v2 cpu.max: on the round-6 boxes 16 CPUs' worth of time on a
+                # 256-thread host: 256 workers were throttled to the rate of 16, 692 audio-s/s against 705 with 64 workers)
+                quota = cpu_quota()
+                if quota is not None:
+                    n_workers = max(1, min(n_workers, int(quota + 0.5)))
 
                 def all_cpus():
                     try:
@@ -182,7 +196,7 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, second
                 wall_all = time.perf_counter() - t2
                 if all(p.returncode == 0 for p in procs) and all(len(o.decode().splitlines()) == n_tab for o in outs):
                     all_cores = {"value": n_workers * tab_audio / wall_all, "unit": "audio-seconds/s", "cores": n_workers,
-                                 "sample": f"{n_workers} single-load pipelines side by side, {n_tab} utterances each"}
+                                 "sample": f"{n_workers} single-load pipelines side by side, {n_tab} utterances each (workers = min(logical CPUs, cgroup CPU quota))"}
     cpu_model = "unknown"
     try:
         for line in subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().splitlines():
@@ -190,7 +204,7 @@ def cpu_baseline(model_dir: Path, graph_dir: Path, pcms, streaming: bool, second
                 cpu_model = line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model, "host_cpus": os.cpu_count(),
+    return {"value": audio / wall, "unit": "audio-seconds/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "cgroup_cpu_quota": cpu_quota(),
             "sample": f"{n_done} of the {len(pcms)} utterances, one reference pipeline per utterance "
                       f"({'online2-cli-nnet3-decode-faster on stdin' if streaming else 'transcribe_wav.py-style 3-process pipeline'}; model + HCLG "
                       f"re-loaded every call, as the reference does)",
