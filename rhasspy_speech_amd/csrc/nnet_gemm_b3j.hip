@@ -772,21 +772,19 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   static const int stagger = [] { const char *e = TuneEnv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
   int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
   if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
-  // The 160-row tile (five row blocks per wave) where it saves a round of tiles: a tile's k loop is as long as staging its weights
-  // takes, whatever its height, so the launch costs one loop time per round -- the half-height tiles of the last, partly filled round
-  // included -- and a 160-row tile's loop is measured about 1.18 times a 128-row tile's (more activation DMAs and MFMAs beside the
-  // same weight DMAs).  RS_GEMM_B3J_MR=4|5 forces a height (tests: same bits either way).
+  // The 160-row tile (five row blocks per wave) where it turns a launch of two rounds of tiles into ONE: a tile's k loop is as long as
+  // staging its weights takes, whatever its height, so a long-K launch costs about one loop time per round -- the half-height tiles of
+  // the last, partly filled round included.  Measured (profiles/r06/notes_experiments.txt): hidden layers (K = 750) 101 -> 90 us; no gain
+  // where K is short (the pre-final and output layers, K = 250: the tile's time is its epilogue, which grows with its rows) or where
+  // the taller tiles still need several rounds.  RS_GEMM_B3J_MR=4|5 forces a height (tests: same bits either way).
   if (wm == 1) {
     const char *em = std::getenv("RS_GEMM_B3J_MR");
     const int force = em ? std::atoi(em) : 0;
-    static const double cost5 = [] { const char *e = TuneEnv("RS_GEMM_B3J_MR5_COST"); return e ? std::atof(e) : 1.18; }();
+    int ksteps = 0;
+    for (int i = 0; i < d.nsegs; i++) ksteps += (d.segs[i].ncols + kB3KS - 1) / kB3KS;
     const long rounds4 = ((long)((rows + 127) / 128) * ncol + slots - 1) / slots, rounds5 = ((long)((rows + 159) / 160) * ncol + slots - 1) / slots;
-    if (force == 5 || (force != 4 && (double)rounds5 * cost5 < (double)rounds4)) {
-      const long tiles5 = rows / 160;
-      const long full5 = tiles5 * ncol / slots * slots / ncol;
-      const bool all5 = full5 * 160 >= rows || rounds5 == ((long)((rows + 159) / 160) * ncol + slots - 1) / slots;      // (the last round's tiles full-height too: same loop time)
+    if (force == 5 || (force != 4 && rounds5 == 1 && rounds4 > 1 && ksteps >= 32)) {
       const int nbig5 = (rows + 159) / 160;
-      (void)full5; (void)all5;
       if (JStripOk(d, 160)) LaunchB3J<1, false, true, 2, 5>(d, rows, nbig5, 0, s);
       else LaunchB3J<1, false, false, 2, 5>(d, rows, nbig5, 0, s);
       return;
