@@ -46,9 +46,7 @@ namespace rs {
 namespace {
 using namespace b3;
 
-constexpr int kJColTiles = 8;                                           // 32-column tiles per tile
 constexpr int kJP = kB3Parts;
-constexpr int kJBBytes = kJColTiles * kJP * kB3FragBytes;               // 16 KiB: [column tile][part] fragments
 // WM wave rows of four waves each, MRT 32-row blocks per wave:
 //   WM = 2 -> 256-row tile, 512 threads, three stages (96 KiB, one workgroup per CU);
 //   WM = 1, MRT = 4 -> 128-row tile, 256 threads, three stages (72 KiB, two workgroups per CU: one's epilogue hides behind the other's loop);
@@ -56,10 +54,15 @@ constexpr int kJBBytes = kJColTiles * kJP * kB3FragBytes;               // 16 Ki
 //     stage its WEIGHTS (16 KiB per k-step whatever the height: profiles/r04/b3j_notes.txt), so a launch costs about as many loop times as
 //     it has rounds of tiles, full-height or not; the headline's hidden layers have 76-84 k rows = 596-653 tiles of 128 rows = two rounds of
 //     the 512 slots, and 477-522 tiles of 160.  The launcher takes this shape where it saves a round (LaunchGemmB3J).
-template <int WM, int MRT = 4> struct JShape {
-  static constexpr int kThreads = 256 * WM, kWaves = 4 * WM, kRowBlocks = MRT * WM;
+//   WM = 2, WN = 2 (round 6, "narrow"): 256 x 128 tile of four waves, two wave rows x two wave columns, for layers of at most 128 columns
+//     (a factorised TDNN's bottlenecks): the same 24 KiB and 24 MFMAs per wave and k-step as the 128 x 256 tile, all of them useful --
+//     on the 256-column shapes half of such a layer's weight stream and MFMAs are padding.
+template <int WM, int MRT = 4, int WN = 4> struct JShape {
+  static constexpr int kThreads = 64 * WM * WN, kWaves = WM * WN, kRowBlocks = MRT * WM;
+  static constexpr int kColTiles = 2 * WN;                                  // 32-column tiles per tile
+  static constexpr int kBBytes = kColTiles * kJP * kB3FragBytes;            // 16 KiB (8 narrow): [column tile][part] fragments
   static constexpr int kABytes = kRowBlocks * kJP * kB3FragBytes;         // [part][row block] fragments
-  static constexpr int kStage = kABytes + kJBBytes;
+  static constexpr int kStage = kABytes + kBBytes;
 #ifndef RS_B3J_STAGES
 #define RS_B3J_STAGES 3
 #endif
@@ -67,7 +70,7 @@ template <int WM, int MRT = 4> struct JShape {
 #define RS_B3J_STAGES_WM2 4
 #endif
   static constexpr int kStages = WM == 2 ? RS_B3J_STAGES_WM2 : RS_B3J_STAGES, kAhead = kStages - 1;
-  static constexpr int kColTilesPerWave = kJColTiles / kWaves;             // weight column tiles a wave stages
+  static constexpr int kColTilesPerWave = kColTiles / kWaves;              // weight column tiles a wave stages
 };
 
 // Timing ablations (results WRONG with a bit set): 512 = weight DMAs of different workgroups ask for different k-steps, 1024 = no weight DMA, 2048 = no activation DMA, 4 = no MFMAs, 8 = no DMA, 16 = no per-k-step barrier, 64 = no epilogue, 128 = epilogue without its image stores, 256 = image stores folded into a 1 MB window (no HBM write stream)
@@ -107,12 +110,14 @@ __device__ unsigned long long g_b3j_trace[8192 * 6];
 
 // SDIV: the small tiles of a MIXED launch are 1 / SDIV of the full height (2: the tail of a batch launch; 4: a launch of 32-row tiles
 // only -- a stream advance's few thousand rows, one tile's worth of time on four times the CUs)
-template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4>
-__global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4, int WN = 4>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void GemmKernelB3J(GemmDev d, int rows, int nbig, int nfirst, int epi_mode) {
   RS_TRACE(0);
   RS_TRACE_ID();
-  typedef JShape<WM, MRT> SH;
-  static_assert(!STRIP || (WM == 1 && SH::kStages == 3), "the strip form: four waves, ring of three weight stages");
+  typedef JShape<WM, MRT, WN> SH;
+  constexpr int kJBBytes = SH::kBBytes;
+  static_assert(!STRIP || (WM == 1 && WN == 4 && SH::kStages == 3), "the strip form: four waves side by side, ring of three weight stages");
+  static_assert(WN == 4 || (WN == 2 && WM == 2 && MRT == 4), "the narrow shape: two wave rows x two wave columns");
   static_assert(MRT == 4 || (MRT == 5 && WM == 1 && SDIV == 2), "five row blocks per wave: the 160-row tile of four waves");
   constexpr int kJRowBlocks = SH::kRowBlocks, kJABytes = SH::kABytes, kJAhead = SH::kAhead, kJThreads = SH::kThreads, kJWaves = SH::kWaves;
   // STRIP: a stage of the ring holds a k-step's weights only; behind the ring two strips (the 16-column group in use, the next one)
@@ -121,11 +126,11 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
   // count is not a multiple of 64)
   constexpr int kStripRows = 32 * MRT + 64, kStripBytes = kJP * 2 * kStripRows * 16, kStripInstr = (kStripRows + 63) / 64;
   constexpr unsigned kStripBase = (unsigned)SH::kStages * kJBBytes;
-  constexpr int MR = MRT, BM = 32 * kJRowBlocks, BN = kB3BN;
+  constexpr int MR = MRT, BM = 32 * kJRowBlocks, BN = 64 * WN;
   constexpr int kSmallBlocks = MR / SDIV, kSmallBM = 32 * WM * kSmallBlocks;      // a MIXED launch's small tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int ncol = (d.n + BN - 1) / BN;
   // Block order: `nfirst` half-height tiles, then the full-height tiles, then the remaining half-height ones.  With all tiles of
   // a round the same height every workgroup reaches its epilogue at the same moment and the launch pays for a burst of output
@@ -554,14 +559,14 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
     // stores makes the compiler wait for vmcnt(0) -- which on this ISA also counts the stores in flight -- so every store used
     // to wait for the previous one to reach memory (seen in the ISA; profiles/r02/b3j_wm1_ablate.txt).
     int img_phys[WM * MR];                    // image path: a thread's units of a slab all sit on row tid & 31
-    int f32_phys[WM * MR][2048 / NT];         // FP32 path: unit q of a slab sits on row (tid >> 6) + (NT / 64) q
+    int f32_phys[WM * MR][8 * BN / NT];       // FP32 path: unit q of a slab (32 rows x BN / 4 float4s) sits on row (tid + NT q) / (BN / 4)
 #pragma unroll
     for (int sl = 0; sl < WM * MR; sl++) {
       const int row = row0 + sl * 32 + (tid & 31);
       img_phys[sl] = (d.out_img.base && row < rows) ? (d.row_map ? d.row_map[row] : row) + d.out_img.guard : 0;
 #pragma unroll
-      for (int q = 0; q < 2048 / NT; q++) {
-        const int r2 = row0 + sl * 32 + ((tid + NT * q) >> 6);
+      for (int q = 0; q < 8 * BN / NT; q++) {
+        const int r2 = row0 + sl * 32 + (tid + NT * q) / (BN / 4);
         f32_phys[sl][q] = ((d.write_f32 || d.res) && r2 < rows) ? (d.row_map ? d.row_map[r2] : r2) : 0;
       }
     }
@@ -574,8 +579,8 @@ __global__ __launch_bounds__(256 * WM, WM == 1 ? 2 : 1) void GemmKernelB3J(GemmD
       dd::LdsBarrier(); \
       if (d.res) {      /* a folded residual sum (LayerOp::res_buf): see nnet_b3_epilogue.inc */ \
 _Pragma("unroll") \
-        for (int q = 0; q < 2048 / NT; q++) { \
-          const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \
+        for (int q = 0; q < 8 * BN / NT; q++) { \
+          const int unit = tid + NT * q, rl = unit / (BN / 4), c4 = (unit % (BN / 4)) * 4; \
           const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
           if (row < rows && col < d.n) { \
             f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[rl * C_LD + c4]); \
@@ -604,8 +609,8 @@ _Pragma("unroll") \
         dd::LdsBarrier(); \
       } else if (vec_out && d.write_f32) { \
 _Pragma("unroll") \
-        for (int q = 0; q < 2048 / NT; q++) { \
-          const int unit = tid + NT * q, rl = unit >> 6, c4 = (unit & 63) * 4; \
+        for (int q = 0; q < 8 * BN / NT; q++) { \
+          const int unit = tid + NT * q, rl = unit / (BN / 4), c4 = (unit % (BN / 4)) * 4; \
           const int row = row0 + (SL) * 32 + rl, col = n0 + c4; \
           if (row < rows && col < d.n) \
             *reinterpret_cast<f32x4 *>(d.out + (size_t)f32_phys[(SL)][q] * d.ldo + col) = \
@@ -621,7 +626,7 @@ _Pragma("unroll") \
       if (d.out_img.base) { \
         float rm = 0.f; \
 _Pragma("unroll") \
-        for (int q = 0; q < 1024 / NT; q++) { \
+        for (int q = 0; q < 4 * BN / NT; q++) { \
           const int unit = tid + NT * q, rl = unit & 31, kg = (unit >> 5) & 1, ksi = unit >> 6; \
           const int row = row0 + (SL) * 32 + rl, col = n0 + ksi * 16 + kg * 8; \
           if (row < rows && (col >> 4) < d.out_img.nks) { \
@@ -656,29 +661,29 @@ _Pragma("unroll") \
   }
 }
 
-template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4>
+template <int WM, bool MIXED, bool STRIP, int SDIV = 2, int MRT = 4, int WN = 4>
 void LaunchB3J(const GemmDev &d, int rows, int nbig, int nfirst, hipStream_t s) {
-  typedef JShape<WM, MRT> SH;
-  constexpr int BM = 32 * SH::kRowBlocks, kSmallBM = 32 * WM * (MRT / SDIV);
+  typedef JShape<WM, MRT, WN> SH;
+  constexpr int BM = 32 * SH::kRowBlocks, kSmallBM = 32 * WM * (MRT / SDIV), BN = 64 * WN;
   // (STRIP: the ring holds weights only, two strips of 32 MRT + 64 rows x 16 columns x two parts behind it)
-  constexpr size_t ring = STRIP ? (size_t)SH::kStages * kJBBytes + 2 * (size_t)(kJP * 2 * (32 * MRT + 64) * 16) : (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
+  constexpr size_t ring = STRIP ? (size_t)SH::kStages * SH::kBBytes + 2 * (size_t)(kJP * 2 * (32 * MRT + 64) * 16) : (size_t)SH::kStages * SH::kStage, ctile = kB3EpiBytes;
   constexpr size_t smem0 = ring > ctile ? ring : ctile;
   // RS_GEMM_B3J_ONE_PER_CU=1 (measurement): ask for so much LDS that only one workgroup fits a CU
   static const bool one_per_cu = [] { const char *e = TuneEnv("RS_GEMM_B3J_ONE_PER_CU"); return e && std::atoi(e) != 0; }();
   const size_t smem = (one_per_cu && smem0 < 100 * 1024) ? 100 * 1024 : smem0;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(smem, 100 * 1024));
     attr_set = true;
   }
-  const int ncol = (d.n + kB3BN - 1) / kB3BN;
+  const int ncol = (d.n + BN - 1) / BN;
   const int rest = std::max(rows - nbig * BM, 0), nsmall = MIXED ? (rest + kSmallBM - 1) / kSmallBM : 0;
   // the half-height tiles are numbered through both of their block ranges: the first range holds a multiple of 8 of them
   const bool alt = nfirst < 0;
   nfirst = MIXED ? std::min(std::abs(nfirst) / 8 * 8, nsmall / 8 * 8) : 0;
   if (alt && nbig < nfirst) nfirst = 0;
   const int blocks = ((nbig + 7) / 8 * 8 + nfirst + (std::max(nsmall - nfirst, 0) + 7) / 8 * 8) * ncol;
-  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
+  hipLaunchKernelGGL((GemmKernelB3J<WM, MIXED, STRIP, SDIV, MRT, WN>), dim3(blocks), dim3(SH::kThreads), smem, s, d, rows, nbig, alt ? -nfirst : nfirst, GemmEpiMode(d, rows));
 #ifdef RS_B3J_TRACE
   static int traced = 0;
   const char *tf = TuneEnv("RS_B3J_TRACE_FILE");
@@ -787,6 +792,18 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
       const int nbig5 = (rows + 159) / 160;
       if (JStripOk(d, 160)) LaunchB3J<1, false, true, 2, 5>(d, rows, nbig5, 0, s);
       else LaunchB3J<1, false, false, 2, 5>(d, rows, nbig5, 0, s);
+      return;
+    }
+  }
+  // Layers of at most 128 columns: the 256 x 128 tile (two wave rows x two wave columns).  RS_GEMM_B3J_NARROW=0 (tests: same bits) keeps
+  // the 256-column shapes, half of whose weight stream and MFMAs are padding for such a layer.
+  if (wm == 1 && d.n <= 128) {
+    const char *en = std::getenv("RS_GEMM_B3J_NARROW");
+    if (!(en && std::atoi(en) == 0)) {
+      const long tiles_n = rows / 256, full_n = tiles_n / slots * slots;
+      const bool all_n = full_n * 256 >= rows || (rows + 255) / 256 <= slots;
+      if (all_n) LaunchB3J<2, false, false, 2, 4, 2>(d, rows, (rows + 255) / 256, 0, s);
+      else LaunchB3J<2, true, false, 2, 4, 2>(d, rows, (int)full_n, 0, s);
       return;
     }
   }

@@ -600,6 +600,20 @@ def test_160_row_tiles_are_bitwise_the_128_row_ones(zam_grammar, zam_tdnnf, monk
                 np.testing.assert_array_equal(auto.matrix(u, 2), out["4"].matrix(u, 2))
             assert out["5"].words(u) == out["4"].words(u) == auto.words(u) and out["5"].costs(u) == out["4"].costs(u) == auto.costs(u)
         assert "range_retries=0 precision_retries=0" in model.describe()
+        if dirs is zam_tdnnf:
+            # the bottleneck layers (128 columns) on the 256 x 128 tile of two wave rows x two wave columns (the default) against the
+            # 256-column shapes; also a batch large enough for more than one round of such tiles' slots (RS_GEMM_B3J_SLOTS)
+            monkeypatch.setenv("RS_GEMM_B3J_NARROW", "0")
+            wide = model.decode_batch(some)
+            monkeypatch.delenv("RS_GEMM_B3J_NARROW")
+            monkeypatch.setenv("RS_GEMM_B3J_SLOTS", "24")
+            few_slots = model.decode_batch(some)
+            monkeypatch.delenv("RS_GEMM_B3J_SLOTS")
+            for u in range(len(some)):
+                if auto.num_frames(u) == 0:
+                    continue
+                np.testing.assert_array_equal(auto.matrix(u, 2), wide.matrix(u, 2))
+                np.testing.assert_array_equal(auto.matrix(u, 2), few_slots.matrix(u, 2))
 
 
 def test_small_launches_on_the_all_dma_gemm_are_bitwise_the_image_gemm(zam_grammar, monkeypatch):
