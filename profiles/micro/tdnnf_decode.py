@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The headline batch (256 x 3 s) on the full-size factorised TDNN (tests/configs.py: TDNNF_SPEC), N un-overlapped calls: what
 `rocprofv3 --kernel-trace --stats` is pointed at for the per-kernel times of that model (profiles/r06/tdnnf_*).
-usage: tdnnf_decode.py [calls] [frame_subsampling_factor]"""
+usage: tdnnf_decode.py [calls] [frame_subsampling_factor] [utterances]"""
 import sys
 import tempfile
 import time
@@ -17,7 +17,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 fsf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 md, gd = configs.build_tdnnf_model(Path(tempfile.gettempdir()) / "rs_tdnnf_prof")
 model = _lib.Model(md, gd, _lib.default_opts(frame_subsampling_factor=fsf))
-pcms = configs.grammar_utterances()
+pcms = configs.grammar_utterances(int(sys.argv[3]) if len(sys.argv) > 3 else 256)
 model.decode_batch(pcms)
 t0 = time.perf_counter()
 st = np.zeros(8)

@@ -69,7 +69,7 @@ template <int WM, int MRT = 4, int WN = 4> struct JShape {
 #ifndef RS_B3J_STAGES_WM2
 #define RS_B3J_STAGES_WM2 4
 #endif
-  static constexpr int kStages = WM == 2 ? RS_B3J_STAGES_WM2 : RS_B3J_STAGES, kAhead = kStages - 1;
+  static constexpr int kStages = (WM == 2 && WN == 4) ? RS_B3J_STAGES_WM2 : RS_B3J_STAGES, kAhead = kStages - 1;      // (eight waves: one workgroup per CU, four stages)
   static constexpr int kColTilesPerWave = kColTiles / kWaves;              // weight column tiles a wave stages
 };
 
@@ -777,6 +777,18 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
   static const int stagger = [] { const char *e = TuneEnv("RS_GEMM_B3J_STAGGER"); return e ? std::atoi(e) : 1; }();
   int nfirst = stagger ? (int)(slots / 2) : 0;          // half-height tiles that go first (LaunchB3J clips it to what there is)
   if (stagger == 2 && nbig >= nfirst) nfirst = -nfirst;
+  // Layers of at most 128 columns: the 256 x 128 tile (two wave rows x two wave columns).  RS_GEMM_B3J_NARROW=0 (tests: same bits) keeps
+  // the 256-column shapes, half of whose weight stream and MFMAs are padding for such a layer.
+  if (wm == 1 && d.n <= 128) {
+    const char *en = std::getenv("RS_GEMM_B3J_NARROW");
+    if (!(en && std::atoi(en) == 0)) {
+      const long tiles_n = rows / 256, full_n = tiles_n / slots * slots;
+      const bool all_n = full_n * 256 >= rows || (rows + 255) / 256 <= slots;
+      if (all_n) LaunchB3J<2, false, false, 2, 4, 2>(d, rows, (rows + 255) / 256, 0, s);
+      else LaunchB3J<2, true, false, 2, 4, 2>(d, rows, (int)full_n, 0, s);
+      return;
+    }
+  }
   // The 160-row tile (five row blocks per wave) where it turns a launch of two rounds of tiles into ONE: a tile's k loop is as long as
   // staging its weights takes, whatever its height, so a long-K launch costs about one loop time per round -- the half-height tiles of
   // the last, partly filled round included.  Measured (profiles/r06/notes_experiments.txt): hidden layers (K = 750) 101 -> 90 us; no gain
@@ -792,18 +804,6 @@ void LaunchGemmB3J(const GemmDev &d, int rows, hipStream_t s) {
       const int nbig5 = (rows + 159) / 160;
       if (JStripOk(d, 160)) LaunchB3J<1, false, true, 2, 5>(d, rows, nbig5, 0, s);
       else LaunchB3J<1, false, false, 2, 5>(d, rows, nbig5, 0, s);
-      return;
-    }
-  }
-  // Layers of at most 128 columns: the 256 x 128 tile (two wave rows x two wave columns).  RS_GEMM_B3J_NARROW=0 (tests: same bits) keeps
-  // the 256-column shapes, half of whose weight stream and MFMAs are padding for such a layer.
-  if (wm == 1 && d.n <= 128) {
-    const char *en = std::getenv("RS_GEMM_B3J_NARROW");
-    if (!(en && std::atoi(en) == 0)) {
-      const long tiles_n = rows / 256, full_n = tiles_n / slots * slots;
-      const bool all_n = full_n * 256 >= rows || (rows + 255) / 256 <= slots;
-      if (all_n) LaunchB3J<2, false, false, 2, 4, 2>(d, rows, (rows + 255) / 256, 0, s);
-      else LaunchB3J<2, true, false, 2, 4, 2>(d, rows, (int)full_n, 0, s);
       return;
     }
   }
