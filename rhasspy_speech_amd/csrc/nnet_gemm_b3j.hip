@@ -484,7 +484,26 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void GemmKernel
       const int rguard = d.res_img.guard - d.out_img.guard;      // (a folded residual read through its image: the same rows of that image)
       // (the block numbers are macro arguments: acc[] must never be indexed by a variable the compiler might not unroll)
       float rm0 = 0.f, rm1 = 0.f, rm2 = 0.f, rm3 = 0.f, rm4 = 0.f;      // max |x| over what this lane splits of its row of row block 0 .. 4
-#define RS_DIRECT(I, J)                                                                                        \
+      // A folded residual's image units of a 32 x 32 block are requested one block AHEAD of the block's own stores: the memory counter
+      // runs in issue order, so a load issued behind a block's stores is waited for together with those stores -- one trip to memory
+      // and back per block, serially (the layer of the factorised model: 268 us, 201 without its residual).  Two register sets, A / B
+      // (whole row blocks ahead -- 64 registers -- spilled the 160-row shapes).
+      f16x8 resA[2][2], resB[2][2];      // [k-step of the 32-column tile][part]
+      const bool res_on = d.res_img.base != nullptr;
+      const unsigned char *res_half = res_on ? d.res_img.base + half * 512 : nullptr;
+      const int res_nks = res_on ? d.res_img.nks : 1;
+#define RS_RES_LOAD(I, J, R)                                                                                   \
+      if (res_on && (!MIXED || (I) < mr_eff)) {                                                                  \
+        const int rp = rok[I] ? phys[I] + rguard : 0;          /* (a row that is not stored: any row of the image) */ \
+        _Pragma("unroll") for (int ksi = 0; ksi < 2; ksi++) {                                                  \
+          int ksg = (n0 + wn * 64 + (J) * 32 + 16 * ksi) >> 4;                                                   \
+          ksg = ksg < res_nks ? ksg : res_nks - 1;                                                               \
+          const unsigned char *rs = res_half + ((size_t)(rp >> 5) * res_nks + ksg) * kB3FragBytes + (rp & 31) * 16; \
+          R[ksi][0] = *reinterpret_cast<const f16x8 *>(rs);                                                      \
+          R[ksi][1] = *reinterpret_cast<const f16x8 *>(rs + d.res_img.part_bytes);                               \
+        }                                                                                                        \
+      }
+#define RS_DIRECT(I, J, R)                                                                                     \
       if (!MIXED || (I) < mr_eff) {                                                                              \
         const int cb = wn * 64 + (J) * 32;                                                                       \
         f32x4 q[4];                                                                                              \
@@ -503,10 +522,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void GemmKernel
           const int col = n0 + cb + 16 * ksi + 8 * half;                                                         \
           if (rok[I] && (col >> 4) < d.out_img.nks) {                                                            \
             f32x4 lo = q[2 * ksi], hi = q[2 * ksi + 1];                                                          \
-            if (d.res_img.base) {                                                                                \
-              const int rp = phys[I] + rguard;                                                                   \
-              const unsigned char *rs = d.res_img.base + ((size_t)(rp >> 5) * d.res_img.nks + (col >> 4)) * kB3FragBytes + half * 512 + (rp & 31) * 16; \
-              const f16x8 r1 = *reinterpret_cast<const f16x8 *>(rs), r2 = *reinterpret_cast<const f16x8 *>(rs + d.res_img.part_bytes); \
+            if (res_on) {                                                                                        \
+              const f16x8 r1 = R[ksi][0], r2 = R[ksi][1];                                                        \
               _Pragma("unroll") for (int e = 0; e < 4; e++) {                                                  \
                 lo[e] = __fadd_rn(__fmul_rn((float)r1[e] + (float)r2[e], d.res_scale), lo[e]);                   \
                 hi[e] = __fadd_rn(__fmul_rn((float)r1[4 + e] + (float)r2[4 + e], d.res_scale), hi[e]);           \
@@ -522,10 +539,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void GemmKernel
           }                                                                                                      \
         }                                                                                                        \
       }
-      RS_DIRECT(0, 0) RS_DIRECT(0, 1) RS_DIRECT(1, 0) RS_DIRECT(1, 1)
-      RS_DIRECT(2, 0) RS_DIRECT(2, 1) RS_DIRECT(3, 0) RS_DIRECT(3, 1)
-      if constexpr (MR > 4) { RS_DIRECT(4, 0) RS_DIRECT(4, 1) }
+      RS_RES_LOAD(0, 0, resA)
+      RS_RES_LOAD(0, 1, resB)
+      RS_DIRECT(0, 0, resA) RS_RES_LOAD(1, 0, resA)
+      RS_DIRECT(0, 1, resB) RS_RES_LOAD(1, 1, resB)
+      RS_DIRECT(1, 0, resA) RS_RES_LOAD(2, 0, resA)
+      RS_DIRECT(1, 1, resB) RS_RES_LOAD(2, 1, resB)
+      RS_DIRECT(2, 0, resA) RS_RES_LOAD(3, 0, resA)
+      RS_DIRECT(2, 1, resB) RS_RES_LOAD(3, 1, resB)
+      RS_DIRECT(3, 0, resA)
+      if constexpr (MR > 4) { RS_RES_LOAD(4, 0, resA) }
+      RS_DIRECT(3, 1, resB)
+      if constexpr (MR > 4) { RS_RES_LOAD(4, 1, resB) RS_DIRECT(4, 0, resA) RS_DIRECT(4, 1, resB) }
 #undef RS_DIRECT
+#undef RS_RES_LOAD
       if (over) d.ovf[0] = 1;
       {
         const int rb = (wm * mr_eff) * 32 + (lane & 31);
