@@ -1498,22 +1498,28 @@ void Model::CollectResults(SearchPlan &sp, DecodeContext &cx, int gi, const Batc
       UttResult &ur = out_utts[u];
       if (ur.status != RS_OK) return;
       RawLattice lat;
-      std::unordered_map<int, int> id;
+      // token index -> lattice state in order of first appearance (a per-thread table with stamps: a hash map per utterance was a
+      // fifth of the tail's host time)
+      thread_local std::vector<int> id_of, id_stamp;
+      thread_local int id_epoch = 0;
+      int max_tok = 0;
+      for (int k = ubegin[u]; k < ubegin[u + 1]; k++) { const LatArc *a = h_arcs + k; max_tok = std::max(max_tok, std::max(a->src, a->arc >= 0 ? a->dst : 0)); }
+      if ((int)id_of.size() <= max_tok) { id_of.resize((size_t)max_tok + 1); id_stamp.resize((size_t)max_tok + 1, 0); }
+      if (++id_epoch == 0x7fffffff) { std::fill(id_stamp.begin(), id_stamp.end(), 0); id_epoch = 1; }
+      int n_ids = 0;
       auto sid = [&](int tok) {
-        auto it = id.find(tok);
-        if (it != id.end()) return it->second;
-        int k = (int)id.size();
-        id[tok] = k;
-        return k;
+        if (id_stamp[tok] != id_epoch) { id_stamp[tok] = id_epoch; id_of[tok] = n_ids++; }
+        return id_of[tok];
       };
       lat.start = sid(0);   // the start token is the first token of frame 0
       for (int k = ubegin[u]; k < ubegin[u + 1]; k++) { const LatArc *a = h_arcs + k; sid(a->src); if (a->arc >= 0) sid(a->dst); }
-      lat.num_states = (int)id.size();
+      lat.num_states = n_ids;
       lat.final_cost.assign(lat.num_states, std::numeric_limits<double>::infinity());
+      lat.arcs.reserve((size_t)(ubegin[u + 1] - ubegin[u]));
       for (int k = ubegin[u]; k < ubegin[u + 1]; k++) {
         const LatArc *a = h_arcs + k;
-        if (a->arc < 0) { lat.final_cost[id[a->src]] = a->graph; continue; }
-        lat.arcs.push_back({id[a->src], id[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic, hclg_.arcs[a->arc].ilabel});
+        if (a->arc < 0) { lat.final_cost[id_of[a->src]] = a->graph; continue; }
+        lat.arcs.push_back({id_of[a->src], id_of[a->dst], hclg_.arcs[a->arc].olabel, (double)a->graph, (double)a->acoustic, hclg_.arcs[a->arc].ilabel});
       }
       std::vector<NbestPath> paths = LatticeNbest(lat, nbest, opts_.lattice_beam, unscale ? lat_scale / opts_.acoustic_scale : lat_scale);
       ur.counters[4] = (int64_t)lat.arcs.size();

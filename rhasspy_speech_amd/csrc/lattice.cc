@@ -4,6 +4,7 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <deque>
 #include <map>
 #include <memory>
 #include <queue>
@@ -90,7 +91,12 @@ std::vector<NbestPath> LatticeNbest(const RawLattice &lat, int n, double lattice
   }
   const size_t want = acoustic_scale == 1.0 ? (size_t)n : (size_t)20000;
   std::vector<NbestPath> found;
-  std::unordered_map<int, Pair> cur;
+  // per-state scratch with stamps (round 5: an unordered_map + a map + a priority queue built and torn down per expanded prefix)
+  std::vector<Pair> cur(N);
+  std::vector<int> stamp(N, 0), done(N, 0), members;
+  int epoch = 0;
+  struct Step { int olabel, dst; Pair w; };
+  std::vector<Step> steps;
   while (!heap.empty() && found.size() < want) {
     HeapItem it = heap.top();
     heap.pop();
@@ -105,31 +111,32 @@ std::vector<NbestPath> LatticeNbest(const RawLattice &lat, int n, double lattice
       continue;
     }
     // epsilon closure in topological order
-    cur.clear();
+    epoch++;
+    members.clear();
     std::priority_queue<std::pair<int, int>, std::vector<std::pair<int, int>>, std::greater<std::pair<int, int>>> q;
-    for (auto &sp : nd.seed) { cur[sp.first] = sp.second; q.push({topo[sp.first], sp.first}); }
-    std::vector<char> done_flag;
-    std::unordered_map<int, char> done;
-    std::vector<int> members;
+    for (auto &sp : nd.seed) {
+      const int st = sp.first;
+      if (stamp[st] != epoch) { stamp[st] = epoch; members.push_back(st); cur[st] = sp.second; q.push({topo[st], st}); }
+      else if (Better(sp.second, cur[st])) { cur[st] = sp.second; q.push({topo[st], st}); }
+    }
     while (!q.empty()) {
       int s = q.top().second;
       q.pop();
-      if (done.count(s)) continue;
-      done[s] = 1;
-      members.push_back(s);
+      if (done[s] == epoch) continue;
+      done[s] = epoch;
       const Pair ps = cur[s];
       for (int k = begin[s]; k < begin[s + 1]; k++) {
         const RawLattice::Arc &a = lat.arcs[order[k]];
         if (a.olabel != 0) continue;
         Pair cand{ps.g + a.graph, ps.a + a.acoustic};
         if (cand.g + cand.a + beta[a.dst] > cutoff) continue;
-        auto f = cur.find(a.dst);
-        if (f == cur.end() || Better(cand, f->second)) {
-          cur[a.dst] = cand;
-          q.push({topo[a.dst], a.dst});
-        }
+        if (stamp[a.dst] != epoch) { stamp[a.dst] = epoch; members.push_back(a.dst); cur[a.dst] = cand; q.push({topo[a.dst], a.dst}); }
+        else if (Better(cand, cur[a.dst])) { cur[a.dst] = cand; q.push({topo[a.dst], a.dst}); }
       }
     }
+    // (members in the order the closure processed them was the order of round 5's `members`: popped states, i.e. topological;
+    // the results below do not depend on it -- minima under a strict order with ties resolved by the sort further down)
+    std::sort(members.begin(), members.end(), [&](int x, int y) { return topo[x] < topo[y]; });
     // complete here?
     bool have = false;
     Pair bestf{0, 0};
@@ -146,8 +153,8 @@ std::vector<NbestPath> LatticeNbest(const RawLattice &lat, int n, double lattice
       c->total = bestf;
       heap.push({bestf.g + bestf.a, ids++, c});
     }
-    // extend by one word
-    std::map<int, std::unordered_map<int, Pair>> nxt;
+    // extend by one word: (word, destination) pairs, the best weight per pair
+    steps.clear();
     for (int s : members) {
       const Pair ps = cur[s];
       for (int k = begin[s]; k < begin[s + 1]; k++) {
@@ -155,21 +162,26 @@ std::vector<NbestPath> LatticeNbest(const RawLattice &lat, int n, double lattice
         if (a.olabel == 0) continue;
         Pair cand{ps.g + a.graph, ps.a + a.acoustic};
         if (cand.g + cand.a + beta[a.dst] > cutoff) continue;
-        auto &dd = nxt[a.olabel];
-        auto f = dd.find(a.dst);
-        if (f == dd.end() || Better(cand, f->second)) dd[a.dst] = cand;
+        steps.push_back({a.olabel, a.dst, cand});
       }
     }
-    for (auto &kv : nxt) {
+    std::stable_sort(steps.begin(), steps.end(), [](const Step &x, const Step &y) { return x.olabel != y.olabel ? x.olabel < y.olabel : x.dst < y.dst; });
+    for (size_t i = 0; i < steps.size();) {
       auto c = std::make_shared<Node>();
       c->words = nd.words;
-      c->words.push_back(kv.first);
+      c->words.push_back(steps[i].olabel);
       double f2 = INF;
-      for (auto &sp : kv.second) {
-        c->seed.push_back({sp.first, sp.second});
-        f2 = std::min(f2, sp.second.g + sp.second.a + beta[sp.first]);
+      size_t j = i;
+      while (j < steps.size() && steps[j].olabel == steps[i].olabel) {
+        Pair best = steps[j].w;
+        size_t k2 = j + 1;
+        while (k2 < steps.size() && steps[k2].olabel == steps[j].olabel && steps[k2].dst == steps[j].dst) { if (Better(steps[k2].w, best)) best = steps[k2].w; k2++; }
+        c->seed.push_back({steps[j].dst, best});
+        f2 = std::min(f2, best.g + best.a + beta[steps[j].dst]);
+        j = k2;
       }
       heap.push({f2, ids++, c});
+      i = j;
     }
   }
   if (acoustic_scale != 1.0)
@@ -244,32 +256,70 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
 
   // epsilon closure (word label 0) of a seed set, pruned with the forward cost `alpha` of the subset; returns the elements
   // sorted by state, best (weight, alignment) per state
+  // Round 6.  A state-level lattice of this decoder is chains of hundreds of arcs without a word label (one transition-id each) between
+  // a few dozen word arcs, so an epsilon closure walks most of an utterance and an element's alignment is hundreds of ids long.
+  // Round 5 kept a (state, weight, alignment) element for EVERY state of the closure and copied the alignment for every arc it looked
+  // at: O(states x length) per closure, twice over.  Now
+  //   * the closure keeps, per state, the best weight and a back pointer (predecessor state + transition-id, or the seed it came in
+  //     by) in flat arrays with stamps -- nothing is copied while it runs;
+  //   * only the states that matter outside the closure become elements of the subset: those with a word arc out and the final ones
+  //     (Kaldi's "minimal representation" of a subset, determinize-lattice-pruned.cc: ConvertToMinimal drops the states all of whose
+  //     arcs are epsilon); the others can only be left by arcs the closure has already followed.  Their alignments are read off the
+  //     back pointers, once.
+  // Subsets that differed in interior states only are now one output state: an equivalent lattice (same word sequences, same best
+  // alignment and costs per sequence: tests/test_lattice_cpu.py against brute-force enumeration and the reference's tools), fewer states.
+  std::vector<char> is_exit(N, 0);
+  for (int s2 = 0; s2 < N; s2++) {
+    if (lat.final_cost[s2] < INF) is_exit[s2] = 1;
+    for (int k = begin[s2]; k < begin[s2 + 1] && !is_exit[s2]; k++) if (lat.arcs[order[k]].olabel != 0) is_exit[s2] = 1;
+  }
+  struct ClState { Pair w; int parent, tid, seed; };      // parent -1: a seed (index `seed` of the seed vector)
+  std::vector<ClState> cl(N);
+  std::vector<int> cl_stamp(N, 0), cl_done(N, 0), cl_members, cl_rev;
+  int cl_epoch = 0;
   auto closure = [&](std::vector<Elem> seed, double alpha) {
-    std::map<int, Elem> cur;       // state -> best element
+    cl_epoch++;
+    cl_members.clear();
     std::priority_queue<std::pair<int, int>, std::vector<std::pair<int, int>>, std::greater<std::pair<int, int>>> q;
-    for (auto &e : seed) {
-      auto f = cur.find(e.state);
-      if (f == cur.end() || Better(e.w, f->second.w)) { cur[e.state] = e; q.push({topo[e.state], e.state}); }
+    for (size_t i = 0; i < seed.size(); i++) {
+      const int st = seed[i].state;
+      if (cl_stamp[st] != cl_epoch) { cl_stamp[st] = cl_epoch; cl_members.push_back(st); cl[st] = ClState{seed[i].w, -1, 0, (int)i}; q.push({topo[st], st}); }
+      else if (Better(seed[i].w, cl[st].w)) { cl[st] = ClState{seed[i].w, -1, 0, (int)i}; q.push({topo[st], st}); }
     }
-    std::map<int, char> done;
     while (!q.empty()) {
       const int s = q.top().second;
       q.pop();
-      if (done.count(s)) continue;
-      done[s] = 1;
-      const Elem es = cur[s];
+      if (cl_done[s] == cl_epoch) continue;
+      cl_done[s] = cl_epoch;
+      const Pair ws = cl[s].w;
       for (int k = begin[s]; k < begin[s + 1]; k++) {
         const RawLattice::Arc &a = lat.arcs[order[k]];
         if (a.olabel != 0) continue;
-        Elem c{a.dst, Pair{es.w.g + a.graph, es.w.a + a.acoustic}, es.tids};
-        if (a.ilabel != 0) c.tids.push_back(a.ilabel);
-        if (alpha + c.w.g + c.w.a + beta[a.dst] > cutoff) continue;
-        auto f = cur.find(a.dst);
-        if (f == cur.end() || Better(c.w, f->second.w)) { cur[a.dst] = c; q.push({topo[a.dst], a.dst}); }
+        const Pair w{ws.g + a.graph, ws.a + a.acoustic};
+        if (alpha + w.g + w.a + beta[a.dst] > cutoff) continue;
+        const bool seen = cl_stamp[a.dst] == cl_epoch;
+        if (seen && !Better(w, cl[a.dst].w)) continue;
+        if (!seen) { cl_stamp[a.dst] = cl_epoch; cl_members.push_back(a.dst); }
+        cl[a.dst] = ClState{w, s, a.ilabel, -1};
+        q.push({topo[a.dst], a.dst});
       }
     }
+    std::sort(cl_members.begin(), cl_members.end());
     std::vector<Elem> v;
-    for (auto &kv : cur) v.push_back(kv.second);
+    for (int st : cl_members) {
+      if (!is_exit[st]) continue;
+      Elem e;
+      e.state = st;
+      e.w = cl[st].w;
+      cl_rev.clear();
+      int p = st;
+      while (cl[p].parent >= 0) { if (cl[p].tid != 0) cl_rev.push_back(cl[p].tid); p = cl[p].parent; }
+      const std::vector<int32_t> &head = seed[cl[p].seed].tids;
+      e.tids.reserve(head.size() + cl_rev.size());
+      e.tids.assign(head.begin(), head.end());
+      e.tids.insert(e.tids.end(), cl_rev.rbegin(), cl_rev.rend());
+      v.push_back(std::move(e));
+    }
     return v;
   };
   // common weight (the best element's, LatticeWeight order) and common alignment prefix are moved out of the subset
@@ -288,7 +338,7 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
     for (auto &e : *v) { e.w.g -= best.g; e.w.a -= best.a; e.tids.erase(e.tids.begin(), e.tids.begin() + pre); }
   };
   std::map<SubsetKey, int> ids;
-  std::vector<SubsetKey> subsets;
+  std::deque<SubsetKey> subsets;      // (a deque: references stay valid while it grows, the subset under expansion is not copied)
   std::vector<double> alpha;          // best forward total of every output state
   // Subsets are expanded best-first on alpha (as Kaldi's pruned determinisation processes its queue,
   // determinize-lattice-pruned.cc); a subset that is reached again with a better forward cost after it was expanded is
@@ -316,6 +366,7 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
   // start: a state whose single epsilon-word arc carries the common part of the initial subset
   {
     std::vector<Elem> init = closure({Elem{lat.start, Pair{0, 0}, {}}}, 0.0);
+    if (init.empty()) return out;          // (nothing with a word arc or a final weight within the beam: cannot happen when best_total is finite)
     CompactLat::Weight common;
     normalise(&init, &common);
     const bool trivial = common.graph == 0 && common.acoustic == 0 && common.tids.empty();
@@ -339,7 +390,7 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
     todo.pop();
     if (subsets[si].elems.empty() || queued > alpha[si] || expanded_at[si] <= alpha[si]) continue;      // placeholder / stale entry
     if (subsets.size() > 2000000) Fail("lattice determinisation: too many states");
-    const std::vector<Elem> elems = subsets[si].elems;      // copy: `subsets` grows below
+    const std::vector<Elem> &elems = subsets[si].elems;
     const double a0 = alpha[si];
     expanded_at[si] = a0;
     out.arcs[si].clear();
@@ -350,10 +401,9 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
       Elem bestf{};
       for (auto &e : elems) {
         if (!(lat.final_cost[e.state] < INF)) continue;
-        Elem c = e;
-        c.w.g += lat.final_cost[e.state];
-        if (a0 + c.w.g + c.w.a > cutoff) continue;
-        if (!have || Better(c.w, bestf.w)) { bestf = c; have = true; }
+        const Pair w{e.w.g + lat.final_cost[e.state], e.w.a};
+        if (a0 + w.g + w.a > cutoff) continue;
+        if (!have || Better(w, bestf.w)) { bestf.state = e.state; bestf.w = w; bestf.tids = e.tids; have = true; }
       }
       if (have) {
         out.is_final[si] = 1;
@@ -368,9 +418,10 @@ CompactLat DeterminizeLattice(const RawLattice &lat, double beam) {
       for (int k = begin[e.state]; k < begin[e.state + 1]; k++) {
         const RawLattice::Arc &a = lat.arcs[order[k]];
         if (a.olabel == 0) continue;
-        Elem c{a.dst, Pair{e.w.g + a.graph, e.w.a + a.acoustic}, e.tids};
+        const Pair w{e.w.g + a.graph, e.w.a + a.acoustic};
+        if (a0 + w.g + w.a + beta[a.dst] > cutoff) continue;
+        Elem c{a.dst, w, e.tids};
         if (a.ilabel != 0) c.tids.push_back(a.ilabel);
-        if (a0 + c.w.g + c.w.a + beta[a.dst] > cutoff) continue;
         nxt[a.olabel].push_back(std::move(c));
       }
     }
