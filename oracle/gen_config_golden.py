@@ -16,7 +16,7 @@ in the model's online.conf.
 c5_tdnnf / c5_tdnnf_fsf3: the first 64 / 32 utterances of configs[1] on the full-size factorised TDNN (tests/configs.py: TDNNF_SPEC),
 the second with --frame-subsampling-factor=3.
 
-Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c1_fsf3 c4_fsf3 c5_tdnnf c5_tdnnf_fsf3 c5_tdnnf_stream]
+Usage: python oracle/gen_config_golden.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c1_fsf3 c4_fsf3 c5_tdnnf c5_tdnnf_fsf3 c5_tdnnf_stream c6_tdnnf1536]
 """
 from __future__ import annotations
 
@@ -150,6 +150,9 @@ def main():
         if "c5_tdnnf_fsf3" in want:
             md, gd = configs.build_tdnnf_model(td / "zamf_fsf3", conf_opts=configs.FSF3_CONF)
             run_offline("c5_tdnnf_fsf3", md, gd, configs.grammar_utterances()[:configs.N_TDNNF_FSF3_UTTS], td)
+        if "c6_tdnnf1536" in want:
+            md, gd = configs.build_tdnnf_model(td / "zamf1536", spec_kw=configs.TDNNF1536_SPEC)
+            run_offline("c6_tdnnf1536", md, gd, configs.grammar_utterances()[:configs.N_TDNNF1536_UTTS], td)
         if "c5_tdnnf_stream" in want:
             md, gd = configs.build_tdnnf_model(td / "zamf")
             pcms = configs.grammar_utterances()[:configs.N_TDNNF_STREAMS]

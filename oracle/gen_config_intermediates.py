@@ -13,7 +13,7 @@ the reference's own classes, one fresh process per utterance like rhasspy runs t
   num_frames   int32   [n_utts]
 into tests/golden/configs/<name>_inter.npz.  tests/test_gpu_configs.py holds the HIP path to them (1e-4).
 
-Usage: python oracle/gen_config_intermediates.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c5_tdnnf c5_tdnnf_fsf3]
+Usage: python oracle/gen_config_intermediates.py [c1_grammar c2_arpa c3_mixed_de c3_mixed_fr c4_streams c5_tdnnf c5_tdnnf_fsf3 c6_tdnnf1536]
 """
 from __future__ import annotations
 
@@ -112,6 +112,9 @@ def main():
         if "c5_tdnnf" in want:
             md, _ = configs.build_tdnnf_model(td / "zamf")
             run("c5_tdnnf", md, configs.grammar_utterances()[:configs.N_TDNNF_UTTS], td, "offline")
+        if "c6_tdnnf1536" in want:
+            md, _ = configs.build_tdnnf_model(td / "zamf1536", spec_kw=configs.TDNNF1536_SPEC)
+            run("c6_tdnnf1536", md, configs.grammar_utterances()[:configs.N_TDNNF1536_UTTS], td, "offline")
         if "c5_tdnnf_fsf3" in want:
             md, _ = configs.build_tdnnf_model(td / "zamf_fsf3", conf_opts=configs.FSF3_CONF)
             run("c5_tdnnf_fsf3", md, configs.grammar_utterances()[:configs.N_TDNNF_FSF3_UTTS], td, "offline")

@@ -82,11 +82,19 @@ TDNNF_SPEC = dict(name="zamia-like-F", tdnnf=True, hidden_dim=1024, bottleneck_d
 N_TDNNF_UTTS, N_TDNNF_FSF3_UTTS, N_TDNNF_STREAMS = 64, 32, 16      # (c5_tdnnf_stream: the first 16 fed to the reference's streaming binary)
 
 
-def build_tdnnf_model(root: Path, conf_opts: dict = None) -> Tuple[Path, Path]:
+# A second factorised shape, the proportions of Kaldi's stock tdnn_f recipe (1536-wide layers, 160-wide bottlenecks): six column tiles
+# per affine, and bottlenecks that are NOT a whole number of 128-column tiles (160 of 256 columns: the 256-column shapes at 37.5 %
+# padding, where the 1024 / 128 model takes the 256 x 128 tile).  c6_tdnnf1536: the first N_TDNNF1536_UTTS utterances of configs[1].
+TDNNF1536_SPEC = dict(name="zamia-like-F1536", tdnnf=True, hidden_dim=1536, bottleneck_dim=160, seed=6,
+                      layer_offsets=((0,), (-1, 0, 1), (-1, 0, 1), (-3, 0, 3), (-3, 0, 3), (-3, 0, 3)))
+N_TDNNF1536_UTTS = 24
+
+
+def build_tdnnf_model(root: Path, conf_opts: dict = None, spec_kw: dict = None) -> Tuple[Path, Path]:
     root = Path(root)
     model_dir, graph_dir = root / "model", root / "graph"
     if not (graph_dir / "HCLG.fst").exists():
-        spec = synth.ModelSpec(**TDNNF_SPEC)
+        spec = synth.ModelSpec(**(spec_kw or TDNNF_SPEC))
         synth.write_model_dir(model_dir, spec)
         synth.make_grammar_graph(graph_dir, spec, seed=11)
         if conf_opts:

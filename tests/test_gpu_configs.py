@@ -909,6 +909,34 @@ def test_config5_tdnnf_streams_and_subsampling(zam_tdnnf, tmp_path_factory):
     _check_nbest_against_reference("c5_tdnnf_fsf3", m3.decode_batch(pcms3, nbest=5), len(pcms3))
 
 
+def test_config6_tdnnf_1536_160_vs_reference(tmp_path_factory, monkeypatch):
+    """A second factorised shape -- 1536-wide layers (six column tiles), 160-wide bottlenecks (NOT a whole number of 128-column tiles:
+    the 256-column shapes at 37.5 % padding) -- against the reference's binaries: transcripts, 5-best lists, costs, iVectors,
+    log-likelihood samples; batch and one stream; the 128- and 160-row tile shapes agree bit for bit."""
+    from rhasspy_speech_amd import _lib
+    md, gd = configs.build_tdnnf_model(tmp_path_factory.mktemp("zam_tdnnf1536"), spec_kw=configs.TDNNF1536_SPEC)
+    pcms = configs.grammar_utterances()[:configs.N_TDNNF1536_UTTS]
+    model = _lib.Model(md, gd, _lib.default_opts(keep_intermediates=1))
+    res = model.decode_batch(pcms)
+    _check_against_reference("c6_tdnnf1536", res.words, res.costs, len(pcms))
+    assert _check_intermediates("c6_tdnnf1536", res, len(pcms)) == []
+    _check_nbest_against_reference("c6_tdnnf1536", model.decode_batch(pcms, nbest=5), len(pcms))
+    assert "range_retries=0 precision_retries=0 exact_fp32=0 regime=split-fp16" in model.describe(), model.describe()
+    for mr in ("4", "5"):
+        monkeypatch.setenv("RS_GEMM_B3J_MR", mr)
+        forced = model.decode_batch(pcms)
+        for u in range(len(pcms)):
+            np.testing.assert_array_equal(forced.matrix(u, 2), res.matrix(u, 2))
+    monkeypatch.delenv("RS_GEMM_B3J_MR")
+    st = _lib.Stream(model)
+    for k in range(0, len(pcms[5]), 6000):
+        st.accept(pcms[5][k:k + 6000])
+        st.advance()
+    sres = st.finish()
+    st.close()
+    assert sres.words(0) == res.words(5)
+
+
 def test_too_short_clips_inside_a_large_batch(zam_grammar):
     """Utterances without a single frame between the others of a batch large enough for the 128-row layer GEMM tiles (ADVICE r05:
     an empty utterance owns L + R halo rows but no entry of a row list, so the physical rows 128 list entries reach over were

@@ -86,7 +86,7 @@ def test_oracle_streaming_matches_reference(oracles, name):
 
 # ---- full-size configurations (tests/configs.py): the restatement against the reference's per-utterance goldens on samples
 @pytest.mark.parametrize("config,utts", [("c1_grammar", (0, 131, 255)), ("c2_arpa", (3, 162)), ("c3_mixed_de", (7,)), ("c3_mixed_fr", (110, 500)),
-                                         ("c4_streams", (5,)), ("c5_tdnnf", (2, 40)), ("c5_tdnnf_fsf3", (9,))])
+                                         ("c4_streams", (5,)), ("c5_tdnnf", (2, 40)), ("c5_tdnnf_fsf3", (9,)), ("c6_tdnnf1536", (3,))])
 def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
     """c2_arpa utterance 162 and c3_mixed_fr utterance 110 are the cases where the reference's order-dependent pruning (tokens created under a running
     next_cutoff, lattice-faster-decoder.cc:774-787) changes the best path's cost: oracle/decoder.c follows the HashList
@@ -104,8 +104,9 @@ def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
         md, gd = configs.build_grammar_model(root, m["model_seed"], m["graph_seed"])
         names, allp = configs.mixed_utterances()
         pcms = [p for nm, p in zip(names, allp) if nm == key]
-    elif config.startswith("c5_tdnnf"):          # the full-size factorised TDNN (also pins the oracle's log-likelihoods on it, below)
-        md, gd = configs.build_tdnnf_model(root, conf_opts=configs.FSF3_CONF if config.endswith("fsf3") else None)
+    elif config.startswith("c5_tdnnf") or config == "c6_tdnnf1536":          # the full-size factorised TDNNs (also pin the oracle's log-likelihoods, below)
+        md, gd = configs.build_tdnnf_model(root, conf_opts=configs.FSF3_CONF if config.endswith("fsf3") else None,
+                                           spec_kw=configs.TDNNF1536_SPEC if config == "c6_tdnnf1536" else None)
         pcms = configs.grammar_utterances()
     else:
         md, gd = configs.build_grammar_model(root)
@@ -115,7 +116,7 @@ def test_oracle_matches_config_goldens(tmp_path_factory, config, utts):
         tr = orc.transcribe_stream(pcms[u]) if config == "c4_streams" else orc.transcribe(pcms[u])
         assert tr.nbest[0].words == ref_words[u], (config, u)
         np.testing.assert_allclose([tr.nbest[0].graph_cost, tr.nbest[0].acoustic_cost], [ref_g[u], ref_a[u]], rtol=2e-4, atol=2e-3)
-    if config.startswith("c5_tdnnf"):
+    if config.startswith("c5_tdnnf") or config == "c6_tdnnf1536":
         g = np.load(configs.GOLDEN / f"{config}_inter.npz")
         sr, sc = (int(x) for x in g["ll_stride"])
         k = 0                                        # (ll_utts[0] is utterance 0)
