@@ -49,6 +49,26 @@ def test_executables_fail_loudly_on_bad_input(tmp_path):
         assert p.returncode != 0 and p.stdout == b"" and b"ERROR" in p.stderr, (exe, p.stderr)
 
 
+def test_wav_executable_checks_what_the_binary_checks(case_cache, tmp_path):
+    """The wav shim with the reference's argv: a wav whose sampling rate is not the model's ends it with Kaldi's "Sampling frequency
+    mismatch" (feat/online-feature.cc:97-101) and status 1 -- before any device work, so this runs without a GPU -- and a spk2utt table
+    that asks for the iVector adaptation state to be carried from one utterance to the next (online2-wav-nnet3-latgen-faster.cc:
+    203-205) is refused rather than decoded differently."""
+    import wave
+    model_dir, graph_dir, wav, pcm = case_cache("tiny_u0")
+    w8 = tmp_path / "u8k.wav"
+    with wave.open(str(w8), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+        w.writeframes(pcm[::2].tobytes())
+    argv = reference_wav_argv(model_dir, graph_dir, w8)
+    p = subprocess.run([sys.executable, str(SHIMS / argv[0]), *argv[1:]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and p.stdout == b"" and b"Sampling frequency mismatch, expected 16000, got 8000" in p.stderr, p.stderr
+    argv = reference_wav_argv(model_dir, graph_dir, wav)
+    argv[-3], argv[-2] = "ark:echo spk a b|", f"scp:printf 'a {wav}\\nb {wav}\\n'|"
+    p = subprocess.run([sys.executable, str(SHIMS / argv[0]), *argv[1:]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and p.stdout == b"" and b"adaptation state" in p.stderr, p.stderr
+
+
 def _nbest_text(lattice: bytes, n: int, env) -> bytes:
     sh = f"lattice-to-nbest --n={n} --acoustic-scale=1.0 ark:- ark:- | nbest-to-linear ark:- ark:/dev/null ark,t:-"
     p = subprocess.run(["bash", "-c", sh], input=lattice, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
