@@ -29,8 +29,8 @@ __device__ __forceinline__ float WaveMax(float v) {
 }
 
 // ------------------------------------------------------------------------------------------ MFCC
-// One wave per output row (halo rows recompute their clamped edge frame: <10 % extra work for 3 s
-// utterances, no special cases downstream).
+// One wave per frame; the rows of an utterance's halo (copies of its first / last frame) are written by the waves of those
+// two frames.
 //
 // The real FFT is the reference's own algorithm (matrix/srfft.cc: in-place single-precision split radix + a
 // post-processing pass whose twiddle comes from a float recurrence), restated as levels of independent butterfly
@@ -126,12 +126,18 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   const int row = blockIdx.x * WPB + wave;
   const bool active = row < g.total_rows;
   int u = 0, t = 0;
+  bool first = false, last = false;      // this row is the utterance's frame 0 / frame T - 1: its cepstra are also the left / right halo rows'
   if (active) {
     u = g.d_row_utt[row];
     t = g.d_row_t[row];
-    int T = g.d_num_frames[u];
+    const int T = g.d_num_frames[u];
+    // A halo row repeats the edge frame next to it: the wave of that frame writes the copies, the halo rows' own waves have
+    // nothing to do (9 % of the rows of a batch of 3 s utterances).  No workgroup-wide step anywhere below: a wave may leave.
+    if (T > 0 && (t < 0 || t >= T)) return;
+    first = T > 0 && t == 0;
+    last = T > 0 && t == T - 1;
     t = t >= T ? T - 1 : t;
-    t = t < 0 ? 0 : t;          // (also the halo rows of an utterance too short for one frame: frame 0 of whatever follows it, never read back)
+    t = t < 0 ? 0 : t;          // (the halo rows of an utterance too short for one frame: frame 0 of whatever follows it, never read back)
   }
   float *x = xbuf[wave];
   float raw_energy = 0.f, dc = 0.f;
@@ -273,6 +279,8 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     c *= m.lifter[lane];
     if (m.use_energy && lane == 0) c = fmaxf(raw_energy, m.log_energy_floor);
     feats[(size_t)(out_rows ? out_rows[row] : row) * ld + lane] = c;      // out_rows: streams write into their pool rows
+    if (first) for (int k = 1; k <= g.L; k++) feats[(size_t)(out_rows ? out_rows[row - k] : row - k) * ld + lane] = c;
+    if (last) for (int k = 1; k <= g.R; k++) feats[(size_t)(out_rows ? out_rows[row + k] : row + k) * ld + lane] = c;
   }
 }
 

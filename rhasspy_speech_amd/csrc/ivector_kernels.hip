@@ -235,8 +235,8 @@ __device__ __forceinline__ unsigned RowMinU(unsigned v) {
   return v;
 }
 constexpr int kUbmRows = 16;          // rows per wave
-template <int NT, int KG, int KU = 4 * KG>   // Gaussian tiles of 16; groups of four k-steps (16 feature dims); k-steps that carry feature dims
-__global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
+template <int NT, int KG, int KU = 4 * KG>
+__global__ __launch_bounds__(256, 2) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
                                                          const float *__restrict__ bm, const float *__restrict__ bv,
                                                          int *__restrict__ post_idx, float *__restrict__ post_w, int ablate) {
   constexpr int KS = 4 * KG, KP = 16 * KG + 1;      // k-steps; LDS pitch (odd: the 16 rows of a read hit 16 banks)
@@ -250,6 +250,11 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, lg = lane & 15;
   const int row0 = (blockIdx.x * 4 + wave) * kUbmRows;
   const int D = iv.feat_dim, G = iv.num_gauss, nsel = iv.num_gselect;
+#ifdef RS_UBM_PROFILE
+  const long long tp0 = clock64();
+  long long tp1 = tp0, tp2 = tp0, tp3 = tp0, tp4 = tp0;
+  int pc_max = 0, pc_sum = 0, pc_slow = 0;
+#endif
   unsigned active = 0;          // bit r: row r is a real frame (wave-uniform)
   for (int i = threadIdx.x; i < 16 * NT; i += 256) gcs[i] = iv.gconsts[i < G ? i : G - 1];
   {
@@ -277,29 +282,58 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
     }
   }
   __syncthreads();
+#ifdef RS_UBM_PROFILE
+  tp1 = clock64();
+#endif
   if (active != 0u) {
     float a1[KS], a2[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) { a1[ks] = xs[wave][lg][4 * ks + grp]; a2[ks] = a1[ks] * a1[ks]; }
     unsigned key[NT][4];
-    // the parameter fragments of tile j + 2 are requested before the MFMAs of tile j: with one or two waves per SIMD nothing
-    // else hides the L2 round trip of a tile's six loads (measured: 193 us for the headline batch without this, all of it
-    // waiting)
+    // The parameter fragments of tile j + 2 are requested before the MFMAs of tile j: with one or two waves per SIMD nothing else
+    // hides the L2 round trip of a tile's six loads (193 us for the headline batch without this, all of it waiting).  The requests
+    // are inline asm and the waits are placed by hand: written as C++ loads the compiler allocates a tile's temporaries in registers
+    // of requests still in flight and puts s_waitcnt vmcnt(0) in front of them -- every tile then waited for the requests made a
+    // moment earlier for two tiles ahead.  Each wait here leaves exactly the newer tiles' requests outstanding.
     constexpr int PF = NT > 2 ? 3 : 2;          // register sets in rotation
     f32x4v pm[PF][KG], pv[PF][KG];
+    const unsigned lane_off = (unsigned)lane * 16u;
+#define RS_UBM_LOAD(dst, base, off) __asm__ volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory")
     auto fetch = [&](int j, int set) __attribute__((always_inline)) {
 #pragma unroll
       for (int kg = 0; kg < KG; kg++) {
-        pm[set][kg] = *reinterpret_cast<const f32x4v *>(bm + ((size_t)(j * KG + kg) * 64 + lane) * 4);
-        pv[set][kg] = *reinterpret_cast<const f32x4v *>(bv + ((size_t)(j * KG + kg) * 64 + lane) * 4);
+        const unsigned off = lane_off + (unsigned)(j * KG + kg) * 1024u;
+        RS_UBM_LOAD(pm[set][kg], bm, off);
+        RS_UBM_LOAD(pv[set][kg], bv, off);
+      }
+    };
+    // (the wait names the set's registers as in-out operands: nothing that reads them can be scheduled above it)
+    auto wait_set = [&](int newer, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kg = 0; kg < KG; kg++) {
+        if (newer >= 2) __asm__ volatile("s_waitcnt vmcnt(%2)" : "+v"(pm[set][kg]), "+v"(pv[set][kg]) : "n"(4 * KG) : "memory");
+        else if (newer == 1) __asm__ volatile("s_waitcnt vmcnt(%2)" : "+v"(pm[set][kg]), "+v"(pv[set][kg]) : "n"(2 * KG) : "memory");
+        else __asm__ volatile("s_waitcnt vmcnt(0)" : "+v"(pm[set][kg]), "+v"(pv[set][kg]) : : "memory");
       }
     };
 #pragma unroll
     for (int j = 0; j < PF - 1 && j < NT; j++) fetch(j, j);
+    // The score arithmetic of tile j - 1 (four values per lane) is placed between the MFMA pairs of tile j, whose accumulators are a
+    // second register set: behind the tile's last MFMA it waited for the pipe to drain and left it idle for ~220 of a tile's 860 cycles.
+    f32x4v c1s[2], c2s[2];
+    auto score = [&](int j, int q, float gc) __attribute__((always_inline)) {
+      const int gi = j * 16 + lg;
+      float v = gc + c1s[j & 1][q];
+      v = v + (-0.5f) * c2s[j & 1][q];
+      const unsigned ko = wv::FloatToOrdered(v);
+      key[j][q] = gi < G ? ko : 0u;            // columns past G: below every real value
+    };
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       if (j + PF - 1 < NT) fetch(j + PF - 1, (j + PF - 1) % PF);
+      wait_set(NT - 1 - j < PF - 1 ? NT - 1 - j : PF - 1, j % PF);
       f32x4v c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+      const float gcp = gcs[(j > 0 ? j - 1 : 0) * 16 + lg];
 #pragma unroll
       for (int kg = 0; kg < KG; kg++) {
         const f32x4v m = pm[j % PF][kg], v = pv[j % PF][kg];
@@ -308,17 +342,20 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
           if (4 * kg + i >= KU) continue;          // all-padding k-steps (D = 40: two of twelve) add exact zeros; skipped
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * kg + i], m[i], c1, 0, 0, 0);
           c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[4 * kg + i], v[i], c2, 0, 0, 0);
+          // (the two chains alternate: an MFMA of this shape issues in 32 cycles and its accumulator is ready after 40 -- left to
+          // the scheduler, runs of one chain follow each other)
+          if (j > 0 && 4 * kg + i < 4) score(j - 1, 4 * kg + i, gcp);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      const int gi = j * 16 + lg;
-      const float gc = gcs[gi];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        float v = gc + c1[q];
-        v = v + (-0.5f) * c2[q];
-        key[j][q] = gi < G ? wv::FloatToOrdered(v) : 0u;            // columns past G: below every real value
-      }
+      c1s[j & 1] = c1; c2s[j & 1] = c2;
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) score(NT - 1, q, gcs[(NT - 1) * 16 + lg]);
+#undef RS_UBM_LOAD
+#ifdef RS_UBM_PROFILE
+    tp2 = clock64();
+#endif
     if (ablate & 1) {          // measurement only (RS_UBM_ABLATE): scoring without the selection
       unsigned acc = 0;
 #pragma unroll
@@ -330,7 +367,14 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
     }
     const float log_min_post = logf(iv.min_post);
     // ---- phase A: row 4 grp + q of every lane group at once.  Candidates (like > max + log min_post) are compacted into the
-    // group's LDS list, the num_gselect best are taken from it (ties -> lowest Gaussian index)
+    // group's LDS list, the num_gselect best are taken from it (ties -> lowest Gaussian index).
+    // (Round 6: this phase was as long as the scoring -- 19 k cycles of a wave alone on its SIMD, twice that beside a second one.
+    // The tests against the cutoff are all made first, their lane masks kept in scalar registers, so that no test waits for the
+    // branch on the previous one; list positions come from v_mbcnt on the group's share of a mask; and the best num_gselect of a list
+    // of at most 16 are found by RANK -- every lane holds one candidate and counts, over 15 row rotations that depend on nothing
+    // but the candidate itself, how many of the others are better -- instead of num_gselect rounds of row-wide max / min
+    // reductions with an LDS round trip each.)
+    const unsigned grp_lo = grp < 2 ? 0xFFFFu << (16 * grp) : 0u, grp_hi = grp >= 2 ? 0xFFFFu << (16 * (grp - 2)) : 0u;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       if (!((active >> q) & 0x1111u)) continue;                      // none of the four rows is a frame (wave-uniform)
@@ -340,50 +384,92 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
       for (int j = 0; j < NT; j++) lmax = max(lmax, key[j][q]);
       const unsigned kmax = RowMaxU(lmax);
       const float max_like = wv::OrderedToFloat(kmax);
-      const unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);
+      unsigned kcut = wv::FloatToOrdered(max_like + log_min_post);
+      if (nsel <= 16) {
+        // Only the num_gselect best of the candidates are kept, and the num_gselect-th largest of the 16 lanes' own maxima is a lower
+        // bound of the num_gselect-th largest score of the row (they are 16 different scores of the row): nothing below it can be
+        // selected.  Frames on which dozens of Gaussians lie within log min_post of the best -- a third of the headline batch's --
+        // made lists of 20-45 candidates per row; with this bound the list is rarely longer than the selection.
+        int above = 0;
+#define RS_UBM_ABOVE(S) above += (int)(wv::Dpp<0x120 + S>(lmax) > lmax);
+        RS_UBM_ABOVE(1) RS_UBM_ABOVE(2) RS_UBM_ABOVE(3) RS_UBM_ABOVE(4) RS_UBM_ABOVE(5) RS_UBM_ABOVE(6) RS_UBM_ABOVE(7) RS_UBM_ABOVE(8)
+        RS_UBM_ABOVE(9) RS_UBM_ABOVE(10) RS_UBM_ABOVE(11) RS_UBM_ABOVE(12) RS_UBM_ABOVE(13) RS_UBM_ABOVE(14) RS_UBM_ABOVE(15)
+#undef RS_UBM_ABOVE
+        const unsigned nth = RowMinU(above < nsel ? lmax : 0xFFFFFFFFu);      // (lanes that tie share a count: at least num_gselect lanes qualify)
+        kcut = max(kcut, nth ? nth - 1u : 0u);                               // candidates are the scores > kcut: nth itself stays one (0: fewer real columns than num_gselect)
+      }
+      unsigned long long cm[NT];
+#pragma unroll
+      for (int j = 0; j < NT; j++) cm[j] = __ballot(key[j][q] > kcut);
+      __builtin_amdgcn_sched_barrier(0);
       int C = 0;                                                     // group-uniform
 #pragma unroll
       for (int j = 0; j < NT; j++) {
-        const bool cand = key[j][q] > kcut;
-        const unsigned long long mask = __ballot(cand);
-        if (mask != 0ull) {                                          // wave-uniform, rare per j
-          const unsigned gm = (unsigned)(mask >> (16 * grp)) & 0xFFFFu;
-          if (cand) {
-            const int pos = C + __popc(gm & ((1u << lg) - 1u));
+        if (cm[j] != 0ull) {                                         // wave-uniform; about 40 % of the tiles hold a candidate of one of the four rows
+          const unsigned ml = (unsigned)cm[j] & grp_lo, mh = (unsigned)(cm[j] >> 32) & grp_hi;
+          if (key[j][q] > kcut) {
+            const int pos = C + (int)__builtin_amdgcn_mbcnt_hi(mh, __builtin_amdgcn_mbcnt_lo(ml, 0u));
             ckey[wave][grp][pos] = key[j][q];
             cgi[wave][grp][pos] = (unsigned short)(j * 16 + lg);
           }
-          C += __popc(gm);
+          C += __popc(ml) + __popc(mh);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      int nfound = 0;
-      const int cmax = (int)wv::MaxU((unsigned)C);                   // longest list of the four groups
-      for (int k = 0; k < nsel; k++) {
-        // best remaining candidate of my group: every lane scans its share of the list, then a row-wide reduction
-        unsigned bv = 0u;
-        int bg = 0x7fffffff, bi = -1;
-        for (int i = lg; i < cmax; i += 16) {
-          if (i < C) {
-            const unsigned kk = ckey[wave][grp][i];
-            const int gg = cgi[wave][grp][i];
-            if (kk > bv || (kk == bv && kk != 0u && gg < bg)) { bv = kk; bg = gg; bi = i; }
-          }
+#ifdef RS_UBM_PROFILE
+      { const int cm_ = (int)wv::MaxU((unsigned)C); pc_max = cm_ > pc_max ? cm_ : pc_max; pc_sum += wv::Sum(lg == 0 ? C : 0); pc_slow += __ballot(C > 16) != 0ull; }
+#endif
+      if (__ballot(C > 16) == 0ull) {
+        // one candidate per lane; sort key: likelihood, then the LOWER Gaussian index (distinct keys: no two lanes share a rank)
+        const bool mine = lg < C;
+        const unsigned k_hi = mine ? ckey[wave][grp][lg] : 0u;
+        const unsigned gidx = mine ? (unsigned)cgi[wave][grp][lg] : 0u;
+        const unsigned k_lo = mine ? 0xFFFFu - gidx : 0u;
+        const unsigned long long mk = ((unsigned long long)k_hi << 32) | k_lo;
+        int rank = 0;
+#define RS_UBM_RANK(S)                                                                                          \
+        {                                                                                                        \
+          const unsigned long long ok = ((unsigned long long)wv::Dpp<0x120 + S>(k_hi) << 32) | wv::Dpp<0x120 + S>(k_lo); \
+          rank += (int)(ok > mk);                                                                                \
         }
-        const unsigned wm = RowMaxU(bv);
-        const bool have = wm != 0u && nfound == k;
-        const int gi = (int)RowMinU((bv == wm && have) ? (unsigned)bg : 0x7fffffffu);
-        if (have && bv == wm && bg == gi) ckey[wave][grp][bi] = 0u;
-        if (have && lg == 0) { sel_ll[wave][r][k] = wv::OrderedToFloat(wm); sel_gi[wave][r][k] = gi; }
-        if (have) nfound = k + 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        RS_UBM_RANK(1) RS_UBM_RANK(2) RS_UBM_RANK(3) RS_UBM_RANK(4) RS_UBM_RANK(5) RS_UBM_RANK(6) RS_UBM_RANK(7) RS_UBM_RANK(8)
+        RS_UBM_RANK(9) RS_UBM_RANK(10) RS_UBM_RANK(11) RS_UBM_RANK(12) RS_UBM_RANK(13) RS_UBM_RANK(14) RS_UBM_RANK(15)
+#undef RS_UBM_RANK
+        if (mine && rank < nsel) { sel_ll[wave][r][rank] = wv::OrderedToFloat(k_hi); sel_gi[wave][r][rank] = (int)gidx; }
+        if (lg == 0) { sel_n[wave][r] = C < nsel ? C : nsel; sel_max[wave][r] = max_like; }
+      } else {
+        // a crowded list (more than 16 Gaussians within log min_post of the best): num_gselect rounds of row-wide selection
+        int nfound = 0;
+        const int cmax = (int)wv::MaxU((unsigned)C);                   // longest list of the four groups
+        for (int k = 0; k < nsel; k++) {
+          // best remaining candidate of my group: every lane scans its share of the list, then a row-wide reduction
+          unsigned bv = 0u;
+          int bg = 0x7fffffff, bi = -1;
+          for (int i = lg; i < cmax; i += 16) {
+            if (i < C) {
+              const unsigned kk = ckey[wave][grp][i];
+              const int gg = cgi[wave][grp][i];
+              if (kk > bv || (kk == bv && kk != 0u && gg < bg)) { bv = kk; bg = gg; bi = i; }
+            }
+          }
+          const unsigned wm = RowMaxU(bv);
+          const bool have = wm != 0u && nfound == k;
+          const int gi = (int)RowMinU((bv == wm && have) ? (unsigned)bg : 0x7fffffffu);
+          if (have && bv == wm && bg == gi) ckey[wave][grp][bi] = 0u;
+          if (have && lg == 0) { sel_ll[wave][r][k] = wv::OrderedToFloat(wm); sel_gi[wave][r][k] = gi; }
+          if (have) nfound = k + 1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lg == 0) { sel_n[wave][r] = nfound; sel_max[wave][r] = max_like; }
       }
-      if (lg == 0) { sel_n[wave][r] = nfound; sel_max[wave][r] = max_like; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+#ifdef RS_UBM_PROFILE
+    tp3 = clock64();
+#endif
     // ---- phase B: exp(like - max) in double as the reference does (lane = 4 row + slot pair), then lane r prunes and
     // renormalises row r (posterior.cc:494-507) and writes it
     {
@@ -427,6 +513,11 @@ __global__ __launch_bounds__(256) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g
       }
     }
   }
+#ifdef RS_UBM_PROFILE
+  tp4 = clock64();
+  if (threadIdx.x == 0 && blockIdx.x % 149 == 0)
+    printf("ubm wg %d: prologue %lld tiles %lld select-A %lld select-B %lld; candidates: longest list %d, %d in 16 rows, %d of 4 passes on the slow path\n", (int)blockIdx.x, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3, pc_max, pc_sum, pc_slow);
+#endif
   // rows that are not frames (halo)
   if (lane < kUbmRows && !((active >> lane) & 1u) && row0 + lane < g.total_rows)
     for (int q = 0; q < nsel; q++) post_idx[(size_t)(row0 + lane) * nsel + q] = -1;

@@ -22,7 +22,7 @@ struct BatchGeom {
   const int *d_row_base = nullptr;        // n_utts + 1
   const int *d_frame_base = nullptr;      // n_utts + 1 (prefix sum of T_u; compact per-frame arrays)
   const int *d_row_utt = nullptr;         // total_rows: utterance of each row
-  const int *d_row_t = nullptr;           // total_rows: clamped frame index t in [0, T_u) of each row
+  const int *d_row_t = nullptr;           // total_rows: frame index of each row, row - row_base[u] - L: negative / >= T_u in the halo
   // streams: the launch covers frames [frame0[u], frame0[u] + T_u) of stream u, its sample_off points at frame0[u]'s first
   // sample; what depends on the absolute frame index (the dither noise) adds it back.  null = 0.
   const int *d_frame0 = nullptr;          // n_utts
