@@ -350,37 +350,81 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
     int i = i_first, d = d_first;
 #pragma unroll
     for (int q = 0; q < kPer; q++) {
-      nx[q] = 0.f; np[q] = 0.f;
-      if (i < n) {
-        const float *row = in + (base + t0 + i) * ld + d;
-        nx[q] = row[0];
-        if (t0 + i - W >= 0) np[q] = row[-(ptrdiff_t)W * ld];
-      }
+      // (no load under a condition: an element past the chunk's end re-reads the chunk's first frame, a frame that has no
+      // predecessor W frames back reads frame 0; neither value is used)
+      const int ti = t0 + (i < n ? i : 0), tp = ti - W > 0 ? ti - W : 0;
+      nx[q] = in[(base + ti) * ld + d];
+      np[q] = in[(base + tp) * ld + d];
       i += i_step; d += d_step;
       if (d >= D) { d -= D; i++; }
     }
   };
+#ifdef RS_CMVN_PROFILE
+  long long cp[6] = {0, 0, 0, 0, 0, 0}, ct = clock64();
+#define RS_CT(i) do { const long long n_ = clock64(); cp[i] += n_ - ct; ct = n_; } while (0)
+#else
+#define RS_CT(i) do { } while (0)
+#endif
   if (t_first < T) fetch(t_first);
+  RS_CT(0);
   for (int t0 = t_first; t0 < T; t0 += kCmvnTC) {
     const int n = T - t0 < kCmvnTC ? T - t0 : kCmvnTC;
 #pragma unroll
     for (int q = 0; q < kPer; q++) {
       const int idx = tid + 256 * q;
-      if (idx < n * D) { xs[idx] = nx[q]; xp[idx] = np[q]; }
+      // (every request is waited for HERE, used or not: one that is consumed under a condition stays "possibly in flight" for the
+      // compiler, and the next fetch() into the same register then waits vmcnt(0) -- for this chunk's output stores as well)
+      __asm__ volatile("" : "+v"(nx[q]), "+v"(np[q]));
+      if (idx < n * D) { xs[idx] = nx[q]; xp[idx] = np[q]; }      // (xp is read where a frame leaves the window, nowhere else)
     }
     __syncthreads();
+    RS_CT(1);
     if (t0 + kCmvnTC < T) fetch(t0 + kCmvnTC);
     if (tid < D) {
+      if (n == kCmvnTC && (t0 >= W || t0 + kCmvnTC <= W)) {
+        // A whole chunk whose frames all push an old frame out of the window, or none does: the chunk's values of this dimension
+        // first (independent LDS reads, all in flight together), then the chain of additions in registers, then the running sums
+        // back.  Read, add and write frame by frame, every frame waited out an LDS round trip behind the previous frame's write
+        // (215 cycles per frame, 60 % of the kernel; round 6).  Same additions in the same order.
+        float xv[kCmvnTC], pv[kCmvnTC];
+        double sv[kCmvnTC];
+        const bool leaving = t0 >= W;
+#pragma unroll
+        for (int i = 0; i < kCmvnTC; i++) xv[i] = xs[i * D + tid];
+        if (leaving) {
+#pragma unroll
+          for (int i = 0; i < kCmvnTC; i++) pv[i] = xp[i * D + tid];
+#pragma unroll
+          for (int i = 0; i < kCmvnTC; i++) { sum += (double)xv[i]; sum -= (double)pv[i]; sv[i] = sum; }      // (count + 1 - 1)
+          count += 1.0; count -= 1.0;
+          if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < kCmvnTC; i++) nn[i] = count;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < kCmvnTC; i++) { sum += (double)xv[i]; sv[i] = sum; }
+          if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < kCmvnTC; i++) nn[i] = count + (double)(i + 1);
+          }
+          count += (double)kCmvnTC;
+        }
+#pragma unroll
+        for (int i = 0; i < kCmvnTC; i++) ss[i * D + tid] = sv[i];
+      } else {
 #pragma unroll 4
-      for (int i = 0; i < n; i++) {
-        sum += (double)xs[i * D + tid];
-        count += 1.0;
-        if (t0 + i - W >= 0) { sum -= (double)xp[i * D + tid]; count -= 1.0; }
-        ss[i * D + tid] = sum;
-        if (tid == 0) nn[i] = count;
+        for (int i = 0; i < n; i++) {
+          sum += (double)xs[i * D + tid];
+          count += 1.0;
+          if (t0 + i - W >= 0) { sum -= (double)xp[i * D + tid]; count -= 1.0; }
+          ss[i * D + tid] = sum;
+          if (tid == 0) nn[i] = count;
+        }
       }
     }
     __syncthreads();
+    RS_CT(2);
     if (tid < n) {
       double nf = nn[tid], a = 0.0;
       if (nf < (double)W) {
@@ -392,19 +436,43 @@ __global__ __launch_bounds__(256) void OnlineCmvnKernel(CmvnDev c, BatchGeom g, 
       al[tid] = (float)(-1.0 / nf);
     }
     __syncthreads();
-    for (int idx = tid; idx < n * D; idx += 256) {
-      const int i = idx / D, d = idx - i * D;
-      double sv = ss[idx];
-      const double a = aa[i];
-      if (a > 0.0) sv += a * gs[d];
-      const float offset = (float)((double)al[i] * sv);
-      const float yv = xs[idx] + offset;
-      out[(base + t0 + i) * ld + d] = yv;
-      if (t0 + i == 0) edge[d] = yv;
-      if (t0 + i == T - 1) edge[D + d] = yv;
+    RS_CT(3);
+    {
+      // (element tid + 256 q by steps, as in fetch(): no division by the runtime dimension; the LDS reads of all of a thread's
+      // elements before the arithmetic)
+      int i = i_first, d = d_first;
+      double svq[kPer], aq[kPer], gq[kPer];
+      float alq[kPer], xq[kPer];
+      int iq[kPer], dq[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; q++) {
+        iq[q] = i; dq[q] = d;
+        const bool on = i < n;
+        const int idx = on ? i * D + d : 0, ii = on ? i : 0;
+        svq[q] = ss[idx]; aq[q] = aa[ii]; gq[q] = gs[d]; alq[q] = al[ii]; xq[q] = xs[idx];
+        i += i_step; d += d_step;
+        if (d >= D) { d -= D; i++; }
+      }
+#pragma unroll
+      for (int q = 0; q < kPer; q++) {
+        if (iq[q] < n) {
+          double sv = svq[q];
+          if (aq[q] > 0.0) sv += aq[q] * gq[q];
+          const float offset = (float)((double)alq[q] * sv);
+          const float yv = xq[q] + offset;
+          out[(base + t0 + iq[q]) * ld + dq[q]] = yv;
+          if (t0 + iq[q] == 0) edge[dq[q]] = yv;
+          if (t0 + iq[q] == T - 1) edge[D + dq[q]] = yv;
+        }
+      }
     }
     __syncthreads();
+    RS_CT(4);
   }
+#ifdef RS_CMVN_PROFILE
+  if (tid == 0 && u % 61 == 0) printf("cmvn utt %d (T=%d): first fetch %lld | stage %lld walk %lld scalars %lld apply %lld\n", u, T, cp[0], cp[1], cp[2], cp[3], cp[4]);
+#endif
+#undef RS_CT
   if (park && tid < D) { park[tid] = sum; if (tid == 0) park[D] = count; }
   if (T > 0 && !t_begin) {
     for (int idx = tid; idx < g.L * D; idx += 256) out[(base - g.L + idx / D) * ld + idx % D] = edge[idx % D];
