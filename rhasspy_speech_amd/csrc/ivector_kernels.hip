@@ -611,20 +611,42 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
   int *off = cnt + G;                                                 // [G + 1]
   float *ows = reinterpret_cast<float *>(off + G + 1);                // [kAccTC * nsel] posteriors sorted by Gaussian (stable in frame order)
   unsigned short *ofr = reinterpret_cast<unsigned short *>(ows + kAccTC * nsel);   // [kAccTC * nsel] ... and their frames (within the chunk)
+  unsigned short *ogi = ofr + kAccTC * nsel;                                        // [kAccTC * nsel] ... and their Gaussians
+  int *gsplit = reinterpret_cast<int *>(ogi + kAccTC * nsel);                        // [17] first Gaussian of each wave's share of the sorted list
   // fresh: the statistics start from zero with this launch (whole utterances at once), so the first chunk writes every sum
   // instead of the caller clearing 8 G D bytes per utterance (42 MB for the headline batch) for this kernel to read back
   if (fresh && t_begin >= t_end) {
     for (int i = tid; i < G * D; i += 1024) wf[i] = 0.0;
     for (int i = tid; i < G; i += 1024) gm[i] = 0.f;
   }
+#ifdef RS_ACC_PROFILE
+  long long ap[6] = {0, 0, 0, 0, 0, 0}, at = clock64();
+#define RS_AT(i) do { const long long n_ = clock64(); ap[i] += n_ - at; at = n_; } while (0)
+#else
+#define RS_AT(i) do { } while (0)
+#endif
   for (int t0 = t_begin; t0 < t_end; t0 += kAccTC) {
     const int n = t_end - t0 < kAccTC ? t_end - t0 : kAccTC, ne = n * nsel;
     const int seglen = (n + nseg - 1) / nseg;
     __syncthreads();
-    for (int i = tid; i < n * D; i += 1024) xs[i] = lda[(base + t0 + i / D) * ld + i % D];
+    if (D <= 64) {
+      // (a wave per frame, lane = dimension: no division by the runtime dimension, four rows in flight per wave)
+      int f = wave;
+      for (; f + 48 < n; f += 64) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = lda[(base + t0 + f + 16 * q) * ld + (lane < D ? lane : 0)];
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (lane < D) xs[(f + 16 * q) * D + lane] = v[q];
+      }
+      for (; f < n; f += 16) if (lane < D) xs[f * D + lane] = lda[(base + t0 + f) * ld + lane];
+    } else {
+      for (int i = tid; i < n * D; i += 1024) xs[i] = lda[(base + t0 + i / D) * ld + i % D];
+    }
     for (int e = tid; e < ne; e += 1024) { eidx[e] = post_idx[(base + t0) * nsel + e]; ew[e] = post_w[(base + t0) * nsel + e]; }
     for (int i = tid; i < nseg * G; i += 1024) hist[i] = 0;
     __syncthreads();
+    RS_AT(0);
     if (RS_ACC_ABLATE & 2) continue;
     // 2a. per-segment histograms
     if (wave < nseg) {
@@ -632,6 +654,7 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
       for (int e = f0 * nsel + lane; e < f1 * nsel; e += 64) { const int gi = eidx[e]; if (gi >= 0) atomicAdd(&hist[wave * G + gi], 1); }
     }
     __syncthreads();
+    RS_AT(1);
     // 2b. per Gaussian: exclusive prefix over the segments; then an exclusive scan over the Gaussians
     for (int gi = tid; gi < G; gi += 1024) {
       int run = 0;
@@ -652,17 +675,35 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
       if (lane == 0) off[G] = carry;
     }
     __syncthreads();
+    RS_AT(2);
     // 2c. stable placement: a wave walks its segment frame by frame
     if (wave < nseg) {
       const int f0 = wave * seglen, f1 = f0 + seglen < n ? f0 + seglen : n;
-      for (int f = f0; f < f1; f++) {
-        if (lane < nsel) {
-          const int e = f * nsel + lane, gi = eidx[e];
-          if (gi >= 0) { const int pos = off[gi] + hist[wave * G + gi]; hist[wave * G + gi]++; ofr[pos] = (unsigned short)f; ows[pos] = ew[e]; }
+      // (four frames' entries and their Gaussians' list starts are read together; the cursors are then advanced frame by frame --
+      // two frames of a segment can name the same Gaussian)
+      for (int fb = f0; fb < f1; fb += 4) {
+        int gq[4], oq[4];
+        float wq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int f = fb + q < f1 ? fb + q : f1 - 1, e = f * nsel + (lane < nsel ? lane : 0);
+          gq[q] = eidx[e]; wq[q] = ew[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) oq[q] = off[gq[q] >= 0 ? gq[q] : 0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int f = fb + q, gi = gq[q];
+          if (f < f1 && lane < nsel && gi >= 0) {
+            const int pos = oq[q] + hist[wave * G + gi];
+            hist[wave * G + gi]++;
+            ofr[pos] = (unsigned short)f; ows[pos] = wq[q]; ogi[pos] = (unsigned short)gi;
+          }
         }
       }
     }
     __syncthreads();
+    RS_AT(3);
     // 3. independent (Gaussian, dim) sums, each in frame order.  A wave takes whole Gaussians (lane = feature dim), so
     // the walk over a Gaussian's entry list is wave-uniform: the list (frame, posterior: LDS broadcasts) is read four
     // entries ahead of the dependent double adds, and the read-modify-write of wfeats is batched so that PG global loads
@@ -672,6 +713,76 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
     constexpr int PG = 16;
     if (RS_ACC_ABLATE & 1) continue;
     const bool first = fresh && t0 == t_begin;
+    if (first && G <= 65535) {
+      // The statistics start from zero with this chunk (every call but the second and later chunks of a long utterance): the sorted
+      // list is dealt to the waves in contiguous pieces of about equal length that begin at a Gaussian's first entry, and a wave
+      // walks its piece ENTRY BY ENTRY -- posterior, frame and Gaussian of the next eight entries are read together, the feature
+      // values they name after that, whichever Gaussians they belong to; a change of Gaussian writes the finished sums.  Gaussian
+      // by Gaussian (the loop below) a wave paid two dependent LDS round trips per entry -- the lists are three entries long on
+      // average, too short for its read-ahead -- and the wave that drew the popular Gaussians held the workgroup: 32-81 k cycles of
+      // the kernel's 110 k (round 6).  Same additions in the same order.
+      const int E = off[G];
+      for (int i = tid; i <= 16; i += 1024) gsplit[i] = G;
+      __syncthreads();
+      for (int gi = tid; gi < G; gi += 1024) {
+        // owner of a Gaussian: the sixteenth of the list its first entry lies in (monotone in gi)
+        const int o = E > 0 ? min(15, (int)((long)off[gi] * 16 / E)) : 0, op = gi > 0 ? (E > 0 ? min(15, (int)((long)off[gi - 1] * 16 / E)) : 0) : -1;
+        for (int w = op + 1; w <= o; w++) gsplit[w] = gi;
+      }
+      __syncthreads();
+      const int g_lo = __builtin_amdgcn_readfirstlane(gsplit[wave]), g_hi = __builtin_amdgcn_readfirstlane(gsplit[wave + 1]);
+      // Gaussians without an entry: zeros (lane = dim)
+      for (int gi = wave; gi < G; gi += 16) {
+        if (__builtin_amdgcn_readfirstlane(cnt[gi]) != 0) continue;
+        for (int d = lane; d < D; d += 64) wf[(size_t)gi * D + d] = 0.0;
+        if (lane == 0) gm[gi] = 0.f;
+      }
+      if (g_lo < g_hi) {
+        const int e_lo = __builtin_amdgcn_readfirstlane(off[g_lo]), e_hi = __builtin_amdgcn_readfirstlane(off[g_hi]);
+        for (int d0 = 0; d0 < D; d0 += 64) {
+          const int d = d0 + lane;
+          const bool dv = d < D;
+          const float *xd = xs + (dv ? d : 0);
+          int gcur = -1;
+          double a = 0.0;
+          float ga = 0.f;
+          for (int e = e_lo; e < e_hi; e += 8) {
+            float w8[8], x8[8];
+            int g8[8], f8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int ee = e + i < e_hi ? e + i : e_hi - 1; w8[i] = ows[ee]; f8[i] = ofr[ee]; g8[i] = ogi[ee]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) x8[i] = xd[f8[i] * D];
+            // (the products are exact in double -- 24 x 24 bits -- so a + w * x is the same sum formed in one step or in two; formed
+            // here, ahead of the chain, an entry costs the chain one addition)
+            double p8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) p8[i] = (double)w8[i] * (double)x8[i];
+            if (e + 8 <= e_hi && __builtin_amdgcn_readfirstlane(g8[7]) == gcur) {
+              // eight more entries of the current Gaussian (the list is sorted): no test per entry
+#pragma unroll
+              for (int i = 0; i < 8; i++) { a += p8[i]; ga += w8[i]; }
+              continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              if (e + i < e_hi) {                                   // (wave-uniform)
+                const int gn = __builtin_amdgcn_readfirstlane(g8[i]);
+                if (gn != gcur) {
+                  if (gcur >= 0) { if (dv) wf[(size_t)gcur * D + d] = a; if (d0 == 0 && lane == 0) gm[gcur] = ga; }
+                  gcur = gn; a = 0.0; ga = 0.f;
+                }
+                a += p8[i];
+                ga += w8[i];
+              }
+            }
+          }
+          if (gcur >= 0) { if (dv) wf[(size_t)gcur * D + d] = a; if (d0 == 0 && lane == 0) gm[gcur] = ga; }
+        }
+      }
+      RS_AT(4);
+      continue;
+    }
     for (int d0 = 0; d0 < D; d0 += 64) {
       const int d = d0 + lane;
       const bool dv = d < D;
@@ -707,12 +818,18 @@ __global__ __launch_bounds__(1024) void IvecAccumKernel(IvecDev iv, BatchGeom g,
         }
       }
     }
+    RS_AT(4);
   }
+#ifdef RS_ACC_PROFILE
+  if ((tid & 63) == 0 && (wave == 0 || wave == 15) && u % 61 == 0)
+    printf("acc utt %d wave %d: stage %lld hist %lld prefix %lld place %lld sums %lld\n", u, wave, ap[0], ap[1], ap[2], ap[3], ap[4]);
+#endif
+#undef RS_AT
 }
 
 static size_t IvecAccumSmemBytes(const IvecDev &iv, int nseg) {
   const size_t ne = (size_t)kAccTC * iv.num_gselect;
-  return (size_t)kAccTC * iv.feat_dim * 4 + ne * 8 + ((size_t)nseg * iv.num_gauss + 2 * (size_t)iv.num_gauss + 1) * 4 + ne * 6 + 64;
+  return (size_t)kAccTC * iv.feat_dim * 4 + ne * 8 + ((size_t)nseg * iv.num_gauss + 2 * (size_t)iv.num_gauss + 1) * 4 + ne * 8 + 17 * 4 + 64;
 }
 
 void LaunchIvecAccumulate(const IvecDev &iv, const BatchGeom &g, const float *lda, int ld, const int *post_idx,
