@@ -117,11 +117,10 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   const int4 *tasks = reinterpret_cast<const int4 *>(m.fft_tasks);
   const float *fft_tw = m.fft_tw;
   extern __shared__ __attribute__((aligned(16))) float mfcc_lds[];
-  float (*xbuf)[NFFT] = reinterpret_cast<float (*)[NFFT]>(mfcc_lds);
-  float (*xrb)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * NFFT);
-  float (*xib)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * (NFFT + NC));
-  float (*pw)[NC + 1] = reinterpret_cast<float (*)[NC + 1]>(mfcc_lds + WPB * (NFFT + 2 * NC));
-  float (*lm)[64] = reinterpret_cast<float (*)[64]>(mfcc_lds + WPB * (NFFT + 3 * NC + 1));
+  float (*xrb)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds);
+  float (*xib)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * NC);
+  float (*pw)[NC + 1] = reinterpret_cast<float (*)[NC + 1]>(mfcc_lds + WPB * (2 * NC));
+  float (*lm)[64] = reinterpret_cast<float (*)[64]>(mfcc_lds + WPB * (3 * NC + 1));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * WPB + wave;
   const bool active = row < g.total_rows;
@@ -139,8 +138,14 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     t = t >= T ? T - 1 : t;
     t = t < 0 ? 0 : t;          // (the halo rows of an utterance too short for one frame: frame 0 of whatever follows it, never read back)
   }
-  float *x = xbuf[wave];
-  float raw_energy = 0.f, dc = 0.f;
+#ifdef RS_MFCC_PROFILE
+  long long mp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mt = clock64();
+#define RS_MT(i) do { const long long n_ = clock64(); mp[i] += n_ - mt; mt = n_; } while (0)
+#else
+#define RS_MT(i) do { } while (0)
+#endif
+  float raw_energy = 0.f;
+  float *xr = xrb[wave], *xi = xib[wave];
   if (active) {
     const int16_t *src = pcm + g.d_sample_off[u] + (int64_t)t * m.shift;
     // 1. load (int16 -> float, unscaled), dither, DC removal.  The frame sum follows the reference's BLAS call
@@ -155,54 +160,52 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     const float *noise = m.dither ? m.dither + (size_t)(t + (g.d_frame0 ? g.d_frame0[u] : 0)) * m.win : m.window;
     const float dv = m.dither ? m.dither_value : 0.f;
     constexpr int JP = NFFT / 128;                      // sample pairs per lane
-    float s0[JP], s1[JP], n0[JP], n1[JP];
+    float s0[JP], s1[JP], n0[JP], n1[JP], w0[JP], w1[JP];
 #pragma unroll
     for (int j = 0; j < JP; j++) {                      // all requests first ...
       const int i0 = 2 * (lane + RS_WAVE * j), c0 = i0 < m.win ? i0 : m.win - 1, c1 = i0 + 1 < m.win ? i0 + 1 : m.win - 1;
       s0[j] = (float)src[c0]; s1[j] = (float)src[c1];
       n0[j] = noise[c0]; n1[j] = noise[c1];
+      w0[j] = m.window[c0]; w1[j] = m.window[c1];
     }
+    float v0[JP], v1[JP];
 #pragma unroll
     for (int j = 0; j < JP; j++) {                      // ... then Dither(): data[i] += RandGauss(&rstate) * dither_value (no FMA: -ffp-contract=off)
       const int i0 = 2 * (lane + RS_WAVE * j), i1 = i0 + 1;
-      const float v0 = s0[j] + n0[j] * dv, v1 = s1[j] + n1[j] * dv;
-      if (i0 < m.win) x[i0] = v0;
-      if (i1 < m.win) { x[i1] = v1; dsum += (double)(v0 + v1); }
-      else if (i0 < m.win) dsum += (double)v0;
+      v0[j] = s0[j] + n0[j] * dv; v1[j] = s1[j] + n1[j] * dv;
+      if (i1 < m.win) dsum += (double)(v0[j] + v1[j]);
+      else if (i0 < m.win) dsum += (double)v0[j];
     }
-    for (int i = m.win + lane; i < NFFT; i += RS_WAVE) x[i] = 0.f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, RS_WAVE);
-    // DC removal (x[i] += -mean) is applied where the samples are read below -- the same subtraction on the same operands, once
-    // for a sample itself and once as its right neighbour's predecessor -- instead of in a pass of its own over the LDS copy
-    dc = m.remove_dc ? (float)dsum / (float)m.win : 0.f;
-    if (m.use_energy && m.raw_energy) {
-      WaveLdsSync();      // the sample pairs were written by other lanes than the ones that read them here
-      float e = 0.f;
-      for (int i = lane; i < m.win; i += RS_WAVE) { const float v = m.remove_dc ? x[i] - dc : x[i]; e += v * v; }
-      raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
+    // DC removal (x[i] += -mean), then
+    // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does) and window; the even /
+    // odd samples are the real / imaginary parts of the half-length complex transform.  A lane keeps its sample pairs in registers
+    // from the load to here: the odd sample's left neighbour is the pair's even one, the even sample's is the previous lane's odd one
+    // (one cross-lane move per pair).  Through an LDS copy of the frame -- written in pairs, read back sample by sample with the
+    // window value fetched under the same condition -- this step was 200 of the kernel's 1 300 instructions per frame, and the
+    // kernel is bound by their number (round 6).  Same subtractions and products on the same operands.
+    const float dc = m.remove_dc ? (float)dsum / (float)m.win : 0.f;      // (x - 0.f is x)
+    float e_raw = 0.f, e_win = 0.f;
+#pragma unroll
+    for (int j = 0; j < JP; j++) {
+      const int i0 = 2 * (lane + RS_WAVE * j), i1 = i0 + 1;
+      float left = __shfl_up(v1[j], 1, RS_WAVE);                            // lane l - 1's odd sample
+      const float carry = j > 0 ? __shfl(v1[j > 0 ? j - 1 : 0], RS_WAVE - 1, RS_WAVE) : v0[0];      // lane 0: the previous round's last sample; sample 0 is its own neighbour
+      left = lane == 0 ? carry : left;
+      const float c0 = v0[j] - dc, c1 = v1[j] - dc, p0 = left - dc;
+      const float y0 = i0 < m.win ? (c0 - m.preemph * p0) * w0[j] : 0.f;
+      const float y1 = i1 < m.win ? (c1 - m.preemph * c0) * w1[j] : 0.f;
+      e_raw += (i0 < m.win ? c0 * c0 : 0.f) + (i1 < m.win ? c1 * c1 : 0.f);
+      e_win += y0 * y0 + y1 * y1;
+      xr[lane + RS_WAVE * j] = y0;
+      xi[lane + RS_WAVE * j] = y1;
     }
+    if (m.use_energy) raw_energy = logf(fmaxf(WaveSum(m.raw_energy ? e_raw : e_win), FLT_EPSILON));
   }
+  RS_MT(0);
   WaveLdsSync();
-  float *xr = xrb[wave], *xi = xib[wave];
-  if (active) {
-    // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does) and
-    // window; the even / odd samples are the real / imaginary parts of the half-length complex transform
-    float e = 0.f;
-    for (int i = lane; i < NFFT; i += RS_WAVE) {
-      float y = 0.f;
-      if (i < m.win) {
-        float prev = x[i > 0 ? i - 1 : 0], cur = x[i];
-        if (m.remove_dc) { prev -= dc; cur -= dc; }
-        const float v = cur - m.preemph * prev;
-        y = v * m.window[i];
-        e += y * y;
-      }
-      if (i & 1) xi[i >> 1] = y; else xr[i >> 1] = y;
-    }
-    if (m.use_energy && !m.raw_energy) raw_energy = logf(fmaxf(WaveSum(e), FLT_EPSILON));
-  }
-  WaveLdsSync();
+  RS_MT(1);
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
   if (NFFT == 512 && m.fft_recs) {
     // at most one task per lane and level: the record of the NEXT level (task + its twiddle factors, three 16-byte loads of one
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
       WaveLdsSync();
     }
   }
+  RS_MT(2);
   // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
   // spectrum element k of the bit-reversal pass is element perm[k] of the in-place result
   if (active) {
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     }
   }
   WaveLdsSync();
+  RS_MT(3);
   // 5. mel filterbank + log
   if (active && lane < m.nbins) {
     int off = m.mel_offset[lane], len = m.mel_len[lane];
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     lm[wave][lane] = logf(fmaxf(e, FLT_EPSILON));
   }
   WaveLdsSync();
+  RS_MT(4);
   // 6. DCT + lifter, write the row
   if (active && lane < m.nceps) {
     const float *d = m.dct + lane * m.nbins;
@@ -282,6 +288,12 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     if (first) for (int k = 1; k <= g.L; k++) feats[(size_t)(out_rows ? out_rows[row - k] : row - k) * ld + lane] = c;
     if (last) for (int k = 1; k <= g.R; k++) feats[(size_t)(out_rows ? out_rows[row + k] : row + k) * ld + lane] = c;
   }
+  RS_MT(5);
+#ifdef RS_MFCC_PROFILE
+  if (lane == 0 && row % 9973 == 0)
+    printf("mfcc row %d: load+dc %lld preemph+window %lld fft %lld power %lld mel %lld dct %lld\n", row, mp[0], mp[1], mp[2], mp[3], mp[4], mp[5]);
+#endif
+#undef RS_MT
 }
 
 template <int NFFT, int WPB>
@@ -289,7 +301,7 @@ static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm
                         hipStream_t s) {
   const int blocks = (g.total_rows + WPB - 1) / WPB;
   if (!blocks) return;
-  constexpr size_t need = sizeof(float) * WPB * (NFFT + 3 * (NFFT / 2) + 1 + 64);
+  constexpr size_t need = sizeof(float) * WPB * (3 * (NFFT / 2) + 1 + 64);
   const size_t smem = exclusive ? std::max<size_t>(need, 159 * 1024) : need;
   static size_t attr = 0;
   if (smem > attr) {
