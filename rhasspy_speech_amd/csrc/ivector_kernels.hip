@@ -235,7 +235,8 @@ __device__ __forceinline__ unsigned RowMinU(unsigned v) {
   return v;
 }
 constexpr int kUbmRows = 16;          // rows per wave
-template <int NT, int KG, int KU = 4 * KG>
+template <int NT, int KG, int KU = 4 * KG>   // Gaussian tiles of 16; groups of four k-steps (16 feature dims); k-steps that carry feature dims
+// (two workgroups per CU = two waves per SIMD: 248 registers + 8 accumulators is the budget the tile loop below is written against)
 __global__ __launch_bounds__(256, 2) void UbmPostMfmaKernel(IvecDev iv, BatchGeom g, const float *__restrict__ feats, int ld,
                                                          const float *__restrict__ bm, const float *__restrict__ bv,
                                                          int *__restrict__ post_idx, float *__restrict__ post_w, int ablate) {
