@@ -1499,9 +1499,13 @@ __device__ __forceinline__ void BlockSumK(const double (&v)[K], double (&out)[K]
 #endif
 // LinearCgd (matrix/optimization.cc:453-566) on the expanded matrix A (n x n in LDS), right-hand side b and start x held one
 // element per thread (tid < n); the code of IvecSolveFullKernel, shared with IvecChainKernel so that both run the same arithmetic.
-template <int NW>
+// (NFIX = 100 with four waves: a thread's half row of the matrix -- 50 elements, the same in all of a solve's products -- is read from
+// LDS once and kept in registers; a product then reads the vector only.  The four waves of a workgroup sit on four SIMDs and share one
+// LDS pipe: a product was 100 wave reads of the matrix + 100 broadcast reads of the vector, and it was the pipe it waited for.)
+template <int NW, int NFIX = 0>
 __device__ __forceinline__ double IvecCgSolve(const IvecDev &iv, const double *A, double *xs, double *ps, double (*xch)[NW][4], int &rb,
-                                              bool mine, int tid, int n, double b, double x) {
+                                              bool mine, int tid, int n_arg, double b, double x) {
+  const int n = NFIX ? NFIX : n_arg;
   if (tid == 0 && x == 0.0) x = iv.prior_offset;          // GetIvector: better initial guess
   if (mine) xs[tid] = x;
   __syncthreads();
@@ -1515,10 +1519,31 @@ __device__ __forceinline__ double IvecCgSolve(const IvecDev &iv, const double *A
   const bool second = two && tid >= 32 * NW && tid - 32 * NW < n;
   const int row = second ? tid - 32 * NW : tid;
   const int c_lo = second ? n / 2 : 0, c_hi = two ? (second ? n : n / 2) : n;
+  constexpr bool in_regs = NFIX == 100 && NW == 4;
+  constexpr int HALF = in_regs ? NFIX / 2 : 1;
+  double areg[HALF];
+  if (in_regs) {
+#pragma unroll
+    for (int i = 0; i < HALF; i++) areg[i] = (mine || second) ? A[(size_t)(c_lo + i) * n + row] : 0.0;
+  }
   auto matvec = [&](const double *vec) __attribute__((always_inline)) {
     constexpr int MB = 10;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (mine || second) {
+    if (in_regs) {
+      if (mine || second) {
+        static_assert(!in_regs || HALF % MB == 0, "whole batches");
+#pragma unroll
+        for (int c = 0; c < HALF; c += MB) {
+          double w[MB];
+#pragma unroll
+          for (int i = 0; i < MB; i++) w[i] = vec[c_lo + c + i];
+#pragma unroll
+          for (int i = 0; i + 4 <= MB; i += 4) { a0 += areg[c + i] * w[i]; a1 += areg[c + i + 1] * w[i + 1]; a2 += areg[c + i + 2] * w[i + 2]; a3 += areg[c + i + 3] * w[i + 3]; }
+#pragma unroll
+          for (int i = MB / 4 * 4; i < MB; i++) a0 += areg[c + i] * w[i];
+        }
+      }
+    } else if (mine || second) {
       int c = c_lo;
       for (; c + MB <= c_hi; c += MB) {
         double a[MB], w[MB];
@@ -1617,7 +1642,7 @@ __global__ __launch_bounds__(64 * NW) void IvecSolveFullKernel(IvecDev iv, const
       }
     }
     const double b = mine ? linear[(size_t)u * n + tid] : 0.0;
-    x = IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);
+    x = n == 100 ? IvecCgSolve<NW, 100>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x) : IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);
   } else if (solve) {
     x = (tid == 0) ? iv.prior_offset : 0.0;
   }
@@ -1698,7 +1723,7 @@ __global__ __launch_bounds__(64 * NW) void IvecChainKernel(IvecDev iv, int n_utt
         li[tid] = b;
       }
       touched = true;
-      if (nf > 0.0) x = IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);      // (its first barrier orders the expansion)
+      if (nf > 0.0) x = n == 100 ? IvecCgSolve<NW, 100>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x) : IvecCgSolve<NW>(iv, A, xs, ps, xch, rb, mine, tid, n, b, x);      // (its first barrier orders the expansion)
       else x = (tid == 0) ? iv.prior_offset : 0.0;
     }
     if (mine) {
