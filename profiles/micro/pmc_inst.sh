@@ -1,0 +1,20 @@
+#!/bin/bash
+# LDS pipe counters per kernel of the headline batch (one call in flight): is a kernel waiting for the CU's one LDS pipe?
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/${1:-pmc_lds}
+mkdir -p $OUT
+P="python bench.py --no-cpu-baseline --no-side-figures --steps 3 --warmup 1 --inflight 1"
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc -- $P > /dev/null 2> $OUT/pmc.log
+f=$(find $OUT/pmc -name "*counter_collection.csv" | head -1)
+python - <<PY
+import csv, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+for r in csv.DictReader(open("$f")):
+    k = r["Kernel_Name"][:48]
+    acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    if r["Counter_Name"] == "SQ_WAVE_CYCLES": n[k] += 1
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:14]:
+    c = max(n[k], 1)
+    print(k.ljust(48), "launches", c, {kk: round(vv / c / 1e6, 2) for kk, vv in v.items()}, "(millions per launch)")
+PY

@@ -562,20 +562,42 @@ void Model::ToDevice() {
     mfcc_dev_.fft_num_tw = (int)(pl.tw.size() / 6);
     for (size_t i = 0; i < pl.level_begin.size(); i++) mfcc_dev_.fft_level_begin[i] = pl.level_begin[i];
     mfcc_dev_.fft_tw = Upload(pl.tw.empty() ? std::vector<float>(6, 0.f) : pl.tw);
+    std::vector<int> pl_perm_swz = pl.perm;      // the bit-reversal gather, in the layout the transform leaves its points in
+    mfcc_dev_.fft_swz[0] = mfcc_dev_.fft_swz[1] = mfcc_dev_.fft_swz[2] = 0;
     {
       bool narrow = true;
       for (size_t l = 0; l + 1 < pl.level_begin.size(); l++) narrow = narrow && pl.level_begin[l + 1] - pl.level_begin[l] <= 64;
       mfcc_dev_.fft_recs = nullptr;
       if (narrow) {
-        std::vector<float> recs(pl.tasks.size() * 12, 0.f);
-        for (size_t i = 0; i < pl.tasks.size(); i++) {
-          std::memcpy(&recs[i * 12], &pl.tasks[i], 16);
-          if (pl.tasks[i].tw >= 0) std::memcpy(&recs[i * 12 + 4], &pl.tw[(size_t)pl.tasks[i].tw * 6], 24);
-        }
+        // 64 records per level, one per lane: {byte offsets of the task's points in the swizzled layout; kind (3: none) | twiddle
+        // class << 8; six factors; -}.  The swizzle (feat_kernels.hip, SrfftRunRec): exhaustive search over the linear ones for a
+        // 256-point plan (profiles/micro/fft_swizzle.py); other sizes keep the plain layout.
+        const size_t nl = pl.level_begin.size() - 1;
+        const int N = t.padded / 2;
+        if (N == 256) { mfcc_dev_.fft_swz[0] = 14; mfcc_dev_.fft_swz[1] = 21; mfcc_dev_.fft_swz[2] = 1; }
+        auto swz = [&](int i) { return i ^ ((i & 32) ? mfcc_dev_.fft_swz[0] : 0) ^ ((i & 64) ? mfcc_dev_.fft_swz[1] : 0) ^ ((i & 128) ? mfcc_dev_.fft_swz[2] : 0); };
+        std::vector<float> recs(nl * 64 * 12, 0.f);
+        for (size_t l = 0; l < nl; l++)
+          for (int j = 0; j < 64; j++) {
+            int head[5] = {0, 0, 0, 0, 3};
+            const int ti = pl.level_begin[l] + j;
+            if (ti < pl.level_begin[l + 1]) {
+              const SrfftTask &tk = pl.tasks[ti];
+              const int kind = tk.kind_logm & 0xff, lg = tk.kind_logm >> 8;
+              int pts[4] = {tk.off, tk.off + 1, tk.off + 2, tk.off + 3};
+              if (kind == 0) { const int mm = 1 << lg, e0 = tk.off + tk.n; pts[0] = e0; pts[1] = e0 + mm / 4; pts[2] = e0 + mm / 2; pts[3] = e0 + mm / 2 + mm / 4; }
+              if (kind == 2) { pts[2] = pts[0]; pts[3] = pts[1]; }
+              for (int q = 0; q < 4; q++) head[q] = 4 * swz(pts[q]);
+              head[4] = kind | ((tk.tw >= 0 ? 0 : tk.tw == -1 ? 1 : 2) << 8);
+              if (tk.tw >= 0) std::memcpy(&recs[(l * 64 + j) * 12 + 5], &pl.tw[(size_t)tk.tw * 6], 24);
+            }
+            std::memcpy(&recs[(l * 64 + j) * 12], head, 20);
+          }
         mfcc_dev_.fft_recs = static_cast<const float4 *>(UploadBytes(recs.data(), recs.size() * sizeof(float)));
+        for (int &v : pl_perm_swz) v = swz(v);
       }
     }
-    mfcc_dev_.fft_perm = Upload(pl.perm);
+    mfcc_dev_.fft_perm = Upload(pl_perm_swz);
     mfcc_dev_.fft_kn = Upload(pl.kn);
   }
   if (t.nceps > 128) Fail("more than 128 cepstral coefficients are not supported");

@@ -22,6 +22,16 @@ __device__ __forceinline__ float WaveSum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RS_WAVE);
   return v;
 }
+// sum of a double over the wave: row rotations inside the rows of 16 lanes, then the four row results through SGPRs
+__device__ __forceinline__ double WaveSumF64(double v) {
+#define RS_DPP_D(CTRL)                                                                                                  \
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true),                       \
+                        __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true));
+  RS_DPP_D(0x121) RS_DPP_D(0x122) RS_DPP_D(0x124) RS_DPP_D(0x128)
+#undef RS_DPP_D
+  auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+  return (rl(0) + rl(16)) + (rl(32) + rl(48));
+}
 __device__ __forceinline__ float WaveMax(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, RS_WAVE));
@@ -37,7 +47,6 @@ __device__ __forceinline__ float WaveMax(float v) {
 // tasks (srfft_plan.h) executed lane-parallel with the same float operations on the same operands, so the power
 // spectrum matches the reference to the bit instead of to its own ~1e-3 rounding noise.  This file is compiled with
 // -ffp-contract=off for that reason.
-// (tw_inline: the task's own six factors, loaded with the task -- MfccDev::fft_recs -- else they are read from tw[6 tk.w ..])
 __device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restrict__ tw, float *xr, float *xi, const float *tw_inline = nullptr) {
   const int kind = tk.x & 0xff, lg = tk.x >> 8, off = tk.y;
   if (kind == 0) {
@@ -100,6 +109,71 @@ __device__ __forceinline__ void SrfftRunTask(const int4 tk, const float *__restr
   }
 }
 
+// The same task from a 48-byte record of the padded, pre-addressed plan (MfccDev::fft_recs: 64 records per level, one per lane):
+//   {byte offsets of the task's (up to) four points inside xr / xi; kind (3 = no task for this lane) | twiddle class << 8 (0 factors
+//    below, 1 none, 2 the sqrt(1/2) case), the six twiddle factors; -}
+// The offsets are those of the SWIZZLED layout (MfccDev::fft_swz): point i of the transform lives at index i ^ g(i >> 5).  In the
+// plain layout the small blocks of the in-place split radix -- points 8 k + n, 16 k + n, ... -- put a half wave's 32 reads on 8 or
+// 4 of the 32 LDS banks: the kernel's LDS pipe was busy 83 % of the time and half of that was bank conflicts (SQ_LDS_IDX_ACTIVE /
+// SQ_LDS_BANK_CONFLICT, profiles/micro/pmc_lds.sh); the swizzle (found by exhaustive search over the linear ones against this plan's
+// access patterns, profiles/micro/fft_swizzle.py) halves the passes of the levels and of the post-processing gather (636 -> 308
+// per frame; 208 would be conflict-free).  Same float operations on the same operands.
+__device__ __forceinline__ void SrfftRunRec(const float4 r0, const float4 r1, const float4 r2, float *xr, int xi_off) {
+  const int meta = __float_as_int(r1.x), kind = meta & 0xff, twc = meta >> 8;
+  char *xb = reinterpret_cast<char *>(xr);
+  float *q0 = reinterpret_cast<float *>(xb + __float_as_int(r0.x)), *q1 = reinterpret_cast<float *>(xb + __float_as_int(r0.y));
+  float *q2 = reinterpret_cast<float *>(xb + __float_as_int(r0.z)), *q3 = reinterpret_cast<float *>(xb + __float_as_int(r0.w));
+  if (kind == 0) {
+    const float ar = q0[0], ai = q0[xi_off], br = q1[0], bi = q1[xi_off], cr = q2[0], ci = q2[xi_off], dr = q3[0], di = q3[xi_off];
+    q0[0] = ar + cr; q0[xi_off] = ai + ci;
+    q1[0] = br + dr; q1[xi_off] = bi + di;
+    const float p_r = ar - cr, p_i = ai - ci, q_r = br - dr, q_i = bi - di;
+    float r1v = p_r + q_i, i2 = p_i + q_r, i1 = p_i - q_r, r2v = p_r - q_i;
+    if (twc == 2) {
+      const float sqhalf = 0.70710678118654752440f;
+      const float t1 = sqhalf * (r1v + i1);
+      i1 = sqhalf * (i1 - r1v);
+      r1v = t1;
+      const float t2 = sqhalf * (i2 - r2v);
+      i2 = -sqhalf * (r2v + i2);
+      r2v = t2;
+    } else if (twc == 0) {
+      const float cn = r1.y, spcn = r1.z, smcn = r1.w, c3n = r2.x, spc3n = r2.y, smc3n = r2.z;
+      float t2 = cn * (r1v + i1);
+      float t1 = spcn * r1v + t2;
+      r1v = smcn * i1 + t2;
+      i1 = t1;
+      t2 = c3n * (r2v + i2);
+      t1 = spc3n * r2v + t2;
+      r2v = smc3n * i2 + t2;
+      i2 = t1;
+    }
+    q2[0] = r1v; q2[xi_off] = i1;
+    q3[0] = r2v; q3[xi_off] = i2;
+  } else if (kind == 1) {
+    float a0 = q0[0], a1 = q1[0], a2 = q2[0], a3 = q3[0];
+    float i0 = q0[xi_off], i1 = q1[xi_off], i2 = q2[xi_off], i3 = q3[xi_off];
+    float t;
+    t = a0 + a2; a2 = a0 - a2; a0 = t;
+    t = i0 + i2; i2 = i0 - i2; i0 = t;
+    t = a1 + a3; a3 = a1 - a3; a1 = t;
+    t = i1 + i3; i3 = i1 - i3; i1 = t;
+    t = a0 + a1; a1 = a0 - a1; a0 = t;
+    t = i0 + i1; i1 = i0 - i1; i0 = t;
+    const float t1 = a2 + i3, t2 = i2 + a3;
+    i2 = i2 - a3;
+    a3 = a2 - i3;
+    a2 = t1;
+    i3 = t2;
+    q0[0] = a0; q1[0] = a1; q2[0] = a2; q3[0] = a3;
+    q0[xi_off] = i0; q1[xi_off] = i1; q2[xi_off] = i2; q3[xi_off] = i3;
+  } else if (kind == 2) {
+    const float a0 = q0[0], a1 = q1[0], i0 = q0[xi_off], i1 = q1[xi_off];
+    q0[0] = a0 + a1; q1[0] = a0 - a1;
+    q0[xi_off] = i0 + i1; q1[xi_off] = i0 - i1;
+  }
+}
+
 // The waves of a workgroup work on different frames, each in its own slices of the LDS arrays: a wave only has to order
 // its own LDS traffic (its earlier writes land before its later reads), no wave ever waits for another one.
 __device__ __forceinline__ void WaveLdsSync() {
@@ -121,9 +195,25 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   float (*xib)[NC] = reinterpret_cast<float (*)[NC]>(mfcc_lds + WPB * NC);
   float (*pw)[NC + 1] = reinterpret_cast<float (*)[NC + 1]>(mfcc_lds + WPB * (2 * NC));
   float (*lm)[64] = reinterpret_cast<float (*)[64]>(mfcc_lds + WPB * (3 * NC + 1));
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (the wave number through readfirstlane: the row, its utterance, frame, sample and noise addresses are then scalars -- s_load look-ups,
+  // one address register per request instead of a 64-bit vector addition each; the front end was 350 of the kernel's ~1 000 vector
+  // instructions per frame, and the kernel is bound by their number)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int row = blockIdx.x * WPB + wave;
   const bool active = row < g.total_rows;
+  // What does not depend on the frame is requested first, ahead of the row's own chain of look-ups (row -> utterance -> offsets ->
+  // samples): the first FFT level's record here, the post-processing pass's gather indices and factors and the lane's mel filter and
+  // lifter in front of the FFT, whose seven LDS round trips cover them.
+  // The kernel is a chain of ~20 dependent trips to L2 per frame, and eight waves per SIMD -- all it can hold -- do not hide them
+  // (its LDS pipe is half busy since the swizzle, its vector ALU 63 %: profiles/micro/pmc_lds.sh, pmc_inst.sh; round 6).
+  constexpr bool kFast = NFFT == 512;
+  float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+  const bool recs_on = kFast && m.fft_recs != nullptr;
+  if (recs_on) {
+    const char *lv = reinterpret_cast<const char *>(m.fft_recs) + (unsigned)lane * 48u;
+    a0 = *reinterpret_cast<const float4 *>(lv); a1 = *reinterpret_cast<const float4 *>(lv + 16); a2 = *reinterpret_cast<const float4 *>(lv + 32);
+  }
+
   int u = 0, t = 0;
   bool first = false, last = false;      // this row is the utterance's frame 0 / frame T - 1: its cepstra are also the left / right halo rows'
   if (active) {
@@ -164,9 +254,14 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
 #pragma unroll
     for (int j = 0; j < JP; j++) {                      // all requests first ...
       const int i0 = 2 * (lane + RS_WAVE * j), c0 = i0 < m.win ? i0 : m.win - 1, c1 = i0 + 1 < m.win ? i0 + 1 : m.win - 1;
-      s0[j] = (float)src[c0]; s1[j] = (float)src[c1];
-      n0[j] = noise[c0]; n1[j] = noise[c1];
-      w0[j] = m.window[c0]; w1[j] = m.window[c1];
+      // (scalar base + 32-bit lane offset: the addressing mode that costs no vector instruction per request)
+      const unsigned b0 = (unsigned)c0, b1 = (unsigned)c1;
+      s0[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b0);
+      s1[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b1);
+      n0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b0);
+      n1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b1);
+      w0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b0);
+      w1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b1);
     }
     float v0[JP], v1[JP];
 #pragma unroll
@@ -176,8 +271,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
       if (i1 < m.win) dsum += (double)(v0[j] + v1[j]);
       else if (i0 < m.win) dsum += (double)v0[j];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, RS_WAVE);
+    dsum = WaveSumF64(dsum);      // (exact in any order, see above: row rotations + four readlanes instead of six ds_bpermute pairs)
     // DC removal (x[i] += -mean), then
     // 2. pre-emphasis (uses the *un-emphasised* left neighbour, as the backwards loop of the reference does) and window; the even /
     // odd samples are the real / imaginary parts of the half-length complex transform.  A lane keeps its sample pairs in registers
@@ -190,44 +284,69 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
 #pragma unroll
     for (int j = 0; j < JP; j++) {
       const int i0 = 2 * (lane + RS_WAVE * j), i1 = i0 + 1;
-      float left = __shfl_up(v1[j], 1, RS_WAVE);                            // lane l - 1's odd sample
-      const float carry = j > 0 ? __shfl(v1[j > 0 ? j - 1 : 0], RS_WAVE - 1, RS_WAVE) : v0[0];      // lane 0: the previous round's last sample; sample 0 is its own neighbour
+      float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1[j]), 0x138, 0xF, 0xF, false));      // wave_shr:1 -- lane l - 1's odd sample
+      const float carry = j > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1[j > 0 ? j - 1 : 0]), RS_WAVE - 1)) : v0[0];      // lane 0: the previous round's last sample; sample 0 is its own neighbour
       left = lane == 0 ? carry : left;
       const float c0 = v0[j] - dc, c1 = v1[j] - dc, p0 = left - dc;
       const float y0 = i0 < m.win ? (c0 - m.preemph * p0) * w0[j] : 0.f;
       const float y1 = i1 < m.win ? (c1 - m.preemph * c0) * w1[j] : 0.f;
-      e_raw += (i0 < m.win ? c0 * c0 : 0.f) + (i1 < m.win ? c1 * c1 : 0.f);
-      e_win += y0 * y0 + y1 * y1;
-      xr[lane + RS_WAVE * j] = y0;
-      xi[lane + RS_WAVE * j] = y1;
+      if (m.use_energy) {      // (kernel-uniform)
+        e_raw += (i0 < m.win ? c0 * c0 : 0.f) + (i1 < m.win ? c1 * c1 : 0.f);
+        e_win += y0 * y0 + y1 * y1;
+      }
+      // (point i of the half-length transform lives at i ^ g(i >> 5), g linear in the three bits: MfccDev::fft_swz, zero without the
+      // pre-addressed plan; i = lane + 64 j, so bit 5 is the lane's and bits 6, 7 are j's)
+      const int pos = ((lane ^ ((lane & 32) ? m.fft_swz[0] : 0)) ^ ((j & 1) ? m.fft_swz[1] : 0) ^ ((j & 2) ? m.fft_swz[2] : 0)) + RS_WAVE * j;
+      xr[pos] = y0;
+      xi[pos] = y1;
     }
     if (m.use_energy) raw_energy = logf(fmaxf(WaveSum(m.raw_energy ? e_raw : e_win), FLT_EPSILON));
   }
   RS_MT(0);
   WaveLdsSync();
   RS_MT(1);
+  // (requested here, where the registers of the sample pairs are free again; first used seven LDS round trips later)
+  int pp_k[2] = {0, 0}, pp_d[2] = {0, 0};
+  float pp_re[2] = {0.f, 0.f}, pp_im[2] = {0.f, 0.f};
+  if (kFast) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int k = lane + 1 + RS_WAVE * q;          // (2 k <= NFFT / 2 for both)
+      pp_k[q] = m.fft_perm[k]; pp_d[q] = m.fft_perm[NFFT / 2 - k];
+      pp_re[q] = m.fft_kn[2 * k]; pp_im[q] = m.fft_kn[2 * k + 1];
+    }
+  }
+  const int mlane = lane < m.nbins ? lane : 0, clane = lane < m.nceps ? lane : 0;
+  const int mel_off = m.mel_offset[mlane], mel_n = m.mel_len[mlane], mel_s = m.mel_start[mlane];
+  const float lift = m.lifter[clane];
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
   if (NFFT == 512 && m.fft_recs) {
     // at most one task per lane and level: the record of the NEXT level (task + its twiddle factors, three 16-byte loads of one
     // 48-byte record) is requested before the current level runs, so no level waits for a global round trip -- the task-then-twiddles
-    // pair of dependent loads per level was 14 of the frame's ~45 (profiles/r04/mfcc_notes.txt)
+    // pair of dependent loads per level was 14 of the frame's ~45 (profiles/r04/mfcc_notes.txt).  Round 6: 64 records per level (a
+    // lane's record at a fixed offset from the level's base), the points' LDS offsets in the record, two register sets in turn.
     const int nl = m.fft_num_levels;
-    auto fetch = [&](int L, float4 *r) __attribute__((always_inline)) {
-      const int ti = m.fft_level_begin[L] + lane;
-      const float4 *src = m.fft_recs + (size_t)(ti < m.fft_level_begin[L + 1] ? ti : m.fft_level_begin[L]) * 3;
-      r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
-    };
-    float4 nxt[3];
-    fetch(0, nxt);
-    for (int L = 0; L < nl; L++) {
-      const float4 r0 = nxt[0], r1 = nxt[1], r2 = nxt[2];
-      if (L + 1 < nl) fetch(L + 1, nxt);
-      if (active && m.fft_level_begin[L] + lane < m.fft_level_begin[L + 1]) {
-        const float w6[6] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
-        SrfftRunTask(make_int4(__float_as_int(r0.x), __float_as_int(r0.y), __float_as_int(r0.z), __float_as_int(r0.w)), fft_tw, xr, xi, w6);
-      }
+    const int xi_off = (int)(xi - xr);
+    const char *rec0 = reinterpret_cast<const char *>(m.fft_recs);
+    const unsigned lane_off = (unsigned)lane * 48u;
+    float4 b0, b1, b2;
+#define RS_FFT_FETCH(L, r0, r1, r2)                                                              \
+    {                                                                                            \
+      const char *lv = rec0 + (size_t)(L) * (64 * 48);                                           \
+      r0 = *reinterpret_cast<const float4 *>(lv + lane_off);                                     \
+      r1 = *reinterpret_cast<const float4 *>(lv + lane_off + 16);                                \
+      r2 = *reinterpret_cast<const float4 *>(lv + lane_off + 32);                                \
+    }
+    for (int L = 0; L < nl; L += 2) {      // (level 0's record: requested at the top of the kernel)
+      if (L + 1 < nl) RS_FFT_FETCH(L + 1, b0, b1, b2)
+      if (active) SrfftRunRec(a0, a1, a2, xr, xi_off);
+      WaveLdsSync();
+      if (L + 1 >= nl) break;
+      if (L + 2 < nl) RS_FFT_FETCH(L + 2, a0, a1, a2)
+      if (active) SrfftRunRec(b0, b1, b2, xr, xi_off);
       WaveLdsSync();
     }
+#undef RS_FFT_FETCH
   } else {
     for (int L = 0; L < m.fft_num_levels; L++) {
       if (active)
@@ -239,11 +358,9 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   // 4. real-FFT post-processing (srfft.cc:379-417) fused with the power spectrum (feature-functions.cc:41-49);
   // spectrum element k of the bit-reversal pass is element perm[k] of the in-place result
   if (active) {
-    for (int k = lane + 1; 2 * k <= NC; k += RS_WAVE) {
+    auto post = [&](int k, int pk, int pd, float kn_re, float kn_im) __attribute__((always_inline)) {
       const int kd = NC - k;
-      const int pk = m.fft_perm[k], pd = m.fft_perm[kd];
       const float bk_re = xr[pk], bk_im = xi[pk], bd_re = xr[pd], bd_im = xi[pd];
-      const float kn_re = m.fft_kn[2 * k], kn_im = m.fft_kn[2 * k + 1];
       const float ck_re = 0.5f * (bk_re + bd_re), ck_im = 0.5f * (bk_im - bd_im);
       const float dk_re = 0.5f * (bk_im + bd_im), dk_im = -0.5f * (bk_re - bd_re);
       // A_k = C_k + kN D_k
@@ -257,6 +374,12 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
         const float b_im = -ck_im + (nk_re * nd_im + kn_im * dk_re);
         pw[wave][kd] = b_re * b_re + b_im * b_im;
       }
+    };
+    if (kFast) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) post(lane + 1 + RS_WAVE * q, pp_k[q], pp_d[q], pp_re[q], pp_im[q]);
+    } else {
+      for (int k = lane + 1; 2 * k <= NC; k += RS_WAVE) post(k, m.fft_perm[k], m.fft_perm[NC - k], m.fft_kn[2 * k], m.fft_kn[2 * k + 1]);
     }
     if (lane == 0) {
       const float d0 = xr[m.fft_perm[0]], d1 = xi[m.fft_perm[0]];
@@ -269,8 +392,8 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   RS_MT(3);
   // 5. mel filterbank + log
   if (active && lane < m.nbins) {
-    int off = m.mel_offset[lane], len = m.mel_len[lane];
-    const float *w = m.mel_weights + m.mel_start[lane];
+    const int off = mel_off, len = mel_n;
+    const float *w = m.mel_weights + mel_s;
     float e = 0.f;
     for (int i = 0; i < len; i++) e += w[i] * pw[wave][off + i];
     lm[wave][lane] = logf(fmaxf(e, FLT_EPSILON));
@@ -282,7 +405,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     const float *d = m.dct + lane * m.nbins;
     float c = 0.f;
     for (int b = 0; b < m.nbins; b++) c += d[b] * lm[wave][b];
-    c *= m.lifter[lane];
+    c *= lift;
     if (m.use_energy && lane == 0) c = fmaxf(raw_energy, m.log_energy_floor);
     feats[(size_t)(out_rows ? out_rows[row] : row) * ld + lane] = c;      // out_rows: streams write into their pool rows
     if (first) for (int k = 1; k <= g.L; k++) feats[(size_t)(out_rows ? out_rows[row - k] : row - k) * ld + lane] = c;

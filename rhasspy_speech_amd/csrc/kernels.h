@@ -44,9 +44,13 @@ struct MfccDev {
   int fft_num_levels, fft_num_tasks, fft_num_tw;
   int fft_level_begin[16];   // task range of each level
   const float *fft_tw;       // 6 floats per twiddled butterfly
-  // the same plan as one 48-byte record per task {kind | logm << 8, off, n, tw; the task's six twiddle factors; -, -} when no level has
-  // more than 64 tasks (a 512-point window): a lane's task of the NEXT level is requested while the current one runs, and the
-  // factors come with it instead of by a second, dependent load (null: plans with wider levels)
+  // the same plan as 64 48-byte records per level, one per lane {byte offsets of the task's points in xr / xi; kind (3: no task) |
+  // twiddle class << 8, the task's six twiddle factors; -} when no level has more than 64 tasks (a 512-point window): a lane's
+  // record of the NEXT level is requested while the current one runs, at a fixed offset from the level's base, and the factors come
+  // with it instead of by a second, dependent load (null: plans with wider levels).  With it the points live in a bank-conflict-
+  // reducing layout: point i at index i ^ g(i >> 5), g(b) = fft_swz[0] (bit 0 of b) ^ fft_swz[1] (bit 1) ^ fft_swz[2] (bit 2);
+  // fft_perm is then the gather in that layout (all zero: the plain layout)
+  int fft_swz[3];
   const float4 *fft_recs;
   const int *fft_perm;       // padded/2: bit-reversal pass as a gather
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
