@@ -404,7 +404,8 @@ void LaunchGemm(const GemmDev &d, int rows, const int *row_ivec, hipStream_t s) 
     return (double)(((tiles + num_cu - 1) / num_cu) * bm * bn) * pref;
   };
   if (d.n <= 64) {
-    if (cost(64, 64) < cost(128, 64)) LaunchGemmT<1, 4, 1>(d, rows, row_ivec, s);
+    static int narrow_bm = [] { const char *e = TuneEnv("RS_GEMM_NARROW_BM"); return e ? std::atoi(e) : 0; }();
+    if (narrow_bm ? narrow_bm == 64 : cost(64, 64) < cost(128, 64)) LaunchGemmT<1, 4, 1>(d, rows, row_ivec, s);
     else LaunchGemmT<2, 4, 1>(d, rows, row_ivec, s);
     return;
   }
