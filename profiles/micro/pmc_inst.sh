@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-pmc_lds}
 mkdir -p $OUT
-P="python bench.py --no-cpu-baseline --no-side-figures --steps 3 --warmup 1 --inflight 1"
+P="python bench.py --workload ${2:-grammar} --no-cpu-baseline --no-side-figures --steps ${3:-3} --warmup 1 --inflight 1"
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc -- $P > /dev/null 2> $OUT/pmc.log
 f=$(find $OUT/pmc -name "*counter_collection.csv" | head -1)
 python - <<PY
