@@ -395,9 +395,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     const int off = mel_off, len = mel_n;
     const float *w = m.mel_weights + mel_s;
     float e = 0.f;
-    // (fused multiply-add here and in the DCT -- the reference's two BLAS calls use it too, in an order of their own; everything up to the
-    // power spectrum is bit for bit the reference's, from here on the features agree to rounding)
-    for (int i = 0; i < len; i++) e = __builtin_fmaf(w[i], pw[wave][off + i], e);
+    for (int i = 0; i < len; i++) e += w[i] * pw[wave][off + i];
     lm[wave][lane] = logf(fmaxf(e, FLT_EPSILON));
   }
   WaveLdsSync();
@@ -406,7 +404,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   if (active && lane < m.nceps) {
     const float *d = m.dct + lane * m.nbins;
     float c = 0.f;
-    for (int b = 0; b < m.nbins; b++) c = __builtin_fmaf(d[b], lm[wave][b], c);
+    for (int b = 0; b < m.nbins; b++) c += d[b] * lm[wave][b];
     c *= lift;
     if (m.use_energy && lane == 0) c = fmaxf(raw_energy, m.log_energy_floor);
     feats[(size_t)(out_rows ? out_rows[row] : row) * ld + lane] = c;      // out_rows: streams write into their pool rows
