@@ -167,6 +167,7 @@ class ModelSpec:
     bottleneck_dim: int = 64
     chain_topology: bool = True      # forward/self-loop pdf classes (nnet3 chain models)
     dither: Optional[float] = None   # None: no --dither line, i.e. the reference's default 1.0 like conf/mfcc_hires.conf (feature-window.h:57)
+    frame_length: Optional[float] = None   # ms; None: no --frame-length line (25 ms: a 512-point FFT); 100 ms pads to 2048 points
     nnet_cmvn: bool = False          # --cmvn-config on the nnet input branch
     binary: bool = True
     xent_branch: bool = True         # extra output-xent branch (ignored by decoding), as chain recipes have
@@ -636,6 +637,8 @@ def write_model_dir(model_dir: Path, spec: ModelSpec) -> None:
             "--low-freq=20", "--high-freq=-400", "--sample-frequency=16000"]
     if spec.dither is not None:
         mfcc.append(f"--dither={spec.dither}")
+    if spec.frame_length is not None:
+        mfcc.append(f"--frame-length={spec.frame_length}")
     (conf / "mfcc.conf").write_text("# hires MFCC (egs/wsj/s5/conf/mfcc_hires.conf)\n" + "\n".join(mfcc) + "\n")
     online = ["--feature-type=mfcc", f"--mfcc-config={conf / 'mfcc.conf'}"]
     if spec.ivector_dim > 0:

@@ -60,6 +60,8 @@ CASES = {
     "tiny_fsf2_noiv_u18": dict(spec=dict(ivector_dim=0, seed=9), graph="grammar", audio="synth:18:40001",
                                conf_opts={"frame-subsampling-factor": 2}),
     "zam_fsf3_u19": dict(big=True, spec=dict(), graph="grammar", audio="synth:19:48000", conf_opts={"frame-subsampling-factor": 3}),
+    # --frame-length=100: a 1600-sample window, padded to 2048 points -- the other FFT size the HIP front end is built for (model.cc)
+    "tiny_win100_u21": dict(spec=dict(frame_length=100.0, seed=11), graph="grammar", audio="synth:21:48000"),
 }
 NBEST = 5
 

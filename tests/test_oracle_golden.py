@@ -7,7 +7,7 @@ from tests import cases
 
 FAST = ["tiny_u0", "tiny_u3_short", "tiny_real_hot", "tiny_real_time", "tiny_text_u1", "tiny_noiv_u2", "tiny_cmvn_u4", "tinyf_u5",
         "tiny_hmm_u6", "tiny_arpa_u7", "tiny_arpa_prune_u8", "tiny_vecfst_u9", "zam_real_cold", "zam_long30", "zam_s12005",
-        "tiny_silence", "tiny_quiet_u10", "tiny_nodither_u11", "tiny_dither05_u12", "zam_quiet_u13", "tiny_confopts_u15"]
+        "tiny_silence", "tiny_quiet_u10", "tiny_nodither_u11", "tiny_dither05_u12", "zam_quiet_u13", "tiny_confopts_u15", "tiny_win100_u21"]
 
 
 def parse_nbest(text: bytes):
