@@ -549,6 +549,11 @@ void Model::ToDevice() {
   mfcc_dev_.raw_energy = t.opts.raw_energy; mfcc_dev_.log_energy_floor = t.log_energy_floor;
   mfcc_dev_.window = Upload(t.window);
   mfcc_dev_.mel_offset = Upload(t.mel_offset); mfcc_dev_.mel_len = Upload(t.mel_len); mfcc_dev_.mel_start = Upload(t.mel_start);
+  {
+    std::vector<int> rec((size_t)t.nbins * 4, 0);
+    for (int b = 0; b < t.nbins; b++) { rec[4 * b] = t.mel_offset[b]; rec[4 * b + 1] = t.mel_len[b]; rec[4 * b + 2] = t.mel_start[b]; }
+    mfcc_dev_.mel_rec = static_cast<const int4 *>(UploadBytes(rec.data(), rec.size() * sizeof(int)));
+  }
   mfcc_dev_.mel_weights = Upload(t.mel_weights);
   mfcc_dev_.dct = Upload(t.dct);
   mfcc_dev_.lifter = Upload(t.lifter);
@@ -599,6 +604,18 @@ void Model::ToDevice() {
     }
     mfcc_dev_.fft_perm = Upload(pl_perm_swz);
     mfcc_dev_.fft_kn = Upload(pl.kn);
+    mfcc_dev_.fft_post = nullptr;
+    if (t.padded == 512) {
+      std::vector<float> post(2 * 64 * 4, 0.f);
+      for (int q = 0; q < 2; q++)
+        for (int lane = 0; lane < 64; lane++) {
+          const int k = lane + 1 + 64 * q, pk = pl_perm_swz[k], pd = pl_perm_swz[256 - k];
+          float *r = &post[(size_t)(q * 64 + lane) * 4];
+          std::memcpy(r, &pk, 4); std::memcpy(r + 1, &pd, 4);
+          r[2] = pl.kn[2 * k]; r[3] = pl.kn[2 * k + 1];
+        }
+      mfcc_dev_.fft_post = static_cast<const float4 *>(UploadBytes(post.data(), post.size() * sizeof(float)));
+    }
   }
   if (t.nceps > 128) Fail("more than 128 cepstral coefficients are not supported");
   // ---- CMVN on the nnet input branch

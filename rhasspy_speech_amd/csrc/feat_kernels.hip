@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "kernels.h"
+#include "env.h"
 
 namespace rs {
 
@@ -184,7 +185,9 @@ __device__ __forceinline__ void WaveLdsSync() {
 // WPB = waves (frames) per workgroup.  4 by default; 16 with all the CU's LDS requested when several decode pipelines are in
 // flight, so that no GemmKernelB3 workgroup of another pipeline can share the CU (DESIGN.md section 5: that kernel
 // perturbs this one's LDS-staged arithmetic when they share a CU).
-template <int NFFT, int WPB>   // padded window (real points)
+// TAB: the FFT plan's records (21.5 KB for a 512-point window) are copied into LDS once per workgroup and every wave reads its records
+// from there: 21 of a frame's ~60 vector memory requests become 1.3 (WPB = 16), and it is their number the kernel is bound by.
+template <int NFFT, int WPB, bool TAB = false>   // padded window (real points)
 __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, const int16_t *__restrict__ pcm,
                                                        float *__restrict__ feats, int ld, const int *__restrict__ out_rows) {
   constexpr int NC = NFFT / 2;        // complex points
@@ -199,6 +202,15 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   // one address register per request instead of a 64-bit vector addition each; the front end was 350 of the kernel's ~1 000 vector
   // instructions per frame, and the kernel is bound by their number)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float4 *lrec = reinterpret_cast<float4 *>(mfcc_lds + WPB * (3 * NC + 1 + 64));      // TAB: [level][3][64] float4
+  if (TAB) {
+    const int n4 = m.fft_num_levels * 64 * 3;
+    for (int i = threadIdx.x; i < n4; i += 64 * WPB) {
+      const int rec = i / 3, c = i - 3 * rec;
+      lrec[((rec >> 6) * 3 + c) * 64 + (rec & 63)] = m.fft_recs[i];
+    }
+    __syncthreads();
+  }
   const int row = blockIdx.x * WPB + wave;
   const bool active = row < g.total_rows;
   // What does not depend on the frame is requested first, ahead of the row's own chain of look-ups (row -> utterance -> offsets ->
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
   constexpr bool kFast = NFFT == 512;
   float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
   const bool recs_on = kFast && m.fft_recs != nullptr;
-  if (recs_on) {
+  if (recs_on && !TAB) {
     const char *lv = reinterpret_cast<const char *>(m.fft_recs) + (unsigned)lane * 48u;
     a0 = *reinterpret_cast<const float4 *>(lv); a1 = *reinterpret_cast<const float4 *>(lv + 16); a2 = *reinterpret_cast<const float4 *>(lv + 32);
   }
@@ -251,17 +263,36 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     const float dv = m.dither ? m.dither_value : 0.f;
     constexpr int JP = NFFT / 128;                      // sample pairs per lane
     float s0[JP], s1[JP], n0[JP], n1[JP], w0[JP], w1[JP];
+    // A lane's two samples, noise values and window values are neighbours: with an even window and aligned rows (the usual case: a
+    // wave-uniform test) each pair is ONE request -- 12 per frame instead of 24.  The kernel's texture addresser is busy 89 % of the
+    // launch (profiles/micro/pmc_ta.sh): ~80 vector memory requests per frame at 16 cycles each are what a frame costs a CU.
+    const bool pairs = (m.win & 1) == 0 && m.win >= 2 && ((reinterpret_cast<uintptr_t>(src) & 3) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(noise) & 7) == 0) && ((reinterpret_cast<uintptr_t>(m.window) & 7) == 0);
+    if (pairs) {
 #pragma unroll
-    for (int j = 0; j < JP; j++) {                      // all requests first ...
-      const int i0 = 2 * (lane + RS_WAVE * j), c0 = i0 < m.win ? i0 : m.win - 1, c1 = i0 + 1 < m.win ? i0 + 1 : m.win - 1;
-      // (scalar base + 32-bit lane offset: the addressing mode that costs no vector instruction per request)
-      const unsigned b0 = (unsigned)c0, b1 = (unsigned)c1;
-      s0[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b0);
-      s1[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b1);
-      n0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b0);
-      n1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b1);
-      w0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b0);
-      w1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b1);
+      for (int j = 0; j < JP; j++) {
+        const int pi = lane + RS_WAVE * j, pc = 2 * pi < m.win ? pi : (m.win >> 1) - 1;      // pair index, clamped into the window
+        const unsigned b = (unsigned)pc;
+        const int sp = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(src) + 4u * b);
+        const float2 np = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(noise) + 8u * b);
+        const float2 wp = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(m.window) + 8u * b);
+        s0[j] = (float)(short)(sp & 0xffff); s1[j] = (float)(sp >> 16);
+        n0[j] = np.x; n1[j] = np.y;
+        w0[j] = wp.x; w1[j] = wp.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < JP; j++) {                      // all requests first ...
+        const int i0 = 2 * (lane + RS_WAVE * j), c0 = i0 < m.win ? i0 : m.win - 1, c1 = i0 + 1 < m.win ? i0 + 1 : m.win - 1;
+        // (scalar base + 32-bit lane offset: the addressing mode that costs no vector instruction per request)
+        const unsigned b0 = (unsigned)c0, b1 = (unsigned)c1;
+        s0[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b0);
+        s1[j] = (float)*reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(src) + 2u * b1);
+        n0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b0);
+        n1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(noise) + 4u * b1);
+        w0[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b0);
+        w1[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m.window) + 4u * b1);
+      }
     }
     float v0[JP], v1[JP];
 #pragma unroll
@@ -312,12 +343,15 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int k = lane + 1 + RS_WAVE * q;          // (2 k <= NFFT / 2 for both)
-      pp_k[q] = m.fft_perm[k]; pp_d[q] = m.fft_perm[NFFT / 2 - k];
-      pp_re[q] = m.fft_kn[2 * k]; pp_im[q] = m.fft_kn[2 * k + 1];
+      (void)k;
+      const float4 pr = m.fft_post[q * RS_WAVE + lane];      // (one request instead of four: the kernel is bound by the NUMBER of its vector memory requests)
+      pp_k[q] = __float_as_int(pr.x); pp_d[q] = __float_as_int(pr.y);
+      pp_re[q] = pr.z; pp_im[q] = pr.w;
     }
   }
   const int mlane = lane < m.nbins ? lane : 0, clane = lane < m.nceps ? lane : 0;
-  const int mel_off = m.mel_offset[mlane], mel_n = m.mel_len[mlane], mel_s = m.mel_start[mlane];
+  const int4 mrec = m.mel_rec[mlane];
+  const int mel_off = mrec.x, mel_n = mrec.y, mel_s = mrec.z;
   const float lift = m.lifter[clane];
   // 3. split-radix complex FFT, level by level (tasks of one level touch disjoint points)
   if (NFFT == 512 && m.fft_recs) {
@@ -332,11 +366,16 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
     float4 b0, b1, b2;
 #define RS_FFT_FETCH(L, r0, r1, r2)                                                              \
     {                                                                                            \
-      const char *lv = rec0 + (size_t)(L) * (64 * 48);                                           \
-      r0 = *reinterpret_cast<const float4 *>(lv + lane_off);                                     \
-      r1 = *reinterpret_cast<const float4 *>(lv + lane_off + 16);                                \
-      r2 = *reinterpret_cast<const float4 *>(lv + lane_off + 32);                                \
+      if (TAB) {                                                                                 \
+        r0 = lrec[((L) * 3 + 0) * 64 + lane]; r1 = lrec[((L) * 3 + 1) * 64 + lane]; r2 = lrec[((L) * 3 + 2) * 64 + lane]; \
+      } else {                                                                                   \
+        const char *lv = rec0 + (size_t)(L) * (64 * 48);                                         \
+        r0 = *reinterpret_cast<const float4 *>(lv + lane_off);                                   \
+        r1 = *reinterpret_cast<const float4 *>(lv + lane_off + 16);                              \
+        r2 = *reinterpret_cast<const float4 *>(lv + lane_off + 32);                              \
+      }                                                                                          \
     }
+    if (TAB) RS_FFT_FETCH(0, a0, a1, a2)
     for (int L = 0; L < nl; L += 2) {      // (level 0's record: requested at the top of the kernel)
       if (L + 1 < nl) RS_FFT_FETCH(L + 1, b0, b1, b2)
       if (active) SrfftRunRec(a0, a1, a2, xr, xi_off);
@@ -419,25 +458,36 @@ __global__ __launch_bounds__(64 * WPB) void MfccKernel(MfccDev m, BatchGeom g, c
 #undef RS_MT
 }
 
-template <int NFFT, int WPB>
+template <int NFFT, int WPB, bool TAB = false>
 static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, bool exclusive, const int *out_rows,
                         hipStream_t s) {
   const int blocks = (g.total_rows + WPB - 1) / WPB;
   if (!blocks) return;
-  constexpr size_t need = sizeof(float) * WPB * (3 * (NFFT / 2) + 1 + 64);
+  const size_t need = sizeof(float) * WPB * (3 * (NFFT / 2) + 1 + 64) + (TAB ? (size_t)m.fft_num_levels * 64 * 48 : 0);
   const size_t smem = exclusive ? std::max<size_t>(need, 159 * 1024) : need;
   static size_t attr = 0;
   if (smem > attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&MfccKernel<NFFT, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&MfccKernel<NFFT, WPB, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = smem;
   }
-  hipLaunchKernelGGL((MfccKernel<NFFT, WPB>), dim3(blocks), dim3(64 * WPB), smem, s, m, g, pcm, feats, ld, out_rows);
+  hipLaunchKernelGGL((MfccKernel<NFFT, WPB, TAB>), dim3(blocks), dim3(64 * WPB), smem, s, m, g, pcm, feats, ld, out_rows);
 }
 
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive,
                 const int *out_rows) {
   if (m.padded == 512) {
+    // Batches that fill the device at least once with 16-frame workgroups take them, with the FFT plan in LDS: alone the launch is
+    // 4 % slower than with four frames per workgroup (167 against 161 us for the headline batch: coarser tail), but the pipelined step
+    // -- four calls in flight, this kernel beside other calls' layer GEMMs -- is 7 % shorter (1.52-1.56 against 1.63-1.69 ms on three
+    // boxes, profiles/micro/mfcc_shape_ab.sh: most of it from the workgroup size, which the 16-wave form without the tables shows
+    // too, the rest from a third fewer vector memory requests).  Small launches (a stream round, one utterance) keep the 4-wave form.
+    static const int shape_env = [] { const char *e = TuneEnv("RS_MFCC_SHAPE"); return e ? std::atoi(e) : -1; }();
+    const bool tab_ok = m.fft_recs != nullptr && m.fft_num_levels * 64 * 48 <= 32 * 1024;
+    const int shape = shape_env >= 0 ? shape_env : (g.total_rows >= 16 * 512 ? 16 : 0);
     if (exclusive) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, true, out_rows, s);
+    else if (shape == 16 && tab_ok) LaunchMfccT<512, 16, true>(m, g, pcm, feats, ld, false, out_rows, s);
+    else if (shape == 8 && tab_ok) LaunchMfccT<512, 8, true>(m, g, pcm, feats, ld, false, out_rows, s);
+    else if (shape == 17) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, false, out_rows, s);
     else LaunchMfccT<512, 4>(m, g, pcm, feats, ld, false, out_rows, s);
   } else {
     LaunchMfccT<2048, 4>(m, g, pcm, feats, ld, exclusive, out_rows, s);

@@ -54,6 +54,10 @@ struct MfccDev {
   const float4 *fft_recs;
   const int *fft_perm;       // padded/2: bit-reversal pass as a gather
   const float *fft_kn;       // (re, im) of the post-processing factor, k = 0 .. padded/4
+  // (512-point window) the same two tables as one 16-byte record per lane and round of the post-processing pass, k = lane + 1 + 64 q:
+  // {fft_perm[k], fft_perm[256 - k], kn re, kn im} -- one request instead of four; and the lane's mel filter {offset, length, start, -}
+  const float4 *fft_post;    // [2][64]
+  const int4 *mel_rec;       // nbins
   // Dither (feature-window.cc:90-98): sample i of frame t += dither[t * win + i] * dither_value, before DC removal.  The
   // table holds the reference's own RandGauss draws for frame t of a fresh decoder process (nnet3_setup.h); null = off.
   const float *dither;
