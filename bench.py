@@ -20,7 +20,7 @@ graph resident (rs_decode_batch; rs_decode_batch_sharded at N > 1; rs_stream_* f
 each over the same number of steps: `hbm_resident` (the samples already in HBM when the timed region starts,
 rs_decode_batch_device), `reference_output_layer` (host PCM AND the output layer evaluated for all 2000 pdfs, which is
 literally what the reference computes; the library default evaluates the 362 pdfs that occur on HCLG arcs: same words, same
-costs) and `hbm_resident_all_pdfs`.  The K timed steps are submitted from a few host threads (`--inflight`, default 4; 3 on the ARPA graph, 5 for the two-model batch) so
+costs) and `hbm_resident_all_pdfs`.  The K timed steps are submitted from a few host threads (`--inflight`, default 4; 3 on the ARPA graph and for the two-model batch) so
 that consecutive batches overlap on the device, as a serving process would run them.  Every step's records are checked
 against the first step's and -- rank 0 -- against the REFERENCE's transcripts (tests/golden/configs).  Stage times and the
 roofline are taken from un-overlapped calls right after the timed region.
@@ -233,7 +233,7 @@ def main() -> None:
     # (timed steps, warm-up, calls in flight).  Headline: four calls in flight since round 4 -- with the layer GEMMs at two thirds of
     # their round-3 time a fourth call's search fits under the others' stages: 2.08 -> 1.91 ms per step (2, 3, 4, 5 in flight: 2.41,
     # 2.08, 1.91, 1.91; a model has four decode contexts)
-    defaults = {"grammar": (600, 20, 4), "arpa": (45, 7, 3), "mixed": (150, 11, 5), "streams": (40, 2, 1)}[wl]
+    defaults = {"grammar": (600, 20, 4), "arpa": (45, 7, 3), "mixed": (150, 11, 3), "streams": (40, 2, 1)}[wl]
     steps = args.steps if args.steps is not None else defaults[0]
     warmup = args.warmup if args.warmup is not None else defaults[1]
     inflight = args.inflight if args.inflight is not None else defaults[2]

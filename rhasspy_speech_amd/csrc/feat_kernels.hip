@@ -476,14 +476,18 @@ static void LaunchMfccT(const MfccDev &m, const BatchGeom &g, const int16_t *pcm
 void LaunchMfcc(const MfccDev &m, const BatchGeom &g, const int16_t *pcm, float *feats, int ld, hipStream_t s, bool exclusive,
                 const int *out_rows) {
   if (m.padded == 512) {
-    // Batches that fill the device at least once with 16-frame workgroups take them, with the FFT plan in LDS: alone the launch is
-    // 4 % slower than with four frames per workgroup (167 against 161 us for the headline batch: coarser tail), but the pipelined step
-    // -- four calls in flight, this kernel beside other calls' layer GEMMs -- is 7 % shorter (1.52-1.56 against 1.63-1.69 ms on three
-    // boxes, profiles/micro/mfcc_shape_ab.sh: most of it from the workgroup size, which the 16-wave form without the tables shows
-    // too, the rest from a third fewer vector memory requests).  Small launches (a stream round, one utterance) keep the 4-wave form.
+    // Launches of one to about twelve device fills of 16-frame workgroups (8 k to 96 k rows: 64 to 256 utterances of 3 s) take them,
+    // with the FFT plan in LDS.  Alone the launch is 4 % slower than with four frames per workgroup (167 against 161 us for the
+    // headline batch: coarser tail), but beside other calls' layer GEMMs -- four calls in flight -- the pipelined step is shorter:
+    // 0.59 against 0.73 ms for 64 utterances, 1.14 / 1.16 for 128, 1.52-1.56 / 1.63-1.69 for 256 (four boxes); 1.51 / 1.44 for 192 is
+    // the exception inside the range, and above it the 4-wave form wins (384: 2.69 / 2.63, 512: 3.56 / 3.36, the mixed workload's
+    // 512-utterance calls 6.8 / 6.5-6.6): profiles/micro/mfcc_shape_{ab,utts,conc,mixed}.sh.  Most of the effect is the workgroup size
+    // (the 16-wave form without the tables shows it too) -- how this kernel's workgroups share CUs with the GEMMs' -- the rest a third
+    // fewer vector memory requests.  An empirical launcher rule, not a model.  Small launches (a stream round, one utterance) keep the
+    // 4-wave form.
     static const int shape_env = [] { const char *e = TuneEnv("RS_MFCC_SHAPE"); return e ? std::atoi(e) : -1; }();
     const bool tab_ok = m.fft_recs != nullptr && m.fft_num_levels * 64 * 48 <= 32 * 1024;
-    const int shape = shape_env >= 0 ? shape_env : (g.total_rows >= 16 * 512 ? 16 : 0);
+    const int shape = shape_env >= 0 ? shape_env : ((g.total_rows >= 16 * 512 && g.total_rows <= 96 * 1024) ? 16 : 0);
     if (exclusive) LaunchMfccT<512, 16>(m, g, pcm, feats, ld, true, out_rows, s);
     else if (shape == 16 && tab_ok) LaunchMfccT<512, 16, true>(m, g, pcm, feats, ld, false, out_rows, s);
     else if (shape == 8 && tab_ok) LaunchMfccT<512, 8, true>(m, g, pcm, feats, ld, false, out_rows, s);
